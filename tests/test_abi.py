@@ -1,0 +1,59 @@
+"""CPU tests of the drop-in boundary: libfo1hip.so loads, exports every symbol
+include/fo1.h declares, and rejects bad arguments with the documented error codes
+(no compute without a GPU)."""
+import os
+import re
+
+import pytest
+
+from vlm_fo1_amd import lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "fo1.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fo1_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    syms = declared_symbols()
+    assert "fo1_hfre_region_pool" in syms
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/fo1.h but not exported"
+    # and the Python binding table covers exactly the header
+    assert sorted(L.SIGNATURES) == syms
+
+
+def test_abi_version():
+    assert L.load().fo1_abi_version() == 1
+
+
+def test_hfre_argument_errors():
+    lib = L.load()
+    S = L.HfreSource
+    ok = S(16, 120, 160, 256, 256, 120, 160, 0.25, 0, 0)
+    arr = (S * 1)(ok)
+    assert lib.fo1_hfre_workspace_bytes(arr, 1, 100) > 0
+    # NULL boxes
+    assert lib.fo1_hfre_region_pool(arr, 1, None, 3, None, 1.0, 1.0, 7, 0, 1.0, 1.0, None, 256, 256, None, 0, None) == -1
+    assert b"NULL" in lib.fo1_last_error()
+    # channel count not a multiple of 64
+    bad = (S * 1)(S(16, 120, 160, 100, 104, 120, 160, 0.25, 0, 0))
+    assert lib.fo1_hfre_region_pool(bad, 1, 16, 3, None, 1.0, 1.0, 7, 0, 1.0, 1.0, 16, 256, 256, None, 0, None) == -1
+    # map larger than the LDS weight tables
+    big = (S * 1)(S(16, 2000, 160, 256, 256, 2000, 160, 0.25, 0, 0))
+    assert lib.fo1_hfre_workspace_bytes(big, 1, 1) == 0
+    # zero boxes is a no-op, not an error
+    assert lib.fo1_hfre_region_pool(arr, 1, None, 0, None, 1.0, 1.0, 7, 0, 1.0, 1.0, None, 256, 256, None, 0, None) == 0
+    # workspace too small -> -2
+    assert lib.fo1_hfre_region_pool(arr, 1, 16, 3, None, 1.0, 1.0, 7, 0, 1.0, 1.0, 16, 256, 256, 16, 8, None) == -2
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(L, "_lib", None)
+    monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(L.Fo1Error):
+        L.load()

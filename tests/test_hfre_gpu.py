@@ -1,0 +1,160 @@
+"""GPU parity tests for fo1_hfre_region_pool (through the C-ABI) against the oracle and
+the committed golden vectors.
+
+Tolerance (stated once, used everywhere here): fp32 output vs the fp32 direct-algorithm
+oracle  rtol 1e-4, atol 2e-5 — the kernel uses the exact separable reformulation, which
+re-associates fp32 sums (SURVEY §7 'Hard parts')."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from hfre_cases import CASES, checksum, make_case, pyramid_sizes, box_fixtures
+from oracle import hfre_oracle as O
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-4, 2e-5
+FPN_STRIDES = [3.5, 7, 14, 28]
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def to_dev(case):
+    d = dict(case)
+    for k in ("aux_maps", "fpn_maps", "vt_maps"):
+        if k in case:
+            # keep the token-major memory layout of the views
+            d[k] = [m.permute(0, 2, 3, 1).contiguous().cuda().permute(0, 3, 1, 2) for m in case[k]]
+    d["boxes"] = case["boxes"].cuda()
+    d["vt_boxes"] = case["vt_boxes"].cuda()
+    return d
+
+
+def engine_out(case_dev, use_vt_boxes=True):
+    from vlm_fo1_amd.hfre import HFREModule
+    fpn = case_dev["fpn"]
+    gh, gw = case_dev["grid_hw"]
+    m = HFREModule(roi_output_size=7, region_feature_dim=case_dev["region_dim"], apply_position_embedding=True,
+                   use_vision_tower_region_feature=True, region_feature_combination="concat",
+                   vision_tower_region_feature_dim=2048 if fpn else 5120, use_simpleFPN_for_vt=fpn,
+                   simple_fpn=(lambda x: case_dev["fpn_maps"]) if fpn else None)
+    vt_in = torch.zeros(1, 1280, gh, gw, dtype=torch.bfloat16, device="cuda") if fpn else case_dev["vt_maps"]
+    if use_vt_boxes:
+        return m(case_dev["aux_maps"], [case_dev["boxes"]], vt_in, [case_dev["vt_boxes"]]).squeeze(0)
+    return m(case_dev["aux_maps"], [case_dev["boxes"]], vt_in, None, vt_scale=case_dev["vt_scale"]).squeeze(0)
+
+
+def oracle_out(case):
+    if case["fpn"]:
+        return O.hfre_oracle(case["aux_maps"], case["boxes"], case["fpn_maps"], case["vt_boxes"],
+                             region_dim=case["region_dim"], grid_hw=case["grid_hw"], vt_strides=FPN_STRIDES)[0]
+    return O.hfre_oracle(case["aux_maps"], case["boxes"], case["vt_maps"], case["vt_boxes"],
+                         region_dim=case["region_dim"], grid_hw=case["grid_hw"])[0]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_hfre_vs_golden_and_oracle(name):
+    case = make_case(name)
+    g = np.load(os.path.join(HERE, "golden", f"hfre_{name}.npz"))
+    assert str(g["checksum"]) == checksum(case)
+    got = engine_out(to_dev(case)).cpu()
+    assert got.dtype == torch.float32 and got.shape == (case["boxes"].shape[0], case["region_dim"])
+    ch = torch.from_numpy(g["channels"]).long()
+    torch.testing.assert_close(got[:, ch], torch.from_numpy(g["out"]), rtol=RTOL, atol=ATOL)
+    torch.testing.assert_close(got, oracle_out(case), rtol=RTOL, atol=ATOL)
+
+
+def test_hfre_in_kernel_vt_scaling_matches_explicit_vt_boxes():
+    case = make_case("demo_fpn")
+    d = to_dev(case)
+    a = engine_out(d, use_vt_boxes=True)
+    b = engine_out(d, use_vt_boxes=False)
+    # vt = aux*scale is one fp32 multiply either way; python-float scale vs fp32 tensor scale may
+    # differ by an ulp in the box, so compare at the parity tolerance, not bitwise
+    torch.testing.assert_close(a, b, rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("budget", [16, 100, 4096])
+def test_hfre_slice_budget_invariance(budget):
+    """Row-slicing is a pure work partition: any pixel budget must give the same result
+    (to fp32 re-association)."""
+    from vlm_fo1_amd import lib as L
+    case = make_case("edge_fpn")
+    d = to_dev(case)
+    ref = engine_out(d).cpu()
+    try:
+        L.check(L.load().fo1_hfre_set_pixel_budget(budget), "set budget")
+        got = engine_out(d).cpu()
+    finally:
+        L.load().fo1_hfre_set_pixel_budget(1024)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(got, oracle_out(case), rtol=RTOL, atol=ATOL)
+
+
+def test_hfre_deterministic():
+    d = to_dev(make_case("countbench30_fpn"))
+    a = engine_out(d)
+    b = engine_out(d)
+    assert torch.equal(a, b), "no atomics: repeated runs must be bit-identical"
+
+
+def test_hfre_inputs_untouched():
+    """Inputs are const (the reference mutates caller box tensors in place, :319,456-463;
+    we must not)."""
+    d = to_dev(make_case("demo_fpn"))
+    b0, v0 = d["boxes"].clone(), d["vt_boxes"].clone()
+    engine_out(d)
+    assert torch.equal(d["boxes"], b0) and torch.equal(d["vt_boxes"], v0)
+
+
+def _full_size_case(H, W, n_boxes, seed):
+    g = torch.Generator().manual_seed(seed)
+    sizes = pyramid_sizes(H, W)
+    aux = [torch.randn(h * w, c, generator=g).bfloat16().reshape(h, w, c).permute(2, 0, 1).unsqueeze(0)
+           for (h, w), c in zip(sizes, (256, 512, 1024, 2048))]
+    gh, gw = round(H / 28) * 2, round(W / 28) * 2
+    fpn = []
+    for f in (4, 2, 1, 0.5):
+        h, w = int(gh * f), int(gw * f)
+        fpn.append(torch.randn(h * w, 512, generator=g).bfloat16().reshape(h, w, 512).permute(2, 0, 1).unsqueeze(0))
+    it = [x for x in box_fixtures()["pixmo"] if len(x["bboxes"]) == 100][0]
+    b = torch.tensor(it["bboxes"], dtype=torch.float32)[:n_boxes]
+    ex, ey = it["extent"]
+    b = b * torch.tensor([W / ex, H / ey, W / ex, H / ey])
+    sw, sh = gw * 14 / W, gh * 14 / H
+    return dict(aux_maps=aux, fpn_maps=fpn, fpn=True, grid_hw=(gh, gw), boxes=b, vt_scale=(sw, sh),
+                vt_boxes=b * torch.tensor([sw, sh, sw, sh]), region_dim=5888)
+
+
+def test_hfre_full_size_coco_like_100_boxes():
+    """BASELINE config 3 geometry: 640x480 image, 100 real UPN boxes, true channel counts."""
+    case = _full_size_case(480, 640, 100, 77)
+    got = engine_out(to_dev(case)).cpu()
+    torch.testing.assert_close(got, oracle_out(case), rtol=RTOL, atol=ATOL)
+
+
+def test_hfre_linearity_at_max_size():
+    """Size-independent property at the largest supported geometry (1344x1344 -> aux 336..42,
+    FPN 384..48): pooling is linear in the maps, so pool(a) + pool(b) == pool(a+b) when a+b is
+    exactly representable (b = a here: 2a is exact in bf16)."""
+    case = _full_size_case(1344, 1344, 100, 5)
+    d = to_dev(case)
+    from vlm_fo1_amd.hfre import HFREModule
+    one = engine_out(d)
+    d2 = dict(d)
+    for k in ("aux_maps", "fpn_maps"):
+        d2[k] = [(m.permute(0, 2, 3, 1) * 2).contiguous().permute(0, 3, 1, 2) for m in d[k]]
+    two = engine_out(d2)
+    m = HFREModule(roi_output_size=7, region_feature_dim=5888, apply_position_embedding=False,
+                   use_vision_tower_region_feature=True, vision_tower_region_feature_dim=2048,
+                   use_simpleFPN_for_vt=True, simple_fpn=lambda x: d["fpn_maps"])
+    gh, gw = d["grid_hw"]
+    nopos = m(d["aux_maps"], [d["boxes"]], torch.zeros(1, 1280, gh, gw, dtype=torch.bfloat16, device="cuda"),
+              [d["vt_boxes"]]).squeeze(0)
+    pos = one - nopos
+    torch.testing.assert_close(two - pos, 2 * nopos, rtol=1e-5, atol=1e-5)
+    # spot-check 5 boxes against the oracle at this size (the full check would take minutes on CPU)
+    sub = dict(case)
+    sub["boxes"] = case["boxes"][:5]
+    sub["vt_boxes"] = case["vt_boxes"][:5]
+    torch.testing.assert_close(one[:5].cpu(), oracle_out(sub), rtol=RTOL, atol=ATOL)

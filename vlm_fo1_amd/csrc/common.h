@@ -1,0 +1,68 @@
+// common.h — shared helpers for the libfo1hip.so translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/fo1.h"
+
+namespace fo1 {
+
+// thread-local error text (fo1_last_error)
+char* err_buf();
+int set_err(int code, const char* fmt, ...);
+
+#define FO1_CHECK_ARG(cond, ...)                                   \
+    do {                                                           \
+        if (!(cond)) return fo1::set_err(FO1_ERR_ARG, __VA_ARGS__); \
+    } while (0)
+
+#define FO1_CHECK_HIP(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess)                                                                \
+            return fo1::set_err((int)_e, "%s failed: %s", #expr, hipGetErrorString(_e));     \
+    } while (0)
+
+#define FO1_CHECK_LAUNCH()                                                                        \
+    do {                                                                                          \
+        hipError_t _e = hipGetLastError();                                                        \
+        if (_e != hipSuccess)                                                                     \
+            return fo1::set_err((int)_e, "kernel launch failed at %s:%d: %s", __FILE__, __LINE__, \
+                                hipGetErrorString(_e));                                           \
+    } while (0)
+
+// bf16 <-> f32 bit helpers (round-to-nearest-even on the way down, like torch)
+__device__ __forceinline__ float bf16_lo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __uint_as_float((uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- optional per-kernel timing (fo1_profile_*) ---------------------------------------
+// When enabled every FO1_LAUNCH is bracketed by hipEvents on the launch stream; disabled
+// (the default, and always during throughput timing) it is a plain launch.
+bool profile_enabled();
+void profile_begin(const char* name, hipStream_t st, double work);
+void profile_end(hipStream_t st);
+
+#define FO1_LAUNCH(name, work, kernel, grid, block, shmem, st, ...)              \
+    do {                                                                         \
+        const bool _prof = fo1::profile_enabled();                               \
+        if (_prof) fo1::profile_begin(name, st, (double)(work));                 \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);         \
+        if (_prof) fo1::profile_end(st);                                         \
+        FO1_CHECK_LAUNCH();                                                      \
+    } while (0)
+
+}  // namespace fo1

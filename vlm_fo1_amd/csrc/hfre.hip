@@ -1,0 +1,343 @@
+// hfre.hip — Hybrid Fine-grained Region Encoder pooling for gfx950 (MI355X).
+//
+// Replaces HFREModule.__call__ / extract_vt_region_feature / gen_sineembed_for_position
+// (reference hybrid_finegrained_region_encoder.py:55-103,230-273,275-469) and the
+// torchvision roi_align + F.interpolate + torch.cat chain inside them.
+//
+// HBM-bound gather, no MFMA: every (box, source, channel-chunk, row-slice) is one
+// 256-thread workgroup that
+//   1. rebuilds the per-axis tap weights of the box in LDS (hfre_math.h),
+//   2. streams the footprint pixels of the bf16 token-major map, 16 B per lane,
+//      channels across lanes (coalesced: consecutive lanes = consecutive channels,
+//      consecutive pixel slots = consecutive pixels), fp32 accumulate,
+//   3. reduces pixel slots with wave shuffles and waves through LDS,
+//   4. writes one fp32 partial row to the workspace.
+// hfre_finish_kernel sums the row-slices of each box in a fixed order, adds the
+// sine box embedding and writes the fp32 output.  No atomics: results are
+// run-to-run deterministic.
+#include "common.h"
+#include "hfre_math.h"
+
+namespace fo1 {
+
+constexpr int kHfreThreads = 256;
+constexpr int kHfreWaves = kHfreThreads / 64;
+constexpr int kHfreMaxChunk = 512;   // channels per workgroup (64 lanes x 8 bf16)
+constexpr int kHfreUnroll = 4;
+
+struct HfreSrcDev {
+    const uint16_t* data;
+    int H, W, C, ld, roi_H, roi_W;
+    float scale;
+    int box_space, out_offset;
+    int chunk, nchunks, max_slices;
+    int wg_base;  // first workgroup id of this source
+    int ws_off;   // float offset of this source inside one box's workspace block
+};
+
+struct HfreParams {
+    HfreSrcDev src[FO1_HFRE_MAX_SOURCES];
+    int n_sources;
+    const float* boxes;     // aux space
+    const float* boxes_vt;  // vt space or nullptr (then aux * (vsx, vsy))
+    int n_boxes;
+    float vsx, vsy;
+    int P;
+    int pos_mode;
+    float pos_w, pos_h;
+    float* out;
+    int out_ld, region_dim;
+    float* ws;
+    int ws_box_stride;  // floats per box
+    int pixel_budget;
+};
+
+struct Footprint {
+    RoiAxis ay, ax;
+    int r_lo, r_hi, c_lo, c_hi;  // inclusive, on the source map
+    int rows_per_slice, n_slices;
+};
+
+__device__ __forceinline__ void load_box(const HfreParams& p, int n, bool vt, float& x1, float& y1, float& x2, float& y2) {
+    const bool direct = vt && p.boxes_vt != nullptr;
+    const float4 b = reinterpret_cast<const float4*>(direct ? p.boxes_vt : p.boxes)[n];
+    x1 = b.x; y1 = b.y; x2 = b.z; y2 = b.w;
+    if (vt && !direct) {
+        x1 *= p.vsx; x2 *= p.vsx;
+        y1 *= p.vsy; y2 *= p.vsy;
+    }
+}
+
+__device__ __forceinline__ Footprint hfre_footprint(const HfreParams& p, const HfreSrcDev& s, int n) {
+    float x1, y1, x2, y2;
+    load_box(p, n, s.box_space == 1, x1, y1, x2, y2);
+    Footprint f;
+    f.ay = make_roi_axis(y1, y2, s.scale, p.P, s.roi_H);
+    f.ax = make_roi_axis(x1, x2, s.scale, p.P, s.roi_W);
+    upsample_range(f.ay.lo, f.ay.hi, s.H, s.roi_H, f.r_lo, f.r_hi);
+    upsample_range(f.ax.lo, f.ax.hi, s.W, s.roi_W, f.c_lo, f.c_hi);
+    const int fh = f.r_hi - f.r_lo + 1, fw = f.c_hi - f.c_lo + 1;
+    if (fh <= 0 || fw <= 0) {
+        f.rows_per_slice = 1;
+        f.n_slices = 0;
+    } else {
+        f.rows_per_slice = slice_rows(fw, p.pixel_budget);
+        f.n_slices = (fh + f.rows_per_slice - 1) / f.rows_per_slice;
+    }
+    return f;
+}
+
+__global__ __launch_bounds__(kHfreThreads) void hfre_pool_kernel(const HfreParams p) {
+    __shared__ float s_wAy[FO1_HFRE_MAX_EXTENT];
+    __shared__ float s_wAx[FO1_HFRE_MAX_EXTENT];
+    __shared__ float s_wy[FO1_HFRE_MAX_EXTENT];
+    __shared__ float s_wx[FO1_HFRE_MAX_EXTENT];
+    __shared__ float s_red[kHfreWaves][kHfreMaxChunk];
+
+    const int bid = blockIdx.x;
+    int si = 0;
+    for (int i = 1; i < p.n_sources; ++i)
+        if (bid >= p.src[i].wg_base) si = i;
+    const HfreSrcDev& s = p.src[si];
+    int local = bid - s.wg_base;
+    const int k = local % s.max_slices;
+    local /= s.max_slices;
+    const int chunk_id = local % s.nchunks;
+    const int n = local / s.nchunks;
+    if (n >= p.n_boxes) return;
+
+    const Footprint f = hfre_footprint(p, s, n);
+    if (k >= f.n_slices) return;  // uniform across the workgroup
+
+    const int tid = threadIdx.x;
+    const int row0 = f.r_lo + k * f.rows_per_slice;
+    int row1 = row0 + f.rows_per_slice - 1;
+    if (row1 > f.r_hi) row1 = f.r_hi;
+    const int nrows = row1 - row0 + 1;
+    const int fw = f.c_hi - f.c_lo + 1;
+
+    // ---- per-axis weights -------------------------------------------------
+    const bool up_y = (s.H != s.roi_H), up_x = (s.W != s.roi_W);
+    if (up_y)
+        for (int a = f.ay.lo + tid; a <= f.ay.hi; a += kHfreThreads) s_wAy[a - f.ay.lo] = roi_axis_weight(f.ay, a);
+    if (up_x)
+        for (int a = f.ax.lo + tid; a <= f.ax.hi; a += kHfreThreads) s_wAx[a - f.ax.lo] = roi_axis_weight(f.ax, a);
+    __syncthreads();
+    for (int r = tid; r < nrows; r += kHfreThreads)
+        s_wy[r] = up_y ? upsample_axis_weight(row0 + r, s_wAy, f.ay.lo, f.ay.hi, s.H, s.roi_H)
+                       : roi_axis_weight(f.ay, row0 + r);
+    for (int c = tid; c < fw; c += kHfreThreads)
+        s_wx[c] = up_x ? upsample_axis_weight(f.c_lo + c, s_wAx, f.ax.lo, f.ax.hi, s.W, s.roi_W)
+                       : roi_axis_weight(f.ax, f.c_lo + c);
+    __syncthreads();
+
+    // ---- stream the footprint ----------------------------------------------
+    const int lpp = s.chunk >> 3;        // lanes per pixel (8 bf16 = 16 B per lane), power of two
+    const int lane = tid & 63, wave = tid >> 6;
+    const int spw = 64 / lpp;            // pixel slots per wave
+    const int slot = wave * spw + lane / lpp;
+    const int cl = lane & (lpp - 1);
+    const int slots = kHfreWaves * spw;
+    const int npix = nrows * fw;
+    const uint16_t* base = s.data + (size_t)chunk_id * s.chunk + (size_t)cl * 8;
+
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+
+    for (int i0 = slot; i0 < npix; i0 += slots * kHfreUnroll) {
+        uint4 v[kHfreUnroll];
+        float w[kHfreUnroll];
+#pragma unroll
+        for (int u = 0; u < kHfreUnroll; ++u) {
+            const int idx = i0 + u * slots;
+            const bool ok = idx < npix;
+            const int id2 = ok ? idx : i0;
+            const int r = id2 / fw;
+            const int c = id2 - r * fw;
+            w[u] = ok ? s_wy[r] * s_wx[c] : 0.0f;
+            const size_t pix = (size_t)(row0 + r) * s.W + (size_t)(f.c_lo + c);
+            v[u] = *reinterpret_cast<const uint4*>(base + pix * s.ld);
+        }
+#pragma unroll
+        for (int u = 0; u < kHfreUnroll; ++u) {
+            acc[0] = fmaf(w[u], bf16_lo(v[u].x), acc[0]);
+            acc[1] = fmaf(w[u], bf16_hi(v[u].x), acc[1]);
+            acc[2] = fmaf(w[u], bf16_lo(v[u].y), acc[2]);
+            acc[3] = fmaf(w[u], bf16_hi(v[u].y), acc[3]);
+            acc[4] = fmaf(w[u], bf16_lo(v[u].z), acc[4]);
+            acc[5] = fmaf(w[u], bf16_hi(v[u].z), acc[5]);
+            acc[6] = fmaf(w[u], bf16_lo(v[u].w), acc[6]);
+            acc[7] = fmaf(w[u], bf16_hi(v[u].w), acc[7]);
+        }
+    }
+
+    // ---- reduce pixel slots inside the wave, then waves through LDS ----------
+    for (int off = 32; off >= lpp; off >>= 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+    }
+    if (lane < lpp) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s_red[wave][cl * 8 + j] = acc[j];
+    }
+    __syncthreads();
+    float* wsrow = p.ws + (size_t)n * p.ws_box_stride + s.ws_off + (size_t)k * s.C + (size_t)chunk_id * s.chunk;
+    for (int c = tid; c < s.chunk; c += kHfreThreads) {
+        float t = s_red[0][c];
+#pragma unroll
+        for (int wv = 1; wv < kHfreWaves; ++wv) t += s_red[wv][c];
+        wsrow[c] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void hfre_finish_kernel(const HfreParams p) {
+    __shared__ int s_nsl[FO1_HFRE_MAX_SOURCES];
+    __shared__ float s_box[4];
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    if (tid < p.n_sources) s_nsl[tid] = hfre_footprint(p, p.src[tid], n).n_slices;
+    if (tid == 32 && p.pos_mode != 0) {
+        float x1, y1, x2, y2;
+        load_box(p, n, p.pos_mode == 1, x1, y1, x2, y2);
+        // reference :457-463 — normalise, xyxy -> cxcywh (fp32, same op order)
+        x1 = x1 / p.pos_w; x2 = x2 / p.pos_w;
+        y1 = y1 / p.pos_h; y2 = y2 / p.pos_h;
+        const float w = x2 - x1, h = y2 - y1;
+        s_box[0] = x1 + w / 2.0f;  // cx
+        s_box[1] = y1 + h / 2.0f;  // cy
+        s_box[2] = w;
+        s_box[3] = h;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * blockDim.x + tid;
+    if (c >= p.region_dim) return;
+    float v = 0.0f;
+    for (int i = 0; i < p.n_sources; ++i) {
+        const HfreSrcDev& s = p.src[i];
+        if (c >= s.out_offset && c < s.out_offset + s.C) {
+            const float* w = p.ws + (size_t)n * p.ws_box_stride + s.ws_off + (c - s.out_offset);
+            const int nsl = s_nsl[i];
+            for (int k = 0; k < nsl; ++k) v += w[(size_t)k * s.C];
+        }
+    }
+    if (p.pos_mode != 0) {
+        // gen_sineembed_for_position (reference :55-103): blocks ordered (y, x, w, h)
+        const int d = p.region_dim / 4;
+        const int q = c / d, i = c - q * d;
+        const float coord = (q == 0) ? s_box[1] : (q == 1) ? s_box[0] : s_box[q];
+        const float dim_t = powf(10000.0f, (float)(2 * (i / 2)) / (float)d);
+        const float ang = coord * 6.283185307179586f / dim_t;
+        v += (i & 1) ? cosf(ang) : sinf(ang);
+    }
+    p.out[(size_t)n * p.out_ld + c] = v;
+}
+
+static int g_hfre_pixel_budget = 1024;
+
+static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxes, HfreParams& p, int& total_wgs) {
+    FO1_CHECK_ARG(sources != nullptr, "hfre: sources is NULL");
+    FO1_CHECK_ARG(n_sources >= 1 && n_sources <= FO1_HFRE_MAX_SOURCES, "hfre: n_sources=%d out of [1,%d]", n_sources,
+                  FO1_HFRE_MAX_SOURCES);
+    FO1_CHECK_ARG(n_boxes >= 0, "hfre: n_boxes=%d < 0", n_boxes);
+    p.n_sources = n_sources;
+    p.pixel_budget = g_hfre_pixel_budget;
+    int wg = 0, ws = 0;
+    for (int i = 0; i < n_sources; ++i) {
+        const fo1_hfre_source_t& s = sources[i];
+        FO1_CHECK_ARG(s.H >= 1 && s.W >= 1 && s.H <= FO1_HFRE_MAX_EXTENT && s.W <= FO1_HFRE_MAX_EXTENT,
+                      "hfre: source %d map %dx%d outside [1,%d]", i, s.H, s.W, FO1_HFRE_MAX_EXTENT);
+        FO1_CHECK_ARG(s.roi_H >= s.H && s.roi_W >= s.W && s.roi_H <= FO1_HFRE_MAX_EXTENT && s.roi_W <= FO1_HFRE_MAX_EXTENT,
+                      "hfre: source %d roi map %dx%d must be >= map %dx%d and <= %d", i, s.roi_H, s.roi_W, s.H, s.W,
+                      FO1_HFRE_MAX_EXTENT);
+        FO1_CHECK_ARG(s.C >= 64 && s.C % 64 == 0, "hfre: source %d C=%d must be a positive multiple of 64", i, s.C);
+        FO1_CHECK_ARG(s.ld >= s.C && s.ld % 8 == 0, "hfre: source %d ld=%d must be >= C and a multiple of 8", i, s.ld);
+        FO1_CHECK_ARG(s.box_space == 0 || s.box_space == 1, "hfre: source %d box_space=%d", i, s.box_space);
+        FO1_CHECK_ARG(s.out_offset >= 0, "hfre: source %d out_offset=%d", i, s.out_offset);
+        HfreSrcDev& d = p.src[i];
+        d.data = (const uint16_t*)s.data;
+        d.H = s.H; d.W = s.W; d.C = s.C; d.ld = s.ld; d.roi_H = s.roi_H; d.roi_W = s.roi_W;
+        d.scale = s.spatial_scale; d.box_space = s.box_space; d.out_offset = s.out_offset;
+        int chunk = kHfreMaxChunk;
+        while (s.C % chunk) chunk >>= 1;
+        d.chunk = chunk;
+        d.nchunks = s.C / chunk;
+        d.max_slices = cdiv(s.H, slice_rows(s.W, p.pixel_budget));
+        d.wg_base = wg;
+        d.ws_off = ws;
+        wg += n_boxes * d.nchunks * d.max_slices;
+        ws += d.max_slices * s.C;
+    }
+    p.ws_box_stride = ws;
+    total_wgs = wg;
+    return FO1_OK;
+}
+
+}  // namespace fo1
+
+extern "C" {
+
+// test/tuning hook: pixels per workgroup slice (default 1024)
+int fo1_hfre_set_pixel_budget(int pixels) {
+    if (pixels < 16 || pixels > 65536) return fo1::set_err(FO1_ERR_ARG, "hfre: pixel budget %d outside [16,65536]", pixels);
+    fo1::g_hfre_pixel_budget = pixels;
+    return FO1_OK;
+}
+
+size_t fo1_hfre_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes) {
+    fo1::HfreParams p;
+    int wgs = 0;
+    if (fo1::hfre_plan(sources, n_sources, n_boxes, p, wgs) != FO1_OK) return 0;
+    return (size_t)p.ws_box_stride * (size_t)(n_boxes > 0 ? n_boxes : 1) * sizeof(float);
+}
+
+int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const float* boxes_aux, int n_boxes,
+                         const float* boxes_vt, float vt_scale_x, float vt_scale_y, int roi_size, int pos_mode, float pos_img_w,
+                         float pos_img_h, float* out, int out_ld, int region_dim, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    using namespace fo1;
+    HfreParams p;
+    int wgs = 0;
+    int rc = hfre_plan(sources, n_sources, n_boxes, p, wgs);
+    if (rc != FO1_OK) return rc;
+    if (n_boxes == 0) return FO1_OK;
+    FO1_CHECK_ARG(boxes_aux != nullptr && out != nullptr, "hfre: NULL boxes/out");
+    FO1_CHECK_ARG(((uintptr_t)boxes_aux & 15) == 0 && ((uintptr_t)boxes_vt & 15) == 0,
+                  "hfre: boxes must be 16-byte aligned");
+    FO1_CHECK_ARG(roi_size >= 1 && roi_size <= 32, "hfre: roi_size=%d", roi_size);
+    FO1_CHECK_ARG(pos_mode >= 0 && pos_mode <= 2, "hfre: pos_mode=%d", pos_mode);
+    FO1_CHECK_ARG(region_dim >= 4 && out_ld >= region_dim, "hfre: region_dim=%d out_ld=%d", region_dim, out_ld);
+    FO1_CHECK_ARG(pos_mode == 0 || (region_dim % 4 == 0 && pos_img_w > 0.f && pos_img_h > 0.f),
+                  "hfre: position embedding needs region_dim %% 4 == 0 and positive image size");
+    for (int i = 0; i < n_sources; ++i) {
+        FO1_CHECK_ARG(sources[i].data != nullptr && ((uintptr_t)sources[i].data & 15) == 0,
+                      "hfre: source %d data NULL or not 16-byte aligned", i);
+        FO1_CHECK_ARG(sources[i].out_offset + sources[i].C <= region_dim, "hfre: source %d writes past region_dim", i);
+    }
+    const size_t need = (size_t)p.ws_box_stride * n_boxes * sizeof(float);
+    if (workspace == nullptr || workspace_bytes < need)
+        return set_err(FO1_ERR_WORKSPACE, "hfre: workspace %zu B < required %zu B", workspace_bytes, need);
+    p.boxes = boxes_aux;
+    p.boxes_vt = boxes_vt;
+    p.n_boxes = n_boxes;
+    p.vsx = vt_scale_x;
+    p.vsy = vt_scale_y;
+    p.P = roi_size;
+    p.pos_mode = pos_mode;
+    p.pos_w = pos_img_w;
+    p.pos_h = pos_img_h;
+    p.out = out;
+    p.out_ld = out_ld;
+    p.region_dim = region_dim;
+    p.ws = (float*)workspace;
+    hipStream_t st = (hipStream_t)stream;
+    // algorithmic bytes (SURVEY §8d upper bound): every source map once in bf16 + fp32 output + boxes
+    double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
+    for (int i = 0; i < n_sources; ++i) bytes += (double)sources[i].H * sources[i].W * sources[i].C * 2.0;
+    FO1_LAUNCH("hfre_pool", bytes, hfre_pool_kernel, dim3(wgs), dim3(kHfreThreads), 0, st, p);
+    FO1_LAUNCH("hfre_finish", (double)n_boxes * region_dim * 8.0, hfre_finish_kernel,
+               dim3(cdiv(region_dim, 256), n_boxes), dim3(256), 0, st, p);
+    return FO1_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+"""ctypes binding of libfo1hip.so (include/fo1.h).
+
+The library is the product: if it is missing or fails to load this module raises —
+there is no eager/CPU fallback anywhere in the package."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfo1hip.so")
+
+c_int, c_float, c_void_p, c_size_t, c_int32 = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
+                                               ctypes.c_int32)
+
+
+class HfreSource(ctypes.Structure):
+    """fo1_hfre_source_t (include/fo1.h)."""
+    _fields_ = [
+        ("data", c_void_p),
+        ("H", c_int32), ("W", c_int32), ("C", c_int32), ("ld", c_int32),
+        ("roi_H", c_int32), ("roi_W", c_int32),
+        ("spatial_scale", c_float),
+        ("box_space", c_int32),
+        ("out_offset", c_int32),
+    ]
+
+
+class ProfileRow(ctypes.Structure):
+    """fo1_profile_row_t (include/fo1.h)."""
+    _fields_ = [("name", ctypes.c_char * 48), ("calls", ctypes.c_int64), ("total_ms", ctypes.c_double),
+                ("total_work", ctypes.c_double)]
+
+
+# name -> (restype, argtypes); mirrors include/fo1.h one to one (tests/test_abi.py checks it)
+SIGNATURES = {
+    "fo1_abi_version": (c_int, []),
+    "fo1_last_error": (ctypes.c_char_p, []),
+    "fo1_profile_enable": (c_int, [c_int]),
+    "fo1_profile_read": (c_int, [ctypes.POINTER(ProfileRow), c_int, c_int]),
+    "fo1_hfre_set_pixel_budget": (c_int, [c_int]),
+    "fo1_hfre_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),
+    "fo1_hfre_region_pool": (c_int, [ctypes.POINTER(HfreSource), c_int, c_void_p, c_int, c_void_p, c_float, c_float,
+                                     c_int, c_int, c_float, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t,
+                                     c_void_p]),
+}
+
+_lib = None
+
+
+class Fo1Error(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Fo1Error(
+                f"{LIB_PATH} not found — build it with `python -m vlm_fo1_amd.build` "
+                "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().fo1_last_error().decode("utf-8", "replace")
+        raise Fo1Error(f"{what} failed (rc={rc}): {msg}")
+
+
+def current_stream_ptr() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def profile(on: bool) -> None:
+    load().fo1_profile_enable(1 if on else 0)
+
+
+def profile_rows(reset: bool = True):
+    """-> list of dict(name, calls, total_ms, total_work) since the last reset."""
+    rows = (ProfileRow * 64)()
+    n = load().fo1_profile_read(rows, 64, 1 if reset else 0)
+    if n < 0:
+        check(n, "fo1_profile_read")
+    return [dict(name=rows[i].name.decode(), calls=rows[i].calls, total_ms=rows[i].total_ms,
+                 total_work=rows[i].total_work) for i in range(min(n, 64))]
