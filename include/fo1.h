@@ -106,6 +106,78 @@ int fo1_hfre_region_pool(
     void* workspace, size_t workspace_bytes,         /* device scratch                       */
     void* stream);
 
+/* ------------------------------------------------------------------------
+ * bf16 GEMM with fused epilogue  (SURVEY §8a rows a2,a4,a5,a8,a9,a11: every nn.Linear /
+ * 1x1-conv / patch-embed of the hot path; reference call sites
+ * modeling_qwen2_5_vl.py:79-81,103-110,151-155,176-177,633-635,731-734,
+ * modeling_davit.py:63-65,157-158,235-236, multimodal_projector/builder.py:64-71,103-110)
+ *
+ *   C[M,N] = epilogue(A[M,K] . W[N,K]^T),  W = nn.Linear weight [out,in], bf16 in, fp32 accumulate
+ *   epilogue (each step rounds to bf16 like the reference's op-by-op bf16 tensors):
+ *     y = bf16(acc + bias[n]);  y = bf16(act(y));  y = bf16(y + residual[m,n])
+ *   act: 0 none, 1 exact-erf GELU, 2 SiLU.   out_f32 != 0: C is fp32 (acc + bias, act), no residual.
+ * K, lda, ldw multiples of 8; A, W 16-byte aligned.  bias/residual may be NULL.
+ * ---------------------------------------------------------------------- */
+int fo1_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias,
+                  const void* residual, int ldr, void* C, int ldc,
+                  int M, int N, int K, int act, int out_f32, void* stream);
+/* Tuning hook: staging 0 auto / 1 register-staged / 2 LDS-DMA; tile 0 auto / 1 128x128 /
+ * 2 64x128 / 3 64x64. */
+int fo1_gemm_set_variant(int staging, int tile);
+
+/* ------------------------------------------------------------------------
+ * Row norms / small elementwise ops (HBM-bound).  All tensors bf16 row-major with explicit row
+ * strides (elements, multiples of 8); D multiple of 8, <= 4096.
+ *   fo1_rmsnorm_bf16   Qwen2RMSNorm              modeling_qwen2_5_vl.py:126-140 (ViT blocks, merger, LLM)
+ *   fo1_layernorm_bf16 nn.LayerNorm              modeling_davit.py:29-48 (PreNorm), :135-141 (ConvEmbed)
+ *                      and the channel LayerNorm of simple_fpn.py:58-78 on token-major maps
+ *   fo1_swiglu_bf16    act_fn(gate)*up           modeling_qwen2_5_vl.py:85-86, :636; input rows are [gate | up]
+ *   fo1_bias_act_bf16  y = act(x + bias)         act 0 none / 1 erf-GELU (nn.GELU, simple_fpn.py:145)
+ *   fo1_argmax_bf16    greedy next token         first index among ties, like torch.argmax
+ * ---------------------------------------------------------------------- */
+int fo1_rmsnorm_bf16(const void* x, int ldx, const void* weight, void* y, int ldy, int M, int D,
+                     float eps, void* stream);
+int fo1_layernorm_bf16(const void* x, int ldx, const void* weight, const void* bias, void* y, int ldy,
+                       int M, int D, float eps, void* stream);
+int fo1_swiglu_bf16(const void* gate_up, int ldgu, void* out, int ldo, int M, int F, void* stream);
+int fo1_bias_act_bf16(const void* x, int ldx, const void* bias, void* y, int ldy, int M, int D, int act,
+                      void* stream);
+int fo1_argmax_bf16(const void* x, int n, int* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Rotary embeddings on the fused QKV activations, and the V -> V^T copy.
+ *   fo1_rope_llm_bf16  apply_multimodal_rotary_pos_emb  modeling_qwen2_5_vl.py:643-685 with the
+ *        section-selected bf16 cos/sin [L, head_dim] of :603-624; rotates heads [0,n_heads) of width
+ *        head_dim starting at column col0 in place; heads >= k_first_head are also appended to
+ *        kcache[(head-k_first_head)*kcache_head_stride + (pos0+t)*head_dim] when kcache != NULL.
+ *   fo1_rope_vit_bf16  apply_rotary_pos_emb_flashatt / _vision  :162-169, :219-230: fp32 cos/sin
+ *        [S, head_dim/2]; rotates the q and k heads (2*n_heads heads from column 0) in place.
+ *   fo1_transpose_bf16 dst[c*ld_dst + col0 + m] = src[m*ld_src + c]   (C multiple of 64)
+ * ---------------------------------------------------------------------- */
+int fo1_rope_llm_bf16(void* qkv, int ld, int col0, int n_heads, int head_dim, const void* cos_bf16,
+                      const void* sin_bf16, int L, void* kcache, int k_first_head,
+                      long long kcache_head_stride, int pos0, void* stream);
+int fo1_rope_vit_bf16(void* qkv, int ld, int n_heads, int head_dim, const float* cos_f32,
+                      const float* sin_f32, int S, void* stream);
+int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst, int col0, int M, int C,
+                       void* stream);
+
+/* ------------------------------------------------------------------------
+ * Fused attention  softmax(scale * Q K^T [+ causal mask]) V   (flash_attn_varlen_func /
+ * _flash_attention_forward / SDPA at modeling_qwen2_5_vl.py:205,319,895,990; DaViT window
+ * attention modeling_davit.py:262-270).  head_dim in {32, 80, 128}; GQA via n_q_heads/n_kv_heads.
+ * `items` = device int32[n_items][4] {q_start, q_end, kv_start, kv_end}: each item is <= 64
+ * queries attending keys [kv_start, kv_end) (and key <= query when causal); kv_start % 4 == 0.
+ * V is passed transposed: VT[(kv_head*head_dim + d)*vt_row_stride + key] (fo1_transpose_bf16),
+ * finite beyond kv_end up to the next multiple of 4.  Strides in elements.
+ * ---------------------------------------------------------------------- */
+int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_stride,
+                       const void* K, long long k_tok_stride, long long k_head_stride,
+                       const void* VT, long long vt_row_stride,
+                       void* O, long long o_tok_stride, long long o_head_stride,
+                       const int32_t* items, int n_items, int n_q_heads, int n_kv_heads, int head_dim,
+                       float scale, int causal, double flops_hint, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

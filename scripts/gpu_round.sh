@@ -13,7 +13,7 @@ echo "== smoke"; timeout 300 python __graft_entry__.py smoke 2>&1 | tee $OUT/smo
 echo "== bench"; timeout 600 python bench.py 2>&1 | tee $OUT/bench.log | tail -3
 echo "== rocprofv3 kernel stats"
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/rocprof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/rocprof.log 2>&1
 cd $ROOT
 find $OUT/prof -name "*kernel_stats*" | head -3
 for f in $(find $OUT/prof -name "*kernel_stats*.csv" | head -1); do head -25 $f; done

@@ -1,0 +1,256 @@
+"""GPU parity tests of the dense / elementwise / attention ops (through the C-ABI) against plain
+torch fp32 references of the same op on the CPU, with the reference's bf16 rounding points.
+
+Tolerances: an op that ends in ONE bf16 rounding of an fp32 result must match the reference's
+rounding to <= 1 bf16 ulp (rtol 2^-7 on the value); accumulations (GEMM, attention) use
+rtol 1.6e-2 / atol scaled to the output magnitude (SURVEY §7 'parity tolerances')."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rb(x):
+    return x.to(BF).float()
+
+
+def close_bf16(got, ref, ulps=1.0, atol=1e-6, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    tol = ulps * 2.0 ** -7 * ref.abs() + atol
+    bad = (got - ref).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())}/{bad.numel()} off; max abs err {(got - ref).abs().max():.4g} " \
+                          f"at ref {ref.flatten()[(got - ref).abs().argmax()]:.4g}"
+
+
+def gemm_ref(a, w, bias=None, res=None, act=0):
+    y = a.float().cpu() @ w.float().cpu().t()
+    if bias is not None:
+        y = y + bias.float().cpu()
+    y = rb(y)
+    if act == 1:
+        y = rb(torch.nn.functional.gelu(y))
+    elif act == 2:
+        y = rb(torch.nn.functional.silu(y))
+    if res is not None:
+        y = rb(y + res.float().cpu())
+    return y
+
+
+GEMM_SHAPES = [
+    # (M, N, K, bias, res, act)
+    (64, 64, 64, False, False, 0),
+    (128, 256, 128, True, False, 0),
+    (200, 328, 1176, True, False, 0),      # patch-embed K=1176 (K % 64 != 0 -> register path), ragged M/N
+    (391, 2560, 2048, True, False, 0),     # LLM qkv
+    (391, 2048, 11008, False, True, 0),    # LLM down + residual
+    (100, 2048, 5888, True, False, 1),     # region projector + GELU
+    (1564, 3424, 1280, True, False, 0),    # ViT MLP (padded 3420 -> 3424)
+    (77, 130, 72, True, True, 2),          # tiny ragged everything
+]
+
+
+@pytest.mark.parametrize("staging", [1, 2])
+@pytest.mark.parametrize("tile", [1, 2, 3])
+def test_gemm_variants(staging, tile):
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(staging * 10 + tile)
+    try:
+        for (M, N, K, hb, hr, act) in GEMM_SHAPES:
+            if staging == 2 and K % 64 != 0:
+                continue
+            L.check(L.load().fo1_gemm_set_variant(staging, tile), "variant")
+            a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+            w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+            bias = (torch.randn(N) * 0.1).to(BF).cuda() if hb else None
+            res = torch.randn(M, N).to(BF).cuda() if hr else None
+            got = ops.gemm(a, w, bias, res, act)
+            ref = gemm_ref(a, w, bias, res, act)
+            scale = ref.abs().max().item()
+            err = (got.float().cpu() - ref).abs().max().item()
+            assert err <= 2e-2 * scale + 1e-3, f"gemm {M}x{N}x{K} staging={staging} tile={tile}: max err {err:.4g} (scale {scale:.4g})"
+            # transposition / tile-mapping sanity: relative Frobenius error must be at rounding level
+            rel = (got.float().cpu() - ref).norm() / ref.norm()
+            assert rel < 4e-3, f"gemm {M}x{N}x{K} staging={staging} tile={tile}: rel fro err {rel:.4g}"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+
+
+def test_gemm_auto_and_fp32_out_and_strided():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(5)
+    M, N, K = 300, 512, 256
+    big = (torch.randn(M, K + 64) * 0.5).to(BF).cuda()
+    a = big[:, 32:32 + K]  # row-strided view, 16-B aligned offset (32*2 B)
+    w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+    got = ops.gemm(a, w, out_f32=True)
+    ref = a.float().cpu() @ w.float().cpu().t()
+    assert got.dtype == torch.float32
+    torch.testing.assert_close(got.cpu(), ref, rtol=1e-3, atol=1e-3)
+    # asymmetric check: A = I picks rows of W^T exactly (catches row/col swaps)
+    eye = torch.eye(128, dtype=BF).cuda()
+    w2 = torch.arange(96 * 128, dtype=torch.float32).reshape(96, 128).remainder(251).to(BF).cuda()
+    got2 = ops.gemm(eye, w2)
+    assert torch.equal(got2.cpu(), w2.cpu().t().contiguous())
+
+
+def test_rmsnorm_layernorm():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(1)
+    for D in (1280, 2048, 256, 512):
+        x = (torch.randn(37, D) * 3).to(BF).cuda()
+        w = (1 + 0.1 * torch.randn(D)).to(BF).cuda()
+        b = (0.1 * torch.randn(D)).to(BF).cuda()
+        got = ops.rmsnorm(x, w, 1e-6)
+        xf = x.float().cpu()
+        ref = rb(w.float().cpu() * rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)))
+        close_bf16(got, ref, ulps=1.01, what=f"rmsnorm D={D}")
+        got = ops.layernorm(x, w, b, 1e-5)
+        ref = rb(torch.nn.functional.layer_norm(xf, (D,), w.float().cpu(), b.float().cpu(), 1e-5))
+        close_bf16(got, ref, ulps=1.01, atol=2e-3, what=f"layernorm D={D}")
+
+
+def test_swiglu_biasact_argmax():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(2)
+    gu = (torch.randn(33, 2 * 3424) * 2).to(BF).cuda()
+    got = ops.swiglu(gu)
+    g, u = gu.float().cpu()[:, :3424], gu.float().cpu()[:, 3424:]
+    ref = rb(rb(torch.nn.functional.silu(g)) * u)
+    close_bf16(got, ref, ulps=1.01, atol=1e-5, what="swiglu")
+    x = torch.randn(50, 640).to(BF).cuda()
+    bias = torch.randn(640).to(BF).cuda()
+    got = ops.bias_act(x, bias, 1)
+    ref = rb(torch.nn.functional.gelu(rb(x.float().cpu() + bias.float().cpu())))
+    close_bf16(got, ref, ulps=1.01, atol=1e-5, what="bias+gelu")
+    row = torch.randn(151936).to(BF)
+    row[777] = row.max() + 1
+    row[90000] = row[777]  # tie: first index wins
+    assert ops.argmax(row.cuda()).item() == 777
+
+
+def test_rope_llm_and_kcache():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(3)
+    L, H, KV, HD = 45, 16, 2, 128
+    qkv = torch.randn(L, (H + 2 * KV) * HD).to(BF).cuda()
+    ang = torch.rand(L, HD // 2) * 6.28
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().to(BF), emb.sin().to(BF)
+    ref_in = qkv.float().cpu()[:, :(H + KV) * HD].reshape(L, H + KV, HD)
+    c, s = cos.float()[:, None, :], sin.float()[:, None, :]
+    rot = torch.cat([-ref_in[..., HD // 2:], ref_in[..., :HD // 2]], -1)
+    ref = rb(rb(ref_in * c) + rb(rot * s))
+    kc = torch.zeros(KV, 64, HD, dtype=BF, device="cuda")
+    v_before = qkv[:, (H + KV) * HD:].clone()
+    ops.rope_llm(qkv, H + KV, HD, cos.cuda(), sin.cuda(), kcache=kc, k_first_head=H, pos0=7)
+    got = qkv.float().cpu()[:, :(H + KV) * HD].reshape(L, H + KV, HD)
+    close_bf16(got, ref, ulps=1.01, atol=1e-6, what="rope_llm")
+    assert torch.equal(qkv[:, (H + KV) * HD:], v_before), "v must be untouched"
+    assert torch.equal(kc[:, 7:7 + L].cpu(), qkv[:, H * HD:(H + KV) * HD].reshape(L, KV, HD).permute(1, 0, 2).cpu())
+    assert kc[:, :7].abs().sum() == 0 and kc[:, 7 + L:].abs().sum() == 0
+
+
+def test_rope_vit():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(4)
+    S, H, HD = 100, 16, 80
+    qkv = torch.randn(S, 3 * H * HD).to(BF).cuda()
+    ang = torch.rand(S, HD // 2) * 6.28
+    x = qkv.float().cpu()[:, :2 * H * HD].reshape(S, 2 * H, HD)
+    emb = torch.cat([ang, ang], -1)
+    c, s = emb.cos()[:, None, :], emb.sin()[:, None, :]
+    rot = torch.cat([-x[..., HD // 2:], x[..., :HD // 2]], -1)
+    ref = rb(x * c + rot * s)
+    v_before = qkv[:, 2 * H * HD:].clone()
+    ops.rope_vit(qkv, H, HD, ang.cos().cuda(), ang.sin().cuda())
+    got = qkv.float().cpu()[:, :2 * H * HD].reshape(S, 2 * H, HD)
+    close_bf16(got, ref, ulps=1.01, atol=1e-6, what="rope_vit")
+    assert torch.equal(qkv[:, 2 * H * HD:], v_before)
+
+
+def test_transpose():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(6)
+    for (M, C, col0, ldd) in [(100, 128, 0, 128), (37, 256, 8, 72), (391, 1280, 0, 448), (5, 64, 3, 16)]:
+        src = torch.randn(M, C).to(BF).cuda()
+        dst = torch.zeros(C, ldd, dtype=BF, device="cuda")
+        ops.transpose_into(src, dst, col0)
+        ref = torch.zeros(C, ldd, dtype=BF)
+        ref[:, col0:col0 + M] = src.cpu().t()
+        assert torch.equal(dst.cpu(), ref), f"transpose {M}x{C} col0={col0}"
+
+
+def attn_ref(q, k, v, segments, causal, scale):
+    """q [L,H,D], k/v [L,KV,D] fp32 cpu; P rounded to bf16 before PV like the kernel / flash-attn."""
+    L, H, D = q.shape
+    KV = k.shape[1]
+    out = torch.zeros(L, H, D)
+    for (s, e) in segments:
+        for h in range(H):
+            kv = h // (H // KV)
+            sc = (q[s:e, h] @ k[s:e, kv].t()) * scale
+            if causal:
+                mask = torch.ones(e - s, e - s, dtype=torch.bool).tril()
+                sc = sc.masked_fill(~mask, float("-inf"))
+            m = sc.max(-1, keepdim=True).values
+            p = rb(torch.exp(sc - m))
+            out[s:e, h] = (p @ v[s:e, kv]) / p.sum(-1, keepdim=True)
+    return out
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(name="llm_causal_gqa", L=391, H=16, KV=2, D=128, segs=None, causal=True),
+    dict(name="llm_causal_short", L=50, H=16, KV=2, D=128, segs=None, causal=True),
+    dict(name="vit_full", L=300, H=16, KV=16, D=80, segs=None, causal=False),
+    dict(name="vit_windows_ragged", L=296, H=16, KV=16, D=80, segs=[(0, 64), (64, 128), (128, 160), (160, 176), (176, 240), (240, 296)], causal=False),
+    dict(name="davit_window", L=288, H=8, KV=8, D=32, segs=[(0, 144), (144, 288)], causal=False),
+])
+def test_attention(cfg):
+    from vlm_fo1_amd import ops
+    torch.manual_seed(7)
+    L, H, KV, D = cfg["L"], cfg["H"], cfg["KV"], cfg["D"]
+    segs = cfg["segs"] or [(0, L)]
+    # fused qkv buffer like the engine uses it
+    qkv = (torch.randn(L, (H + 2 * KV) * D) * 1.5).to(BF).cuda()
+    q = qkv[:, :H * D]
+    k = qkv[:, H * D:(H + KV) * D]
+    v = qkv[:, (H + KV) * D:]
+    Lp = (L + 63) // 64 * 64
+    vt = torch.zeros(KV * D, Lp, dtype=BF, device="cuda")
+    ops.transpose_into(v, vt, 0)
+    items = ops.make_items(segs, "cuda")
+    scale = 1.0 / math.sqrt(D)
+    got = ops.attention(q, k, vt, items, H, KV, D, scale, cfg["causal"])
+    ref = attn_ref(q.float().cpu().reshape(L, H, D), k.float().cpu().reshape(L, KV, D), v.float().cpu().reshape(L, KV, D),
+                   segs, cfg["causal"], scale).reshape(L, H * D)
+    err = (got.float().cpu() - ref).abs()
+    assert err.max() < 3e-2, f"{cfg['name']}: max err {err.max():.4g}; worst row {int(err.max(1).values.argmax())}"
+    rel = (got.float().cpu() - ref).norm() / ref.norm()
+    assert rel < 6e-3, f"{cfg['name']}: rel fro err {rel:.4g}"
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump at a later key tile (spiked K row): the rescale of O and l
+    must be exact (guide rule 26: a rare data-dependent branch needs its own test)."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(8)
+    L, H, D = 256, 2, 128
+    q = torch.randn(L, H * D)
+    k = torch.randn(L, H * D) * 0.3
+    v = torch.randn(L, H * D)
+    k[200] = q[10] * 2.0  # key 200 (4th tile) dominates query 10
+    k[70] = q[33] * 3.0
+    qkv = torch.cat([q, k, v], 1).to(BF).cuda()
+    vt = torch.zeros(H * D, 256, dtype=BF, device="cuda")
+    ops.transpose_into(qkv[:, 2 * H * D:], vt, 0)
+    items = ops.make_items([(0, L)], "cuda")
+    sc = 1 / math.sqrt(D)
+    got = ops.attention(qkv[:, :H * D], qkv[:, H * D:2 * H * D], vt, items, H, H, D, sc, False)
+    qf = qkv.float().cpu()
+    ref = attn_ref(qf[:, :H * D].reshape(L, H, D), qf[:, H * D:2 * H * D].reshape(L, H, D),
+                   qf[:, 2 * H * D:].reshape(L, H, D), [(0, L)], False, sc).reshape(L, H * D)
+    err = (got.float().cpu() - ref).abs()
+    assert err.max() < 3e-2, f"max err {err.max():.4g} at row {int(err.max(1).values.argmax())}"

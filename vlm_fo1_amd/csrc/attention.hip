@@ -1,0 +1,227 @@
+// attention.hip — fused softmax(QK^T)V on MFMA for gfx950: the ViT's windowed/full varlen
+// attention (head dim 80), the LLM's causal GQA prefill (head dim 128) and DaViT's 12x12 window
+// attention (head dim 32).  Replaces flash_attn_varlen_func / _flash_attention_forward /
+// F.scaled_dot_product_attention at reference modeling_qwen2_5_vl.py:205,319,895,990 and the
+// explicit softmax(q k^T) v at modeling_davit.py:262-270.
+//
+// One workgroup = 4 waves = one work item (<= 64 queries of one segment) x one query head; each
+// wave owns 16 queries.  Per 64-key tile: K rows and V^T rows are staged once in LDS and shared by
+// the 4 waves.  Scores are computed TRANSPOSED (S^T = K Q^T, v_mfma_f32_16x16x32_bf16 with a = K,
+// b = Q) so each lane owns one query column: the online-softmax statistics are lane-local plus two
+// cross-lane-group shuffles, and the exponentiated P values are already in the B-operand layout of
+// the second MFMA (O^T = V^T P^T), whose accumulator rows are head-dim indices and whose column is
+// the same query - so the per-query rescale needs no data movement either.  P is rounded to bf16
+// before the PV product (as flash-attention does); accumulation, max and sum are fp32.
+//
+// V is consumed as V^T ([kv_head*HD + d][key]) so that a lane's 8 k-slots are two 8-byte LDS reads;
+// the transposed copy is written once per layer by fo1_transpose_bf16 (rope.hip).
+#include "common.h"
+
+namespace fo1 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct AttnItem {
+    int q_start, q_end;    // queries [q_start, q_end), q_end - q_start <= 64
+    int kv_start, kv_end;  // keys [kv_start, kv_end); causal: additionally key <= query (same index space)
+};
+
+struct AttnParams {
+    const uint16_t* Q; long long q_tok, q_head;      // element strides
+    const uint16_t* K; long long k_tok, k_head;
+    const uint16_t* VT; long long vt_row;            // V^T row stride (elements); row = kv_head*HD + d
+    uint16_t* O; long long o_tok, o_head;
+    const AttnItem* items;
+    int n_items, Hq, group;                          // group = Hq / Hkv
+    float scale;
+    int causal;
+};
+
+template <int HD>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int HDP = (HD + 31) / 32 * 32;  // head dim padded to the MFMA K step
+    constexpr int NC = HDP / 32;              // 32-wide d chunks for QK^T
+    constexpr int NDB = HD / 16;              // 16-wide d blocks for PV
+    constexpr int KB = 64;                    // keys per tile
+    constexpr int LDKR = HDP + 8;             // K tile row pitch (elements)
+    constexpr int LDVT = KB + 4;              // V^T tile row pitch (elements): 136 B rows, conflict-free b64 reads
+    __shared__ __attribute__((aligned(16))) uint16_t sK[KB * LDKR];
+    __shared__ __attribute__((aligned(16))) uint16_t sVT[HD * LDVT];
+
+    const AttnItem it = p.items[blockIdx.x];
+    const int h = blockIdx.y, kvh = h / p.group;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 15, g = lane >> 4;
+    const int q_idx = it.q_start + wave * 16 + ql;          // this lane's query (score column)
+    const bool q_ok = q_idx < it.q_end;
+    const int q_ld = q_ok ? q_idx : it.q_end - 1;
+
+    // Q fragments (B operand): lane (query ql, k-group g) holds d = c*32 + g*8 .. +8
+    bf16x8 qf[NC];
+    {
+        const uint16_t* qp = p.Q + (long long)q_ld * p.q_tok + (long long)h * p.q_head;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int d0 = c * 32 + g * 8;
+            uint4 v = uint4{0, 0, 0, 0};
+            if (d0 < HD) v = *reinterpret_cast<const uint4*>(qp + d0);
+            qf[c] = *reinterpret_cast<bf16x8*>(&v);
+        }
+    }
+
+    f32x4 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int kv_hi = it.kv_end;
+    if (p.causal && it.q_end < kv_hi) kv_hi = it.q_end;  // keys beyond the last query are never attended
+    const uint16_t* Kb = p.K + (long long)kvh * p.k_head;
+    const uint16_t* VTb = p.VT + (long long)kvh * HD * p.vt_row;
+
+    for (int k0 = it.kv_start; k0 < kv_hi; k0 += KB) {
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage K tile: [KB][HDP] (zero beyond HD / beyond kv_hi) ----
+        constexpr int KCH = HDP / 8;  // 16-B chunks per row
+        for (int q = tid; q < KB * KCH; q += 256) {
+            const int r = q / KCH, c = q - r * KCH;
+            uint4 v = uint4{0, 0, 0, 0};
+            if (k0 + r < kv_hi && c * 8 < HD) v = *reinterpret_cast<const uint4*>(Kb + (long long)(k0 + r) * p.k_tok + c * 8);
+            *reinterpret_cast<uint4*>(&sK[r * LDKR + c * 8]) = v;
+        }
+        // ---- stage V^T tile: [HD][KB] in 8-byte pieces (kv_start and vt_row are multiples of 4) ----
+        for (int q = tid; q < HD * (KB / 4); q += 256) {
+            const int d = q / (KB / 4), c = q - d * (KB / 4);
+            uint2 v = uint2{0, 0};
+            if (k0 + c * 4 < kv_hi) v = *reinterpret_cast<const uint2*>(VTb + (long long)d * p.vt_row + k0 + c * 4);
+            *reinterpret_cast<uint2*>(&sVT[d * LDVT + c * 4]) = v;
+        }
+        __syncthreads();
+
+        // ---- S^T = K Q^T : 4 key sub-tiles of 16 ----
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[(kt * 16 + ql) * LDKR + c * 32 + g * 8]);
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c], s[kt], 0, 0, 0);
+            }
+        }
+        // s[kt][r] = score(key = k0 + kt*16 + g*4 + r, query = q_idx)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + kt * 16 + g * 4 + r;
+                const bool ok = key < kv_hi && (!p.causal || key <= q_idx);
+                const float v = ok ? s[kt][r] * p.scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        // a query with no valid key yet (only possible for padding lanes) keeps everything at zero
+        const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run - m_new);
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t w[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = half * 2 + t;
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = (s[kt][r] == -INFINITY) ? 0.f : __expf(s[kt][r] - m_new);
+                    // sum what is actually multiplied into V: the bf16-rounded probabilities
+                    e[r] = bf16_to_f32(f32_to_bf16(e[r]));
+                    psum += e[r];
+                }
+                w[t * 2 + 0] = pack_bf16x2(e[0], e[1]);
+                w[t * 2 + 1] = pack_bf16x2(e[2], e[3]);
+            }
+            uint4 pk = uint4{w[0], w[1], w[2], w[3]};
+            pf[half] = *reinterpret_cast<bf16x8*>(&pk);
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // ---- O^T = alpha * O^T + V^T P^T ----
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // a-operand k-slots: j<4 -> key (2*half)*16 + g*4 + j ; j>=4 -> key (2*half+1)*16 + g*4 + (j-4)
+                const uint16_t* vr = &sVT[(db * 16 + ql) * LDVT + half * 32 + g * 4];
+                const uint2 lo = *reinterpret_cast<const uint2*>(vr);
+                const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
+                uint4 vk = uint4{lo.x, lo.y, hi.x, hi.y};
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vk), pf[half], o[db], 0, 0, 0);
+            }
+        }
+    }
+
+    // o[db][r] = O[query q_idx][d = db*16 + g*4 + r]
+    if (q_ok) {
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        uint16_t* op = p.O + (long long)q_idx * p.o_tok + (long long)h * p.o_head;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            uint2 w;
+            w.x = pack_bf16x2(o[db][0] * inv, o[db][1] * inv);
+            w.y = pack_bf16x2(o[db][2] * inv, o[db][3] * inv);
+            *reinterpret_cast<uint2*>(op + db * 16 + g * 4) = w;
+        }
+    }
+}
+
+template <int HD>
+static int launch_attn(const AttnParams& p, hipStream_t st, double flops) {
+    FO1_LAUNCH("attn_fwd", flops, attn_fwd_kernel<HD>, dim3(p.n_items, p.Hq), dim3(256), 0, st, p);
+    return FO1_OK;
+}
+
+}  // namespace fo1
+
+extern "C" {
+
+int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_stride,
+                       const void* K, long long k_tok_stride, long long k_head_stride,
+                       const void* VT, long long vt_row_stride,
+                       void* O, long long o_tok_stride, long long o_head_stride,
+                       const int32_t* items, int n_items, int n_q_heads, int n_kv_heads, int head_dim,
+                       float scale, int causal, double flops_hint, void* stream) {
+    using namespace fo1;
+    if (n_items == 0) return FO1_OK;
+    FO1_CHECK_ARG(Q && K && VT && O && items, "attention: NULL operand");
+    FO1_CHECK_ARG(n_items > 0 && n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, "attention: bad head counts");
+    FO1_CHECK_ARG(head_dim == 32 || head_dim == 80 || head_dim == 128, "attention: head_dim %d not built (32, 80, 128)", head_dim);
+    FO1_CHECK_ARG(q_tok_stride % 8 == 0 && q_head_stride % 8 == 0 && k_tok_stride % 8 == 0 && k_head_stride % 8 == 0,
+                  "attention: Q/K strides must be multiples of 8 elements");
+    FO1_CHECK_ARG(vt_row_stride % 4 == 0 && o_tok_stride % 4 == 0 && o_head_stride % 4 == 0,
+                  "attention: V^T / O strides must be multiples of 4 elements");
+    FO1_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)VT & 7) == 0 && ((uintptr_t)O & 7) == 0,
+                  "attention: misaligned operand");
+    AttnParams p;
+    p.Q = (const uint16_t*)Q; p.q_tok = q_tok_stride; p.q_head = q_head_stride;
+    p.K = (const uint16_t*)K; p.k_tok = k_tok_stride; p.k_head = k_head_stride;
+    p.VT = (const uint16_t*)VT; p.vt_row = vt_row_stride;
+    p.O = (uint16_t*)O; p.o_tok = o_tok_stride; p.o_head = o_head_stride;
+    p.items = (const AttnItem*)items;
+    p.n_items = n_items; p.Hq = n_q_heads; p.group = n_q_heads / n_kv_heads;
+    p.scale = scale; p.causal = causal;
+    hipStream_t st = (hipStream_t)stream;
+    if (head_dim == 32) return launch_attn<32>(p, st, flops_hint);
+    if (head_dim == 80) return launch_attn<80>(p, st, flops_hint);
+    return launch_attn<128>(p, st, flops_hint);
+}
+
+}  // extern "C"

@@ -1,0 +1,366 @@
+// gemm.hip — bf16 GEMM with fused epilogues on MFMA (gfx950), the dense block of the
+// ViT / DaViT / SimpleFPN / projector / LLM-prefill stages.
+//
+//   C[M,N] = epilogue( A[M,K] · W[N,K]^T )        (W is nn.Linear's [out,in] weight)
+//
+// Replaces torch's F.linear call sites of the reference hot path
+// (modeling_qwen2_5_vl.py:79-81,103-110,151-155,176-177,633-635,731-734; modeling_davit.py:63-65,
+//  157-158,235-236; multimodal_projector/builder.py:64-71,103-110), bf16 in, fp32 accumulate.
+//
+// Tiling for wave64 / CDNA4: 256 threads = 4 waves as 2x2; each wave owns a (BM/2)x(BN/2)
+// block of 16x16 MFMA fragments (v_mfma_f32_16x16x32_bf16, K=32 per instruction).  Operands are
+// swapped (a = W rows, b = A rows) so a lane ends up with 4 consecutive output columns of one row:
+// bias / residual / store are 8-byte vector accesses.  Two staging paths:
+//   reg  : global_load_dwordx4 -> VGPR -> ds_write_b128 into a padded tile (any K % 8 == 0)
+//   glds : global_load_lds_dwordx4 straight into a double-buffered, XOR-swizzled (on the SOURCE
+//          address) lane-linear LDS image, one barrier per K tile (K % 64 == 0)
+// blockIdx -> tile mapping is XCD-aware (8 private L2s): each XCD gets a contiguous run of tiles
+// that share a W panel.
+//
+// Epilogue order mirrors the reference's op-by-op bf16 rounding:
+//   y = bf16(acc + bias); y = bf16(act(y)); y = bf16(y + residual)
+#include "common.h"
+
+namespace fo1 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+struct GemmParams {
+    const uint16_t* A;
+    const uint16_t* W;
+    const uint16_t* bias;
+    const uint16_t* res;
+    uint16_t* C;
+    float* C32;
+    int M, N, K, lda, ldw, ldc, ldr;
+    int act;
+    int tiles_m, tiles_n;
+    long long sA, sW, sC, sR;  // batch strides (elements), blockIdx.y = batch
+};
+
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+    if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ float round_bf16(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+__device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& tn) {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    tm = swz % p.tiles_m;
+    tn = swz / p.tiles_m;
+}
+
+template <int FM, int FN>
+__device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FN][FM], int m_base, int n_base, int lane,
+                                         long long offC, long long offR) {
+    const int mi = lane & 15, nq = (lane >> 4) * 4;
+    const bool vec_ok = (p.ldc % 4 == 0) && ((offC & 3) == 0) && (p.res == nullptr || ((p.ldr % 4 == 0) && ((offR & 3) == 0)));
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = m_base + fm * 16 + mi;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int n0 = n_base + fn * 16 + nq;
+            if (n0 >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[fn][fm][r];
+            const bool full = (n0 + 3 < p.N);
+            if (p.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (full || n0 + r < p.N) v[r] += bf16_to_f32(p.bias[n0 + r]);
+            }
+            if (p.C32) {  // fp32 output: no rounding, no activation/residual support needed
+                float* o = p.C32 + offC + (long long)m * p.ldc + n0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (full || n0 + r < p.N) o[r] = act_apply(v[r], p.act);
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = round_bf16(v[r]);
+            if (p.act != ACT_NONE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = round_bf16(act_apply(v[r], p.act));
+            }
+            uint16_t* o = p.C + offC + (long long)m * p.ldc + n0;
+            if (full && vec_ok) {
+                if (p.res) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + offR + (long long)m * p.ldr + n0);
+                    v[0] += bf16_lo(rv.x); v[1] += bf16_hi(rv.x);
+                    v[2] += bf16_lo(rv.y); v[3] += bf16_hi(rv.y);
+                }
+                uint2 ov;
+                ov.x = pack_bf16x2(v[0], v[1]);
+                ov.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(o) = ov;
+            } else {
+                for (int r = 0; r < 4; ++r) {
+                    if (n0 + r >= p.N) break;
+                    float t = v[r];
+                    if (p.res) t += bf16_to_f32(p.res[offR + (long long)m * p.ldr + n0 + r]);
+                    o[r] = f32_to_bf16(t);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// register-staged path
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bt_reg_kernel(const GemmParams p) {
+    constexpr int BK = 64, LDK = 72;  // 144-B rows: 16-B aligned, conflict-light for ds_read_b128
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int PA = BM * 8 / 256, PB = BN * 8 / 256;
+    __shared__ __attribute__((aligned(16))) uint16_t sA[BM * LDK];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[BN * LDK];
+
+    int tm, tn;
+    tile_coords(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long bz = blockIdx.y;
+    const uint16_t* A = p.A + bz * p.sA;
+    const uint16_t* W = p.W + bz * p.sW;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[PA], rb[PB];
+    const int nk = (p.K + BK - 1) / BK;
+
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int q = tid + i * 256, row = q >> 3, kc = q & 7;
+            int gm = m0 + row;
+            gm = gm < p.M ? gm : p.M - 1;
+            const int k = k0 + kc * 8;
+            ra[i] = (k < p.K) ? *reinterpret_cast<const uint4*>(A + (long long)gm * p.lda + k) : uint4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int q = tid + i * 256, row = q >> 3, kc = q & 7;
+            int gn = n0 + row;
+            gn = gn < p.N ? gn : p.N - 1;
+            const int k = k0 + kc * 8;
+            rb[i] = (k < p.K) ? *reinterpret_cast<const uint4*>(W + (long long)gn * p.ldw + k) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int q = tid + i * 256, row = q >> 3, kc = q & 7;
+            *reinterpret_cast<uint4*>(&sA[row * LDK + kc * 8]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int q = tid + i * 256, row = q >> 3, kc = q & 7;
+            *reinterpret_cast<uint4*>(&sB[row * LDK + kc * 8]) = rb[i];
+        }
+    };
+
+    gload(0);
+    swrite();
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) gload(kt + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 wf[FN], af[FM];
+            const int ko = ks * 32 + (lane >> 4) * 8;
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                wf[fn] = *reinterpret_cast<const bf16x8*>(&sB[(wn * WN + fn * 16 + (lane & 15)) * LDK + ko]);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm)
+                af[fm] = *reinterpret_cast<const bf16x8*>(&sA[(wm * WM + fm * 16 + (lane & 15)) * LDK + ko]);
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
+        }
+        __syncthreads();
+        if (kt + 1 < nk) {
+            swrite();
+            __syncthreads();
+        }
+    }
+    epilogue<FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz * p.sC, bz * p.sR);
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-DMA path (global_load_lds_dwordx4), K % 64 == 0
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
+    constexpr int BK = 64;
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int ROWS = BM + BN;          // rows of 128 B per stage
+    constexpr int INST = ROWS / 8;         // 1-KiB wave-instructions per stage
+    constexpr int IPW = INST / 4;          // per wave
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][ROWS][128]
+
+    int tm, tn;
+    tile_coords(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long bz = blockIdx.y;
+    const uint16_t* A = p.A + bz * p.sA;
+    const uint16_t* W = p.W + bz * p.sW;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // per-lane source row pointers for this wave's IPW instructions (k offset added per tile)
+    const int lr = lane >> 3, lc = lane & 7;
+    const uint16_t* src[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int R = (wave * IPW + i) * 8 + lr;  // tile row: [0,BM) = A rows, [BM,BM+BN) = W rows
+        const int cs = (lc ^ lr) * 8;             // XOR swizzle on the source chunk (R & 7 == lr)
+        if (R < BM) {
+            int gm = m0 + R;
+            gm = gm < p.M ? gm : p.M - 1;
+            src[i] = A + (long long)gm * p.lda + cs;
+        } else {
+            int gn = n0 + (R - BM);
+            gn = gn < p.N ? gn : p.N - 1;
+            src[i] = W + (long long)gn * p.ldw + cs;
+        }
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            char* dst = smem + buf * (ROWS * 128) + (wave * IPW + i) * 1024;  // wave-uniform
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    const int nk = p.K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // carries vmcnt(0): tile kt has landed; everyone is done with the other buffer
+        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        const char* sa = smem + (kt & 1) * (ROWS * 128);
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 wf[FN], af[FM];
+            const int kc = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+                const int R = wn * WN + fn * 16 + (lane & 15);
+                wf[fn] = *reinterpret_cast<const bf16x8*>(sb + R * 128 + ((kc ^ (R & 7)) << 4));
+            }
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int R = wm * WM + fm * 16 + (lane & 15);
+                af[fm] = *reinterpret_cast<const bf16x8*>(sa + R * 128 + ((kc ^ (R & 7)) << 4));
+            }
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
+        }
+    }
+    epilogue<FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz * p.sC, bz * p.sR);
+}
+
+static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds
+static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64
+
+template <int BM, int BN>
+static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
+    p.tiles_m = cdiv(p.M, BM);
+    p.tiles_n = cdiv(p.N, BN);
+    const dim3 grid(p.tiles_m * p.tiles_n, batch);
+    const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
+    if (glds) {
+        constexpr int smem = 2 * (BM + BN) * 128;
+        static bool attr_done = false;
+        if (!attr_done) {
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_glds_kernel<BM, BN>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr_done = true;
+        }
+        FO1_LAUNCH("gemm_bf16_glds", flops, (gemm_bt_glds_kernel<BM, BN>), grid, dim3(256), smem, st, p);
+    } else {
+        FO1_LAUNCH("gemm_bf16_reg", flops, (gemm_bt_reg_kernel<BM, BN>), grid, dim3(256), 0, st, p);
+    }
+    return FO1_OK;
+}
+
+int gemm_dispatch(GemmParams& p, int batch, hipStream_t st) {
+    bool glds = (p.K % 64 == 0);
+    if (g_gemm_variant == 1) glds = false;
+    if (g_gemm_variant == 2 && p.K % 64 != 0) return set_err(FO1_ERR_ARG, "gemm: glds variant needs K %% 64 == 0 (K=%d)", p.K);
+    int tile = g_gemm_tile;
+    if (tile == 0) {
+        const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
+        const long long t64x128 = (long long)cdiv(p.M, 64) * cdiv(p.N, 128) * batch;
+        tile = t128 >= 256 ? 1 : (t64x128 >= 256 ? 2 : 3);
+    }
+    if (tile == 1) return launch_gemm<128, 128>(p, batch, glds, st);
+    if (tile == 2) return launch_gemm<64, 128>(p, batch, glds, st);
+    return launch_gemm<64, 64>(p, batch, glds, st);
+}
+
+}  // namespace fo1
+
+extern "C" {
+
+int fo1_gemm_set_variant(int staging, int tile) {
+    if (staging < 0 || staging > 2 || tile < 0 || tile > 3) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
+    fo1::g_gemm_variant = staging;
+    fo1::g_gemm_tile = tile;
+    return FO1_OK;
+}
+
+int fo1_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                  void* C, int ldc, int M, int N, int K, int act, int out_f32, void* stream) {
+    using namespace fo1;
+    if (M == 0 || N == 0) return FO1_OK;
+    FO1_CHECK_ARG(A && W && C, "gemm: NULL operand");
+    FO1_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    FO1_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (K=%d lda=%d ldw=%d)", K, lda, ldw);
+    FO1_CHECK_ARG(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension too small");
+    FO1_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A/W must be 16-byte aligned");
+    FO1_CHECK_ARG(act >= 0 && act <= 2, "gemm: act=%d", act);
+    FO1_CHECK_ARG(!out_f32 || residual == nullptr, "gemm: fp32 output does not take a residual");
+    FO1_CHECK_ARG(residual == nullptr || ldr >= N, "gemm: ldr too small");
+    GemmParams p;
+    p.A = (const uint16_t*)A; p.W = (const uint16_t*)W; p.bias = (const uint16_t*)bias; p.res = (const uint16_t*)residual;
+    p.C = out_f32 ? nullptr : (uint16_t*)C;
+    p.C32 = out_f32 ? (float*)C : nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
+    p.sA = p.sW = p.sC = p.sR = 0;
+    return gemm_dispatch(p, 1, (hipStream_t)stream);
+}
+
+}  // extern "C"

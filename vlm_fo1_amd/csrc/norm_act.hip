@@ -1,0 +1,232 @@
+// norm_act.hip — row-wise normalisations and small elementwise ops (HBM-bound; 16-byte bf16x8
+// accesses, one wave per row, wave-shuffle reductions).  Rounding points mirror the reference's
+// op-by-op bf16 tensors:
+//   Qwen2RMSNorm        modeling_qwen2_5_vl.py:126-140  fp32 variance; x*rsqrt -> bf16; then * weight -> bf16
+//   nn.LayerNorm        modeling_davit.py:29-48,357     fp32 statistics, one rounding
+//   channel LayerNorm   simple_fpn.py:58-78             (biased variance, eps inside sqrt)
+//   SwiGLU              modeling_qwen2_5_vl.py:85-86,636  bf16(silu(g)) * u -> bf16
+#include "common.h"
+
+namespace fo1 {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+    f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    uint4 u;
+    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+    u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+    return u;
+}
+
+constexpr int kMaxChunksPerLane = 8;  // D <= 64 lanes * 8 chunks * 8 elements = 4096
+
+// mode 0: RMSNorm (w only); mode 1: LayerNorm (w, b)
+template <int MODE>
+__global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ w,
+                                                      const uint16_t* __restrict__ b, uint16_t* __restrict__ y, int ldy,
+                                                      int M, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int nchunk = D >> 3;
+    const uint16_t* xr = x + (size_t)row * ldx;
+    uint4 v[kMaxChunksPerLane];
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            v[i] = *reinterpret_cast<const uint4*>(xr + c * 8);
+            float f[8];
+            unpack8(v[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s += f[j]; ss += f[j] * f[j]; }
+        }
+    }
+    float mean = 0.f, rstd;
+    if (MODE == 0) {
+        ss = wave_sum(ss);
+        rstd = rsqrtf(ss / (float)D + eps);
+    } else {
+        s = wave_sum(s);
+        mean = s / (float)D;
+        // two-pass variance from registers (no catastrophic cancellation)
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < kMaxChunksPerLane; ++i) {
+            const int c = lane + i * 64;
+            if (c < nchunk) {
+                float f[8];
+                unpack8(v[i], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; q += d * d; }
+            }
+        }
+        q = wave_sum(q);
+        rstd = rsqrtf(q / (float)D + eps);
+    }
+    uint16_t* yr = y + (size_t)row * ldy;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            float f[8], wf[8], o[8];
+            unpack8(v[i], f);
+            unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wf);
+            if (MODE == 0) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = wf[j] * bf16_to_f32(f32_to_bf16(f[j] * rstd));
+            } else {
+                float bf[8];
+                unpack8(*reinterpret_cast<const uint4*>(b + c * 8), bf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (f[j] - mean) * rstd * wf[j] + bf[j];
+            }
+            *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+        }
+    }
+}
+
+// out[m, f] = bf16( bf16(silu(g[m,f])) * u[m,f] ),  gu = [g | u] with row stride ldgu
+__global__ __launch_bounds__(256) void swiglu_kernel(const uint16_t* __restrict__ gu, int ldgu, uint16_t* __restrict__ out,
+                                                     int ldo, int M, int F) {
+    const int chunks = F >> 3;
+    const long long total = (long long)M * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks), c = (int)(i - (long long)m * chunks);
+        float g[8], u[8], o[8];
+        unpack8(*reinterpret_cast<const uint4*>(gu + (size_t)m * ldgu + c * 8), g);
+        unpack8(*reinterpret_cast<const uint4*>(gu + (size_t)m * ldgu + F + c * 8), u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float s = bf16_to_f32(f32_to_bf16(g[j] / (1.0f + expf(-g[j]))));
+            o[j] = s * u[j];
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)m * ldo + c * 8) = pack8(o);
+    }
+}
+
+// y = act(x (+ bias)) elementwise over [M, D] rows; act 1 = erf GELU; used by the conv paths
+__global__ __launch_bounds__(256) void bias_act_kernel(const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ bias,
+                                                       uint16_t* __restrict__ y, int ldy, int M, int D, int act) {
+    const int chunks = D >> 3;
+    const long long total = (long long)M * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks), c = (int)(i - (long long)m * chunks);
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + (size_t)m * ldx + c * 8), f);
+        if (bias) {
+            float bf[8];
+            unpack8(*reinterpret_cast<const uint4*>(bias + c * 8), bf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = bf16_to_f32(f32_to_bf16(f[j] + bf[j]));
+        }
+        if (act == 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = 0.5f * f[j] * (1.0f + erff(f[j] * 0.70710678118654752440f));
+        }
+        *reinterpret_cast<uint4*>(y + (size_t)m * ldy + c * 8) = pack8(f);
+    }
+}
+
+// argmax over a bf16 row (first index among ties, like torch.argmax): one workgroup
+__global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* __restrict__ x, int n, int* __restrict__ out) {
+    __shared__ float s_v[16];
+    __shared__ int s_i[16];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = bf16_to_f32(x[i]);
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_v[wave] = best; s_i[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi)) { best = s_v[w]; bi = s_i[w]; }
+        *out = bi;
+    }
+}
+
+}  // namespace fo1
+
+extern "C" {
+
+static int rownorm_check(const void* x, const void* w, const void* y, int M, int D, int ldx, int ldy) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && w && y, "norm: NULL operand");
+    FO1_CHECK_ARG(M >= 0 && D > 0 && D % 8 == 0 && D <= 4096, "norm: D=%d must be a multiple of 8 and <= 4096", D);
+    FO1_CHECK_ARG(ldx >= D && ldy >= D && ldx % 8 == 0 && ldy % 8 == 0, "norm: bad leading dimensions");
+    return FO1_OK;
+}
+
+int fo1_rmsnorm_bf16(const void* x, int ldx, const void* weight, void* y, int ldy, int M, int D, float eps, void* stream) {
+    using namespace fo1;
+    int rc = rownorm_check(x, weight, y, M, D, ldx, ldy);
+    if (rc) return rc;
+    if (M == 0) return FO1_OK;
+    FO1_LAUNCH("rmsnorm", (double)M * D * 4.0, rownorm_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t*)x, ldx, (const uint16_t*)weight, (const uint16_t*)nullptr, (uint16_t*)y, ldy, M, D, eps);
+    return FO1_OK;
+}
+
+int fo1_layernorm_bf16(const void* x, int ldx, const void* weight, const void* bias, void* y, int ldy, int M, int D, float eps,
+                       void* stream) {
+    using namespace fo1;
+    int rc = rownorm_check(x, weight, y, M, D, ldx, ldy);
+    if (rc) return rc;
+    FO1_CHECK_ARG(bias != nullptr, "layernorm: NULL bias");
+    if (M == 0) return FO1_OK;
+    FO1_LAUNCH("layernorm", (double)M * D * 4.0, rownorm_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t*)x, ldx, (const uint16_t*)weight, (const uint16_t*)bias, (uint16_t*)y, ldy, M, D, eps);
+    return FO1_OK;
+}
+
+int fo1_swiglu_bf16(const void* gate_up, int ldgu, void* out, int ldo, int M, int F, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(gate_up && out, "swiglu: NULL operand");
+    FO1_CHECK_ARG(F > 0 && F % 8 == 0 && ldgu >= 2 * F && ldgu % 8 == 0 && ldo >= F && ldo % 8 == 0, "swiglu: bad shape F=%d", F);
+    if (M == 0) return FO1_OK;
+    const long long total = (long long)M * (F / 8);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    FO1_LAUNCH("swiglu", (double)M * F * 6.0, swiglu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t*)gate_up, ldgu, (uint16_t*)out, ldo, M, F);
+    return FO1_OK;
+}
+
+int fo1_bias_act_bf16(const void* x, int ldx, const void* bias, void* y, int ldy, int M, int D, int act, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && y, "bias_act: NULL operand");
+    FO1_CHECK_ARG(D > 0 && D % 8 == 0 && ldx >= D && ldy >= D && ldx % 8 == 0 && ldy % 8 == 0, "bias_act: bad shape D=%d", D);
+    FO1_CHECK_ARG(act == 0 || act == 1, "bias_act: act=%d", act);
+    if (M == 0) return FO1_OK;
+    const long long total = (long long)M * (D / 8);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    FO1_LAUNCH("bias_act", (double)M * D * 4.0, bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t*)x, ldx, (const uint16_t*)bias, (uint16_t*)y, ldy, M, D, act);
+    return FO1_OK;
+}
+
+int fo1_argmax_bf16(const void* x, int n, int* out, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && out && n > 0, "argmax: bad arguments");
+    FO1_LAUNCH("argmax", (double)n * 2.0, argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)x, n, out);
+    return FO1_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+// rope.hip — rotary position embedding on the fused QKV activations, and the V -> V^T copy the
+// attention kernel consumes.  HBM-bound, 16-byte accesses.
+//
+//  * LLM mRoPE (reference modeling_qwen2_5_vl.py:603-624,643-685): cos/sin arrive already
+//    section-selected ([L,128], bf16 like `cos.to(dtype=x.dtype)` :624); rotate-half form with the
+//    reference's three bf16 roundings: bf16( bf16(x*cos) + bf16(rot(x)*sin) ).
+//  * ViT 2-D RoPE (:162-169 / :219-230): fp32 math on fp32 cos/sin [S, HD/2], one rounding.
+//  * transpose: dst[c, col0 + m] = src[m, c]  (V^T rows = kv_head*HD + d; KV-cache append when col0 > 0)
+#include "common.h"
+
+namespace fo1 {
+
+__device__ __forceinline__ void unpack8r(const uint4& u, float (&f)[8]) {
+    f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+    f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+}
+__device__ __forceinline__ uint4 pack8r(const float (&f)[8]) {
+    uint4 u;
+    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+    u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+    return u;
+}
+__device__ __forceinline__ float rb(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// x: [L, ld] rows; heads [0, n_heads) of width HD starting at column col0 are rotated in place
+// (n_heads counts q heads + k heads when they are adjacent).  cos/sin: bf16 [L, HD].
+// Optionally the rotated K heads are also copied to kcache[kv_head][pos0 + t][HD].
+template <int HD>
+__global__ __launch_bounds__(256) void rope_llm_kernel(uint16_t* __restrict__ x, int ld, int col0, int n_heads,
+                                                       const uint16_t* __restrict__ cosb, const uint16_t* __restrict__ sinb, int L,
+                                                       uint16_t* __restrict__ kcache, int k_first_head, long long kc_head_stride,
+                                                       int pos0) {
+    constexpr int HC = HD / 16;  // chunk pairs per head (each thread does chunk c and its partner c + HD/16)
+    const long long total = (long long)L * n_heads * HC;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % HC);
+        const long long r = i / HC;
+        const int hd = (int)(r % n_heads), t = (int)(r / n_heads);
+        uint16_t* p = x + (long long)t * ld + col0 + hd * HD;
+        const int d0 = c * 8;
+        float a[8], b[8], ca[8], sa[8], cb[8], sb[8], oa[8], ob[8];
+        unpack8r(*reinterpret_cast<const uint4*>(p + d0), a);             // x[d],        d <  HD/2
+        unpack8r(*reinterpret_cast<const uint4*>(p + d0 + HD / 2), b);    // x[d + HD/2]
+        unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)t * HD + d0), ca);
+        unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)t * HD + d0), sa);
+        unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)t * HD + d0 + HD / 2), cb);
+        unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)t * HD + d0 + HD / 2), sb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            oa[j] = rb(a[j] * ca[j]) + rb(-b[j] * sa[j]);  // rotate_half: first half pairs with -x2
+            ob[j] = rb(b[j] * cb[j]) + rb(a[j] * sb[j]);   //              second half pairs with x1
+        }
+        const uint4 ua = pack8r(oa), ub = pack8r(ob);
+        *reinterpret_cast<uint4*>(p + d0) = ua;
+        *reinterpret_cast<uint4*>(p + d0 + HD / 2) = ub;
+        if (kcache && hd >= k_first_head) {
+            uint16_t* kc = kcache + (long long)(hd - k_first_head) * kc_head_stride + (long long)(pos0 + t) * HD;
+            *reinterpret_cast<uint4*>(kc + d0) = ua;
+            *reinterpret_cast<uint4*>(kc + d0 + HD / 2) = ub;
+        }
+    }
+}
+
+// ViT: qkv [S, ld]; q heads at col 0, k heads at col n_heads*HD; cos/sin fp32 [S, HD/2]
+template <int HD>
+__global__ __launch_bounds__(256) void rope_vit_kernel(uint16_t* __restrict__ x, int ld, int n_heads2,
+                                                       const float* __restrict__ cosf_, const float* __restrict__ sinf_, int S) {
+    constexpr int HH = HD / 2, HC = HH / 8;  // 40 -> 5 chunk pairs per head
+    const long long total = (long long)S * n_heads2 * HC;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % HC);
+        const long long r = i / HC;
+        const int hd = (int)(r % n_heads2), t = (int)(r / n_heads2);
+        uint16_t* p = x + (long long)t * ld + hd * HD;
+        const int d0 = c * 8;
+        float a[8], b[8], oa[8], ob[8];
+        unpack8r(*reinterpret_cast<const uint4*>(p + d0), a);
+        unpack8r(*reinterpret_cast<const uint4*>(p + d0 + HH), b);
+        const float* cp = cosf_ + (long long)t * HH + d0;
+        const float* sp = sinf_ + (long long)t * HH + d0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float cs = cp[j], sn = sp[j];
+            oa[j] = a[j] * cs - b[j] * sn;
+            ob[j] = b[j] * cs + a[j] * sn;
+        }
+        *reinterpret_cast<uint4*>(p + d0) = pack8r(oa);
+        *reinterpret_cast<uint4*>(p + d0 + HH) = pack8r(ob);
+    }
+}
+
+// dst[c * ldd + col0 + m] = src[m * lds + c], tile 64 rows x 64 cols through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ src, int lds_, uint16_t* __restrict__ dst,
+                                                        long long ldd, int col0, int M, int C) {
+    __shared__ uint16_t tile[64][66];
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    // load: 64 rows x 8 chunks of 8 channels
+    for (int q = tid; q < 64 * 8; q += 256) {
+        const int r = q >> 3, cc = q & 7;
+        uint4 v = uint4{0, 0, 0, 0};
+        if (m0 + r < M) v = *reinterpret_cast<const uint4*>(src + (long long)(m0 + r) * lds_ + c0 + cc * 8);
+        const uint16_t* e = reinterpret_cast<const uint16_t*>(&v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tile[r][cc * 8 + j] = e[j];
+    }
+    __syncthreads();
+    // store: 64 channels x 64 rows; thread -> (channel = q >> 2 .. , 16-row group)
+    for (int q = tid; q < 64 * 16; q += 256) {
+        const int ch = q >> 4, rg = q & 15;  // 4 rows per piece
+        const int m = m0 + rg * 4;
+        if (m >= M) continue;
+        uint16_t e[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) e[j] = tile[rg * 4 + j][ch];
+        uint16_t* d = dst + (long long)(c0 + ch) * ldd + col0 + m;
+        if (m + 3 < M && (((uintptr_t)d) & 7) == 0) {
+            uint2 w;
+            w.x = (uint32_t)e[0] | ((uint32_t)e[1] << 16);
+            w.y = (uint32_t)e[2] | ((uint32_t)e[3] << 16);
+            *reinterpret_cast<uint2*>(d) = w;
+        } else {
+            for (int j = 0; j < 4 && m + j < M; ++j) d[j] = e[j];
+        }
+    }
+}
+
+}  // namespace fo1
+
+extern "C" {
+
+int fo1_rope_llm_bf16(void* qkv, int ld, int col0, int n_heads, int head_dim, const void* cos_bf16, const void* sin_bf16, int L,
+                      void* kcache, int k_first_head, long long kcache_head_stride, int pos0, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(qkv && cos_bf16 && sin_bf16, "rope_llm: NULL operand");
+    FO1_CHECK_ARG(head_dim == 128, "rope_llm: head_dim %d not built (128)", head_dim);
+    FO1_CHECK_ARG(ld % 8 == 0 && col0 % 8 == 0 && n_heads > 0, "rope_llm: bad layout");
+    if (L == 0) return FO1_OK;
+    const long long total = (long long)L * n_heads * (head_dim / 16);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    FO1_LAUNCH("rope_llm", (double)L * n_heads * head_dim * 4.0, rope_llm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+               (uint16_t*)qkv, ld, col0, n_heads, (const uint16_t*)cos_bf16, (const uint16_t*)sin_bf16, L, (uint16_t*)kcache,
+               k_first_head, kcache_head_stride, pos0);
+    return FO1_OK;
+}
+
+int fo1_rope_vit_bf16(void* qkv, int ld, int n_heads, int head_dim, const float* cos_f32, const float* sin_f32, int S, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(qkv && cos_f32 && sin_f32, "rope_vit: NULL operand");
+    FO1_CHECK_ARG(head_dim == 80, "rope_vit: head_dim %d not built (80)", head_dim);
+    FO1_CHECK_ARG(ld % 8 == 0 && n_heads > 0, "rope_vit: bad layout");
+    if (S == 0) return FO1_OK;
+    const long long total = (long long)S * (2 * n_heads) * (head_dim / 16);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    FO1_LAUNCH("rope_vit", (double)S * 2 * n_heads * head_dim * 4.0, rope_vit_kernel<80>, dim3(grid), dim3(256), 0,
+               (hipStream_t)stream, (uint16_t*)qkv, ld, 2 * n_heads, cos_f32, sin_f32, S);
+    return FO1_OK;
+}
+
+int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst, int col0, int M, int C, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(src && dst, "transpose: NULL operand");
+    FO1_CHECK_ARG(C > 0 && C % 64 == 0 && ld_src % 8 == 0 && ld_src >= C, "transpose: C=%d must be a multiple of 64", C);
+    FO1_CHECK_ARG(col0 >= 0 && ld_dst >= col0 + M, "transpose: destination too narrow");
+    if (M == 0) return FO1_OK;
+    FO1_LAUNCH("transpose", (double)M * C * 4.0, transpose_kernel, dim3(cdiv(M, 64), C / 64), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, col0, M, C);
+    return FO1_OK;
+}
+
+}  // extern "C"

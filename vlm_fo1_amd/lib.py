@@ -10,8 +10,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfo1hip.so")
 
-c_int, c_float, c_void_p, c_size_t, c_int32 = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t,
-                                               ctypes.c_int32)
+c_int, c_float, c_void_p, c_size_t, c_int32, c_longlong = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
+                                                           ctypes.c_size_t, ctypes.c_int32, ctypes.c_longlong)
 
 
 class HfreSource(ctypes.Structure):
@@ -43,6 +43,21 @@ SIGNATURES = {
     "fo1_hfre_region_pool": (c_int, [ctypes.POINTER(HfreSource), c_int, c_void_p, c_int, c_void_p, c_float, c_float,
                                      c_int, c_int, c_float, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                      c_void_p]),
+    "fo1_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                              c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_gemm_set_variant": (c_int, [c_int, c_int]),
+    "fo1_rmsnorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "fo1_layernorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "fo1_swiglu_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fo1_bias_act_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_argmax_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "fo1_rope_llm_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                  c_longlong, c_int, c_void_p]),
+    "fo1_rope_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "fo1_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p]),
+    "fo1_attention_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,
+                                   c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_float, c_int, ctypes.c_double, c_void_p]),
 }
 
 _lib = None
@@ -59,6 +74,10 @@ def load() -> ctypes.CDLL:
             raise Fo1Error(
                 f"{LIB_PATH} not found — build it with `python -m vlm_fo1_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no fallback path.")
+        # torch (the device-memory / stream plumbing) must load ITS HIP runtime first so that
+        # libfo1hip.so binds to the same libamdhip64/libhsa instance; loading ours first puts a
+        # second runtime in the process and launches fail with "no ROCm-capable device".
+        import torch  # noqa: F401
         lib = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -1,0 +1,173 @@
+"""Thin torch-tensor front ends for the C-ABI ops in libfo1hip.so (include/fo1.h).
+
+torch is only the allocator / stream owner here: every function validates layouts, allocates the
+output with torch.empty and enqueues the HIP kernel(s) on the current stream.  No function has a
+PyTorch fallback; a missing library or a CPU tensor raises."""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import lib as _L
+
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+
+
+def _chk(t: torch.Tensor, name: str, dtype=torch.bfloat16):
+    if t.device.type != "cuda":
+        raise _L.Fo1Error(f"{name}: expected a HIP device tensor, got {t.device}")
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+
+
+def _rows(t: torch.Tensor, name: str):
+    """2-D view [M, D] with unit inner stride -> (ptr, ld, M, D)."""
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: need a 2-D row-major tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+    return t.data_ptr(), t.stride(0), t.shape[0], t.shape[1]
+
+
+def _stream():
+    return _L.current_stream_ptr()
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         act: int = ACT_NONE, out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
+    """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (nn.Linear semantics, fo1_gemm_bf16)."""
+    _chk(a, "a"); _chk(w, "w")
+    pa, lda, M, K = _rows(a, "a")
+    pw, ldw, N, K2 = _rows(w, "w")
+    if K != K2:
+        raise ValueError(f"gemm: K mismatch {K} vs {K2}")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+    po, ldc, Mo, No = _rows(out, "out")
+    assert (Mo, No) == (M, N)
+    pr, ldr = (None, 0)
+    if residual is not None:
+        _chk(residual, "residual")
+        pr, ldr, Mr, Nr = _rows(residual, "residual")
+        assert (Mr, Nr) == (M, N)
+    if bias is not None:
+        _chk(bias, "bias")
+        assert bias.numel() == N and bias.is_contiguous()
+    rc = _L.load().fo1_gemm_bf16(pa, lda, pw, ldw, bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc,
+                                 M, N, K, act, 1 if out_f32 else 0, _stream())
+    _L.check(rc, "fo1_gemm_bf16")
+    return out
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, "x"); _chk(weight, "weight")
+    px, ldx, M, D = _rows(x, "x")
+    if out is None:
+        out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    po, ldy, _, _ = _rows(out, "out")
+    _L.check(_L.load().fo1_rmsnorm_bf16(px, ldx, weight.data_ptr(), po, ldy, M, D, float(eps), _stream()), "fo1_rmsnorm_bf16")
+    return out
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, "x"); _chk(weight, "weight"); _chk(bias, "bias")
+    px, ldx, M, D = _rows(x, "x")
+    if out is None:
+        out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    po, ldy, _, _ = _rows(out, "out")
+    _L.check(_L.load().fo1_layernorm_bf16(px, ldx, weight.data_ptr(), bias.data_ptr(), po, ldy, M, D, float(eps), _stream()),
+             "fo1_layernorm_bf16")
+    return out
+
+
+def swiglu(gate_up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(gate_up, "gate_up")
+    p, ld, M, F2 = _rows(gate_up, "gate_up")
+    F = F2 // 2
+    if out is None:
+        out = torch.empty(M, F, dtype=torch.bfloat16, device=gate_up.device)
+    po, ldo, _, _ = _rows(out, "out")
+    _L.check(_L.load().fo1_swiglu_bf16(p, ld, po, ldo, M, F, _stream()), "fo1_swiglu_bf16")
+    return out
+
+
+def bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], act: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(x, "x")
+    p, ld, M, D = _rows(x, "x")
+    if out is None:
+        out = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    po, ldo, _, _ = _rows(out, "out")
+    _L.check(_L.load().fo1_bias_act_bf16(p, ld, bias.data_ptr() if bias is not None else None, po, ldo, M, D, act, _stream()),
+             "fo1_bias_act_bf16")
+    return out
+
+
+def argmax(row: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _chk(row, "row")
+    assert row.is_contiguous()
+    if out is None:
+        out = torch.empty(1, dtype=torch.int32, device=row.device)
+    _L.check(_L.load().fo1_argmax_bf16(row.data_ptr(), row.numel(), out.data_ptr(), _stream()), "fo1_argmax_bf16")
+    return out
+
+
+def rope_llm(qkv: torch.Tensor, n_heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor,
+             kcache: Optional[torch.Tensor] = None, k_first_head: int = 0, pos0: int = 0, col0: int = 0) -> None:
+    """In place on heads [0,n_heads) (q heads then k heads) of qkv [L, ld]; cos/sin bf16 [L, head_dim]."""
+    _chk(qkv, "qkv"); _chk(cos, "cos"); _chk(sin, "sin")
+    p, ld, L, _ = _rows(qkv, "qkv")
+    assert cos.shape == (L, head_dim) and cos.is_contiguous() and sin.is_contiguous()
+    kc_ptr, kc_stride = None, 0
+    if kcache is not None:
+        _chk(kcache, "kcache")
+        assert kcache.dim() == 3 and kcache.shape[2] == head_dim and kcache.stride(2) == 1 and kcache.stride(1) == head_dim
+        kc_ptr, kc_stride = kcache.data_ptr(), kcache.stride(0)
+    _L.check(_L.load().fo1_rope_llm_bf16(p, ld, col0, n_heads, head_dim, cos.data_ptr(), sin.data_ptr(), L, kc_ptr,
+                                         k_first_head, kc_stride, pos0, _stream()), "fo1_rope_llm_bf16")
+
+
+def rope_vit(qkv: torch.Tensor, n_heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor) -> None:
+    _chk(qkv, "qkv"); _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32)
+    p, ld, S, _ = _rows(qkv, "qkv")
+    assert cos.shape == (S, head_dim // 2) and cos.is_contiguous() and sin.is_contiguous()
+    _L.check(_L.load().fo1_rope_vit_bf16(p, ld, n_heads, head_dim, cos.data_ptr(), sin.data_ptr(), S, _stream()),
+             "fo1_rope_vit_bf16")
+
+
+def transpose_into(src: torch.Tensor, dst: torch.Tensor, col0: int = 0) -> None:
+    """dst[c, col0 + m] = src[m, c];  src [M, C] (C % 64 == 0), dst [C, >= col0 + M]."""
+    _chk(src, "src"); _chk(dst, "dst")
+    p, ld, M, C = _rows(src, "src")
+    pd, ldd, Cd, _ = _rows(dst, "dst")
+    assert Cd == C
+    _L.check(_L.load().fo1_transpose_bf16(p, ld, pd, ldd, col0, M, C, _stream()), "fo1_transpose_bf16")
+
+
+def make_items(segments: Sequence[Sequence[int]], device, causal: bool = False, block: int = 64) -> torch.Tensor:
+    """Host-side work list for fo1_attention_bf16: split every segment [start, end) into query blocks
+    of <= 64.  Index bookkeeping belongs on the host."""
+    rows = []
+    for s, e in segments:
+        for q0 in range(s, e, block):
+            rows.append((q0, min(q0 + block, e), s, e))
+    return torch.tensor(rows, dtype=torch.int32).reshape(-1, 4).to(device)
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_q_heads: int, n_kv_heads: int,
+              head_dim: int, scale: float, causal: bool, out: Optional[torch.Tensor] = None,
+              flops: float = 0.0) -> torch.Tensor:
+    """q: [L, >= n_q_heads*head_dim] view (heads contiguous), k: [Lk, ...] view, vt: [n_kv_heads*head_dim, ld] (V^T).
+    Returns out [L, n_q_heads*head_dim]."""
+    _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt")
+    assert items.dtype == torch.int32 and items.is_contiguous() and items.device == q.device
+    pq, ldq, L, _ = _rows(q, "q")
+    pk, ldk, _, _ = _rows(k, "k")
+    pv, ldv, _, _ = _rows(vt, "vt")
+    if out is None:
+        out = torch.empty(L, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
+    po, ldo, _, _ = _rows(out, "out")
+    rc = _L.load().fo1_attention_bf16(pq, ldq, head_dim, pk, ldk, head_dim, pv, ldv, po, ldo, head_dim,
+                                      items.data_ptr(), items.shape[0], n_q_heads, n_kv_heads, head_dim, float(scale),
+                                      1 if causal else 0, float(flops), _stream())
+    _L.check(rc, "fo1_attention_bf16")
+    return out
