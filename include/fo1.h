@@ -178,6 +178,39 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
                        const int32_t* items, int n_items, int n_q_heads, int n_kv_heads, int head_dim,
                        float scale, int causal, double flops_hint, void* stream);
 
+/* ------------------------------------------------------------------------
+ * DaViT / SimpleFPN / splice data-movement kernels on token-major bf16 maps [H*W, C] (C % 8 == 0).
+ *   fo1_dwconv3x3_bf16          y = x + bf16(dwconv3x3(x) + bias)   DepthWiseConv2d inside PreNorm(None,.)
+ *                               modeling_davit.py:72-99,29-48; weight re-laid out [9][C] (tap-major)
+ *   fo1_im2col_bf16             col[(oy,ox), (ky,kx,c)] for ConvEmbed (:102-148) and the FPN 3x3 conv
+ *                               (simple_fpn.py:165-175); the conv itself is fo1_gemm_bf16 on col
+ *   fo1_window_partition_bf16   zero-pad to multiples of ws and regroup rows window by window (:208-213,244-254)
+ *   fo1_window_reverse_add_bf16 y = shortcut + window_reverse(yw)[:H,:W]   (:216-222,272-281 + PreNorm residual)
+ *   fo1_channel_attention_bf16  ChannelAttention (:151-172) for 32-wide groups: qkv rows [q|k|v] ->
+ *                               out[n, g*32+c] = sum_c' softmax_c'(q_g^T k_g / sqrt(N))[c][c'] v[n, g*32+c']
+ *   fo1_pixel_shuffle2_bf16     ConvTranspose2d(k=2,s=2) output regrouping (simple_fpn.py:141-150):
+ *                               dst[(2y+dy, 2x+dx), co] = src[(y,x), (dy*2+dx)*Co + co]
+ *   fo1_maxpool2_bf16           nn.MaxPool2d(2,2) (simple_fpn.py:153)
+ *   fo1_nchw_to_hwc8_bf16       image [3,H,W] (bf16 or fp32) -> [H*W, 8] bf16, channels 3..7 zero
+ *   fo1_gather_rows_bf16        out[r] = table[plan[r].kind][plan[r].index]  — embed_tokens + image/region
+ *                               token splice (omchat_qwen2_5_vl.py:291-373); plan = int32[R][2]
+ * ---------------------------------------------------------------------- */
+int fo1_dwconv3x3_bf16(const void* x, const void* weight9c, const void* bias, void* y, int H, int W, int C,
+                       void* stream);
+int fo1_im2col_bf16(const void* x, void* col, int H, int W, int C, int KH, int KW, int stride, int pad,
+                    int ld_col, void* stream);
+int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, void* stream);
+int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, int H, int W, int C, int ws,
+                                void* stream);
+size_t fo1_channel_attention_workspace_bytes(int N, int C);
+int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, void* workspace,
+                               size_t workspace_bytes, void* stream);
+int fo1_pixel_shuffle2_bf16(const void* src, void* dst, int H, int W, int Co, void* stream);
+int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, void* stream);
+int fo1_nchw_to_hwc8_bf16(const void* img, int is_f32, void* out, int H, int W, void* stream);
+int fo1_gather_rows_bf16(const void* table0, int ld0, const void* table1, int ld1, const void* table2,
+                         int ld2, const int32_t* plan, void* out, int ldo, int R, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

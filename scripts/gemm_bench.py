@@ -19,6 +19,8 @@ for name, M, N, K in SHAPES:
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
     for staging in (1, 2):
         for tile in (1, 2, 3):
+            if staging == 2 and K % 64 != 0:
+                continue
             L.load().fo1_gemm_set_variant(staging, tile)
             for _ in range(3):
                 ops.gemm(a, w, out=out)

@@ -1,0 +1,105 @@
+"""GPU parity: engine LLM (vlm_fo1_amd/llm.py over the C-ABI) vs oracle/llm_oracle.py.
+
+Tolerances: hidden states after N layers — per-token cosine >= 0.9999 and
+max|delta| / max|x| <= 2^-5; last-row logits max|delta| <= 0.05 with identical argmax whenever the
+oracle's top-1 margin exceeds that bound."""
+import pytest
+import torch
+
+from oracle import llm_oracle as LO
+
+pytestmark = pytest.mark.gpu
+
+
+def check_hidden(got, ref, what):
+    got, ref = got.float().cpu(), ref.float()
+    cos = torch.nn.functional.cosine_similarity(got, ref, dim=-1)
+    rel = (got - ref).abs().max() / ref.abs().max()
+    assert cos.min() >= 0.9999, f"{what}: min cosine {cos.min():.6f} at token {int(cos.argmin())}"
+    assert rel <= 2 ** -5, f"{what}: max rel err {rel:.4g}"
+
+
+def make(cfg_kw, seed, L, grid):
+    from vlm_fo1_amd.llm import LLMConfig, QwenLLM
+    cfg = LLMConfig(**cfg_kw)
+    sd = LO.random_llm_state(cfg.num_layers, cfg.hidden_size, cfg.num_heads, cfg.num_kv_heads, cfg.head_dim,
+                             cfg.intermediate_size, cfg.vocab_size, seed=seed)
+    eng = QwenLLM(cfg, sd, "cuda")
+    return cfg, sd, eng
+
+
+def oracle_kw(cfg):
+    return dict(n_layers=cfg.num_layers, n_heads=cfg.num_heads, n_kv=cfg.num_kv_heads, head_dim=cfg.head_dim,
+                eps=cfg.rms_norm_eps, theta=cfg.rope_theta, sections=cfg.mrope_section)
+
+
+@pytest.mark.parametrize("name,cfg_kw,L,grid", [
+    ("tiny", dict(hidden_size=256, num_layers=2, num_heads=2, num_kv_heads=1, intermediate_size=512, vocab_size=512, max_seq=256), 90, (5, 7)),
+    ("true_shape_2layers", dict(num_layers=2, vocab_size=4096, max_seq=1024), 460, (17, 23)),
+])
+def test_prefill_hidden_states_and_logits(name, cfg_kw, L, grid):
+    cfg, sd, eng = make(cfg_kw, 5, L, grid)
+    g = torch.Generator().manual_seed(1)
+    n_img = grid[0] * grid[1]
+    n_before, n_after = 14, L - 14 - n_img
+    x = (torch.randn(L, cfg.hidden_size, generator=g) * 0.05).bfloat16()
+    pos, delta = LO.rope_index(n_before, grid, n_after)
+    coll = []
+    last, logits, tok = eng.prefill(x.cuda(), pos, delta, collect=coll)
+    ref_final, ref_hs = LO.llm_forward(sd, x.float(), pos, return_all=True, **oracle_kw(cfg))
+    for i, (a, b) in enumerate(zip(coll, ref_hs)):
+        check_hidden(a, b, f"{name} layer {i}")
+    check_hidden(last, ref_final[-1:], f"{name} final norm")
+    ref_logits = ref_final[-1:] @ sd["embed_tokens.weight"].float().t()
+    err = (logits.float().cpu() - ref_logits).abs().max()
+    assert err <= 0.05, f"{name}: logits max err {err:.4g}"
+    top2 = ref_logits[0].topk(2).values
+    if top2[0] - top2[1] > 0.1:
+        assert int(tok.item()) == int(ref_logits.argmax())
+
+
+def test_decode_matches_prefill_teacher_forced():
+    """K decode steps through the KV cache must reproduce what a longer prefill computes."""
+    cfg_kw = dict(hidden_size=256, num_layers=2, num_heads=2, num_kv_heads=1, intermediate_size=512, vocab_size=512, max_seq=256)
+    cfg, sd, eng = make(cfg_kw, 9, 0, None)
+    g = torch.Generator().manual_seed(2)
+    grid, n_before = (4, 6), 10
+    n_img = 24
+    base_after = 20
+    K = 5
+    ids_tail = torch.randint(0, 512, (K,), generator=g)
+    emb = sd["embed_tokens.weight"]
+    L0 = n_before + n_img + base_after
+    x0 = (torch.randn(L0, 256, generator=g) * 0.05).bfloat16()
+    pos0, delta = LO.rope_index(n_before, grid, base_after)
+    eng.prefill(x0.cuda(), pos0, delta)
+    dec_logits = []
+    for t in range(K):
+        _, lg, _ = eng.decode_step(ids_tail[t:t + 1].to(torch.int32).cuda())
+        dec_logits.append(lg.float().cpu())
+    # oracle: one long causal pass
+    xfull = torch.cat([x0.float(), emb[ids_tail].float()], 0)
+    posf, _ = LO.rope_index(n_before, grid, base_after + K)
+    ref = LO.llm_forward(sd, xfull, posf, **oracle_kw(cfg))
+    ref_logits = ref[L0:] @ emb.float().t()
+    for t in range(K):
+        err = (dec_logits[t][0] - ref_logits[t]).abs().max()
+        assert err <= 0.05, f"decode step {t}: logits max err {err:.4g}"
+
+
+def test_build_inputs_splice_and_errors():
+    from vlm_fo1_amd.llm import DEFAULT_REGION_INDEX, IMAGE_TOKEN_INDEX
+    cfg_kw = dict(hidden_size=256, num_layers=1, num_heads=2, num_kv_heads=1, intermediate_size=512, vocab_size=512, max_seq=128)
+    cfg, sd, eng = make(cfg_kw, 4, 0, None)
+    img = torch.randn(6, 256).bfloat16().cuda()
+    reg = torch.randn(2, 256).bfloat16().cuda()
+    ids = [1, 2, IMAGE_TOKEN_INDEX, 3, DEFAULT_REGION_INDEX, 4, DEFAULT_REGION_INDEX, 5]
+    emb, pos, delta = eng.build_inputs(ids, img, reg, (2, 3))
+    ref, nb, na = LO.splice(torch.tensor(ids), sd["embed_tokens.weight"], img.cpu(), reg.cpu())
+    assert torch.equal(emb.cpu(), ref)
+    pr, dr = LO.rope_index(nb, (2, 3), na)
+    assert torch.equal(pos, pr) and delta == dr
+    with pytest.raises(IndexError):
+        eng.build_inputs(ids + [DEFAULT_REGION_INDEX], img, reg, (2, 3))
+    with pytest.raises(ValueError):
+        eng.build_inputs(ids, img, reg, (3, 3))

@@ -1,0 +1,117 @@
+"""GPU parity of the DaViT / SimpleFPN / splice data-movement kernels vs plain torch on the CPU.
+Pure copies must be bit-exact; arithmetic ops follow the 1-bf16-ulp rule of test_ops_gpu.py."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_ops_gpu import close_bf16, rb
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def tm(x_nchw):  # [1,C,H,W] -> token-major [H*W, C]
+    return x_nchw[0].permute(1, 2, 0).reshape(-1, x_nchw.shape[1]).contiguous()
+
+
+def test_dwconv3x3_residual():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(0)
+    for (H, W, C) in [(13, 16, 256), (25, 32, 64), (5, 3, 8)]:
+        x = torch.randn(1, C, H, W).to(BF)
+        w = (torch.randn(C, 1, 3, 3) * 0.3).to(BF)
+        b = (torch.randn(C) * 0.1).to(BF)
+        ref = x.float() + rb(F.conv2d(x.float(), w.float(), b.float(), padding=1, groups=C))
+        w9c = w.reshape(C, 9).t().contiguous()
+        got = ops.dwconv3x3_res(tm(x).cuda(), w9c.cuda(), b.cuda(), H, W)
+        close_bf16(got, rb(tm(ref)), ulps=1.01, atol=1e-5, what=f"dwconv {H}x{W}x{C}")
+
+
+@pytest.mark.parametrize("H,W,C,K,s,p", [(20, 27, 8, 7, 4, 3), (25, 32, 64, 3, 2, 1), (12, 12, 128, 3, 1, 1)])
+def test_im2col_conv_equivalence(H, W, C, K, s, p):
+    """im2col + GEMM == conv2d with the weight re-laid out [Cout][ky][kx][Cin]."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(1)
+    Co = 64
+    x = torch.randn(1, C, H, W).to(BF)
+    w = (torch.randn(Co, C, K, K) * 0.05).to(BF)
+    b = (torch.randn(Co) * 0.1).to(BF)
+    ref = rb(F.conv2d(x.float(), w.float(), b.float(), stride=s, padding=p))
+    col, Ho, Wo = ops.im2col(tm(x).cuda(), H, W, K, K, s, p)
+    assert (Ho, Wo) == tuple(ref.shape[2:])
+    unf = F.unfold(x.float(), K, padding=p, stride=s)[0].t().reshape(Ho * Wo, C, K * K).permute(0, 2, 1).reshape(Ho * Wo, -1)
+    assert torch.equal(col.float().cpu(), unf), "im2col is a pure copy: must be bit exact"
+    wg = w.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
+    got = ops.gemm(col, wg.cuda(), b.cuda())
+    err = (got.float().cpu() - tm(ref)).abs().max()
+    assert err < 2e-2 * tm(ref).abs().max() + 1e-3, f"conv via im2col+gemm: max err {err:.4g}"
+
+
+def test_window_partition_reverse():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(2)
+    for (H, W, C, ws) in [(25, 32, 64, 12), (24, 36, 32, 12), (5, 7, 8, 12)]:
+        x = torch.randn(H, W, C).to(BF)
+        pad_b, pad_r = (ws - H % ws) % ws, (ws - W % ws) % ws
+        xp = F.pad(x, (0, 0, 0, pad_r, 0, pad_b))
+        Hp, Wp = xp.shape[:2]
+        ref = xp.view(Hp // ws, ws, Wp // ws, ws, C).permute(0, 2, 1, 3, 4).reshape(-1, C)
+        got = ops.window_partition(x.reshape(-1, C).cuda(), H, W, ws)
+        assert torch.equal(got.cpu(), ref)
+        yw = torch.randn_like(ref)
+        y = yw.view(Hp // ws, Wp // ws, ws, ws, C).permute(0, 2, 1, 3, 4).reshape(Hp, Wp, C)[:H, :W]
+        refo = rb(x.float() + y.float())
+        goto = ops.window_reverse_add(yw.cuda(), x.reshape(-1, C).cuda(), H, W, ws)
+        assert torch.equal(goto.float().cpu(), refo.reshape(-1, C))
+
+
+def test_channel_attention():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(3)
+    for (N, C) in [(300, 64), (1000, 256), (37, 32)]:
+        G = C // 32
+        qkv = torch.randn(N, 3 * C).to(BF)
+        x = qkv.float().reshape(1, N, 3, G, 32).permute(2, 0, 3, 1, 4)
+        q, k, v = x[0], x[1], x[2]
+        att = rb(rb(rb(q * (float(N) ** -0.5)).transpose(-1, -2) @ k).softmax(-1))
+        ref = rb((att @ v.transpose(-1, -2)).transpose(-1, -2)).transpose(1, 2).reshape(N, C)
+        got = ops.channel_attention(qkv.cuda(), C)
+        err = (got.float().cpu() - ref).abs().max()
+        assert err < 0.03 * ref.abs().max() + 2e-3, f"channel attention N={N} C={C}: max err {err:.4g} (scale {ref.abs().max():.3g})"
+
+
+def test_pixel_shuffle_maxpool_nchw_gather():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(4)
+    H, W, Co, Ci = 6, 9, 16, 24
+    x = torch.randn(1, Ci, H, W).to(BF)
+    wt = (torch.randn(Ci, Co, 2, 2) * 0.1).to(BF)
+    b = (torch.randn(Co) * 0.1).to(BF)
+    ref = rb(F.conv_transpose2d(x.float(), wt.float(), b.float(), stride=2))
+    wg = wt.permute(2, 3, 1, 0).reshape(4 * Co, Ci).contiguous()  # rows (dy, dx, co)
+    Cip = 64  # K must be a multiple of 8; pad to a friendly size
+    a = torch.zeros(H * W, Cip, dtype=BF); a[:, :Ci] = tm(x)
+    wgp = torch.zeros(4 * Co, Cip, dtype=BF); wgp[:, :Ci] = wg
+    y4 = ops.gemm(a.cuda(), wgp.cuda(), b.repeat(4).cuda())
+    got = ops.pixel_shuffle2(y4, H, W, Co)
+    err = (got.float().cpu() - tm(ref)).abs().max()
+    assert err < 2e-2, f"convT via gemm+pixel_shuffle: {err:.4g}"
+    # maxpool
+    xm = torch.randn(1, 32, 7, 10).to(BF)
+    refm = F.max_pool2d(xm.float(), 2, 2)
+    gotm = ops.maxpool2(tm(xm).cuda(), 7, 10)
+    assert torch.equal(gotm.float().cpu(), tm(refm))
+    # nchw -> hwc8
+    img = torch.randn(3, 11, 13)
+    g8 = ops.nchw_to_hwc8(img.cuda())
+    assert torch.equal(g8[:, :3].cpu(), img.to(BF).permute(1, 2, 0).reshape(-1, 3)) and g8[:, 3:].abs().sum() == 0
+    g8b = ops.nchw_to_hwc8(img.to(BF).cuda())
+    assert torch.equal(g8b.cpu(), g8.cpu())
+    # gather rows
+    t0, t1, t2 = torch.randn(50, 64).to(BF), torch.randn(7, 64).to(BF), torch.randn(3, 64).to(BF)
+    plan = torch.tensor([[0, 49], [1, 0], [1, 6], [2, 2], [0, 0], [2, 0]], dtype=torch.int32)
+    gotg = ops.gather_rows(plan.cuda(), 64, t0.cuda(), t1.cuda(), t2.cuda())
+    refg = torch.stack([t0[49], t1[0], t1[6], t2[2], t0[0], t2[0]])
+    assert torch.equal(gotg.cpu(), refg)

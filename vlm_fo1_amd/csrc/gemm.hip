@@ -322,9 +322,11 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st) {
     if (g_gemm_variant == 2 && p.K % 64 != 0) return set_err(FO1_ERR_ARG, "gemm: glds variant needs K %% 64 == 0 (K=%d)", p.K);
     int tile = g_gemm_tile;
     if (tile == 0) {
+        // measured on MI355X (profiles/r01_gemm_bench.log): 64x128 wins once it yields >= ~2 workgroups
+        // per CU, 128x128 only for very large grids, 64x64 for everything skinny
         const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
         const long long t64x128 = (long long)cdiv(p.M, 64) * cdiv(p.N, 128) * batch;
-        tile = t128 >= 256 ? 1 : (t64x128 >= 256 ? 2 : 3);
+        tile = t128 >= 2048 ? 1 : (t64x128 >= 512 ? 2 : 3);
     }
     if (tile == 1) return launch_gemm<128, 128>(p, batch, glds, st);
     if (tile == 2) return launch_gemm<64, 128>(p, batch, glds, st);

@@ -1,0 +1,380 @@
+// vision_ops.hip — data-movement and small-reduction kernels of the DaViT / SimpleFPN / splice
+// stages (all HBM-bound, 16-byte bf16x8 accesses on token-major [H*W, C] maps):
+//   dwconv3x3      DepthWiseConv2d + PreNorm(None) residual          modeling_davit.py:72-99,29-48
+//   im2col         ConvEmbed / 3x3 FPN conv as implicit-GEMM staging modeling_davit.py:102-148, simple_fpn.py:141-176
+//   window part./reverse  WindowAttention pad+partition / merge+crop  modeling_davit.py:208-222,244-254,272-281
+//   channel attention     ChannelAttention                            modeling_davit.py:151-172
+//   pixel shuffle   ConvTranspose2d(k=2,s=2) epilogue                 simple_fpn.py:141-150
+//   maxpool2x2      nn.MaxPool2d(2,2)                                 simple_fpn.py:153
+//   nchw_to_hwc8    image [3,H,W] -> token-major with 8 channels (conv-embed staging)
+//   gather_rows     embedding lookup + image/region token splice      omchat_qwen2_5_vl.py:291-373
+#include "common.h"
+
+namespace fo1 {
+
+__device__ __forceinline__ void un8(const uint4& u, float (&f)[8]) {
+    f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+    f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+}
+__device__ __forceinline__ uint4 pk8(const float (&f)[8]) {
+    uint4 u;
+    u.x = pack_bf16x2(f[0], f[1]); u.y = pack_bf16x2(f[2], f[3]);
+    u.z = pack_bf16x2(f[4], f[5]); u.w = pack_bf16x2(f[6], f[7]);
+    return u;
+}
+__device__ __forceinline__ float rbf(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+
+// y[h,w,c] = x[h,w,c] + bf16( sum_{ky,kx} x[h+ky-1, w+kx-1, c] * wt[(ky*3+kx)*C + c] + bias[c] )
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                        const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int H, int W, int C) {
+    const int chunks = C >> 3;
+    const long long total = (long long)H * W * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const int pix = (int)(i / chunks);
+        const int h = pix / W, w = pix - h * W;
+        float acc[8], ctr[8];
+        un8(*reinterpret_cast<const uint4*>(bias + c * 8), acc);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int hh = h + ky - 1;
+            if (hh < 0 || hh >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ww = w + kx - 1;
+                if (ww < 0 || ww >= W) continue;
+                float xv[8], wv[8];
+                un8(*reinterpret_cast<const uint4*>(x + ((long long)hh * W + ww) * C + c * 8), xv);
+                un8(*reinterpret_cast<const uint4*>(wt + (ky * 3 + kx) * C + c * 8), wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
+                if (ky == 1 && kx == 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ctr[j] = xv[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = ctr[j] + rbf(acc[j]);
+        *reinterpret_cast<uint4*>(y + (long long)pix * C + c * 8) = pk8(acc);
+    }
+}
+
+// col[(oy*Wo+ox), (ky*KW+kx)*C + c] = x[oy*s-p+ky, ox*s-p+kx, c]  (0 outside); row stride ldc >= KH*KW*C
+__global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ col, int H, int W, int C,
+                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int ldc) {
+    const int chunks = C >> 3;
+    const int kk = KH * KW;
+    const long long total = (long long)Ho * Wo * kk * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        long long r = i / chunks;
+        const int k = (int)(r % kk);
+        const int opix = (int)(r / kk);
+        const int oy = opix / Wo, ox = opix - oy * Wo;
+        const int ky = k / KW, kx = k - ky * KW;
+        const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+        uint4 v = uint4{0, 0, 0, 0};
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(x + ((long long)iy * W + ix) * C + c * 8);
+        *reinterpret_cast<uint4*>(col + (long long)opix * ldc + k * C + c * 8) = v;
+    }
+}
+
+// xw[(wy*nWx + wx)*ws*ws + iy*ws + ix, c] = x[wy*ws+iy, wx*ws+ix, c]  (0 when outside HxW)
+__global__ __launch_bounds__(256) void window_partition_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ xw, int H, int W,
+                                                               int C, int ws, int nWy, int nWx) {
+    const int chunks = C >> 3;
+    const long long total = (long long)nWy * nWx * ws * ws * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const int row = (int)(i / chunks);
+        const int win = row / (ws * ws), in = row - win * ws * ws;
+        const int wy = win / nWx, wx = win - wy * nWx;
+        const int iy = in / ws, ix = in - iy * ws;
+        const int h = wy * ws + iy, w = wx * ws + ix;
+        uint4 v = uint4{0, 0, 0, 0};
+        if (h < H && w < W) v = *reinterpret_cast<const uint4*>(x + ((long long)h * W + w) * C + c * 8);
+        *reinterpret_cast<uint4*>(xw + (long long)row * C + c * 8) = v;
+    }
+}
+
+// y[h,w,c] = shortcut[h,w,c] + yw[window row of (h,w), c]
+__global__ __launch_bounds__(256) void window_reverse_add_kernel(const uint16_t* __restrict__ yw, const uint16_t* __restrict__ shortcut,
+                                                                 uint16_t* __restrict__ y, int H, int W, int C, int ws, int nWx) {
+    const int chunks = C >> 3;
+    const long long total = (long long)H * W * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const int pix = (int)(i / chunks);
+        const int h = pix / W, w = pix - h * W;
+        const int row = ((h / ws) * nWx + (w / ws)) * ws * ws + (h % ws) * ws + (w % ws);
+        float a[8], b[8];
+        un8(*reinterpret_cast<const uint4*>(yw + (long long)row * C + c * 8), a);
+        un8(*reinterpret_cast<const uint4*>(shortcut + (long long)pix * C + c * 8), b);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] += b[j];
+        *reinterpret_cast<uint4*>(y + (long long)pix * C + c * 8) = pk8(a);
+    }
+}
+
+// ---- channel attention (group width 32) -------------------------------------------------------
+// qkv: [N, 3C] rows = [q | k | v].  Phase 1: partial Gram matrices over token chunks.
+//   part[chunk][g][c][c'] = sum_{n in chunk} q[n, g*32+c] * k[n, g*32+c']      (fp32)
+constexpr int kCaTok = 256;  // tokens per chunk
+__global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, float* __restrict__ part) {
+    __shared__ float sq[64][33];
+    __shared__ float sk[64][33];
+    const int g = blockIdx.y, chunk = blockIdx.x, G = gridDim.y;
+    const int tid = threadIdx.x;
+    const int ci = tid >> 4, cj = tid & 15;  // thread owns the 2x2 block (2ci..2ci+1, 2cj..2cj+1)
+    float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
+    const int n_begin = chunk * kCaTok, n_end = min(N, n_begin + kCaTok);
+    for (int n0 = n_begin; n0 < n_end; n0 += 64) {
+        __syncthreads();
+        // 64 tokens x 32 channels of q and k: 64 x 4 chunks each -> 512 16-byte loads, 2 per thread
+        for (int t = tid; t < 512; t += 256) {
+            const int which = t >> 8, r = (t & 255) >> 2, cc = t & 3;
+            float f[8];
+            if (n0 + r < n_end) {
+                un8(*reinterpret_cast<const uint4*>(qkv + (long long)(n0 + r) * ld + which * C + g * 32 + cc * 8), f);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) f[j] = 0.f;
+            }
+            float(*dst)[33] = which ? sk : sq;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) dst[r][cc * 8 + j] = f[j];
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            const float q0 = sq[r][2 * ci], q1 = sq[r][2 * ci + 1];
+            const float k0 = sk[r][2 * cj], k1 = sk[r][2 * cj + 1];
+            a00 = fmaf(q0, k0, a00); a01 = fmaf(q0, k1, a01);
+            a10 = fmaf(q1, k0, a10); a11 = fmaf(q1, k1, a11);
+        }
+    }
+    float* o = part + (((long long)chunk * G + g) * 32) * 32;
+    o[(2 * ci) * 32 + 2 * cj] = a00; o[(2 * ci) * 32 + 2 * cj + 1] = a01;
+    o[(2 * ci + 1) * 32 + 2 * cj] = a10; o[(2 * ci + 1) * 32 + 2 * cj + 1] = a11;
+}
+
+// Phase 2: A[g][c][:] = softmax_c'( bf16( scale * sum_chunks part ) ) rounded to bf16 (stored fp32)
+__global__ __launch_bounds__(64) void chattn_softmax_kernel(const float* __restrict__ part, int n_chunks, int G, float scale,
+                                                            float* __restrict__ A) {
+    const int g = blockIdx.x, lane = threadIdx.x;  // 64 lanes: 2 rows at a time
+    for (int r0 = 0; r0 < 32; r0 += 2) {
+        const int r = r0 + (lane >> 5), c = lane & 31;
+        float s = 0.f;
+        for (int k = 0; k < n_chunks; ++k) s += part[(((long long)k * G + g) * 32 + r) * 32 + c];
+        s = rbf(s * scale);
+        float m = s;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        float e = expf(s - m), sum = e;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+        A[((long long)g * 32 + r) * 32 + c] = rbf(e / sum);
+    }
+}
+
+// Phase 3: out[n, g*32 + c] = bf16( sum_c' A[g][c][c'] * v[n, g*32 + c'] )
+__global__ __launch_bounds__(256) void chattn_apply_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, const float* __restrict__ A,
+                                                           uint16_t* __restrict__ out, int ldo) {
+    __shared__ float sA[32][33];
+    __shared__ float sv[8][33];
+    const int g = blockIdx.y, tid = threadIdx.x;
+    for (int t = tid; t < 1024; t += 256) sA[t >> 5][t & 31] = A[(long long)g * 1024 + t];
+    const int tl = tid >> 5, c = tid & 31;  // 8 tokens per pass, 32 output channels
+    for (int n0 = blockIdx.x * 8; n0 < N; n0 += gridDim.x * 8) {
+        __syncthreads();
+        const int n = n0 + tl;
+        sv[tl][c] = (n < N) ? bf16_to_f32(qkv[(long long)n * ld + 2 * C + g * 32 + c]) : 0.f;
+        __syncthreads();
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) acc = fmaf(sA[c][k], sv[tl][k], acc);
+        if (n < N) out[(long long)n * ldo + g * 32 + c] = f32_to_bf16(acc);
+    }
+}
+
+// dst[(2y+dy)*2W + 2x+dx, co] = src[y*W + x, (dy*2+dx)*Co + co]
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int H, int W, int Co) {
+    const int chunks = Co >> 3;
+    const long long total = (long long)H * W * 4 * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        long long r = i / chunks;
+        const int q = (int)(r & 3);
+        const int pix = (int)(r >> 2);
+        const int y = pix / W, x = pix - y * W;
+        const int dy = q >> 1, dx = q & 1;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (long long)pix * 4 * Co + q * Co + c * 8);
+        *reinterpret_cast<uint4*>(dst + ((long long)(2 * y + dy) * (2 * W) + 2 * x + dx) * Co + c * 8) = v;
+    }
+}
+
+// y[oy, ox, c] = max over the 2x2 window (floor mode: Ho = H/2, Wo = W/2)
+__global__ __launch_bounds__(256) void maxpool2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2, chunks = C >> 3;
+    const long long total = (long long)Ho * Wo * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const int pix = (int)(i / chunks);
+        const int oy = pix / Wo, ox = pix - oy * Wo;
+        float m[8], t[8];
+        un8(*reinterpret_cast<const uint4*>(x + ((long long)(2 * oy) * W + 2 * ox) * C + c * 8), m);
+#pragma unroll
+        for (int q = 1; q < 4; ++q) {
+            un8(*reinterpret_cast<const uint4*>(x + ((long long)(2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C + c * 8), t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], t[j]);
+        }
+        *reinterpret_cast<uint4*>(y + (long long)pix * C + c * 8) = pk8(m);
+    }
+}
+
+// img: [3, H, W] (bf16 or fp32) -> out [H*W, 8] bf16 (channels 3..7 zero)
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_hwc8_kernel(const T* __restrict__ img, uint16_t* __restrict__ out, int H, int W) {
+    const long long total = (long long)H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if constexpr (sizeof(T) == 2) f[c] = bf16_to_f32(((const uint16_t*)img)[c * total + i]);
+            else f[c] = ((const float*)img)[c * total + i];
+        }
+        *reinterpret_cast<uint4*>(out + i * 8) = pk8(f);
+    }
+}
+
+// out[r, :] = src_table[kind[r]][index[r], :]   (kind 0: embedding table, 1: image tokens, 2: region tokens)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint16_t* __restrict__ t0, const uint16_t* __restrict__ t1,
+                                                          const uint16_t* __restrict__ t2, int ld0, int ld1, int ld2,
+                                                          const int* __restrict__ plan, uint16_t* __restrict__ out, int ldo, int R, int D) {
+    const int chunks = D >> 3;
+    const long long total = (long long)R * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const int r = (int)(i / chunks);
+        const int kind = plan[2 * r], idx = plan[2 * r + 1];
+        const uint16_t* src = kind == 0 ? t0 + (long long)idx * ld0 : (kind == 1 ? t1 + (long long)idx * ld1 : t2 + (long long)idx * ld2);
+        *reinterpret_cast<uint4*>(out + (long long)r * ldo + c * 8) = *reinterpret_cast<const uint4*>(src + c * 8);
+    }
+}
+
+static inline int grid_for(long long total) {
+    long long g = (total + 255) / 256;
+    return (int)(g < 4096 ? (g > 0 ? g : 1) : 4096);
+}
+
+}  // namespace fo1
+
+extern "C" {
+
+int fo1_dwconv3x3_bf16(const void* x, const void* weight9c, const void* bias, void* y, int H, int W, int C, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && weight9c && bias && y && x != y, "dwconv: NULL operand or in-place call");
+    FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0, "dwconv: bad shape %dx%dx%d", H, W, C);
+    FO1_LAUNCH("dwconv3x3", (double)H * W * C * 4.0, dwconv3x3_kernel, dim3(grid_for((long long)H * W * (C / 8))), dim3(256), 0,
+               (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, H, W, C);
+    return FO1_OK;
+}
+
+int fo1_im2col_bf16(const void* x, void* col, int H, int W, int C, int KH, int KW, int stride, int pad, int ld_col, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && col, "im2col: NULL operand");
+    FO1_CHECK_ARG(C > 0 && C % 8 == 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "im2col: bad parameters");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
+    FO1_CHECK_ARG(Ho > 0 && Wo > 0 && ld_col >= KH * KW * C && ld_col % 8 == 0, "im2col: bad output shape");
+    FO1_LAUNCH("im2col", (double)Ho * Wo * KH * KW * C * 4.0, im2col_kernel, dim3(grid_for((long long)Ho * Wo * KH * KW * (C / 8))),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)col, H, W, C, KH, KW, stride, pad, Ho, Wo, ld_col);
+    return FO1_OK;
+}
+
+int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && xw && C % 8 == 0 && ws > 0, "window_partition: bad arguments");
+    const int nWy = cdiv(H, ws), nWx = cdiv(W, ws);
+    FO1_LAUNCH("window_partition", (double)nWy * nWx * ws * ws * C * 4.0, window_partition_kernel,
+               dim3(grid_for((long long)nWy * nWx * ws * ws * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+               (uint16_t*)xw, H, W, C, ws, nWy, nWx);
+    return FO1_OK;
+}
+
+int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, int H, int W, int C, int ws, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(yw && shortcut && y && C % 8 == 0 && ws > 0, "window_reverse: bad arguments");
+    FO1_LAUNCH("window_reverse_add", (double)H * W * C * 6.0, window_reverse_add_kernel, dim3(grid_for((long long)H * W * (C / 8))),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)yw, (const uint16_t*)shortcut, (uint16_t*)y, H, W, C, ws, cdiv(W, ws));
+    return FO1_OK;
+}
+
+size_t fo1_channel_attention_workspace_bytes(int N, int C) {
+    const int G = C / 32, chunks = fo1::cdiv(N, fo1::kCaTok);
+    return ((size_t)chunks * G * 1024 + (size_t)G * 1024) * sizeof(float);
+}
+
+int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, void* workspace, size_t workspace_bytes,
+                               void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(qkv && out && workspace, "channel_attention: NULL operand");
+    FO1_CHECK_ARG(N > 0 && C > 0 && C % 32 == 0 && ld >= 3 * C && ld % 8 == 0 && ldo >= C, "channel_attention: bad shape N=%d C=%d", N, C);
+    if (workspace_bytes < fo1_channel_attention_workspace_bytes(N, C))
+        return set_err(FO1_ERR_WORKSPACE, "channel_attention: workspace too small");
+    const int G = C / 32, chunks = cdiv(N, kCaTok);
+    float* part = (float*)workspace;
+    float* A = part + (size_t)chunks * G * 1024;
+    hipStream_t st = (hipStream_t)stream;
+    FO1_LAUNCH("chattn_gram", (double)N * C * 4.0, chattn_gram_kernel, dim3(chunks, G), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part);
+    // reference: q * N^-0.5 (modeling_davit.py:165)
+    FO1_LAUNCH("chattn_softmax", (double)chunks * G * 4096.0, chattn_softmax_kernel, dim3(G), dim3(64), 0, st, (const float*)part, chunks, G,
+               1.0f / sqrtf((float)N), A);
+    int gx = cdiv(N, 8);
+    if (gx > 512) gx = 512;
+    FO1_LAUNCH("chattn_apply", (double)N * C * 4.0, chattn_apply_kernel, dim3(gx, G), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C,
+               (const float*)A, (uint16_t*)out, ldo);
+    return FO1_OK;
+}
+
+int fo1_pixel_shuffle2_bf16(const void* src, void* dst, int H, int W, int Co, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(src && dst && Co > 0 && Co % 8 == 0, "pixel_shuffle: bad arguments");
+    FO1_LAUNCH("pixel_shuffle2", (double)H * W * 4 * Co * 4.0, pixel_shuffle2_kernel, dim3(grid_for((long long)H * W * 4 * (Co / 8))),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst, H, W, Co);
+    return FO1_OK;
+}
+
+int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && y && C % 8 == 0 && H >= 2 && W >= 2, "maxpool: bad arguments");
+    FO1_LAUNCH("maxpool2", (double)H * W * C * 2.5, maxpool2_kernel, dim3(grid_for((long long)(H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
+               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, H, W, C);
+    return FO1_OK;
+}
+
+int fo1_nchw_to_hwc8_bf16(const void* img, int is_f32, void* out, int H, int W, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(img && out && H > 0 && W > 0, "nchw_to_hwc8: bad arguments");
+    if (is_f32)
+        FO1_LAUNCH("nchw_to_hwc8", (double)H * W * 28.0, nchw_to_hwc8_kernel<float>, dim3(grid_for((long long)H * W)), dim3(256), 0,
+                   (hipStream_t)stream, (const float*)img, (uint16_t*)out, H, W);
+    else
+        FO1_LAUNCH("nchw_to_hwc8", (double)H * W * 22.0, nchw_to_hwc8_kernel<uint16_t>, dim3(grid_for((long long)H * W)), dim3(256), 0,
+                   (hipStream_t)stream, (const uint16_t*)img, (uint16_t*)out, H, W);
+    return FO1_OK;
+}
+
+int fo1_gather_rows_bf16(const void* table0, int ld0, const void* table1, int ld1, const void* table2, int ld2, const int32_t* plan,
+                         void* out, int ldo, int R, int D, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(plan && out && D > 0 && D % 8 == 0 && ldo >= D, "gather_rows: bad arguments");
+    if (R == 0) return FO1_OK;
+    FO1_LAUNCH("gather_rows", (double)R * D * 4.0, gather_rows_kernel, dim3(grid_for((long long)R * (D / 8))), dim3(256), 0,
+               (hipStream_t)stream, (const uint16_t*)table0, (const uint16_t*)table1, (const uint16_t*)table2, ld0, ld1, ld2, plan,
+               (uint16_t*)out, ldo, R, D);
+    return FO1_OK;
+}
+
+}  // extern "C"

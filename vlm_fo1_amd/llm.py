@@ -1,0 +1,190 @@
+"""Qwen2.5-VL language-model half of the hot path on the MI355X engine.
+
+Host code only orchestrates: every tensor op is a libfo1hip.so kernel (vlm_fo1_amd/ops.py).  Index
+bookkeeping the reference does with device syncs (`get_rope_index`, sentinel search,
+modeling_qwen2_5_vl.py:1546-1701, omchat_qwen2_5_vl.py:318-319) is done on the host from the
+sentinel positions and the image grid before any launch.
+
+Weights: fused at load time — q/k/v -> one [2560, 2048] GEMM, gate/up -> one [22016, 2048] GEMM
+(rows [gate; up]) — checkpoint key names as in the reference state dict.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+IMAGE_TOKEN_INDEX = -200
+DEFAULT_REGION_INDEX = -300
+
+
+@dataclass
+class LLMConfig:
+    hidden_size: int = 2048
+    num_layers: int = 36
+    num_heads: int = 16
+    num_kv_heads: int = 2
+    head_dim: int = 128
+    intermediate_size: int = 11008
+    vocab_size: int = 151936
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    mrope_section: Tuple[int, int, int] = (16, 24, 24)
+    max_seq: int = 8192
+
+
+def rope_index_host(n_before: int, grid_hw_merged: Tuple[int, int], n_after: int):
+    """[3, L] int64 position ids for <text><image gh x gw><text> and the rope delta
+    (reference get_rope_index :1630-1697, single image, t = 1)."""
+    gh, gw = grid_hw_merged
+    pre = torch.arange(n_before).view(1, -1).expand(3, -1)
+    t_idx = torch.zeros(gh * gw, dtype=torch.long)
+    h_idx = torch.arange(gh).view(-1, 1).expand(-1, gw).flatten()
+    w_idx = torch.arange(gw).view(1, -1).expand(gh, -1).flatten()
+    img = torch.stack([t_idx, h_idx, w_idx]) + n_before
+    nxt = int(img.max()) + 1 if gh * gw > 0 else n_before
+    post = torch.arange(n_after).view(1, -1).expand(3, -1) + nxt
+    pos = torch.cat([pre, img, post], dim=1)
+    return pos, int(pos.max()) + 1 - pos.shape[1]
+
+
+def mrope_tables(pos: torch.Tensor, head_dim: int, theta: float, sections: Sequence[int]):
+    """pos [3, L] (host) -> cos, sin [L, head_dim] bf16 (host): fp32 tables, section select, cast
+    (reference :609-624, :675-681)."""
+    inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
+    fr = pos.float()[:, :, None] * inv[None, None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    cos, sin = emb.cos(), emb.sin()
+    sec = list(sections) * 2
+    cs = torch.cat([m[i % 3] for i, m in enumerate(cos.split(sec, dim=-1))], dim=-1)
+    sn = torch.cat([m[i % 3] for i, m in enumerate(sin.split(sec, dim=-1))], dim=-1)
+    return cs.to(torch.bfloat16).contiguous(), sn.to(torch.bfloat16).contiguous()
+
+
+class QwenLLM:
+    def __init__(self, cfg: LLMConfig, state: Dict[str, torch.Tensor], device, lm_head: Optional[torch.Tensor] = None):
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        bf = torch.bfloat16
+
+        def dv(t):
+            return t.to(device=self.dev, dtype=bf).contiguous()
+
+        self.embed = dv(state["embed_tokens.weight"])
+        self.lm_head = dv(lm_head) if lm_head is not None else self.embed  # tied embeddings
+        self.norm = dv(state["norm.weight"])
+        self.layers = []
+        for i in range(cfg.num_layers):
+            p = f"layers.{i}."
+            a = p + "self_attn."
+            self.layers.append(dict(
+                ln1=dv(state[p + "input_layernorm.weight"]),
+                ln2=dv(state[p + "post_attention_layernorm.weight"]),
+                wqkv=dv(torch.cat([state[a + "q_proj.weight"], state[a + "k_proj.weight"], state[a + "v_proj.weight"]], 0)),
+                bqkv=dv(torch.cat([state[a + "q_proj.bias"], state[a + "k_proj.bias"], state[a + "v_proj.bias"]], 0)),
+                wo=dv(state[a + "o_proj.weight"]),
+                wgu=dv(torch.cat([state[p + "mlp.gate_proj.weight"], state[p + "mlp.up_proj.weight"]], 0)),
+                wdown=dv(state[p + "mlp.down_proj.weight"]),
+            ))
+        c = cfg
+        # KV cache: K [layer][kv_head][pos][head_dim]; V^T [layer][kv_head*head_dim][pos] (zeroed: the
+        # attention kernel may read up to 3 finite columns past kv_end)
+        self.kcache = torch.zeros(c.num_layers, c.num_kv_heads, c.max_seq, c.head_dim, dtype=bf, device=self.dev)
+        self.vtcache = torch.zeros(c.num_layers, c.num_kv_heads * c.head_dim, c.max_seq, dtype=bf, device=self.dev)
+        self.kv_len = 0
+        self.rope_delta = 0
+
+    # ---- splice ------------------------------------------------------------------------------
+    def build_inputs(self, input_ids: Sequence[int], image_tokens: torch.Tensor, region_tokens: Optional[torch.Tensor],
+                     grid_hw_merged: Tuple[int, int]):
+        """Sentinel ids -> (embeds [L', d] on device, pos [3, L'] host).  One image per prompt
+        (what prepare_inputs produces)."""
+        plan: List[Tuple[int, int]] = []
+        ri = 0
+        n_before = None
+        n_img = image_tokens.shape[0]
+        for t in input_ids:
+            if t == IMAGE_TOKEN_INDEX:
+                if n_before is not None:
+                    raise ValueError("more than one <image> sentinel in the prompt")
+                n_before = len(plan)
+                plan.extend((1, j) for j in range(n_img))
+            elif t == DEFAULT_REGION_INDEX:
+                if region_tokens is None or ri >= region_tokens.shape[0]:
+                    # same failure the reference raises at omchat_qwen2_5_vl.py:361
+                    raise IndexError("prompt has more <regionfeat> placeholders than region features")
+                plan.append((2, ri))
+                ri += 1
+            else:
+                plan.append((0, int(t)))
+        if n_before is None:
+            raise ValueError("prompt has no <image> sentinel")
+        if grid_hw_merged[0] * grid_hw_merged[1] != n_img:
+            # reference modeling_qwen2_5_vl.py:1797-1800
+            raise ValueError(f"Image features and image tokens do not match: tokens: {grid_hw_merged[0] * grid_hw_merged[1]}, features {n_img}")
+        plan_t = torch.tensor(plan, dtype=torch.int32).to(self.dev)
+        emb = ops.gather_rows(plan_t, self.cfg.hidden_size, self.embed, image_tokens, region_tokens)
+        n_after = len(plan) - n_before - n_img
+        pos, delta = rope_index_host(n_before, grid_hw_merged, n_after)
+        return emb, pos, delta
+
+    # ---- transformer -------------------------------------------------------------------------
+    def _forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, collect: Optional[list] = None):
+        c = self.cfg
+        L = x.shape[0]
+        H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
+        kv_end = pos0 + L
+        if kv_end > c.max_seq:
+            raise ValueError(f"sequence {kv_end} exceeds the KV cache ({c.max_seq})")
+        items = torch.tensor([[q0, min(q0 + 64, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, 64)], dtype=torch.int32).to(self.dev)
+        scale = 1.0 / math.sqrt(HD)
+        flops = 4.0 * H * HD * (L * (pos0 + (L + 1) / 2.0))
+        for li, w in enumerate(self.layers):
+            h = ops.rmsnorm(x, w["ln1"], c.rms_norm_eps)
+            qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
+            ops.rope_llm(qkv, H + KV, HD, cos, sin, kcache=self.kcache[li], k_first_head=H, pos0=pos0)
+            ops.transpose_into(qkv[:, (H + KV) * HD:], self.vtcache[li], col0=pos0)
+            att = ops.attention_strided(qkv[:, :H * HD], q_row0=pos0, k=self.kcache[li], vt=self.vtcache[li], items=items,
+                                        n_q_heads=H, n_kv_heads=KV, head_dim=HD, scale=scale, causal=True, flops=flops)
+            x = ops.gemm(att, w["wo"], residual=x)
+            h = ops.rmsnorm(x, w["ln2"], c.rms_norm_eps)
+            gu = ops.gemm(h, w["wgu"])
+            a = ops.swiglu(gu)
+            x = ops.gemm(a, w["wdown"], residual=x)
+            if collect is not None:
+                collect.append(x)
+        return x
+
+    def prefill(self, embeds: torch.Tensor, pos: torch.Tensor, rope_delta: int = 0, collect: Optional[list] = None):
+        """embeds [L, d] bf16 device, pos [3, L] host -> (final-norm last hidden [1, d], logits [1, V], next id tensor)."""
+        c = self.cfg
+        cos, sin = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
+        cos, sin = cos.to(self.dev), sin.to(self.dev)
+        x = self._forward(embeds, cos, sin, 0, collect)
+        self.kv_len = embeds.shape[0]
+        self.rope_delta = rope_delta
+        return self._head(x)
+
+    def _head(self, x: torch.Tensor):
+        c = self.cfg
+        last = ops.rmsnorm(x[-1:], self.norm, c.rms_norm_eps)
+        logits = ops.gemm(last, self.lm_head)  # last row only: output-identical to the reference's all-row lm_head
+        tok = ops.argmax(logits[0])
+        return last, logits, tok
+
+    def decode_step(self, token_id: torch.Tensor):
+        """One greedy step: token_id int32 [1] on device -> (logits, next id).  Position =
+        cache_position + rope_delta on all three axes (reference :1848-1860)."""
+        c = self.cfg
+        plan = torch.stack([torch.zeros_like(token_id), token_id]).t().contiguous().to(torch.int32)
+        x = ops.gather_rows(plan, c.hidden_size, self.embed)
+        p = self.kv_len + self.rope_delta
+        pos = torch.full((3, 1), p, dtype=torch.long)
+        cos, sin = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
+        x = self._forward(x, cos.to(self.dev), sin.to(self.dev), self.kv_len)
+        self.kv_len += 1
+        return self._head(x)

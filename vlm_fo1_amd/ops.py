@@ -171,3 +171,133 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.T
                                       1 if causal else 0, float(flops), _stream())
     _L.check(rc, "fo1_attention_bf16")
     return out
+
+
+# ---- DaViT / SimpleFPN / splice helpers -----------------------------------------------------
+def dwconv3x3_res(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """x [H*W, C] token-major -> x + dwconv3x3(x) (+bias); w9c is the [9, C] tap-major weight."""
+    _chk(x, "x"); _chk(w9c, "w9c"); _chk(bias, "bias")
+    assert x.is_contiguous() and x.shape[0] == H * W and w9c.shape == (9, x.shape[1]) and w9c.is_contiguous()
+    y = torch.empty_like(x)
+    _L.check(_L.load().fo1_dwconv3x3_bf16(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), y.data_ptr(), H, W, x.shape[1], _stream()),
+             "fo1_dwconv3x3_bf16")
+    return y
+
+
+def im2col(x: torch.Tensor, H: int, W: int, KH: int, KW: int, stride: int, pad: int, ld: Optional[int] = None):
+    """x [H*W, C] -> (col [Ho*Wo, ld>=KH*KW*C] (pad columns zero), Ho, Wo)."""
+    _chk(x, "x")
+    assert x.is_contiguous() and x.shape[0] == H * W
+    C = x.shape[1]
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    K = KH * KW * C
+    ld = ld or K
+    col = torch.zeros(Ho * Wo, ld, dtype=torch.bfloat16, device=x.device) if ld != K else \
+        torch.empty(Ho * Wo, ld, dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_im2col_bf16(x.data_ptr(), col.data_ptr(), H, W, C, KH, KW, stride, pad, ld, _stream()), "fo1_im2col_bf16")
+    return col, Ho, Wo
+
+
+def window_partition(x: torch.Tensor, H: int, W: int, ws: int) -> torch.Tensor:
+    _chk(x, "x")
+    assert x.is_contiguous() and x.shape[0] == H * W
+    nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
+    xw = torch.empty(nW * ws * ws, x.shape[1], dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_window_partition_bf16(x.data_ptr(), xw.data_ptr(), H, W, x.shape[1], ws, _stream()),
+             "fo1_window_partition_bf16")
+    return xw
+
+
+def window_reverse_add(yw: torch.Tensor, shortcut: torch.Tensor, H: int, W: int, ws: int) -> torch.Tensor:
+    _chk(yw, "yw"); _chk(shortcut, "shortcut")
+    assert yw.is_contiguous() and shortcut.is_contiguous()
+    y = torch.empty_like(shortcut)
+    _L.check(_L.load().fo1_window_reverse_add_bf16(yw.data_ptr(), shortcut.data_ptr(), y.data_ptr(), H, W, shortcut.shape[1], ws,
+                                                   _stream()), "fo1_window_reverse_add_bf16")
+    return y
+
+
+_ca_ws = {}
+
+
+def channel_attention(qkv: torch.Tensor, C: int) -> torch.Tensor:
+    _chk(qkv, "qkv")
+    p, ld, N, _ = _rows(qkv, "qkv")
+    need = _L.load().fo1_channel_attention_workspace_bytes(N, C)
+    key = qkv.device
+    ws = _ca_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
+        _ca_ws[key] = ws
+    out = torch.empty(N, C, dtype=torch.bfloat16, device=qkv.device)
+    _L.check(_L.load().fo1_channel_attention_bf16(p, ld, N, C, out.data_ptr(), C, ws.data_ptr(), ws.numel(), _stream()),
+             "fo1_channel_attention_bf16")
+    return out
+
+
+def pixel_shuffle2(src: torch.Tensor, H: int, W: int, Co: int) -> torch.Tensor:
+    _chk(src, "src")
+    assert src.is_contiguous() and src.shape == (H * W, 4 * Co)
+    dst = torch.empty(4 * H * W, Co, dtype=torch.bfloat16, device=src.device)
+    _L.check(_L.load().fo1_pixel_shuffle2_bf16(src.data_ptr(), dst.data_ptr(), H, W, Co, _stream()), "fo1_pixel_shuffle2_bf16")
+    return dst
+
+
+def maxpool2(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    _chk(x, "x")
+    assert x.is_contiguous() and x.shape[0] == H * W
+    y = torch.empty((H // 2) * (W // 2), x.shape[1], dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_maxpool2_bf16(x.data_ptr(), y.data_ptr(), H, W, x.shape[1], _stream()), "fo1_maxpool2_bf16")
+    return y
+
+
+def nchw_to_hwc8(img: torch.Tensor) -> torch.Tensor:
+    """img [3,H,W] bf16/fp32 -> [H*W, 8] bf16."""
+    if img.device.type != "cuda":
+        raise _L.Fo1Error("nchw_to_hwc8: expected a HIP device tensor")
+    assert img.dim() == 3 and img.shape[0] == 3 and img.is_contiguous() and img.dtype in (torch.bfloat16, torch.float32)
+    H, W = img.shape[1:]
+    out = torch.empty(H * W, 8, dtype=torch.bfloat16, device=img.device)
+    _L.check(_L.load().fo1_nchw_to_hwc8_bf16(img.data_ptr(), 1 if img.dtype == torch.float32 else 0, out.data_ptr(), H, W, _stream()),
+             "fo1_nchw_to_hwc8_bf16")
+    return out
+
+
+def gather_rows(plan: torch.Tensor, D: int, t0: torch.Tensor, t1: Optional[torch.Tensor] = None, t2: Optional[torch.Tensor] = None):
+    """plan int32 [R,2] (kind, index) on device."""
+    assert plan.dtype == torch.int32 and plan.is_contiguous()
+    R = plan.shape[0]
+    out = torch.empty(R, D, dtype=torch.bfloat16, device=plan.device)
+
+    def pl(t):
+        if t is None:
+            return None, 0
+        _chk(t, "table")
+        assert t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == D
+        return t.data_ptr(), t.stride(0)
+
+    p0, l0 = pl(t0); p1, l1 = pl(t1); p2, l2 = pl(t2)
+    _L.check(_L.load().fo1_gather_rows_bf16(p0, l0, p1, l1, p2, l2, plan.data_ptr(), out.data_ptr(), D, R, D, _stream()),
+             "fo1_gather_rows_bf16")
+    return out
+
+
+def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_q_heads: int,
+                      n_kv_heads: int, head_dim: int, scale: float, causal: bool, flops: float = 0.0,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Attention against a KV cache.  q [Lq, n_q_heads*head_dim] holds absolute positions
+    q_row0 .. q_row0+Lq (the items index absolute positions); k is the cache [n_kv, Lmax, head_dim],
+    vt the transposed V cache [n_kv*head_dim, Lmax]."""
+    _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt")
+    assert items.dtype == torch.int32 and items.is_contiguous()
+    pq, ldq, Lq, _ = _rows(q, "q")
+    assert k.dim() == 3 and k.stride(2) == 1
+    pv, ldv, _, _ = _rows(vt, "vt")
+    if out is None:
+        out = torch.empty(Lq, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
+    po, ldo, _, _ = _rows(out, "out")
+    rc = _L.load().fo1_attention_bf16(pq - q_row0 * ldq * 2, ldq, head_dim, k.data_ptr(), k.stride(1), k.stride(0), pv, ldv,
+                                      po - q_row0 * ldo * 2, ldo, head_dim, items.data_ptr(), items.shape[0], n_q_heads,
+                                      n_kv_heads, head_dim, float(scale), 1 if causal else 0, float(flops), _stream())
+    _L.check(rc, "fo1_attention_bf16")
+    return out
