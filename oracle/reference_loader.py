@@ -63,3 +63,37 @@ def vendored_davit():
         _cache["davit"] = _load("ref_davit_modeling", os.path.join(_DAVIT_DIR, "modeling_davit.py"))
         _cache["davit_cfg"] = _load("ref_davit_configs", os.path.join(_DAVIT_DIR, "configs.py"))
     return _cache["davit"], _cache["davit_cfg"]
+
+
+def vendored_vit_encoder():
+    """qwen2_5_vl_encoder.py (custom_forward + VisionFeaturesGather) executed in place, with stubs for
+    the two imports that need torchvision (ToPILImage, the HF image processor)."""
+    if "vit_enc" not in _cache:
+        qwen = vendored_qwen()
+        saved = {k: sys.modules.get(k) for k in (
+            "torchvision", "torchvision.transforms", "vlm_fo1", "vlm_fo1.model", "vlm_fo1.model.multimodal_encoder",
+            "vlm_fo1.model.multimodal_encoder.qwen2_5_vl", "vlm_fo1.model.multimodal_encoder.qwen2_5_vl.modeling_qwen2_5_vl",
+            "transformers.models.qwen2_vl.image_processing_qwen2_vl")}
+        try:
+            tv = types.ModuleType("torchvision"); tvt = types.ModuleType("torchvision.transforms")
+            tvt.ToPILImage = object
+            tv.transforms = tvt
+            sys.modules["torchvision"] = tv
+            sys.modules["torchvision.transforms"] = tvt
+            ip = types.ModuleType("transformers.models.qwen2_vl.image_processing_qwen2_vl")
+            ip.Qwen2VLImageProcessor = object
+            sys.modules["transformers.models.qwen2_vl.image_processing_qwen2_vl"] = ip
+            for pkg in ("vlm_fo1", "vlm_fo1.model", "vlm_fo1.model.multimodal_encoder", "vlm_fo1.model.multimodal_encoder.qwen2_5_vl"):
+                m = types.ModuleType(pkg)
+                m.__path__ = []
+                sys.modules[pkg] = m
+            sys.modules["vlm_fo1.model.multimodal_encoder.qwen2_5_vl.modeling_qwen2_5_vl"] = qwen
+            _cache["vit_enc"] = _load("ref_qwen_vit_encoder", os.path.join(
+                REFERENCE_ROOT, "vlm_fo1", "model", "multimodal_encoder", "qwen2_5_vl_encoder.py"))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    sys.modules.pop(k, None)
+                else:
+                    sys.modules[k] = v
+    return _cache["vit_enc"]

@@ -1,0 +1,139 @@
+"""DaViT-L auxiliary tower on the MI355X engine.
+
+Mirrors `DavitVisionTower.forward` -> `DaViT.forward_features`
+(davit_aux_encoder.py:54-69, davit/modeling_davit.py:478-506) and returns the four stage outputs as
+token-major [H_i*W_i, C_i] bf16 maps — the memory layout the reference's NCHW *views* already have
+(modeling_davit.py:493) and the one the HFRE kernel reads.
+
+Every conv is a GEMM: the 7x7/s4 and 3x3/s2 ConvEmbeds run as im2col + fo1_gemm_bf16 with the weights
+re-laid out [Cout][ky][kx][Cin] at load time; depthwise 3x3 convs, window partition/reverse and the
+channel attention are dedicated HBM-bound kernels (vision_ops.hip)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+
+from . import ops
+
+DAVIT_LARGE = dict(depths=(1, 1, 9, 1), dims=(256, 512, 1024, 2048), heads=(8, 16, 32, 64), groups=(8, 16, 32, 64),
+                   patch_size=(7, 3, 3, 3), patch_stride=(4, 2, 2, 2), patch_padding=(3, 1, 1, 1),
+                   patch_prenorm=(False, True, True, True), window=12)  # davit/configs.py:70-136
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class DaViT:
+    def __init__(self, state: Dict[str, torch.Tensor], device, cfg=DAVIT_LARGE):
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        bf = torch.bfloat16
+
+        def dv(t):
+            return t.to(device=self.dev, dtype=bf).contiguous()
+
+        self.convs = []
+        prev = 3
+        for i, c in enumerate(cfg["dims"]):
+            w = state[f"convs.{i}.proj.weight"]  # [Cout, Cin, k, k]
+            k = cfg["patch_size"][i]
+            cin_p = 8 if i == 0 else prev           # stage 0: image staged as [H*W, 8] (channels 3..7 zero)
+            wp = torch.zeros(c, k, k, cin_p, dtype=w.dtype)
+            wp[..., :w.shape[1]] = w.permute(0, 2, 3, 1)
+            K = k * k * cin_p
+            Kp = _round_up(K, 64)
+            wg = torch.zeros(c, Kp, dtype=w.dtype)
+            wg[:, :K] = wp.reshape(c, K)
+            self.convs.append(dict(w=dv(wg), b=dv(state[f"convs.{i}.proj.bias"]), K=K, Kp=Kp,
+                                   nw=dv(state[f"convs.{i}.norm.weight"]), nb=dv(state[f"convs.{i}.norm.bias"])))
+            prev = c
+        self.blocks = []
+        for i, c in enumerate(cfg["dims"]):
+            stage = []
+            for j in range(cfg["depths"][i]):
+                blk = {}
+                for name, attn in (("spatial_block", "window_attn"), ("channel_block", "channel_attn")):
+                    p = f"blocks.{i}.{j}.{name}."
+                    d = {}
+                    for cv in ("conv1", "conv2"):
+                        d[cv + "_w"] = dv(state[p + cv + ".fn.dw.weight"].reshape(c, 9).t())  # tap-major [9, C]
+                        d[cv + "_b"] = dv(state[p + cv + ".fn.dw.bias"])
+                    d["an_w"], d["an_b"] = dv(state[p + attn + ".norm.weight"]), dv(state[p + attn + ".norm.bias"])
+                    d["qkv_w"], d["qkv_b"] = dv(state[p + attn + ".fn.qkv.weight"]), dv(state[p + attn + ".fn.qkv.bias"])
+                    d["proj_w"], d["proj_b"] = dv(state[p + attn + ".fn.proj.weight"]), dv(state[p + attn + ".fn.proj.bias"])
+                    d["fn_w"], d["fn_b"] = dv(state[p + "ffn.norm.weight"]), dv(state[p + "ffn.norm.bias"])
+                    d["fc1_w"], d["fc1_b"] = dv(state[p + "ffn.fn.net.fc1.weight"]), dv(state[p + "ffn.fn.net.fc1.bias"])
+                    d["fc2_w"], d["fc2_b"] = dv(state[p + "ffn.fn.net.fc2.weight"]), dv(state[p + "ffn.fn.net.fc2.bias"])
+                    blk[name] = d
+                stage.append(blk)
+            self.blocks.append(stage)
+        self._items: Dict[int, torch.Tensor] = {}
+        self._vt: Dict[Tuple[int, int], torch.Tensor] = {}
+
+    def _window_items(self, n_windows: int, ws2: int):
+        if n_windows not in self._items:
+            self._items[n_windows] = ops.make_items([(i * ws2, (i + 1) * ws2) for i in range(n_windows)], self.dev)
+        return self._items[n_windows]
+
+    def _ffn(self, x, d):
+        h = ops.layernorm(x, d["fn_w"], d["fn_b"], 1e-5)
+        h = ops.gemm(h, d["fc1_w"], d["fc1_b"], act=ops.ACT_GELU)
+        return ops.gemm(h, d["fc2_w"], d["fc2_b"], residual=x)
+
+    def _spatial(self, x, H, W, C, heads, d):
+        ws = self.cfg["window"]
+        x = ops.dwconv3x3_res(x, d["conv1_w"], d["conv1_b"], H, W)
+        h = ops.layernorm(x, d["an_w"], d["an_b"], 1e-5)
+        hw = ops.window_partition(h, H, W, ws)          # zero-padded AFTER the norm, like the reference (:248-251)
+        qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
+        n = hw.shape[0]
+        key = (C, n)
+        if key not in self._vt:
+            self._vt[key] = torch.zeros(C, _round_up(n, 64), dtype=torch.bfloat16, device=self.dev)
+        vt = self._vt[key]
+        ops.transpose_into(qkv[:, 2 * C:], vt, 0)
+        hd = C // heads
+        items = self._window_items(n // (ws * ws), ws * ws)
+        att = ops.attention(qkv[:, :C], qkv[:, C:2 * C], vt, items, heads, heads, hd, float(hd) ** -0.5, False,
+                            flops=4.0 * C * n * ws * ws)
+        y = ops.gemm(att, d["proj_w"], d["proj_b"])
+        x = ops.window_reverse_add(y, x, H, W, ws)
+        x = ops.dwconv3x3_res(x, d["conv2_w"], d["conv2_b"], H, W)
+        return self._ffn(x, d)
+
+    def _channel(self, x, H, W, C, d):
+        x = ops.dwconv3x3_res(x, d["conv1_w"], d["conv1_b"], H, W)
+        h = ops.layernorm(x, d["an_w"], d["an_b"], 1e-5)
+        qkv = ops.gemm(h, d["qkv_w"], d["qkv_b"])
+        a = ops.channel_attention(qkv, C)
+        x = ops.gemm(a, d["proj_w"], d["proj_b"], residual=x)
+        x = ops.dwconv3x3_res(x, d["conv2_w"], d["conv2_b"], H, W)
+        return self._ffn(x, d)
+
+    def forward(self, img: torch.Tensor):
+        """img [3,H,W] or [1,3,H,W] (device, bf16/fp32, CLIP-normalised).  Returns
+        ([4 token-major maps [H_i*W_i, C_i] bf16], [(H_i, W_i)])."""
+        cfg = self.cfg
+        if img.dim() == 4:
+            img = img[0]
+        H, W = img.shape[1:]
+        x = ops.nchw_to_hwc8(img.contiguous())
+        outs, sizes = [], []
+        for i, C in enumerate(cfg["dims"]):
+            cv = self.convs[i]
+            k, s, p = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
+            if i > 0 and cfg["patch_prenorm"][i]:
+                x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
+            col, H, W = ops.im2col(x, H, W, k, k, s, p, ld=cv["Kp"])
+            x = ops.gemm(col, cv["w"], cv["b"])
+            if i == 0 or not cfg["patch_prenorm"][i]:
+                x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
+            for blk in self.blocks[i]:
+                x = self._spatial(x, H, W, C, cfg["heads"][i], blk["spatial_block"])
+                x = self._channel(x, H, W, C, blk["channel_block"])
+            outs.append(x)
+            sizes.append((H, W))
+        return outs, sizes

@@ -1,0 +1,72 @@
+"""ViTDet SimpleFPN on the MI355X engine.
+
+Mirrors `SimpleFP.forward` (simple_fpn.py:100-216) as instantiated by the HFRE
+(hybrid_finegrained_region_encoder.py:175, strides [3.5, 7, 14, 28] at :245) on the token-major
+last ViT map.  ConvTranspose2d(k=2,s=2) = GEMM [n, Cin] x [4*Cout, Cin]^T + pixel shuffle;
+1x1 conv = GEMM; 3x3 conv = im2col + GEMM; the channel LayerNorm (eps 1e-6, biased variance) is the
+row LayerNorm on token-major maps; MaxPool2d(2,2) is its own kernel."""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import ops
+
+
+class SimpleFPN:
+    STAGES = ("simfp_1", "simfp_2", "simfp_3", "simfp_4")
+
+    def __init__(self, state: Dict[str, torch.Tensor], device):
+        self.dev = torch.device(device)
+        bf = torch.bfloat16
+
+        def dv(t):
+            return t.to(device=self.dev, dtype=bf).contiguous()
+
+        def convT(w, b):  # [Cin, Cout, 2, 2] -> GEMM weight rows (dy, dx, co), bias tiled x4
+            cin, cout = w.shape[:2]
+            return dv(w.permute(2, 3, 1, 0).reshape(4 * cout, cin)), dv(b.repeat(4)), cout
+
+        def conv1(w):
+            return dv(w.reshape(w.shape[0], w.shape[1]))
+
+        def conv3(w):  # [Cout, Cin, 3, 3] -> [Cout, (ky,kx,cin)]
+            return dv(w.permute(0, 2, 3, 1).reshape(w.shape[0], -1))
+
+        s = state
+        self.t1a = convT(s["simfp_1.0.weight"], s["simfp_1.0.bias"])
+        self.t1_ln = (dv(s["simfp_1.1.weight"]), dv(s["simfp_1.1.bias"]))
+        self.t1b = convT(s["simfp_1.3.weight"], s["simfp_1.3.bias"])
+        self.t2 = convT(s["simfp_2.0.weight"], s["simfp_2.0.bias"])
+        self.heads = []
+        for name, a, b in (("simfp_1", "4.", "5."), ("simfp_2", "1.", "2."), ("simfp_3", "0.", "1."), ("simfp_4", "1.", "2.")):
+            self.heads.append(dict(
+                w1=conv1(s[f"{name}.{a}weight"]), n1=(dv(s[f"{name}.{a}norm.weight"]), dv(s[f"{name}.{a}norm.bias"])),
+                w3=conv3(s[f"{name}.{b}weight"]), n3=(dv(s[f"{name}.{b}norm.weight"]), dv(s[f"{name}.{b}norm.bias"]))))
+
+    def _up(self, x, H, W, t):
+        w, b, cout = t
+        return ops.pixel_shuffle2(ops.gemm(x, w, b), H, W, cout), 2 * H, 2 * W
+
+    def _head(self, x, H, W, h):
+        y = ops.gemm(x, h["w1"])
+        y = ops.layernorm(y, h["n1"][0], h["n1"][1], 1e-6)
+        col, _, _ = ops.im2col(y, H, W, 3, 3, 1, 1)
+        y = ops.gemm(col, h["w3"])
+        return ops.layernorm(y, h["n3"][0], h["n3"][1], 1e-6)
+
+    def forward(self, x: torch.Tensor, H: int, W: int) -> Tuple[List[torch.Tensor], List[Tuple[int, int]]]:
+        """x [H*W, 1280] token-major bf16 -> 4 token-major maps [.., 512] at (4H,4W), (2H,2W), (H,W), (H/2,W/2)."""
+        outs, sizes = [], []
+        y, h1, w1 = self._up(x, H, W, self.t1a)
+        y = ops.layernorm(y, self.t1_ln[0], self.t1_ln[1], 1e-6)
+        y = ops.bias_act(y, None, 1)
+        y, h1, w1 = self._up(y, h1, w1, self.t1b)
+        outs.append(self._head(y, h1, w1, self.heads[0])); sizes.append((h1, w1))
+        y, h2, w2 = self._up(x, H, W, self.t2)
+        outs.append(self._head(y, h2, w2, self.heads[1])); sizes.append((h2, w2))
+        outs.append(self._head(x, H, W, self.heads[2])); sizes.append((H, W))
+        y = ops.maxpool2(x, H, W)
+        outs.append(self._head(y, H // 2, W // 2, self.heads[3])); sizes.append((H // 2, W // 2))
+        return outs, sizes

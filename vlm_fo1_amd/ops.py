@@ -263,23 +263,32 @@ def nchw_to_hwc8(img: torch.Tensor) -> torch.Tensor:
     return out
 
 
-def gather_rows(plan: torch.Tensor, D: int, t0: torch.Tensor, t1: Optional[torch.Tensor] = None, t2: Optional[torch.Tensor] = None):
-    """plan int32 [R,2] (kind, index) on device."""
+def gather_rows(plan: torch.Tensor, D: int, t0: torch.Tensor, t1: Optional[torch.Tensor] = None, t2: Optional[torch.Tensor] = None,
+                out: Optional[torch.Tensor] = None):
+    """out[r, :D] = table[plan[r,0]][plan[r,1], :D];  plan int32 [R,2] (kind, index) on device.  `out` may be
+    wider than D (its other columns are left untouched)."""
     assert plan.dtype == torch.int32 and plan.is_contiguous()
     R = plan.shape[0]
-    out = torch.empty(R, D, dtype=torch.bfloat16, device=plan.device)
+    if out is None:
+        out = torch.empty(R, D, dtype=torch.bfloat16, device=plan.device)
+    po, ldo, Ro, Do = _rows(out, "out")
+    assert Ro == R and Do >= D
 
     def pl(t):
         if t is None:
             return None, 0
         _chk(t, "table")
-        assert t.dim() == 2 and t.stride(1) == 1 and t.shape[1] == D
+        assert t.dim() == 2 and t.stride(1) == 1 and t.shape[1] >= D
         return t.data_ptr(), t.stride(0)
 
     p0, l0 = pl(t0); p1, l1 = pl(t1); p2, l2 = pl(t2)
-    _L.check(_L.load().fo1_gather_rows_bf16(p0, l0, p1, l1, p2, l2, plan.data_ptr(), out.data_ptr(), D, R, D, _stream()),
+    _L.check(_L.load().fo1_gather_rows_bf16(p0, l0, p1, l1, p2, l2, plan.data_ptr(), po, ldo, R, D, _stream()),
              "fo1_gather_rows_bf16")
     return out
+
+
+def gather_rows_into(plan: torch.Tensor, D: int, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    return gather_rows(plan, D, table, out=out)
 
 
 def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_q_heads: int,

@@ -1,0 +1,181 @@
+"""Qwen2.5-VL vision tower on the MI355X engine.
+
+Mirrors the reference's `Qwen2_5_VlVisionTower.forward` + monkey-patched `custom_forward` +
+`VisionFeaturesGather.extract_multi_level_features` (qwen2_5_vl_encoder.py:37-158,228-257): patch
+embed as a GEMM, window re-order, 32 blocks (windowed / full varlen attention), merger, and the
+hidden states captured after the full-attention blocks — written straight into RASTER order
+token-major maps [gh*gw, 1280] (the un-window/un-merge shuffle of :57-70 is folded into one row
+gather), which is exactly the layout the HFRE kernel reads.
+
+All index bookkeeping the reference does on device with .item()/.tolist() syncs (get_window_index,
+rot_pos_emb, cu_seqlens; modeling_qwen2_5_vl.py:436-504) is computed once per grid shape on the host
+and cached.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+@dataclass
+class ViTConfig:
+    depth: int = 32
+    hidden_size: int = 1280
+    num_heads: int = 16
+    intermediate_size: int = 3420
+    out_hidden_size: int = 2048
+    patch_size: int = 14
+    spatial_merge_size: int = 2
+    temporal_patch_size: int = 2
+    in_channels: int = 3
+    window_size: int = 112
+    fullatt_block_indexes: Tuple[int, ...] = (7, 15, 23, 31)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class GridPlan:
+    """Host-side index plan for one patch grid (gh, gw)."""
+
+    def __init__(self, gh: int, gw: int, cfg: ViTConfig, device):
+        m = cfg.spatial_merge_size
+        unit = m * m
+        S = gh * gw
+        vmw = cfg.window_size // m // cfg.patch_size
+        lh, lw = gh // m, gw // m
+        index = torch.arange(lh * lw).reshape(1, lh, lw)
+        pad_h, pad_w = vmw - lh % vmw, vmw - lw % vmw
+        nwh, nww = (lh + pad_h) // vmw, (lw + pad_w) // vmw
+        ip = F.pad(index, (0, pad_w, 0, pad_h), "constant", -100)
+        ip = ip.reshape(1, nwh, vmw, nww, vmw).permute(0, 1, 3, 2, 4).reshape(1, nwh * nww, vmw, vmw)
+        seqlens = (ip != -100).sum([2, 3]).reshape(-1)
+        widx = ip.reshape(-1)
+        widx = widx[widx != -100]                       # window order -> merge-unit index
+        cu = [0] + (seqlens.cumsum(0) * unit).tolist()
+        cu = sorted(set(cu))
+        # row permutation: window-order row r reads merge-block-order row perm[r]
+        perm = (widx[:, None] * unit + torch.arange(unit)[None, :]).reshape(-1)
+        inv_unit = torch.argsort(widx)                   # merge unit -> position in window order
+        # raster (y, x) -> merge-block row -> window-order row
+        ys, xs = torch.meshgrid(torch.arange(gh), torch.arange(gw), indexing="ij")
+        mrow = ((ys // m) * lw + (xs // m)) * unit + (ys % m) * m + (xs % m)
+        raster_to_win = (inv_unit[mrow // unit] * unit + mrow % unit).reshape(-1)
+        # 2-D rope angles in merge-block order, then window order
+        hd = cfg.hidden_size // cfg.num_heads
+        dim = hd // 2
+        inv = 1.0 / (10000.0 ** (torch.arange(0, dim, 2, dtype=torch.float) / dim))
+        full = torch.outer(torch.arange(max(gh, gw), dtype=torch.float), inv)
+        hpos = torch.arange(gh).unsqueeze(1).expand(-1, gw).reshape(lh, m, lw, m).permute(0, 2, 1, 3).flatten()
+        wpos = torch.arange(gw).unsqueeze(0).expand(gh, -1).reshape(lh, m, lw, m).permute(0, 2, 1, 3).flatten()
+        fr = full[torch.stack([hpos, wpos], -1)].flatten(1)[perm]   # [S, hd/2]
+        self.gh, self.gw, self.S = gh, gw, S
+        z = torch.zeros(S, dtype=torch.int32)
+        self.plan_in = torch.stack([z, perm.to(torch.int32)], 1).contiguous().to(device)
+        self.plan_raster = torch.stack([z, raster_to_win.to(torch.int32)], 1).contiguous().to(device)
+        zu = torch.zeros(S // unit, dtype=torch.int32)
+        self.plan_tokens = torch.stack([zu, inv_unit.to(torch.int32)], 1).contiguous().to(device)
+        self.cos = fr.cos().contiguous().to(device)
+        self.sin = fr.sin().contiguous().to(device)
+        self.items_win = ops.make_items([(a, b) for a, b in zip(cu[:-1], cu[1:])], device)
+        self.items_full = ops.make_items([(0, S)], device)
+        self.cu_window = cu
+        self.Sp = _round_up(S, 64)
+
+
+class QwenViT:
+    def __init__(self, cfg: ViTConfig, state: Dict[str, torch.Tensor], device):
+        self.cfg = cfg
+        self.dev = torch.device(device)
+        bf = torch.bfloat16
+        d, ff = cfg.hidden_size, cfg.intermediate_size
+        self.ffp = _round_up(ff, 64)  # 3420 -> 3456: zero rows/cols are exact and make K % 64 == 0
+
+        def dv(t):
+            return t.to(device=self.dev, dtype=bf).contiguous()
+
+        def padrows(t, n):
+            out = torch.zeros(n, *t.shape[1:], dtype=t.dtype)
+            out[:t.shape[0]] = t
+            return out
+
+        pw = state["patch_embed.proj.weight"].reshape(d, -1)
+        self.k_in = pw.shape[1]
+        self.k_in_p = _round_up(self.k_in, 64)  # 1176 -> 1216
+        pwp = torch.zeros(d, self.k_in_p, dtype=pw.dtype)
+        pwp[:, :self.k_in] = pw
+        self.patch_w = dv(pwp)
+        self.blocks = []
+        for i in range(cfg.depth):
+            p = f"blocks.{i}."
+            wd = torch.zeros(d, self.ffp, dtype=state[p + "mlp.down_proj.weight"].dtype)
+            wd[:, :ff] = state[p + "mlp.down_proj.weight"]
+            self.blocks.append(dict(
+                n1=dv(state[p + "norm1.weight"]), n2=dv(state[p + "norm2.weight"]),
+                wqkv=dv(state[p + "attn.qkv.weight"]), bqkv=dv(state[p + "attn.qkv.bias"]),
+                wo=dv(state[p + "attn.proj.weight"]), bo=dv(state[p + "attn.proj.bias"]),
+                wgu=dv(torch.cat([padrows(state[p + "mlp.gate_proj.weight"], self.ffp), padrows(state[p + "mlp.up_proj.weight"], self.ffp)], 0)),
+                bgu=dv(torch.cat([padrows(state[p + "mlp.gate_proj.bias"], self.ffp), padrows(state[p + "mlp.up_proj.bias"], self.ffp)], 0)),
+                wd=dv(wd), bd=dv(state[p + "mlp.down_proj.bias"]),
+            ))
+        self.ln_q = dv(state["merger.ln_q.weight"])
+        self.m0w, self.m0b = dv(state["merger.mlp.0.weight"]), dv(state["merger.mlp.0.bias"])
+        self.m2w, self.m2b = dv(state["merger.mlp.2.weight"]), dv(state["merger.mlp.2.bias"])
+        self._plans: Dict[Tuple[int, int], GridPlan] = {}
+
+    def plan(self, gh: int, gw: int) -> GridPlan:
+        key = (gh, gw)
+        if key not in self._plans:
+            self._plans[key] = GridPlan(gh, gw, self.cfg, self.dev)
+        return self._plans[key]
+
+    def forward(self, pixel_values: torch.Tensor, gh: int, gw: int, capture: str = "all"):
+        """pixel_values [S, 1176] (device, bf16, merge-block order as the HF processor emits them).
+        Returns (image_tokens [S/4, out_hidden] raster-merged order,
+                 feature maps: list of [gh*gw, 1280] raster token-major (all full-attention blocks, or
+                 only the last one when capture == "last" — what the SimpleFPN variant consumes))."""
+        c = self.cfg
+        g = self.plan(gh, gw)
+        S, d, H = g.S, c.hidden_size, c.num_heads
+        hd = d // H
+        if pixel_values.shape != (S, self.k_in):
+            raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match grid {gh}x{gw} (expected [{S}, {self.k_in}])")
+        pix = pixel_values.to(torch.bfloat16)
+        # window re-order folded into the patch-embed input gather; pad K 1176 -> 1216 (zeros)
+        xin = torch.zeros(S, self.k_in_p, dtype=torch.bfloat16, device=self.dev)
+        ops.gather_rows_into(g.plan_in, self.k_in, pix, out=xin)
+        x = ops.gemm(xin, self.patch_w)
+        vt = torch.zeros(d, g.Sp, dtype=torch.bfloat16, device=self.dev)  # V^T scratch, reused by every block
+        scale = 1.0 / math.sqrt(hd)
+        nwin = len(g.cu_window) - 1
+        fl_win = 4.0 * d * sum((b - a) ** 2 for a, b in zip(g.cu_window[:-1], g.cu_window[1:]))
+        fl_full = 4.0 * d * S * S
+        feats: List[torch.Tensor] = []
+        for i, w in enumerate(self.blocks):
+            full = i in c.fullatt_block_indexes
+            h = ops.rmsnorm(x, w["n1"], 1e-6)
+            qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
+            ops.rope_vit(qkv, H, hd, g.cos, g.sin)
+            ops.transpose_into(qkv[:, 2 * d:], vt, 0)
+            att = ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
+                                flops=fl_full if full else fl_win)
+            x = ops.gemm(att, w["wo"], w["bo"], residual=x)
+            h = ops.rmsnorm(x, w["n2"], 1e-6)
+            gu = ops.gemm(h, w["wgu"], w["bgu"])
+            a = ops.swiglu(gu)
+            x = ops.gemm(a, w["wd"], w["bd"], residual=x)
+            if full and (capture == "all" or i == c.fullatt_block_indexes[-1]):
+                feats.append(ops.gather_rows(g.plan_raster, d, x))
+        u = c.spatial_merge_size ** 2
+        m = ops.rmsnorm(x, self.ln_q, 1e-6).view(S // u, u * d)
+        m = ops.gemm(m, self.m0w, self.m0b, act=ops.ACT_GELU)
+        m = ops.gemm(m, self.m2w, self.m2b)
+        tokens = ops.gather_rows(g.plan_tokens, c.out_hidden_size, m)
+        return tokens, feats
