@@ -27,74 +27,112 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
 
 def build_workload(device, n_boxes=32, img_hw=(480, 640), seed=1234):
     """BASELINE.json configs[1]: 1 image (640x480 synthetic) x 32 proposals (first 32 boxes of the
-    CountBench fixture item with N>=32, rescaled to the image), true channel counts."""
-    from hfre_cases import box_fixtures, pyramid_sizes
+    CountBench fixture item with N>=32, rescaled to the image), Qwen2.5-VL-3B / DaViT-L true shapes.
+    Everything the timed region reads is resident in HBM."""
+    from hfre_cases import box_fixtures
+    from vlm_fo1_amd.model import synthetic_prompt
     H, W = img_hw
     g = torch.Generator().manual_seed(seed)
-    sizes = pyramid_sizes(H, W)
-    aux = [torch.randn(h * w, c, generator=g).bfloat16().reshape(h, w, c).permute(2, 0, 1).unsqueeze(0)
-           for (h, w), c in zip(sizes, (256, 512, 1024, 2048))]
     gh, gw = round(H / 28) * 2, round(W / 28) * 2
-    fpn = []
-    for f in (4, 2, 1, 0.5):
-        h, w = int(gh * f), int(gw * f)
-        fpn.append(torch.randn(h * w, 512, generator=g).bfloat16().reshape(h, w, 512).permute(2, 0, 1).unsqueeze(0))
-    items = [x for x in box_fixtures()["countbench"] if len(x["bboxes"]) >= n_boxes]
-    it = items[0]
+    pix = torch.randn(gh * gw, 1176, generator=g).bfloat16()        # normalised patches, HF processor layout
+    aux = torch.randn(3, H, W, generator=g).bfloat16()               # CLIP-normalised aux image ('dynamic': no resize)
+    it = [x for x in box_fixtures()["countbench"] if len(x["bboxes"]) >= n_boxes][0]
     b = torch.tensor(it["bboxes"], dtype=torch.float32)[:n_boxes]
     ex, ey = it["extent"]
     b = b * torch.tensor([W / ex, H / ey, W / ex, H / ey])
-    sw, sh = gw * 14 / W, gh * 14 / H
-    case = dict(aux_maps=aux, fpn_maps=fpn, fpn=True, grid_hw=(gh, gw), boxes=b, vt_scale=(sw, sh),
-                vt_boxes=b * torch.tensor([sw, sh, sw, sh]), region_dim=5888, img_hw=img_hw)
+    ids = synthetic_prompt(n_boxes, n_text=60, seed=seed)
+    case = dict(pix=pix, aux=aux, boxes=b, ids=ids, grid=(gh, gw), img_hw=img_hw)
     if device is not None:
-        case["dev"] = dict(
-            aux_maps=[m.permute(0, 2, 3, 1).contiguous().to(device).permute(0, 3, 1, 2) for m in aux],
-            fpn_maps=[m.permute(0, 2, 3, 1).contiguous().to(device).permute(0, 3, 1, 2) for m in fpn],
-            boxes=b.to(device), vt_boxes=case["vt_boxes"].to(device),
-            vt_in=torch.zeros(1, 1280, gh, gw, dtype=torch.bfloat16, device=device))
+        case["dev"] = dict(pix=pix.to(device), aux=aux.to(device), boxes=b.to(device))
     return case
 
 
 class Pipeline:
-    """The stages of the hot path implemented so far, run back to back on one stream."""
-    stages = ["hfre_region_pool"]
+    """Every stage of the hot path, back to back on one stream: one step = one image up to and
+    including its first generated token."""
+    stages = ["qwen_vit(32 blocks)+merger", "mm_projector", "davit_large", "simple_fpn", "hfre_region_pool",
+              "mm_projector_aux", "splice+mrope", "llm_prefill(36 layers)", "lm_head(last row)+argmax"]
 
-    def __init__(self, case):
-        from vlm_fo1_amd.hfre import HFREModule
-        self.d = case["dev"]
-        self.hfre = HFREModule(roi_output_size=7, region_feature_dim=case["region_dim"], apply_position_embedding=True,
-                               use_vision_tower_region_feature=True, vision_tower_region_feature_dim=2048,
-                               use_simpleFPN_for_vt=True, simple_fpn=lambda x: self.d["fpn_maps"])
+    def __init__(self, case, device):
+        from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights
+        self.cfg = FO1Config()
+        self.weights = random_weights(self.cfg, device, seed=0)
+        self.eng = FO1Engine(self.cfg, self.weights, device)
+        self.case = case
 
     def step(self):
-        d = self.d
-        return self.hfre(d["aux_maps"], [d["boxes"]], d["vt_in"], [d["vt_boxes"]])
+        d = self.case["dev"]
+        return self.eng.prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"])
 
 
-def cpu_baseline(case, budget_s=15.0):
-    """Oracle (port) of the same stages on the host cores, bounded sample."""
-    from oracle import hfre_oracle as O
+def cpu_baseline(case, pipe, budget_s=25.0):
+    """The oracle (port) of the same stages on the host cores.  Bounded sample: the towers and the LLM are
+    timed on a few blocks each and scaled by the block count (every block of a stage does identical work);
+    DaViT, SimpleFPN, HFRE and the projectors are timed in full."""
+    import torch.nn.functional as F
+    from oracle import davit_oracle as DO, fpn_oracle as FO, hfre_oracle as HO, llm_oracle as LO, vit_oracle as VO
     torch.set_num_threads(os.cpu_count())
-    n = 0
+    W = pipe.weights
+    gh, gw = case["grid"]
+    t = {}
+
+    def cpu(sd, keep):
+        return {k: v.float().cpu() for k, v in sd.items() if keep(k)}
+
+    nv, nl = 2, 1
+    vit_sd = cpu(W["vit"], lambda k: not k.startswith("blocks.") or int(k.split(".")[1]) < nv)
     t0 = time.perf_counter()
-    while True:
-        O.hfre_oracle(case["aux_maps"], case["boxes"], case["fpn_maps"], case["vt_boxes"],
-                      region_dim=case["region_dim"], grid_hw=case["grid_hw"], vt_strides=[3.5, 7, 14, 28])
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 20:
-            break
-    return dict(value=n / el, unit="images/s", cores=os.cpu_count(), kind="port",
-                sample=f"{n} image(s) x {case['boxes'].shape[0]} boxes through oracle stages {Pipeline.stages} "
-                       f"(oracle/hfre_oracle.py + roi_align_ref.c, OpenMP over boxes) in {el:.1f}s")
+    tokens, maps = VO.vit_forward(vit_sd, case["pix"].float(), gh, gw, depth=nv, n_heads=16, fullatt=(1,))
+    t["vit_blocks%d+embed+merger" % nv] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    VO.vit_forward(vit_sd, case["pix"].float(), gh, gw, depth=1, n_heads=16, fullatt=(0,))
+    t["vit_1block+embed+merger"] = time.perf_counter() - t0
+    per_vit_block = max(t["vit_blocks%d+embed+merger" % nv] - t["vit_1block+embed+merger"], 1e-3)
+    vit_total = t["vit_1block+embed+merger"] + per_vit_block * (pipe.cfg.vit.depth - 1)
+    dav_sd = cpu(W["davit"], lambda k: True)
+    t0 = time.perf_counter()
+    aux_maps, aux_sizes = DO.davit_forward(dav_sd, case["aux"].float().unsqueeze(0))
+    t["davit"] = time.perf_counter() - t0
+    fpn_sd = cpu(W["fpn"], lambda k: True)
+    t0 = time.perf_counter()
+    fpn = FO.fpn_forward(fpn_sd, maps[-1].reshape(gh, gw, 1280).permute(2, 0, 1).unsqueeze(0))
+    t["fpn"] = time.perf_counter() - t0
+    H, Wd = case["img_hw"]
+    sw, sh = gw * 14 / Wd, gh * 14 / H
+    aux_nchw = [m.reshape(h, w, -1).permute(2, 0, 1).unsqueeze(0) for m, (h, w) in zip(aux_maps, aux_sizes)]
+    t0 = time.perf_counter()
+    feat = HO.hfre_oracle(aux_nchw, case["boxes"], fpn, case["boxes"] * torch.tensor([sw, sh, sw, sh]), region_dim=5888,
+                          grid_hw=(gh, gw), vt_strides=[3.5, 7, 14, 28])[0]
+    t["hfre"] = time.perf_counter() - t0
+    proj = cpu(W["proj"], lambda k: True)
+    t0 = time.perf_counter()
+    reg = F.linear(F.gelu(F.linear(feat, proj["mm_projector_aux.0.weight"], proj["mm_projector_aux.0.bias"])),
+                   proj["mm_projector_aux.2.weight"], proj["mm_projector_aux.2.bias"])
+    img = F.linear(F.gelu(F.linear(tokens, proj["mm_projector.0.weight"], proj["mm_projector.0.bias"])),
+                   proj["mm_projector.2.weight"], proj["mm_projector.2.bias"])
+    t["projectors"] = time.perf_counter() - t0
+    llm_sd = cpu(W["llm"], lambda k: not k.startswith("layers.") or int(k.split(".")[1]) < nl)
+    emb, nb, na = LO.splice(torch.tensor(case["ids"]), llm_sd["embed_tokens.weight"], img, reg)
+    pos, _ = LO.rope_index(nb, (gh // 2, gw // 2), na)
+    t0 = time.perf_counter()
+    fin = LO.llm_forward(llm_sd, emb, pos, n_layers=nl, n_heads=16, n_kv=2, head_dim=128, eps=1e-6, theta=1e6, sections=(16, 24, 24))
+    t["llm_%dlayer" % nl] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    (fin[-1:] @ llm_sd["embed_tokens.weight"].t()).argmax()
+    t["lm_head"] = time.perf_counter() - t0
+    total = vit_total + t["davit"] + t["fpn"] + t["hfre"] + t["projectors"] + t["llm_%dlayer" % nl] / nl * pipe.cfg.llm.num_layers + t["lm_head"]
+    return dict(value=1.0 / total, unit="images/s", cores=os.cpu_count(), kind="port",
+                seconds_per_image=round(total, 2), stage_seconds={k: round(v, 3) for k, v in t.items()},
+                sample=f"1 image x {case['boxes'].shape[0]} boxes through the oracle stages on {os.cpu_count()} host threads (torch fp32): "
+                       f"DaViT-L, SimpleFPN, HFRE, projectors, lm_head timed in full; ViT timed on {nv} of {pipe.cfg.vit.depth} blocks and "
+                       f"the LLM on {nl} of {pipe.cfg.llm.num_layers} layers, scaled by block count")
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--boxes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -114,7 +152,7 @@ def main():
     from vlm_fo1_amd import lib as L
     L.load()
     case = build_workload(dev, n_boxes=args.boxes, seed=1234 + rank)
-    pipe = Pipeline(case)
+    pipe = Pipeline(case, dev)
 
     for _ in range(args.warmup):
         pipe.step()
@@ -145,17 +183,23 @@ def main():
         for _ in range(min(args.steps, 50)):
             pipe.step()
         torch.cuda.synchronize()
+        torch.cuda.synchronize()
         rows = L.profile_rows(reset=True)
         L.profile(False)
         rows.sort(key=lambda r: -r["total_ms"])
         dom = rows[0]
+        nprof = min(args.steps, 50)
         avg_ms = dom["total_ms"] / dom["calls"]
         work = dom["total_work"] / dom["calls"]
-        ach = work / (avg_ms * 1e-3) / 1e9  # GB/s
-        roof = dict(kernel=dom["name"], bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(ach / HBM_PEAK_GBS, 5), traffic=None, avg_us=round(avg_ms * 1e3, 3),
-                    algorithmic_bytes=work,
-                    kernels={r["name"]: round(r["total_ms"] / r["calls"] * 1e3, 3) for r in rows})
+        mfma = dom["name"].startswith("gemm") or dom["name"].startswith("attn")
+        ach = work / (avg_ms * 1e-3) / (1e12 if mfma else 1e9)
+        peak = MFMA_BF16_PEAK_TF if mfma else HBM_PEAK_GBS
+        roof = dict(kernel=dom["name"], bound="mfma" if mfma else "hbm", achieved=round(ach, 2), peak=peak,
+                    unit="TFLOP/s" if mfma else "GB/s", frac=round(ach / peak, 5), traffic=None,
+                    avg_us=round(avg_ms * 1e3, 3), launches_per_step=dom["calls"] // nprof,
+                    algorithmic_work_per_launch=work,
+                    per_step_ms={r["name"]: round(r["total_ms"] / nprof, 4) for r in rows},
+                    launches={r["name"]: r["calls"] // nprof for r in rows})
 
     if rank == 0:
         n_img = args.steps * world
@@ -163,14 +207,14 @@ def main():
                    warmup=args.warmup, ms_per_step=el / args.steps * 1e3, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="bf16", data="synthetic",
                    region_tokens_per_sec=n_img * args.boxes / el,
-                   config=dict(workload=f"BASELINE configs[1]: 1 image 640x480 x {args.boxes} proposals "
-                                        "(CountBench UPN boxes), Qwen2.5-VL-3B / DaViT-L shapes, bf16 maps, fp32 region features",
+                   config=dict(workload=f"BASELINE configs[1]: 1 image 640x480 (S=1564 patches) x {args.boxes} proposals "
+                                        f"(CountBench UPN boxes), Qwen2.5-VL-3B + DaViT-L + SimpleFPN true shapes, prompt "
+                                        f"{len(case['ids']) - 1 + 391} tokens after splice, prefill to the first greedy token",
                                stages=Pipeline.stages,
-                               stages_not_yet_in_step=["qwen_vit", "davit", "simple_fpn", "mm_projector_aux", "llm_prefill"],
                                parallelism=f"dp{world} (images sharded, no data-path collective)"),
                    roofline=roof)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(case)
+            out["cpu_baseline"] = cpu_baseline(case, pipe)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

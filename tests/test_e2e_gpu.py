@@ -1,0 +1,80 @@
+"""End-to-end GPU parity: the whole hot path (ViT -> FPN, DaViT -> HFRE -> projectors -> splice -> mRoPE ->
+LLM prefill -> first token) on the engine vs the composed CPU oracles, true channel widths, reduced depth
+(ViT 4 blocks, LLM 2 layers, 4k vocab) so the CPU side finishes in seconds.
+
+north_star tolerance for region tokens ("within a stated bf16 tolerance"): per-token cosine >= 0.999 and
+max|delta| <= 2^-4 * max|ref| (they sit behind the full DaViT-L + 4 ViT blocks + FPN, whose intrinsic bf16
+noise floor is measured in test_towers_gpu.py); image tokens the same; logits max|delta| <= 0.05 and the
+greedy token equal whenever the oracle's top-1 margin exceeds 0.1."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def cpu_state(weights):
+    return {k: {n: t.float().cpu() for n, t in sd.items()} for k, sd in weights.items()}
+
+
+def mlp2(x, sd, prefix):
+    h = F.gelu(F.linear(x, sd[prefix + "0.weight"], sd[prefix + "0.bias"]))
+    return F.linear(h, sd[prefix + "2.weight"], sd[prefix + "2.bias"])
+
+
+def test_full_hot_path_vs_oracle():
+    from hfre_cases import box_fixtures
+    from oracle import davit_oracle as DO, fpn_oracle as FO, hfre_oracle as HO, llm_oracle as LO, vit_oracle as VO
+    from vlm_fo1_amd.llm import LLMConfig
+    from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights, synthetic_prompt
+    from vlm_fo1_amd.vit import ViTConfig
+    cfg = FO1Config(vit=ViTConfig(depth=4, fullatt_block_indexes=(1, 3)), llm=LLMConfig(num_layers=2, vocab_size=4096, max_seq=1024))
+    weights = random_weights(cfg, "cuda", seed=3)
+    eng = FO1Engine(cfg, weights, "cuda")
+    H, W = 399, 500          # the demo image geometry (aux tower: dynamic size, no resize)
+    gh, gw = 28, 36
+    g = torch.Generator().manual_seed(9)
+    pix = torch.randn(gh * gw, 1176, generator=g).bfloat16()
+    aux = torch.randn(3, H, W, generator=g).bfloat16()
+    it = [x for x in box_fixtures()["countbench"] if len(x["bboxes"]) == 7][0]
+    boxes = torch.tensor(it["bboxes"], dtype=torch.float32) * torch.tensor([W / it["extent"][0], H / it["extent"][1]] * 2)
+    ids = synthetic_prompt(boxes.shape[0], vocab=4096, seed=1)
+    out = eng.prefill(ids, pix.cuda(), (gh, gw), aux.cuda(), boxes.cuda())
+
+    sd = cpu_state(weights)
+    tokens, maps = VO.vit_forward(sd["vit"], pix.float(), gh, gw, depth=4, n_heads=16, fullatt=(1, 3))
+    img_tok = mlp2(tokens, sd["proj"], "mm_projector.")
+    fpn_in = maps[-1].bfloat16().float().reshape(gh, gw, 1280).permute(2, 0, 1).unsqueeze(0)
+    fpn = [m.bfloat16() for m in FO.fpn_forward(sd["fpn"], fpn_in)]
+    aux_maps, aux_sizes = DO.davit_forward(sd["davit"], aux.float().unsqueeze(0))
+    aux_nchw = [m.bfloat16().reshape(h, w, -1).permute(2, 0, 1).unsqueeze(0) for m, (h, w) in zip(aux_maps, aux_sizes)]
+    sw, sh = gw * 14 / W, gh * 14 / H
+    vtb = boxes * torch.tensor([sw, sh, sw, sh])
+    feat = HO.hfre_oracle(aux_nchw, boxes, fpn, vtb, region_dim=5888, grid_hw=(gh, gw), vt_strides=[3.5, 7, 14, 28])[0]
+    reg_tok = mlp2(feat.bfloat16().float(), sd["proj"], "mm_projector_aux.")
+
+    def check(got, ref, what, cos_min=0.999, rel_max=2 ** -4):
+        got, ref = got.float().cpu(), ref.float()
+        cos = F.cosine_similarity(got, ref, dim=-1)
+        rel = (got - ref).abs().max() / ref.abs().max()
+        assert cos.min() >= cos_min and rel <= rel_max, f"{what}: min cos {cos.min():.6f}, rel {rel:.4g}"
+
+    check(out["image_tokens"], img_tok, "image tokens")
+    check(out["region_tokens"], reg_tok, "region tokens")
+    emb, nb, na = LO.splice(torch.tensor(ids), sd["llm"]["embed_tokens.weight"], img_tok, reg_tok)
+    assert emb.shape == out["embeds"].shape
+    pos, delta = LO.rope_index(nb, (gh // 2, gw // 2), na)
+    assert torch.equal(pos, out["position_ids"]) and delta == out["rope_delta"]
+    final = LO.llm_forward(sd["llm"], emb, pos, n_layers=2, n_heads=16, n_kv=2, head_dim=128, eps=1e-6, theta=1e6,
+                           sections=(16, 24, 24))
+    check(out["last_hidden"], final[-1:], "final hidden", cos_min=0.999)
+    ref_logits = final[-1:] @ sd["llm"]["embed_tokens.weight"].t()
+    err = (out["logits"].float().cpu() - ref_logits).abs().max()
+    assert err <= 0.05, f"logits max err {err:.4g}"
+    top2 = ref_logits[0].topk(2).values
+    if top2[0] - top2[1] > 0.1:
+        assert int(out["next_token"].item()) == int(ref_logits.argmax())
+    # greedy decode runs and is deterministic
+    a = eng.generate(ids, pix.cuda(), (gh, gw), aux.cuda(), boxes.cuda(), max_new_tokens=6)
+    b = eng.generate(ids, pix.cuda(), (gh, gw), aux.cuda(), boxes.cuda(), max_new_tokens=6)
+    assert a == b and len(a) == 6 and a[0] == int(out["next_token"].item())

