@@ -60,9 +60,9 @@ class Pipeline:
         self.eng = FO1Engine(self.cfg, self.weights, device)
         self.case = case
 
-    def step(self):
+    def step(self, graph=True):
         d = self.case["dev"]
-        return self.eng.prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"])
+        return self.eng.prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
 
 
 def cpu_baseline(case, pipe, budget_s=25.0):
@@ -71,7 +71,8 @@ def cpu_baseline(case, pipe, budget_s=25.0):
     DaViT, SimpleFPN, HFRE and the projectors are timed in full."""
     import torch.nn.functional as F
     from oracle import davit_oracle as DO, fpn_oracle as FO, hfre_oracle as HO, llm_oracle as LO, vit_oracle as VO
-    torch.set_num_threads(os.cpu_count())
+    ncpu = min(32, len(os.sched_getaffinity(0)))  # 256-thread torch on this box thrashes; 32 is the fastest setting we measured
+    torch.set_num_threads(ncpu)
     W = pipe.weights
     gh, gw = case["grid"]
     t = {}
@@ -121,9 +122,9 @@ def cpu_baseline(case, pipe, budget_s=25.0):
     (fin[-1:] @ llm_sd["embed_tokens.weight"].t()).argmax()
     t["lm_head"] = time.perf_counter() - t0
     total = vit_total + t["davit"] + t["fpn"] + t["hfre"] + t["projectors"] + t["llm_%dlayer" % nl] / nl * pipe.cfg.llm.num_layers + t["lm_head"]
-    return dict(value=1.0 / total, unit="images/s", cores=os.cpu_count(), kind="port",
+    return dict(value=1.0 / total, unit="images/s", cores=ncpu, host_cpus=os.cpu_count(), kind="port",
                 seconds_per_image=round(total, 2), stage_seconds={k: round(v, 3) for k, v in t.items()},
-                sample=f"1 image x {case['boxes'].shape[0]} boxes through the oracle stages on {os.cpu_count()} host threads (torch fp32): "
+                sample=f"1 image x {case['boxes'].shape[0]} boxes through the oracle stages on {ncpu} host threads (torch fp32): "
                        f"DaViT-L, SimpleFPN, HFRE, projectors, lm_head timed in full; ViT timed on {nv} of {pipe.cfg.vit.depth} blocks and "
                        f"the LLM on {nl} of {pipe.cfg.llm.num_layers} layers, scaled by block count")
 
@@ -135,6 +136,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--boxes", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
+    ap.add_argument("--profile-shapes", action="store_true", help="per-shape GEMM rows in roofline.per_step_ms")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -154,8 +157,9 @@ def main():
     case = build_workload(dev, n_boxes=args.boxes, seed=1234 + rank)
     pipe = Pipeline(case, dev)
 
+    use_graph = not args.eager
     for _ in range(args.warmup):
-        pipe.step()
+        pipe.step(use_graph)
 
     def barrier():
         if world > 1:
@@ -166,7 +170,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        pipe.step()
+        pipe.step(use_graph)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -179,6 +183,7 @@ def main():
     # ---- roofline of the dominant kernel: separate profiled pass (hipEvents per launch) ----
     roof = None
     if rank == 0:
+        L.load().fo1_gemm_profile_shapes(1 if args.profile_shapes else 0)
         L.profile(True)
         for _ in range(min(args.steps, 50)):
             pipe.step()
@@ -210,7 +215,7 @@ def main():
                    config=dict(workload=f"BASELINE configs[1]: 1 image 640x480 (S=1564 patches) x {args.boxes} proposals "
                                         f"(CountBench UPN boxes), Qwen2.5-VL-3B + DaViT-L + SimpleFPN true shapes, prompt "
                                         f"{len(case['ids']) - 1 + 391} tokens after splice, prefill to the first greedy token",
-                               stages=Pipeline.stages,
+                               stages=Pipeline.stages, launch="eager" if args.eager else "hipGraph replay (1 graph per shape signature)",
                                parallelism=f"dp{world} (images sharded, no data-path collective)"),
                    roofline=roof)
         if not args.no_cpu_baseline and world == 1:

@@ -121,9 +121,17 @@ int fo1_hfre_region_pool(
 int fo1_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias,
                   const void* residual, int ldr, void* C, int ldc,
                   int M, int N, int K, int act, int out_f32, void* stream);
-/* Tuning hook: staging 0 auto / 1 register-staged / 2 LDS-DMA; tile 0 auto / 1 128x128 /
- * 2 64x128 / 3 64x64. */
+/* Same, with a caller-owned fp32 scratch (16-byte aligned) that enables split-K for skinny outputs:
+ * partials [splits][M][N] are reduced in a fixed order by a second kernel (deterministic). */
+int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void* bias,
+                     const void* residual, int ldr, void* C, int ldc,
+                     int M, int N, int K, int act, int out_f32,
+                     void* workspace, size_t workspace_bytes, void* stream);
+/* Tuning hooks: staging 0 auto / 1 register-staged / 2 LDS-DMA; tile 0 auto / 1 128x128 /
+ * 2 64x128 / 3 64x64; split-K 0 auto / n forced; per-shape kernel names in the profile. */
 int fo1_gemm_set_variant(int staging, int tile);
+int fo1_gemm_set_splitk(int splits);
+int fo1_gemm_profile_shapes(int on);
 
 /* ------------------------------------------------------------------------
  * Row norms / small elementwise ops (HBM-bound).  All tensors bf16 row-major with explicit row

@@ -254,3 +254,36 @@ def test_attention_online_softmax_rescale_branch():
                    qf[:, 2 * H * D:].reshape(L, H, D), [(0, L)], False, sc).reshape(L, H * D)
     err = (got.float().cpu() - ref).abs()
     assert err.max() < 3e-2, f"max err {err.max():.4g} at row {int(err.max(1).values.argmax())}"
+
+
+@pytest.mark.parametrize("splits", [2, 3, 8])
+def test_gemm_splitk(splits):
+    """Split-K partials + fixed-order reduce must match the single-pass kernel to fp32 re-association."""
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(11)
+    try:
+        for (M, N, K, hb, hr, act) in [(515, 2048, 11008, False, True, 0), (515, 2560, 2048, True, False, 0),
+                                       (100, 2048, 5888, True, False, 1), (33, 132, 512, True, True, 2)]:
+            if K % 64 != 0:
+                continue
+            a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+            w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+            bias = (torch.randn(N) * 0.1).to(BF).cuda() if hb else None
+            res = torch.randn(M, N).to(BF).cuda() if hr else None
+            for tile in (2, 3):
+                L.check(L.load().fo1_gemm_set_variant(2, tile), "variant")
+                L.check(L.load().fo1_gemm_set_splitk(1), "splitk")
+                one = ops.gemm(a, w, bias, res, act).float().cpu()
+                L.check(L.load().fo1_gemm_set_splitk(splits), "splitk")
+                got = ops.gemm(a, w, bias, res, act).float().cpu()
+                ref = gemm_ref(a, w, bias, res, act)
+                scale = ref.abs().max().item()
+                assert (got - ref).abs().max() <= 2e-2 * scale + 1e-3, f"splitk={splits} {M}x{N}x{K} tile={tile}"
+                # vs the unsplit kernel: differences only from fp32 summation order (<= 1 bf16 ulp on a few elements)
+                assert (got - one).abs().max() <= 2 ** -7 * scale + 1e-3
+                got32 = ops.gemm(a, w, bias, None, 0, out_f32=True).cpu()
+                ref32 = a.float().cpu() @ w.float().cpu().t() + (bias.float().cpu() if hb else 0)
+                torch.testing.assert_close(got32, ref32, rtol=2e-3, atol=2e-3 * scale)
+    finally:
+        L.load().fo1_gemm_set_splitk(0)
+        L.load().fo1_gemm_set_variant(0, 0)

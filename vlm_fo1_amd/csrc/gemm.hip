@@ -37,6 +37,8 @@ struct GemmParams {
     int act;
     int tiles_m, tiles_n;
     long long sA, sW, sC, sR;  // batch strides (elements), blockIdx.y = batch
+    int splits, kper;          // split-K: blockIdx.z = split, kper k-tiles (of 64) per split
+    float* part;               // fp32 partials [splits][M][N] when splits > 1
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
@@ -112,6 +114,25 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FN][F
                     o[r] = f32_to_bf16(t);
                 }
             }
+        }
+    }
+}
+
+// split-K: raw fp32 accumulators of split z -> part[z][m][n] (N % 4 == 0 guaranteed by the dispatcher)
+template <int FM, int FN>
+__device__ __forceinline__ void store_partial(const GemmParams& p, f32x4 (&acc)[FN][FM], int m_base, int n_base, int lane, int z) {
+    const int mi = lane & 15, nq = (lane >> 4) * 4;
+    float* base = p.part + (long long)z * p.M * p.N;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = m_base + fm * 16 + mi;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int n0 = n_base + fn * 16 + nq;
+            if (n0 >= p.N) continue;
+            *reinterpret_cast<float4*>(base + (long long)m * p.N + n0) =
+                float4{acc[fn][fm][0], acc[fn][fm][1], acc[fn][fm][2], acc[fn][fm][3]};
         }
     }
 }
@@ -241,7 +262,9 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
         const int R = (wave * IPW + i) * 8 + lr;  // tile row: [0,BM) = A rows, [BM,BM+BN) = W rows
-        const int cs = (lc ^ lr) * 8;             // XOR swizzle on the source chunk (R & 7 == lr)
+        // XOR swizzle on the SOURCE chunk with (R >> 1) & 7: two 128-B rows share one 256-B bank row, so
+        // 16 consecutive rows land on 16 distinct (half, 16-B slot) positions -> conflict-free ds_read_b128
+        const int cs = (lc ^ ((R >> 1) & 7)) * 8;
         if (R < BM) {
             int gm = m0 + R;
             gm = gm < p.M ? gm : p.M - 1;
@@ -261,11 +284,13 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
         }
     };
 
-    const int nk = p.K / BK;
-    issue(0, 0);
+    const int nk_all = p.K / BK;
+    const int kt0 = blockIdx.z * p.kper;
+    const int nk = min(nk_all - kt0, p.kper);   // this split's k-tiles: [kt0, kt0 + nk)
+    issue(kt0, 0);
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();  // carries vmcnt(0): tile kt has landed; everyone is done with the other buffer
-        if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
         const char* sa = smem + (kt & 1) * (ROWS * 128);
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -275,12 +300,12 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn) {
                 const int R = wn * WN + fn * 16 + (lane & 15);
-                wf[fn] = *reinterpret_cast<const bf16x8*>(sb + R * 128 + ((kc ^ (R & 7)) << 4));
+                wf[fn] = *reinterpret_cast<const bf16x8*>(sb + R * 128 + ((kc ^ ((R >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
                 const int R = wm * WM + fm * 16 + (lane & 15);
-                af[fm] = *reinterpret_cast<const bf16x8*>(sa + R * 128 + ((kc ^ (R & 7)) << 4));
+                af[fm] = *reinterpret_cast<const bf16x8*>(sa + R * 128 + ((kc ^ ((R >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
@@ -289,18 +314,69 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
                     acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
         }
     }
+    if (p.splits > 1) {
+        store_partial<FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, blockIdx.z);
+        return;
+    }
     epilogue<FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz * p.sC, bz * p.sR);
+}
+
+// out = epilogue( sum_z part[z] ) in a fixed order (deterministic); 4 consecutive n per thread
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParams p) {
+    const int n4 = p.N >> 2;
+    const long long total = (long long)p.M * n4;
+    const long long plane = (long long)p.M * p.N;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / n4), n0 = (int)(i - (long long)m * n4) * 4;
+        float4 a = *reinterpret_cast<const float4*>(p.part + (long long)m * p.N + n0);
+        for (int z = 1; z < p.splits; ++z) {
+            const float4 b = *reinterpret_cast<const float4*>(p.part + z * plane + (long long)m * p.N + n0);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float v[4] = {a.x, a.y, a.z, a.w};
+        if (p.bias) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bf16_to_f32(p.bias[n0 + r]);
+        }
+        if (p.C32) {
+            float* o = p.C32 + (long long)m * p.ldc + n0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = act_apply(v[r], p.act);
+            continue;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = round_bf16(v[r]);
+        if (p.act != ACT_NONE) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = round_bf16(act_apply(v[r], p.act));
+        }
+        if (p.res) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += bf16_to_f32(p.res[(long long)m * p.ldr + n0 + r]);
+        }
+        uint16_t* o = p.C + (long long)m * p.ldc + n0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = f32_to_bf16(v[r]);
+    }
 }
 
 static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds
 static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64
+static int g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
+static int g_gemm_profile_shapes = 0;
 
 template <int BM, int BN>
 static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
-    const dim3 grid(p.tiles_m * p.tiles_n, batch);
+    const dim3 grid(p.tiles_m * p.tiles_n, batch, glds ? p.splits : 1);
     const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
+    char pname[48];
+    const char* name = glds ? "gemm_bf16_glds" : "gemm_bf16_reg";
+    if (profile_enabled() && g_gemm_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemm %dx%dx%d t%dx%d s%d", p.M, p.N, p.K, BM, BN, glds ? p.splits : 1);
+        name = pname;
+    }
     if (glds) {
         constexpr int smem = 2 * (BM + BN) * 128;
         static bool attr_done = false;
@@ -309,14 +385,19 @@ static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem));
             attr_done = true;
         }
-        FO1_LAUNCH("gemm_bf16_glds", flops, (gemm_bt_glds_kernel<BM, BN>), grid, dim3(256), smem, st, p);
+        FO1_LAUNCH(name, flops, (gemm_bt_glds_kernel<BM, BN>), grid, dim3(256), smem, st, p);
+        if (p.splits > 1) {
+            const long long total = (long long)p.M * (p.N / 4);
+            const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            FO1_LAUNCH("gemm_splitk_reduce", (double)p.M * p.N * 4.0 * p.splits, gemm_splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
+        }
     } else {
-        FO1_LAUNCH("gemm_bf16_reg", flops, (gemm_bt_reg_kernel<BM, BN>), grid, dim3(256), 0, st, p);
+        FO1_LAUNCH(name, flops, (gemm_bt_reg_kernel<BM, BN>), grid, dim3(256), 0, st, p);
     }
     return FO1_OK;
 }
 
-int gemm_dispatch(GemmParams& p, int batch, hipStream_t st) {
+int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws_bytes) {
     bool glds = (p.K % 64 == 0);
     if (g_gemm_variant == 1) glds = false;
     if (g_gemm_variant == 2 && p.K % 64 != 0) return set_err(FO1_ERR_ARG, "gemm: glds variant needs K %% 64 == 0 (K=%d)", p.K);
@@ -327,6 +408,32 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st) {
         const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
         const long long t64x128 = (long long)cdiv(p.M, 64) * cdiv(p.N, 128) * batch;
         tile = t128 >= 2048 ? 1 : (t64x128 >= 512 ? 2 : 3);
+    }
+    // split-K (LDS-DMA path, single batch): skinny outputs that cannot fill 256 CUs with >= 2 workgroups each
+    p.splits = 1;
+    p.kper = p.K / 64 + 1;
+    p.part = nullptr;
+    if (glds && batch == 1 && ws != nullptr && p.N % 4 == 0) {
+        const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
+        const long long tiles = (long long)cdiv(p.M, bm) * cdiv(p.N, bn);
+        const int nk = p.K / 64;
+        int splits = g_gemm_splitk;
+        if (splits == 0) {
+            splits = 1;
+            if (tiles < 512 && nk >= 8) {
+                splits = (int)((768 + tiles - 1) / tiles);
+                if (splits > 8) splits = 8;
+                if (splits > nk / 4) splits = nk / 4;
+                if (splits < 1) splits = 1;
+            }
+        }
+        if (splits > nk) splits = nk;
+        while (splits > 1 && (size_t)splits * p.M * p.N * sizeof(float) > ws_bytes) --splits;
+        if (splits > 1) {
+            p.kper = cdiv(nk, splits);
+            p.splits = cdiv(nk, p.kper);
+            p.part = ws;
+        }
     }
     if (tile == 1) return launch_gemm<128, 128>(p, batch, glds, st);
     if (tile == 2) return launch_gemm<64, 128>(p, batch, glds, st);
@@ -344,8 +451,29 @@ int fo1_gemm_set_variant(int staging, int tile) {
     return FO1_OK;
 }
 
+int fo1_gemm_set_splitk(int splits) {
+    if (splits < 0 || splits > 64) return fo1::set_err(FO1_ERR_ARG, "gemm: bad split-K %d", splits);
+    fo1::g_gemm_splitk = splits;
+    return FO1_OK;
+}
+
+int fo1_gemm_profile_shapes(int on) {
+    fo1::g_gemm_profile_shapes = on != 0;
+    return FO1_OK;
+}
+
+int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                     void* C, int ldc, int M, int N, int K, int act, int out_f32, void* workspace, size_t workspace_bytes,
+                     void* stream);
+
 int fo1_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                   void* C, int ldc, int M, int N, int K, int act, int out_f32, void* stream) {
+    return fo1_gemm_bf16_ws(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, out_f32, nullptr, 0, stream);
+}
+
+int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                     void* C, int ldc, int M, int N, int K, int act, int out_f32, void* workspace, size_t workspace_bytes,
+                     void* stream) {
     using namespace fo1;
     if (M == 0 || N == 0) return FO1_OK;
     FO1_CHECK_ARG(A && W && C, "gemm: NULL operand");
@@ -362,7 +490,8 @@ int fo1_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bi
     p.C32 = out_f32 ? (float*)C : nullptr;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
     p.sA = p.sW = p.sC = p.sR = 0;
-    return gemm_dispatch(p, 1, (hipStream_t)stream);
+    FO1_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "gemm: workspace must be 16-byte aligned");
+    return gemm_dispatch(p, 1, (hipStream_t)stream, (float*)workspace, workspace_bytes);
 }
 
 }  // extern "C"

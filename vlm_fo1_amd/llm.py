@@ -97,16 +97,15 @@ class QwenLLM:
         self.vtcache = torch.zeros(c.num_layers, c.num_kv_heads * c.head_dim, c.max_seq, dtype=bf, device=self.dev)
         self.kv_len = 0
         self.rope_delta = 0
+        self._item_cache: Dict[Tuple[int, int], torch.Tensor] = {}
 
     # ---- splice ------------------------------------------------------------------------------
-    def build_inputs(self, input_ids: Sequence[int], image_tokens: torch.Tensor, region_tokens: Optional[torch.Tensor],
-                     grid_hw_merged: Tuple[int, int]):
-        """Sentinel ids -> (embeds [L', d] on device, pos [3, L'] host).  One image per prompt
-        (what prepare_inputs produces)."""
+    def plan_inputs(self, input_ids: Sequence[int], n_img: int, n_regions: int, grid_hw_merged: Tuple[int, int]):
+        """HOST part of the splice: sentinel ids -> (gather plan int32 [L',2] (cpu), pos [3,L'] (cpu), rope delta).
+        One image per prompt (what prepare_inputs produces)."""
         plan: List[Tuple[int, int]] = []
         ri = 0
         n_before = None
-        n_img = image_tokens.shape[0]
         for t in input_ids:
             if t == IMAGE_TOKEN_INDEX:
                 if n_before is not None:
@@ -114,7 +113,7 @@ class QwenLLM:
                 n_before = len(plan)
                 plan.extend((1, j) for j in range(n_img))
             elif t == DEFAULT_REGION_INDEX:
-                if region_tokens is None or ri >= region_tokens.shape[0]:
+                if ri >= n_regions:
                     # same failure the reference raises at omchat_qwen2_5_vl.py:361
                     raise IndexError("prompt has more <regionfeat> placeholders than region features")
                 plan.append((2, ri))
@@ -126,11 +125,20 @@ class QwenLLM:
         if grid_hw_merged[0] * grid_hw_merged[1] != n_img:
             # reference modeling_qwen2_5_vl.py:1797-1800
             raise ValueError(f"Image features and image tokens do not match: tokens: {grid_hw_merged[0] * grid_hw_merged[1]}, features {n_img}")
-        plan_t = torch.tensor(plan, dtype=torch.int32).to(self.dev)
-        emb = ops.gather_rows(plan_t, self.cfg.hidden_size, self.embed, image_tokens, region_tokens)
         n_after = len(plan) - n_before - n_img
         pos, delta = rope_index_host(n_before, grid_hw_merged, n_after)
-        return emb, pos, delta
+        return torch.tensor(plan, dtype=torch.int32).reshape(-1, 2), pos, delta
+
+    def embed(self, plan_dev: torch.Tensor, image_tokens: torch.Tensor, region_tokens: Optional[torch.Tensor]):
+        """DEVICE part of the splice: one row gather over (embed table | image tokens | region tokens)."""
+        return ops.gather_rows(plan_dev, self.cfg.hidden_size, self.embed, image_tokens, region_tokens)
+
+    def build_inputs(self, input_ids: Sequence[int], image_tokens: torch.Tensor, region_tokens: Optional[torch.Tensor],
+                     grid_hw_merged: Tuple[int, int]):
+        """Sentinel ids -> (embeds [L', d] on device, pos [3, L'] host, rope delta)."""
+        n_reg = 0 if region_tokens is None else region_tokens.shape[0]
+        plan, pos, delta = self.plan_inputs(input_ids, image_tokens.shape[0], n_reg, grid_hw_merged)
+        return self.embed(plan.to(self.dev), image_tokens, region_tokens), pos, delta
 
     # ---- transformer -------------------------------------------------------------------------
     def _forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, collect: Optional[list] = None):
@@ -140,7 +148,7 @@ class QwenLLM:
         kv_end = pos0 + L
         if kv_end > c.max_seq:
             raise ValueError(f"sequence {kv_end} exceeds the KV cache ({c.max_seq})")
-        items = torch.tensor([[q0, min(q0 + 64, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, 64)], dtype=torch.int32).to(self.dev)
+        items = self._items(pos0, kv_end)
         scale = 1.0 / math.sqrt(HD)
         flops = 4.0 * H * HD * (L * (pos0 + (L + 1) / 2.0))
         for li, w in enumerate(self.layers):
@@ -159,11 +167,26 @@ class QwenLLM:
                 collect.append(x)
         return x
 
-    def prefill(self, embeds: torch.Tensor, pos: torch.Tensor, rope_delta: int = 0, collect: Optional[list] = None):
-        """embeds [L, d] bf16 device, pos [3, L] host -> (final-norm last hidden [1, d], logits [1, V], next id tensor)."""
+    def _items(self, pos0: int, kv_end: int) -> torch.Tensor:
+        key = (pos0, kv_end)
+        it = self._item_cache.get(key)
+        if it is None:
+            if len(self._item_cache) > 4096:
+                self._item_cache.clear()
+            it = torch.tensor([[q0, min(q0 + 64, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, 64)], dtype=torch.int32).to(self.dev)
+            self._item_cache[key] = it
+        return it
+
+    def prefill(self, embeds: torch.Tensor, pos: torch.Tensor, rope_delta: int = 0, collect: Optional[list] = None,
+                tables: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """embeds [L, d] bf16 device, pos [3, L] host -> (final-norm last hidden [1, d], logits [1, V], next id tensor).
+        `tables` = device (cos, sin) [L, head_dim] bf16 when the caller already uploaded them (graph replay)."""
         c = self.cfg
-        cos, sin = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
-        cos, sin = cos.to(self.dev), sin.to(self.dev)
+        if tables is None:
+            cos, sin = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
+            cos, sin = cos.to(self.dev), sin.to(self.dev)
+        else:
+            cos, sin = tables
         x = self._forward(embeds, cos, sin, 0, collect)
         self.kv_len = embeds.shape[0]
         self.rope_delta = rope_delta

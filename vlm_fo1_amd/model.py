@@ -85,6 +85,7 @@ class FO1Engine:
                                vision_tower_spatial_scale=1 / cfg.vit.patch_size,
                                use_simpleFPN_for_vt=cfg.mm_use_simpleFPN_for_vt, aux_vision_tower_spatial_scale=0.25)
         self._dummy_box = torch.tensor([[0., 10., 0., 10.]], device=self.dev)  # omchat_qwen2_5_vl.py:90-91
+        self._graphs = {}
 
     # ---- encoders ------------------------------------------------------------------------------
     def encode_images(self, pixel_values: torch.Tensor, gh: int, gw: int):
@@ -118,22 +119,71 @@ class FO1Engine:
         return self.mm_projector_aux(feat.to(torch.bfloat16))                              # :106-107
 
     # ---- one image: everything up to the first generated token -----------------------------------
+    def _device_prefill(self, pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions: bool):
+        image_tokens, vt_feats = self.encode_images(pix, gh, gw)
+        region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw) if want_regions else None
+        emb = self.llm.embed(plan_dev, image_tokens, region_tokens)
+        last, logits, tok = self.llm.prefill(emb, None, 0, tables=(cos, sin))
+        return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,
+                    next_token=tok)
+
     def prefill(self, input_ids: Sequence[int], pixel_values: torch.Tensor, grid_hw: Tuple[int, int], aux_image: torch.Tensor,
-                boxes: Optional[torch.Tensor]):
+                boxes: Optional[torch.Tensor], use_graph: bool = False):
+        """Everything up to the first greedy token.  use_graph=True replays a captured hipGraph of the ~1000
+        kernel launches for this (grid, aux size, #boxes, sequence length) signature: index plans / rope tables
+        are computed on the host and copied into the graph's static input buffers before the replay."""
+        from .llm import mrope_tables
         gh, gw = grid_hw
-        image_tokens, vt_feats = self.encode_images(pixel_values, gh, gw)
-        has_regions = any(t == DEFAULT_REGION_INDEX for t in input_ids)
-        region_tokens = self.encode_regions(aux_image, boxes, vt_feats, gh, gw) if (boxes is not None or has_regions) else None
         m = self.cfg.vit.spatial_merge_size
-        emb, pos, delta = self.llm.build_inputs(input_ids, image_tokens, region_tokens, (gh // m, gw // m))
-        last, logits, tok = self.llm.prefill(emb, pos, delta)
-        return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, position_ids=pos, rope_delta=delta,
-                    last_hidden=last, logits=logits, next_token=tok)
+        n_img = (gh // m) * (gw // m)
+        want_regions = (boxes is not None) or any(t == DEFAULT_REGION_INDEX for t in input_ids)
+        if boxes is None or boxes.shape[0] == 0:
+            boxes = self._dummy_box
+        n_reg = boxes.shape[0] if want_regions else 0
+        plan, pos, delta = self.llm.plan_inputs(input_ids, n_img, n_reg, (gh // m, gw // m))
+        c = self.cfg.llm
+        cos, sin = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
+        boxes = boxes.to(device=self.dev, dtype=torch.float32)
+        if not use_graph:
+            out = self._device_prefill(pixel_values, gh, gw, aux_image, boxes, plan.to(self.dev), cos.to(self.dev), sin.to(self.dev),
+                                       want_regions)
+        else:
+            key = (gh, gw, tuple(aux_image.shape), n_reg, plan.shape[0], want_regions, pixel_values.dtype, aux_image.dtype)
+            ent = self._graphs.get(key)
+            if ent is None:
+                st = dict(pix=pixel_values.clone(), aux=aux_image.clone(), boxes=boxes.clone(), plan=plan.to(self.dev),
+                          cos=cos.to(self.dev), sin=sin.to(self.dev))
+                # warm-up on a side stream (allocates every lazily-created scratch buffer), then capture
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._device_prefill(st["pix"], gh, gw, st["aux"], st["boxes"], st["plan"], st["cos"], st["sin"], want_regions)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    res = self._device_prefill(st["pix"], gh, gw, st["aux"], st["boxes"], st["plan"], st["cos"], st["sin"], want_regions)
+                ent = (g, st, res)
+                self._graphs[key] = ent
+            g, st, res = ent
+            st["pix"].copy_(pixel_values, non_blocking=True)
+            st["aux"].copy_(aux_image, non_blocking=True)
+            st["boxes"].copy_(boxes, non_blocking=True)
+            st["plan"].copy_(plan, non_blocking=True)
+            st["cos"].copy_(cos, non_blocking=True)
+            st["sin"].copy_(sin, non_blocking=True)
+            g.replay()
+            out = dict(res)
+        self.llm.kv_len = plan.shape[0]
+        self.llm.rope_delta = delta
+        out["position_ids"] = pos
+        out["rope_delta"] = delta
+        return out
 
     def generate(self, input_ids: Sequence[int], pixel_values, grid_hw, aux_image, boxes, max_new_tokens: int = 512,
-                 stop_ids: Sequence[int] = ()) -> List[int]:
+                 stop_ids: Sequence[int] = (), use_graph: bool = False) -> List[int]:
         """Greedy decode (do_sample=False in every reference caller: mm_utils.py:640-654)."""
-        out = self.prefill(input_ids, pixel_values, grid_hw, aux_image, boxes)
+        out = self.prefill(input_ids, pixel_values, grid_hw, aux_image, boxes, use_graph=use_graph)
         tok = out["next_token"]
         new: List[int] = []
         for _ in range(max_new_tokens):

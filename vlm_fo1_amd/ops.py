@@ -33,6 +33,19 @@ def _stream():
     return _L.current_stream_ptr()
 
 
+_gemm_ws = {}
+
+
+def _gemm_workspace(device) -> torch.Tensor:
+    """Per-device fp32 scratch for split-K partials (caller-owned memory; the library never allocates).
+    Ops on one stream are serialised, so one buffer per device is enough."""
+    ws = _gemm_ws.get(device)
+    if ws is None:
+        ws = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)  # 64 MiB
+        _gemm_ws[device] = ws
+    return ws
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
          act: int = ACT_NONE, out: Optional[torch.Tensor] = None, out_f32: bool = False) -> torch.Tensor:
     """out[M,N] = epilogue(a[M,K] @ w[N,K]^T)  (nn.Linear semantics, fo1_gemm_bf16)."""
@@ -53,9 +66,10 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if bias is not None:
         _chk(bias, "bias")
         assert bias.numel() == N and bias.is_contiguous()
-    rc = _L.load().fo1_gemm_bf16(pa, lda, pw, ldw, bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc,
-                                 M, N, K, act, 1 if out_f32 else 0, _stream())
-    _L.check(rc, "fo1_gemm_bf16")
+    ws = _gemm_workspace(a.device)
+    rc = _L.load().fo1_gemm_bf16_ws(pa, lda, pw, ldw, bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc,
+                                    M, N, K, act, 1 if out_f32 else 0, ws.data_ptr(), ws.numel() * 4, _stream())
+    _L.check(rc, "fo1_gemm_bf16_ws")
     return out
 
 
