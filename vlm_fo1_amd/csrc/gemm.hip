@@ -401,30 +401,33 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
     bool glds = (p.K % 64 == 0);
     if (g_gemm_variant == 1) glds = false;
     if (g_gemm_variant == 2 && p.K % 64 != 0) return set_err(FO1_ERR_ARG, "gemm: glds variant needs K %% 64 == 0 (K=%d)", p.K);
+    // Dispatch heuristics measured on MI355X (profiles/r01_gemm_bench_v2.log):
+    //  * 128x128 tiles once they alone give >= 3 workgroups per CU, else 64x128 if that gives >= 2 per CU,
+    //    else 64x64;
+    //  * split-K only for deep-K skinny outputs (K >= 4096, < 2 workgroups per CU): e.g. the LLM down
+    //    projection 515x2048x11008 goes 79 -> 46 us with 64x128 tiles x 8 splits; at K = 2048 the fp32
+    //    partial round trip costs more than it buys.
+    const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
+    const long long t64x128 = (long long)cdiv(p.M, 64) * cdiv(p.N, 128) * batch;
+    const int nk = p.K / 64;
     int tile = g_gemm_tile;
+    int splits = g_gemm_splitk;
+    const bool can_split = glds && batch == 1 && ws != nullptr && p.N % 4 == 0;
     if (tile == 0) {
-        // measured on MI355X (profiles/r01_gemm_bench.log): 64x128 wins once it yields >= ~2 workgroups
-        // per CU, 128x128 only for very large grids, 64x64 for everything skinny
-        const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
-        const long long t64x128 = (long long)cdiv(p.M, 64) * cdiv(p.N, 128) * batch;
-        tile = t128 >= 2048 ? 1 : (t64x128 >= 512 ? 2 : 3);
+        tile = t128 >= 768 ? 1 : (t64x128 >= 512 ? 2 : 3);
+        if (splits == 0 && can_split && nk >= 64 && t64x128 < 512) tile = 2;
     }
-    // split-K (LDS-DMA path, single batch): skinny outputs that cannot fill 256 CUs with >= 2 workgroups each
     p.splits = 1;
-    p.kper = p.K / 64 + 1;
+    p.kper = nk + 1;
     p.part = nullptr;
-    if (glds && batch == 1 && ws != nullptr && p.N % 4 == 0) {
+    if (can_split) {
         const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
         const long long tiles = (long long)cdiv(p.M, bm) * cdiv(p.N, bn);
-        const int nk = p.K / 64;
-        int splits = g_gemm_splitk;
         if (splits == 0) {
             splits = 1;
-            if (tiles < 512 && nk >= 8) {
-                splits = (int)((768 + tiles - 1) / tiles);
+            if (nk >= 64 && tiles < 512) {
+                splits = (int)((1024 + tiles - 1) / tiles);
                 if (splits > 8) splits = 8;
-                if (splits > nk / 4) splits = nk / 4;
-                if (splits < 1) splits = 1;
             }
         }
         if (splits > nk) splits = nk;

@@ -129,7 +129,7 @@ class QwenLLM:
         pos, delta = rope_index_host(n_before, grid_hw_merged, n_after)
         return torch.tensor(plan, dtype=torch.int32).reshape(-1, 2), pos, delta
 
-    def embed(self, plan_dev: torch.Tensor, image_tokens: torch.Tensor, region_tokens: Optional[torch.Tensor]):
+    def embed_rows(self, plan_dev: torch.Tensor, image_tokens: torch.Tensor, region_tokens: Optional[torch.Tensor]):
         """DEVICE part of the splice: one row gather over (embed table | image tokens | region tokens)."""
         return ops.gather_rows(plan_dev, self.cfg.hidden_size, self.embed, image_tokens, region_tokens)
 
@@ -138,7 +138,7 @@ class QwenLLM:
         """Sentinel ids -> (embeds [L', d] on device, pos [3, L'] host, rope delta)."""
         n_reg = 0 if region_tokens is None else region_tokens.shape[0]
         plan, pos, delta = self.plan_inputs(input_ids, image_tokens.shape[0], n_reg, grid_hw_merged)
-        return self.embed(plan.to(self.dev), image_tokens, region_tokens), pos, delta
+        return self.embed_rows(plan.to(self.dev), image_tokens, region_tokens), pos, delta
 
     # ---- transformer -------------------------------------------------------------------------
     def _forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, collect: Optional[list] = None):

@@ -122,7 +122,7 @@ class FO1Engine:
     def _device_prefill(self, pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions: bool):
         image_tokens, vt_feats = self.encode_images(pix, gh, gw)
         region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw) if want_regions else None
-        emb = self.llm.embed(plan_dev, image_tokens, region_tokens)
+        emb = self.llm.embed_rows(plan_dev, image_tokens, region_tokens)
         last, logits, tok = self.llm.prefill(emb, None, 0, tables=(cos, sin))
         return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,
                     next_token=tok)
