@@ -186,8 +186,7 @@ def main():
         L.load().fo1_gemm_profile_shapes(1 if args.profile_shapes else 0)
         L.profile(True)
         for _ in range(min(args.steps, 50)):
-            pipe.step()
-        torch.cuda.synchronize()
+            pipe.step(graph=False)   # per-kernel hipEvents need individual launches, not a graph replay
         torch.cuda.synchronize()
         rows = L.profile_rows(reset=True)
         L.profile(False)

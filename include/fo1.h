@@ -174,7 +174,8 @@ int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst,
  * Fused attention  softmax(scale * Q K^T [+ causal mask]) V   (flash_attn_varlen_func /
  * _flash_attention_forward / SDPA at modeling_qwen2_5_vl.py:205,319,895,990; DaViT window
  * attention modeling_davit.py:262-270).  head_dim in {32, 80, 128}; GQA via n_q_heads/n_kv_heads.
- * `items` = device int32[n_items][4] {q_start, q_end, kv_start, kv_end}: each item is <= 64
+ * `items` = device int32[n_items][4] {q_start, q_end, kv_start, kv_end}: each item is <= q_block
+ * (16, 32 or 64: one wave per 16 queries; smaller blocks = more workgroups for short sequences)
  * queries attending keys [kv_start, kv_end) (and key <= query when causal); kv_start % 4 == 0.
  * V is passed transposed: VT[(kv_head*head_dim + d)*vt_row_stride + key] (fo1_transpose_bf16),
  * finite beyond kv_end up to the next multiple of 4.  Strides in elements.
@@ -183,8 +184,8 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
                        const void* K, long long k_tok_stride, long long k_head_stride,
                        const void* VT, long long vt_row_stride,
                        void* O, long long o_tok_stride, long long o_head_stride,
-                       const int32_t* items, int n_items, int n_q_heads, int n_kv_heads, int head_dim,
-                       float scale, int causal, double flops_hint, void* stream);
+                       const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads,
+                       int head_dim, float scale, int causal, double flops_hint, void* stream);
 
 /* ------------------------------------------------------------------------
  * DaViT / SimpleFPN / splice data-movement kernels on token-major bf16 maps [H*W, C] (C % 8 == 0).

@@ -23,7 +23,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 struct AttnItem {
-    int q_start, q_end;    // queries [q_start, q_end), q_end - q_start <= 64
+    int q_start, q_end;    // queries [q_start, q_end), q_end - q_start <= q_block (16 per wave)
     int kv_start, kv_end;  // keys [kv_start, kv_end); causal: additionally key <= query (same index space)
 };
 
@@ -38,8 +38,9 @@ struct AttnParams {
     int causal;
 };
 
-template <int HD>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+template <int HD, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int NT = NW * 64;
     constexpr int HDP = (HD + 31) / 32 * 32;  // head dim padded to the MFMA K step
     constexpr int NC = HDP / 32;              // 32-wide d chunks for QK^T
     constexpr int NDB = HD / 16;              // 16-wide d blocks for PV
@@ -84,14 +85,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         __syncthreads();  // previous tile fully consumed
         // ---- stage K tile: [KB][HDP] (zero beyond HD / beyond kv_hi) ----
         constexpr int KCH = HDP / 8;  // 16-B chunks per row
-        for (int q = tid; q < KB * KCH; q += 256) {
+        for (int q = tid; q < KB * KCH; q += NT) {
             const int r = q / KCH, c = q - r * KCH;
             uint4 v = uint4{0, 0, 0, 0};
             if (k0 + r < kv_hi && c * 8 < HD) v = *reinterpret_cast<const uint4*>(Kb + (long long)(k0 + r) * p.k_tok + c * 8);
             *reinterpret_cast<uint4*>(&sK[r * LDKR + c * 8]) = v;
         }
         // ---- stage V^T tile: [HD][KB] in 8-byte pieces (kv_start and vt_row are multiples of 4) ----
-        for (int q = tid; q < HD * (KB / 4); q += 256) {
+        for (int q = tid; q < HD * (KB / 4); q += NT) {
             const int d = q / (KB / 4), c = q - d * (KB / 4);
             uint2 v = uint2{0, 0};
             if (k0 + c * 4 < kv_hi) v = *reinterpret_cast<const uint2*>(VTb + (long long)d * p.vt_row + k0 + c * 4);
@@ -184,8 +185,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
 }
 
 template <int HD>
-static int launch_attn(const AttnParams& p, hipStream_t st, double flops) {
-    FO1_LAUNCH("attn_fwd", flops, attn_fwd_kernel<HD>, dim3(p.n_items, p.Hq), dim3(256), 0, st, p);
+static int launch_attn(const AttnParams& p, int q_block, hipStream_t st, double flops) {
+    if (q_block == 16)
+        FO1_LAUNCH("attn_fwd", flops, (attn_fwd_kernel<HD, 1>), dim3(p.n_items, p.Hq), dim3(64), 0, st, p);
+    else if (q_block == 32)
+        FO1_LAUNCH("attn_fwd", flops, (attn_fwd_kernel<HD, 2>), dim3(p.n_items, p.Hq), dim3(128), 0, st, p);
+    else
+        FO1_LAUNCH("attn_fwd", flops, (attn_fwd_kernel<HD, 4>), dim3(p.n_items, p.Hq), dim3(256), 0, st, p);
     return FO1_OK;
 }
 
@@ -197,13 +203,14 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
                        const void* K, long long k_tok_stride, long long k_head_stride,
                        const void* VT, long long vt_row_stride,
                        void* O, long long o_tok_stride, long long o_head_stride,
-                       const int32_t* items, int n_items, int n_q_heads, int n_kv_heads, int head_dim,
+                       const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads, int head_dim,
                        float scale, int causal, double flops_hint, void* stream) {
     using namespace fo1;
     if (n_items == 0) return FO1_OK;
     FO1_CHECK_ARG(Q && K && VT && O && items, "attention: NULL operand");
     FO1_CHECK_ARG(n_items > 0 && n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, "attention: bad head counts");
     FO1_CHECK_ARG(head_dim == 32 || head_dim == 80 || head_dim == 128, "attention: head_dim %d not built (32, 80, 128)", head_dim);
+    FO1_CHECK_ARG(q_block == 16 || q_block == 32 || q_block == 64, "attention: q_block %d must be 16, 32 or 64", q_block);
     FO1_CHECK_ARG(q_tok_stride % 8 == 0 && q_head_stride % 8 == 0 && k_tok_stride % 8 == 0 && k_head_stride % 8 == 0,
                   "attention: Q/K strides must be multiples of 8 elements");
     FO1_CHECK_ARG(vt_row_stride % 4 == 0 && o_tok_stride % 4 == 0 && o_head_stride % 4 == 0,
@@ -219,9 +226,9 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
     p.n_items = n_items; p.Hq = n_q_heads; p.group = n_q_heads / n_kv_heads;
     p.scale = scale; p.causal = causal;
     hipStream_t st = (hipStream_t)stream;
-    if (head_dim == 32) return launch_attn<32>(p, st, flops_hint);
-    if (head_dim == 80) return launch_attn<80>(p, st, flops_hint);
-    return launch_attn<128>(p, st, flops_hint);
+    if (head_dim == 32) return launch_attn<32>(p, q_block, st, flops_hint);
+    if (head_dim == 80) return launch_attn<80>(p, q_block, st, flops_hint);
+    return launch_attn<128>(p, q_block, st, flops_hint);
 }
 
 }  // extern "C"

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void window_reverse_add_kernel(const uint16_t*
 // ---- channel attention (group width 32) -------------------------------------------------------
 // qkv: [N, 3C] rows = [q | k | v].  Phase 1: partial Gram matrices over token chunks.
 //   part[chunk][g][c][c'] = sum_{n in chunk} q[n, g*32+c] * k[n, g*32+c']      (fp32)
-constexpr int kCaTok = 256;  // tokens per chunk
+constexpr int kCaTok = 512;  // tokens per chunk
 __global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, float* __restrict__ part) {
     __shared__ float sq[64][33];
     __shared__ float sk[64][33];
@@ -159,23 +159,33 @@ __global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __rest
     o[(2 * ci + 1) * 32 + 2 * cj] = a10; o[(2 * ci + 1) * 32 + 2 * cj + 1] = a11;
 }
 
-// Phase 2: A[g][c][:] = softmax_c'( bf16( scale * sum_chunks part ) ) rounded to bf16 (stored fp32)
-__global__ __launch_bounds__(64) void chattn_softmax_kernel(const float* __restrict__ part, int n_chunks, int G, float scale,
-                                                            float* __restrict__ A) {
-    const int g = blockIdx.x, lane = threadIdx.x;  // 64 lanes: 2 rows at a time
-    for (int r0 = 0; r0 < 32; r0 += 2) {
-        const int r = r0 + (lane >> 5), c = lane & 31;
-        float s = 0.f;
-        for (int k = 0; k < n_chunks; ++k) s += part[(((long long)k * G + g) * 32 + r) * 32 + c];
-        s = rbf(s * scale);
-        float m = s;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        float e = expf(s - m), sum = e;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        A[((long long)g * 32 + r) * 32 + c] = rbf(e / sum);
+// Phase 2: A[g][c][:] = softmax_c'( bf16( scale * sum_chunks part ) ) rounded to bf16 (stored fp32).
+// One 1024-thread workgroup per group: thread (r, c) sums its element over the chunks in a fixed order
+// (4 independent loads in flight), rows are 32-lane halves of a wave.
+__global__ __launch_bounds__(1024) void chattn_softmax_kernel(const float* __restrict__ part, int n_chunks, int G, float scale,
+                                                              float* __restrict__ A) {
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int r = tid >> 5, c = tid & 31;
+    const long long stride = (long long)G * 1024;
+    const float* p = part + ((long long)g * 32 + r) * 32 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = 0;
+    for (; k + 4 <= n_chunks; k += 4) {
+        s0 += p[(long long)k * stride];
+        s1 += p[(long long)(k + 1) * stride];
+        s2 += p[(long long)(k + 2) * stride];
+        s3 += p[(long long)(k + 3) * stride];
     }
+    for (; k < n_chunks; ++k) s0 += p[(long long)k * stride];
+    float s = rbf(((s0 + s1) + (s2 + s3)) * scale);
+    float m = s;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    const float e = expf(s - m);
+    float sum = e;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    A[((long long)g * 32 + r) * 32 + c] = rbf(e / sum);
 }
 
 // Phase 3: out[n, g*32 + c] = bf16( sum_c' A[g][c][c'] * v[n, g*32 + c'] )
@@ -329,7 +339,7 @@ int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out,
     hipStream_t st = (hipStream_t)stream;
     FO1_LAUNCH("chattn_gram", (double)N * C * 4.0, chattn_gram_kernel, dim3(chunks, G), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part);
     // reference: q * N^-0.5 (modeling_davit.py:165)
-    FO1_LAUNCH("chattn_softmax", (double)chunks * G * 4096.0, chattn_softmax_kernel, dim3(G), dim3(64), 0, st, (const float*)part, chunks, G,
+    FO1_LAUNCH("chattn_softmax", (double)chunks * G * 4096.0, chattn_softmax_kernel, dim3(G), dim3(1024), 0, st, (const float*)part, chunks, G,
                1.0f / sqrtf((float)N), A);
     int gx = cdiv(N, 8);
     if (gx > 512) gx = 512;

@@ -70,13 +70,15 @@ class DaViT:
                     blk[name] = d
                 stage.append(blk)
             self.blocks.append(stage)
-        self._items: Dict[int, torch.Tensor] = {}
+        self._items: Dict[Tuple[int, int], torch.Tensor] = {}
         self._vt: Dict[Tuple[int, int], torch.Tensor] = {}
 
-    def _window_items(self, n_windows: int, ws2: int):
-        if n_windows not in self._items:
-            self._items[n_windows] = ops.make_items([(i * ws2, (i + 1) * ws2) for i in range(n_windows)], self.dev)
-        return self._items[n_windows]
+    def _window_items(self, n_windows: int, ws2: int, heads: int):
+        key = (n_windows, heads)
+        if key not in self._items:
+            segs = [(i * ws2, (i + 1) * ws2) for i in range(n_windows)]
+            self._items[key] = ops.make_items(segs, self.dev, block=ops.pick_q_block(segs, heads))
+        return self._items[key]
 
     def _ffn(self, x, d):
         h = ops.layernorm(x, d["fn_w"], d["fn_b"], 1e-5)
@@ -96,7 +98,7 @@ class DaViT:
         vt = self._vt[key]
         ops.transpose_into(qkv[:, 2 * C:], vt, 0)
         hd = C // heads
-        items = self._window_items(n // (ws * ws), ws * ws)
+        items = self._window_items(n // (ws * ws), ws * ws, heads)
         att = ops.attention(qkv[:, :C], qkv[:, C:2 * C], vt, items, heads, heads, hd, float(hd) ** -0.5, False,
                             flops=4.0 * C * n * ws * ws)
         y = ops.gemm(att, d["proj_w"], d["proj_b"])

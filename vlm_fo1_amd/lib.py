@@ -60,7 +60,7 @@ SIGNATURES = {
     "fo1_rope_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "fo1_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p]),
     "fo1_attention_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,
-                                   c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_float, c_int, ctypes.c_double, c_void_p]),
     "fo1_dwconv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fo1_im2col_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
@@ -119,9 +119,9 @@ def profile(on: bool) -> None:
 
 def profile_rows(reset: bool = True):
     """-> list of dict(name, calls, total_ms, total_work) since the last reset."""
-    rows = (ProfileRow * 64)()
-    n = load().fo1_profile_read(rows, 64, 1 if reset else 0)
+    rows = (ProfileRow * 512)()
+    n = load().fo1_profile_read(rows, 512, 1 if reset else 0)
     if n < 0:
         check(n, "fo1_profile_read")
     return [dict(name=rows[i].name.decode(), calls=rows[i].calls, total_ms=rows[i].total_ms,
-                 total_work=rows[i].total_work) for i in range(min(n, 64))]
+                 total_work=rows[i].total_work) for i in range(min(n, 512))]

@@ -173,7 +173,9 @@ class QwenLLM:
         if it is None:
             if len(self._item_cache) > 4096:
                 self._item_cache.clear()
-            it = torch.tensor([[q0, min(q0 + 64, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, 64)], dtype=torch.int32).to(self.dev)
+            blk = ops.pick_q_block([(pos0, kv_end)], self.cfg.num_heads)
+            it = torch.tensor([[q0, min(q0 + blk, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, blk)], dtype=torch.int32).to(self.dev)
+            it.q_block = blk
             self._item_cache[key] = it
         return it
 

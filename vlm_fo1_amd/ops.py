@@ -157,14 +157,25 @@ def transpose_into(src: torch.Tensor, dst: torch.Tensor, col0: int = 0) -> None:
     _L.check(_L.load().fo1_transpose_bf16(p, ld, pd, ldd, col0, M, C, _stream()), "fo1_transpose_bf16")
 
 
+def pick_q_block(segments: Sequence[Sequence[int]], n_heads: int, target_wgs: int = 512) -> int:
+    """Largest query block (64/32/16 = 4/2/1 waves) that still yields >= target_wgs workgroups (2 per CU)."""
+    for blk in (64, 32):
+        if sum((e - s + blk - 1) // blk for s, e in segments) * n_heads >= target_wgs:
+            return blk
+    return 16
+
+
 def make_items(segments: Sequence[Sequence[int]], device, causal: bool = False, block: int = 64) -> torch.Tensor:
     """Host-side work list for fo1_attention_bf16: split every segment [start, end) into query blocks
-    of <= 64.  Index bookkeeping belongs on the host."""
+    of <= block.  Index bookkeeping belongs on the host.  The block size rides along as
+    attribute `q_block` of the returned tensor."""
     rows = []
     for s, e in segments:
         for q0 in range(s, e, block):
             rows.append((q0, min(q0 + block, e), s, e))
-    return torch.tensor(rows, dtype=torch.int32).reshape(-1, 4).to(device)
+    t = torch.tensor(rows, dtype=torch.int32).reshape(-1, 4).to(device)
+    t.q_block = block
+    return t
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_q_heads: int, n_kv_heads: int,
@@ -181,7 +192,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.T
         out = torch.empty(L, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
     po, ldo, _, _ = _rows(out, "out")
     rc = _L.load().fo1_attention_bf16(pq, ldq, head_dim, pk, ldk, head_dim, pv, ldv, po, ldo, head_dim,
-                                      items.data_ptr(), items.shape[0], n_q_heads, n_kv_heads, head_dim, float(scale),
+                                      items.data_ptr(), items.shape[0], getattr(items, "q_block", 64), n_q_heads, n_kv_heads,
+                                      head_dim, float(scale),
                                       1 if causal else 0, float(flops), _stream())
     _L.check(rc, "fo1_attention_bf16")
     return out
@@ -320,7 +332,8 @@ def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.T
         out = torch.empty(Lq, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
     po, ldo, _, _ = _rows(out, "out")
     rc = _L.load().fo1_attention_bf16(pq - q_row0 * ldq * 2, ldq, head_dim, k.data_ptr(), k.stride(1), k.stride(0), pv, ldv,
-                                      po - q_row0 * ldo * 2, ldo, head_dim, items.data_ptr(), items.shape[0], n_q_heads,
+                                      po - q_row0 * ldo * 2, ldo, head_dim, items.data_ptr(), items.shape[0],
+                                      getattr(items, "q_block", 64), n_q_heads,
                                       n_kv_heads, head_dim, float(scale), 1 if causal else 0, float(flops), _stream())
     _L.check(rc, "fo1_attention_bf16")
     return out

@@ -84,8 +84,9 @@ class GridPlan:
         self.plan_tokens = torch.stack([zu, inv_unit.to(torch.int32)], 1).contiguous().to(device)
         self.cos = fr.cos().contiguous().to(device)
         self.sin = fr.sin().contiguous().to(device)
-        self.items_win = ops.make_items([(a, b) for a, b in zip(cu[:-1], cu[1:])], device)
-        self.items_full = ops.make_items([(0, S)], device)
+        wins = [(a, b) for a, b in zip(cu[:-1], cu[1:])]
+        self.items_win = ops.make_items(wins, device, block=ops.pick_q_block(wins, cfg.num_heads))
+        self.items_full = ops.make_items([(0, S)], device, block=ops.pick_q_block([(0, S)], cfg.num_heads))
         self.cu_window = cu
         self.Sp = _round_up(S, 64)
 
