@@ -1,0 +1,82 @@
+"""COCO-val proposal classification with the MI355X engine — same CLI, inputs and output file as the
+reference's evaluation/eval_coco.py:12-100 (per image: prompt with the UPN proposals -> generate -> regex ->
+COCO-json records with the ORIGINAL proposal box and its UPN score), plus sharding over the GPUs of one node:
+
+    python evaluation/eval_coco.py --model_id resources/VLM-FO1_Qwen2.5-VL-3B-v01 ...            # 1 GPU
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 evaluation/eval_coco.py ...               # 8 GPUs
+
+Images are dealt to ranks by cost; the only collective is the final gather of generated token ids
+(vlm_fo1_amd/sharded_eval.py); rank 0 writes a dump byte-identical to the 1-GPU run."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from vlm_fo1.mm_utils import extract_predictions_to_indexes, prepare_inputs  # noqa: E402
+from vlm_fo1.model.builder import load_pretrained_model  # noqa: E402
+from vlm_fo1_amd import sharded_eval as SE  # noqa: E402
+
+
+def records_from_answer(ans, data, cat_ids):
+    """One image's COCO records (reference eval_coco.py:68-85)."""
+    out = []
+    for label, idxs in extract_predictions_to_indexes(ans).items():
+        for b in idxs:
+            box, score = data["bbox_list"][b], data["score_list"][b]
+            if label in cat_ids:
+                out.append({"image_id": data["id"], "category_id": cat_ids[label],
+                            "bbox": [box[0], box[1], box[2] - box[0], box[3] - box[1]], "score": score})
+    return out
+
+
+def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=None, device="cuda:0"):
+    rank, world, local = SE.init_distributed()
+    if world > 1:
+        device = f"cuda:{local}"
+    print(f"Evaluating {model_id} on {eval_data_path}... (rank {rank}/{world})")
+    tokenizer, model, image_processors = load_pretrained_model(model_id, device=device)
+    with open(eval_data_path) as f:
+        data_list = [json.loads(line) for line in f]
+    cat_ids = {c["name"]: c["id"] for c in json.load(open(original_data_path))["categories"]}
+
+    def generate(i):
+        d = data_list[i]
+        messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(img_folder, d["image"])}},
+                                                 {"type": "text", "text": d["conversations"][0]["value"]}],
+                     "bbox_list": d["bbox_list"]}]
+        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
+                            temperature=0.0, do_sample=False)
+        kw["streamer"] = None
+        out = model.generate(**kw)
+        return out[0, kw["inputs"].shape[1]:].tolist()
+
+    costs = [len(d["bbox_list"]) + 64 for d in data_list]     # boxes drive prompt length; image size unknown before load
+    merged = SE.run_sharded(len(data_list), costs, generate, device=device if world > 1 else "cpu")
+    if rank != 0:
+        return
+    res = []
+    for i, toks in merged:
+        if toks is None:
+            print(f"Error: {data_list[i]['id']}")
+            continue
+        ans = tokenizer.decode(toks).strip()
+        res.extend(records_from_answer(ans, data_list[i], cat_ids))
+    output_path = os.path.join(out_dir, model_id.split("/")[-1])
+    os.makedirs(output_path, exist_ok=True)
+    out_file = f"{output_path}/{eval_data_path.split('/')[-1].replace('.jsonl', '')}_predictions.json"
+    json.dump(res, open(out_file, "w"))
+    print(f"predictions saved to: {out_file}")
+
+
+if __name__ == "__main__":
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("--model_id", type=str, default="resources/VLM-FO1_Qwen2.5-VL-3B-v01")
+    p.add_argument("--eval_data_path", type=str, default="evaluation/processed_data/cocoVal2017_with_upn_score_0.3_0.8.jsonl")
+    p.add_argument("--original_data_path", type=str, default="evaluation/processed_data/instances_val2017.json")
+    p.add_argument("--img_folder", type=str, default="data/coco/val2017")
+    p.add_argument("--out_dir", type=str, default="./evaluation")
+    p.add_argument("--device", type=str, default="cuda:0")
+    a = p.parse_args()
+    eval_coco(a.model_id, a.eval_data_path, a.original_data_path, a.img_folder, a.out_dir, a.device)

@@ -1,0 +1,68 @@
+"""CountBench / Pixmo-Count accuracy with the MI355X engine — same CLI and scoring as the reference's
+evaluation/eval_countbench.py:14-76 (first integer of the answer after stripping <regionN> tags), sharded over
+the GPUs of one node like eval_coco.py (torchrun --nproc-per-node N).  Variable box counts (2..100 per image)
+are balanced across ranks by cost."""
+import json
+import os
+import re
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from vlm_fo1.mm_utils import prepare_inputs  # noqa: E402
+from vlm_fo1.model.builder import load_pretrained_model  # noqa: E402
+from vlm_fo1_amd import sharded_eval as SE  # noqa: E402
+
+
+def count_from_answer(outputs: str) -> int:
+    """reference eval_countbench.py:48-53"""
+    ans = re.sub(r"<region\d+>", "", outputs)
+    numbers = re.findall(r"(?<!region)\d+", ans)
+    return int(numbers[0]) if numbers else 0
+
+
+def eval_countbench(data_path, image_path, model_id, device):
+    rank, world, local = SE.init_distributed()
+    if world > 1:
+        device = f"cuda:{local}"
+    tokenizer, model, image_processors = load_pretrained_model(model_id, device=device)
+    with open(data_path) as f:
+        data = json.load(f)
+
+    def generate(i):
+        item = data[i]
+        messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(image_path, item["image"])}},
+                                                 {"type": "text", "text": item["question"]}], "bbox_list": item["bboxes"]}]
+        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
+                            temperature=0.0, do_sample=False)
+        kw["streamer"] = None
+        out = model.generate(**kw)
+        return out[0, kw["inputs"].shape[1]:].tolist()
+
+    costs = [len(item["bboxes"]) + 64 for item in data]
+    merged = SE.run_sharded(len(data), costs, generate, device=device if world > 1 else "cpu")
+    if rank != 0:
+        return None
+    correct = total = 0
+    for i, toks in merged:
+        gt = data[i]["answer"]
+        outputs = tokenizer.decode(toks).strip() if toks is not None else ""
+        pred = count_from_answer(outputs)
+        total += 1
+        correct += int(pred == gt)
+        if gt != pred:
+            print(f"gt is {gt}, but pred is {outputs}")
+    accuracy = correct / total if total > 0 else 0
+    print(f"Accuracy: {accuracy:.4f}")
+    return accuracy
+
+
+if __name__ == "__main__":
+    import argparse
+    p = argparse.ArgumentParser()
+    p.add_argument("--data_path", type=str, default="evaluation/processed_data/countbench_with_upn_score_0.3_0.8.json")
+    p.add_argument("--image_path", type=str, default="data/CountBenchQA/images")
+    p.add_argument("--model_id", type=str, default="resources/VLM-FO1_Qwen2.5-VL-3B-v01")
+    p.add_argument("--device", type=str, default="cuda:0")
+    a = p.parse_args()
+    eval_countbench(a.data_path, a.image_path, a.model_id, a.device)

@@ -1,0 +1,115 @@
+"""GPU test of the drop-in boundary end to end: a synthetic checkpoint directory (config.json + safetensors with
+the reference's key names) -> vlm_fo1.model.builder.load_pretrained_model -> vlm_fo1.mm_utils.prepare_inputs ->
+model.generate(**kwargs) -> slice / decode / extract exactly as the reference's inference.py:37-52 does."""
+import json
+import os
+import types
+
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+CONFIG = {
+    "model_type": "omchat_qwen2_5_vl", "hidden_size": 2048, "num_hidden_layers": 2, "num_attention_heads": 16,
+    "num_key_value_heads": 2, "intermediate_size": 11008, "vocab_size": 8192, "rms_norm_eps": 1e-6, "rope_theta": 1000000.0,
+    "rope_scaling": {"type": "mrope", "mrope_section": [16, 24, 24]}, "tie_word_embeddings": True, "eos_token_id": 151645,
+    "vision_config": {"depth": 2, "hidden_size": 1280, "num_heads": 16, "intermediate_size": 3420, "out_hidden_size": 2048,
+                      "patch_size": 14, "spatial_merge_size": 2, "temporal_patch_size": 2, "window_size": 112,
+                      "fullatt_block_indexes": [1]},
+    "mm_vision_tower": "qwen2.5-vl", "mm_vision_tower_aux": "davit-large", "mm_projector_type": "mlp2x_gelu",
+    "mm_projector_aux_type": "mlp2x_gelu", "mm_use_vision_tower_region_feature": True, "mm_use_simpleFPN_for_vt": True,
+    "mm_region_hidden_size": 5888, "mm_use_region_index_token": True, "aux_image_size": 768, "aux_image_aspect_ratio": "dynamic",
+}
+
+
+def checkpoint_state():
+    from vlm_fo1.model.fo1_model import FO1HFConfig
+    from vlm_fo1_amd.model import random_weights
+    w = random_weights(FO1HFConfig(CONFIG).engine_config(), "cuda", seed=2)
+    state = {}
+    for k, v in w["vit"].items():
+        state["model.vision_tower.image_tower." + k] = v
+    for k, v in w["davit"].items():
+        state["model.vision_tower_aux.image_tower." + k] = v
+    for k, v in w["fpn"].items():
+        state["model.object_vp_extractor.simple_fpn." + k] = v
+    for k, v in w["proj"].items():
+        state["model." + k] = v
+    for k, v in w["llm"].items():
+        state["model." + k] = v
+    return state
+
+
+def test_load_prepare_generate_roundtrip(tmp_path, monkeypatch):
+    from safetensors.torch import save_file
+    from test_dropin_surface import ToyTokenizer
+    from vlm_fo1 import mm_utils as MU
+    from vlm_fo1.model import builder
+    from vlm_fo1.task_templates import OD_template
+    model_dir = tmp_path / "VLM-FO1_Qwen2.5-VL-3B-v01"
+    model_dir.mkdir()
+    state = {k: v.cpu().contiguous() for k, v in checkpoint_state().items()}
+    keys = sorted(state)
+    half = len(keys) // 2                                   # sharded checkpoint: two safetensors files
+    save_file({k: state[k] for k in keys[:half]}, str(model_dir / "model-00001-of-00002.safetensors"))
+    save_file({k: state[k] for k in keys[half:]}, str(model_dir / "model-00002-of-00002.safetensors"))
+    json.dump(CONFIG, open(model_dir / "config.json", "w"))
+    json.dump({"eos_token_id": [151645, 151643]}, open(model_dir / "generation_config.json", "w"))
+
+    class Tok(ToyTokenizer):
+        def _enc(self, text):
+            return [i % 8000 + 100 for i in super()._enc(text)]
+
+        def decode(self, ids, **kw):
+            return " ".join(str(int(i)) for i in ids)
+
+    monkeypatch.setattr(builder, "_load_tokenizer", lambda p: Tok())
+    tokenizer, model, procs = builder.load_pretrained_model(str(model_dir), device="cuda")
+    assert model.config.mm_use_region_index_token is True and model.get_vision_tower().is_loaded
+
+    img_path = str(tmp_path / "demo.jpg")
+    Image.effect_noise((500, 399), 64).convert("RGB").save(img_path)
+    boxes = [[161.0, 11.0, 292.0, 127.0], [268.0, 61.0, 428.0, 226.0], [12.0, 100.0, 140.0, 227.0]]
+    messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": img_path}},
+                                             {"type": "text", "text": OD_template.format("orange")}], "bbox_list": boxes}]
+    kw = MU.prepare_inputs(str(model_dir), model, procs, tokenizer, messages, max_tokens=5, top_p=0.05, temperature=0.0, do_sample=False)
+    kw["streamer"] = None
+    with torch.inference_mode():
+        out = model.generate(**kw)
+    L = kw["inputs"].shape[1]
+    assert out.shape[0] == 1 and L < out.shape[1] <= L + 5 and torch.equal(out[0, :L].cpu(), kw["inputs"][0].cpu())
+    new = out[0, L:].tolist()
+    text = tokenizer.decode(out[0, L:]).strip()
+    assert MU.extract_predictions_to_bboxes(text, boxes) == {}     # random weights: no markup, parser must cope
+    # same tokens from the engine called directly (graph replay on: second call hits the captured graph)
+    out2 = model.generate(**kw)
+    assert out2[0, L:].tolist() == new
+    model.use_graph = False
+    out3 = model.generate(**kw)
+    assert out3[0, L:].tolist() == new, "graph replay and eager launches must decode the same tokens"
+    # EOS handling: make the first generated token an EOS -> generation stops right after it
+    model.config._gen["eos_token_id"] = [new[0]]
+    out4 = model.generate(**kw)
+    assert out4.shape[1] == L + 1
+    # errors the reference raises, kept: more <regionfeat> placeholders than boxes after the 100-box cap -> IndexError
+    kw_bad = dict(kw)
+    kw_bad["bbox_list"] = [kw["bbox_list"][0][:2]]
+    with pytest.raises(IndexError):
+        model.generate(**kw_bad)
+
+
+def test_unknown_checkpoint_key_and_unsupported_config_fail_loudly():
+    from vlm_fo1.model import builder
+    st = {"model.vision_tower.image_tower.x": torch.zeros(1), "model.something_else.weight": torch.zeros(1)}
+    with pytest.raises(KeyError):
+        builder.split_checkpoint(st)
+    with pytest.raises(Exception):
+        builder.split_checkpoint({"model.norm.weight": torch.zeros(1)})
+    from vlm_fo1.model.fo1_model import FO1HFConfig
+    bad = dict(CONFIG); bad["mm_region_feature_combination"] = "mean"
+    with pytest.raises(NotImplementedError):
+        FO1HFConfig(bad).engine_config()
+    with pytest.raises(NotImplementedError):
+        builder.load_pretrained_model("x/vlm-fo1_qwen2.5-vl", load_8bit=True)

@@ -1,0 +1,72 @@
+"""CPU tests of the N>1 path (world_size 2, gloo): cost-balanced sharding with no data-path collective and
+one gather at the reducer; rank 0's merged result must equal the single-process result, including a failed
+item and ragged token counts."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from vlm_fo1_amd import sharded_eval as SE
+
+
+def fake_generate(i):
+    if i == 5:
+        raise RuntimeError("boom")
+    return [(i * 7 + k) % 1000 for k in range(1 + i % 4)]
+
+
+def _worker(rank, world, port, n, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    SE.init_distributed("gloo")
+    costs = [(i % 5) + 1 for i in range(n)]
+    merged = SE.run_sharded(n, costs, fake_generate, device="cpu")
+    if rank == 0:
+        q.put(merged)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def test_assign_is_balanced_and_complete():
+    costs = [100, 1, 1, 1, 50, 50, 2, 3, 99, 4]
+    for w in (1, 2, 4, 8):
+        shards = SE.assign(costs, w)
+        assert sorted(i for s in shards for i in s) == list(range(len(costs)))
+        loads = [sum(costs[i] for i in s) for s in shards]
+        assert max(loads) - min(loads) <= max(costs)
+    assert SE.assign(costs, 2) == SE.assign(costs, 2)  # deterministic
+
+
+def test_world_size_2_gather_equals_single_process():
+    n = 23
+    single = sorted([(i, None if i == 5 else fake_generate(i)) for i in range(n)], key=lambda r: r[0])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert merged == single
+
+
+def test_eval_parsers_known_answers():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "evaluation"))
+    from eval_coco import records_from_answer
+    from eval_countbench import count_from_answer
+    assert count_from_answer("<region3><region12> There are 7 objects, 2 big") == 7
+    assert count_from_answer("none") == 0
+    data = {"id": 42, "bbox_list": [[0, 0, 10, 20], [5, 5, 15, 25]], "score_list": [0.9, 0.5]}
+    recs = records_from_answer("<ground>person</ground><objects><region1></objects><ground>ufo</ground><objects><region0></objects>",
+                               data, {"person": 1})
+    assert recs == [{"image_id": 42, "category_id": 1, "bbox": [5, 5, 10, 20], "score": 0.5}]

@@ -1,0 +1,102 @@
+"""`load_pretrained_model` of the drop-in surface.
+
+Same signature and return value as the reference's `vlm_fo1/model/builder.py:8-142`:
+
+    tokenizer, model, (primary_image_processor, aux_image_processor) = load_pretrained_model(model_path, device="cuda")
+
+but the model is the MI355X engine (vlm_fo1_amd.model.FO1Engine over libfo1hip.so): the checkpoint's
+safetensors are read straight into the engine's weight layout (fused QKV / gate-up, padded MLP, GEMM-shaped conv
+weights) — no HF `from_pretrained`, no flash-attn, no torchvision.  The reference's name gates on the path
+('vlm-fo1', 'qwen2.5-vl') are kept (:35,39)."""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, Tuple
+
+import torch
+
+from vlm_fo1.model.fo1_model import FO1ForCausalLM, FO1HFConfig
+from vlm_fo1.model.image_processing import CLIPStyleAuxProcessor, Qwen2VLPatchProcessor
+
+_PREFIXES = (  # checkpoint prefix -> engine sub-dict   (reference builder.py:113-129 and the module tree of omchat_arch.py:8-33)
+    ("model.vision_tower.image_tower.", "vit"),
+    ("model.vision_tower_aux.image_tower.", "davit"),
+    ("model.object_vp_extractor.simple_fpn.", "fpn"),
+    ("model.mm_projector_aux.", "proj:mm_projector_aux."),
+    ("model.mm_projector.", "proj:mm_projector."),
+    ("model.embed_tokens.", "llm:embed_tokens."),
+    ("model.layers.", "llm:layers."),
+    ("model.norm.", "llm:norm."),
+    ("lm_head.", "llm:lm_head."),
+)
+
+
+def split_checkpoint(state: Dict[str, torch.Tensor]) -> Dict[str, Dict[str, torch.Tensor]]:
+    """Route flat checkpoint keys into the engine's sub state-dicts; unknown keys are an error (the reference
+    loads the towers with strict=True, builder.py:116,126)."""
+    out: Dict[str, Dict[str, torch.Tensor]] = dict(vit={}, davit={}, fpn={}, llm={}, proj={})
+    unknown = []
+    for k, v in state.items():
+        for prefix, dest in _PREFIXES:
+            if k.startswith(prefix):
+                sub, _, new_prefix = dest.partition(":")
+                out[sub][new_prefix + k[len(prefix):]] = v
+                break
+        else:
+            if k.endswith("rotary_emb.inv_freq") or ".rotary_pos_emb.inv_freq" in k:
+                continue  # non-persistent buffers some exporters keep
+            unknown.append(k)
+    if unknown:
+        raise KeyError(f"{len(unknown)} checkpoint tensors have no place in the MI355X engine, e.g. {unknown[:5]}")
+    if not out["vit"]:
+        raise Exception("No vision_tower weights found")  # same failure as the reference (builder.py:135-137)
+    return out
+
+
+def read_checkpoint(model_path: str) -> Dict[str, torch.Tensor]:
+    files = sorted(f for f in os.listdir(model_path) if f.endswith(".safetensors"))
+    state: Dict[str, torch.Tensor] = {}
+    if files:
+        from safetensors.torch import load_file
+        for f in files:
+            state.update(load_file(os.path.join(model_path, f), device="cpu"))
+    else:
+        state = torch.load(os.path.join(model_path, "pytorch_model.bin"), map_location="cpu")
+    return state
+
+
+def _load_tokenizer(model_path: str):
+    from transformers import AutoTokenizer
+    return AutoTokenizer.from_pretrained(model_path, use_fast=False)   # slow tokenizer like the reference (:37)
+
+
+def build_model(config: dict, state: Dict[str, torch.Tensor], device: str = "cuda", generation_config: dict = None) -> FO1ForCausalLM:
+    """config.json dict + flat checkpoint state dict -> engine-backed model (no files involved; also the test entry point)."""
+    hf_cfg = FO1HFConfig(config, generation_config or {})
+    return FO1ForCausalLM(hf_cfg, split_checkpoint(state), device)
+
+
+def load_pretrained_model(model_path, load_8bit=False, load_4bit=False, device="cuda"):
+    if load_8bit or load_4bit:
+        raise NotImplementedError("bitsandbytes 8/4-bit loading is not part of the MI355X engine (bf16 weights only)")
+    lowered = model_path.lower()
+    if "vlm-fo1" not in lowered:
+        raise ValueError(f"{model_path!r}: only VLM-FO1 checkpoints are handled (the reference gates on 'vlm-fo1' in the path)")
+    if not ("qwen2.5-vl" in lowered or "qwen2_5_vl" in lowered):
+        raise ValueError(f"{model_path!r}: only the Qwen2.5-VL variant of VLM-FO1 is built")
+    tokenizer = _load_tokenizer(model_path)
+    with open(os.path.join(model_path, "config.json")) as f:
+        config = json.load(f)
+    gen_cfg = {}
+    gpath = os.path.join(model_path, "generation_config.json")
+    if os.path.exists(gpath):
+        with open(gpath) as f:
+            gen_cfg = json.load(f)
+    print(f"Loading weights from {model_path} into the MI355X engine ...")
+    model = build_model(config, read_checkpoint(model_path), device, gen_cfg)
+    primary = Qwen2VLPatchProcessor(min_pixels=56 * 56, max_pixels=2048 * 2048)            # qwen2_5_vl_encoder.py:179,210
+    aux = CLIPStyleAuxProcessor(size=config.get("aux_image_size", 768),                      # builder.py:65-75
+                                resize_mode=config.get("aux_image_aspect_ratio", "squash"))
+    model.eval()
+    return tokenizer, model, (primary, aux)

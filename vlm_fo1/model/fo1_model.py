@@ -1,0 +1,160 @@
+"""Engine-backed stand-in for the reference's `OmChatQwen25VLForCausalLM`
+(vlm_fo1/model/language_model/omchat_qwen2_5_vl.py:28-572): exposes what the reference's callers touch —
+`generate(**prepare_inputs(...))`, `config` attribute access, `get_vision_tower()/get_vision_tower_aux()`,
+`eval()/to()` — and owns generation itself (greedy loop + KV cache in the engine) instead of leaning on HF
+`GenerationMixin` internals, which drifted under transformers 5."""
+from __future__ import annotations
+
+import types
+from typing import Dict, List, Optional
+
+import torch
+
+from vlm_fo1_amd.davit import DAVIT_LARGE
+from vlm_fo1_amd.llm import LLMConfig
+from vlm_fo1_amd.model import FO1Config, FO1Engine
+from vlm_fo1_amd.vit import ViTConfig
+
+
+class FO1HFConfig:
+    """`config.json` with attribute access (`getattr(config, 'mm_*', default)` as the reference reads it:
+    omchat_arch.py:11-31, builder.py:65-70, mm_utils.py:593)."""
+
+    def __init__(self, d: dict, generation: Optional[dict] = None):
+        self._d = dict(d)
+        self._gen = dict(generation or {})
+        for k, v in d.items():
+            if k == "vision_config" and isinstance(v, dict):
+                v = types.SimpleNamespace(**v)
+            setattr(self, k, v)
+
+    def to_dict(self):
+        return dict(self._d)
+
+    # ---- engine configuration derived from the checkpoint's config (asserted, never guessed) ----
+    def engine_config(self) -> FO1Config:
+        d = self._d
+        txt = d.get("text_config", d)
+        vis = d["vision_config"]
+        rs = txt.get("rope_scaling") or d.get("rope_scaling") or {}
+        heads = txt["num_attention_heads"]
+        llm = LLMConfig(hidden_size=txt["hidden_size"], num_layers=txt["num_hidden_layers"], num_heads=heads,
+                        num_kv_heads=txt["num_key_value_heads"], head_dim=txt["hidden_size"] // heads,
+                        intermediate_size=txt["intermediate_size"], vocab_size=txt["vocab_size"],
+                        rms_norm_eps=txt.get("rms_norm_eps", 1e-6), rope_theta=txt.get("rope_theta", 1e6),
+                        mrope_section=tuple(rs.get("mrope_section", (16, 24, 24))),
+                        max_seq=min(int(d.get("tokenizer_model_max_length") or 8192), 32768))
+        vit = ViTConfig(depth=vis["depth"], hidden_size=vis["hidden_size"], num_heads=vis["num_heads"],
+                        intermediate_size=vis["intermediate_size"], out_hidden_size=vis["out_hidden_size"],
+                        patch_size=vis.get("patch_size", 14), spatial_merge_size=vis.get("spatial_merge_size", 2),
+                        temporal_patch_size=vis.get("temporal_patch_size", 2), in_channels=vis.get("in_channels", vis.get("in_chans", 3)),
+                        window_size=vis.get("window_size", 112), fullatt_block_indexes=tuple(vis.get("fullatt_block_indexes", (7, 15, 23, 31))))
+        unsupported = []
+        if not d.get("mm_use_vision_tower_region_feature", False):
+            unsupported.append("mm_use_vision_tower_region_feature=False")
+        if d.get("mm_region_feature_combination", "concat") != "concat":
+            unsupported.append(f"mm_region_feature_combination={d.get('mm_region_feature_combination')!r}")
+        if d.get("mm_pos_embedding_strategy", "bbox_based") != "bbox_based":
+            unsupported.append(f"mm_pos_embedding_strategy={d.get('mm_pos_embedding_strategy')!r}")
+        if d.get("mm_use_vt_region_feature_only", False) or d.get("mm_apply_region_layer_norm", False):
+            unsupported.append("vt-only / region layer norm")
+        aux = str(d.get("mm_vision_tower_aux", "davit-large"))
+        if "davit-large" not in aux:
+            unsupported.append(f"mm_vision_tower_aux={aux!r}")
+        if unsupported:
+            raise NotImplementedError("checkpoint configuration not built for the MI355X engine: " + ", ".join(unsupported))
+        return FO1Config(vit=vit, llm=llm, mm_projector_type=d.get("mm_projector_type", "linear"),
+                         mm_projector_aux_type=d.get("mm_projector_aux_type", "linear"),
+                         mm_use_simpleFPN_for_vt=bool(d.get("mm_use_simpleFPN_for_vt", False)),
+                         mm_region_hidden_size=int(d["mm_region_hidden_size"]), mm_roi_output_size=int(d.get("mm_roi_output_size", 7)),
+                         mm_apply_position_embedding=bool(d.get("mm_apply_position_embedding", True)))
+
+    def eos_ids(self) -> List[int]:
+        e = self._gen.get("eos_token_id", self._d.get("eos_token_id"))
+        if e is None:
+            return []
+        return list(e) if isinstance(e, (list, tuple)) else [int(e)]
+
+
+class _TowerHandle:
+    """What callers get from `get_vision_tower()` / `get_vision_tower_aux()`: loaded flag, config, processor."""
+
+    def __init__(self, config, image_processor=None):
+        self.is_loaded = True
+        self.config = config
+        self.image_processor = image_processor
+
+
+class FO1ForCausalLM:
+    def __init__(self, config: FO1HFConfig, weights: Dict[str, Dict[str, torch.Tensor]], device="cuda"):
+        self.config = config
+        self.device = torch.device(device)
+        self.dtype = torch.bfloat16
+        self.engine = FO1Engine(config.engine_config(), weights, device)
+        self._vt = _TowerHandle(getattr(config, "vision_config", None))
+        self._vt_aux = _TowerHandle(types.SimpleNamespace(**DAVIT_LARGE))
+        self.use_graph = True   # replay a captured hipGraph per input-shape signature
+
+    # ---- nn.Module-ish surface the reference drivers call ----
+    def eval(self):
+        return self
+
+    def to(self, *args, **kwargs):
+        return self
+
+    def get_model(self):
+        return self
+
+    def get_vision_tower(self):
+        return self._vt
+
+    def get_vision_tower_aux(self):
+        return self._vt_aux
+
+    # ---- generation ----
+    @torch.no_grad()
+    def generate(self, inputs=None, images=None, images_aux=None, image_grid_thws=None, bbox_list=None, do_sample=False,
+                 temperature=0.0, max_new_tokens=512, streamer=None, top_p=1.0, use_cache=True, stopping_criteria=None,
+                 pad_token_id=None, **unused) -> torch.LongTensor:
+        """Greedy decoding of one prompt.  Returns [1, L_in + new] like HF generate (the reference slices
+        `output_ids[0, inputs.shape[1]:]`, inference.py:47-48)."""
+        if inputs is None or inputs.dim() != 2 or inputs.shape[0] != 1:
+            raise ValueError("generate: `inputs` must be a [1, L] id tensor (the reference drivers are batch-1)")
+        if do_sample or (temperature not in (0, 0.0, None)):
+            raise NotImplementedError("sampling is not built; every reference caller decodes greedily (temperature=0)")
+        if not images or image_grid_thws is None:
+            raise ValueError("generate: the engine path needs one image (images / image_grid_thws)")
+        dev = self.device
+        ids = inputs[0].tolist()
+        pix = images[0].to(device=dev, dtype=torch.bfloat16)
+        grid = image_grid_thws[0].reshape(-1, 3)[0].tolist()
+        if grid[0] != 1:
+            raise NotImplementedError("video grids (t > 1) are outside the hot path")
+        aux = images_aux[0].to(device=dev, dtype=torch.bfloat16) if images_aux else None
+        boxes = None
+        if bbox_list is not None and len(bbox_list) > 0 and bbox_list[0] is not None:
+            boxes = bbox_list[0].to(device=dev, dtype=torch.float32)
+        if aux is None:
+            raise ValueError("generate: images_aux is required (mm_use_region_index_token checkpoints)")
+        eng = self.engine
+        out = eng.prefill(ids, pix, (grid[1], grid[2]), aux, boxes, use_graph=self.use_graph)
+        tok = out["next_token"]
+        eos = set(self.config.eos_ids())
+        all_ids = inputs.to(dev)
+        if streamer is not None:
+            streamer.put(inputs.cpu())
+        for _ in range(int(max_new_tokens)):
+            t = tok.to(torch.long).reshape(1, 1)
+            all_ids = torch.cat([all_ids, t.to(all_ids.dtype)], dim=1)
+            if streamer is not None:
+                streamer.put(t.cpu())
+            tid = int(t.item())
+            stop = tid in eos
+            if not stop and stopping_criteria:
+                stop = any(bool(c(all_ids, None)) for c in stopping_criteria)
+            if stop:
+                break
+            _, _, tok = eng.llm.decode_step(tok)
+        if streamer is not None:
+            streamer.end()
+        return all_ids.to(inputs.device)

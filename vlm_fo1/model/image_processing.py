@@ -1,0 +1,112 @@
+"""Host-side image preprocessing for the two towers, dependency-free (PIL + numpy):
+no torchvision, no HF image-processor classes (the default one needs torchvision under transformers 5).
+
+* Qwen2VLPatchProcessor — what the reference obtains from `Qwen2VLImageProcessor.from_pretrained(model_path,
+  min_pixels=56*56, max_pixels=2048*2048)` (qwen2_5_vl_encoder.py:179,210): smart-resize to multiples of 28
+  within [min_pixels, max_pixels], bicubic, /255, CLIP mean/std, then patches in 2x2 merge-block order, each
+  patch vector (C=3, T=2, 14, 14) with the single frame duplicated along T.  -> pixel_values [S, 1176],
+  image_grid_thw [1, 3].
+* CLIPStyleAuxProcessor — the reference's `CLIPImageProcessor(**img_cfg)` (davit/configs.py:139-152,
+  image_processing_clip.py:222-367): RGB, optional squash-resize to 768x768 (bicubic) — skipped in 'dynamic'
+  mode — /255, ImageNet mean/std, channels first.
+Equivalence with the installed HF PIL processor / the reference CLIP processor: tests/test_dropin_surface.py."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+from PIL import Image
+
+OPENAI_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56, max_pixels: int = 2048 * 2048):
+    """Both sides to multiples of `factor`, area clamped to [min_pixels, max_pixels], aspect kept."""
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError(f"absolute aspect ratio must be smaller than 200, got {max(height, width) / min(height, width)}")
+    hb, wb = round(height / factor) * factor, round(width / factor) * factor
+    if hb * wb > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        hb = max(factor, math.floor(height / beta / factor) * factor)
+        wb = max(factor, math.floor(width / beta / factor) * factor)
+    elif hb * wb < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        hb = math.ceil(height * beta / factor) * factor
+        wb = math.ceil(width * beta / factor) * factor
+    return hb, wb
+
+
+def _normalise(img: Image.Image, mean, std) -> np.ndarray:
+    """uint8 HWC -> float32 CHW, (x/255 - mean)/std with HF's rounding points (rescale in float64 -> float32,
+    normalise in float32)."""
+    a = np.asarray(img, dtype=np.uint8)
+    a = (a.astype(np.float64) * (1 / 255)).astype(np.float32)
+    a = (a - np.array(mean, dtype=np.float32)) / np.array(std, dtype=np.float32)
+    return np.ascontiguousarray(a.transpose(2, 0, 1))
+
+
+class Qwen2VLPatchProcessor:
+    def __init__(self, min_pixels: int = 56 * 56, max_pixels: int = 2048 * 2048, patch_size: int = 14, merge_size: int = 2,
+                 temporal_patch_size: int = 2):
+        self.min_pixels, self.max_pixels = min_pixels, max_pixels
+        self.patch_size, self.merge_size, self.temporal_patch_size = patch_size, merge_size, temporal_patch_size
+
+    def preprocess(self, images, videos=None, return_tensors: Optional[str] = "pt") -> Dict[str, torch.Tensor]:
+        if videos is not None:
+            raise NotImplementedError("video input is outside the hot path")
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        p, m, t = self.patch_size, self.merge_size, self.temporal_patch_size
+        pix, grids = [], []
+        for img in images:
+            img = img.convert("RGB")
+            w, h = img.size
+            rh, rw = smart_resize(h, w, p * m, self.min_pixels, self.max_pixels)
+            if (rh, rw) != (h, w):
+                img = img.resize((rw, rh), Image.Resampling.BICUBIC)
+            a = _normalise(img, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD)              # [3, rh, rw]
+            gh, gw = rh // p, rw // p
+            x = np.broadcast_to(a[None], (t,) + a.shape)                          # frame duplicated along T
+            x = x.reshape(t, 3, gh // m, m, p, gw // m, m, p)
+            # -> (by, bx, dy, dx, C, T, py, px): rows in 2x2 merge-block order, vector (C, T, 14, 14)
+            x = x.transpose(2, 5, 3, 6, 1, 0, 4, 7).reshape(gh * gw, 3 * t * p * p)
+            pix.append(np.ascontiguousarray(x))
+            grids.append([1, gh, gw])
+        pv = np.concatenate(pix, axis=0)
+        g = np.array(grids, dtype=np.int64)
+        if return_tensors == "pt":
+            return {"pixel_values": torch.from_numpy(pv), "image_grid_thw": torch.from_numpy(g)}
+        return {"pixel_values": pv, "image_grid_thw": g}
+
+    __call__ = preprocess
+
+
+class CLIPStyleAuxProcessor:
+    def __init__(self, size: int = 768, resize_mode: str = "squash", image_mean=IMAGENET_MEAN, image_std=IMAGENET_STD):
+        self.size = size
+        self.resize_mode = resize_mode
+        self.do_resize = resize_mode != "dynamic"      # davit_aux_encoder.py:47-49
+        self.image_mean, self.image_std = image_mean, image_std
+        if resize_mode not in ("squash", "dynamic"):
+            raise NotImplementedError(f"aux resize mode {resize_mode!r} is not built (squash / dynamic)")
+
+    def preprocess(self, images, return_tensors: Optional[str] = "pt") -> Dict[str, object]:
+        if not isinstance(images, (list, tuple)):
+            images = [images]
+        out = []
+        for img in images:
+            img = img.convert("RGB")
+            if self.do_resize:
+                img = img.resize((self.size, self.size), Image.Resampling.BICUBIC)
+            out.append(_normalise(img, self.image_mean, self.image_std))
+        if return_tensors == "pt":
+            same = all(o.shape == out[0].shape for o in out)
+            return {"pixel_values": torch.from_numpy(np.stack(out)) if same else [torch.from_numpy(o) for o in out]}
+        return {"pixel_values": out}
+
+    __call__ = preprocess

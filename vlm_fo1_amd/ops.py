@@ -158,11 +158,10 @@ def transpose_into(src: torch.Tensor, dst: torch.Tensor, col0: int = 0) -> None:
 
 
 def pick_q_block(segments: Sequence[Sequence[int]], n_heads: int, target_wgs: int = 512) -> int:
-    """Largest query block (64/32/16 = 4/2/1 waves) that still yields >= target_wgs workgroups (2 per CU)."""
-    for blk in (64, 32):
-        if sum((e - s + blk - 1) // blk for s, e in segments) * n_heads >= target_wgs:
-            return blk
-    return 16
+    """Query block (64/32/16 = 4/2/1 waves per workgroup).  Measured on MI355X (profiles/r01 notes): smaller
+    blocks re-stage every K/V tile once per block and LOSE (LLM prefill L=515: 64 -> 1.9 ms, auto 16/32 -> 4.7 ms
+    per image), so 64 stays the default; the knob is kept for very short sequences."""
+    return 64
 
 
 def make_items(segments: Sequence[Sequence[int]], device, causal: bool = False, block: int = 64) -> torch.Tensor:
