@@ -151,8 +151,11 @@ class FO1Engine:
             key = (gh, gw, tuple(aux_image.shape), n_reg, plan.shape[0], want_regions, pixel_values.dtype, aux_image.dtype)
             ent = self._graphs.get(key)
             if ent is None:
-                st = dict(pix=pixel_values.clone(), aux=aux_image.clone(), boxes=boxes.clone(), plan=plan.to(self.dev),
-                          cos=cos.to(self.dev), sin=sin.to(self.dev))
+                # static input buffers must be ordinary tensors even when the caller runs under
+                # torch.inference_mode() (the reference's inference.py:46 does): they are updated in place later
+                with torch.inference_mode(False):
+                    st = dict(pix=pixel_values.clone(), aux=aux_image.clone(), boxes=boxes.clone(), plan=plan.clone().to(self.dev),
+                              cos=cos.clone().to(self.dev), sin=sin.clone().to(self.dev))
                 # warm-up on a side stream (allocates every lazily-created scratch buffer), then capture
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
