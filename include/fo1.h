@@ -115,7 +115,10 @@ int fo1_hfre_region_pool(
  *   C[M,N] = epilogue(A[M,K] . W[N,K]^T),  W = nn.Linear weight [out,in], bf16 in, fp32 accumulate
  *   epilogue (each step rounds to bf16 like the reference's op-by-op bf16 tensors):
  *     y = bf16(acc + bias[n]);  y = bf16(act(y));  y = bf16(y + residual[m,n])
- *   act: 0 none, 1 exact-erf GELU, 2 SiLU.   out_f32 != 0: C is fp32 (acc + bias, act), no residual.
+ *   act: 0 none, 1 exact-erf GELU, 2 SiLU, 3 fused SwiGLU: W rows (and bias) interleaved in 16-row groups
+ *        [gate 16 | up 16 | ...] (N = 2F, N % 32 == 0); C[M, F] = bf16(bf16(silu(bf16(gate))) * bf16(up)) —
+ *        act_fn(gate_proj(x)) * up_proj(x) of modeling_qwen2_5_vl.py:85-86,636 without the [M,2F] round trip.
+ *   out_f32 != 0: C is fp32 (acc + bias, act), no residual.
  * K, lda, ldw multiples of 8; A, W 16-byte aligned.  bias/residual may be NULL.
  * ---------------------------------------------------------------------- */
 int fo1_gemm_bf16(const void* A, int lda, const void* W, int ldw, const void* bias,

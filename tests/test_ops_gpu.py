@@ -292,3 +292,26 @@ def test_gemm_splitk(splits):
     finally:
         L.load().fo1_gemm_set_splitk(0)
         L.load().fo1_gemm_set_variant(0, 0)
+
+
+def test_gemm_fused_swiglu_epilogue():
+    """gate/up GEMM with SwiGLU in the epilogue == separate GEMM + swiglu kernel, bit for bit (same rounding points)."""
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(12)
+    try:
+        for (M, F, K, hb) in [(515, 11008, 2048, False), (1564, 3456, 1280, True), (37, 64, 128, True)]:
+            a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+            wg = (torch.randn(F, K) * 0.05).to(BF)
+            wu = (torch.randn(F, K) * 0.05).to(BF)
+            bg = (torch.randn(F) * 0.1).to(BF) if hb else None
+            bu = (torch.randn(F) * 0.1).to(BF) if hb else None
+            for tile in (0, 1, 2, 3):
+                L.check(L.load().fo1_gemm_set_variant(0, tile), "variant")
+                fused = ops.gemm(a, ops.interleave_gate_up(wg, wu).cuda(), ops.interleave_gate_up(bg, bu).cuda() if hb else None,
+                                 act=ops.ACT_SWIGLU16)
+                gu = ops.gemm(a, torch.cat([wg, wu], 0).cuda(), torch.cat([bg, bu], 0).cuda() if hb else None)
+                ref = ops.swiglu(gu)
+                assert fused.shape == (M, F)
+                assert torch.equal(fused, ref), f"fused swiglu differs (M={M} F={F} tile={tile}): max {(fused.float() - ref.float()).abs().max()}"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)

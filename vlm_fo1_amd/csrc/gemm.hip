@@ -41,7 +41,7 @@ struct GemmParams {
     float* part;               // fp32 partials [splits][M][N] when splits > 1
 };
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
@@ -65,6 +65,36 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FN][F
                                          long long offC, long long offR) {
     const int mi = lane & 15, nq = (lane >> 4) * 4;
     const bool vec_ok = (p.ldc % 4 == 0) && ((offC & 3) == 0) && (p.res == nullptr || ((p.ldr % 4 == 0) && ((offR & 3) == 0)));
+    if (p.act == ACT_SWIGLU16) {
+        // W rows are interleaved in 16-row groups [gate 16 | up 16 | gate 16 | ...]: fragment pair (fn, fn+1) holds
+        // gate and up of the same 16 features.  out[m, f] = bf16( bf16(silu(bf16(g))) * bf16(u) ), C has N/2 columns.
+        if constexpr (FN >= 2) {
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int m = m_base + fm * 16 + mi;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int fn = 0; fn + 1 < FN; fn += 2) {
+                    const int n0 = n_base + fn * 16 + nq;       // gate column; up column = n0 + 16
+                    if (n0 >= p.N) continue;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float g = acc[fn][fm][r], u = acc[fn + 1][fm][r];
+                        if (p.bias) { g += bf16_to_f32(p.bias[n0 + r]); u += bf16_to_f32(p.bias[n0 + 16 + r]); }
+                        g = round_bf16(g);
+                        u = round_bf16(u);
+                        o[r] = round_bf16(g / (1.0f + expf(-g))) * u;
+                    }
+                    uint2 ov;
+                    ov.x = pack_bf16x2(o[0], o[1]);
+                    ov.y = pack_bf16x2(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(p.C + offC + (long long)m * p.ldc + ((n_base + fn * 16) >> 1) + nq) = ov;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int fm = 0; fm < FM; ++fm) {
         const int m = m_base + fm * 16 + mi;
@@ -412,7 +442,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
     const int nk = p.K / 64;
     int tile = g_gemm_tile;
     int splits = g_gemm_splitk;
-    const bool can_split = glds && batch == 1 && ws != nullptr && p.N % 4 == 0;
+    const bool can_split = glds && batch == 1 && ws != nullptr && p.N % 4 == 0 && p.act != ACT_SWIGLU16;
     if (tile == 0) {
         tile = t128 >= 768 ? 1 : (t64x128 >= 512 ? 2 : 3);
         if (splits == 0 && can_split && nk >= 64 && t64x128 < 512) tile = 2;
@@ -482,9 +512,16 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
     FO1_CHECK_ARG(A && W && C, "gemm: NULL operand");
     FO1_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     FO1_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (K=%d lda=%d ldw=%d)", K, lda, ldw);
-    FO1_CHECK_ARG(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension too small");
+    FO1_CHECK_ARG(lda >= K && ldw >= K, "gemm: leading dimension too small");
     FO1_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A/W must be 16-byte aligned");
-    FO1_CHECK_ARG(act >= 0 && act <= 2, "gemm: act=%d", act);
+    FO1_CHECK_ARG(act >= 0 && act <= 3, "gemm: act=%d", act);
+    if (act == 3) {
+        FO1_CHECK_ARG(!out_f32 && residual == nullptr && N % 32 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 7) == 0,
+                      "gemm: swiglu epilogue needs bf16 out, no residual, N %% 32 == 0 (N=%d), ldc %% 4 == 0", N);
+        FO1_CHECK_ARG(ldc >= N / 2, "gemm: swiglu output has N/2 columns; ldc too small");
+    } else {
+        FO1_CHECK_ARG(ldc >= N, "gemm: ldc too small");
+    }
     FO1_CHECK_ARG(!out_f32 || residual == nullptr, "gemm: fp32 output does not take a residual");
     FO1_CHECK_ARG(residual == nullptr || ldr >= N, "gemm: ldr too small");
     GemmParams p;

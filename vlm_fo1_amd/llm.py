@@ -6,7 +6,7 @@ modeling_qwen2_5_vl.py:1546-1701, omchat_qwen2_5_vl.py:318-319) is done on the h
 sentinel positions and the image grid before any launch.
 
 Weights: fused at load time — q/k/v -> one [2560, 2048] GEMM, gate/up -> one [22016, 2048] GEMM
-(rows [gate; up]) — checkpoint key names as in the reference state dict.
+(rows interleaved [gate 16 | up 16 | ...] so SwiGLU runs in the GEMM epilogue) — checkpoint key names as in the reference state dict.
 """
 from __future__ import annotations
 
@@ -87,7 +87,7 @@ class QwenLLM:
                 wqkv=dv(torch.cat([state[a + "q_proj.weight"], state[a + "k_proj.weight"], state[a + "v_proj.weight"]], 0)),
                 bqkv=dv(torch.cat([state[a + "q_proj.bias"], state[a + "k_proj.bias"], state[a + "v_proj.bias"]], 0)),
                 wo=dv(state[a + "o_proj.weight"]),
-                wgu=dv(torch.cat([state[p + "mlp.gate_proj.weight"], state[p + "mlp.up_proj.weight"]], 0)),
+                wgu=dv(ops.interleave_gate_up(state[p + "mlp.gate_proj.weight"], state[p + "mlp.up_proj.weight"])),
                 wdown=dv(state[p + "mlp.down_proj.weight"]),
             ))
         c = cfg
@@ -160,8 +160,7 @@ class QwenLLM:
                                         n_q_heads=H, n_kv_heads=KV, head_dim=HD, scale=scale, causal=True, flops=flops)
             x = ops.gemm(att, w["wo"], residual=x)
             h = ops.rmsnorm(x, w["ln2"], c.rms_norm_eps)
-            gu = ops.gemm(h, w["wgu"])
-            a = ops.swiglu(gu)
+            a = ops.gemm(h, w["wgu"], act=ops.ACT_SWIGLU16)   # gate/up GEMM with the SwiGLU fused into its epilogue
             x = ops.gemm(a, w["wdown"], residual=x)
             if collect is not None:
                 collect.append(x)

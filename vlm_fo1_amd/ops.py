@@ -12,7 +12,7 @@ import torch
 
 from . import lib as _L
 
-ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_SWIGLU16 = 0, 1, 2, 3
 
 
 def _chk(t: torch.Tensor, name: str, dtype=torch.bfloat16):
@@ -54,10 +54,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     pw, ldw, N, K2 = _rows(w, "w")
     if K != K2:
         raise ValueError(f"gemm: K mismatch {K} vs {K2}")
+    n_out = N // 2 if act == ACT_SWIGLU16 else N
     if out is None:
-        out = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
+        out = torch.empty(M, n_out, dtype=torch.float32 if out_f32 else torch.bfloat16, device=a.device)
     po, ldc, Mo, No = _rows(out, "out")
-    assert (Mo, No) == (M, N)
+    assert (Mo, No) == (M, n_out)
     pr, ldr = (None, 0)
     if residual is not None:
         _chk(residual, "residual")
@@ -92,6 +93,16 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     _L.check(_L.load().fo1_layernorm_bf16(px, ldx, weight.data_ptr(), bias.data_ptr(), po, ldy, M, D, float(eps), _stream()),
              "fo1_layernorm_bf16")
     return out
+
+
+def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
+    """[F, ...] gate and up -> [2F, ...] rows interleaved in 16-row groups [gate 16 | up 16 | ...], the weight/bias
+    layout of the fused SwiGLU GEMM epilogue (act = ACT_SWIGLU16).  F must be a multiple of 16."""
+    F = gate.shape[0]
+    assert up.shape == gate.shape and F % 16 == 0
+    g = gate.reshape(F // 16, 16, *gate.shape[1:])
+    u = up.reshape(F // 16, 16, *up.shape[1:])
+    return torch.stack([g, u], dim=1).reshape(2 * F, *gate.shape[1:]).contiguous()
 
 
 def swiglu(gate_up: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:

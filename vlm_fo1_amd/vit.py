@@ -122,8 +122,8 @@ class QwenViT:
                 n1=dv(state[p + "norm1.weight"]), n2=dv(state[p + "norm2.weight"]),
                 wqkv=dv(state[p + "attn.qkv.weight"]), bqkv=dv(state[p + "attn.qkv.bias"]),
                 wo=dv(state[p + "attn.proj.weight"]), bo=dv(state[p + "attn.proj.bias"]),
-                wgu=dv(torch.cat([padrows(state[p + "mlp.gate_proj.weight"], self.ffp), padrows(state[p + "mlp.up_proj.weight"], self.ffp)], 0)),
-                bgu=dv(torch.cat([padrows(state[p + "mlp.gate_proj.bias"], self.ffp), padrows(state[p + "mlp.up_proj.bias"], self.ffp)], 0)),
+                wgu=dv(ops.interleave_gate_up(padrows(state[p + "mlp.gate_proj.weight"], self.ffp), padrows(state[p + "mlp.up_proj.weight"], self.ffp))),
+                bgu=dv(ops.interleave_gate_up(padrows(state[p + "mlp.gate_proj.bias"], self.ffp), padrows(state[p + "mlp.up_proj.bias"], self.ffp))),
                 wd=dv(wd), bd=dv(state[p + "mlp.down_proj.bias"]),
             ))
         self.ln_q = dv(state["merger.ln_q.weight"])
@@ -169,8 +169,7 @@ class QwenViT:
                                 flops=fl_full if full else fl_win)
             x = ops.gemm(att, w["wo"], w["bo"], residual=x)
             h = ops.rmsnorm(x, w["n2"], 1e-6)
-            gu = ops.gemm(h, w["wgu"], w["bgu"])
-            a = ops.swiglu(gu)
+            a = ops.gemm(h, w["wgu"], w["bgu"], act=ops.ACT_SWIGLU16)
             x = ops.gemm(a, w["wd"], w["bd"], residual=x)
             if full and (capture == "all" or i == c.fullatt_block_indexes[-1]):
                 feats.append(ops.gather_rows(g.plan_raster, d, x))
