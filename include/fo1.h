@@ -86,7 +86,7 @@ typedef struct fo1_hfre_source {
     int32_t out_offset;  /* first output channel written by this source                    */
 } fo1_hfre_source_t;
 
-/* Tuning hook: footprint pixels one workgroup streams per row-slice (default 1024). */
+/* Tuning hook: footprint pixels one workgroup streams per row-slice (0 = auto: 256 up to 48 boxes, else 512). */
 int fo1_hfre_set_pixel_budget(int pixels);
 
 /* Bytes of scratch fo1_hfre_region_pool needs for these sources / n_boxes. */

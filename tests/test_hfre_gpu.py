@@ -86,7 +86,7 @@ def test_hfre_slice_budget_invariance(budget):
         L.check(L.load().fo1_hfre_set_pixel_budget(budget), "set budget")
         got = engine_out(d).cpu()
     finally:
-        L.load().fo1_hfre_set_pixel_budget(1024)
+        L.load().fo1_hfre_set_pixel_budget(0)
     torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6)
     torch.testing.assert_close(got, oracle_out(case), rtol=RTOL, atol=ATOL)
 

@@ -390,6 +390,109 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// LDS-DMA path, 3-stage ring: two K tiles in flight across each barrier (counted vmcnt + raw s_barrier;
+// __syncthreads() would drain the DMA queue with vmcnt(0)).  All LDS lives in ONE dynamic array.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_bt_glds3_kernel(const GemmParams p) {
+    constexpr int BK = 64, NS = 3;
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int ROWS = BM + BN;
+    constexpr int INST = ROWS / 8;
+    constexpr int IPW = INST / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [NS][ROWS][128]
+
+    int tm, tn;
+    tile_coords(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const long long bz = blockIdx.y;
+    const uint16_t* A = p.A + bz * p.sA;
+    const uint16_t* W = p.W + bz * p.sW;
+
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lr = lane >> 3, lc = lane & 7;
+    const uint16_t* src[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int R = (wave * IPW + i) * 8 + lr;
+        const int cs = (lc ^ ((R >> 1) & 7)) * 8;
+        if (R < BM) {
+            int gm = m0 + R;
+            gm = gm < p.M ? gm : p.M - 1;
+            src[i] = A + (long long)gm * p.lda + cs;
+        } else {
+            int gn = n0 + (R - BM);
+            gn = gn < p.N ? gn : p.N - 1;
+            src[i] = W + (long long)gn * p.ldw + cs;
+        }
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            char* dst = smem + buf * (ROWS * 128) + (wave * IPW + i) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    const int nk_all = p.K / BK;
+    const int kt0 = blockIdx.z * p.kper;
+    const int nk = min(nk_all - kt0, p.kper);
+    issue(kt0, 0);
+    if (nk > 1) issue(kt0 + 1, 1);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        // this wave's loads of tile kt have landed (only tile kt+1's IPW loads may still be in flight)
+        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // every wave's tile-kt loads landed; everyone finished computing tile kt-1
+        asm volatile("" ::: "memory");
+        if (kt + 2 < nk) {
+            int nb = buf + 2;
+            if (nb >= NS) nb -= NS;
+            issue(kt0 + kt + 2, nb);   // overwrites the buffer tile kt-1 was read from
+        }
+        const char* sa = smem + buf * (ROWS * 128);
+        const char* sb = sa + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8 wf[FN], af[FM];
+            const int kc = ks * 4 + (lane >> 4);
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+                const int R = wn * WN + fn * 16 + (lane & 15);
+                wf[fn] = *reinterpret_cast<const bf16x8*>(sb + R * 128 + ((kc ^ ((R >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int R = wm * WM + fm * 16 + (lane & 15);
+                af[fm] = *reinterpret_cast<const bf16x8*>(sa + R * 128 + ((kc ^ ((R >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm)
+                    acc[fn][fm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[fn], af[fm], acc[fn][fm], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's LDS reads of tile kt are done before it arrives at the next barrier
+        if (++buf == NS) buf = 0;
+    }
+    if (p.splits > 1) {
+        store_partial<FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, blockIdx.z);
+        return;
+    }
+    epilogue<FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz * p.sC, bz * p.sR);
+}
+
 static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds
 static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64
 static int g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
@@ -406,6 +509,22 @@ static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
     if (profile_enabled() && g_gemm_profile_shapes) {
         snprintf(pname, sizeof pname, "gemm %dx%dx%d t%dx%d s%d", p.M, p.N, p.K, BM, BN, glds ? p.splits : 1);
         name = pname;
+    }
+    if (glds && g_gemm_variant == 3) {
+        constexpr int smem3 = 3 * (BM + BN) * 128;
+        static bool attr3_done = false;
+        if (!attr3_done) {
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_glds3_kernel<BM, BN>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, smem3));
+            attr3_done = true;
+        }
+        FO1_LAUNCH(name, flops, (gemm_bt_glds3_kernel<BM, BN>), grid, dim3(256), smem3, st, p);
+        if (p.splits > 1) {
+            const long long total = (long long)p.M * (p.N / 4);
+            const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            FO1_LAUNCH("gemm_splitk_reduce", (double)p.M * p.N * 4.0 * p.splits, gemm_splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
+        }
+        return FO1_OK;
     }
     if (glds) {
         constexpr int smem = 2 * (BM + BN) * 128;
@@ -430,7 +549,7 @@ static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
 int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws_bytes) {
     bool glds = (p.K % 64 == 0);
     if (g_gemm_variant == 1) glds = false;
-    if (g_gemm_variant == 2 && p.K % 64 != 0) return set_err(FO1_ERR_ARG, "gemm: glds variant needs K %% 64 == 0 (K=%d)", p.K);
+    if (g_gemm_variant >= 2 && p.K % 64 != 0) return set_err(FO1_ERR_ARG, "gemm: glds variant needs K %% 64 == 0 (K=%d)", p.K);
     // Dispatch heuristics measured on MI355X (profiles/r01_gemm_bench_v2.log):
     //  * 128x128 tiles once they alone give >= 3 workgroups per CU, else 64x128 if that gives >= 2 per CU,
     //    else 64x64;
@@ -444,7 +563,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
     int splits = g_gemm_splitk;
     const bool can_split = glds && batch == 1 && ws != nullptr && p.N % 4 == 0 && p.act != ACT_SWIGLU16;
     if (tile == 0) {
-        tile = t128 >= 768 ? 1 : (t64x128 >= 512 ? 2 : 3);
+        tile = (t128 >= 768 && nk >= 16) ? 1 : (t64x128 >= 512 ? 2 : 3);   // shallow K (DaViT stage 0, K=256): 64x128 wins
         if (splits == 0 && can_split && nk >= 64 && t64x128 < 512) tile = 2;
     }
     p.splits = 1;
@@ -478,7 +597,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
 extern "C" {
 
 int fo1_gemm_set_variant(int staging, int tile) {
-    if (staging < 0 || staging > 2 || tile < 0 || tile > 3) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
+    if (staging < 0 || staging > 3 || tile < 0 || tile > 3) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
     fo1::g_gemm_variant = staging;
     fo1::g_gemm_tile = tile;
     return FO1_OK;

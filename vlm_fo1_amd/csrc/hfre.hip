@@ -50,7 +50,11 @@ struct HfreParams {
     float* ws;
     int ws_box_stride;  // floats per box
     int pixel_budget;
+    float* wbuf;        // per (box, source): wy[kHfreWStride] | wx[kHfreWStride] tap weights on the source map
+    int* hdr;           // per (box, source): r_lo, r_hi, c_lo, c_hi, rows_per_slice, n_slices, -, -
 };
+
+constexpr int kHfreWStride = FO1_HFRE_MAX_EXTENT;
 
 struct Footprint {
     RoiAxis ay, ax;
@@ -87,9 +91,37 @@ __device__ __forceinline__ Footprint hfre_footprint(const HfreParams& p, const H
     return f;
 }
 
-__global__ __launch_bounds__(kHfreThreads) void hfre_pool_kernel(const HfreParams p) {
+// Stage 1: one workgroup per (box, source) builds the per-axis tap weights on the source map once
+// (roi_align taps composed with the bilinear-upsample taps) and a small header; every pooling workgroup of
+// that (box, source) then just loads them.
+__global__ __launch_bounds__(kHfreThreads) void hfre_weights_kernel(const HfreParams p) {
     __shared__ float s_wAy[FO1_HFRE_MAX_EXTENT];
     __shared__ float s_wAx[FO1_HFRE_MAX_EXTENT];
+    const int n = blockIdx.x / p.n_sources, si = blockIdx.x - n * p.n_sources;
+    const HfreSrcDev& s = p.src[si];
+    const Footprint f = hfre_footprint(p, s, n);
+    const int tid = threadIdx.x;
+    int* h = p.hdr + (size_t)blockIdx.x * 8;
+    if (tid == 0) {
+        h[0] = f.r_lo; h[1] = f.r_hi; h[2] = f.c_lo; h[3] = f.c_hi; h[4] = f.rows_per_slice; h[5] = f.n_slices;
+    }
+    if (f.n_slices == 0) return;
+    const bool up_y = (s.H != s.roi_H), up_x = (s.W != s.roi_W);
+    if (up_y)
+        for (int a = f.ay.lo + tid; a <= f.ay.hi; a += kHfreThreads) s_wAy[a - f.ay.lo] = roi_axis_weight(f.ay, a);
+    if (up_x)
+        for (int a = f.ax.lo + tid; a <= f.ax.hi; a += kHfreThreads) s_wAx[a - f.ax.lo] = roi_axis_weight(f.ax, a);
+    __syncthreads();
+    float* wy = p.wbuf + (size_t)blockIdx.x * 2 * kHfreWStride;
+    float* wx = wy + kHfreWStride;
+    const int fh = f.r_hi - f.r_lo + 1, fw = f.c_hi - f.c_lo + 1;
+    for (int r = tid; r < fh; r += kHfreThreads)
+        wy[r] = up_y ? upsample_axis_weight(f.r_lo + r, s_wAy, f.ay.lo, f.ay.hi, s.H, s.roi_H) : roi_axis_weight(f.ay, f.r_lo + r);
+    for (int c = tid; c < fw; c += kHfreThreads)
+        wx[c] = up_x ? upsample_axis_weight(f.c_lo + c, s_wAx, f.ax.lo, f.ax.hi, s.W, s.roi_W) : roi_axis_weight(f.ax, f.c_lo + c);
+}
+
+__global__ __launch_bounds__(kHfreThreads) void hfre_pool_kernel(const HfreParams p) {
     __shared__ float s_wy[FO1_HFRE_MAX_EXTENT];
     __shared__ float s_wx[FO1_HFRE_MAX_EXTENT];
     __shared__ float s_red[kHfreWaves][kHfreMaxChunk];
@@ -106,30 +138,26 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_pool_kernel(const HfreParam
     const int n = local / s.nchunks;
     if (n >= p.n_boxes) return;
 
-    const Footprint f = hfre_footprint(p, s, n);
-    if (k >= f.n_slices) return;  // uniform across the workgroup
+    const int* h = p.hdr + ((size_t)n * p.n_sources + si) * 8;
+    const int n_slices = h[5];
+    if (k >= n_slices) return;  // uniform across the workgroup
+    const int r_lo = h[0], r_hi = h[1], c_lo = h[2], c_hi = h[3], rps = h[4];
 
     const int tid = threadIdx.x;
-    const int row0 = f.r_lo + k * f.rows_per_slice;
-    int row1 = row0 + f.rows_per_slice - 1;
-    if (row1 > f.r_hi) row1 = f.r_hi;
+    const int row0 = r_lo + k * rps;
+    int row1 = row0 + rps - 1;
+    if (row1 > r_hi) row1 = r_hi;
     const int nrows = row1 - row0 + 1;
-    const int fw = f.c_hi - f.c_lo + 1;
+    const int fw = c_hi - c_lo + 1;
 
-    // ---- per-axis weights -------------------------------------------------
-    const bool up_y = (s.H != s.roi_H), up_x = (s.W != s.roi_W);
-    if (up_y)
-        for (int a = f.ay.lo + tid; a <= f.ay.hi; a += kHfreThreads) s_wAy[a - f.ay.lo] = roi_axis_weight(f.ay, a);
-    if (up_x)
-        for (int a = f.ax.lo + tid; a <= f.ax.hi; a += kHfreThreads) s_wAx[a - f.ax.lo] = roi_axis_weight(f.ax, a);
+    // ---- per-axis weights: coalesced copy of this slice's rows / the footprint's columns ------
+    const float* gwy = p.wbuf + ((size_t)n * p.n_sources + si) * 2 * kHfreWStride + (row0 - r_lo);
+    const float* gwx = p.wbuf + ((size_t)n * p.n_sources + si) * 2 * kHfreWStride + kHfreWStride;
+    for (int r = tid; r < nrows; r += kHfreThreads) s_wy[r] = gwy[r];
+    for (int c = tid; c < fw; c += kHfreThreads) s_wx[c] = gwx[c];
     __syncthreads();
-    for (int r = tid; r < nrows; r += kHfreThreads)
-        s_wy[r] = up_y ? upsample_axis_weight(row0 + r, s_wAy, f.ay.lo, f.ay.hi, s.H, s.roi_H)
-                       : roi_axis_weight(f.ay, row0 + r);
-    for (int c = tid; c < fw; c += kHfreThreads)
-        s_wx[c] = up_x ? upsample_axis_weight(f.c_lo + c, s_wAx, f.ax.lo, f.ax.hi, s.W, s.roi_W)
-                       : roi_axis_weight(f.ax, f.c_lo + c);
-    __syncthreads();
+
+    struct { int c_lo; } f = {c_lo};
 
     // ---- stream the footprint ----------------------------------------------
     const int lpp = s.chunk >> 3;        // lanes per pixel (8 bf16 = 16 B per lane), power of two
@@ -196,7 +224,7 @@ __global__ __launch_bounds__(256) void hfre_finish_kernel(const HfreParams p) {
     __shared__ float s_box[4];
     const int n = blockIdx.y;
     const int tid = threadIdx.x;
-    if (tid < p.n_sources) s_nsl[tid] = hfre_footprint(p, p.src[tid], n).n_slices;
+    if (tid < p.n_sources) s_nsl[tid] = p.hdr[((size_t)n * p.n_sources + tid) * 8 + 5];
     if (tid == 32 && p.pos_mode != 0) {
         float x1, y1, x2, y2;
         load_box(p, n, p.pos_mode == 1, x1, y1, x2, y2);
@@ -233,7 +261,13 @@ __global__ __launch_bounds__(256) void hfre_finish_kernel(const HfreParams p) {
     p.out[(size_t)n * p.out_ld + c] = v;
 }
 
-static int g_hfre_pixel_budget = 1024;
+static int g_hfre_pixel_budget = 0;  // 0 = auto
+
+// workspace = [partials: n_boxes * ws_box_stride floats][weights: n_boxes*n_sources*2*kHfreWStride floats][headers: n_boxes*n_sources*8 ints]
+static size_t hfre_ws_total(const HfreParams& p, int n_sources, int n_boxes) {
+    const size_t nb = (size_t)(n_boxes > 0 ? n_boxes : 1);
+    return ((size_t)p.ws_box_stride * nb + nb * n_sources * 2 * kHfreWStride) * sizeof(float) + nb * n_sources * 8 * sizeof(int);
+}
 
 static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxes, HfreParams& p, int& total_wgs) {
     FO1_CHECK_ARG(sources != nullptr, "hfre: sources is NULL");
@@ -241,7 +275,9 @@ static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxe
                   FO1_HFRE_MAX_SOURCES);
     FO1_CHECK_ARG(n_boxes >= 0, "hfre: n_boxes=%d < 0", n_boxes);
     p.n_sources = n_sources;
-    p.pixel_budget = g_hfre_pixel_budget;
+    // measured on MI355X (profiles/r01_hfre.md): per-workgroup streaming is latency-bound (~16 KB in flight), so
+    // small slices win until the empty-workgroup count takes over: 256 px up to ~48 boxes, 512 px beyond
+    p.pixel_budget = g_hfre_pixel_budget > 0 ? g_hfre_pixel_budget : (n_boxes <= 48 ? 256 : 512);
     int wg = 0, ws = 0;
     for (int i = 0; i < n_sources; ++i) {
         const fo1_hfre_source_t& s = sources[i];
@@ -279,7 +315,7 @@ extern "C" {
 
 // test/tuning hook: pixels per workgroup slice (default 1024)
 int fo1_hfre_set_pixel_budget(int pixels) {
-    if (pixels < 16 || pixels > 65536) return fo1::set_err(FO1_ERR_ARG, "hfre: pixel budget %d outside [16,65536]", pixels);
+    if (pixels != 0 && (pixels < 16 || pixels > 65536)) return fo1::set_err(FO1_ERR_ARG, "hfre: pixel budget %d outside [16,65536] (0 = auto)", pixels);
     fo1::g_hfre_pixel_budget = pixels;
     return FO1_OK;
 }
@@ -288,7 +324,7 @@ size_t fo1_hfre_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources,
     fo1::HfreParams p;
     int wgs = 0;
     if (fo1::hfre_plan(sources, n_sources, n_boxes, p, wgs) != FO1_OK) return 0;
-    return (size_t)p.ws_box_stride * (size_t)(n_boxes > 0 ? n_boxes : 1) * sizeof(float);
+    return hfre_ws_total(p, n_sources, n_boxes);
 }
 
 int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const float* boxes_aux, int n_boxes,
@@ -314,7 +350,7 @@ int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const 
                       "hfre: source %d data NULL or not 16-byte aligned", i);
         FO1_CHECK_ARG(sources[i].out_offset + sources[i].C <= region_dim, "hfre: source %d writes past region_dim", i);
     }
-    const size_t need = (size_t)p.ws_box_stride * n_boxes * sizeof(float);
+    const size_t need = hfre_ws_total(p, n_sources, n_boxes);
     if (workspace == nullptr || workspace_bytes < need)
         return set_err(FO1_ERR_WORKSPACE, "hfre: workspace %zu B < required %zu B", workspace_bytes, need);
     p.boxes = boxes_aux;
@@ -330,7 +366,10 @@ int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const 
     p.out_ld = out_ld;
     p.region_dim = region_dim;
     p.ws = (float*)workspace;
+    p.wbuf = p.ws + (size_t)p.ws_box_stride * n_boxes;
+    p.hdr = (int*)(p.wbuf + (size_t)n_boxes * n_sources * 2 * kHfreWStride);
     hipStream_t st = (hipStream_t)stream;
+    FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreThreads), 0, st, p);
     // algorithmic bytes (SURVEY §8d upper bound): every source map once in bf16 + fp32 output + boxes
     double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
     for (int i = 0; i < n_sources; ++i) bytes += (double)sources[i].H * sources[i].W * sources[i].C * 2.0;
