@@ -180,6 +180,37 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
 
+    # ---- greedy decode through the KV cache (fixed K new tokens, reported separately; not part of `value`) ----
+    dec = None
+    if rank == 0:
+        K = 32
+        out = pipe.step(use_graph)
+        tok = out["next_token"]
+        llm = pipe.eng.llm
+        if use_graph:
+            llm.sync_decode_state()
+            _, tok = llm.decode_step_graph(tok)
+            for _ in range(2):
+                llm.decode_step_graph()
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            for _ in range(K):
+                _, tok = llm.decode_step_graph()
+                tok.item()                      # the host reads every token (stop criteria), as generate() does
+            td = (time.perf_counter() - td) / K
+        else:
+            for _ in range(3):
+                _, _, tok = llm.decode_step(tok)
+            torch.cuda.synchronize()
+            td = time.perf_counter()
+            for _ in range(K):
+                _, _, tok = llm.decode_step(tok)
+                tok.item()
+            td = (time.perf_counter() - td) / K
+        dec = dict(ms_per_token=round(td * 1e3, 3), tokens_per_sec=round(1.0 / td, 1), new_tokens_timed=K,
+                   weight_stream_floor_ms=round(6.2e9 / 8e12 * 1e3, 3),
+                   images_per_sec_with_64_token_answer=round(1.0 / (el / args.steps + 64 * td), 2))
+
     # ---- roofline of the dominant kernel: separate profiled pass (hipEvents per launch) ----
     roof = None
     if rank == 0:
@@ -216,7 +247,7 @@ def main():
                                         f"{len(case['ids']) - 1 + 391} tokens after splice, prefill to the first greedy token",
                                stages=Pipeline.stages, launch="eager" if args.eager else "hipGraph replay (1 graph per shape signature)",
                                parallelism=f"dp{world} (images sharded, no data-path collective)"),
-                   roofline=roof)
+                   decode=dec, roofline=roof)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(case, pipe)
         print(json.dumps(out))

@@ -134,6 +134,7 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
  * 2 64x128 / 3 64x64; split-K 0 auto / n forced; per-shape kernel names in the profile. */
 int fo1_gemm_set_variant(int staging, int tile);
 int fo1_gemm_set_splitk(int splits);
+int fo1_gemm_set_gemv(int on);   /* M <= 4 goes to the weight-streaming GEMV kernel (default on) */
 int fo1_gemm_profile_shapes(int on);
 
 /* ------------------------------------------------------------------------
@@ -163,15 +164,21 @@ int fo1_argmax_bf16(const void* x, int n, int* out, void* stream);
  *        kcache[(head-k_first_head)*kcache_head_stride + (pos0+t)*head_dim] when kcache != NULL.
  *   fo1_rope_vit_bf16  apply_rotary_pos_emb_flashatt / _vision  :162-169, :219-230: fp32 cos/sin
  *        [S, head_dim/2]; rotates the q and k heads (2*n_heads heads from column 0) in place.
- *   fo1_transpose_bf16 dst[c*ld_dst + col0 + m] = src[m*ld_src + c]   (C multiple of 64)
+ *   fo1_transpose_bf16 dst[c*ld_dst + col0 + m] = src[m*ld_src + c]   (C multiple of 64; col0 from *dyn_col0 if set)
  * ---------------------------------------------------------------------- */
 int fo1_rope_llm_bf16(void* qkv, int ld, int col0, int n_heads, int head_dim, const void* cos_bf16,
                       const void* sin_bf16, int L, void* kcache, int k_first_head,
-                      long long kcache_head_stride, int pos0, void* stream);
+                      long long kcache_head_stride, int pos0, const int32_t* dyn_state, void* stream);
 int fo1_rope_vit_bf16(void* qkv, int ld, int n_heads, int head_dim, const float* cos_f32,
                       const float* sin_f32, int S, void* stream);
-int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst, int col0, int M, int C,
-                       void* stream);
+int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst, int col0,
+                       const int32_t* dyn_col0, int M, int C, void* stream);
+/* Decode-step bookkeeping kept on the device so that ONE captured hipGraph serves every generated token:
+ * state = device int32[8]: [0] cache position, [1] rope-table row (position + rope delta), [4..7] the attention
+ * work item {pos, pos+1, 0, pos+1}.  fo1_rope_llm_bf16 (dyn_state), fo1_transpose_bf16 (dyn_col0 = &state[0]) and
+ * fo1_attention_bf16 (items = &state[4], q_row_base = &state[0]) read it; fo1_decode_advance increments it.
+ * (reference: cache_position + rope_deltas arithmetic of modeling_qwen2_5_vl.py:1848-1860) */
+int fo1_decode_advance(int32_t* state, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused attention  softmax(scale * Q K^T [+ causal mask]) V   (flash_attn_varlen_func /
@@ -188,7 +195,8 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
                        const void* VT, long long vt_row_stride,
                        void* O, long long o_tok_stride, long long o_head_stride,
                        const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads,
-                       int head_dim, float scale, int causal, double flops_hint, void* stream);
+                       int head_dim, float scale, int causal, const int32_t* q_row_base, double flops_hint,
+                       void* stream);
 
 /* ------------------------------------------------------------------------
  * DaViT / SimpleFPN / splice data-movement kernels on token-major bf16 maps [H*W, C] (C % 8 == 0).

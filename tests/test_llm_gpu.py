@@ -103,3 +103,35 @@ def test_build_inputs_splice_and_errors():
         eng.build_inputs(ids + [DEFAULT_REGION_INDEX], img, reg, (2, 3))
     with pytest.raises(ValueError):
         eng.build_inputs(ids, img, reg, (3, 3))
+
+
+def test_decode_graph_replay_equals_eager_steps():
+    """The captured decode-step graph (device-side position state, fo1_decode_advance) must reproduce the
+    eager per-token launches bit for bit, token after token, across two separate prompts."""
+    cfg_kw = dict(hidden_size=256, num_layers=2, num_heads=2, num_kv_heads=1, intermediate_size=512, vocab_size=512, max_seq=256)
+    cfg, sd, eng = make(cfg_kw, 21, 0, None)
+    for trial, (L0, grid, nb) in enumerate([(70, (4, 6), 11), (95, (5, 5), 30)]):
+        g = torch.Generator().manual_seed(trial)
+        x0 = (torch.randn(L0, 256, generator=g) * 0.05).bfloat16().cuda()
+        n_img = grid[0] * grid[1]
+        pos0, delta = LO.rope_index(nb, grid, L0 - nb - n_img)
+        K = 6
+        # eager
+        _, _, tok = eng.prefill(x0, pos0, delta)
+        eager_tokens, eager_logits = [int(tok.item())], []
+        for _ in range(K):
+            _, lg, tok = eng.decode_step(tok)
+            eager_logits.append(lg.clone())
+            eager_tokens.append(int(tok.item()))
+        # graph
+        _, _, tok = eng.prefill(x0, pos0, delta)
+        eng.sync_decode_state()
+        graph_tokens = [int(tok.item())]
+        first = True
+        for i in range(K):
+            lg, tok = eng.decode_step_graph(tok if first else None)
+            first = False
+            assert torch.equal(lg, eager_logits[i]), f"trial {trial} step {i}: logits differ between graph and eager decode"
+            graph_tokens.append(int(tok.item()))
+        assert graph_tokens == eager_tokens
+        assert eng.kv_len == L0 + K and int(eng.dstate[0].item()) == L0 + K

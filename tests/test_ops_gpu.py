@@ -315,3 +315,28 @@ def test_gemm_fused_swiglu_epilogue():
                 assert torch.equal(fused, ref), f"fused swiglu differs (M={M} F={F} tile={tile}): max {(fused.float() - ref.float()).abs().max()}"
     finally:
         L.load().fo1_gemm_set_variant(0, 0)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+def test_gemv_matches_tile_gemm(M):
+    """The decode-step GEMV (M <= 4) must agree with the MFMA tile kernel on every epilogue form."""
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(20 + M)
+    try:
+        for (N, K, hb, hr, act) in [(2560, 2048, True, False, 0), (2048, 11008, False, True, 0), (151936, 2048, False, False, 0),
+                                    (2048, 2048, False, True, 0), (22016, 2048, False, False, 3), (130, 72, True, True, 1),
+                                    (6912, 1280, True, False, 3)]:
+            a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+            w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+            bias = (torch.randn(N) * 0.1).to(BF).cuda() if hb else None
+            n_out = N // 2 if act == 3 else N
+            res = torch.randn(M, n_out).to(BF).cuda() if hr else None
+            L.load().fo1_gemm_set_gemv(1)
+            got = ops.gemm(a, w, bias, res, act).float().cpu()
+            L.load().fo1_gemm_set_gemv(0)
+            ref = ops.gemm(a, w, bias, res, act).float().cpu()
+            scale = ref.abs().max().item()
+            err = (got - ref).abs().max().item()
+            assert got.shape == ref.shape and err <= 2 ** -7 * scale + 1e-3, f"gemv M={M} N={N} K={K} act={act}: err {err:.4g} scale {scale:.4g}"
+    finally:
+        L.load().fo1_gemm_set_gemv(1)

@@ -143,6 +143,9 @@ class FO1ForCausalLM:
         all_ids = inputs.to(dev)
         if streamer is not None:
             streamer.put(inputs.cpu())
+        first = True
+        if self.use_graph:
+            eng.llm.sync_decode_state()
         for _ in range(int(max_new_tokens)):
             t = tok.to(torch.long).reshape(1, 1)
             all_ids = torch.cat([all_ids, t.to(all_ids.dtype)], dim=1)
@@ -154,7 +157,11 @@ class FO1ForCausalLM:
                 stop = any(bool(c(all_ids, None)) for c in stopping_criteria)
             if stop:
                 break
-            _, _, tok = eng.llm.decode_step(tok)
+            if self.use_graph:
+                _, tok = eng.llm.decode_step_graph(tok if first else None)
+                first = False
+            else:
+                _, _, tok = eng.llm.decode_step(tok)
         if streamer is not None:
             streamer.end()
         return all_ids.to(inputs.device)

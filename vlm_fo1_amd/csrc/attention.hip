@@ -36,6 +36,7 @@ struct AttnParams {
     int n_items, Hq, group;                          // group = Hq / Hkv
     float scale;
     int causal;
+    const int* q_row_base;                           // optional: Q/O row = query index - *q_row_base (decode graphs)
 };
 
 template <int HD, int NW>
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     const int ql = lane & 15, g = lane >> 4;
     const int q_idx = it.q_start + wave * 16 + ql;          // this lane's query (score column)
     const bool q_ok = q_idx < it.q_end;
-    const int q_ld = q_ok ? q_idx : it.q_end - 1;
+    const int q_base = p.q_row_base ? *p.q_row_base : 0;
+    const int q_ld = (q_ok ? q_idx : it.q_end - 1) - q_base;
 
     // Q fragments (B operand): lane (query ql, k-group g) holds d = c*32 + g*8 .. +8
     bf16x8 qf[NC];
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     // o[db][r] = O[query q_idx][d = db*16 + g*4 + r]
     if (q_ok) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
-        uint16_t* op = p.O + (long long)q_idx * p.o_tok + (long long)h * p.o_head;
+        uint16_t* op = p.O + (long long)(q_idx - q_base) * p.o_tok + (long long)h * p.o_head;
 #pragma unroll
         for (int db = 0; db < NDB; ++db) {
             uint2 w;
@@ -204,7 +206,7 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
                        const void* VT, long long vt_row_stride,
                        void* O, long long o_tok_stride, long long o_head_stride,
                        const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads, int head_dim,
-                       float scale, int causal, double flops_hint, void* stream) {
+                       float scale, int causal, const int32_t* q_row_base, double flops_hint, void* stream) {
     using namespace fo1;
     if (n_items == 0) return FO1_OK;
     FO1_CHECK_ARG(Q && K && VT && O && items, "attention: NULL operand");
@@ -224,7 +226,7 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
     p.O = (uint16_t*)O; p.o_tok = o_tok_stride; p.o_head = o_head_stride;
     p.items = (const AttnItem*)items;
     p.n_items = n_items; p.Hq = n_q_heads; p.group = n_q_heads / n_kv_heads;
-    p.scale = scale; p.causal = causal;
+    p.scale = scale; p.causal = causal; p.q_row_base = (const int*)q_row_base;
     hipStream_t st = (hipStream_t)stream;
     if (head_dim == 32) return launch_attn<32>(p, q_block, st, flops_hint);
     if (head_dim == 80) return launch_attn<80>(p, q_block, st, flops_hint);

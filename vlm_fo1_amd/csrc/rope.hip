@@ -29,8 +29,11 @@ template <int HD>
 __global__ __launch_bounds__(256) void rope_llm_kernel(uint16_t* __restrict__ x, int ld, int col0, int n_heads,
                                                        const uint16_t* __restrict__ cosb, const uint16_t* __restrict__ sinb, int L,
                                                        uint16_t* __restrict__ kcache, int k_first_head, long long kc_head_stride,
-                                                       int pos0) {
+                                                       int pos0, const int* __restrict__ dyn) {
     constexpr int HC = HD / 16;  // chunk pairs per head (each thread does chunk c and its partner c + HD/16)
+    // decode graphs: position and rope-table row come from device memory (dyn = {cache position, table row})
+    int row0 = 0;
+    if (dyn) { pos0 = dyn[0]; row0 = dyn[1]; }
     const long long total = (long long)L * n_heads * HC;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % HC);
@@ -41,10 +44,10 @@ __global__ __launch_bounds__(256) void rope_llm_kernel(uint16_t* __restrict__ x,
         float a[8], b[8], ca[8], sa[8], cb[8], sb[8], oa[8], ob[8];
         unpack8r(*reinterpret_cast<const uint4*>(p + d0), a);             // x[d],        d <  HD/2
         unpack8r(*reinterpret_cast<const uint4*>(p + d0 + HD / 2), b);    // x[d + HD/2]
-        unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)t * HD + d0), ca);
-        unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)t * HD + d0), sa);
-        unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)t * HD + d0 + HD / 2), cb);
-        unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)t * HD + d0 + HD / 2), sb);
+        unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)(row0 + t) * HD + d0), ca);
+        unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)(row0 + t) * HD + d0), sa);
+        unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)(row0 + t) * HD + d0 + HD / 2), cb);
+        unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)(row0 + t) * HD + d0 + HD / 2), sb);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             oa[j] = rb(a[j] * ca[j]) + rb(-b[j] * sa[j]);  // rotate_half: first half pairs with -x2
@@ -91,8 +94,9 @@ __global__ __launch_bounds__(256) void rope_vit_kernel(uint16_t* __restrict__ x,
 
 // dst[c * ldd + col0 + m] = src[m * lds + c], tile 64 rows x 64 cols through LDS
 __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ src, int lds_, uint16_t* __restrict__ dst,
-                                                        long long ldd, int col0, int M, int C) {
+                                                        long long ldd, int col0, int M, int C, const int* __restrict__ dyn_col) {
     __shared__ uint16_t tile[64][66];
+    if (dyn_col) col0 = *dyn_col;
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
     const int tid = threadIdx.x;
     // load: 64 rows x 8 chunks of 8 channels
@@ -125,12 +129,21 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restri
     }
 }
 
+__global__ void decode_advance_kernel(int* __restrict__ st) {
+    if (threadIdx.x == 0) {
+        const int pos = st[0] + 1;
+        st[0] = pos;
+        st[1] = st[1] + 1;
+        st[4] = pos; st[5] = pos + 1; st[6] = 0; st[7] = pos + 1;
+    }
+}
+
 }  // namespace fo1
 
 extern "C" {
 
 int fo1_rope_llm_bf16(void* qkv, int ld, int col0, int n_heads, int head_dim, const void* cos_bf16, const void* sin_bf16, int L,
-                      void* kcache, int k_first_head, long long kcache_head_stride, int pos0, void* stream) {
+                      void* kcache, int k_first_head, long long kcache_head_stride, int pos0, const int32_t* dyn_state, void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(qkv && cos_bf16 && sin_bf16, "rope_llm: NULL operand");
     FO1_CHECK_ARG(head_dim == 128, "rope_llm: head_dim %d not built (128)", head_dim);
@@ -140,7 +153,7 @@ int fo1_rope_llm_bf16(void* qkv, int ld, int col0, int n_heads, int head_dim, co
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     FO1_LAUNCH("rope_llm", (double)L * n_heads * head_dim * 4.0, rope_llm_kernel<128>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                (uint16_t*)qkv, ld, col0, n_heads, (const uint16_t*)cos_bf16, (const uint16_t*)sin_bf16, L, (uint16_t*)kcache,
-               k_first_head, kcache_head_stride, pos0);
+               k_first_head, kcache_head_stride, pos0, (const int*)dyn_state);
     return FO1_OK;
 }
 
@@ -157,14 +170,24 @@ int fo1_rope_vit_bf16(void* qkv, int ld, int n_heads, int head_dim, const float*
     return FO1_OK;
 }
 
-int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst, int col0, int M, int C, void* stream) {
+int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst, int col0, const int32_t* dyn_col0, int M, int C,
+                       void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(src && dst, "transpose: NULL operand");
     FO1_CHECK_ARG(C > 0 && C % 64 == 0 && ld_src % 8 == 0 && ld_src >= C, "transpose: C=%d must be a multiple of 64", C);
     FO1_CHECK_ARG(col0 >= 0 && ld_dst >= col0 + M, "transpose: destination too narrow");
     if (M == 0) return FO1_OK;
     FO1_LAUNCH("transpose", (double)M * C * 4.0, transpose_kernel, dim3(cdiv(M, 64), C / 64), dim3(256), 0, (hipStream_t)stream,
-               (const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, col0, M, C);
+               (const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, col0, M, C, (const int*)dyn_col0);
+    return FO1_OK;
+}
+
+// Decode bookkeeping on the device so one captured hipGraph serves every step: state = int32[8]
+//   [0] cache position, [1] rope-table row, [4..7] the attention work item {q_start, q_end, 0, kv_end}
+int fo1_decode_advance(int32_t* state, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(state != nullptr, "decode_advance: NULL state");
+    FO1_LAUNCH("decode_advance", 32.0, decode_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)state);
     return FO1_OK;
 }
 

@@ -49,6 +49,7 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fo1_gemm_set_variant": (c_int, [c_int, c_int]),
     "fo1_gemm_set_splitk": (c_int, [c_int]),
+    "fo1_gemm_set_gemv": (c_int, [c_int]),
     "fo1_gemm_profile_shapes": (c_int, [c_int]),
     "fo1_rmsnorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "fo1_layernorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
@@ -56,12 +57,13 @@ SIGNATURES = {
     "fo1_bias_act_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_argmax_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "fo1_rope_llm_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
-                                  c_longlong, c_int, c_void_p]),
+                                  c_longlong, c_int, c_void_p, c_void_p]),
+    "fo1_decode_advance": (c_int, [c_void_p, c_void_p]),
     "fo1_rope_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
-    "fo1_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_int, c_int, c_int, c_void_p]),
+    "fo1_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
     "fo1_attention_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,
                                    c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                   c_float, c_int, ctypes.c_double, c_void_p]),
+                                   c_float, c_int, c_void_p, ctypes.c_double, c_void_p]),
     "fo1_dwconv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fo1_im2col_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_window_partition_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -98,6 +98,15 @@ class QwenLLM:
         self.kv_len = 0
         self.rope_delta = 0
         self._item_cache: Dict[Tuple[int, int], torch.Tensor] = {}
+        # ---- decode-step graph state (fo1_decode_advance, include/fo1.h) ----
+        # text positions have t = h = w, so one [max_seq, head_dim] table indexed by (cache position + rope delta)
+        # covers every decode step; it is built on the host with the prefill's exact code path
+        p = torch.arange(c.max_seq).view(1, -1).expand(3, -1)
+        cos_t, sin_t = mrope_tables(p, c.head_dim, c.rope_theta, c.mrope_section)
+        self.rope_cos, self.rope_sin = cos_t.to(self.dev), sin_t.to(self.dev)
+        self.dstate = torch.zeros(8, dtype=torch.int32, device=self.dev)       # [pos, rope_row, -, -, item(4)]
+        self.dplan = torch.zeros(1, 2, dtype=torch.int32, device=self.dev)     # gather plan of the one new token: (0, token id)
+        self._dgraph = None
 
     # ---- splice ------------------------------------------------------------------------------
     def plan_inputs(self, input_ids: Sequence[int], n_img: int, n_regions: int, grid_hw_merged: Tuple[int, int]):
@@ -193,12 +202,71 @@ class QwenLLM:
         self.rope_delta = rope_delta
         return self._head(x)
 
+    def sync_decode_state(self):
+        """Publish (kv_len, rope row, first decode work item) to the device-side decode state."""
+        n = self.kv_len
+        st = torch.tensor([n, n + self.rope_delta, 0, 0, n, n + 1, 0, n + 1], dtype=torch.int32)
+        self.dstate.copy_(st, non_blocking=True)
+
     def _head(self, x: torch.Tensor):
         c = self.cfg
         last = ops.rmsnorm(x[-1:], self.norm, c.rms_norm_eps)
         logits = ops.gemm(last, self.lm_head)  # last row only: output-identical to the reference's all-row lm_head
         tok = ops.argmax(logits[0])
         return last, logits, tok
+
+    def _decode_device(self):
+        """One decode step whose every position-dependent quantity is read from device memory (self.dstate /
+        self.dplan): capturable once, replayable for every token."""
+        c = self.cfg
+        H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
+        x = ops.gather_rows(self.dplan, c.hidden_size, self.embed)
+        scale = 1.0 / math.sqrt(HD)
+        pos_ptr = self.dstate[0:1]
+        items = self.dstate[4:8].view(1, 4)
+        for li, w in enumerate(self.layers):
+            h = ops.rmsnorm(x, w["ln1"], c.rms_norm_eps)
+            qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
+            ops.rope_llm(qkv, H + KV, HD, self.rope_cos, self.rope_sin, kcache=self.kcache[li], k_first_head=H, dyn_state=self.dstate)
+            ops.transpose_into(qkv[:, (H + KV) * HD:], self.vtcache[li], dyn_col0=pos_ptr)
+            att = ops.attention_strided(qkv[:, :H * HD], 0, self.kcache[li], self.vtcache[li], items, H, KV, HD, scale, True,
+                                        q_row_base=pos_ptr, n_items=1)
+            x = ops.gemm(att, w["wo"], residual=x)
+            h = ops.rmsnorm(x, w["ln2"], c.rms_norm_eps)
+            a = ops.gemm(h, w["wgu"], act=ops.ACT_SWIGLU16)
+            x = ops.gemm(a, w["wdown"], residual=x)
+        last = ops.rmsnorm(x, self.norm, c.rms_norm_eps)
+        logits = ops.gemm(last, self.lm_head)
+        ops.argmax(logits[0], out=self.dplan.view(-1)[1:2])    # next token id lands in the gather plan of the next step
+        ops.decode_advance(self.dstate)
+        return logits
+
+    def decode_step_graph(self, token_id: Optional[torch.Tensor] = None):
+        """Greedy step via one replayed hipGraph.  `token_id` (device int32 [1]) seeds the plan on the first step
+        after a prefill; later steps reuse the id the previous replay wrote.  Returns (logits, next id tensor)."""
+        if token_id is not None:
+            self.dplan.view(-1)[1:2].copy_(token_id.to(torch.int32).view(1), non_blocking=True)
+        if self._dgraph is None:
+            snap = self.dstate.clone()
+            plan = self.dplan.clone()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._decode_device()          # warm-up: allocates scratch (the step it computes is re-done below)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            self.dstate.copy_(snap)
+            self.dplan.copy_(plan)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                logits = self._decode_device()
+            self.dstate.copy_(snap)            # the capture itself does not execute, but keep the state exact
+            self.dplan.copy_(plan)
+            self._dgraph = (g, logits)
+        g, logits = self._dgraph
+        g.replay()
+        self.kv_len += 1
+        return logits, self.dplan.view(-1)[1:2]
 
     def decode_step(self, token_id: torch.Tensor):
         """One greedy step: token_id int32 [1] on device -> (logits, next id).  Position =

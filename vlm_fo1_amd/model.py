@@ -189,12 +189,19 @@ class FO1Engine:
         out = self.prefill(input_ids, pixel_values, grid_hw, aux_image, boxes, use_graph=use_graph)
         tok = out["next_token"]
         new: List[int] = []
+        first = True
+        if use_graph:
+            self.llm.sync_decode_state()
         for _ in range(max_new_tokens):
             t = int(tok.item())
             new.append(t)
             if t in stop_ids:
                 break
-            _, _, tok = self.llm.decode_step(tok)
+            if use_graph:
+                _, tok = self.llm.decode_step_graph(tok if first else None)
+                first = False
+            else:
+                _, _, tok = self.llm.decode_step(tok)
         return new
 
 

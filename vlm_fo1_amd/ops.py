@@ -137,18 +137,22 @@ def argmax(row: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
 
 
 def rope_llm(qkv: torch.Tensor, n_heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor,
-             kcache: Optional[torch.Tensor] = None, k_first_head: int = 0, pos0: int = 0, col0: int = 0) -> None:
-    """In place on heads [0,n_heads) (q heads then k heads) of qkv [L, ld]; cos/sin bf16 [L, head_dim]."""
+             kcache: Optional[torch.Tensor] = None, k_first_head: int = 0, pos0: int = 0, col0: int = 0,
+             dyn_state: Optional[torch.Tensor] = None) -> None:
+    """In place on heads [0,n_heads) (q heads then k heads) of qkv [L, ld]; cos/sin bf16 [L, head_dim] — or, with
+    dyn_state (device int32: [cache position, table row]), full per-position tables indexed on the device."""
     _chk(qkv, "qkv"); _chk(cos, "cos"); _chk(sin, "sin")
     p, ld, L, _ = _rows(qkv, "qkv")
-    assert cos.shape == (L, head_dim) and cos.is_contiguous() and sin.is_contiguous()
+    assert cos.shape[1] == head_dim and cos.is_contiguous() and sin.is_contiguous()
+    assert dyn_state is not None or cos.shape[0] == L
     kc_ptr, kc_stride = None, 0
     if kcache is not None:
         _chk(kcache, "kcache")
         assert kcache.dim() == 3 and kcache.shape[2] == head_dim and kcache.stride(2) == 1 and kcache.stride(1) == head_dim
         kc_ptr, kc_stride = kcache.data_ptr(), kcache.stride(0)
     _L.check(_L.load().fo1_rope_llm_bf16(p, ld, col0, n_heads, head_dim, cos.data_ptr(), sin.data_ptr(), L, kc_ptr,
-                                         k_first_head, kc_stride, pos0, _stream()), "fo1_rope_llm_bf16")
+                                         k_first_head, kc_stride, pos0, dyn_state.data_ptr() if dyn_state is not None else None,
+                                         _stream()), "fo1_rope_llm_bf16")
 
 
 def rope_vit(qkv: torch.Tensor, n_heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor) -> None:
@@ -159,13 +163,20 @@ def rope_vit(qkv: torch.Tensor, n_heads: int, head_dim: int, cos: torch.Tensor, 
              "fo1_rope_vit_bf16")
 
 
-def transpose_into(src: torch.Tensor, dst: torch.Tensor, col0: int = 0) -> None:
-    """dst[c, col0 + m] = src[m, c];  src [M, C] (C % 64 == 0), dst [C, >= col0 + M]."""
+def transpose_into(src: torch.Tensor, dst: torch.Tensor, col0: int = 0, dyn_col0: Optional[torch.Tensor] = None) -> None:
+    """dst[c, col0 + m] = src[m, c];  src [M, C] (C % 64 == 0), dst [C, >= col0 + M]; col0 read from the device int
+    `dyn_col0` when given."""
     _chk(src, "src"); _chk(dst, "dst")
     p, ld, M, C = _rows(src, "src")
     pd, ldd, Cd, _ = _rows(dst, "dst")
     assert Cd == C
-    _L.check(_L.load().fo1_transpose_bf16(p, ld, pd, ldd, col0, M, C, _stream()), "fo1_transpose_bf16")
+    _L.check(_L.load().fo1_transpose_bf16(p, ld, pd, ldd, col0, dyn_col0.data_ptr() if dyn_col0 is not None else None, M, C,
+                                          _stream()), "fo1_transpose_bf16")
+
+
+def decode_advance(state: torch.Tensor) -> None:
+    assert state.dtype == torch.int32 and state.numel() >= 8 and state.is_contiguous()
+    _L.check(_L.load().fo1_decode_advance(state.data_ptr(), _stream()), "fo1_decode_advance")
 
 
 def pick_q_block(segments: Sequence[Sequence[int]], n_heads: int, target_wgs: int = 512) -> int:
@@ -203,8 +214,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.T
     po, ldo, _, _ = _rows(out, "out")
     rc = _L.load().fo1_attention_bf16(pq, ldq, head_dim, pk, ldk, head_dim, pv, ldv, po, ldo, head_dim,
                                       items.data_ptr(), items.shape[0], getattr(items, "q_block", 64), n_q_heads, n_kv_heads,
-                                      head_dim, float(scale),
-                                      1 if causal else 0, float(flops), _stream())
+                                      head_dim, float(scale), 1 if causal else 0, None, float(flops), _stream())
     _L.check(rc, "fo1_attention_bf16")
     return out
 
@@ -329,10 +339,11 @@ def gather_rows_into(plan: torch.Tensor, D: int, table: torch.Tensor, out: torch
 
 def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_q_heads: int,
                       n_kv_heads: int, head_dim: int, scale: float, causal: bool, flops: float = 0.0,
-                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Attention against a KV cache.  q [Lq, n_q_heads*head_dim] holds absolute positions
-    q_row0 .. q_row0+Lq (the items index absolute positions); k is the cache [n_kv, Lmax, head_dim],
-    vt the transposed V cache [n_kv*head_dim, Lmax]."""
+                      out: Optional[torch.Tensor] = None, q_row_base: Optional[torch.Tensor] = None, n_items: Optional[int] = None) -> torch.Tensor:
+    """Attention against a KV cache.  q [Lq, n_q_heads*head_dim] holds absolute positions q_row0 .. q_row0+Lq (the
+    items index absolute positions) — or, with `q_row_base` (device int32 scalar), positions *q_row_base + row so a
+    captured graph can serve every decode step.  k is the cache [n_kv, Lmax, head_dim], vt the transposed V cache
+    [n_kv*head_dim, Lmax]; `items` may be a raw int32 view (n_items rows of 4)."""
     _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt")
     assert items.dtype == torch.int32 and items.is_contiguous()
     pq, ldq, Lq, _ = _rows(q, "q")
@@ -341,9 +352,12 @@ def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.T
     if out is None:
         out = torch.empty(Lq, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
     po, ldo, _, _ = _rows(out, "out")
+    if q_row_base is not None:
+        q_row0 = 0
     rc = _L.load().fo1_attention_bf16(pq - q_row0 * ldq * 2, ldq, head_dim, k.data_ptr(), k.stride(1), k.stride(0), pv, ldv,
-                                      po - q_row0 * ldo * 2, ldo, head_dim, items.data_ptr(), items.shape[0],
-                                      getattr(items, "q_block", 64), n_q_heads,
-                                      n_kv_heads, head_dim, float(scale), 1 if causal else 0, float(flops), _stream())
+                                      po - q_row0 * ldo * 2, ldo, head_dim, items.data_ptr(),
+                                      n_items if n_items is not None else items.shape[0], getattr(items, "q_block", 64),
+                                      n_q_heads, n_kv_heads, head_dim, float(scale), 1 if causal else 0,
+                                      q_row_base.data_ptr() if q_row_base is not None else None, float(flops), _stream())
     _L.check(rc, "fo1_attention_bf16")
     return out
