@@ -145,7 +145,8 @@ int fo1_gemm_profile_shapes(int on);
  *                      and the channel LayerNorm of simple_fpn.py:58-78 on token-major maps
  *   fo1_swiglu_bf16    act_fn(gate)*up           modeling_qwen2_5_vl.py:85-86, :636; input rows are [gate | up]
  *   fo1_bias_act_bf16  y = act(x + bias)         act 0 none / 1 erf-GELU (nn.GELU, simple_fpn.py:145)
- *   fo1_argmax_bf16    greedy next token         first index among ties, like torch.argmax
+ *   fo1_argmax_bf16    greedy next token         first index among ties, like torch.argmax (two-stage over 128
+ *                                                slices when a 1 KiB scratch is given)
  * ---------------------------------------------------------------------- */
 int fo1_rmsnorm_bf16(const void* x, int ldx, const void* weight, void* y, int ldy, int M, int D,
                      float eps, void* stream);
@@ -154,7 +155,7 @@ int fo1_layernorm_bf16(const void* x, int ldx, const void* weight, const void* b
 int fo1_swiglu_bf16(const void* gate_up, int ldgu, void* out, int ldo, int M, int F, void* stream);
 int fo1_bias_act_bf16(const void* x, int ldx, const void* bias, void* y, int ldy, int M, int D, int act,
                       void* stream);
-int fo1_argmax_bf16(const void* x, int n, int* out, void* stream);
+int fo1_argmax_bf16(const void* x, int n, int* out, void* scratch /* 1 KiB device scratch or NULL */, void* stream);
 
 /* ------------------------------------------------------------------------
  * Rotary embeddings on the fused QKV activations, and the V -> V^T copy.
@@ -230,6 +231,17 @@ int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, void* stream)
 int fo1_nchw_to_hwc8_bf16(const void* img, int is_f32, void* out, int H, int W, void* stream);
 int fo1_gather_rows_bf16(const void* table0, int ld0, const void* table1, int ld1, const void* table2,
                          int ld2, const int32_t* plan, void* out, int ldo, int R, int D, void* stream);
+
+/* Decode-step attention of ONE new token against the KV cache, split over 64-key chunks across workgroups
+ * (grid = max chunks x KV heads; the query heads sharing a KV head ride as MFMA query columns), chunk count taken
+ * from the device-side kv length so the launch replays inside a hipGraph; partials merged in a fixed order.
+ * q: bf16 [n_q_heads*head_dim]; kcache/vtcache as for fo1_attention_bf16; out bf16 [n_q_heads*head_dim].
+ * (reference: the 1-token fast path of omchat_qwen2_5_vl.py:143-155 + attention at modeling_qwen2_5_vl.py:738-802) */
+size_t fo1_attention_decode_workspace_bytes(int max_kv_len, int n_kv_heads, int head_dim);
+int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok_stride, long long k_head_stride,
+                              const void* vtcache, long long vt_row_stride, void* out, const int32_t* dyn_kv_len,
+                              int max_kv_len, int n_q_heads, int n_kv_heads, int head_dim, float scale,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

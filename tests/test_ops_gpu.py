@@ -340,3 +340,29 @@ def test_gemv_matches_tile_gemm(M):
             assert got.shape == ref.shape and err <= 2 ** -7 * scale + 1e-3, f"gemv M={M} N={N} K={K} act={act}: err {err:.4g} scale {scale:.4g}"
     finally:
         L.load().fo1_gemm_set_gemv(1)
+
+
+def test_attention_decode_split_kv():
+    """Flash-decoding path (KV split over workgroups, device-side kv length) == the single-workgroup kernel."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(31)
+    H, KV, D, Lmax = 16, 2, 128, 512
+    kc = torch.zeros(KV, Lmax, D, dtype=BF, device="cuda")
+    vt = torch.zeros(KV * D, Lmax, dtype=BF, device="cuda")
+    for n in (1, 63, 64, 65, 300, 512):
+        k = (torch.randn(n, KV * D) * 1.2).to(BF).cuda()
+        v = torch.randn(n, KV * D).to(BF).cuda()
+        kc.zero_(); vt.zero_()
+        kc[:, :n] = k.view(n, KV, D).permute(1, 0, 2)
+        ops.transpose_into(v, vt, 0)
+        q = (torch.randn(1, H * D) * 1.2).to(BF).cuda()
+        kv_len = torch.tensor([n], dtype=torch.int32, device="cuda")
+        got = ops.attention_decode(q, kc, vt, kv_len, Lmax, H, KV, D, 1 / math.sqrt(D))
+        ref = attn_ref(q.float().cpu().reshape(1, H, D).expand(n, H, D).contiguous(), k.float().cpu().reshape(n, KV, D),
+                       v.float().cpu().reshape(n, KV, D), [(0, n)], False, 1 / math.sqrt(D))[0].reshape(1, H * D)
+        err = (got.float().cpu() - ref).abs().max()
+        assert err < 3e-2, f"decode attention n={n}: max err {err:.4g}"
+    big = torch.randn(151936).to(BF)
+    big[150000] = big.max() + 2
+    big[151000] = big[150000]
+    assert ops.argmax(big.cuda()).item() == 150000, "two-stage argmax: first index among ties"

@@ -37,9 +37,14 @@ struct AttnParams {
     float scale;
     int causal;
     const int* q_row_base;                           // optional: Q/O row = query index - *q_row_base (decode graphs)
+    // split-KV decode (PARTIAL): each item covers one KV chunk; unnormalised fp32 O and (m, l) go to `part`
+    float* part;                                     // [n_items][Hq][16 slots][HD + 2]
+    const int* dyn_kv_len;                           // optional: kv_end/kv_start of item i derived on device: chunk i of *dyn_kv_len keys
+    int kv_chunk;
+    int q_range_end;                                 // PARTIAL: number of query heads per KV head
 };
 
-template <int HD, int NW>
+template <int HD, int NW, bool PARTIAL = false>
 __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     constexpr int NT = NW * 64;
     constexpr int HDP = (HD + 31) / 32 * 32;  // head dim padded to the MFMA K step
@@ -51,7 +56,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) uint16_t sK[KB * LDKR];
     __shared__ __attribute__((aligned(16))) uint16_t sVT[HD * LDVT];
 
-    const AttnItem it = p.items[blockIdx.x];
+    AttnItem it;
+    if (!PARTIAL) it = p.items[blockIdx.x];
+    if (PARTIAL) {
+        it.q_start = 0;
+        it.q_end = p.q_range_end;   // chunk blockIdx.x of the first *dyn_kv_len keys; empty chunks leave (m, l) = (-inf, 0)
+        const int kv_len = *p.dyn_kv_len;
+        it.kv_start = blockIdx.x * p.kv_chunk;
+        it.kv_end = min(kv_len, it.kv_start + p.kv_chunk);
+        if (it.kv_start >= kv_len) return;
+    }
     const int h = blockIdx.y, kvh = h / p.group;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 15, g = lane >> 4;
@@ -172,6 +186,16 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         }
     }
 
+    if (PARTIAL) {
+        if (wave == 0 && q_ok) {
+            float* pr = p.part + (((long long)blockIdx.x * p.Hq + h) * 16 + ql) * (HD + 2);
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                *reinterpret_cast<float4*>(pr + db * 16 + g * 4) = float4{o[db][0], o[db][1], o[db][2], o[db][3]};
+            if (g == 0) { pr[HD] = m_run; pr[HD + 1] = l_run; }
+        }
+        return;
+    }
     // o[db][r] = O[query q_idx][d = db*16 + g*4 + r]
     if (q_ok) {
         const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
@@ -184,6 +208,25 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
             *reinterpret_cast<uint2*>(op + db * 16 + g * 4) = w;
         }
     }
+}
+
+// out[head, d] = sum_s exp(m_s - M) O_s[d] / sum_s exp(m_s - M) l_s over the valid KV chunks (fixed order)
+template <int HD>
+__global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __restrict__ part, const int* __restrict__ dyn_kv_len,
+                                                                 int kv_chunk, int n_kv_heads, int group, uint16_t* __restrict__ out) {
+    const int head = blockIdx.x, d = threadIdx.x;
+    const int kvh = head / group, slot = head - kvh * group;
+    const int n_valid = (*dyn_kv_len + kv_chunk - 1) / kv_chunk;
+    float M = -INFINITY;
+    for (int s = 0; s < n_valid; ++s) M = fmaxf(M, part[(((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + HD]);
+    float num = 0.f, den = 0.f;
+    for (int s = 0; s < n_valid; ++s) {
+        const float* pr = part + (((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2);
+        const float w = __expf(pr[HD] - M);
+        num += w * pr[d];
+        den += w * pr[HD + 1];
+    }
+    out[(long long)head * HD + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
 }
 
 template <int HD>
@@ -227,10 +270,51 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
     p.items = (const AttnItem*)items;
     p.n_items = n_items; p.Hq = n_q_heads; p.group = n_q_heads / n_kv_heads;
     p.scale = scale; p.causal = causal; p.q_row_base = (const int*)q_row_base;
+    p.part = nullptr; p.dyn_kv_len = nullptr; p.kv_chunk = 0; p.q_range_end = 0;
     hipStream_t st = (hipStream_t)stream;
     if (head_dim == 32) return launch_attn<32>(p, q_block, st, flops_hint);
     if (head_dim == 80) return launch_attn<80>(p, q_block, st, flops_hint);
     return launch_attn<128>(p, q_block, st, flops_hint);
+}
+
+// Decode-step attention for ONE new token against the KV cache, split over KV chunks of 64 keys
+// ("flash-decoding"): grid = (max_chunks, n_kv_heads); the n_q_heads/n_kv_heads query heads that share a KV head
+// ride as the query columns of the MFMA.  Chunk count follows the DEVICE-side kv length (state[0] + 1 keys), so the
+// launch is graph-replayable for every step; partial (O, m, l) are merged in a fixed order by a second kernel.
+size_t fo1_attention_decode_workspace_bytes(int max_kv_len, int n_kv_heads, int head_dim) {
+    return (size_t)fo1::cdiv(max_kv_len, 64) * n_kv_heads * 16 * (head_dim + 2) * sizeof(float);
+}
+
+int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok_stride, long long k_head_stride, const void* vtcache,
+                              long long vt_row_stride, void* out, const int32_t* dyn_kv_len, int max_kv_len, int n_q_heads,
+                              int n_kv_heads, int head_dim, float scale, void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(q && kcache && vtcache && out && dyn_kv_len && workspace, "attention_decode: NULL operand");
+    FO1_CHECK_ARG(head_dim == 128, "attention_decode: head_dim %d not built (128)", head_dim);
+    FO1_CHECK_ARG(n_q_heads % n_kv_heads == 0 && n_q_heads / n_kv_heads <= 16, "attention_decode: at most 16 query heads per KV head");
+    FO1_CHECK_ARG(vt_row_stride % 4 == 0 && k_tok_stride % 8 == 0 && k_head_stride % 8 == 0, "attention_decode: bad strides");
+    if (workspace_bytes < fo1_attention_decode_workspace_bytes(max_kv_len, n_kv_heads, head_dim))
+        return set_err(FO1_ERR_WORKSPACE, "attention_decode: workspace too small");
+    static const AttnItem* one_item = nullptr;
+    AttnParams p;
+    const int group = n_q_heads / n_kv_heads;
+    p.Q = (const uint16_t*)q; p.q_tok = head_dim; p.q_head = (long long)group * head_dim;   // "queries" walk the heads of a group
+    p.K = (const uint16_t*)kcache; p.k_tok = k_tok_stride; p.k_head = k_head_stride;
+    p.VT = (const uint16_t*)vtcache; p.vt_row = vt_row_stride;
+    p.O = nullptr; p.o_tok = 0; p.o_head = 0;
+    p.items = (const AttnItem*)workspace;   // unused in PARTIAL mode except q range below (read from a device constant)
+    p.n_items = cdiv(max_kv_len, 64); p.Hq = n_kv_heads; p.group = 1;
+    p.scale = scale; p.causal = 0; p.q_row_base = nullptr;
+    p.part = (float*)workspace; p.dyn_kv_len = (const int*)dyn_kv_len; p.kv_chunk = 64;
+    (void)one_item;
+    p.items = nullptr;
+    p.q_range_end = group;
+    hipStream_t st = (hipStream_t)stream;
+    FO1_LAUNCH("attn_decode_split", (double)max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
+               dim3(p.n_items, n_kv_heads), dim3(256), 0, st, p);
+    FO1_LAUNCH("attn_decode_combine", (double)n_q_heads * head_dim * 8.0, attn_decode_combine_kernel<128>, dim3(n_q_heads), dim3(128), 0, st,
+               (const float*)workspace, (const int*)dyn_kv_len, 64, n_kv_heads, group, (uint16_t*)out);
+    return FO1_OK;
 }
 
 }  // extern "C"

@@ -137,6 +137,55 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const uint16_t* __restric
     }
 }
 
+// argmax stage 1: 128 workgroups scan contiguous slices (first index among ties), partial (value, index) to scratch
+__global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t* __restrict__ x, int n, float* __restrict__ pv, int* __restrict__ pi) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float v = bf16_to_f32(x[i]);
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_v[wave] = best; s_i[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi)) { best = s_v[w]; bi = s_i[w]; }
+        pv[blockIdx.x] = best;
+        pi[blockIdx.x] = bi;
+    }
+}
+
+__global__ __launch_bounds__(128) void argmax_final_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int np, int* __restrict__ out) {
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if ((int)threadIdx.x < np) { best = pv[threadIdx.x]; bi = pi[threadIdx.x]; }
+    __shared__ float s_v[2];
+    __shared__ int s_i[2];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_v[1] > best || (s_v[1] == best && s_i[1] < bi)) { best = s_v[1]; bi = s_i[1]; }
+        *out = bi;
+    }
+}
+
 // argmax over a bf16 row (first index among ties, like torch.argmax): one workgroup
 __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* __restrict__ x, int n, int* __restrict__ out) {
     __shared__ float s_v[16];
@@ -222,10 +271,18 @@ int fo1_bias_act_bf16(const void* x, int ldx, const void* bias, void* y, int ldy
     return FO1_OK;
 }
 
-int fo1_argmax_bf16(const void* x, int n, int* out, void* stream) {
+int fo1_argmax_bf16(const void* x, int n, int* out, void* scratch, void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(x && out && n > 0, "argmax: bad arguments");
-    FO1_LAUNCH("argmax", (double)n * 2.0, argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)x, n, out);
+    if (scratch == nullptr || n < 16384) {
+        FO1_LAUNCH("argmax", (double)n * 2.0, argmax_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)x, n, out);
+        return FO1_OK;
+    }
+    // two stages over 128 slices: scratch = 128 floats + 128 ints (1 KiB), caller-owned
+    float* pv = (float*)scratch;
+    int* pi = (int*)(pv + 128);
+    FO1_LAUNCH("argmax", (double)n * 2.0, argmax_partial_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, n, pv, pi);
+    FO1_LAUNCH("argmax_final", 1024.0, argmax_final_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, (const float*)pv, (const int*)pi, 128, out);
     return FO1_OK;
 }
 

@@ -55,7 +55,10 @@ SIGNATURES = {
     "fo1_layernorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "fo1_swiglu_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fo1_bias_act_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "fo1_argmax_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "fo1_argmax_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "fo1_attention_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fo1_attention_decode_bf16": (c_int, [c_void_p, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_int,
+                                          c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
     "fo1_rope_llm_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_longlong, c_int, c_void_p, c_void_p]),
     "fo1_decode_advance": (c_int, [c_void_p, c_void_p]),

@@ -229,8 +229,8 @@ class QwenLLM:
             qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
             ops.rope_llm(qkv, H + KV, HD, self.rope_cos, self.rope_sin, kcache=self.kcache[li], k_first_head=H, dyn_state=self.dstate)
             ops.transpose_into(qkv[:, (H + KV) * HD:], self.vtcache[li], dyn_col0=pos_ptr)
-            att = ops.attention_strided(qkv[:, :H * HD], 0, self.kcache[li], self.vtcache[li], items, H, KV, HD, scale, True,
-                                        q_row_base=pos_ptr, n_items=1)
+            # split-KV decode attention: chunk count follows the device-side kv length (= dstate[7] = position + 1)
+            att = ops.attention_decode(qkv[:, :H * HD], self.kcache[li], self.vtcache[li], self.dstate[7:8], c.max_seq, H, KV, HD, scale)
             x = ops.gemm(att, w["wo"], residual=x)
             h = ops.rmsnorm(x, w["ln2"], c.rms_norm_eps)
             a = ops.gemm(h, w["wgu"], act=ops.ACT_SWIGLU16)

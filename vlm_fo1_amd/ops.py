@@ -127,12 +127,44 @@ def bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], act: int, out: Optio
     return out
 
 
+_argmax_scratch = {}
+
+
 def argmax(row: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(row, "row")
     assert row.is_contiguous()
     if out is None:
         out = torch.empty(1, dtype=torch.int32, device=row.device)
-    _L.check(_L.load().fo1_argmax_bf16(row.data_ptr(), row.numel(), out.data_ptr(), _stream()), "fo1_argmax_bf16")
+    sc = _argmax_scratch.get(row.device)
+    if sc is None:
+        sc = torch.empty(256, dtype=torch.int32, device=row.device)
+        _argmax_scratch[row.device] = sc
+    _L.check(_L.load().fo1_argmax_bf16(row.data_ptr(), row.numel(), out.data_ptr(), sc.data_ptr(), _stream()), "fo1_argmax_bf16")
+    return out
+
+
+_attn_dec_ws = {}
+
+
+def attention_decode(q: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tensor, kv_len_dev: torch.Tensor, max_kv_len: int,
+                     n_q_heads: int, n_kv_heads: int, head_dim: int, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One new token (q [1, n_q_heads*head_dim]) against the cache; kv_len_dev = device int32 scalar holding the
+    number of keys to attend (cache position + 1)."""
+    _chk(q, "q"); _chk(kcache, "kcache"); _chk(vtcache, "vtcache")
+    assert kv_len_dev.dtype == torch.int32 and kcache.dim() == 3 and q.shape[0] == 1
+    need = _L.load().fo1_attention_decode_workspace_bytes(max_kv_len, n_kv_heads, head_dim)
+    key = (q.device, need)
+    ws = _attn_dec_ws.get(key)
+    if ws is None:
+        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
+        _attn_dec_ws[key] = ws
+    if out is None:
+        out = torch.empty(1, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
+    pv, ldv, _, _ = _rows(vtcache, "vtcache")
+    rc = _L.load().fo1_attention_decode_bf16(q.data_ptr(), kcache.data_ptr(), kcache.stride(1), kcache.stride(0), pv, ldv, out.data_ptr(),
+                                             kv_len_dev.data_ptr(), max_kv_len, n_q_heads, n_kv_heads, head_dim, float(scale),
+                                             ws.data_ptr(), ws.numel(), _stream())
+    _L.check(rc, "fo1_attention_decode_bf16")
     return out
 
 
