@@ -269,14 +269,11 @@ class QwenLLM:
         return logits, self.dplan.view(-1)[1:2]
 
     def decode_step(self, token_id: torch.Tensor):
-        """One greedy step: token_id int32 [1] on device -> (logits, next id).  Position =
-        cache_position + rope_delta on all three axes (reference :1848-1860)."""
-        c = self.cfg
-        plan = torch.stack([torch.zeros_like(token_id), token_id]).t().contiguous().to(torch.int32)
-        x = ops.gather_rows(plan, c.hidden_size, self.embed)
-        p = self.kv_len + self.rope_delta
-        pos = torch.full((3, 1), p, dtype=torch.long)
-        cos, sin = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
-        x = self._forward(x, cos.to(self.dev), sin.to(self.dev), self.kv_len)
+        """One greedy step with individually launched kernels (same device code as the graph path, so the two are
+        bit-identical): token_id int32 [1] on device -> (last hidden placeholder, logits [1, V], next id tensor).
+        Position = cache_position + rope_delta on all three axes (reference :1848-1860)."""
+        self.dplan.view(-1)[1:2].copy_(token_id.to(torch.int32).view(1), non_blocking=True)
+        self.sync_decode_state()
+        logits = self._decode_device()
         self.kv_len += 1
-        return self._head(x)
+        return None, logits, self.dplan.view(-1)[1:2].clone()
