@@ -180,6 +180,15 @@ int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst,
  * fo1_attention_bf16 (items = &state[4], q_row_base = &state[0]) read it; fo1_decode_advance increments it.
  * (reference: cache_position + rope_deltas arithmetic of modeling_qwen2_5_vl.py:1848-1860) */
 int fo1_decode_advance(int32_t* state, void* stream);
+/* One kernel for the decode step's q/k/v post-processing: mRoPE on the q and k heads of the fused qkv row (in place,
+ * table row = state[1]), K heads appended to the K cache and V heads (transposed) to the V^T cache at position state[0]. */
+int fo1_decode_qkv_post_bf16(void* qkv_row, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
+                             const void* sin_table, const int32_t* state, void* kcache, long long kcache_head_stride,
+                             void* vtcache, long long vt_row_stride, void* stream);
+/* Weight-streaming GEMV (M <= 4) with the fo1_gemm_bf16 epilogues and an optional fused Qwen2RMSNorm on the input rows
+ * (norm_weight [K] or NULL): folds input_layernorm / post_attention_layernorm into the projections of the decode step. */
+int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                  void* C, int ldc, int M, int N, int K, int act, const void* norm_weight, float norm_eps, void* stream);
 
 /* ------------------------------------------------------------------------
  * Fused attention  softmax(scale * Q K^T [+ causal mask]) V   (flash_attn_varlen_func /

@@ -14,6 +14,7 @@ llm = pipe.eng.llm
 for _ in range(3):
     _, _, tok = llm.decode_step(tok)
 torch.cuda.synchronize()
+L.load().fo1_gemm_profile_shapes(1)
 L.profile(True)
 N = 10
 for _ in range(N):

@@ -366,3 +366,47 @@ def test_attention_decode_split_kv():
     big[150000] = big.max() + 2
     big[151000] = big[150000]
     assert ops.argmax(big.cuda()).item() == 150000, "two-stage argmax: first index among ties"
+
+
+def test_gemv_fused_rmsnorm_and_ksplit():
+    """fo1_gemv_bf16 with the RMSNorm folded into its prologue == rmsnorm kernel + GEMV, bit for bit; deep-K shapes
+    take the K-split-across-waves variant and must match the tile kernel."""
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(40)
+    for (M, N, K, act) in [(1, 2560, 2048, 0), (1, 22016, 2048, 3), (1, 2048, 11008, 0), (3, 512, 4096, 1), (1, 151936, 2048, 0)]:
+        x = (torch.randn(M, K) * 2).to(BF).cuda()
+        w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+        nw = (1 + 0.1 * torch.randn(K)).to(BF).cuda()
+        fused = ops.gemv(x, w, act=act, norm_weight=nw, norm_eps=1e-6)
+        ref = ops.gemv(ops.rmsnorm(x, nw, 1e-6), w, act=act)
+        assert torch.equal(fused, ref), f"fused norm differs M={M} N={N} K={K}"
+        L.load().fo1_gemm_set_gemv(0)
+        try:
+            tile = ops.gemm(ops.rmsnorm(x, nw, 1e-6), w, act=act)
+        finally:
+            L.load().fo1_gemm_set_gemv(1)
+        scale = tile.float().abs().max().item()
+        assert (fused.float() - tile.float()).abs().max().item() <= 2 ** -7 * scale + 1e-3
+
+
+def test_decode_qkv_post_matches_rope_and_transpose():
+    from vlm_fo1_amd import ops
+    torch.manual_seed(41)
+    H, KV, HD, Lmax = 16, 2, 128, 128
+    p = torch.arange(Lmax).view(1, -1).expand(3, -1)
+    from vlm_fo1_amd.llm import mrope_tables
+    cos, sin = mrope_tables(p, HD, 1e6, (16, 24, 24))
+    cos, sin = cos.cuda(), sin.cuda()
+    for pos, row in [(0, 0), (37, 21), (100, 90)]:
+        qkv = torch.randn(1, (H + 2 * KV) * HD).to(BF).cuda()
+        ref = qkv.clone()
+        kc_ref = torch.zeros(KV, Lmax, HD, dtype=BF, device="cuda")
+        vt_ref = torch.zeros(KV * HD, Lmax, dtype=BF, device="cuda")
+        ops.rope_llm(ref, H + KV, HD, cos[row:row + 1].contiguous(), sin[row:row + 1].contiguous(), kcache=kc_ref, k_first_head=H, pos0=pos)
+        ops.transpose_into(ref[:, (H + KV) * HD:], vt_ref, pos)
+        kc = torch.zeros_like(kc_ref); vt = torch.zeros_like(vt_ref)
+        st = torch.tensor([pos, row, 0, 0, pos, pos + 1, 0, pos + 1], dtype=torch.int32, device="cuda")
+        ops.decode_qkv_post(qkv, H, KV, HD, cos, sin, st, kc, vt)
+        assert torch.equal(qkv, ref) and torch.equal(kc, kc_ref) and torch.equal(vt, vt_ref)
+        ops.decode_advance(st)
+        assert st.tolist() == [pos + 1, row + 1, 0, 0, pos + 1, pos + 2, 0, pos + 2]

@@ -499,8 +499,9 @@ static int g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
 static int g_gemm_profile_shapes = 0;
 static int g_gemm_gemv = 1;      // route M <= 4 to the weight-streaming GEMV (gemv.hip)
 
+extern int g_gemv_profile_shapes;
 int gemv_dispatch(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr, void* C, int ldc,
-                  int M, int N, int K, int act, hipStream_t st);
+                  int M, int N, int K, int act, hipStream_t st, const void* norm_w, float norm_eps);
 
 template <int BM, int BN>
 static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
@@ -620,6 +621,7 @@ int fo1_gemm_set_gemv(int on) {
 
 int fo1_gemm_profile_shapes(int on) {
     fo1::g_gemm_profile_shapes = on != 0;
+    fo1::g_gemv_profile_shapes = on != 0;
     return FO1_OK;
 }
 
@@ -660,7 +662,7 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
     p.sA = p.sW = p.sC = p.sR = 0;
     FO1_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "gemm: workspace must be 16-byte aligned");
     if (g_gemm_gemv && M <= 4 && !out_f32 && (size_t)(M > 2 ? 4 : M) * K * 2 <= 150 * 1024 && (act != 3 || N % 32 == 0))
-        return gemv_dispatch(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+        return gemv_dispatch(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, (hipStream_t)stream, nullptr, 0.f);
     return gemm_dispatch(p, 1, (hipStream_t)stream, (float*)workspace, workspace_bytes);
 }
 

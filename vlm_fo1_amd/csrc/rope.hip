@@ -129,6 +129,46 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restri
     }
 }
 
+// Decode step, one token: mRoPE on the q and k heads of the fused qkv row (in place), append the rotated K heads to
+// the K cache and the V heads (transposed) to the V^T cache, all at the device-side position.  One workgroup.
+template <int HD>
+__global__ __launch_bounds__(256) void decode_qkv_post_kernel(uint16_t* __restrict__ qkv, int n_q, int n_kv, const uint16_t* __restrict__ cosb,
+                                                              const uint16_t* __restrict__ sinb, const int* __restrict__ st,
+                                                              uint16_t* __restrict__ kcache, long long kc_head_stride,
+                                                              uint16_t* __restrict__ vtcache, long long vt_row_stride) {
+    constexpr int HC = HD / 16;
+    const int pos = st[0], row = st[1];
+    const int tid = threadIdx.x;
+    const int n_rope = (n_q + n_kv) * HC;
+    for (int i = tid; i < n_rope; i += 256) {
+        const int c = i % HC, hd = i / HC;
+        uint16_t* p = qkv + hd * HD;
+        const int d0 = c * 8;
+        float a[8], b[8], ca[8], sa[8], cb[8], sb[8], oa[8], ob[8];
+        unpack8r(*reinterpret_cast<const uint4*>(p + d0), a);
+        unpack8r(*reinterpret_cast<const uint4*>(p + d0 + HD / 2), b);
+        unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)row * HD + d0), ca);
+        unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)row * HD + d0), sa);
+        unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)row * HD + d0 + HD / 2), cb);
+        unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)row * HD + d0 + HD / 2), sb);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            oa[j] = rb(a[j] * ca[j]) + rb(-b[j] * sa[j]);
+            ob[j] = rb(b[j] * cb[j]) + rb(a[j] * sb[j]);
+        }
+        const uint4 ua = pack8r(oa), ub = pack8r(ob);
+        *reinterpret_cast<uint4*>(p + d0) = ua;
+        *reinterpret_cast<uint4*>(p + d0 + HD / 2) = ub;
+        if (hd >= n_q) {
+            uint16_t* kc = kcache + (long long)(hd - n_q) * kc_head_stride + (long long)pos * HD;
+            *reinterpret_cast<uint4*>(kc + d0) = ua;
+            *reinterpret_cast<uint4*>(kc + d0 + HD / 2) = ub;
+        }
+    }
+    const uint16_t* v = qkv + (n_q + n_kv) * HD;
+    for (int i = tid; i < n_kv * HD; i += 256) vtcache[(long long)i * vt_row_stride + pos] = v[i];
+}
+
 __global__ void decode_advance_kernel(int* __restrict__ st) {
     if (threadIdx.x == 0) {
         const int pos = st[0] + 1;
@@ -179,6 +219,18 @@ int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst,
     if (M == 0) return FO1_OK;
     FO1_LAUNCH("transpose", (double)M * C * 4.0, transpose_kernel, dim3(cdiv(M, 64), C / 64), dim3(256), 0, (hipStream_t)stream,
                (const uint16_t*)src, ld_src, (uint16_t*)dst, ld_dst, col0, M, C, (const int*)dyn_col0);
+    return FO1_OK;
+}
+
+int fo1_decode_qkv_post_bf16(void* qkv_row, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table, const void* sin_table,
+                             const int32_t* state, void* kcache, long long kcache_head_stride, void* vtcache, long long vt_row_stride,
+                             void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(qkv_row && cos_table && sin_table && state && kcache && vtcache, "decode_qkv_post: NULL operand");
+    FO1_CHECK_ARG(head_dim == 128, "decode_qkv_post: head_dim %d not built (128)", head_dim);
+    FO1_LAUNCH("decode_qkv_post", (double)(n_q_heads + 2 * n_kv_heads) * head_dim * 4.0, decode_qkv_post_kernel<128>, dim3(1), dim3(256), 0,
+               (hipStream_t)stream, (uint16_t*)qkv_row, n_q_heads, n_kv_heads, (const uint16_t*)cos_table, (const uint16_t*)sin_table,
+               (const int*)state, (uint16_t*)kcache, kcache_head_stride, (uint16_t*)vtcache, vt_row_stride);
     return FO1_OK;
 }
 

@@ -62,6 +62,10 @@ SIGNATURES = {
     "fo1_rope_llm_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                   c_longlong, c_int, c_void_p, c_void_p]),
     "fo1_decode_advance": (c_int, [c_void_p, c_void_p]),
+    "fo1_decode_qkv_post_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p,
+                                         c_longlong, c_void_p]),
+    "fo1_gemv_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                              c_void_p, c_float, c_void_p]),
     "fo1_rope_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "fo1_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
     "fo1_attention_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,

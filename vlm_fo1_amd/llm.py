@@ -225,18 +225,15 @@ class QwenLLM:
         pos_ptr = self.dstate[0:1]
         items = self.dstate[4:8].view(1, 4)
         for li, w in enumerate(self.layers):
-            h = ops.rmsnorm(x, w["ln1"], c.rms_norm_eps)
-            qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
-            ops.rope_llm(qkv, H + KV, HD, self.rope_cos, self.rope_sin, kcache=self.kcache[li], k_first_head=H, dyn_state=self.dstate)
-            ops.transpose_into(qkv[:, (H + KV) * HD:], self.vtcache[li], dyn_col0=pos_ptr)
+            # 7 launches per layer: norms folded into the GEMV prologues, rope + K/V^T cache append in one kernel
+            qkv = ops.gemv(x, w["wqkv"], w["bqkv"], norm_weight=w["ln1"], norm_eps=c.rms_norm_eps)
+            ops.decode_qkv_post(qkv, H, KV, HD, self.rope_cos, self.rope_sin, self.dstate, self.kcache[li], self.vtcache[li])
             # split-KV decode attention: chunk count follows the device-side kv length (= dstate[7] = position + 1)
             att = ops.attention_decode(qkv[:, :H * HD], self.kcache[li], self.vtcache[li], self.dstate[7:8], c.max_seq, H, KV, HD, scale)
-            x = ops.gemm(att, w["wo"], residual=x)
-            h = ops.rmsnorm(x, w["ln2"], c.rms_norm_eps)
-            a = ops.gemm(h, w["wgu"], act=ops.ACT_SWIGLU16)
-            x = ops.gemm(a, w["wdown"], residual=x)
-        last = ops.rmsnorm(x, self.norm, c.rms_norm_eps)
-        logits = ops.gemm(last, self.lm_head)
+            x = ops.gemv(att, w["wo"], residual=x)
+            a = ops.gemv(x, w["wgu"], act=ops.ACT_SWIGLU16, norm_weight=w["ln2"], norm_eps=c.rms_norm_eps)
+            x = ops.gemv(a, w["wdown"], residual=x)
+        logits = ops.gemv(x, self.lm_head, norm_weight=self.norm, norm_eps=c.rms_norm_eps)
         ops.argmax(logits[0], out=self.dplan.view(-1)[1:2])    # next token id lands in the gather plan of the next step
         ops.decode_advance(self.dstate)
         return logits

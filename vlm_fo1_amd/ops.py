@@ -206,6 +206,37 @@ def transpose_into(src: torch.Tensor, dst: torch.Tensor, col0: int = 0, dyn_col0
                                           _stream()), "fo1_transpose_bf16")
 
 
+def gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         act: int = ACT_NONE, norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 0.0,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Decode-step projection: out[M<=4, N] = epilogue(rmsnorm?(x) @ w^T) (fo1_gemv_bf16)."""
+    _chk(x, "x"); _chk(w, "w")
+    px, ldx, M, K = _rows(x, "x")
+    pw, ldw, N, K2 = _rows(w, "w")
+    assert K == K2 and M <= 4
+    n_out = N // 2 if act == ACT_SWIGLU16 else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device)
+    po, ldc, _, _ = _rows(out, "out")
+    pr, ldr = (None, 0)
+    if residual is not None:
+        pr, ldr, _, _ = _rows(residual, "residual")
+    rc = _L.load().fo1_gemv_bf16(px, ldx, pw, ldw, bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc, M, N, K, act,
+                                 norm_weight.data_ptr() if norm_weight is not None else None, float(norm_eps), _stream())
+    _L.check(rc, "fo1_gemv_bf16")
+    return out
+
+
+def decode_qkv_post(qkv_row: torch.Tensor, n_q_heads: int, n_kv_heads: int, head_dim: int, cos_table: torch.Tensor,
+                    sin_table: torch.Tensor, state: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tensor) -> None:
+    _chk(qkv_row, "qkv_row"); _chk(kcache, "kcache"); _chk(vtcache, "vtcache")
+    assert qkv_row.shape[0] == 1 and qkv_row.stride(1) == 1 and kcache.dim() == 3 and state.dtype == torch.int32
+    pv, ldv, _, _ = _rows(vtcache, "vtcache")
+    rc = _L.load().fo1_decode_qkv_post_bf16(qkv_row.data_ptr(), n_q_heads, n_kv_heads, head_dim, cos_table.data_ptr(), sin_table.data_ptr(),
+                                            state.data_ptr(), kcache.data_ptr(), kcache.stride(0), pv, ldv, _stream())
+    _L.check(rc, "fo1_decode_qkv_post_bf16")
+
+
 def decode_advance(state: torch.Tensor) -> None:
     assert state.dtype == torch.int32 and state.numel() >= 8 and state.is_contiguous()
     _L.check(_L.load().fo1_decode_advance(state.data_ptr(), _stream()), "fo1_decode_advance")
