@@ -86,6 +86,8 @@ class FO1Engine:
                                use_simpleFPN_for_vt=cfg.mm_use_simpleFPN_for_vt, aux_vision_tower_spatial_scale=0.25)
         self._dummy_box = torch.tensor([[0., 10., 0., 10.]], device=self.dev)  # omchat_qwen2_5_vl.py:90-91
         self._graphs = {}
+        self.overlap_towers = True
+        self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
 
     # ---- encoders ------------------------------------------------------------------------------
     def encode_images(self, pixel_values: torch.Tensor, gh: int, gw: int):
@@ -93,9 +95,11 @@ class FO1Engine:
         tokens, feats = self.vit.forward(pixel_values, gh, gw, capture="last" if self.fpn is not None else "all")
         return self.mm_projector(tokens), feats
 
-    def encode_regions(self, aux_image: torch.Tensor, boxes: Optional[torch.Tensor], vt_feats: List[torch.Tensor], gh: int, gw: int):
-        """-> region tokens [N, d_llm]  (encode_regions :75-108).  boxes: fp32 [N,4] xyxy in aux-image pixels."""
-        aux_maps, aux_sizes = self.davit.forward(aux_image)
+    def encode_regions(self, aux_image: torch.Tensor, boxes: Optional[torch.Tensor], vt_feats: List[torch.Tensor], gh: int, gw: int,
+                       aux_out=None, fpn_out=None):
+        """-> region tokens [N, d_llm]  (encode_regions :75-108).  boxes: fp32 [N,4] xyxy in aux-image pixels.
+        aux_out / fpn_out: tower outputs already computed by the caller (two-stream overlap)."""
+        aux_maps, aux_sizes = aux_out if aux_out is not None else self.davit.forward(aux_image)
         if boxes is None or boxes.shape[0] == 0:
             boxes = self._dummy_box
         boxes = boxes.to(device=self.dev, dtype=torch.float32)
@@ -109,7 +113,7 @@ class FO1Engine:
 
         aux_views = [nchw(t, s) for t, s in zip(aux_maps, aux_sizes)]
         if self.fpn is not None:
-            fpn_maps, fpn_sizes = self.fpn.forward(vt_feats[-1], gh, gw)
+            fpn_maps, fpn_sizes = fpn_out if fpn_out is not None else self.fpn.forward(vt_feats[-1], gh, gw)
             fpn_views = [nchw(t, s) for t, s in zip(fpn_maps, fpn_sizes)]
             self.hfre.simple_fpn = lambda x: fpn_views
             vt_in = nchw(vt_feats[-1], (gh, gw))
@@ -120,8 +124,22 @@ class FO1Engine:
 
     # ---- one image: everything up to the first generated token -----------------------------------
     def _device_prefill(self, pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions: bool):
-        image_tokens, vt_feats = self.encode_images(pix, gh, gw)
-        region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw) if want_regions else None
+        if want_regions and self.overlap_towers:
+            # the two towers are independent until the HFRE: DaViT runs on a side stream while the ViT (+ SimpleFPN) runs
+            # on the main one — most of their GEMMs under-fill 256 CUs on their own.  Inside a hipGraph capture this
+            # becomes a fork/join of two branches.
+            main = torch.cuda.current_stream()
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                aux_maps, aux_sizes = self.davit.forward(aux)
+            image_tokens, vt_feats = self.encode_images(pix, gh, gw)
+            fpn_out = self.fpn.forward(vt_feats[-1], gh, gw) if self.fpn is not None else None
+            main.wait_stream(side)
+            region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw, aux_out=(aux_maps, aux_sizes), fpn_out=fpn_out)
+        else:
+            image_tokens, vt_feats = self.encode_images(pix, gh, gw)
+            region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw) if want_regions else None
         emb = self.llm.embed_rows(plan_dev, image_tokens, region_tokens)
         last, logits, tok = self.llm.prefill(emb, None, 0, tables=(cos, sin))
         return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,

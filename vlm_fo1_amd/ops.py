@@ -37,12 +37,13 @@ _gemm_ws = {}
 
 
 def _gemm_workspace(device) -> torch.Tensor:
-    """Per-device fp32 scratch for split-K partials (caller-owned memory; the library never allocates).
-    Ops on one stream are serialised, so one buffer per device is enough."""
-    ws = _gemm_ws.get(device)
+    """fp32 scratch for split-K partials (caller-owned memory; the library never allocates): one buffer per
+    (device, stream) — ops on one stream are serialised, branches on different streams get their own."""
+    key = (device, torch.cuda.current_stream().cuda_stream)   # per stream: concurrent branches must not share partials
+    ws = _gemm_ws.get(key)
     if ws is None:
         ws = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)  # 64 MiB
-        _gemm_ws[device] = ws
+        _gemm_ws[key] = ws
     return ws
 
 
