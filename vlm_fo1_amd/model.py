@@ -86,7 +86,9 @@ class FO1Engine:
                                use_simpleFPN_for_vt=cfg.mm_use_simpleFPN_for_vt, aux_vision_tower_spatial_scale=0.25)
         self._dummy_box = torch.tensor([[0., 10., 0., 10.]], device=self.dev)  # omchat_qwen2_5_vl.py:90-91
         self._graphs = {}
-        self.overlap_towers = True
+        # Two-stream tower overlap (DaViT || ViT+FPN) is OFF: measured on MI355X / ROCm 7.2 a forked hipGraph replays at
+        # 39.7 ms vs 21.9 ms single-stream (cross-stream joins serialise the node launches), see profiles/README.md.
+        self.overlap_towers = False
         self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
 
     # ---- encoders ------------------------------------------------------------------------------
