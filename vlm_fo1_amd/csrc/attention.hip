@@ -97,24 +97,51 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     const uint16_t* Kb = p.K + (long long)kvh * p.k_head;
     const uint16_t* VTb = p.VT + (long long)kvh * HD * p.vt_row;
 
+    // K / V^T tiles are prefetched into registers one tile ahead (issue-early / write-late): the global-load
+    // latency of tile t+1 hides under the MFMAs + softmax of tile t.
+    constexpr int KCH = HDP / 8;                       // 16-B chunks per K row
+    constexpr int NKR = (KB * KCH + NT - 1) / NT;      // K chunks per thread
+    constexpr int NVR = (HD * (KB / 4) + NT - 1) / NT; // V^T 8-byte pieces per thread
+    uint4 rk[NKR];
+    uint2 rv[NVR];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NKR; ++i) {
+            const int q = tid + i * NT;
+            const int r = q / KCH, c = q - r * KCH;
+            rk[i] = uint4{0, 0, 0, 0};
+            if (q < KB * KCH && k0 + r < kv_hi && c * 8 < HD)
+                rk[i] = *reinterpret_cast<const uint4*>(Kb + (long long)(k0 + r) * p.k_tok + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NVR; ++i) {
+            const int q = tid + i * NT;
+            const int d = q / (KB / 4), c = q - d * (KB / 4);
+            rv[i] = uint2{0, 0};
+            if (q < HD * (KB / 4) && k0 + c * 4 < kv_hi)
+                rv[i] = *reinterpret_cast<const uint2*>(VTb + (long long)d * p.vt_row + k0 + c * 4);
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < NKR; ++i) {
+            const int q = tid + i * NT;
+            const int r = q / KCH, c = q - r * KCH;
+            if (q < KB * KCH) *reinterpret_cast<uint4*>(&sK[r * LDKR + c * 8]) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVR; ++i) {
+            const int q = tid + i * NT;
+            const int d = q / (KB / 4), c = q - d * (KB / 4);
+            if (q < HD * (KB / 4)) *reinterpret_cast<uint2*>(&sVT[d * LDVT + c * 4]) = rv[i];
+        }
+    };
+    if (it.kv_start < kv_hi) gload(it.kv_start);
     for (int k0 = it.kv_start; k0 < kv_hi; k0 += KB) {
         __syncthreads();  // previous tile fully consumed
-        // ---- stage K tile: [KB][HDP] (zero beyond HD / beyond kv_hi) ----
-        constexpr int KCH = HDP / 8;  // 16-B chunks per row
-        for (int q = tid; q < KB * KCH; q += NT) {
-            const int r = q / KCH, c = q - r * KCH;
-            uint4 v = uint4{0, 0, 0, 0};
-            if (k0 + r < kv_hi && c * 8 < HD) v = *reinterpret_cast<const uint4*>(Kb + (long long)(k0 + r) * p.k_tok + c * 8);
-            *reinterpret_cast<uint4*>(&sK[r * LDKR + c * 8]) = v;
-        }
-        // ---- stage V^T tile: [HD][KB] in 8-byte pieces (kv_start and vt_row are multiples of 4) ----
-        for (int q = tid; q < HD * (KB / 4); q += NT) {
-            const int d = q / (KB / 4), c = q - d * (KB / 4);
-            uint2 v = uint2{0, 0};
-            if (k0 + c * 4 < kv_hi) v = *reinterpret_cast<const uint2*>(VTb + (long long)d * p.vt_row + k0 + c * 4);
-            *reinterpret_cast<uint2*>(&sVT[d * LDVT + c * 4]) = v;
-        }
+        swrite();
         __syncthreads();
+        if (k0 + KB < kv_hi) gload(k0 + KB);
 
         // ---- S^T = K Q^T : 4 key sub-tiles of 16 ----
         f32x4 s[4];

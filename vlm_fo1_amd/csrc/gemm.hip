@@ -39,6 +39,7 @@ struct GemmParams {
     long long sA, sW, sC, sR;  // batch strides (elements), blockIdx.y = batch
     int splits, kper;          // split-K: blockIdx.z = split, kper k-tiles (of 64) per split
     float* part;               // fp32 partials [splits][M][N] when splits > 1
+    int debug;                 // ablation (bench only): 1 skip global loads after tile 0, 2 skip MFMA, 4 skip LDS reads + MFMA
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3 };
@@ -318,9 +319,11 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
     const int kt0 = blockIdx.z * p.kper;
     const int nk = min(nk_all - kt0, p.kper);   // this split's k-tiles: [kt0, kt0 + nk)
     issue(kt0, 0);
+    const int dbg = p.debug;
     for (int kt = 0; kt < nk; ++kt) {
         __syncthreads();  // carries vmcnt(0): tile kt has landed; everyone is done with the other buffer
-        if (kt + 1 < nk) issue(kt0 + kt + 1, (kt + 1) & 1);
+        if (kt + 1 < nk && !(dbg & 1)) issue(kt0 + kt + 1, (kt + 1) & 1);
+        if (dbg & 4) continue;
         const char* sa = smem + (kt & 1) * (ROWS * 128);
         const char* sb = sa + BM * 128;
 #pragma unroll
@@ -336,6 +339,13 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
             for (int fm = 0; fm < FM; ++fm) {
                 const int R = wm * WM + fm * 16 + (lane & 15);
                 af[fm] = *reinterpret_cast<const bf16x8*>(sa + R * 128 + ((kc ^ ((R >> 1) & 7)) << 4));
+            }
+            if (dbg & 2) {   // keep the LDS reads alive without MFMA
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn) asm volatile("" ::"v"(wf[fn]));
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) asm volatile("" ::"v"(af[fm]));
+                continue;
             }
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
@@ -497,6 +507,7 @@ static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds
 static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64
 static int g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
 static int g_gemm_profile_shapes = 0;
+static int g_gemm_debug = 0;
 static int g_gemm_gemv = 1;      // route M <= 4 to the weight-streaming GEMV (gemv.hip)
 
 extern int g_gemv_profile_shapes;
@@ -574,6 +585,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
     p.splits = 1;
     p.kper = nk + 1;
     p.part = nullptr;
+    p.debug = g_gemm_debug;
     if (can_split) {
         const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
         const long long tiles = (long long)cdiv(p.M, bm) * cdiv(p.N, bn);
@@ -611,6 +623,11 @@ int fo1_gemm_set_variant(int staging, int tile) {
 int fo1_gemm_set_splitk(int splits) {
     if (splits < 0 || splits > 64) return fo1::set_err(FO1_ERR_ARG, "gemm: bad split-K %d", splits);
     fo1::g_gemm_splitk = splits;
+    return FO1_OK;
+}
+
+int fo1_gemm_set_debug(int bits) {
+    fo1::g_gemm_debug = bits;
     return FO1_OK;
 }
 
