@@ -130,8 +130,9 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
                      const void* residual, int ldr, void* C, int ldc,
                      int M, int N, int K, int act, int out_f32,
                      void* workspace, size_t workspace_bytes, void* stream);
-/* Tuning hooks: staging 0 auto / 1 register-staged / 2 LDS-DMA; tile 0 auto / 1 128x128 /
- * 2 64x128 / 3 64x64; split-K 0 auto / n forced; per-shape kernel names in the profile. */
+/* Tuning hooks: staging 0 auto / 1 register-staged / 2 LDS-DMA two-stage / 3, 4, 6 LDS-DMA ring of that depth
+ * (counted vmcnt; 6 only for the 64x64 tile, else 4); tile 0 auto / 1 128x128 / 2 64x128 / 3 64x64 / 4 128x256
+ * (8 waves); split-K 0 auto / n forced; per-shape kernel names in the profile. */
 int fo1_gemm_set_variant(int staging, int tile);
 int fo1_gemm_set_splitk(int splits);
 int fo1_gemm_set_debug(int bits); /* ablation for benches only: 1 no global loads, 2 no MFMA, 4 no LDS reads + MFMA (results invalid) */

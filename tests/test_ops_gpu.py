@@ -52,8 +52,8 @@ GEMM_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("staging", [1, 2, 3])
-@pytest.mark.parametrize("tile", [1, 2, 3])
+@pytest.mark.parametrize("staging", [1, 2, 3, 4, 6])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
 def test_gemm_variants(staging, tile):
     from vlm_fo1_amd import lib as L, ops
     torch.manual_seed(staging * 10 + tile)

@@ -1,6 +1,7 @@
 // common.h — shared helpers for the libfo1hip.so translation units (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -50,19 +51,23 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- optional per-kernel timing (fo1_profile_*) ---------------------------------------
-// When enabled every FO1_LAUNCH is bracketed by hipEvents on the launch stream; disabled
-// (the default, and always during throughput timing) it is a plain launch.
+// When enabled every FO1_LAUNCH goes through hipExtLaunchKernelGGL with a start/stop event pair, which the runtime fills
+// from the dispatch packet's own begin/end timestamps (the clocks rocprofv3's kernel trace reads), so a row's time is
+// kernel execution only -- no inter-packet latency.  Disabled (the default, and always during throughput timing and
+// graph capture) it is a plain launch.
 bool profile_enabled();
-void profile_begin(const char* name, hipStream_t st, double work);
-void profile_end(hipStream_t st);
+void profile_events(const char* name, double work, hipEvent_t* e0, hipEvent_t* e1);
 
-#define FO1_LAUNCH(name, work, kernel, grid, block, shmem, st, ...)              \
-    do {                                                                         \
-        const bool _prof = fo1::profile_enabled();                               \
-        if (_prof) fo1::profile_begin(name, st, (double)(work));                 \
-        hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);         \
-        if (_prof) fo1::profile_end(st);                                         \
-        FO1_CHECK_LAUNCH();                                                      \
+#define FO1_LAUNCH(name, work, kernel, grid, block, shmem, st, ...)                                   \
+    do {                                                                                              \
+        if (fo1::profile_enabled()) {                                                                 \
+            hipEvent_t _e0, _e1;                                                                      \
+            fo1::profile_events(name, (double)(work), &_e0, &_e1);                                    \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, _e0, _e1, 0, __VA_ARGS__);          \
+        } else {                                                                                      \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                          \
+        }                                                                                             \
+        FO1_CHECK_LAUNCH();                                                                           \
     } while (0)
 
 }  // namespace fo1

@@ -35,7 +35,7 @@ static std::mutex g_prof_mu;
 
 bool profile_enabled() { return g_prof_on; }
 
-void profile_begin(const char* name, hipStream_t st, double work) {
+void profile_events(const char* name, double work, hipEvent_t* e0, hipEvent_t* e1) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRec r;
     r.name = name;
@@ -48,13 +48,9 @@ void profile_begin(const char* name, hipStream_t st, double work) {
         (void)hipEventCreate(&r.e0);
         (void)hipEventCreate(&r.e1);
     }
-    (void)hipEventRecord(r.e0, st);
+    *e0 = r.e0;
+    *e1 = r.e1;
     g_prof.push_back(r);
-}
-
-void profile_end(hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_prof_mu);
-    (void)hipEventRecord(g_prof.back().e1, st);
 }
 
 }  // namespace fo1

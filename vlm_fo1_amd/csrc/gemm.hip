@@ -39,6 +39,7 @@ struct GemmParams {
     long long sA, sW, sC, sR;  // batch strides (elements), blockIdx.y = batch
     int splits, kper;          // split-K: blockIdx.z = split, kper k-tiles (of 64) per split
     float* part;               // fp32 partials [splits][M][N] when splits > 1
+    int stages;                // LDS ring depth: 2 = two-stage kernel, 3/4/6 = counted-vmcnt ring
     int debug;                 // ablation (bench only): 1 skip global loads after tile 0, 2 skip MFMA, 4 skip LDS reads + MFMA
 };
 
@@ -262,13 +263,14 @@ __global__ __launch_bounds__(256) void gemm_bt_reg_kernel(const GemmParams p) {
 // ------------------------------------------------------------------------------------------
 // LDS-DMA path (global_load_lds_dwordx4), K % 64 == 0
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
+template <int BM, int BN, int WGM = 2, int WGN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void gemm_bt_glds_kernel(const GemmParams p) {
+    constexpr int NWV = WGM * WGN;
     constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
     constexpr int ROWS = BM + BN;          // rows of 128 B per stage
     constexpr int INST = ROWS / 8;         // 1-KiB wave-instructions per stage
-    constexpr int IPW = INST / 4;          // per wave
+    constexpr int IPW = INST / NWV;        // per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][ROWS][128]
 
     int tm, tn;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm_bt_glds_kernel(const GemmParams p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const long long bz = blockIdx.y;
     const uint16_t* A = p.A + bz * p.sA;
     const uint16_t* W = p.W + bz * p.sW;
@@ -404,9 +406,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
 // LDS-DMA path, 3-stage ring: two K tiles in flight across each barrier (counted vmcnt + raw s_barrier;
 // __syncthreads() would drain the DMA queue with vmcnt(0)).  All LDS lives in ONE dynamic array.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void gemm_bt_glds3_kernel(const GemmParams p) {
-    constexpr int BK = 64, NS = 3;
+template <int BM, int BN, int NS>
+__global__ __launch_bounds__(256) void gemm_bt_ring_kernel(const GemmParams p) {
+    constexpr int BK = 64;
     constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
     constexpr int ROWS = BM + BN;
     constexpr int INST = ROWS / 8;
@@ -457,19 +459,24 @@ __global__ __launch_bounds__(256) void gemm_bt_glds3_kernel(const GemmParams p) 
     const int nk_all = p.K / BK;
     const int kt0 = blockIdx.z * p.kper;
     const int nk = min(nk_all - kt0, p.kper);
-    issue(kt0, 0);
-    if (nk > 1) issue(kt0 + 1, 1);
+#pragma unroll
+    for (int t = 0; t < NS - 1; ++t)
+        if (t < nk) issue(kt0 + t, t);
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        // this wave's loads of tile kt have landed (only tile kt+1's IPW loads may still be in flight)
-        if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(IPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this wave's loads of tile kt have landed; tiles kt+1 .. kt+NS-2 (IPW loads each) may still be in flight
+        const int ahead = min(nk - 1 - kt, NS - 2);
+        if (ahead <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(IPW) : "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(2 * IPW) : "memory");
+        else if (ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"i"(3 * IPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"(4 * IPW) : "memory");
         __builtin_amdgcn_s_barrier();   // every wave's tile-kt loads landed; everyone finished computing tile kt-1
         asm volatile("" ::: "memory");
-        if (kt + 2 < nk) {
-            int nb = buf + 2;
+        if (kt + NS - 1 < nk) {
+            int nb = buf + NS - 1;
             if (nb >= NS) nb -= NS;
-            issue(kt0 + kt + 2, nb);   // overwrites the buffer tile kt-1 was read from
+            issue(kt0 + kt + NS - 1, nb);   // overwrites the buffer tile kt-1 was read from
         }
         const char* sa = smem + buf * (ROWS * 128);
         const char* sb = sa + BM * 128;
@@ -503,7 +510,7 @@ __global__ __launch_bounds__(256) void gemm_bt_glds3_kernel(const GemmParams p) 
     epilogue<FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz * p.sC, bz * p.sR);
 }
 
-static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds
+static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds two-stage, 3/4/6 glds ring of that depth
 static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64
 static int g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
 static int g_gemm_profile_shapes = 0;
@@ -514,6 +521,48 @@ extern int g_gemv_profile_shapes;
 int gemv_dispatch(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr, void* C, int ldc,
                   int M, int N, int K, int act, hipStream_t st, const void* norm_w, float norm_eps);
 
+// 128 x 256 tile, 8 waves (2 x 4): halves the L2->LDS traffic of the 64 x 128 tile for wide-N GEMMs
+static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
+    constexpr int BM = 128, BN = 256;
+    p.tiles_m = cdiv(p.M, BM);
+    p.tiles_n = cdiv(p.N, BN);
+    const dim3 grid(p.tiles_m * p.tiles_n, batch, p.splits);
+    const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
+    char pname[48];
+    const char* name = "gemm_bt_glds<128,256>";
+    if (profile_enabled() && g_gemm_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemm %dx%dx%d t%dx%d s%d", p.M, p.N, p.K, BM, BN, p.splits);
+        name = pname;
+    }
+    constexpr int smem = 2 * (BM + BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_glds_kernel<BM, BN, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    FO1_LAUNCH(name, flops, (gemm_bt_glds_kernel<BM, BN, 2, 4>), grid, dim3(512), smem, st, p);
+    if (p.splits > 1) {
+        const long long total = (long long)p.M * (p.N / 4);
+        const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        FO1_LAUNCH("gemm_splitk_reduce", (double)p.M * p.N * 4.0 * p.splits, gemm_splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
+    }
+    return FO1_OK;
+}
+
+template <int BM, int BN, int NS>
+static int launch_ring(GemmParams& p, const char* name, double flops, dim3 grid, hipStream_t st) {
+    static_assert((NS - 2) * ((BM + BN) / 32) <= 63, "vmcnt is a 6-bit counter");
+    constexpr int smem = NS * (BM + BN) * 128;
+    static_assert(smem <= 160 * 1024, "LDS per workgroup");
+    static bool attr_done = false;
+    if (!attr_done) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_ring_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    FO1_LAUNCH(name, flops, (gemm_bt_ring_kernel<BM, BN, NS>), grid, dim3(256), smem, st, p);
+    return FO1_OK;
+}
+
 template <int BM, int BN>
 static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
     p.tiles_m = cdiv(p.M, BM);
@@ -521,20 +570,25 @@ static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
     const dim3 grid(p.tiles_m * p.tiles_n, batch, glds ? p.splits : 1);
     const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
     char pname[48];
-    const char* name = glds ? "gemm_bf16_glds" : "gemm_bf16_reg";
-    if (profile_enabled() && g_gemm_profile_shapes) {
-        snprintf(pname, sizeof pname, "gemm %dx%dx%d t%dx%d s%d", p.M, p.N, p.K, BM, BN, glds ? p.splits : 1);
+    // one profile row per kernel template, so the rows map 1:1 onto rocprofv3's kernel names
+    const char* name = !glds ? "gemm_bf16_reg"
+                     : (BM == 128 ? "gemm_bt_glds<128,128>" : (BN == 128 ? "gemm_bt_glds<64,128>" : "gemm_bt_glds<64,64>"));
+    if (glds && p.stages >= 3) {
+        const int ns = p.stages == 3 ? 3 : ((p.stages == 4 || BM + BN > 128) ? 4 : 6);
+        snprintf(pname, sizeof pname, "gemm_bt_ring<%d,%d,%d>", BM, BN, ns);
         name = pname;
     }
-    if (glds && g_gemm_variant == 3) {
-        constexpr int smem3 = 3 * (BM + BN) * 128;
-        static bool attr3_done = false;
-        if (!attr3_done) {
-            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_glds3_kernel<BM, BN>,
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, smem3));
-            attr3_done = true;
-        }
-        FO1_LAUNCH(name, flops, (gemm_bt_glds3_kernel<BM, BN>), grid, dim3(256), smem3, st, p);
+    if (profile_enabled() && g_gemm_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemm %dx%dx%d t%dx%d s%d r%d", p.M, p.N, p.K, BM, BN, glds ? p.splits : 1, glds ? p.stages : 0);
+        name = pname;
+    }
+    if (glds && p.stages >= 3) {
+        int rc = FO1_OK;
+        if (p.stages == 3) rc = launch_ring<BM, BN, 3>(p, name, flops, grid, st);
+        else if (p.stages == 4) rc = launch_ring<BM, BN, 4>(p, name, flops, grid, st);
+        else if constexpr (BM + BN <= 128) rc = launch_ring<BM, BN, 6>(p, name, flops, grid, st);
+        else rc = launch_ring<BM, BN, 4>(p, name, flops, grid, st);
+        if (rc != FO1_OK) return rc;
         if (p.splits > 1) {
             const long long total = (long long)p.M * (p.N / 4);
             const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -566,33 +620,39 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
     bool glds = (p.K % 64 == 0);
     if (g_gemm_variant == 1) glds = false;
     if (g_gemm_variant >= 2 && p.K % 64 != 0) return set_err(FO1_ERR_ARG, "gemm: glds variant needs K %% 64 == 0 (K=%d)", p.K);
-    // Dispatch heuristics measured on MI355X (profiles/r01_gemm_bench_v2.log):
+    // Dispatch heuristics measured on MI355X with COLD weights (scripts/gemm_bench.py cold,
+    // profiles/r01_gemm_bench_cold.log): in the pipeline every GEMM streams its weights from HBM (8 GB of weights
+    // per step against a 256 MB Infinity Cache), which a warm micro-benchmark hides.
     //  * 128x128 tiles once they alone give >= 3 workgroups per CU, else 64x128 if that gives >= 2 per CU,
-    //    else 64x64;
-    //  * split-K only for deep-K skinny outputs (K >= 4096, < 2 workgroups per CU): e.g. the LLM down
-    //    projection 515x2048x11008 goes 79 -> 46 us with 64x128 tiles x 8 splits; at K = 2048 the fp32
-    //    partial round trip costs more than it buys.
+    //    else 64x64; 128x256 (8 waves) for >= 4 full rounds of such tiles;
+    //  * few-tile launches (<= 3 workgroups per CU) are latency-bound on HBM misses: they take the 3-deep
+    //    LDS ring (two k-tiles in flight per workgroup): LLM qkv 25.9 -> 18.2 us, ViT down 39.3 -> 29.2 us;
+    //    many-tile launches keep the two-stage kernel, whose smaller LDS footprint holds more workgroups per CU;
+    //  * split-K only for deep-K skinny outputs (K >= 4096), to about one workgroup per CU:
+    //    LLM down projection 515x2048x11008: 131 us unsplit -> 52 us with 64x128 tiles x 2 splits on the ring.
     const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * batch;
     const long long t64x128 = (long long)cdiv(p.M, 64) * cdiv(p.N, 128) * batch;
+    const long long t64 = (long long)cdiv(p.M, 64) * cdiv(p.N, 64) * batch;
     const int nk = p.K / 64;
     int tile = g_gemm_tile;
     int splits = g_gemm_splitk;
     const bool can_split = glds && batch == 1 && ws != nullptr && p.N % 4 == 0 && p.act != ACT_SWIGLU16;
-    if (tile == 0) {
+    const bool auto_tile = tile == 0;
+    if (auto_tile) {
         tile = (t128 >= 768 && nk >= 16) ? 1 : (t64x128 >= 512 ? 2 : 3);   // shallow K (DaViT stage 0, K=256): 64x128 wins
+        if (glds && nk >= 16 && (long long)cdiv(p.M, 128) * cdiv(p.N, 256) * batch >= 1024) tile = 4;
         if (splits == 0 && can_split && nk >= 64 && t64x128 < 512) tile = 2;
     }
     p.splits = 1;
     p.kper = nk + 1;
     p.part = nullptr;
     p.debug = g_gemm_debug;
+    long long tiles = tile == 3 ? t64 : (tile == 2 ? t64x128 : t128);
     if (can_split) {
-        const int bm = tile == 1 ? 128 : 64, bn = tile == 3 ? 64 : 128;
-        const long long tiles = (long long)cdiv(p.M, bm) * cdiv(p.N, bn);
         if (splits == 0) {
             splits = 1;
-            if (nk >= 64 && tiles < 512) {
-                splits = (int)((1024 + tiles - 1) / tiles);
+            if (nk >= 64 && tiles < 512 && tile == 2) {
+                splits = (int)((256 + tiles - 1) / tiles);
                 if (splits > 8) splits = 8;
             }
         }
@@ -604,6 +664,11 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
             p.part = ws;
         }
     }
+    if (g_gemm_variant >= 3) p.stages = g_gemm_variant;
+    else if (g_gemm_variant == 0 && glds && ((tile == 3 && t64 <= 768) || (tile == 2 && tiles * p.splits < 512))) p.stages = 3;
+    else p.stages = 2;
+    if (tile == 4 && glds && p.stages == 2) return launch_gemm_wide(p, batch, st);
+    if (tile == 4) tile = 1;
     if (tile == 1) return launch_gemm<128, 128>(p, batch, glds, st);
     if (tile == 2) return launch_gemm<64, 128>(p, batch, glds, st);
     return launch_gemm<64, 64>(p, batch, glds, st);
@@ -614,7 +679,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
 extern "C" {
 
 int fo1_gemm_set_variant(int staging, int tile) {
-    if (staging < 0 || staging > 3 || tile < 0 || tile > 3) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
+    if (staging < 0 || staging > 6 || staging == 5 || tile < 0 || tile > 4) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
     fo1::g_gemm_variant = staging;
     fo1::g_gemm_tile = tile;
     return FO1_OK;
