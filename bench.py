@@ -234,15 +234,29 @@ def main():
     roof = None
     if rank == 0:
         L.load().fo1_gemm_profile_shapes(1 if args.profile_shapes else 0)
-        L.profile(True)
-        for _ in range(min(args.steps, 50)):
-            pipe.step(graph=False)   # per-kernel hipEvents need individual launches, not a graph replay
-        torch.cuda.synchronize()
-        rows = L.profile_rows(reset=True)
-        L.profile(False)
-        rows.sort(key=lambda r: -r["total_ms"])
-        dom = rows[0]
         nprof = min(args.steps, 50)
+        TAGS = {"qwen_vit+merger": "vit", "mm_projector": "proj", "davit_large": "davit", "simple_fpn": "fpn",
+                "hfre_region_pool": "hfre", "mm_projector_aux": "proj_aux", "splice": "splice", "llm_prefill+lm_head+argmax": "llm"}
+        L.profile(True)
+        pipe.eng.stage_hook = lambda stage: L.profile_stage(TAGS[stage])   # tags records, no sync
+        for _ in range(nprof):
+            pipe.step(graph=False)   # per-kernel timestamps need individual launches, not a graph replay
+        torch.cuda.synchronize()
+        pipe.eng.stage_hook = None
+        L.profile(False)
+        merged, stage_ms = {}, {}
+        inv = {v: k for k, v in TAGS.items()}
+        for r in L.profile_rows(reset=True):
+            tag, _, kname = r["name"].rpartition("|")
+            stage = inv.get(tag, "unattributed")
+            stage_ms[stage] = stage_ms.get(stage, 0.0) + r["total_ms"]
+            m = merged.setdefault(kname, dict(name=kname, calls=0, total_ms=0.0, total_work=0.0))
+            m["calls"] += r["calls"]
+            m["total_ms"] += r["total_ms"]
+            m["total_work"] += r["total_work"]
+        rows = sorted(merged.values(), key=lambda r: -r["total_ms"])
+        dom = rows[0]
+        stage_ms = {k: round(v / nprof, 4) for k, v in stage_ms.items() if v > 0}
         avg_ms = dom["total_ms"] / dom["calls"]
         work = dom["total_work"] / dom["calls"]
         mfma = dom["name"].startswith("gemm") or dom["name"].startswith("attn")
@@ -275,6 +289,14 @@ def main():
                                stages=Pipeline.stages, launch="eager" if args.eager else "hipGraph replay (1 graph per shape signature)",
                                parallelism=f"dp{world} (images sharded, no data-path collective)"),
                    decode=dec, roofline=roof)
+        if roof is not None:
+            # stage times (sum of kernel execution time per stage, eager pass) and the two region-token rates
+            out["stage_kernel_ms"] = stage_ms
+            t_reg = stage_ms.get("hfre_region_pool", 0.0) + stage_ms.get("mm_projector_aux", 0.0)
+            t_enc = t_reg + stage_ms.get("davit_large", 0.0) + stage_ms.get("simple_fpn", 0.0)
+            if t_reg > 0:
+                out["region_tokens_per_sec_hfre_plus_connector"] = round(args.boxes / (t_reg * 1e-3), 1)
+                out["region_tokens_per_sec_encode_regions"] = round(args.boxes / (t_enc * 1e-3), 1)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(case, pipe)
         print(json.dumps(out))

@@ -34,8 +34,11 @@ const char* fo1_last_error(void);
 
 /* ------------------------------------------------------------------------
  * Per-kernel timing for bench.py's roofline line.  While enabled, every kernel the
- * library launches is bracketed by hipEvents on its launch stream.  Off by default and
- * during throughput timing (the event records perturb back-to-back launches).
+ * library launches goes through hipExtLaunchKernelGGL with a start/stop event pair on its
+ * launch stream (kernel execution time only, the clocks rocprofv3's kernel trace reads).
+ * Off by default, during throughput timing and during graph capture.
+ * fo1_profile_stage(tag) labels the records since the previous call "<tag>|<kernel>" (stage
+ * boundaries for the per-stage breakdown); it does not synchronise.
  * `total_work` accumulates the ALGORITHMIC bytes (HBM-bound kernels) or flops
  * (MFMA-bound kernels) of each launch, as documented per kernel in DESIGN.md.
  * ---------------------------------------------------------------------- */
@@ -47,6 +50,7 @@ typedef struct fo1_profile_row {
 } fo1_profile_row_t;
 int fo1_profile_enable(int on);
 int fo1_profile_read(fo1_profile_row_t* rows, int cap, int reset);
+int fo1_profile_stage(const char* tag);
 
 /* ------------------------------------------------------------------------
  * HFRE region pooling  
@@ -168,6 +172,8 @@ int fo1_argmax_bf16(const void* x, int n, int* out, void* scratch /* 1 KiB devic
  *   fo1_rope_vit_bf16  apply_rotary_pos_emb_flashatt / _vision  :162-169, :219-230: fp32 cos/sin
  *        [S, head_dim/2]; rotates the q and k heads (2*n_heads heads from column 0) in place.
  *   fo1_transpose_bf16 dst[c*ld_dst + col0 + m] = src[m*ld_src + c]   (C multiple of 64; col0 from *dyn_col0 if set)
+ *   fo1_qkv_post_llm_bf16 / fo1_qkv_post_vit_bf16  prefill: the rope above on the q/k heads of the fused qkv rows
+ *        [q heads | k heads | v heads] PLUS the V -> V^T copy (and, LLM, the K-cache append at pos0) in ONE launch.
  * ---------------------------------------------------------------------- */
 int fo1_rope_llm_bf16(void* qkv, int ld, int col0, int n_heads, int head_dim, const void* cos_bf16,
                       const void* sin_bf16, int L, void* kcache, int k_first_head,
@@ -176,6 +182,11 @@ int fo1_rope_vit_bf16(void* qkv, int ld, int n_heads, int head_dim, const float*
                       const float* sin_f32, int S, void* stream);
 int fo1_transpose_bf16(const void* src, int ld_src, void* dst, long long ld_dst, int col0,
                        const int32_t* dyn_col0, int M, int C, void* stream);
+int fo1_qkv_post_llm_bf16(void* qkv, int ld, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_bf16,
+                          const void* sin_bf16, int L, void* kcache, long long kcache_head_stride,
+                          void* vtcache, long long vt_row_stride, int pos0, void* stream);
+int fo1_qkv_post_vit_bf16(void* qkv, int ld, int n_heads, int head_dim, const float* cos_f32,
+                          const float* sin_f32, int S, void* vt, long long vt_ld, void* stream);
 /* Decode-step bookkeeping kept on the device so that ONE captured hipGraph serves every generated token:
  * state = device int32[8]: [0] cache position, [1] rope-table row (position + rope delta), [4..7] the attention
  * work item {pos, pos+1, 0, pos+1}.  fo1_rope_llm_bf16 (dyn_state), fo1_transpose_bf16 (dyn_col0 = &state[0]) and

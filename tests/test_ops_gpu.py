@@ -410,3 +410,34 @@ def test_decode_qkv_post_matches_rope_and_transpose():
         assert torch.equal(qkv, ref) and torch.equal(kc, kc_ref) and torch.equal(vt, vt_ref)
         ops.decode_advance(st)
         assert st.tolist() == [pos + 1, row + 1, 0, 0, pos + 1, pos + 2, 0, pos + 2]
+
+
+def test_qkv_post_fused_equals_separate_kernels():
+    """The one-launch prefill post-processing (rope + K append + V^T) must be bit-identical to the separately
+    tested rope_* and transpose kernels."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(21)
+    # LLM: 16 q heads, 2 kv heads, hd 128, ragged L, append at pos0
+    L, H, KV, HD, pos0, max_seq = 139, 16, 2, 128, 37, 256
+    qkv = torch.randn(L, (H + 2 * KV) * HD).to(BF).cuda()
+    cos = torch.randn(L, HD).to(BF).cuda()
+    sin = torch.randn(L, HD).to(BF).cuda()
+    a, b = qkv.clone(), qkv.clone()
+    kc_a = torch.zeros(KV, max_seq, HD, dtype=BF, device="cuda"); kc_b = torch.zeros_like(kc_a)
+    vt_a = torch.zeros(KV * HD, max_seq, dtype=BF, device="cuda"); vt_b = torch.zeros_like(vt_a)
+    ops.rope_llm(a, H + KV, HD, cos, sin, kcache=kc_a, k_first_head=H, pos0=pos0)
+    ops.transpose_into(a[:, (H + KV) * HD:], vt_a, col0=pos0)
+    ops.qkv_post_llm(b, H, KV, HD, cos, sin, kc_b, vt_b, pos0)
+    assert torch.equal(a, b) and torch.equal(kc_a, kc_b) and torch.equal(vt_a, vt_b)
+    assert vt_b[:, :pos0].abs().sum() == 0 and vt_b[:, pos0 + L:].abs().sum() == 0
+    # ViT: 16 heads, hd 80
+    S, H, hd = 203, 16, 80
+    d = H * hd
+    qkv = torch.randn(S, 3 * d).to(BF).cuda()
+    cos = torch.randn(S, hd // 2).cuda(); sin = torch.randn(S, hd // 2).cuda()
+    a, b = qkv.clone(), qkv.clone()
+    vt_a = torch.zeros(d, 256, dtype=BF, device="cuda"); vt_b = torch.zeros_like(vt_a)
+    ops.rope_vit(a, H, hd, cos, sin)
+    ops.transpose_into(a[:, 2 * d:], vt_a, 0)
+    ops.qkv_post_vit(b, H, hd, cos, sin, vt_b)
+    assert torch.equal(a, b) and torch.equal(vt_a, vt_b)

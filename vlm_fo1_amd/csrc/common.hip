@@ -30,6 +30,7 @@ struct ProfRec {
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
+static size_t g_prof_mark = 0;   // records [g_prof_mark, size) have no stage tag yet
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_event_pool;
 static std::mutex g_prof_mu;
 
@@ -89,8 +90,19 @@ int fo1_profile_read(fo1_profile_row_t* rows, int cap, int reset) {
     if (reset) {
         for (auto& r : g_prof) g_event_pool.emplace_back(r.e0, r.e1);
         g_prof.clear();
+        g_prof_mark = 0;
     }
     return (int)agg.size();
+}
+
+// Tags every record since the previous call (or reset) with "<tag>|"; no synchronisation.
+int fo1_profile_stage(const char* tag) {
+    using namespace fo1;
+    if (!tag || strlen(tag) > 15) return set_err(FO1_ERR_ARG, "profile: stage tag must be 1..15 characters");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (size_t i = g_prof_mark; i < g_prof.size(); ++i) g_prof[i].name = std::string(tag) + "|" + g_prof[i].name;
+    g_prof_mark = g_prof.size();
+    return FO1_OK;
 }
 
 int fo1_abi_version(void) { return FO1_ABI_VERSION; }

@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void gemm_bt_ring_kernel(const GemmParams p) {
 }
 
 static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds two-stage, 3/4/6 glds ring of that depth
-static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64
+static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x256 (8 waves)
 static int g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
 static int g_gemm_profile_shapes = 0;
 static int g_gemm_debug = 0;

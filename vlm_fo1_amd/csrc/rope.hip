@@ -26,16 +26,16 @@ __device__ __forceinline__ float rb(float v) { return bf16_to_f32(f32_to_bf16(v)
 // (n_heads counts q heads + k heads when they are adjacent).  cos/sin: bf16 [L, HD].
 // Optionally the rotated K heads are also copied to kcache[kv_head][pos0 + t][HD].
 template <int HD>
-__global__ __launch_bounds__(256) void rope_llm_kernel(uint16_t* __restrict__ x, int ld, int col0, int n_heads,
-                                                       const uint16_t* __restrict__ cosb, const uint16_t* __restrict__ sinb, int L,
-                                                       uint16_t* __restrict__ kcache, int k_first_head, long long kc_head_stride,
-                                                       int pos0, const int* __restrict__ dyn) {
+__device__ __forceinline__ void rope_llm_body(uint16_t* __restrict__ x, int ld, int col0, int n_heads,
+                                              const uint16_t* __restrict__ cosb, const uint16_t* __restrict__ sinb, int L,
+                                              uint16_t* __restrict__ kcache, int k_first_head, long long kc_head_stride,
+                                              int pos0, const int* __restrict__ dyn, int bid, int nblk) {
     constexpr int HC = HD / 16;  // chunk pairs per head (each thread does chunk c and its partner c + HD/16)
     // decode graphs: position and rope-table row come from device memory (dyn = {cache position, table row})
     int row0 = 0;
     if (dyn) { pos0 = dyn[0]; row0 = dyn[1]; }
     const long long total = (long long)L * n_heads * HC;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = bid * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)nblk * blockDim.x) {
         const int c = (int)(i % HC);
         const long long r = i / HC;
         const int hd = (int)(r % n_heads), t = (int)(r / n_heads);
@@ -64,13 +64,21 @@ __global__ __launch_bounds__(256) void rope_llm_kernel(uint16_t* __restrict__ x,
     }
 }
 
+template <int HD>
+__global__ __launch_bounds__(256) void rope_llm_kernel(uint16_t* __restrict__ x, int ld, int col0, int n_heads,
+                                                       const uint16_t* __restrict__ cosb, const uint16_t* __restrict__ sinb, int L,
+                                                       uint16_t* __restrict__ kcache, int k_first_head, long long kc_head_stride,
+                                                       int pos0, const int* __restrict__ dyn) {
+    rope_llm_body<HD>(x, ld, col0, n_heads, cosb, sinb, L, kcache, k_first_head, kc_head_stride, pos0, dyn, blockIdx.x, gridDim.x);
+}
+
 // ViT: qkv [S, ld]; q heads at col 0, k heads at col n_heads*HD; cos/sin fp32 [S, HD/2]
 template <int HD>
-__global__ __launch_bounds__(256) void rope_vit_kernel(uint16_t* __restrict__ x, int ld, int n_heads2,
-                                                       const float* __restrict__ cosf_, const float* __restrict__ sinf_, int S) {
+__device__ __forceinline__ void rope_vit_body(uint16_t* __restrict__ x, int ld, int n_heads2, const float* __restrict__ cosf_,
+                                              const float* __restrict__ sinf_, int S, int bid, int nblk) {
     constexpr int HH = HD / 2, HC = HH / 8;  // 40 -> 5 chunk pairs per head
     const long long total = (long long)S * n_heads2 * HC;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    for (long long i = bid * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)nblk * blockDim.x) {
         const int c = (int)(i % HC);
         const long long r = i / HC;
         const int hd = (int)(r % n_heads2), t = (int)(r / n_heads2);
@@ -92,12 +100,17 @@ __global__ __launch_bounds__(256) void rope_vit_kernel(uint16_t* __restrict__ x,
     }
 }
 
+template <int HD>
+__global__ __launch_bounds__(256) void rope_vit_kernel(uint16_t* __restrict__ x, int ld, int n_heads2,
+                                                       const float* __restrict__ cosf_, const float* __restrict__ sinf_, int S) {
+    rope_vit_body<HD>(x, ld, n_heads2, cosf_, sinf_, S, blockIdx.x, gridDim.x);
+}
+
 // dst[c * ldd + col0 + m] = src[m * lds + c], tile 64 rows x 64 cols through LDS
-__global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ src, int lds_, uint16_t* __restrict__ dst,
-                                                        long long ldd, int col0, int M, int C, const int* __restrict__ dyn_col) {
+__device__ __forceinline__ void transpose_body(const uint16_t* __restrict__ src, int lds_, uint16_t* __restrict__ dst,
+                                               long long ldd, int col0, int M, int C, int bx, int by) {
     __shared__ uint16_t tile[64][66];
-    if (dyn_col) col0 = *dyn_col;
-    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int m0 = bx * 64, c0 = by * 64;
     const int tid = threadIdx.x;
     // load: 64 rows x 8 chunks of 8 channels
     for (int q = tid; q < 64 * 8; q += 256) {
@@ -126,6 +139,41 @@ __global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restri
         } else {
             for (int j = 0; j < 4 && m + j < M; ++j) d[j] = e[j];
         }
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const uint16_t* __restrict__ src, int lds_, uint16_t* __restrict__ dst,
+                                                        long long ldd, int col0, int M, int C, const int* __restrict__ dyn_col) {
+    if (dyn_col) col0 = *dyn_col;
+    transpose_body(src, lds_, dst, ldd, col0, M, C, blockIdx.x, blockIdx.y);
+}
+
+// Prefill: one launch does the rotary embedding of the q/k heads AND the V -> V^T copy (independent column ranges of the
+// same fused qkv rows): workgroups [0, n_tr) take one 64x64 transpose tile each, the rest share the RoPE work grid-stride.
+template <int HD>
+__global__ __launch_bounds__(256) void qkv_post_llm_kernel(uint16_t* __restrict__ x, int ld, int n_heads, const uint16_t* __restrict__ cosb,
+                                                           const uint16_t* __restrict__ sinb, int L, uint16_t* __restrict__ kcache,
+                                                           int k_first_head, long long kc_head_stride, int pos0, int v_col, int v_ch,
+                                                           uint16_t* __restrict__ vt, long long vt_ld, int n_tr) {
+    const int b = blockIdx.x;
+    if (b < n_tr) {
+        const int tm = (L + 63) / 64;
+        transpose_body(x + v_col, ld, vt, vt_ld, pos0, L, v_ch, b % tm, b / tm);
+    } else {
+        rope_llm_body<HD>(x, ld, 0, n_heads, cosb, sinb, L, kcache, k_first_head, kc_head_stride, pos0, nullptr, b - n_tr, gridDim.x - n_tr);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void qkv_post_vit_kernel(uint16_t* __restrict__ x, int ld, int n_heads2, const float* __restrict__ cosf_,
+                                                           const float* __restrict__ sinf_, int S, int v_col, int v_ch,
+                                                           uint16_t* __restrict__ vt, long long vt_ld, int n_tr) {
+    const int b = blockIdx.x;
+    if (b < n_tr) {
+        const int tm = (S + 63) / 64;
+        transpose_body(x + v_col, ld, vt, vt_ld, 0, S, v_ch, b % tm, b / tm);
+    } else {
+        rope_vit_body<HD>(x, ld, n_heads2, cosf_, sinf_, S, b - n_tr, gridDim.x - n_tr);
     }
 }
 
@@ -207,6 +255,40 @@ int fo1_rope_vit_bf16(void* qkv, int ld, int n_heads, int head_dim, const float*
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     FO1_LAUNCH("rope_vit", (double)S * 2 * n_heads * head_dim * 4.0, rope_vit_kernel<80>, dim3(grid), dim3(256), 0,
                (hipStream_t)stream, (uint16_t*)qkv, ld, 2 * n_heads, cos_f32, sin_f32, S);
+    return FO1_OK;
+}
+
+int fo1_qkv_post_llm_bf16(void* qkv, int ld, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_bf16, const void* sin_bf16, int L,
+                          void* kcache, long long kcache_head_stride, void* vtcache, long long vt_row_stride, int pos0, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(qkv && cos_bf16 && sin_bf16 && kcache && vtcache, "qkv_post_llm: NULL operand");
+    FO1_CHECK_ARG(head_dim == 128, "qkv_post_llm: head_dim %d not built (128)", head_dim);
+    FO1_CHECK_ARG(ld % 8 == 0 && n_q_heads > 0 && n_kv_heads > 0 && ld >= (n_q_heads + 2 * n_kv_heads) * head_dim, "qkv_post_llm: bad layout");
+    FO1_CHECK_ARG(pos0 >= 0 && vt_row_stride >= pos0 + L, "qkv_post_llm: V^T cache too narrow");
+    if (L == 0) return FO1_OK;
+    const int nh = n_q_heads + n_kv_heads, v_ch = n_kv_heads * head_dim;
+    const long long total = (long long)L * nh * (head_dim / 16);
+    const int n_rope = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int n_tr = cdiv(L, 64) * (v_ch / 64);
+    FO1_LAUNCH("qkv_post_llm", (double)L * (nh + n_kv_heads) * head_dim * 4.0, qkv_post_llm_kernel<128>, dim3(n_tr + n_rope), dim3(256), 0,
+               (hipStream_t)stream, (uint16_t*)qkv, ld, nh, (const uint16_t*)cos_bf16, (const uint16_t*)sin_bf16, L, (uint16_t*)kcache,
+               n_q_heads, kcache_head_stride, pos0, nh * head_dim, v_ch, (uint16_t*)vtcache, vt_row_stride, n_tr);
+    return FO1_OK;
+}
+
+int fo1_qkv_post_vit_bf16(void* qkv, int ld, int n_heads, int head_dim, const float* cos_f32, const float* sin_f32, int S, void* vt,
+                          long long vt_ld, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(qkv && cos_f32 && sin_f32 && vt, "qkv_post_vit: NULL operand");
+    FO1_CHECK_ARG(head_dim == 80, "qkv_post_vit: head_dim %d not built (80)", head_dim);
+    const int d = n_heads * head_dim;
+    FO1_CHECK_ARG(ld % 8 == 0 && n_heads > 0 && ld >= 3 * d && d % 64 == 0 && vt_ld >= S, "qkv_post_vit: bad layout");
+    if (S == 0) return FO1_OK;
+    const long long total = (long long)S * (2 * n_heads) * (head_dim / 16);
+    const int n_rope = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    const int n_tr = cdiv(S, 64) * (d / 64);
+    FO1_LAUNCH("qkv_post_vit", (double)S * 3 * d * 4.0, qkv_post_vit_kernel<80>, dim3(n_tr + n_rope), dim3(256), 0, (hipStream_t)stream,
+               (uint16_t*)qkv, ld, 2 * n_heads, cos_f32, sin_f32, S, 2 * d, d, (uint16_t*)vt, vt_ld, n_tr);
     return FO1_OK;
 }
 

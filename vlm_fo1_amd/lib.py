@@ -38,6 +38,7 @@ SIGNATURES = {
     "fo1_last_error": (ctypes.c_char_p, []),
     "fo1_profile_enable": (c_int, [c_int]),
     "fo1_profile_read": (c_int, [ctypes.POINTER(ProfileRow), c_int, c_int]),
+    "fo1_profile_stage": (c_int, [ctypes.c_char_p]),
     "fo1_hfre_set_pixel_budget": (c_int, [c_int]),
     "fo1_hfre_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),
     "fo1_hfre_region_pool": (c_int, [ctypes.POINTER(HfreSource), c_int, c_void_p, c_int, c_void_p, c_float, c_float,
@@ -69,6 +70,9 @@ SIGNATURES = {
                               c_void_p, c_float, c_void_p]),
     "fo1_rope_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "fo1_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
+    "fo1_qkv_post_llm_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_longlong,
+                                      c_void_p, c_longlong, c_int, c_void_p]),
+    "fo1_qkv_post_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_longlong, c_void_p]),
     "fo1_attention_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,
                                    c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_float, c_int, c_void_p, ctypes.c_double, c_void_p]),
@@ -125,6 +129,11 @@ def current_stream_ptr() -> int:
 
 def profile(on: bool) -> None:
     load().fo1_profile_enable(1 if on else 0)
+
+
+def profile_stage(tag: str) -> None:
+    """Label the kernel records since the previous call '<tag>|<kernel>' (no sync)."""
+    check(load().fo1_profile_stage(tag.encode()), "fo1_profile_stage")
 
 
 def profile_rows(reset: bool = True):

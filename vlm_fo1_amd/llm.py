@@ -163,8 +163,7 @@ class QwenLLM:
         for li, w in enumerate(self.layers):
             h = ops.rmsnorm(x, w["ln1"], c.rms_norm_eps)
             qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
-            ops.rope_llm(qkv, H + KV, HD, cos, sin, kcache=self.kcache[li], k_first_head=H, pos0=pos0)
-            ops.transpose_into(qkv[:, (H + KV) * HD:], self.vtcache[li], col0=pos0)
+            ops.qkv_post_llm(qkv, H, KV, HD, cos, sin, self.kcache[li], self.vtcache[li], pos0)   # mRoPE + K append + V^T, one launch
             att = ops.attention_strided(qkv[:, :H * HD], q_row0=pos0, k=self.kcache[li], vt=self.vtcache[li], items=items,
                                         n_q_heads=H, n_kv_heads=KV, head_dim=HD, scale=scale, causal=True, flops=flops)
             x = ops.gemm(att, w["wo"], residual=x)

@@ -89,19 +89,29 @@ class FO1Engine:
         # Two-stream tower overlap (DaViT || ViT+FPN) is OFF: measured on MI355X / ROCm 7.2 a forked hipGraph replays at
         # 39.7 ms vs 21.9 ms single-stream (cross-stream joins serialise the node launches), see profiles/README.md.
         self.overlap_towers = False
+        self.stage_hook = None   # callable(stage_name) at stage boundaries; measurement only, never set while capturing a graph
         self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
 
     # ---- encoders ------------------------------------------------------------------------------
+    def _mark(self, stage: str):
+        """Stage boundary for measurement (bench.py sets `stage_hook` in its eager profiling pass only)."""
+        if self.stage_hook is not None:
+            self.stage_hook(stage)
+
     def encode_images(self, pixel_values: torch.Tensor, gh: int, gw: int):
         """-> (image tokens [S/4, d_llm], captured ViT maps (token-major raster))  (encode_images :44-72)."""
         tokens, feats = self.vit.forward(pixel_values, gh, gw, capture="last" if self.fpn is not None else "all")
-        return self.mm_projector(tokens), feats
+        self._mark("qwen_vit+merger")
+        out = self.mm_projector(tokens)
+        self._mark("mm_projector")
+        return out, feats
 
     def encode_regions(self, aux_image: torch.Tensor, boxes: Optional[torch.Tensor], vt_feats: List[torch.Tensor], gh: int, gw: int,
                        aux_out=None, fpn_out=None):
         """-> region tokens [N, d_llm]  (encode_regions :75-108).  boxes: fp32 [N,4] xyxy in aux-image pixels.
         aux_out / fpn_out: tower outputs already computed by the caller (two-stream overlap)."""
         aux_maps, aux_sizes = aux_out if aux_out is not None else self.davit.forward(aux_image)
+        self._mark("davit_large")
         if boxes is None or boxes.shape[0] == 0:
             boxes = self._dummy_box
         boxes = boxes.to(device=self.dev, dtype=torch.float32)
@@ -116,13 +126,17 @@ class FO1Engine:
         aux_views = [nchw(t, s) for t, s in zip(aux_maps, aux_sizes)]
         if self.fpn is not None:
             fpn_maps, fpn_sizes = fpn_out if fpn_out is not None else self.fpn.forward(vt_feats[-1], gh, gw)
+            self._mark("simple_fpn")
             fpn_views = [nchw(t, s) for t, s in zip(fpn_maps, fpn_sizes)]
             self.hfre.simple_fpn = lambda x: fpn_views
             vt_in = nchw(vt_feats[-1], (gh, gw))
         else:
             vt_in = [nchw(t, (gh, gw)) for t in vt_feats]
         feat = self.hfre(aux_views, [boxes], vt_in, None, vt_scale=(sw, sh)).squeeze(0)   # fp32 [N, C_region]
-        return self.mm_projector_aux(feat.to(torch.bfloat16))                              # :106-107
+        self._mark("hfre_region_pool")
+        out = self.mm_projector_aux(feat.to(torch.bfloat16))                               # :106-107
+        self._mark("mm_projector_aux")
+        return out
 
     # ---- one image: everything up to the first generated token -----------------------------------
     def _device_prefill(self, pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions: bool):
@@ -143,7 +157,9 @@ class FO1Engine:
             image_tokens, vt_feats = self.encode_images(pix, gh, gw)
             region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw) if want_regions else None
         emb = self.llm.embed_rows(plan_dev, image_tokens, region_tokens)
+        self._mark("splice")
         last, logits, tok = self.llm.prefill(emb, None, 0, tables=(cos, sin))
+        self._mark("llm_prefill+lm_head+argmax")
         return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,
                     next_token=tok)
 

@@ -196,6 +196,31 @@ def rope_vit(qkv: torch.Tensor, n_heads: int, head_dim: int, cos: torch.Tensor, 
              "fo1_rope_vit_bf16")
 
 
+def qkv_post_llm(qkv: torch.Tensor, n_q: int, n_kv: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor,
+                 kcache: torch.Tensor, vtcache: torch.Tensor, pos0: int = 0) -> None:
+    """Prefill, one launch: mRoPE on the q/k heads of qkv [L, (n_q+2 n_kv) hd] in place, K heads appended to
+    kcache [n_kv, max_seq, hd] at pos0, V heads copied transposed into vtcache [n_kv*hd, max_seq] at column pos0."""
+    _chk(qkv, "qkv"); _chk(cos, "cos"); _chk(sin, "sin"); _chk(kcache, "kcache"); _chk(vtcache, "vtcache")
+    p, ld, L, _ = _rows(qkv, "qkv")
+    assert cos.shape == (L, head_dim) and cos.is_contiguous() and sin.is_contiguous()
+    assert kcache.dim() == 3 and kcache.shape[2] == head_dim and kcache.stride(2) == 1 and kcache.stride(1) == head_dim
+    pv, ldv, Cv, _ = _rows(vtcache, "vtcache")
+    assert Cv == n_kv * head_dim
+    _L.check(_L.load().fo1_qkv_post_llm_bf16(p, ld, n_q, n_kv, head_dim, cos.data_ptr(), sin.data_ptr(), L, kcache.data_ptr(),
+                                             kcache.stride(0), pv, ldv, pos0, _stream()), "fo1_qkv_post_llm_bf16")
+
+
+def qkv_post_vit(qkv: torch.Tensor, n_heads: int, head_dim: int, cos: torch.Tensor, sin: torch.Tensor, vt: torch.Tensor) -> None:
+    """ViT block, one launch: 2-D RoPE on the q/k heads of qkv [S, 3 d] in place + V -> vt [d, >= S]."""
+    _chk(qkv, "qkv"); _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32); _chk(vt, "vt")
+    p, ld, S, _ = _rows(qkv, "qkv")
+    assert cos.shape == (S, head_dim // 2) and cos.is_contiguous() and sin.is_contiguous()
+    pv, ldv, Cv, _ = _rows(vt, "vt")
+    assert Cv == n_heads * head_dim
+    _L.check(_L.load().fo1_qkv_post_vit_bf16(p, ld, n_heads, head_dim, cos.data_ptr(), sin.data_ptr(), S, pv, ldv, _stream()),
+             "fo1_qkv_post_vit_bf16")
+
+
 def transpose_into(src: torch.Tensor, dst: torch.Tensor, col0: int = 0, dyn_col0: Optional[torch.Tensor] = None) -> None:
     """dst[c, col0 + m] = src[m, c];  src [M, C] (C % 64 == 0), dst [C, >= col0 + M]; col0 read from the device int
     `dyn_col0` when given."""

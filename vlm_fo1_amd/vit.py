@@ -163,8 +163,7 @@ class QwenViT:
             full = i in c.fullatt_block_indexes
             h = ops.rmsnorm(x, w["n1"], 1e-6)
             qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
-            ops.rope_vit(qkv, H, hd, g.cos, g.sin)
-            ops.transpose_into(qkv[:, 2 * d:], vt, 0)
+            ops.qkv_post_vit(qkv, H, hd, g.cos, g.sin, vt)   # 2-D RoPE on q/k + V -> V^T, one launch
             att = ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
                                 flops=fl_full if full else fl_win)
             x = ops.gemm(att, w["wo"], w["bo"], residual=x)
