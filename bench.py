@@ -239,24 +239,39 @@ def main():
                 "hfre_region_pool": "hfre", "mm_projector_aux": "proj_aux", "splice": "splice", "llm_prefill+lm_head+argmax": "llm"}
         L.profile(True)
         pipe.eng.stage_hook = lambda stage: L.profile_stage(TAGS[stage])   # tags records, no sync
+        per_step, per_stage = [], []
+        inv = {v: k for k, v in TAGS.items()}
         for _ in range(nprof):
             pipe.step(graph=False)   # per-kernel timestamps need individual launches, not a graph replay
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            # drain once per step (<= ~1000 event pairs outstanding); the per-kernel figure is the MEDIAN over steps of the
+            # step's total for that kernel, so a sporadic stall in one step does not leak into the average
+            ks, st = {}, {}
+            for r in L.profile_rows(reset=True):
+                tag, _, kname = r["name"].rpartition("|")
+                stage = inv.get(tag, "unattributed")
+                st[stage] = st.get(stage, 0.0) + r["total_ms"]
+                m = ks.setdefault(kname, dict(name=kname, calls=0, total_ms=0.0, total_work=0.0))
+                m["calls"] += r["calls"]
+                m["total_ms"] += r["total_ms"]
+                m["total_work"] += r["total_work"]
+            per_step.append(ks)
+            per_stage.append(st)
         pipe.eng.stage_hook = None
         L.profile(False)
-        merged, stage_ms = {}, {}
-        inv = {v: k for k, v in TAGS.items()}
-        for r in L.profile_rows(reset=True):
-            tag, _, kname = r["name"].rpartition("|")
-            stage = inv.get(tag, "unattributed")
-            stage_ms[stage] = stage_ms.get(stage, 0.0) + r["total_ms"]
-            m = merged.setdefault(kname, dict(name=kname, calls=0, total_ms=0.0, total_work=0.0))
-            m["calls"] += r["calls"]
-            m["total_ms"] += r["total_ms"]
-            m["total_work"] += r["total_work"]
-        rows = sorted(merged.values(), key=lambda r: -r["total_ms"])
+
+        def median(v):
+            v = sorted(v)
+            return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+        rows = []
+        for kname, first in per_step[0].items():   # every step launches the same kernels
+            rows.append(dict(name=kname, calls=first["calls"], total_work=first["total_work"],
+                             total_ms=median([ks[kname]["total_ms"] for ks in per_step if kname in ks])))
+        rows.sort(key=lambda r: -r["total_ms"])
         dom = rows[0]
-        stage_ms = {k: round(v / nprof, 4) for k, v in stage_ms.items() if v > 0}
+        stage_ms = {k: round(median([st.get(k, 0.0) for st in per_stage]), 4) for k in per_stage[0]}
+        nprof = 1   # rows now hold ONE step's launches / work with the median step time
         avg_ms = dom["total_ms"] / dom["calls"]
         work = dom["total_work"] / dom["calls"]
         mfma = dom["name"].startswith("gemm") or dom["name"].startswith("attn")

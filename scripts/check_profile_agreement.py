@@ -1,0 +1,31 @@
+"""Compare bench.py's in-process per-kernel averages (hipExtLaunchKernelGGL timestamps) with rocprofv3's kernel-trace averages
+of the same command.  usage: check_profile_agreement.py <bench.json> <kernel_stats.csv>"""
+import csv
+import json
+import re
+import sys
+
+b = json.load(open(sys.argv[1]))["roofline"]
+stats = {}
+for r in csv.DictReader(open(sys.argv[2])):
+    stats[r["Name"]] = (int(r["Calls"]), float(r["AverageNs"]) / 1e3)
+
+
+def rocprof_avg(bench_name):
+    pats = {"attn_fwd": r"attn_fwd_kernel<\d+, 4, false>", "rmsnorm": r"rownorm_kernel<0>", "layernorm": r"rownorm_kernel<1>"}
+    m = re.match(r"gemm_bt_glds<(\d+),(\d+)>", bench_name)
+    if m:
+        pat = rf"gemm_bt_glds_kernel<{m.group(1)}, {m.group(2)},"
+    else:
+        m = re.match(r"gemm_bt_ring<(\d+),(\d+),(\d+)>", bench_name)
+        pat = rf"gemm_bt_ring_kernel<{m.group(1)}, {m.group(2)}, {m.group(3)}>" if m else pats.get(bench_name, re.escape(bench_name) + "_kernel")
+    sel = [(c, a) for k, (c, a) in stats.items() if re.search(pat, k)]
+    n = sum(c for c, _ in sel)
+    return sum(c * a for c, a in sel) / n if n else None
+
+
+print(f"{'kernel':28s} {'bench us':>9s} {'rocprof us':>10s} {'ratio':>6s}")
+for name, ms in list(b["per_step_ms"].items())[:14]:
+    avg = ms / b["launches"][name] * 1e3
+    ra = rocprof_avg(name)
+    print(f"{name:28s} {avg:9.1f} {ra if ra is None else round(ra, 1)!s:>10s} {'' if not ra else f'{avg / ra:6.2f}'}")
