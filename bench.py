@@ -163,12 +163,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    # FO1_BENCH_ONE_DEVICE=1 (tests on a 1-GPU box only): every rank on cuda:0, rendezvous over gloo — exercises the multi-rank
+    # control flow (barriers, max-over-ranks, rank-0 line); RCCL refuses two ranks on one device.
+    one_dev = os.environ.get("FO1_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from vlm_fo1_amd import lib as L
@@ -195,7 +203,7 @@ def main():
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        t = torch.tensor([el], device="cpu" if one_dev else dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
 
@@ -302,7 +310,7 @@ def main():
                                         f"(CountBench UPN boxes), Qwen2.5-VL-3B + DaViT-L + SimpleFPN true shapes, prompt "
                                         f"{len(case['ids']) - 1 + 391} tokens after splice, prefill to the first greedy token",
                                stages=Pipeline.stages, launch="eager" if args.eager else "hipGraph replay (1 graph per shape signature)",
-                               parallelism=f"dp{world} (images sharded, no data-path collective)"),
+                               parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
                    decode=dec, roofline=roof)
         if roof is not None:
             # stage times (sum of kernel execution time per stage, eager pass) and the two region-token rates
@@ -316,6 +324,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(case, pipe)
         print(json.dumps(out))
     if world > 1:
+        torch.distributed.barrier()   # ranks leave together (rank 0 was still measuring decode / roofline)
         torch.distributed.destroy_process_group()
 
 

@@ -101,3 +101,23 @@ def test_graph_replay_is_bit_identical_to_eager():
         for k in ("image_tokens", "region_tokens", "embeds", "last_hidden", "logits", "next_token"):
             assert torch.equal(e[k], r[k]), f"trial {trial}: {k} differs between eager and graph replay"
     assert len(eng._graphs) == 1, "one signature -> one captured graph"
+
+
+def test_bench_two_ranks_control_flow(tmp_path):
+    """bench.py under torch.distributed.run with 2 ranks (both on cuda:0 over gloo — a 1-GPU box cannot host two RCCL ranks):
+    the barrier / max-over-ranks / rank-0-prints-one-line contract and hipGraph capture with a live process group."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FO1_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, f"exactly one JSON line from rank 0, got {len(lines)}"
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
+    assert "cpu_baseline" not in out and out["roofline"]["bound"] in ("mfma", "hbm")

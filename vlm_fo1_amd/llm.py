@@ -254,7 +254,7 @@ class QwenLLM:
             self.dstate.copy_(snap)
             self.dplan.copy_(plan)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL watchdog threads may touch the runtime meanwhile
                 logits = self._decode_device()
             self.dstate.copy_(snap)            # the capture itself does not execute, but keep the state exact
             self.dplan.copy_(plan)

@@ -200,7 +200,7 @@ class FO1Engine:
                 torch.cuda.current_stream().wait_stream(s)
                 torch.cuda.synchronize()
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL watchdog threads may touch the runtime meanwhile
                     res = self._device_prefill(st["pix"], gh, gw, st["aux"], st["boxes"], st["plan"], st["cos"], st["sin"], want_regions)
                 ent = (g, st, res)
                 self._graphs[key] = ent
