@@ -238,6 +238,29 @@ def main():
                    weight_stream_floor_ms=round(6.2e9 / 8e12 * 1e3, 3),
                    images_per_sec_with_64_token_answer=round(1.0 / (el / args.steps + 64 * td), 2))
 
+    # ---- host-side preprocessing of one image (SURVEY 8d "preprocess (CPU)" stage, 8f rank 2): not part of `value` ----
+    prep = None
+    if rank == 0:
+        import numpy as np
+        from PIL import Image
+        from vlm_fo1.model.image_processing import CLIPStyleAuxProcessor, Qwen2VLPatchProcessor
+        H, W = case["img_hw"]
+        pil = Image.fromarray(np.random.default_rng(1234).integers(0, 256, (H, W, 3), dtype=np.uint8), "RGB")
+        prep = {}
+        for label, on_dev in (("host_fp32_then_upload", False), ("uint8_upload_then_device_kernels", True)):
+            p1, p2 = Qwen2VLPatchProcessor(), CLIPStyleAuxProcessor(resize_mode="dynamic")
+            if on_dev:
+                p1.device = p2.device = dev
+            for it in range(12):
+                if it == 2:
+                    torch.cuda.synchronize()
+                    tp = time.perf_counter()
+                a = p1.preprocess(pil, return_tensors="pt")["pixel_values"].to(dev, dtype=torch.bfloat16)
+                b = p2.preprocess(pil, return_tensors="pt")["pixel_values"][0].to(dev, dtype=torch.bfloat16)
+            torch.cuda.synchronize()
+            prep[label + "_ms"] = round((time.perf_counter() - tp) / 10 * 1e3, 3)
+        prep["note"] = "PIL image (already decoded, no resize needed at 640x480) -> both towers' bf16 device tensors"
+
     # ---- roofline of the dominant kernel: separate profiled pass (hipEvents per launch) ----
     roof = None
     if rank == 0:
@@ -311,7 +334,7 @@ def main():
                                         f"{len(case['ids']) - 1 + 391} tokens after splice, prefill to the first greedy token",
                                stages=Pipeline.stages, launch="eager" if args.eager else "hipGraph replay (1 graph per shape signature)",
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
-                   decode=dec, roofline=roof)
+                   decode=dec, preprocess=prep, roofline=roof)
         if roof is not None:
             # stage times (sum of kernel execution time per stage, eager pass) and the two region-token rates
             out["stage_kernel_ms"] = stage_ms

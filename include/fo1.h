@@ -265,6 +265,19 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
                               int max_kv_len, int n_q_heads, int n_kv_heads, int head_dim, float scale,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Image preprocessing, device side  
+ * Replaces, after the host's PIL decode + bicubic resize, the rescale / normalise / layout work of
+ *   Qwen2VLImageProcessor (qwen2_5_vl_encoder.py:206-212 -> pixel_values [S, 1176], patches in 2x2 merge-block order,
+ *   vector (C=3, T=2, 14, 14), frame duplicated along T)   -> fo1_patchify_u8_bf16
+ *   CLIPImageProcessor.preprocess (image_processing_clip.py:222-367; davit/configs.py:139-152) -> fo1_normalize_u8_bf16
+ * image: uint8 [H, W, 3] (RGB, HWC) on the device; lut: bf16 [3][256] = bf16((v/255 - mean_c)/std_c) built by the host with
+ * the reference's arithmetic, so outputs are bit-identical to "CPU processor then .to(bfloat16)".
+ * ---------------------------------------------------------------------- */
+int fo1_patchify_u8_bf16(const void* image_hwc_u8, int H, int W, const void* lut_bf16, void* out, int ld,
+                         int patch, int merge, void* stream);
+int fo1_normalize_u8_bf16(const void* image_hwc_u8, int H, int W, const void* lut_bf16, void* out_chw, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,3 +113,26 @@ def test_unknown_checkpoint_key_and_unsupported_config_fail_loudly():
         FO1HFConfig(bad).engine_config()
     with pytest.raises(NotImplementedError):
         builder.load_pretrained_model("x/vlm-fo1_qwen2.5-vl", load_8bit=True)
+
+
+def test_device_preprocessing_is_bit_identical_to_host_path():
+    """rescale/normalise/patch layout on the GPU (fo1_patchify_u8_bf16, fo1_normalize_u8_bf16) from the resized
+    uint8 image == the host processors' fp32 output cast to bf16, bit for bit, incl. the smart-resize and squash-resize cases."""
+    import numpy as np
+    from PIL import Image
+    from vlm_fo1.model.image_processing import CLIPStyleAuxProcessor, Qwen2VLPatchProcessor
+    rng = np.random.default_rng(7)
+    for (w, h) in [(500, 399), (640, 480), (56, 56), (333, 711)]:
+        img = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8), "RGB")
+        host, dev = Qwen2VLPatchProcessor(), Qwen2VLPatchProcessor()
+        dev.device = torch.device("cuda")
+        a, b = host.preprocess(img, return_tensors="pt"), dev.preprocess(img, return_tensors="pt")
+        assert torch.equal(a["image_grid_thw"], b["image_grid_thw"])
+        assert b["pixel_values"].dtype == torch.bfloat16 and b["pixel_values"].is_cuda
+        assert torch.equal(a["pixel_values"].to(torch.bfloat16), b["pixel_values"].cpu()), f"primary {w}x{h}"
+        for mode in ("dynamic", "squash"):
+            host, dev = CLIPStyleAuxProcessor(resize_mode=mode), CLIPStyleAuxProcessor(resize_mode=mode)
+            dev.device = torch.device("cuda")
+            a = host.preprocess(img, return_tensors="pt")["pixel_values"][0]
+            b = dev.preprocess(img, return_tensors="pt")["pixel_values"][0]
+            assert tuple(a.shape) == tuple(b.shape) and torch.equal(a.to(torch.bfloat16), b.cpu()), f"aux {mode} {w}x{h}"

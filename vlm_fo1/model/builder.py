@@ -98,5 +98,9 @@ def load_pretrained_model(model_path, load_8bit=False, load_4bit=False, device="
     primary = Qwen2VLPatchProcessor(min_pixels=56 * 56, max_pixels=2048 * 2048)            # qwen2_5_vl_encoder.py:179,210
     aux = CLIPStyleAuxProcessor(size=config.get("aux_image_size", 768),                      # builder.py:65-75
                                 resize_mode=config.get("aux_image_aspect_ratio", "squash"))
+    # rescale / normalise / patch layout on the GPU from the resized uint8 image (bit-identical to the host path + bf16 cast);
+    # FO1_HOST_PREPROCESS=1 keeps the reference's host-side fp32 tensors
+    if os.environ.get("FO1_HOST_PREPROCESS") != "1":
+        primary.device = aux.device = model.device
     model.eval()
     return tokenizer, model, (primary, aux)

@@ -41,6 +41,15 @@ def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56
     return hb, wb
 
 
+def normalise_lut(mean, std) -> torch.Tensor:
+    """bf16 [3, 256]: every possible uint8 sample through `_normalise`'s arithmetic, then the tower's bf16 cast — the whole
+    per-sample computation as a table for the device path (fo1_patchify_u8_bf16 / fo1_normalize_u8_bf16)."""
+    v = np.arange(256, dtype=np.uint8)
+    a = (v.astype(np.float64) * (1 / 255)).astype(np.float32)
+    a = (a[None, :] - np.array(mean, dtype=np.float32)[:, None]) / np.array(std, dtype=np.float32)[:, None]
+    return torch.from_numpy(np.ascontiguousarray(a)).to(torch.bfloat16)
+
+
 def _normalise(img: Image.Image, mean, std) -> np.ndarray:
     """uint8 HWC -> float32 CHW, (x/255 - mean)/std with HF's rounding points (rescale in float64 -> float32,
     normalise in float32)."""
@@ -55,6 +64,11 @@ class Qwen2VLPatchProcessor:
                  temporal_patch_size: int = 2):
         self.min_pixels, self.max_pixels = min_pixels, max_pixels
         self.patch_size, self.merge_size, self.temporal_patch_size = patch_size, merge_size, temporal_patch_size
+        # device: None = the reference's behaviour (fp32 tensors on the host); a cuda device = upload the resized uint8
+        # image and do rescale / normalise / patch layout on the GPU, returning bf16 device tensors (bit-identical to the
+        # host path followed by .to(bfloat16); set by vlm_fo1.model.builder for the MI355X engine)
+        self.device = None
+        self._lut = None
 
     def preprocess(self, images, videos=None, return_tensors: Optional[str] = "pt") -> Dict[str, torch.Tensor]:
         if videos is not None:
@@ -69,16 +83,28 @@ class Qwen2VLPatchProcessor:
             rh, rw = smart_resize(h, w, p * m, self.min_pixels, self.max_pixels)
             if (rh, rw) != (h, w):
                 img = img.resize((rw, rh), Image.Resampling.BICUBIC)
-            a = _normalise(img, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD)              # [3, rh, rw]
             gh, gw = rh // p, rw // p
+            if self.device is not None:
+                if t != 2:
+                    raise NotImplementedError("device patchify is built for temporal_patch_size = 2")
+                from vlm_fo1_amd import ops
+                if self._lut is None:
+                    self._lut = normalise_lut(OPENAI_CLIP_MEAN, OPENAI_CLIP_STD).to(self.device)
+                u8 = torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device, non_blocking=True)
+                pix.append(ops.patchify_u8(u8, self._lut, p, m))
+                grids.append([1, gh, gw])
+                continue
+            a = _normalise(img, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD)              # [3, rh, rw]
             x = np.broadcast_to(a[None], (t,) + a.shape)                          # frame duplicated along T
             x = x.reshape(t, 3, gh // m, m, p, gw // m, m, p)
             # -> (by, bx, dy, dx, C, T, py, px): rows in 2x2 merge-block order, vector (C, T, 14, 14)
             x = x.transpose(2, 5, 3, 6, 1, 0, 4, 7).reshape(gh * gw, 3 * t * p * p)
             pix.append(np.ascontiguousarray(x))
             grids.append([1, gh, gw])
-        pv = np.concatenate(pix, axis=0)
         g = np.array(grids, dtype=np.int64)
+        if self.device is not None:
+            return {"pixel_values": pix[0] if len(pix) == 1 else torch.cat(pix, dim=0), "image_grid_thw": torch.from_numpy(g)}
+        pv = np.concatenate(pix, axis=0)
         if return_tensors == "pt":
             return {"pixel_values": torch.from_numpy(pv), "image_grid_thw": torch.from_numpy(g)}
         return {"pixel_values": pv, "image_grid_thw": g}
@@ -92,6 +118,8 @@ class CLIPStyleAuxProcessor:
         self.resize_mode = resize_mode
         self.do_resize = resize_mode != "dynamic"      # davit_aux_encoder.py:47-49
         self.image_mean, self.image_std = image_mean, image_std
+        self.device = None       # see Qwen2VLPatchProcessor.device
+        self._lut = None
         if resize_mode not in ("squash", "dynamic"):
             raise NotImplementedError(f"aux resize mode {resize_mode!r} is not built (squash / dynamic)")
 
@@ -103,7 +131,17 @@ class CLIPStyleAuxProcessor:
             img = img.convert("RGB")
             if self.do_resize:
                 img = img.resize((self.size, self.size), Image.Resampling.BICUBIC)
+            if self.device is not None:
+                from vlm_fo1_amd import ops
+                if self._lut is None:
+                    self._lut = normalise_lut(self.image_mean, self.image_std).to(self.device)
+                u8 = torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device, non_blocking=True)
+                out.append(ops.normalize_u8(u8, self._lut))
+                continue
             out.append(_normalise(img, self.image_mean, self.image_std))
+        if self.device is not None:
+            same = all(o.shape == out[0].shape for o in out)
+            return {"pixel_values": torch.stack(out) if same else out}
         if return_tensors == "pt":
             same = all(o.shape == out[0].shape for o in out)
             return {"pixel_values": torch.from_numpy(np.stack(out)) if same else [torch.from_numpy(o) for o in out]}

@@ -72,6 +72,8 @@ SIGNATURES = {
     "fo1_transpose_bf16": (c_int, [c_void_p, c_int, c_void_p, c_longlong, c_int, c_void_p, c_int, c_int, c_void_p]),
     "fo1_qkv_post_llm_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_longlong,
                                       c_void_p, c_longlong, c_int, c_void_p]),
+    "fo1_patchify_u8_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fo1_normalize_u8_bf16": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fo1_qkv_post_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_longlong, c_void_p]),
     "fo1_attention_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,
                                    c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int,

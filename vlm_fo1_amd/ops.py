@@ -450,3 +450,30 @@ def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.T
                                       q_row_base.data_ptr() if q_row_base is not None else None, float(flops), _stream())
     _L.check(rc, "fo1_attention_bf16")
     return out
+
+
+# ---- image preprocessing (device side) -------------------------------------------------------------------------------------
+def patchify_u8(image_hwc: torch.Tensor, lut: torch.Tensor, patch: int = 14, merge: int = 2) -> torch.Tensor:
+    """uint8 [H, W, 3] (device) -> bf16 [S, 6*patch^2] normalised patches in merge-block order (fo1_patchify_u8_bf16)."""
+    if image_hwc.dtype != torch.uint8 or not image_hwc.is_cuda or image_hwc.dim() != 3 or image_hwc.shape[2] != 3 or not image_hwc.is_contiguous():
+        raise ValueError("patchify_u8: need a contiguous device uint8 [H, W, 3] tensor")
+    _chk(lut, "lut")
+    assert lut.shape == (3, 256) and lut.is_contiguous()
+    H, W, _ = image_hwc.shape
+    out = torch.empty((H // patch) * (W // patch), 6 * patch * patch, dtype=torch.bfloat16, device=image_hwc.device)
+    _L.check(_L.load().fo1_patchify_u8_bf16(image_hwc.data_ptr(), H, W, lut.data_ptr(), out.data_ptr(), out.stride(0), patch, merge,
+                                            _stream()), "fo1_patchify_u8_bf16")
+    return out
+
+
+def normalize_u8(image_hwc: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
+    """uint8 [H, W, 3] (device) -> bf16 [3, H, W] normalised, channels first (fo1_normalize_u8_bf16)."""
+    if image_hwc.dtype != torch.uint8 or not image_hwc.is_cuda or image_hwc.dim() != 3 or image_hwc.shape[2] != 3 or not image_hwc.is_contiguous():
+        raise ValueError("normalize_u8: need a contiguous device uint8 [H, W, 3] tensor")
+    _chk(lut, "lut")
+    assert lut.shape == (3, 256) and lut.is_contiguous()
+    H, W, _ = image_hwc.shape
+    out = torch.empty(3, H, W, dtype=torch.bfloat16, device=image_hwc.device)
+    _L.check(_L.load().fo1_normalize_u8_bf16(image_hwc.data_ptr(), H, W, lut.data_ptr(), out.data_ptr(), _stream()),
+             "fo1_normalize_u8_bf16")
+    return out
