@@ -154,6 +154,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--boxes", type=int, default=32)
+    ap.add_argument("--image", default="480x640", help="HxW of the synthetic image (default = BASELINE configs[1]; 1344x1344 with "
+                    "--boxes 100 is the high-resolution configuration's geometry)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
     ap.add_argument("--profile-shapes", action="store_true", help="per-shape GEMM rows in roofline.per_step_ms")
@@ -181,7 +183,8 @@ def main():
 
     from vlm_fo1_amd import lib as L
     L.load()
-    case = build_workload(dev, n_boxes=args.boxes, seed=1234 + rank)
+    img_hw = tuple(int(v) for v in args.image.lower().split("x"))
+    case = build_workload(dev, n_boxes=args.boxes, img_hw=img_hw, seed=1234 + rank)
     pipe = Pipeline(case, dev)
 
     use_graph = not args.eager
@@ -329,9 +332,10 @@ def main():
                    warmup=args.warmup, ms_per_step=el / args.steps * 1e3, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="bf16", data="synthetic",
                    region_tokens_per_sec=n_img * args.boxes / el,
-                   config=dict(workload=f"BASELINE configs[1]: 1 image 640x480 (S=1564 patches) x {args.boxes} proposals "
+                   config=dict(workload=f"{'BASELINE configs[1]' if (img_hw == (480, 640) and args.boxes == 32) else 'non-default geometry'}: 1 image "
+                                        f"{img_hw[1]}x{img_hw[0]} (S={case['grid'][0] * case['grid'][1]} patches) x {args.boxes} proposals "
                                         f"(CountBench UPN boxes), Qwen2.5-VL-3B + DaViT-L + SimpleFPN true shapes, prompt "
-                                        f"{len(case['ids']) - 1 + 391} tokens after splice, prefill to the first greedy token",
+                                        f"{len(case['ids']) - 1 + case['grid'][0] * case['grid'][1] // 4} tokens after splice, prefill to the first greedy token",
                                stages=Pipeline.stages, launch="eager" if args.eager else "hipGraph replay (1 graph per shape signature)",
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
                    decode=dec, preprocess=prep, roofline=roof)
