@@ -48,21 +48,25 @@ def build_workload(device, n_boxes=32, img_hw=(480, 640), seed=1234):
 
 
 class Pipeline:
-    """Every stage of the hot path, back to back on one stream: one step = one image up to and
-    including its first generated token."""
+    """Every stage of the hot path, back to back on one stream: one step = one image up to and including its first generated
+    token.  `inflight` > 1: that many engine replicas (shared weights, private KV cache / graphs) on their own HIP streams, steps
+    dealt round-robin, so independent images overlap on the GPU (a batch-1 pass under-fills 256 CUs)."""
     stages = ["qwen_vit(32 blocks)+merger", "mm_projector", "davit_large", "simple_fpn", "hfre_region_pool",
               "mm_projector_aux", "splice+mrope", "llm_prefill(36 layers)", "lm_head(last row)+argmax"]
 
-    def __init__(self, case, device):
+    def __init__(self, case, device, inflight=1):
         from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights
         self.cfg = FO1Config()
         self.weights = random_weights(self.cfg, device, seed=0)
         self.eng = FO1Engine(self.cfg, self.weights, device)
+        self.engs = [self.eng] + [self.eng.replica() for _ in range(inflight - 1)]
+        self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(inflight - 1)]
         self.case = case
 
-    def step(self, graph=True):
+    def step(self, graph=True, slot=0):
         d = self.case["dev"]
-        return self.eng.prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
+        with torch.cuda.stream(self.streams[slot]):
+            return self.engs[slot].prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
 
 
 def cpu_baseline(case, pipe, budget_s=25.0):
@@ -156,6 +160,8 @@ def main():
     ap.add_argument("--boxes", type=int, default=32)
     ap.add_argument("--image", default="480x640", help="HxW of the synthetic image (default = BASELINE configs[1]; 1344x1344 with "
                     "--boxes 100 is the high-resolution configuration's geometry)")
+    ap.add_argument("--inflight", type=int, default=2, help="independent single-image passes in flight per GPU (streams); 1 = strictly "
+                    "one image at a time (latency mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
     ap.add_argument("--profile-shapes", action="store_true", help="per-shape GEMM rows in roofline.per_step_ms")
@@ -185,11 +191,13 @@ def main():
     L.load()
     img_hw = tuple(int(v) for v in args.image.lower().split("x"))
     case = build_workload(dev, n_boxes=args.boxes, img_hw=img_hw, seed=1234 + rank)
-    pipe = Pipeline(case, dev)
+    R = max(1, args.inflight)
+    pipe = Pipeline(case, dev, inflight=R)
 
     use_graph = not args.eager
-    for _ in range(args.warmup):
-        pipe.step(use_graph)
+    for slot in range(R):
+        for _ in range(args.warmup):
+            pipe.step(use_graph, slot)
 
     def barrier():
         if world > 1:
@@ -199,8 +207,8 @@ def main():
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        pipe.step(use_graph)
+    for k in range(args.steps):
+        pipe.step(use_graph, k % R)
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -209,6 +217,20 @@ def main():
         t = torch.tensor([el], device="cpu" if one_dev else dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
+
+    # ---- latency mode: strictly one image at a time on one stream (not `value` unless --inflight 1) ----
+    single = None
+    if rank == 0:
+        if R == 1:
+            single = dict(images_per_sec=args.steps / el, ms_per_image=el / args.steps * 1e3)
+        else:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe.step(use_graph, 0)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            single = dict(images_per_sec=round(args.steps / e1, 2), ms_per_image=round(e1 / args.steps * 1e3, 3))
 
     # ---- greedy decode through the KV cache (fixed K new tokens, reported separately; not part of `value`) ----
     dec = None
@@ -239,7 +261,7 @@ def main():
             td = (time.perf_counter() - td) / K
         dec = dict(ms_per_token=round(td * 1e3, 3), tokens_per_sec=round(1.0 / td, 1), new_tokens_timed=K,
                    weight_stream_floor_ms=round(6.2e9 / 8e12 * 1e3, 3),
-                   images_per_sec_with_64_token_answer=round(1.0 / (el / args.steps + 64 * td), 2))
+                   images_per_sec_with_64_token_answer=round(1.0 / (single["ms_per_image"] * 1e-3 + 64 * td), 2))
 
     # ---- host-side preprocessing of one image (SURVEY 8d "preprocess (CPU)" stage, 8f rank 2): not part of `value` ----
     prep = None
@@ -336,9 +358,12 @@ def main():
                                         f"{img_hw[1]}x{img_hw[0]} (S={case['grid'][0] * case['grid'][1]} patches) x {args.boxes} proposals "
                                         f"(CountBench UPN boxes), Qwen2.5-VL-3B + DaViT-L + SimpleFPN true shapes, prompt "
                                         f"{len(case['ids']) - 1 + case['grid'][0] * case['grid'][1] // 4} tokens after splice, prefill to the first greedy token",
-                               stages=Pipeline.stages, launch="eager" if args.eager else "hipGraph replay (1 graph per shape signature)",
+                               stages=Pipeline.stages,
+                               launch=("eager" if args.eager else "hipGraph replay (1 graph per shape signature)") +
+                                      (f"; {R} independent images in flight on {R} HIP streams (engine replicas share weights)" if R > 1 else "; one image at a time"),
+                               images_in_flight=R,
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
-                   decode=dec, preprocess=prep, roofline=roof)
+                   one_image_at_a_time=single, decode=dec, preprocess=prep, roofline=roof)
         if roof is not None:
             # stage times (sum of kernel execution time per stage, eager pass) and the two region-token rates
             out["stage_kernel_ms"] = stage_ms

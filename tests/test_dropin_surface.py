@@ -165,8 +165,9 @@ def _noise_image(w, h, seed):
     return Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8))
 
 
-@pytest.mark.parametrize("w,h", [(500, 399), (640, 480), (30, 40), (2500, 1900)])
-def test_primary_processor_matches_hf_pil_processor(w, h):
+@pytest.mark.parametrize("w,h,max_pixels", [(500, 399, 2048 * 2048), (640, 480, 2048 * 2048), (30, 40, 2048 * 2048),
+                                            (700, 530, 512 * 512)])   # last: the area > max_pixels branch, scaled down to stay fast
+def test_primary_processor_matches_hf_pil_processor(w, h, max_pixels):
     """Our smart-resize + patchify vs the installed HF `Qwen2VLImageProcessorPil`."""
     try:
         from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import Qwen2VLImageProcessorPil
@@ -174,9 +175,9 @@ def test_primary_processor_matches_hf_pil_processor(w, h):
         pytest.skip("HF PIL processor not importable")
     from vlm_fo1.model.image_processing import Qwen2VLPatchProcessor
     img = _noise_image(w, h, w + h)
-    hf = Qwen2VLImageProcessorPil(size={"shortest_edge": 56 * 56, "longest_edge": 2048 * 2048})
+    hf = Qwen2VLImageProcessorPil(size={"shortest_edge": 56 * 56, "longest_edge": max_pixels})
     ref = hf(images=img, return_tensors="pt")
-    got = Qwen2VLPatchProcessor().preprocess(img, videos=None, return_tensors="pt")
+    got = Qwen2VLPatchProcessor(max_pixels=max_pixels).preprocess(img, videos=None, return_tensors="pt")
     assert torch.equal(got["image_grid_thw"], ref["image_grid_thw"])
     torch.testing.assert_close(got["pixel_values"], ref["pixel_values"].float(), rtol=0, atol=2e-6)
 

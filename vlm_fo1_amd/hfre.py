@@ -121,8 +121,9 @@ class HFREModule:
             raise ValueError(f"feature channels {off} != region_feature_dim {self.region_feature_dim}")
         arr = (_lib.HfreSource * len(srcs))(*srcs)
         need = L.fo1_hfre_workspace_bytes(arr, len(srcs), N)
-        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-            self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+        # scratch from the owner-scoped pool (vlm_fo1_amd/ops.py): never resized in place — a captured graph may hold the pointer
+        from . import ops as _ops
+        self._ws = _ops._workspace("hfre", dev, max(int(need), 1))
         out = torch.empty(1, N, off, dtype=torch.float32, device=dev)
         # reference :446-448 — image size = vt map size / vt spatial scale (python floats)
         pos_w = gw / self.vision_tower_spatial_scale

@@ -107,6 +107,23 @@ class QwenLLM:
         self.dstate = torch.zeros(8, dtype=torch.int32, device=self.dev)       # [pos, rope_row, -, -, item(4)]
         self.dplan = torch.zeros(1, 2, dtype=torch.int32, device=self.dev)     # gather plan of the one new token: (0, token id)
         self._dgraph = None
+        self._ws_owner = object()   # scratch-buffer key (ops.workspace_scope); FO1Engine overrides it with its own token
+
+    def replica(self) -> "QwenLLM":
+        """Same weights and rope tables (shared, read-only), private per-request state: KV cache, decode state, decode graph.
+        For several requests in flight on different streams (FO1Engine.replica)."""
+        import copy
+        r = copy.copy(self)
+        c = self.cfg
+        r.kcache = torch.zeros_like(self.kcache)
+        r.vtcache = torch.zeros_like(self.vtcache)
+        r.kv_len = 0
+        r.rope_delta = 0
+        r.dstate = torch.zeros_like(self.dstate)
+        r.dplan = torch.zeros_like(self.dplan)
+        r._dgraph = None
+        r._ws_owner = object()
+        return r
 
     # ---- splice ------------------------------------------------------------------------------
     def plan_inputs(self, input_ids: Sequence[int], n_img: int, n_regions: int, grid_hw_merged: Tuple[int, int]):
@@ -196,10 +213,11 @@ class QwenLLM:
             cos, sin = cos.to(self.dev), sin.to(self.dev)
         else:
             cos, sin = tables
-        x = self._forward(embeds, cos, sin, 0, collect)
-        self.kv_len = embeds.shape[0]
-        self.rope_delta = rope_delta
-        return self._head(x)
+        with ops.workspace_scope(self._ws_owner):
+            x = self._forward(embeds, cos, sin, 0, collect)
+            self.kv_len = embeds.shape[0]
+            self.rope_delta = rope_delta
+            return self._head(x)
 
     def sync_decode_state(self):
         """Publish (kv_len, rope row, first decode work item) to the device-side decode state."""
@@ -217,6 +235,10 @@ class QwenLLM:
     def _decode_device(self):
         """One decode step whose every position-dependent quantity is read from device memory (self.dstate /
         self.dplan): capturable once, replayable for every token."""
+        with ops.workspace_scope(self._ws_owner):
+            return self._decode_device_impl()
+
+    def _decode_device_impl(self):
         c = self.cfg
         H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
         x = ops.gather_rows(self.dplan, c.hidden_size, self.embed)

@@ -6,6 +6,7 @@ PyTorch fallback; a missing library or a CPU tensor raises."""
 from __future__ import annotations
 
 import math
+import threading
 from typing import Optional, Sequence
 
 import torch
@@ -33,18 +34,44 @@ def _stream():
     return _L.current_stream_ptr()
 
 
-_gemm_ws = {}
+# ---- caller-owned scratch (the library never allocates) ----------------------------------------------------------------
+# One buffer per (kind, device, owner, size class).  `owner` is set by an engine for the duration of its device work
+# (`workspace_scope`): replicas running on different streams — and the hipGraphs they captured, which hold raw pointers —
+# must never share partial-sum scratch.  Outside any scope the key falls back to the current stream.  Buffers are never
+# freed or resized in place: a captured graph may still reference them.
+_ws_pool = {}
+_ws_tls = threading.local()
+
+
+class workspace_scope:
+    def __init__(self, owner):
+        self.owner = owner
+
+    def __enter__(self):
+        self.prev = getattr(_ws_tls, "owner", None)
+        _ws_tls.owner = self.owner
+        return self
+
+    def __exit__(self, *exc):
+        _ws_tls.owner = self.prev
+        return False
+
+
+def _workspace(kind: str, device, nbytes: int) -> torch.Tensor:
+    owner = getattr(_ws_tls, "owner", None)
+    who = ("owner", owner) if owner is not None else ("stream", torch.cuda.current_stream().cuda_stream)
+    size = 1 << max(12, int(nbytes - 1).bit_length())      # power-of-two size classes
+    key = (kind, device, who, size)
+    ws = _ws_pool.get(key)
+    if ws is None:
+        ws = torch.empty(size, dtype=torch.uint8, device=device)
+        _ws_pool[key] = ws
+    return ws
 
 
 def _gemm_workspace(device) -> torch.Tensor:
-    """fp32 scratch for split-K partials (caller-owned memory; the library never allocates): one buffer per
-    (device, stream) — ops on one stream are serialised, branches on different streams get their own."""
-    key = (device, torch.cuda.current_stream().cuda_stream)   # per stream: concurrent branches must not share partials
-    ws = _gemm_ws.get(key)
-    if ws is None:
-        ws = torch.empty(16 * 1024 * 1024, dtype=torch.float32, device=device)  # 64 MiB
-        _gemm_ws[key] = ws
-    return ws
+    """fp32 scratch for split-K partials, 64 MiB."""
+    return _workspace("gemm", device, 64 * 1024 * 1024)
 
 
 def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
@@ -70,7 +97,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         assert bias.numel() == N and bias.is_contiguous()
     ws = _gemm_workspace(a.device)
     rc = _L.load().fo1_gemm_bf16_ws(pa, lda, pw, ldw, bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc,
-                                    M, N, K, act, 1 if out_f32 else 0, ws.data_ptr(), ws.numel() * 4, _stream())
+                                    M, N, K, act, 1 if out_f32 else 0, ws.data_ptr(), ws.numel(), _stream())
     _L.check(rc, "fo1_gemm_bf16_ws")
     return out
 
@@ -144,9 +171,6 @@ def argmax(row: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tenso
     return out
 
 
-_attn_dec_ws = {}
-
-
 def attention_decode(q: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tensor, kv_len_dev: torch.Tensor, max_kv_len: int,
                      n_q_heads: int, n_kv_heads: int, head_dim: int, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One new token (q [1, n_q_heads*head_dim]) against the cache; kv_len_dev = device int32 scalar holding the
@@ -154,11 +178,7 @@ def attention_decode(q: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tenso
     _chk(q, "q"); _chk(kcache, "kcache"); _chk(vtcache, "vtcache")
     assert kv_len_dev.dtype == torch.int32 and kcache.dim() == 3 and q.shape[0] == 1
     need = _L.load().fo1_attention_decode_workspace_bytes(max_kv_len, n_kv_heads, head_dim)
-    key = (q.device, need)
-    ws = _attn_dec_ws.get(key)
-    if ws is None:
-        ws = torch.empty(need, dtype=torch.uint8, device=q.device)
-        _attn_dec_ws[key] = ws
+    ws = _workspace("attn_decode", q.device, need)
     if out is None:
         out = torch.empty(1, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
     pv, ldv, _, _ = _rows(vtcache, "vtcache")
@@ -352,18 +372,11 @@ def window_reverse_add(yw: torch.Tensor, shortcut: torch.Tensor, H: int, W: int,
     return y
 
 
-_ca_ws = {}
-
-
 def channel_attention(qkv: torch.Tensor, C: int) -> torch.Tensor:
     _chk(qkv, "qkv")
     p, ld, N, _ = _rows(qkv, "qkv")
     need = _L.load().fo1_channel_attention_workspace_bytes(N, C)
-    key = qkv.device
-    ws = _ca_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = torch.empty(need, dtype=torch.uint8, device=qkv.device)
-        _ca_ws[key] = ws
+    ws = _workspace("channel_attention", qkv.device, need)
     out = torch.empty(N, C, dtype=torch.bfloat16, device=qkv.device)
     _L.check(_L.load().fo1_channel_attention_bf16(p, ld, N, C, out.data_ptr(), C, ws.data_ptr(), ws.numel(), _stream()),
              "fo1_channel_attention_bf16")
