@@ -1,14 +1,18 @@
 #!/bin/bash
-# Round-end evidence: full GPU suite, default bench line, rocprofv3 kernel stats of the same command, PMC traffic passes.
+# Round-end evidence: full GPU suite, default bench line, rocprofv3 kernel stats of the same command (and of the one-image-at-a-time
+# variant, whose per-kernel durations are not stretched by a concurrent pass), PMC traffic passes.
 TAG=${1:-final}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 timeout 1500 python -m pytest tests -m gpu -x -q --timeout 600 > $OUT/pytest.log 2>&1; tail -3 $OUT/pytest.log
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-400 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $ROOT/bench.py --no-cpu-baseline > $OUT/rocprof.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o b -- python $ROOT/bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o b -- python $ROOT/bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof1 -o bench -- python $ROOT/bench.py --no-cpu-baseline --inflight 1 > $OUT/rocprof1.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o b -- python $ROOT/bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o b -- python $ROOT/bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
 cd $ROOT
-f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); cp $f $OUT/kernel_stats.csv
+cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+cp $(find $OUT/prof1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_inflight1.csv
 python scripts/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc_traffic.json
+python scripts/check_profile_agreement.py $OUT/bench.json $OUT/kernel_stats_inflight1.csv
 find $OUT -name "*.db" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -size +8M -delete
