@@ -66,6 +66,10 @@ def test_load_prepare_generate_roundtrip(tmp_path, monkeypatch):
             return " ".join(str(int(i)) for i in ids)
 
     monkeypatch.setattr(builder, "_load_tokenizer", lambda p: Tok())
+    # the synthetic checkpoint's embedding table has 8192 rows: move the hard-coded <|im_start|>/<|im_end|> ids
+    # (151644/151645, mm_utils.py:481-482) inside it; with the real ids the engine must refuse instead of reading out of bounds
+    monkeypatch.setattr(MU, "_IM_START_ID", 8190)
+    monkeypatch.setattr(MU, "_IM_END_ID", 8191)
     tokenizer, model, procs = builder.load_pretrained_model(str(model_dir), device="cuda")
     assert model.config.mm_use_region_index_token is True and model.get_vision_tower().is_loaded
 
@@ -98,6 +102,11 @@ def test_load_prepare_generate_roundtrip(tmp_path, monkeypatch):
     kw_bad["bbox_list"] = [kw["bbox_list"][0][:2]]
     with pytest.raises(IndexError):
         model.generate(**kw_bad)
+    kw_oob = dict(kw)
+    kw_oob["inputs"] = kw["inputs"].clone()
+    kw_oob["inputs"][0, 0] = 151644            # a token id outside the 8192-row table: IndexError, not an out-of-bounds gather
+    with pytest.raises(IndexError):
+        model.generate(**kw_oob)
 
 
 def test_unknown_checkpoint_key_and_unsupported_config_fail_loudly():

@@ -145,7 +145,10 @@ class QwenLLM:
                 plan.append((2, ri))
                 ri += 1
             else:
-                plan.append((0, int(t)))
+                t = int(t)
+                if t < 0 or t >= self.cfg.vocab_size:   # torch's embedding lookup raises the same way in the reference
+                    raise IndexError(f"token id {t} is outside the embedding table (vocab_size {self.cfg.vocab_size})")
+                plan.append((0, t))
         if n_before is None:
             raise ValueError("prompt has no <image> sentinel")
         if grid_hw_merged[0] * grid_hw_merged[1] != n_img:

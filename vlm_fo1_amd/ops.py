@@ -64,7 +64,7 @@ def _workspace(kind: str, device, nbytes: int) -> torch.Tensor:
     key = (kind, device, who, size)
     ws = _ws_pool.get(key)
     if ws is None:
-        ws = torch.empty(size, dtype=torch.uint8, device=device)
+        ws = torch.zeros(size, dtype=torch.uint8, device=device)   # zeroed once: decode attention keeps arrival counters in its tail
         _ws_pool[key] = ws
     return ws
 
