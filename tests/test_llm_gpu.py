@@ -103,6 +103,20 @@ def test_build_inputs_splice_and_errors():
         eng.build_inputs(ids + [DEFAULT_REGION_INDEX], img, reg, (2, 3))
     with pytest.raises(ValueError):
         eng.build_inputs(ids, img, reg, (3, 3))
+    with pytest.raises(IndexError):                      # token id outside the 512-row embedding table
+        eng.build_inputs([1, 2, 512, IMAGE_TOKEN_INDEX], img, None, (2, 3))
+    # KV-cache limits are enforced on the host (the device-side decode state would index past the cache)
+    emb = torch.randn(126, 256).bfloat16().cuda()
+    pos = torch.arange(126).view(1, -1).expand(3, -1)
+    _, _, tok = eng.prefill(emb, pos)
+    for _ in range(2):                                   # positions 126, 127 fit the 128-entry cache
+        _, _, tok = eng.decode_step(tok)
+    with pytest.raises(ValueError):
+        eng.decode_step(tok)
+    with pytest.raises(ValueError):
+        eng.decode_step_graph(tok)
+    with pytest.raises(ValueError):
+        eng.prefill(torch.randn(129, 256).bfloat16().cuda(), torch.arange(129).view(1, -1).expand(3, -1))
 
 
 def test_decode_graph_replay_equals_eager_steps():

@@ -222,6 +222,11 @@ class QwenLLM:
             self.rope_delta = rope_delta
             return self._head(x)
 
+    def _check_room(self):
+        """The device-side decode state indexes the caches blindly: refuse on the host before a step would run past them."""
+        if self.kv_len + 1 > self.cfg.max_seq:
+            raise ValueError(f"sequence {self.kv_len + 1} exceeds the KV cache ({self.cfg.max_seq})")
+
     def sync_decode_state(self):
         """Publish (kv_len, rope row, first decode work item) to the device-side decode state."""
         n = self.kv_len
@@ -265,6 +270,7 @@ class QwenLLM:
     def decode_step_graph(self, token_id: Optional[torch.Tensor] = None):
         """Greedy step via one replayed hipGraph.  `token_id` (device int32 [1]) seeds the plan on the first step
         after a prefill; later steps reuse the id the previous replay wrote.  Returns (logits, next id tensor)."""
+        self._check_room()
         if token_id is not None:
             self.dplan.view(-1)[1:2].copy_(token_id.to(torch.int32).view(1), non_blocking=True)
         if self._dgraph is None:
@@ -293,6 +299,7 @@ class QwenLLM:
         """One greedy step with individually launched kernels (same device code as the graph path, so the two are
         bit-identical): token_id int32 [1] on device -> (last hidden placeholder, logits [1, V], next id tensor).
         Position = cache_position + rope_delta on all three axes (reference :1848-1860)."""
+        self._check_room()
         self.dplan.view(-1)[1:2].copy_(token_id.to(torch.int32).view(1), non_blocking=True)
         self.sync_decode_state()
         logits = self._decode_device()
