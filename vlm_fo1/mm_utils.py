@@ -74,7 +74,8 @@ def tokenizer_image_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX
 def tokenizer_image_region_token(prompt, tokenizer, image_token_index=IMAGE_TOKEN_INDEX,
                                  region_token_index=DEFAULT_REGION_INDEX, return_tensors=None):
     """Tokenise around `<image>` and `<regionfeat>`: one -200 per image split, one -300 per region split
-    (reference :83-135).  Only the very first text chunk loses a leading BOS."""
+    (reference :83-135).  When the tokenizer prepends a BOS, it is kept once at the front and stripped from the first text
+    chunk of every `<image>` group (the reference's offset quirk, reproduced); chunks after a `<regionfeat>` keep theirs."""
     groups = [[tokenizer(part).input_ids for part in img_chunk.split("<regionfeat>")] for img_chunk in prompt.split("<image>")]
     ids: List[int] = []
     skip = 0

@@ -88,10 +88,8 @@ class FO1Engine:
         self._graphs = {}
         # Two-stream tower overlap (DaViT || ViT+FPN) is OFF: measured on MI355X / ROCm 7.2 a forked hipGraph replays at
         # 39.7 ms vs 21.9 ms single-stream (cross-stream joins serialise the node launches), see profiles/README.md.
-        self.overlap_towers = False
         self._ws_owner = self.llm._ws_owner = object()   # scratch buffers are keyed by this token (ops.workspace_scope)
         self.stage_hook = None   # callable(stage_name) at stage boundaries; measurement only, never set while capturing a graph
-        self._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
 
     # ---- encoders ------------------------------------------------------------------------------
     def replica(self) -> "FO1Engine":
@@ -104,7 +102,6 @@ class FO1Engine:
         r.hfre = copy.copy(self.hfre)
         r._ws_owner = r.llm._ws_owner = object()   # scratch buffers are keyed by this token (ops.workspace_scope)
         r._graphs = {}
-        r._side_stream = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         r.stage_hook = None
         return r
 
@@ -121,11 +118,9 @@ class FO1Engine:
         self._mark("mm_projector")
         return out, feats
 
-    def encode_regions(self, aux_image: torch.Tensor, boxes: Optional[torch.Tensor], vt_feats: List[torch.Tensor], gh: int, gw: int,
-                       aux_out=None, fpn_out=None):
-        """-> region tokens [N, d_llm]  (encode_regions :75-108).  boxes: fp32 [N,4] xyxy in aux-image pixels.
-        aux_out / fpn_out: tower outputs already computed by the caller (two-stream overlap)."""
-        aux_maps, aux_sizes = aux_out if aux_out is not None else self.davit.forward(aux_image)
+    def encode_regions(self, aux_image: torch.Tensor, boxes: Optional[torch.Tensor], vt_feats: List[torch.Tensor], gh: int, gw: int):
+        """-> region tokens [N, d_llm]  (encode_regions :75-108).  boxes: fp32 [N,4] xyxy in aux-image pixels."""
+        aux_maps, aux_sizes = self.davit.forward(aux_image)
         self._mark("davit_large")
         if boxes is None or boxes.shape[0] == 0:
             boxes = self._dummy_box
@@ -140,7 +135,7 @@ class FO1Engine:
 
         aux_views = [nchw(t, s) for t, s in zip(aux_maps, aux_sizes)]
         if self.fpn is not None:
-            fpn_maps, fpn_sizes = fpn_out if fpn_out is not None else self.fpn.forward(vt_feats[-1], gh, gw)
+            fpn_maps, fpn_sizes = self.fpn.forward(vt_feats[-1], gh, gw)
             self._mark("simple_fpn")
             fpn_views = [nchw(t, s) for t, s in zip(fpn_maps, fpn_sizes)]
             self.hfre.simple_fpn = lambda x: fpn_views
@@ -159,22 +154,11 @@ class FO1Engine:
             return self._device_prefill_impl(pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions)
 
     def _device_prefill_impl(self, pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions: bool):
-        if want_regions and self.overlap_towers:
-            # the two towers are independent until the HFRE: DaViT runs on a side stream while the ViT (+ SimpleFPN) runs
-            # on the main one — most of their GEMMs under-fill 256 CUs on their own.  Inside a hipGraph capture this
-            # becomes a fork/join of two branches.
-            main = torch.cuda.current_stream()
-            side = self._side_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                aux_maps, aux_sizes = self.davit.forward(aux)
-            image_tokens, vt_feats = self.encode_images(pix, gh, gw)
-            fpn_out = self.fpn.forward(vt_feats[-1], gh, gw) if self.fpn is not None else None
-            main.wait_stream(side)
-            region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw, aux_out=(aux_maps, aux_sizes), fpn_out=fpn_out)
-        else:
-            image_tokens, vt_feats = self.encode_images(pix, gh, gw)
-            region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw) if want_regions else None
+        # The two towers are independent until the HFRE, but running DaViT on a side stream INSIDE one pass was measured
+        # slower (forked hipGraph replay 39.7 ms vs 21.9 ms on ROCm 7.2); overlap comes from independent images on
+        # different streams instead (FO1Engine.replica).
+        image_tokens, vt_feats = self.encode_images(pix, gh, gw)
+        region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw) if want_regions else None
         emb = self.llm.embed_rows(plan_dev, image_tokens, region_tokens)
         self._mark("splice")
         last, logits, tok = self.llm.prefill(emb, None, 0, tables=(cos, sin))
