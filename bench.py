@@ -160,7 +160,7 @@ def main():
     ap.add_argument("--boxes", type=int, default=32)
     ap.add_argument("--image", default="480x640", help="HxW of the synthetic image (default = BASELINE configs[1]; 1344x1344 with "
                     "--boxes 100 is the high-resolution configuration's geometry)")
-    ap.add_argument("--inflight", type=int, default=2, help="independent single-image passes in flight per GPU (streams); 1 = strictly "
+    ap.add_argument("--inflight", type=int, default=3, help="independent single-image passes in flight per GPU (streams); 1 = strictly "
                     "one image at a time (latency mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")

@@ -13,6 +13,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import torch  # noqa: E402
 from vlm_fo1.mm_utils import extract_predictions_to_indexes, prepare_inputs  # noqa: E402
 from vlm_fo1.model.builder import load_pretrained_model  # noqa: E402
 from vlm_fo1_amd import sharded_eval as SE  # noqa: E402
@@ -40,17 +41,21 @@ def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=
         data_list = [json.loads(line) for line in f]
     cat_ids = {c["name"]: c["id"] for c in json.load(open(original_data_path))["categories"]}
 
-    def generate(i):
-        d = data_list[i]
-        messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(img_folder, d["image"])}},
-                                                 {"type": "text", "text": d["conversations"][0]["value"]}],
-                     "bbox_list": d["bbox_list"]}]
-        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
-                            temperature=0.0, do_sample=False)
-        kw["streamer"] = None
-        out = model.generate(**kw)
-        return out[0, kw["inputs"].shape[1]:].tolist()
+    def make_generate(m, stream):
+        def generate(i):
+            d = data_list[i]
+            messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(img_folder, d["image"])}},
+                                                     {"type": "text", "text": d["conversations"][0]["value"]}],
+                         "bbox_list": d["bbox_list"]}]
+            with torch.cuda.stream(stream):
+                kw = prepare_inputs(model_id, m, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
+                                    temperature=0.0, do_sample=False)
+                kw["streamer"] = None
+                out = m.generate(**kw)
+                return out[0, kw["inputs"].shape[1]:].tolist()
+        return generate
 
+    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT requests in flight per GPU (default 2)
     costs = [len(d["bbox_list"]) + 64 for d in data_list]     # boxes drive prompt length; image size unknown before load
     merged = SE.run_sharded(len(data_list), costs, generate, device=device if world > 1 else "cpu")
     if rank != 0:

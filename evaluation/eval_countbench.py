@@ -9,6 +9,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
+import torch  # noqa: E402
 from vlm_fo1.mm_utils import prepare_inputs  # noqa: E402
 from vlm_fo1.model.builder import load_pretrained_model  # noqa: E402
 from vlm_fo1_amd import sharded_eval as SE  # noqa: E402
@@ -29,16 +30,20 @@ def eval_countbench(data_path, image_path, model_id, device):
     with open(data_path) as f:
         data = json.load(f)
 
-    def generate(i):
-        item = data[i]
-        messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(image_path, item["image"])}},
-                                                 {"type": "text", "text": item["question"]}], "bbox_list": item["bboxes"]}]
-        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
-                            temperature=0.0, do_sample=False)
-        kw["streamer"] = None
-        out = model.generate(**kw)
-        return out[0, kw["inputs"].shape[1]:].tolist()
+    def make_generate(m, stream):
+        def generate(i):
+            item = data[i]
+            messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(image_path, item["image"])}},
+                                                     {"type": "text", "text": item["question"]}], "bbox_list": item["bboxes"]}]
+            with torch.cuda.stream(stream):
+                kw = prepare_inputs(model_id, m, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
+                                    temperature=0.0, do_sample=False)
+                kw["streamer"] = None
+                out = m.generate(**kw)
+                return out[0, kw["inputs"].shape[1]:].tolist()
+        return generate
 
+    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT requests in flight per GPU (default 2)
     costs = [len(item["bboxes"]) + 64 for item in data]
     merged = SE.run_sharded(len(data), costs, generate, device=device if world > 1 else "cpu")
     if rank != 0:

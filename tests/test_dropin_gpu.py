@@ -145,3 +145,52 @@ def test_device_preprocessing_is_bit_identical_to_host_path():
             a = host.preprocess(img, return_tensors="pt")["pixel_values"][0]
             b = dev.preprocess(img, return_tensors="pt")["pixel_values"][0]
             assert tuple(a.shape) == tuple(b.shape) and torch.equal(a.to(torch.bfloat16), b.cpu()), f"aux {mode} {w}x{h}"
+
+
+def test_two_requests_in_flight_through_the_dropin_model(tmp_path, monkeypatch):
+    """FO1ForCausalLM.replica() + sharded_eval.request_workers: three worker threads, each with its own engine replica and HIP
+    stream, generate for 6 requests; every answer equals the sequential one."""
+    from safetensors.torch import save_file
+    from test_dropin_surface import ToyTokenizer
+    from vlm_fo1 import mm_utils as MU
+    from vlm_fo1.model import builder
+    from vlm_fo1.task_templates import OD_template
+    from vlm_fo1_amd import sharded_eval as SE
+    model_dir = tmp_path / "VLM-FO1_Qwen2.5-VL-3B-v01"
+    model_dir.mkdir()
+    save_file({k: v.cpu().contiguous() for k, v in checkpoint_state().items()}, str(model_dir / "model.safetensors"))
+    json.dump(CONFIG, open(model_dir / "config.json", "w"))
+
+    class Tok(ToyTokenizer):
+        def _enc(self, text):
+            return [i % 8000 + 100 for i in super()._enc(text)]
+
+    monkeypatch.setattr(builder, "_load_tokenizer", lambda p: Tok())
+    monkeypatch.setattr(MU, "_IM_START_ID", 8190)
+    monkeypatch.setattr(MU, "_IM_END_ID", 8191)
+    tokenizer, model, procs = builder.load_pretrained_model(str(model_dir), device="cuda")
+    paths = []
+    for j, size in enumerate([(500, 399), (420, 280), (500, 399)]):
+        p = str(tmp_path / f"img{j}.jpg")
+        Image.effect_noise(size, 32 + 16 * j).convert("RGB").save(p)
+        paths.append(p)
+    boxes = [[161.0, 11.0, 292.0, 127.0], [268.0, 61.0, 428.0, 226.0], [12.0, 100.0, 140.0, 227.0], [30.0, 30.0, 90.0, 200.0]]
+    reqs = [(paths[i % 3], boxes[: 2 + i % 3], ["orange", "apple", "cat"][i % 3]) for i in range(6)]
+
+    def make_generate(m, stream):
+        def generate(i):
+            path, bl, word = reqs[i]
+            messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": path}},
+                                                     {"type": "text", "text": OD_template.format(word)}], "bbox_list": bl}]
+            with torch.cuda.stream(stream):
+                kw = MU.prepare_inputs(str(model_dir), m, procs, tokenizer, messages, max_tokens=6, top_p=0.05, temperature=0.0, do_sample=False)
+                kw["streamer"] = None
+                out = m.generate(**kw)
+                return out[0, kw["inputs"].shape[1]:].tolist()
+        return generate
+
+    sequential = SE.run_sharded(len(reqs), [1.0] * len(reqs), make_generate(model, torch.cuda.current_stream()))
+    workers = SE.request_workers(model, make_generate, n=3)
+    assert len(workers) == 3
+    overlapped = SE.run_sharded(len(reqs), [1.0] * len(reqs), workers)
+    assert overlapped == sequential and all(t is not None and len(t) == 6 for _, t in sequential)

@@ -124,20 +124,23 @@ def test_bench_two_ranks_control_flow(tmp_path):
 
 
 def test_replicas_in_flight_match_sequential():
-    """FO1Engine.replica(): shared weights, private per-request state.  Two different images submitted back to back on two
-    streams (graph replays overlapping on the GPU) must give exactly what one engine gives for each image alone, and the
-    replica's decode must continue from ITS OWN KV cache."""
+    """FO1Engine.replica(): shared weights, private per-request state.  Four engines, four different images, all submitted back
+    to back on four streams (graph replays overlapping on the GPU) for many rounds, then from four host threads with greedy
+    decoding: every result must be exactly what one engine gives for that image alone.  (Regression: a module-level argmax
+    scratch and a per-module DaViT V^T buffer used to be shared between replicas.)"""
+    import threading
     from vlm_fo1_amd.llm import LLMConfig
     from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights, synthetic_prompt
     from vlm_fo1_amd.vit import ViTConfig
     cfg = FO1Config(vit=ViTConfig(depth=2, fullatt_block_indexes=(1,)), llm=LLMConfig(num_layers=2, vocab_size=4096, max_seq=1024))
     eng = FO1Engine(cfg, random_weights(cfg, "cuda", seed=5), "cuda")
-    rep = eng.replica()
-    assert rep.llm.layers[0]["wqkv"].data_ptr() == eng.llm.layers[0]["wqkv"].data_ptr(), "weights must be shared"
-    assert rep.llm.kcache.data_ptr() != eng.llm.kcache.data_ptr(), "KV cache must be private"
+    R = 4
+    engines = [eng] + [eng.replica() for _ in range(R - 1)]
+    assert engines[1].llm.layers[0]["wqkv"].data_ptr() == eng.llm.layers[0]["wqkv"].data_ptr(), "weights must be shared"
+    assert engines[1].llm.kcache.data_ptr() != eng.llm.kcache.data_ptr(), "KV cache must be private"
     gh, gw, H, W = 10, 14, 140, 196
     reqs = []
-    for trial in range(2):
+    for trial in range(R):
         g = torch.Generator().manual_seed(300 + trial)
         reqs.append(dict(pix=torch.randn(gh * gw, 1176, generator=g).bfloat16().cuda(), aux=torch.randn(3, H, W, generator=g).bfloat16().cuda(),
                          boxes=(torch.rand(5, 4, generator=g) * 60 + torch.tensor([0., 0., 70., 70.])).cuda(),
@@ -146,12 +149,12 @@ def test_replicas_in_flight_match_sequential():
     ref = []
     for r in reqs:   # sequential, one engine
         o = eng.prefill(r["ids"], r["pix"], (gh, gw), r["aux"], r["boxes"], use_graph=True)
+        torch.cuda.synchronize()
         ref.append({k: o[k].clone() for k in keys})
-        ref[-1]["gen"] = eng.generate(r["ids"], r["pix"], (gh, gw), r["aux"], r["boxes"], max_new_tokens=5, use_graph=True)
+        ref[-1]["gen"] = eng.generate(r["ids"], r["pix"], (gh, gw), r["aux"], r["boxes"], max_new_tokens=8, use_graph=True)
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    engines = [eng, rep]
-    for rounds in range(3):   # overlapped: both in flight before either is read
+    streams = [torch.cuda.Stream() for _ in range(R)]
+    for rounds in range(12):   # overlapped: all in flight before any is read
         outs = []
         for e, s, r in zip(engines, streams, reqs):
             with torch.cuda.stream(s):
@@ -159,8 +162,18 @@ def test_replicas_in_flight_match_sequential():
         torch.cuda.synchronize()
         for i, o in enumerate(outs):
             for k in keys:
-                assert torch.equal(o[k], ref[i][k]), f"round {rounds}, request {i}: {k} differs with two images in flight"
-    # decode continues from each engine's own cache
-    for e, s, r, rf in zip(engines, streams, reqs, ref):
-        with torch.cuda.stream(s):
-            assert e.generate(r["ids"], r["pix"], (gh, gw), r["aux"], r["boxes"], max_new_tokens=5, use_graph=True) == rf["gen"]
+                assert torch.equal(o[k], ref[i][k]), f"round {rounds}, request {i}: {k} differs with {R} images in flight"
+    # host threads, prefill + decode from each engine's own cache
+    for rounds in range(3):
+        got = [None] * R
+
+        def work(i):
+            with torch.cuda.stream(streams[i]):
+                r = reqs[i]
+                got[i] = engines[i].generate(r["ids"], r["pix"], (gh, gw), r["aux"], r["boxes"], max_new_tokens=8, use_graph=True)
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(R)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+        assert got == [rf["gen"] for rf in ref], f"threaded round {rounds}: {got} vs {[rf['gen'] for rf in ref]}"

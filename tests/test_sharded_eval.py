@@ -70,3 +70,29 @@ def test_eval_parsers_known_answers():
     recs = records_from_answer("<ground>person</ground><objects><region1></objects><ground>ufo</ground><objects><region0></objects>",
                                data, {"person": 1})
     assert recs == [{"image_id": 42, "category_id": 1, "bbox": [5, 5, 10, 20], "score": 0.5}]
+
+
+def test_worker_threads_give_the_single_worker_result():
+    """Several requests in flight per rank (run_sharded with a list of callables): every item exactly once, failed items
+    recorded, output sorted by item index — identical to the one-worker run whatever the interleaving."""
+    import threading
+    import time
+    n = 37
+    costs = [1.0] * n
+    seen, lock = [], threading.Lock()
+
+    def make(tag, delay):
+        def gen(i):
+            with lock:
+                seen.append((tag, i))
+            time.sleep(delay * ((i * 7) % 3))
+            return fake_generate(i)
+        return gen
+
+    one = SE.run_sharded(n, costs, fake_generate, device="cpu")
+    many = SE.run_sharded(n, costs, [make("a", 0.001), make("b", 0.002), make("c", 0.0)], device="cpu")
+    assert many == one
+    assert sorted(i for _, i in seen) == list(range(n)) and len({t for t, _ in seen}) > 1
+    # no GPU / no replica(): request_workers degrades to one worker
+    w = SE.request_workers(object(), lambda m, s: fake_generate, n=3)
+    assert len(w) == 1

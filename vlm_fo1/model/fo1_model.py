@@ -95,6 +95,14 @@ class FO1ForCausalLM:
         self._vt_aux = _TowerHandle(types.SimpleNamespace(**DAVIT_LARGE))
         self.use_graph = True   # replay a captured hipGraph per input-shape signature
 
+    def replica(self) -> "FO1ForCausalLM":
+        """Same weights, private per-request state (KV cache, graphs, scratch): one per worker thread / HIP stream, so several
+        requests can be in flight on one GPU (vlm_fo1_amd.sharded_eval.run_sharded with a list of workers)."""
+        import copy
+        r = copy.copy(self)
+        r.engine = self.engine.replica()
+        return r
+
     # ---- nn.Module-ish surface the reference drivers call ----
     def eval(self):
         return self

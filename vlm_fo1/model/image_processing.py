@@ -90,7 +90,7 @@ class Qwen2VLPatchProcessor:
                 from vlm_fo1_amd import ops
                 if self._lut is None:
                     self._lut = normalise_lut(OPENAI_CLIP_MEAN, OPENAI_CLIP_STD).to(self.device)
-                u8 = torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device, non_blocking=True)
+                u8 = torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device)   # blocking: the host array is a temporary
                 pix.append(ops.patchify_u8(u8, self._lut, p, m))
                 grids.append([1, gh, gw])
                 continue
@@ -135,7 +135,7 @@ class CLIPStyleAuxProcessor:
                 from vlm_fo1_amd import ops
                 if self._lut is None:
                     self._lut = normalise_lut(self.image_mean, self.image_std).to(self.device)
-                u8 = torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device, non_blocking=True)
+                u8 = torch.from_numpy(np.array(img, dtype=np.uint8)).to(self.device)   # blocking: the host array is a temporary
                 out.append(ops.normalize_u8(u8, self._lut))
                 continue
             out.append(_normalise(img, self.image_mean, self.image_std))

@@ -71,7 +71,6 @@ class DaViT:
                 stage.append(blk)
             self.blocks.append(stage)
         self._items: Dict[Tuple[int, int], torch.Tensor] = {}
-        self._vt: Dict[Tuple[int, int], torch.Tensor] = {}
 
     def _window_items(self, n_windows: int, ws2: int, heads: int):
         key = (n_windows, heads)
@@ -92,10 +91,10 @@ class DaViT:
         hw = ops.window_partition(h, H, W, ws)          # zero-padded AFTER the norm, like the reference (:248-251)
         qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
         n = hw.shape[0]
-        key = (C, n)
-        if key not in self._vt:
-            self._vt[key] = torch.zeros(C, _round_up(n, 64), dtype=torch.bfloat16, device=self.dev)
-        vt = self._vt[key]
+        # V^T scratch [C, n padded to 64] from the owner-scoped pool (zero-initialised; the pad columns are never written):
+        # this module is shared by engine replicas, so the buffer must belong to the running request, not to the module
+        n_pad = _round_up(n, 64)
+        vt = ops._workspace(f"davit_vt_{C}x{n_pad}", x.device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
         ops.transpose_into(qkv[:, 2 * C:], vt, 0)
         hd = C // heads
         items = self._window_items(n // (ws * ws), ws * ws, heads)

@@ -107,6 +107,7 @@ class QwenLLM:
         self.dstate = torch.zeros(8, dtype=torch.int32, device=self.dev)       # [pos, rope_row, -, -, item(4)]
         self.dplan = torch.zeros(1, 2, dtype=torch.int32, device=self.dev)     # gather plan of the one new token: (0, token id)
         self._dgraph = None
+        self._dstate_keep = None
         self._ws_owner = object()   # scratch-buffer key (ops.workspace_scope); FO1Engine overrides it with its own token
 
     def replica(self) -> "QwenLLM":
@@ -122,6 +123,7 @@ class QwenLLM:
         r.dstate = torch.zeros_like(self.dstate)
         r.dplan = torch.zeros_like(self.dplan)
         r._dgraph = None
+        r._dstate_keep = None
         r._ws_owner = object()
         return r
 
@@ -232,6 +234,7 @@ class QwenLLM:
         n = self.kv_len
         st = torch.tensor([n, n + self.rope_delta, 0, 0, n, n + 1, 0, n + 1], dtype=torch.int32)
         self.dstate.copy_(st, non_blocking=True)
+        self._dstate_keep = st      # keep the source alive until the next upload replaces it
 
     def _head(self, x: torch.Tensor):
         c = self.cfg
@@ -274,24 +277,26 @@ class QwenLLM:
         if token_id is not None:
             self.dplan.view(-1)[1:2].copy_(token_id.to(torch.int32).view(1), non_blocking=True)
         if self._dgraph is None:
-            snap = self.dstate.clone()
-            plan = self.dplan.clone()
-            s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                self._decode_device()          # warm-up: allocates scratch (the step it computes is re-done below)
-            torch.cuda.current_stream().wait_stream(s)
-            torch.cuda.synchronize()
-            self.dstate.copy_(snap)
-            self.dplan.copy_(plan)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL watchdog threads may touch the runtime meanwhile
-                logits = self._decode_device()
-            self.dstate.copy_(snap)            # the capture itself does not execute, but keep the state exact
-            self.dplan.copy_(plan)
-            self._dgraph = (g, logits)
+            with ops.graph_lock.capture():   # exclusive (see ops._CaptureLock)
+                snap = self.dstate.clone()
+                plan = self.dplan.clone()
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._decode_device()          # warm-up: allocates scratch (the step it computes is re-done below)
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                self.dstate.copy_(snap)
+                self.dplan.copy_(plan)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL watchdog threads may touch the runtime meanwhile
+                    logits = self._decode_device()
+                self.dstate.copy_(snap)            # the capture itself does not execute, but keep the state exact
+                self.dplan.copy_(plan)
+                self._dgraph = (g, logits)
         g, logits = self._dgraph
-        g.replay()
+        with ops.graph_lock.replay():
+            g.replay()
         self.kv_len += 1
         return logits, self.dplan.view(-1)[1:2]
 

@@ -43,6 +43,60 @@ _ws_pool = {}
 _ws_tls = threading.local()
 
 
+class _CaptureLock:
+    """hipGraph capture (and the eager warm-up pass before it) is exclusive; graph replays from other request threads are
+    shared.  Concurrent stream captures from several host threads crash inside the runtime (segfault in capture_end on
+    ROCm 7.2); replays only hold the lock for the host-side launch call, so the GPU work still overlaps."""
+
+    def __init__(self):
+        self._cond = threading.Condition()
+        self._readers = 0
+        self._writer = False
+
+    class _Side:
+        def __init__(self, enter, leave):
+            self._enter, self._leave = enter, leave
+
+        def __enter__(self):
+            self._enter()
+
+        def __exit__(self, *exc):
+            self._leave()
+            return False
+
+    def _r_in(self):
+        with self._cond:
+            while self._writer:
+                self._cond.wait()
+            self._readers += 1
+
+    def _r_out(self):
+        with self._cond:
+            self._readers -= 1
+            if self._readers == 0:
+                self._cond.notify_all()
+
+    def _w_in(self):
+        with self._cond:
+            while self._writer or self._readers:
+                self._cond.wait()
+            self._writer = True
+
+    def _w_out(self):
+        with self._cond:
+            self._writer = False
+            self._cond.notify_all()
+
+    def replay(self):
+        return self._Side(self._r_in, self._r_out)
+
+    def capture(self):
+        return self._Side(self._w_in, self._w_out)
+
+
+graph_lock = _CaptureLock()
+
+
 class workspace_scope:
     def __init__(self, owner):
         self.owner = owner
@@ -155,18 +209,12 @@ def bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], act: int, out: Optio
     return out
 
 
-_argmax_scratch = {}
-
-
 def argmax(row: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _chk(row, "row")
     assert row.is_contiguous()
     if out is None:
         out = torch.empty(1, dtype=torch.int32, device=row.device)
-    sc = _argmax_scratch.get(row.device)
-    if sc is None:
-        sc = torch.empty(256, dtype=torch.int32, device=row.device)
-        _argmax_scratch[row.device] = sc
+    sc = _workspace("argmax", row.device, 4096)   # per-owner: concurrent requests must not share the two-stage partials
     _L.check(_L.load().fo1_argmax_bf16(row.data_ptr(), row.numel(), out.data_ptr(), sc.data_ptr(), _stream()), "fo1_argmax_bf16")
     return out
 

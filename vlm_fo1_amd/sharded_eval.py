@@ -86,17 +86,64 @@ def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu") -
     return merged
 
 
-def run_sharded(n_items: int, costs: Sequence[float], generate: Callable[[int], List[int]], device="cpu",
-                progress: Optional[Callable] = None):
-    """Every rank runs `generate(i)` (-> new token ids) on its shard; rank 0 gets [(i, ids|None)] for all items."""
+def request_workers(model, make_generate: Callable, n: Optional[int] = None) -> list:
+    """[make_generate(model_i, stream_i)] for `n` requests in flight on one GPU (default: $FO1_INFLIGHT or 2): worker 0 uses the
+    loaded model on the current stream, the others a `model.replica()` (shared weights, private KV cache / graphs / scratch)
+    on a fresh HIP stream.  `make_generate(model, stream)` must return `generate(i) -> token ids` that runs its device work
+    under `torch.cuda.stream(stream)`.  Falls back to one worker when the model cannot be replicated or there is no GPU."""
+    if n is None:
+        n = int(os.environ.get("FO1_INFLIGHT", "2"))
+    if n <= 1 or not torch.cuda.is_available() or not hasattr(model, "replica"):
+        return [make_generate(model, torch.cuda.current_stream() if torch.cuda.is_available() else None)]
+    workers = [make_generate(model, torch.cuda.current_stream())]
+    for _ in range(n - 1):
+        workers.append(make_generate(model.replica(), torch.cuda.Stream()))
+    return workers
+
+
+def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", progress: Optional[Callable] = None):
+    """Every rank runs `generate(i)` (-> new token ids) on its shard; rank 0 gets [(i, ids|None)] for all items.
+
+    `generate` may be a LIST of callables: one worker thread per callable, each pulling the next item of the rank's shard
+    from a shared queue.  Give every callable its own engine replica + HIP stream (FO1ForCausalLM.replica()): the requests
+    then overlap on the GPU (a batch-1 pass under-fills 256 CUs; one request's decode GEMVs run under another's prefill).
+    The records are sorted by item index afterwards, so the output does not depend on the interleaving."""
     rank, world, _ = world_info()
     mine = assign(costs, world)[rank]
     it = progress(mine) if progress else mine
-    local = []
-    for i in it:
+    workers = list(generate) if isinstance(generate, (list, tuple)) else [generate]
+
+    def run_one(fn, i):
         try:
-            local.append((i, [int(t) for t in generate(i)]))
+            return (i, [int(t) for t in fn(i)])
         except Exception as e:  # per-item error record instead of the reference's silent `continue`
             print(f"[rank {rank}] item {i} failed: {type(e).__name__}: {e}")
-            local.append((i, None))
+            return (i, None)
+
+    if len(workers) == 1:
+        local = [run_one(workers[0], i) for i in it]
+    else:
+        import queue
+        import threading
+        q: "queue.Queue[int]" = queue.Queue()
+        for i in it:
+            q.put(i)
+        local, lock = [], threading.Lock()
+
+        def loop(fn):
+            while True:
+                try:
+                    i = q.get_nowait()
+                except queue.Empty:
+                    return
+                rec = run_one(fn, i)
+                with lock:
+                    local.append(rec)
+
+        threads = [threading.Thread(target=loop, args=(fn,), daemon=True) for fn in workers]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        local.sort(key=lambda r: r[0])
     return gather_records(local, device)
