@@ -240,6 +240,11 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
  * ---------------------------------------------------------------------- */
 int fo1_dwconv3x3_bf16(const void* x, const void* weight9c, const void* bias, void* y, int H, int W, int C,
                        void* stream);
+/* fo1_dwconv3x3_bf16 followed by the LayerNorm every DaViT block applies to its result (modeling_davit.py:29-48 PreNorm after
+ * :72-99 DepthWiseConv2d), one launch: y = x + dwconv(x) (the residual stream), h = LayerNorm(y).  Bit-identical to the two
+ * separate calls.  C <= 2048. */
+int fo1_dwconv3x3_ln_bf16(const void* x, const void* weight9c, const void* bias, void* y, const void* ln_weight,
+                          const void* ln_bias, float ln_eps, void* h, int H, int W, int C, void* stream);
 int fo1_im2col_bf16(const void* x, void* col, int H, int W, int C, int KH, int KW, int stride, int pad,
                     int ld_col, void* stream);
 int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, void* stream);

@@ -115,3 +115,20 @@ def test_pixel_shuffle_maxpool_nchw_gather():
     gotg = ops.gather_rows(plan.cuda(), 64, t0.cuda(), t1.cuda(), t2.cuda())
     refg = torch.stack([t0[49], t1[0], t1[6], t2[2], t0[0], t2[0]])
     assert torch.equal(gotg.cpu(), refg)
+
+
+def test_dwconv_layernorm_fused_equals_separate_kernels():
+    """fo1_dwconv3x3_ln_bf16 == fo1_dwconv3x3_bf16 then fo1_layernorm_bf16, bit for bit (DaViT stage widths, ragged sizes)."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(31)
+    for (H, W, C) in [(13, 17, 256), (9, 11, 512), (7, 5, 1024), (4, 5, 2048), (1, 1, 256), (3, 130, 512)]:
+        x = torch.randn(H * W, C).to(torch.bfloat16).cuda()
+        w9 = (torch.randn(9, C) * 0.2).to(torch.bfloat16).cuda()
+        b = (torch.randn(C) * 0.1).to(torch.bfloat16).cuda()
+        lw = (1 + 0.1 * torch.randn(C)).to(torch.bfloat16).cuda()
+        lb = (0.1 * torch.randn(C)).to(torch.bfloat16).cuda()
+        y_ref = ops.dwconv3x3_res(x, w9, b, H, W)
+        h_ref = ops.layernorm(y_ref, lw, lb, 1e-5)
+        y, h = ops.dwconv3x3_res_ln(x, w9, b, H, W, lw, lb, 1e-5)
+        assert torch.equal(y, y_ref), f"{H}x{W}x{C}: conv output differs"
+        assert torch.equal(h, h_ref), f"{H}x{W}x{C}: LayerNorm output differs ({int((h != h_ref).sum())} elements)"

@@ -60,6 +60,89 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restri
     }
 }
 
+// Depthwise 3x3 + residual AND the LayerNorm every DaViT block applies right after it, one launch:
+//   y = x + bf16(dwconv(x) + bias)            (the residual stream, as dwconv3x3_kernel)
+//   h = LayerNorm(y) * ln_w + ln_b            (as rownorm_kernel<1>: two-pass variance from registers)
+// One wave per pixel: lane l owns channel chunks l, l+64, ... (8 channels each), so the taps are 1 KB-contiguous reads and the
+// row statistics are one wave reduction.  Arithmetic order matches the two separate kernels bit for bit.
+constexpr int kDwLnChunks = 4;   // C <= 64 * 4 * 8 = 2048
+__device__ __forceinline__ float dw_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                           const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
+                                                           const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b,
+                                                           uint16_t* __restrict__ hout, int H, int W, int C, float eps) {
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= H * W) return;
+    const int lane = threadIdx.x & 63;
+    const int chunks = C >> 3;
+    const int h = pix / W, w = pix - h * W;
+    float val[kDwLnChunks][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < kDwLnChunks; ++i) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+            float acc[8], ctr[8];
+            un8(*reinterpret_cast<const uint4*>(bias + c * 8), acc);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int hh = h + ky - 1;
+                if (hh < 0 || hh >= H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ww = w + kx - 1;
+                    if (ww < 0 || ww >= W) continue;
+                    float xv[8], wv[8];
+                    un8(*reinterpret_cast<const uint4*>(x + ((long long)hh * W + ww) * C + c * 8), xv);
+                    un8(*reinterpret_cast<const uint4*>(wt + (ky * 3 + kx) * C + c * 8), wv);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
+                    if (ky == 1 && kx == 1) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) ctr[j] = xv[j];
+                    }
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = ctr[j] + rbf(acc[j]);
+            const uint4 packed = pk8(acc);
+            *reinterpret_cast<uint4*>(y + (long long)pix * C + c * 8) = packed;
+            un8(packed, val[i]);              // LayerNorm sees the bf16 values that were stored
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += val[i][j];
+        }
+    }
+    s = dw_wave_sum(s);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < kDwLnChunks; ++i) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = val[i][j] - mean; q += d * d; }
+        }
+    }
+    q = dw_wave_sum(q);
+    const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < kDwLnChunks; ++i) {
+        const int c = lane + i * 64;
+        if (c < chunks) {
+            float wf[8], bf[8], o[8];
+            un8(*reinterpret_cast<const uint4*>(ln_w + c * 8), wf);
+            un8(*reinterpret_cast<const uint4*>(ln_b + c * 8), bf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (val[i][j] - mean) * rstd * wf[j] + bf[j];
+            *reinterpret_cast<uint4*>(hout + (long long)pix * C + c * 8) = pk8(o);
+        }
+    }
+}
+
 // col[(oy*Wo+ox), (ky*KW+kx)*C + c] = x[oy*s-p+ky, ox*s-p+kx, c]  (0 outside); row stride ldc >= KH*KW*C
 __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ col, int H, int W, int C,
                                                      int KH, int KW, int stride, int pad, int Ho, int Wo, int ldc) {
@@ -289,6 +372,18 @@ int fo1_dwconv3x3_bf16(const void* x, const void* weight9c, const void* bias, vo
     FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0, "dwconv: bad shape %dx%dx%d", H, W, C);
     FO1_LAUNCH("dwconv3x3", (double)H * W * C * 4.0, dwconv3x3_kernel, dim3(grid_for((long long)H * W * (C / 8))), dim3(256), 0,
                (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, H, W, C);
+    return FO1_OK;
+}
+
+int fo1_dwconv3x3_ln_bf16(const void* x, const void* weight9c, const void* bias, void* y, const void* ln_weight, const void* ln_bias,
+                          float ln_eps, void* h, int H, int W, int C, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && weight9c && bias && y && ln_weight && ln_bias && h && x != y && x != h && y != h,
+                  "dwconv_ln: NULL operand or aliased buffers");
+    FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 64 * kDwLnChunks * 8, "dwconv_ln: bad shape %dx%dx%d (C <= 2048)", H, W, C);
+    FO1_LAUNCH("dwconv3x3_ln", (double)H * W * C * 6.0, dwconv3x3_ln_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
+               (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps);
     return FO1_OK;
 }
 

@@ -79,15 +79,15 @@ class DaViT:
             self._items[key] = ops.make_items(segs, self.dev, block=ops.pick_q_block(segs, heads))
         return self._items[key]
 
-    def _ffn(self, x, d):
-        h = ops.layernorm(x, d["fn_w"], d["fn_b"], 1e-5)
+    def _conv_ffn(self, x, H, W, d):
+        """conv2 (depthwise 3x3 + residual) -> LayerNorm -> MLP(+residual); the conv and the norm are one launch."""
+        x, h = ops.dwconv3x3_res_ln(x, d["conv2_w"], d["conv2_b"], H, W, d["fn_w"], d["fn_b"], 1e-5)
         h = ops.gemm(h, d["fc1_w"], d["fc1_b"], act=ops.ACT_GELU)
         return ops.gemm(h, d["fc2_w"], d["fc2_b"], residual=x)
 
     def _spatial(self, x, H, W, C, heads, d):
         ws = self.cfg["window"]
-        x = ops.dwconv3x3_res(x, d["conv1_w"], d["conv1_b"], H, W)
-        h = ops.layernorm(x, d["an_w"], d["an_b"], 1e-5)
+        x, h = ops.dwconv3x3_res_ln(x, d["conv1_w"], d["conv1_b"], H, W, d["an_w"], d["an_b"], 1e-5)
         hw = ops.window_partition(h, H, W, ws)          # zero-padded AFTER the norm, like the reference (:248-251)
         qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
         n = hw.shape[0]
@@ -102,17 +102,14 @@ class DaViT:
                             flops=4.0 * C * n * ws * ws)
         y = ops.gemm(att, d["proj_w"], d["proj_b"])
         x = ops.window_reverse_add(y, x, H, W, ws)
-        x = ops.dwconv3x3_res(x, d["conv2_w"], d["conv2_b"], H, W)
-        return self._ffn(x, d)
+        return self._conv_ffn(x, H, W, d)
 
     def _channel(self, x, H, W, C, d):
-        x = ops.dwconv3x3_res(x, d["conv1_w"], d["conv1_b"], H, W)
-        h = ops.layernorm(x, d["an_w"], d["an_b"], 1e-5)
+        x, h = ops.dwconv3x3_res_ln(x, d["conv1_w"], d["conv1_b"], H, W, d["an_w"], d["an_b"], 1e-5)
         qkv = ops.gemm(h, d["qkv_w"], d["qkv_b"])
         a = ops.channel_attention(qkv, C)
         x = ops.gemm(a, d["proj_w"], d["proj_b"], residual=x)
-        x = ops.dwconv3x3_res(x, d["conv2_w"], d["conv2_b"], H, W)
-        return self._ffn(x, d)
+        return self._conv_ffn(x, H, W, d)
 
     def forward(self, img: torch.Tensor):
         """img [3,H,W] or [1,3,H,W] (device, bf16/fp32, CLIP-normalised).  Returns

@@ -387,6 +387,18 @@ def dwconv3x3_res(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int
     return y
 
 
+def dwconv3x3_res_ln(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int, W: int, ln_w: torch.Tensor, ln_b: torch.Tensor,
+                     eps: float):
+    """-> (y = x + dwconv3x3(x) + bias, LayerNorm(y)) in one launch (fo1_dwconv3x3_ln_bf16), bit-identical to
+    dwconv3x3_res followed by layernorm."""
+    _chk(x, "x"); _chk(w9c, "w9c"); _chk(bias, "bias"); _chk(ln_w, "ln_w"); _chk(ln_b, "ln_b")
+    assert x.is_contiguous() and x.shape[0] == H * W and w9c.shape == (9, x.shape[1]) and w9c.is_contiguous()
+    y, h = torch.empty_like(x), torch.empty_like(x)
+    _L.check(_L.load().fo1_dwconv3x3_ln_bf16(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), y.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+                                             float(eps), h.data_ptr(), H, W, x.shape[1], _stream()), "fo1_dwconv3x3_ln_bf16")
+    return y, h
+
+
 def im2col(x: torch.Tensor, H: int, W: int, KH: int, KW: int, stride: int, pad: int, ld: Optional[int] = None):
     """x [H*W, C] -> (col [Ho*Wo, ld>=KH*KW*C] (pad columns zero), Ho, Wo)."""
     _chk(x, "x")
