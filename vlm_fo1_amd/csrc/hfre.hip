@@ -23,7 +23,7 @@ namespace fo1 {
 constexpr int kHfreThreads = 256;
 constexpr int kHfreWaves = kHfreThreads / 64;
 constexpr int kHfreMaxChunk = 512;   // channels per workgroup (64 lanes x 8 bf16)
-constexpr int kHfreUnroll = 4;
+constexpr int kHfreUnroll = 8;
 
 struct HfreSrcDev {
     const uint16_t* data;
