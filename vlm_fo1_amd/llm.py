@@ -52,9 +52,26 @@ def rope_index_host(n_before: int, grid_hw_merged: Tuple[int, int], n_after: int
     return pos, int(pos.max()) + 1 - pos.shape[1]
 
 
+_MROPE_CACHE: Dict[tuple, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
 def mrope_tables(pos: torch.Tensor, head_dim: int, theta: float, sections: Sequence[int]):
     """pos [3, L] (host) -> cos, sin [L, head_dim] bf16 (host): fp32 tables, section select, cast
-    (reference :609-624, :675-681)."""
+    (reference :609-624, :675-681).  Memoised on the position ids: they depend only on the prompt structure (tokens before the
+    image, merged grid, tokens after), which repeats from request to request, and the dozen small torch CPU ops below cost
+    ~10 ms per call on a many-core host (intra-op thread-pool wake-ups) — more than half a GPU pass."""
+    key = (pos.shape[1], head_dim, float(theta), tuple(sections), pos.numpy().tobytes())
+    hit = _MROPE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    out = _mrope_tables(pos, head_dim, theta, sections)
+    if len(_MROPE_CACHE) >= 256:
+        _MROPE_CACHE.pop(next(iter(_MROPE_CACHE)))
+    _MROPE_CACHE[key] = out
+    return out
+
+
+def _mrope_tables(pos: torch.Tensor, head_dim: int, theta: float, sections: Sequence[int]):
     inv = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.float32) / head_dim))
     fr = pos.float()[:, :, None] * inv[None, None, :]
     emb = torch.cat([fr, fr], dim=-1)
