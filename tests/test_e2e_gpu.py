@@ -177,3 +177,44 @@ def test_replicas_in_flight_match_sequential():
         [t.join() for t in th]
         torch.cuda.synchronize()
         assert got == [rf["gen"] for rf in ref], f"threaded round {rounds}: {got} vs {[rf['gen'] for rf in ref]}"
+
+
+def test_random_geometries_graph_equals_eager_and_finite():
+    """Ragged everything: random image sizes (smart-resized to multiples of 28 for the primary tower, raw 'dynamic' size for the aux
+    tower), random box counts / boxes incl. degenerate and out-of-image ones.  For every geometry the graph replay must equal the eager
+    launches bit for bit, outputs must be finite, and a second request of another geometry must not disturb the first graph."""
+    import random
+    from vlm_fo1.model.image_processing import smart_resize
+    from vlm_fo1_amd.llm import LLMConfig
+    from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights, synthetic_prompt
+    from vlm_fo1_amd.vit import ViTConfig
+    cfg = FO1Config(vit=ViTConfig(depth=2, fullatt_block_indexes=(1,)), llm=LLMConfig(num_layers=2, vocab_size=4096, max_seq=2048))
+    eng = FO1Engine(cfg, random_weights(cfg, "cuda", seed=11), "cuda")
+    rnd = random.Random(2024)
+    first = None
+    for trial in range(7):
+        W, H = rnd.choice([(500, 399), (333, 711), (64, 60), (640, 480), (97, 301), (420, 420), (801, 127)]) if trial < 7 else (0, 0)
+        rh, rw = smart_resize(H, W, 28, 56 * 56, 2048 * 2048)
+        gh, gw = rh // 14, rw // 14
+        n = rnd.choice([1, 2, 7, 33, 100])
+        g = torch.Generator().manual_seed(500 + trial)
+        pix = torch.randn(gh * gw, 1176, generator=g).bfloat16().cuda()
+        aux = torch.randn(3, H, W, generator=g).bfloat16().cuda()
+        b = torch.rand(n, 4, generator=g)
+        x1, y1 = b[:, 0] * W * 1.1 - 0.05 * W, b[:, 1] * H * 1.1 - 0.05 * H          # some boxes start outside the image
+        boxes = torch.stack([x1, y1, x1 + b[:, 2] * W * 0.6, y1 + b[:, 3] * H * 0.6], 1)
+        boxes[0, 2:] = boxes[0, :2]                                                    # a zero-area box
+        boxes = boxes.cuda()
+        ids = synthetic_prompt(n, vocab=4096, seed=trial)
+        e = eng.prefill(ids, pix, (gh, gw), aux, boxes, use_graph=False)
+        e = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in e.items()}
+        r = eng.prefill(ids, pix, (gh, gw), aux, boxes, use_graph=True)
+        for k in ("image_tokens", "region_tokens", "last_hidden", "logits", "next_token"):
+            assert torch.isfinite(r[k].float()).all(), f"{W}x{H} n={n}: {k} not finite"
+            assert torch.equal(e[k], r[k]), f"{W}x{H} n={n}: {k} differs between eager and graph replay"
+        assert r["region_tokens"].shape == (n, 2048) and r["image_tokens"].shape == (gh * gw // 4, 2048)
+        if first is None:
+            first = (ids, pix, (gh, gw), aux, boxes, {k: r[k].clone() for k in ("region_tokens", "logits")})
+    ids, pix, grid, aux, boxes, ref = first
+    again = eng.prefill(ids, pix, grid, aux, boxes, use_graph=True)
+    assert torch.equal(again["region_tokens"], ref["region_tokens"]) and torch.equal(again["logits"], ref["logits"])
