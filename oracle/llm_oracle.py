@@ -151,3 +151,69 @@ def random_llm_state(n_layers, d, n_heads, n_kv, head_dim, d_ff, vocab, seed=0, 
         sd[p + "mlp.up_proj.weight"] = w(d_ff, d)
         sd[p + "mlp.down_proj.weight"] = w(d, d_ff)
     return sd
+
+
+def llm_forward_cached(sd: Dict[str, torch.Tensor], x: torch.Tensor, pos: torch.Tensor, cache: Optional[list] = None, *,
+                       n_layers: int, n_heads: int, n_kv: int, head_dim: int, eps: float, theta: float, sections: Sequence[int],
+                       bf16_rope_tables: bool = True):
+    """Same arithmetic as llm_forward, but through a KV cache: x [Ln, d] are the NEW rows (a prompt on the first call, one
+    token per greedy step afterwards), pos [3, Ln] their position ids.  `cache` is a list of per-layer (k, v) with RoPE
+    already applied to k (what the reference's DynamicCache holds, modeling_qwen2_5_vl.py:770-776); pass the returned list
+    back in.  Returns (final-norm hidden states of the new rows [Ln, d], cache).  Decode position = cache length + rope
+    delta on all three axes (:1848-1860) is the caller's job (it builds `pos`)."""
+    Ln = x.shape[0]
+    cos, sin = mrope_cos_sin(pos, head_dim, theta, sections)
+    if bf16_rope_tables:
+        cos, sin = cos.bfloat16().float(), sin.bfloat16().float()
+    h = x.float()
+    past = 0 if cache is None else cache[0][0].shape[0]
+    new_cache = []
+    qi = torch.arange(past, past + Ln)[:, None]
+    ki = torch.arange(past + Ln)[None, :]
+    mask = ki <= qi
+    rep = n_heads // n_kv
+    for i in range(n_layers):
+        p = f"layers.{i}."
+        r = rmsnorm(h, sd[p + "input_layernorm.weight"], eps)
+        q = F.linear(r, sd[p + "self_attn.q_proj.weight"].float(), sd[p + "self_attn.q_proj.bias"].float()).view(Ln, n_heads, head_dim)
+        k = F.linear(r, sd[p + "self_attn.k_proj.weight"].float(), sd[p + "self_attn.k_proj.bias"].float()).view(Ln, n_kv, head_dim)
+        v = F.linear(r, sd[p + "self_attn.v_proj.weight"].float(), sd[p + "self_attn.v_proj.bias"].float()).view(Ln, n_kv, head_dim)
+        q = q * cos[:, None] + rotate_half(q) * sin[:, None]
+        k = k * cos[:, None] + rotate_half(k) * sin[:, None]
+        if cache is not None:
+            k = torch.cat([cache[i][0], k], 0)
+            v = torch.cat([cache[i][1], v], 0)
+        new_cache.append((k, v))
+        # GQA without materialising repeat_kv: group the query heads of one kv head
+        qg = q.view(Ln, n_kv, rep, head_dim)
+        att = torch.einsum("qgrd,kgd->grqk", qg, k) / math.sqrt(head_dim)
+        att = att.masked_fill(~mask, float("-inf")).softmax(-1)
+        o = torch.einsum("grqk,kgd->qgrd", att, v).reshape(Ln, n_heads * head_dim)
+        h = h + F.linear(o, sd[p + "self_attn.o_proj.weight"].float())
+        r = rmsnorm(h, sd[p + "post_attention_layernorm.weight"], eps)
+        g = F.linear(r, sd[p + "mlp.gate_proj.weight"].float())
+        u = F.linear(r, sd[p + "mlp.up_proj.weight"].float())
+        h = h + F.linear(F.silu(g) * u, sd[p + "mlp.down_proj.weight"].float())
+    return rmsnorm(h, sd["norm.weight"], eps), new_cache
+
+
+def greedy_decode(sd: Dict[str, torch.Tensor], embeds: torch.Tensor, pos: torch.Tensor, rope_delta: int, n_new: int,
+                  lm_head: Optional[torch.Tensor] = None, forced: Optional[Sequence[int]] = None, **kw):
+    """Greedy generation through the cache (HF GenerationMixin greedy search + the reference's decode fast path,
+    omchat_qwen2_5_vl.py:143-155).  Returns (ids [n_new], logits [n_new, V]).  With `forced` the i-th fed-back token is
+    forced[i] instead of the argmax (teacher forcing on somebody else's choices); logits[i] are still the oracle's."""
+    head = (lm_head if lm_head is not None else sd["embed_tokens.weight"]).float()
+    hid, cache = llm_forward_cached(sd, embeds, pos, None, **kw)
+    ids, logits = [], []
+    last = hid[-1:]
+    for i in range(n_new):
+        lg = (last @ head.t())[0]
+        logits.append(lg)
+        t = int(lg.argmax())
+        ids.append(t)
+        if i + 1 == n_new:
+            break
+        fed = t if forced is None else int(forced[i])
+        p = cache[0][0].shape[0] + rope_delta
+        last, cache = llm_forward_cached(sd, sd["embed_tokens.weight"][fed:fed + 1].float(), torch.full((3, 1), p, dtype=torch.long), cache, **kw)
+    return ids, torch.stack(logits)

@@ -218,3 +218,62 @@ def test_random_geometries_graph_equals_eager_and_finite():
     ids, pix, grid, aux, boxes, ref = first
     again = eng.prefill(ids, pix, grid, aux, boxes, use_graph=True)
     assert torch.equal(again["region_tokens"], ref["region_tokens"]) and torch.equal(again["logits"], ref["logits"])
+
+
+def test_free_running_greedy_ids_vs_oracle():
+    """north_star: "decoded text/box-index outputs are bit-identical".  K = 16 free-running greedy tokens from the engine
+    (prefill + KV-cache decode, graph path) against the oracle's greedy decode (oracle/llm_oracle.greedy_decode: HF greedy
+    search + the reference's decode fast path, omchat_qwen2_5_vl.py:143-155) on the reduced model (true widths, ViT 4 blocks,
+    LLM 2 layers, 4k vocab).  The oracle is teacher-forced on the ENGINE's ids, so every one of the 16 steps is compared even
+    after a near-tie: at step i the engine's token must BE the oracle's argmax whenever the oracle's top-1 margin exceeds
+    2 x the logit tolerance (0.05), and must in any case score within that tolerance of the oracle's maximum.  The ids are
+    compared exactly (integers); the number of margin-qualified steps is asserted to be most of them."""
+    from hfre_cases import box_fixtures
+    from oracle import davit_oracle as DO, fpn_oracle as FO, hfre_oracle as HO, llm_oracle as LO, vit_oracle as VO
+    from vlm_fo1_amd.llm import LLMConfig
+    from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights, synthetic_prompt
+    from vlm_fo1_amd.vit import ViTConfig
+    K = 16
+    cfg = FO1Config(vit=ViTConfig(depth=4, fullatt_block_indexes=(1, 3)), llm=LLMConfig(num_layers=2, vocab_size=4096, max_seq=1024))
+    weights = random_weights(cfg, "cuda", seed=21)
+    # random N(0, 0.02) embeddings give a 4096-way near-uniform softmax: scale the tied head so top-1 margins are not all ties
+    weights["llm"]["embed_tokens.weight"] = (weights["llm"]["embed_tokens.weight"].float() * 4).bfloat16()
+    eng = FO1Engine(cfg, weights, "cuda")
+    H, W, gh, gw = 399, 500, 28, 36
+    g = torch.Generator().manual_seed(10)
+    pix = torch.randn(gh * gw, 1176, generator=g).bfloat16()
+    aux = torch.randn(3, H, W, generator=g).bfloat16()
+    it = [x for x in box_fixtures()["countbench"] if len(x["bboxes"]) == 7][0]
+    boxes = torch.tensor(it["bboxes"], dtype=torch.float32) * torch.tensor([W / it["extent"][0], H / it["extent"][1]] * 2)
+    ids = synthetic_prompt(boxes.shape[0], vocab=4096, seed=2)
+    got = {}
+    for graph in (False, True):
+        got[graph] = eng.generate(ids, pix.cuda(), (gh, gw), aux.cuda(), boxes.cuda(), max_new_tokens=K, use_graph=graph)
+        assert len(got[graph]) == K
+    assert got[False] == got[True], "eager and graph-replayed greedy decodes differ"
+    sd = cpu_state(weights)
+    tokens, maps = VO.vit_forward(sd["vit"], pix.float(), gh, gw, depth=4, n_heads=16, fullatt=(1, 3))
+    img_tok = mlp2(tokens, sd["proj"], "mm_projector.")
+    fpn = [m.bfloat16() for m in FO.fpn_forward(sd["fpn"], maps[-1].bfloat16().float().reshape(gh, gw, 1280).permute(2, 0, 1).unsqueeze(0))]
+    aux_maps, aux_sizes = DO.davit_forward(sd["davit"], aux.float().unsqueeze(0))
+    aux_nchw = [m.bfloat16().reshape(h, w, -1).permute(2, 0, 1).unsqueeze(0) for m, (h, w) in zip(aux_maps, aux_sizes)]
+    sw, sh = gw * 14 / W, gh * 14 / H
+    feat = HO.hfre_oracle(aux_nchw, boxes, fpn, boxes * torch.tensor([sw, sh, sw, sh]), region_dim=5888, grid_hw=(gh, gw),
+                          vt_strides=[3.5, 7, 14, 28])[0]
+    reg_tok = mlp2(feat.bfloat16().float(), sd["proj"], "mm_projector_aux.")
+    emb, nb, na = LO.splice(torch.tensor(ids), sd["llm"]["embed_tokens.weight"], img_tok, reg_tok)
+    pos, delta = LO.rope_index(nb, (gh // 2, gw // 2), na)
+    kw = dict(n_layers=2, n_heads=16, n_kv=2, head_dim=128, eps=1e-6, theta=1e6, sections=(16, 24, 24))
+    ref_ids, ref_logits = LO.greedy_decode(sd["llm"], emb, pos, delta, K, forced=got[True], **kw)
+    tol = 0.05
+    qualified = 0
+    for i in range(K):
+        top2 = ref_logits[i].topk(2).values
+        margin = float(top2[0] - top2[1])
+        t = got[True][i]
+        assert float(ref_logits[i].max() - ref_logits[i][t]) <= 2 * tol, \
+            f"step {i}: engine token {t} scores {float(ref_logits[i].max() - ref_logits[i][t]):.3g} below the oracle's maximum"
+        if margin > 2 * tol:
+            qualified += 1
+            assert t == ref_ids[i], f"step {i}: engine id {t} != oracle greedy id {ref_ids[i]} (oracle margin {margin:.3g})"
+    assert qualified >= K // 2, f"only {qualified} of {K} steps had an oracle margin > {2 * tol}: the test is not discriminating"
