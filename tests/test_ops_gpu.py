@@ -441,3 +441,77 @@ def test_qkv_post_fused_equals_separate_kernels():
     ops.transpose_into(a[:, 2 * d:], vt_a, 0)
     ops.qkv_post_vit(b, H, hd, cos, sin, vt_b)
     assert torch.equal(a, b) and torch.equal(vt_a, vt_b)
+
+
+P8_SHAPES = [
+    # (M, N, K, bias, res, act, splits)   — fo1 tile code 5: 256x256 ping-pong kernel (32x32x16 MFMA, counted-vmcnt LDS-DMA ring)
+    (700, 520, 64, True, False, 0, 1),         # one k tile (prologue-only pipeline), ragged M and N
+    (300, 256, 128, False, True, 0, 1),        # two k tiles
+    (1025, 1028, 192, True, True, 0, 1),       # three k tiles (odd), one row / one column group past the tile edge
+    (1564, 3840, 1280, True, False, 0, 1),     # ViT qkv, one image
+    (5208, 2560, 2048, True, False, 0, 1),     # LLM qkv, 8 images x 651 rows
+    (3128, 1280, 3456, True, True, 0, 1),      # ViT down + residual, 2 images
+    (2604, 2048, 5888, True, False, 1, 1),     # GELU epilogue
+    (777, 512, 320, True, True, 2, 1),         # SiLU epilogue + residual
+    (2604, 2048, 11008, False, True, 0, 3),    # LLM down, split-K 3 (fp32 partials + fixed-order reduce)
+    (1300, 1024, 1024, True, False, 0, 2),     # split-K 2
+]
+
+
+def test_gemm_p8_256x256():
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(55)
+    try:
+        for (M, N, K, hb, hr, act, splits) in P8_SHAPES:
+            L.check(L.load().fo1_gemm_set_variant(0, 5), "variant")
+            L.check(L.load().fo1_gemm_set_splitk(splits), "splitk")
+            a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+            w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+            bias = (torch.randn(N) * 0.1).to(BF).cuda() if hb else None
+            res = torch.randn(M, N).to(BF).cuda() if hr else None
+            got = ops.gemm(a, w, bias, res, act)
+            ref = gemm_ref(a, w, bias, res, act)
+            scale = ref.abs().max().item()
+            err = (got.float().cpu() - ref).abs().max().item()
+            rel = (got.float().cpu() - ref).norm() / ref.norm()
+            assert err <= 2e-2 * scale + 1e-3 and rel < 4e-3, f"p8 gemm {M}x{N}x{K} act={act} splits={splits}: max err {err:.4g} (scale {scale:.4g}), rel fro {rel:.4g}"
+            # race screen: the pipeline's LDS hazards (DMA landing vs ds_read, restaging vs the lagging half's reads) would show up as
+            # run-to-run differences; 12 more launches must be bit-identical
+            for _ in range(12):
+                again = ops.gemm(a, w, bias, res, act)
+                assert torch.equal(again, got), f"p8 gemm {M}x{N}x{K}: two launches differ (race)"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_splitk(0)
+
+
+def test_gemm_p8_swiglu_and_one_hot():
+    """(a) the interleaved-SwiGLU epilogue on 32x32 fragments against the unfused reference; (b) an A = one-hot-rows GEMM whose exact
+    answer is a row of W: catches any row/column or k-chunk mix-up exactly (no tolerance)."""
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(56)
+    try:
+        L.check(L.load().fo1_gemm_set_variant(0, 5), "variant")
+        M, K, Fh = 1564, 1280, 3456
+        a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+        wg = (torch.randn(Fh, K) * 0.05).to(BF)
+        wu = (torch.randn(Fh, K) * 0.05).to(BF)
+        bg, bu = (torch.randn(Fh) * 0.1).to(BF), (torch.randn(Fh) * 0.1).to(BF)
+        w = ops.interleave_gate_up(wg, wu).cuda()
+        b = ops.interleave_gate_up(bg, bu).cuda()
+        got = ops.gemm(a, w, b, act=ops.ACT_SWIGLU16)
+        g = rb(a.float().cpu() @ wg.float().t() + bg.float())
+        u = rb(a.float().cpu() @ wu.float().t() + bu.float())
+        ref = rb(rb(torch.nn.functional.silu(g)) * u)
+        err = (got.float().cpu() - ref).abs().max().item()
+        assert got.shape == (M, Fh) and err <= 2e-2 * ref.abs().max().item() + 1e-3, f"p8 swiglu: max err {err:.4g}"
+        # one-hot A: row m picks column (7 m + 3) mod K of W  ->  C[m, n] = W[n, k(m)] exactly
+        M, N, K = 1100, 768, 448
+        kk = (torch.arange(M) * 7 + 3) % K
+        a = torch.zeros(M, K)
+        a[torch.arange(M), kk] = 1.0
+        w = (torch.randn(N, K)).to(BF)
+        got = ops.gemm(a.to(BF).cuda(), w.cuda())
+        assert torch.equal(got.cpu(), w[:, kk].t().contiguous()), "p8 gemm: one-hot A does not select W columns exactly"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)

@@ -21,6 +21,8 @@
 //   y = bf16(acc + bias); y = bf16(act(y)); y = bf16(y + residual)
 #include "common.h"
 
+#include <type_traits>
+
 namespace fo1 {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -510,8 +512,295 @@ __global__ __launch_bounds__(256) void gemm_bt_ring_kernel(const GemmParams p) {
     epilogue<FM, FN>(p, acc, m0 + wm * WM, n0 + wn * WN, lane, bz * p.sC, bz * p.sR);
 }
 
+// ------------------------------------------------------------------------------------------
+// 256 x 256 x 64 tile, 8 waves (2 x 4, wave tile 128 x 64), v_mfma_f32_32x32x16_bf16, LDS-DMA staging with counted
+// vmcnt and a ping-pong ("8-phase") schedule — the large-M path (batched prefill: M = images x rows).
+//
+// A K tile is consumed in 4 phases, one C quadrant (64 x 32 per wave, 8 MFMAs) each; every phase is
+//     [load segment: ds_read the quadrant's operand fragments, issue ONE 16-KiB group of the LDS-DMA prefetch]  s_barrier
+//     [MFMA segment: 8 x v_mfma_f32_32x32x16_bf16]                                                              s_barrier
+// and waves 4-7 run one barrier behind waves 0-3, so each SIMD (it hosts one wave of either half) always has one wave in
+// its MFMA segment while the other reads LDS / issues DMA.  The DMA runs up to two K tiles ahead: a tile's four 16-KiB
+// groups {A rows 0-63 | A rows 64-127 | W rows 0-31 | W rows 32-63 of every wave} are re-staged one phase after their last
+// read (reads are retired with lgkmcnt(0) before the barrier that ends the load segment, so the lagging half cannot still
+// be reading), and the only wait is ONE counted s_waitcnt vmcnt(6) per K tile (three groups stay in flight across it).
+// LDS: 2 buffers x 4 groups x 16 KiB = 128 KiB, one workgroup per CU.  The LDS image is lane-linear per DMA instruction
+// (8 rows x 128 B); the bank-conflict swizzle (chunk ^ ((row >> 1) & 7)) sits on the SOURCE address and on the read.
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define FO1_P8_BARRIER()                      \
+    do {                                      \
+        asm volatile("" ::: "memory");        \
+        __builtin_amdgcn_s_barrier();         \
+        asm volatile("" ::: "memory");        \
+    } while (0)
+
+// grouped tile order inside each XCD's contiguous run: 8 tile rows x consecutive tile columns, so the ~32 tiles an XCD
+// runs at once share 8 A panels and 4 W panels in its L2
+__device__ __forceinline__ void tile_coords_grouped(const GemmParams& p, int& tm, int& tn) {
+    const int nwg = p.tiles_m * p.tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    constexpr int GM = 8;
+    const int per_group = GM * p.tiles_n;
+    const int gid = swz / per_group, in = swz - gid * per_group;
+    const int first = gid * GM;
+    const int gsz = min(p.tiles_m - first, GM);
+    tm = first + in % gsz;
+    tn = in / gsz;
+}
+
+template <int ACT>
+__device__ __forceinline__ float act_apply_t(float v) {
+    if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    if constexpr (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+
+// Epilogue for 32x32 accumulator fragments:
+//   acc[mf][nf][r] = C[m_base + mf*32 + (lane & 31)][n_base + nf*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
+// EPI: 0..2 = bias -> bf16 -> act EPI -> bf16 -> +residual -> bf16 (the reference's rounding points); 3 = interleaved SwiGLU;
+// 4 = raw fp32 partials of this K split.  The variant is a template parameter so that each instantiation's 32 unrolled
+// store groups stay small (erff / expf inlined 128 times blow the unroll budget and push the accumulators to scratch).
+template <int EPI, int MF, int NF>
+__device__ __forceinline__ void epilogue32(const GemmParams& p, f32x16 (&acc)[MF][NF], int m_base, int n_base, int lane, long long offC,
+                                           long long offR, int split) {
+    const int mi = lane & 31, hi4 = (lane >> 5) * 4;
+    if constexpr (EPI == 4) {
+        float* base = p.part + (long long)split * p.M * p.N;
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = m_base + mf * 32 + mi;
+            const bool m_ok = m < p.M;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n0 = n_base + nf * 32 + g * 8 + hi4;
+                    if (m_ok && n0 < p.N)   // N % 4 == 0 guaranteed by the dispatcher
+                        *reinterpret_cast<float4*>(base + (long long)m * p.N + n0) =
+                            float4{acc[mf][nf][g * 4 + 0], acc[mf][nf][g * 4 + 1], acc[mf][nf][g * 4 + 2], acc[mf][nf][g * 4 + 3]};
+                }
+        }
+    } else if constexpr (EPI == ACT_SWIGLU16) {
+        // 16-row interleaved [gate 16 | up 16]: one 32-row fragment holds gate (r < 8) and up (r >= 8) of the same 16 features
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = m_base + mf * 32 + mi;
+            const bool m_ok = m < p.M;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) {
+                const int nb = n_base + nf * 32;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int f0 = g * 8 + hi4;   // feature inside the group; gate row nb + f0 + r, up row nb + 16 + f0 + r
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float gt = acc[mf][nf][g * 4 + r], up = acc[mf][nf][8 + g * 4 + r];
+                        if (p.bias && nb < p.N) { gt += bf16_to_f32(p.bias[nb + f0 + r]); up += bf16_to_f32(p.bias[nb + 16 + f0 + r]); }
+                        gt = round_bf16(gt);
+                        up = round_bf16(up);
+                        o[r] = round_bf16(gt / (1.0f + expf(-gt))) * up;
+                    }
+                    uint2 ov;
+                    ov.x = pack_bf16x2(o[0], o[1]);
+                    ov.y = pack_bf16x2(o[2], o[3]);
+                    if (m_ok && nb < p.N) *reinterpret_cast<uint2*>(p.C + offC + (long long)m * p.ldc + (nb >> 1) + f0) = ov;
+                }
+            }
+        }
+    } else {
+        // the dispatcher only routes here when N % 4 == 0 and C / residual rows are 8-byte aligned
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+            const int m = m_base + mf * 32 + mi;
+            const bool m_ok = m < p.M;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n0 = n_base + nf * 32 + g * 8 + hi4;
+                    const bool ok = m_ok && n0 < p.N;
+                    float v[4] = {acc[mf][nf][g * 4 + 0], acc[mf][nf][g * 4 + 1], acc[mf][nf][g * 4 + 2], acc[mf][nf][g * 4 + 3]};
+                    if (p.bias && ok) {
+                        const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + n0);
+                        v[0] += bf16_lo(bv.x); v[1] += bf16_hi(bv.x); v[2] += bf16_lo(bv.y); v[3] += bf16_hi(bv.y);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = round_bf16(v[r]);
+                    if constexpr (EPI != ACT_NONE) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = round_bf16(act_apply_t<EPI>(v[r]));
+                    }
+                    if (p.res && ok) {
+                        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + offR + (long long)m * p.ldr + n0);
+                        v[0] += bf16_lo(rv.x); v[1] += bf16_hi(rv.x); v[2] += bf16_lo(rv.y); v[3] += bf16_hi(rv.y);
+                    }
+                    uint2 ov;
+                    ov.x = pack_bf16x2(v[0], v[1]);
+                    ov.y = pack_bf16x2(v[2], v[3]);
+                    if (ok) *reinterpret_cast<uint2*>(p.C + offC + (long long)m * p.ldc + n0) = ov;
+                }
+        }
+    }
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bt_p8_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int GROUP = 16384, BUFSZ = 4 * GROUP;       // A0 | A1 | B0 | B1
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUFSZ]
+
+    int tm, tn;
+    tile_coords_grouped(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = wave >= 4;                              // waves 4-7 run one barrier behind
+    const long long bz = blockIdx.y;
+    const uint16_t* A = p.A + bz * p.sA;
+    const uint16_t* W = p.W + bz * p.sW;
+
+    // ---- DMA source pointers: group g, instruction i (local rows 16*wave + 8*i + (lane >> 3)), chunk swizzled on the source ----
+    const uint16_t* src[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = wave * 16 + i * 8 + (lane >> 3);
+            const int cs = ((lane & 7) ^ ((lr >> 1) & 7)) * 8;
+            if (g < 2) {   // A half g: local row = wm'*64 + j  ->  tile row wm'*128 + g*64 + j
+                int gm = m0 + (lr >> 6) * 128 + g * 64 + (lr & 63);
+                gm = gm < p.M ? gm : p.M - 1;
+                src[g][i] = A + (long long)gm * p.lda + cs;
+            } else {       // W half g-2: local row = wn'*32 + j  ->  tile row wn'*64 + (g-2)*32 + j
+                int gn = n0 + (lr >> 5) * 64 + (g - 2) * 32 + (lr & 31);
+                gn = gn < p.N ? gn : p.N - 1;
+                src[g][i] = W + (long long)gn * p.ldw + cs;
+            }
+        }
+    const int nk_all = p.K / BK;
+    const int kt0 = blockIdx.z * p.kper;
+    const int nk = min(nk_all - kt0, p.kper);
+    auto stage = [&](int g, int kt, int buf) {   // one 16-KiB group of k-tile kt0+kt into buffer buf
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* dst = smem + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;   // wave-uniform
+            const uint16_t* s = (g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i]) + (long long)(kt0 + kt) * BK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets (bytes inside a group) ----
+    const int hi = lane >> 5;
+    int a_off[2], a_sw[2];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+        const int lr = wm * 64 + fm * 32 + (lane & 31);
+        a_off[fm] = lr * 128;
+        a_sw[fm] = (lr >> 1) & 7;
+    }
+    const int b_lr = wn * 32 + (lane & 31);
+    const int b_off = b_lr * 128, b_sw = (b_lr >> 1) & 7;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 areg[2][4], breg[4];
+
+    // ---- prologue: tile 0 complete, tile 1's A0 / B1 / A1 in flight (its B0 is issued in phase 0 of tile 0) ----
+    stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+    if (nk > 1) {
+        stage(0, 1, 1); stage(3, 1, 1); stage(1, 1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    FO1_P8_BARRIER();
+    if (late) FO1_P8_BARRIER();
+
+    auto tile = [&](auto BUFC, int t) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const char* base = smem + BUF * BUFSZ;
+        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        auto loadA = [&](int h) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int fm = 0; fm < 2; ++fm)
+                    areg[fm][ks] = *reinterpret_cast<const bf16x8*>(base + h * GROUP + a_off[fm] + (((ks * 2 + hi) ^ a_sw[fm]) << 4));
+        };
+        auto loadB = [&](int h) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                breg[ks] = *reinterpret_cast<const bf16x8*>(base + (2 + h) * GROUP + b_off + (((ks * 2 + hi) ^ b_sw) << 4));
+        };
+        auto end_load = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave's LDS reads are retired before it arrives
+            __builtin_amdgcn_sched_barrier(0);
+            FO1_P8_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto end_mfma = [&](bool last) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(last && late)) FO1_P8_BARRIER();   // the lagging half's final barrier has no partner: drop it
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#define FO1_P8_MFMA(AH, BH)                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                       \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) _Pragma("unroll") for (int fm = 0; fm < 2; ++fm)                    \
+        acc[(AH) * 2 + fm][BH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[ks], areg[fm][ks], acc[(AH) * 2 + fm][BH], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);
+        // phase 0: quadrant (a0, b0)
+        loadB(0);
+        loadA(0);
+        if (more1) stage(2, t + 1, BUF ^ 1);
+        end_load();
+        FO1_P8_MFMA(0, 0)
+        end_mfma(false);
+        // phase 1: quadrant (a0, b1)
+        loadB(1);
+        if (more2) stage(0, t + 2, BUF);
+        end_load();
+        FO1_P8_MFMA(0, 1)
+        end_mfma(false);
+        // phase 2: quadrant (a1, b1)
+        loadA(1);
+        if (more2) stage(3, t + 2, BUF);
+        end_load();
+        FO1_P8_MFMA(1, 1)
+        end_mfma(false);
+        // phase 3: quadrant (a1, b0); the counted wait that retires tile t+1
+        loadB(0);
+        if (more2) {
+            stage(1, t + 2, BUF);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (more1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        end_load();
+        FO1_P8_MFMA(1, 0)
+        end_mfma(!more1);
+#undef FO1_P8_MFMA
+    };
+    for (int t = 0; t < nk; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
+}
+
 static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds two-stage, 3/4/6 glds ring of that depth
-static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x256 (8 waves)
+static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x256 (8 waves), 5 = 256x256 ping-pong
 static int g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
 static int g_gemm_profile_shapes = 0;
 static int g_gemm_debug = 0;
@@ -522,14 +811,14 @@ int gemv_dispatch(const void* A, int lda, const void* W, int ldw, const void* bi
                   int M, int N, int K, int act, hipStream_t st, const void* norm_w, float norm_eps);
 
 // 128 x 256 tile, 8 waves (2 x 4): halves the L2->LDS traffic of the 64 x 128 tile for wide-N GEMMs
+template <int BM, int BN>
 static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
-    constexpr int BM = 128, BN = 256;
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
     const dim3 grid(p.tiles_m * p.tiles_n, batch, p.splits);
     const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
     char pname[48];
-    const char* name = "gemm_bt_glds<128,256>";
+    const char* name = BM == 128 ? "gemm_bt_glds<128,256>" : "gemm_bt_glds<256,256>";
     if (profile_enabled() && g_gemm_profile_shapes) {
         snprintf(pname, sizeof pname, "gemm %dx%dx%d t%dx%d s%d", p.M, p.N, p.K, BM, BN, p.splits);
         name = pname;
@@ -541,6 +830,42 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
         attr_done = true;
     }
     FO1_LAUNCH(name, flops, (gemm_bt_glds_kernel<BM, BN, 2, 4>), grid, dim3(512), smem, st, p);
+    if (p.splits > 1) {
+        const long long total = (long long)p.M * (p.N / 4);
+        const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        FO1_LAUNCH("gemm_splitk_reduce", (double)p.M * p.N * 4.0 * p.splits, gemm_splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
+    }
+    return FO1_OK;
+}
+
+// 256 x 256 ping-pong kernel (gemm_bt_p8_kernel)
+static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
+    p.tiles_m = cdiv(p.M, 256);
+    p.tiles_n = cdiv(p.N, 256);
+    const dim3 grid(p.tiles_m * p.tiles_n, batch, p.splits);
+    const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
+    char pname[48];
+    const char* name = "gemm_bt_p8<256,256>";
+    if (profile_enabled() && g_gemm_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemm %dx%dx%d t256x256 s%d", p.M, p.N, p.K, p.splits);
+        name = pname;
+    }
+    constexpr int smem = 2 * 4 * 16384;
+    static bool attr_done = false;
+    if (!attr_done) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    const int epi = p.splits > 1 ? 4 : p.act;
+    if (epi == 0) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<0>, grid, dim3(512), smem, st, p);
+    else if (epi == 1) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<1>, grid, dim3(512), smem, st, p);
+    else if (epi == 2) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<2>, grid, dim3(512), smem, st, p);
+    else if (epi == 3) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<3>, grid, dim3(512), smem, st, p);
+    else FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<4>, grid, dim3(512), smem, st, p);
     if (p.splits > 1) {
         const long long total = (long long)p.M * (p.N / 4);
         const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -642,6 +967,9 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         tile = (t128 >= 768 && nk >= 16) ? 1 : (t64x128 >= 512 ? 2 : 3);   // shallow K (DaViT stage 0, K=256): 64x128 wins
         if (glds && nk >= 16 && (long long)cdiv(p.M, 128) * cdiv(p.N, 256) * batch >= 1024) tile = 4;
         if (splits == 0 && can_split && nk >= 64 && t64x128 < 512) tile = 2;
+        // large M (batched prefill): the 256 x 256 ping-pong kernel once its tiles fill >= 80 % of the rounds they occupy
+        const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256) * batch;
+        if (glds && nk >= 8 && p.M >= 1024 && t256 >= 205 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.8) tile = 5;
     }
     p.splits = 1;
     p.kper = nk + 1;
@@ -664,10 +992,18 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
             p.part = ws;
         }
     }
+    const bool p8_ok = glds && p.C32 == nullptr && p.N % 4 == 0 && p.ldc % 4 == 0 && ((uintptr_t)p.C & 7) == 0 && p.sC % 4 == 0 &&
+                       (p.bias == nullptr || ((uintptr_t)p.bias & 7) == 0) &&
+                       (p.res == nullptr || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 7) == 0 && p.sR % 4 == 0)) && (p.act != ACT_SWIGLU16 || p.N % 32 == 0);
+    if (tile == 5 && p8_ok) {
+        p.stages = 2;
+        return launch_gemm_p8(p, batch, st);
+    }
+    if (tile == 5) tile = 1;
     if (g_gemm_variant >= 3) p.stages = g_gemm_variant;
     else if (g_gemm_variant == 0 && glds && ((tile == 3 && t64 <= 768) || (tile == 2 && tiles * p.splits < 512))) p.stages = 3;
     else p.stages = 2;
-    if (tile == 4 && glds && p.stages == 2) return launch_gemm_wide(p, batch, st);
+    if (tile == 4 && glds && p.stages == 2) return launch_gemm_wide<128, 256>(p, batch, st);
     if (tile == 4) tile = 1;
     if (tile == 1) return launch_gemm<128, 128>(p, batch, glds, st);
     if (tile == 2) return launch_gemm<64, 128>(p, batch, glds, st);
@@ -679,7 +1015,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
 extern "C" {
 
 int fo1_gemm_set_variant(int staging, int tile) {
-    if (staging < 0 || staging > 6 || staging == 5 || tile < 0 || tile > 4) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
+    if (staging < 0 || staging > 6 || staging == 5 || tile < 0 || tile > 5) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
     fo1::g_gemm_variant = staging;
     fo1::g_gemm_tile = tile;
     return FO1_OK;
