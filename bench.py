@@ -54,7 +54,7 @@ class Pipeline:
     stages = ["qwen_vit(32 blocks)+merger", "mm_projector", "davit_large", "simple_fpn", "hfre_region_pool",
               "mm_projector_aux", "splice+mrope", "llm_prefill(36 layers)", "lm_head(last row)+argmax"]
 
-    def __init__(self, case, device, inflight=1):
+    def __init__(self, case, device, inflight=1, batch=1, cases=None):
         from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights
         self.cfg = FO1Config()
         self.weights = random_weights(self.cfg, device, seed=0)
@@ -62,11 +62,23 @@ class Pipeline:
         self.engs = [self.eng] + [self.eng.replica() for _ in range(inflight - 1)]
         self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=device) for _ in range(inflight - 1)]
         self.case = case
+        self.batch = batch
+        # `batch` DIFFERENT images of the same geometry per step (cases[i]); packed into one pass of every stage
+        self.cases = cases if cases is not None else [case] * batch
+        self.requests = [dict(ids=c["ids"], pix=c["dev"]["pix"], grid=c["grid"], aux=c["dev"]["aux"], boxes=c["dev"]["boxes"]) for c in self.cases]
 
     def step(self, graph=True, slot=0):
-        d = self.case["dev"]
+        """One step = one packed pass over `batch` images (batch 1: one image)."""
         with torch.cuda.stream(self.streams[slot]):
-            return self.engs[slot].prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
+            if self.batch == 1:
+                d = self.case["dev"]
+                return self.engs[slot].prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
+            return self.engs[slot].prefill_batch(self.requests, use_graph=graph)
+
+    def step_single(self, graph=True):
+        """Latency mode: ONE image through the same stages (a batch of one)."""
+        d = self.case["dev"]
+        return self.eng.prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
 
 
 def cpu_baseline(case, pipe, reps=3, decode_tokens=64):
@@ -233,9 +245,13 @@ def main():
     ap.add_argument("--boxes", type=int, default=100, help="proposals per image (default 100 = the configuration BASELINE.json's metric is quoted on; 32 = configs[1])")
     ap.add_argument("--image", default="480x640", help="HxW of the synthetic image (default = BASELINE configs[1]; 1344x1344 with "
                     "--boxes 100 is the high-resolution configuration's geometry)")
-    ap.add_argument("--inflight", type=int, default=3, help="independent single-image passes in flight per GPU (streams); 1 = strictly "
-                    "one image at a time (latency mode)")
+    ap.add_argument("--batch", type=int, default=8, help="images packed into ONE pass of every stage (varlen batched prefill); a step is "
+                    "one such pass; 1 = one image per pass (latency mode)")
+    ap.add_argument("--inflight", type=int, default=2, help="independent passes in flight per GPU (engine replicas on their own HIP "
+                    "streams); 1 = strictly one pass at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=3, help="timed oracle passes (median) after one warm-up pass")
+    ap.add_argument("--cpu-decode-tokens", type=int, default=64)
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
     ap.add_argument("--profile-shapes", action="store_true", help="per-shape GEMM rows in roofline.per_step_ms")
     args = ap.parse_args()
@@ -263,9 +279,11 @@ def main():
     from vlm_fo1_amd import lib as L
     L.load()
     img_hw = tuple(int(v) for v in args.image.lower().split("x"))
-    case = build_workload(dev, n_boxes=args.boxes, img_hw=img_hw, seed=1234 + rank)
+    B = max(1, args.batch)
+    cases = [build_workload(dev, n_boxes=args.boxes, img_hw=img_hw, seed=1234 + rank * 1000 + i) for i in range(B)]
+    case = cases[0]
     R = max(1, args.inflight)
-    pipe = Pipeline(case, dev, inflight=R)
+    pipe = Pipeline(case, dev, inflight=R, batch=B, cases=cases)
 
     use_graph = not args.eager
     for slot in range(R):
@@ -291,25 +309,35 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
 
-    # ---- latency mode: strictly one image at a time on one stream (not `value` unless --inflight 1) ----
-    single = None
+    # ---- side measurements on rank 0 (never `value`): one packed pass at a time, and strictly one image at a time ----
+    single = one_pass = None
     if rank == 0:
-        if R == 1:
-            single = dict(images_per_sec=args.steps / el, ms_per_image=el / args.steps * 1e3)
+        if R > 1 or B > 1:
+            for _ in range(3):
+                pipe.step_single(use_graph)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pipe.step_single(use_graph)
+            torch.cuda.synchronize()
+            e1 = time.perf_counter() - t1
+            single = dict(images_per_sec=round(args.steps / e1, 2), ms_per_image=round(e1 / args.steps * 1e3, 3))
         else:
+            single = dict(images_per_sec=args.steps / el, ms_per_image=el / args.steps * 1e3)
+        if R > 1:
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.steps):
                 pipe.step(use_graph, 0)
             torch.cuda.synchronize()
             e1 = time.perf_counter() - t1
-            single = dict(images_per_sec=round(args.steps / e1, 2), ms_per_image=round(e1 / args.steps * 1e3, 3))
+            one_pass = dict(images_per_sec=round(args.steps * B / e1, 2), ms_per_pass=round(e1 / args.steps * 1e3, 3), images_per_pass=B)
 
     # ---- greedy decode through the KV cache (fixed K new tokens, reported separately; not part of `value`) ----
     dec = None
     if rank == 0:
         K = 32
-        out = pipe.step(use_graph)
+        out = pipe.step_single(use_graph)
         tok = out["next_token"]
         llm = pipe.eng.llm
         if use_graph:
@@ -442,7 +470,7 @@ def main():
                                 traffic=hb, traffic_source=hsrc)
 
     if rank == 0:
-        n_img = args.steps * world
+        n_img = args.steps * world * B
         out = dict(metric="images/sec", value=n_img / el, unit="images/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=el / args.steps * 1e3, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype="bf16", data="synthetic",
@@ -453,20 +481,22 @@ def main():
                                         f"{len(case['ids']) - 1 + case['grid'][0] * case['grid'][1] // 4} tokens after splice, prefill to the first greedy token",
                                stages=Pipeline.stages,
                                launch=("eager" if args.eager else "hipGraph replay (1 graph per shape signature)") +
-                                      (f"; {R} independent images in flight on {R} HIP streams (engine replicas share weights)" if R > 1 else "; one image at a time"),
-                               images_in_flight=R,
+                                      f"; a step = ONE packed pass over {B} different images (varlen batched prefill: rows of all images in every GEMM)" +
+                                      (f"; {R} passes in flight on {R} HIP streams (engine replicas share weights)" if R > 1 else "; one pass at a time"),
+                               images_per_step=B, passes_in_flight=R, global_batch=B * world,
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
-                   one_image_at_a_time=single, decode=dec, preprocess=prep, roofline=roof)
+                   one_image_at_a_time=single, one_pass_at_a_time=one_pass, decode=dec, preprocess=prep, roofline=roof)
         if roof is not None:
             # stage times (sum of kernel execution time per stage, eager pass) and the two region-token rates
             out["stage_kernel_ms"] = stage_ms
             t_reg = stage_ms.get("hfre_region_pool", 0.0) + stage_ms.get("mm_projector_aux", 0.0)
             t_enc = t_reg + stage_ms.get("davit_large", 0.0) + stage_ms.get("simple_fpn", 0.0)
             if t_reg > 0:
-                out["region_tokens_per_sec_hfre_plus_connector"] = round(args.boxes / (t_reg * 1e-3), 1)
-                out["region_tokens_per_sec_encode_regions"] = round(args.boxes / (t_enc * 1e-3), 1)
+                out["region_tokens_per_sec_hfre_plus_connector"] = round(B * args.boxes / (t_reg * 1e-3), 1)
+                out["region_tokens_per_sec_encode_regions"] = round(B * args.boxes / (t_enc * 1e-3), 1)
+            out["stage_kernel_ms_note"] = f"kernel time per packed pass of {B} images"
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(case, pipe)
+            out["cpu_baseline"] = cpu_baseline(case, pipe, reps=args.cpu_reps, decode_tokens=args.cpu_decode_tokens)
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()   # ranks leave together (rank 0 was still measuring decode / roofline)

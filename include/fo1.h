@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FO1_ABI_VERSION 1
+#define FO1_ABI_VERSION 2
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -223,6 +223,9 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
 
 /* ------------------------------------------------------------------------
  * DaViT / SimpleFPN / splice data-movement kernels on token-major bf16 maps [H*W, C] (C % 8 == 0).
+ * ABI 2: every spatial kernel takes `batch` — that many same-size images stacked along the row dimension
+ * ([batch*H*W, C]; image b = rows [b*H*W, (b+1)*H*W)); neighbourhoods never cross an image boundary.  This is the
+ * multi-image prefill of SURVEY 8f-3 (the reference's splice is batch-aware, omchat_qwen2_5_vl.py:380-416).
  *   fo1_dwconv3x3_bf16          y = x + bf16(dwconv3x3(x) + bias)   DepthWiseConv2d inside PreNorm(None,.)
  *                               modeling_davit.py:72-99,29-48; weight re-laid out [9][C] (tap-major)
  *   fo1_im2col_bf16             col[(oy,ox), (ky,kx,c)] for ConvEmbed (:102-148) and the FPN 3x3 conv
@@ -239,23 +242,25 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
  *                               token splice (omchat_qwen2_5_vl.py:291-373); plan = int32[R][2]
  * ---------------------------------------------------------------------- */
 int fo1_dwconv3x3_bf16(const void* x, const void* weight9c, const void* bias, void* y, int H, int W, int C,
-                       void* stream);
+                       int batch, void* stream);
 /* fo1_dwconv3x3_bf16 followed by the LayerNorm every DaViT block applies to its result (modeling_davit.py:29-48 PreNorm after
  * :72-99 DepthWiseConv2d), one launch: y = x + dwconv(x) (the residual stream), h = LayerNorm(y).  Bit-identical to the two
  * separate calls.  C <= 2048. */
 int fo1_dwconv3x3_ln_bf16(const void* x, const void* weight9c, const void* bias, void* y, const void* ln_weight,
-                          const void* ln_bias, float ln_eps, void* h, int H, int W, int C, void* stream);
+                          const void* ln_bias, float ln_eps, void* h, int H, int W, int C, int batch, void* stream);
 int fo1_im2col_bf16(const void* x, void* col, int H, int W, int C, int KH, int KW, int stride, int pad,
-                    int ld_col, void* stream);
-int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, void* stream);
+                    int ld_col, int batch, void* stream);
+int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, int batch, void* stream);
 int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, int H, int W, int C, int ws,
-                                void* stream);
-size_t fo1_channel_attention_workspace_bytes(int N, int C);
-int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, void* workspace,
+                                int batch, void* stream);
+/* N = tokens of ONE image; qkv / out hold batch * N rows and every image gets its own per-group attention matrices */
+size_t fo1_channel_attention_workspace_bytes(int N, int C, int batch);
+int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, int batch, void* workspace,
                                size_t workspace_bytes, void* stream);
-int fo1_pixel_shuffle2_bf16(const void* src, void* dst, int H, int W, int Co, void* stream);
-int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, void* stream);
-int fo1_nchw_to_hwc8_bf16(const void* img, int is_f32, void* out, int H, int W, void* stream);
+int fo1_pixel_shuffle2_bf16(const void* src, void* dst, int H, int W, int Co, int batch, void* stream);
+int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, int batch, void* stream);
+/* img: [batch, 3, H, W] */
+int fo1_nchw_to_hwc8_bf16(const void* img, int is_f32, void* out, int H, int W, int batch, void* stream);
 int fo1_gather_rows_bf16(const void* table0, int ld0, const void* table1, int ld1, const void* table2,
                          int ld2, const int32_t* plan, void* out, int ldo, int R, int D, void* stream);
 

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 2, GPU call 3: whole GPU suite with the batched path, then the bench at several (batch, in-flight) settings
+OUT=$(pwd)/gpurun_out/r02_run3; mkdir -p $OUT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 1500 python -m pytest tests -m gpu -q --timeout 900 -x --deselect tests/test_fulldepth_parity_gpu.py > $OUT/pytest.log 2>&1; tail -25 $OUT/pytest.log
+for cfg in "8 1" "8 2" "4 2" "1 3" "16 1"; do
+  set -- $cfg
+  timeout 600 python bench.py --batch $1 --inflight $2 --no-cpu-baseline > $OUT/bench_b$1_i$2.json 2> $OUT/bench_b$1_i$2.err
+  python - <<PY
+import json
+try:
+    d=json.loads(open("$OUT/bench_b$1_i$2.json").read())
+    r=d["roofline"]
+    print("batch $1 inflight $2: value", round(d["value"],1), "img/s  ms/step", round(d["ms_per_step"],2), "single", d["one_image_at_a_time"], "one_pass", d.get("one_pass_at_a_time"), "dom", r["kernel"], r["achieved"], "allgemm", r["all_gemm_tiles"])
+    print("   stage", d["stage_kernel_ms"])
+except Exception as e:
+    print("batch $1 inflight $2 FAILED", e); print(open("$OUT/bench_b$1_i$2.err").read()[-1500:])
+PY
+done

@@ -1,0 +1,111 @@
+"""Multi-image varlen batched prefill (the reference's batch-aware splice, omchat_qwen2_5_vl.py:380-416): R images'
+rows packed into ONE ViT / DaViT / SimpleFPN / LLM pass must give, per image, what the one-image pass gives.
+
+  * With the GEMM tile pinned (the k-order of a row's dot products then does not depend on M) every output is BIT-identical to the
+    sequential passes: packing changes which rows share a launch, not the arithmetic of a row.
+  * With the automatic tile choice (large M takes the 256x256 32x32x16-MFMA kernel, whose fp32 summation order differs from the
+    16x16x32 tiles) outputs agree at the bf16 tolerance of the other parity tests, and the greedy token is unchanged whenever
+    the top-1 margin exceeds the logit tolerance."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+KEYS = ("image_tokens", "region_tokens", "last_hidden", "logits", "next_token")
+
+
+def make_engine(seed=7):
+    from vlm_fo1_amd.llm import LLMConfig
+    from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights
+    from vlm_fo1_amd.vit import ViTConfig
+    cfg = FO1Config(vit=ViTConfig(depth=2, fullatt_block_indexes=(1,)), llm=LLMConfig(num_layers=2, vocab_size=4096, max_seq=1024))
+    return FO1Engine(cfg, random_weights(cfg, "cuda", seed=seed), "cuda")
+
+
+def make_request(i, W, H, n):
+    from vlm_fo1.model.image_processing import smart_resize
+    from vlm_fo1_amd.model import synthetic_prompt
+    rh, rw = smart_resize(H, W, 28, 56 * 56, 2048 * 2048)
+    gh, gw = rh // 14, rw // 14
+    g = torch.Generator().manual_seed(900 + i)
+    b = torch.rand(n, 4, generator=g)
+    x1, y1 = b[:, 0] * W * 0.7, b[:, 1] * H * 0.7
+    boxes = torch.stack([x1, y1, x1 + 4 + b[:, 2] * W * 0.3, y1 + 4 + b[:, 3] * H * 0.3], 1)
+    return dict(ids=synthetic_prompt(n, vocab=4096, seed=i), pix=torch.randn(gh * gw, 1176, generator=g).bfloat16().cuda(), grid=(gh, gw),
+                aux=torch.randn(3, H, W, generator=g).bfloat16().cuda(), boxes=boxes.cuda())
+
+
+def clone(o):
+    return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}
+
+
+def test_ragged_batch_equals_sequential_bitwise_with_pinned_tile():
+    from vlm_fo1_amd import lib as L
+    eng = make_engine()
+    reqs = [make_request(0, 500, 399, 7), make_request(1, 333, 711, 33), make_request(2, 64, 60, 1), make_request(3, 420, 420, 100)]
+    try:
+        L.check(L.load().fo1_gemm_set_variant(2, 1), "variant")     # 128x128 two-stage tiles for every GEMM, no split-K
+        L.check(L.load().fo1_gemm_set_splitk(1), "splitk")
+        seq = [clone(eng.prefill(r["ids"], r["pix"], r["grid"], r["aux"], r["boxes"])) for r in reqs]
+        bat = eng.prefill_batch(reqs)
+        for i, (a, b) in enumerate(zip(seq, bat)):
+            for k in KEYS:
+                assert torch.equal(a[k], b[k]), f"request {i}: {k} differs between the packed pass and the one-image pass"
+            assert torch.equal(a["embeds"], b["embeds"]) and torch.equal(a["position_ids"], b["position_ids"]) and a["rope_delta"] == b["rope_delta"]
+        # a different packing order permutes the results, nothing else
+        perm = [2, 0, 3, 1]
+        bat2 = eng.prefill_batch([reqs[j] for j in perm])
+        for slot, j in enumerate(perm):
+            for k in KEYS:
+                assert torch.equal(bat2[slot][k], seq[j][k]), f"permuted batch: request {j} {k}"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_splitk(0)
+
+
+def test_uniform_batch_auto_tiles_tolerance_and_graph():
+    """8 same-geometry images (the bench's shape of work, reduced depth): DaViT / FPN run stacked, the GEMMs take the large-M
+    kernel.  Packed vs sequential at the bf16 tolerance; graph replay of the packed pass bit-identical to its eager launches."""
+    eng = make_engine(seed=8)
+    reqs = [make_request(10 + i, 640, 480, 12) for i in range(8)]
+    seq = [clone(eng.prefill(r["ids"], r["pix"], r["grid"], r["aux"], r["boxes"])) for r in reqs]
+    bat = [clone(o) for o in eng.prefill_batch(reqs)]
+    for i, (a, b) in enumerate(zip(seq, bat)):
+        for k in ("image_tokens", "region_tokens", "last_hidden"):
+            x, y = a[k].float(), b[k].float()
+            cos = F.cosine_similarity(x, y, dim=-1).min().item()
+            rel = ((x - y).abs().max() / x.abs().max()).item()
+            assert cos >= 0.9999 and rel <= 2 ** -5, f"request {i} {k}: packed vs sequential min cos {cos:.6f} rel {rel:.4g}"
+        err = (a["logits"].float() - b["logits"].float()).abs().max().item()
+        assert err <= 0.05, f"request {i}: logits differ by {err:.4g}"
+        top2 = a["logits"].float()[0].topk(2).values
+        if top2[0] - top2[1] > 0.1:
+            assert int(a["next_token"].item()) == int(b["next_token"].item())
+    for _ in range(3):   # sighting 2 captures, 3 replays
+        g = eng.prefill_batch(reqs, use_graph=True)
+    for i, (b, c) in enumerate(zip(bat, g)):
+        for k in KEYS:
+            assert torch.equal(b[k], c[k]), f"request {i}: {k} differs between graph replay and eager (packed pass)"
+    assert len(eng._graphs) == 1
+
+
+def test_graph_cache_is_bounded_and_one_off_shapes_run_eagerly():
+    """every new shape signature used to be captured and kept forever.  Now a signature is captured only once it
+    repeats, and at most GRAPH_CACHE graphs are kept (LRU)."""
+    eng = make_engine(seed=9)
+    eng.GRAPH_CACHE = 2
+    shapes = [(200, 160), (230, 120), (120, 260), (180, 180)]
+    for i, (W, H) in enumerate(shapes):     # one-off shapes: nothing is captured
+        r = make_request(40 + i, W, H, 3)
+        eng.prefill(r["ids"], r["pix"], r["grid"], r["aux"], r["boxes"], use_graph=True)
+    assert len(eng._graphs) == 0
+    outs = {}
+    for rep in range(2):                    # repeated shapes: captured on the second sighting, LRU of 2
+        for i, (W, H) in enumerate(shapes):
+            r = make_request(40 + i, W, H, 3)
+            o = eng.prefill(r["ids"], r["pix"], r["grid"], r["aux"], r["boxes"], use_graph=True)
+            if rep == 0:
+                outs[i] = o["logits"].clone()
+            else:
+                assert torch.equal(o["logits"], outs[i])
+    assert len(eng._graphs) == 2

@@ -10,9 +10,12 @@ Two views per stage:
 
 Tolerances: SURVEY §7 asks for per-token cosine >= 0.9999 and max|d|/max|x| <= 2^-5 "after 32-36 layers" as a starting point
 "to tighten after first measurements".  bf16 storage re-rounds every operator output; the reference's own bf16 execution
-deviates from an fp32 evaluation of the same weights by the floors in FLOOR below, measured in the build container by
-running the reference's modules in bf16 and fp32 on the CPU at full depth (tests/golden/measure_bf16_floor.py, results in
-tests/golden/bf16_floor.json).  Each assertion uses min(SURVEY bound, measured floor with 1.5x margin on 1 - cos / rel).
+deviates from an fp32 evaluation of the same weights by the floors in tests/golden/bf16_floor.json, measured in the build
+container by running the reference's own modules in bf16 and in fp32 on the CPU at full depth on this very configuration
+(tests/golden/measure_bf16_floor.py; e.g. ViT map min cos 0.99967, LLM layer-36 hidden 0.99899 / rel 0.032, last-row logits
+0.14).  Each assertion uses min(SURVEY bound, measured floor with a 1.5x margin on 1 - cos and on rel): the engine may be
+as noisy as the reference's bf16 execution, not noisier.  First measurement on MI355X (profiles/r02_fulldepth_metrics_first.json):
+the engine sits AT that floor at every stage (ViT map 0.99963, DaViT stage 3 0.99979, LLM hidden 0.99900, logits 0.13).
 Every metric is also written to gpurun_out/fulldepth_metrics.json so the numbers behind the assertions are on record."""
 import json
 import os
@@ -161,7 +164,7 @@ def test_index_bookkeeping_exact(run):
 def test_vit_32_blocks(run):
     check(run, "vit_last_fullatt_map(block 31)", "vit_map")
     check(run, "vit_image_tokens(32 blocks+merger)", "vit_tokens")
-    check(run, "image_tokens(mm_projector)", "vit_tokens")
+    check(run, "image_tokens(mm_projector)", "image_tokens")
 
 
 def test_davit_large(run):
@@ -172,7 +175,7 @@ def test_davit_large(run):
 def test_simple_fpn(run):
     for i in range(4):
         check(run, f"fpn_level{i}_isolated", "fpn", survey_cos=0.9998)
-        check(run, f"fpn_level{i}_composed", "vit_map")
+        check(run, f"fpn_level{i}_composed", f"fpn_level{i}")
 
 
 def test_hfre_100_boxes(run):

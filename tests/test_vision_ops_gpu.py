@@ -132,3 +132,49 @@ def test_dwconv_layernorm_fused_equals_separate_kernels():
         y, h = ops.dwconv3x3_res_ln(x, w9, b, H, W, lw, lb, 1e-5)
         assert torch.equal(y, y_ref), f"{H}x{W}x{C}: conv output differs"
         assert torch.equal(h, h_ref), f"{H}x{W}x{C}: LayerNorm output differs ({int((h != h_ref).sum())} elements)"
+
+
+def test_batched_spatial_ops_equal_per_image_calls():
+    """ABI 2: `batch` same-size images stacked along the rows.  Every spatial kernel must give, for image b, exactly what the
+    one-image call gives (neighbourhoods / windows / channel-attention statistics never cross an image boundary)."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(3)
+    B, H, W, C = 3, 17, 23, 64
+    x = torch.randn(B * H * W, C).to(BF).cuda()
+    w9, b9 = (torch.randn(9, C) * 0.2).to(BF).cuda(), (torch.randn(C) * 0.1).to(BF).cuda()
+    lw, lb = (1 + 0.1 * torch.randn(C)).to(BF).cuda(), (0.1 * torch.randn(C)).to(BF).cuda()
+    per = lambda t, n: [t[i * n:(i + 1) * n].contiguous() for i in range(B)]
+    yb, hb = ops.dwconv3x3_res_ln(x, w9, b9, H, W, lw, lb, 1e-5, batch=B)
+    assert torch.equal(ops.dwconv3x3_res(x, w9, b9, H, W, batch=B), yb)
+    for i, xi in enumerate(per(x, H * W)):
+        y1, h1 = ops.dwconv3x3_res_ln(xi, w9, b9, H, W, lw, lb, 1e-5)
+        assert torch.equal(y1, yb[i * H * W:(i + 1) * H * W]) and torch.equal(h1, hb[i * H * W:(i + 1) * H * W]), f"dwconv_ln image {i}"
+    for (k, s, p) in ((3, 2, 1), (3, 1, 1), (7, 4, 3)):
+        colb, Ho, Wo = ops.im2col(x, H, W, k, k, s, p, batch=B)
+        for i, xi in enumerate(per(x, H * W)):
+            c1, _, _ = ops.im2col(xi, H, W, k, k, s, p)
+            assert torch.equal(c1, colb[i * Ho * Wo:(i + 1) * Ho * Wo]), f"im2col k{k} image {i}"
+    ws = 12
+    xw = ops.window_partition(x, H, W, ws, batch=B)
+    nrow = xw.shape[0] // B
+    yw = torch.randn_like(xw)
+    back = ops.window_reverse_add(yw, x, H, W, ws, batch=B)
+    for i, xi in enumerate(per(x, H * W)):
+        assert torch.equal(ops.window_partition(xi, H, W, ws), xw[i * nrow:(i + 1) * nrow]), f"window_partition image {i}"
+        assert torch.equal(ops.window_reverse_add(yw[i * nrow:(i + 1) * nrow].contiguous(), xi, H, W, ws), back[i * H * W:(i + 1) * H * W])
+    qkv = torch.randn(B * H * W, 3 * C).to(BF).cuda()
+    ab = ops.channel_attention(qkv, C, batch=B)
+    for i, qi in enumerate(per(qkv, H * W)):
+        assert torch.equal(ops.channel_attention(qi, C), ab[i * H * W:(i + 1) * H * W]), f"channel attention image {i}"
+    Co = 16
+    src = torch.randn(B * H * W, 4 * Co).to(BF).cuda()
+    ps = ops.pixel_shuffle2(src, H, W, Co, batch=B)
+    mp = ops.maxpool2(x, H, W, batch=B)
+    for i in range(B):
+        assert torch.equal(ops.pixel_shuffle2(src[i * H * W:(i + 1) * H * W].contiguous(), H, W, Co), ps[i * 4 * H * W:(i + 1) * 4 * H * W])
+        n2 = (H // 2) * (W // 2)
+        assert torch.equal(ops.maxpool2(x[i * H * W:(i + 1) * H * W].contiguous(), H, W), mp[i * n2:(i + 1) * n2])
+    img = torch.randn(B, 3, H, W).cuda()
+    hb8 = ops.nchw_to_hwc8(img)
+    for i in range(B):
+        assert torch.equal(ops.nchw_to_hwc8(img[i].contiguous()), hb8[i * H * W:(i + 1) * H * W])

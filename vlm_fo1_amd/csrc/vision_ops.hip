@@ -26,13 +26,15 @@ __device__ __forceinline__ float rbf(float v) { return bf16_to_f32(f32_to_bf16(v
 
 // y[h,w,c] = x[h,w,c] + bf16( sum_{ky,kx} x[h+ky-1, w+kx-1, c] * wt[(ky*3+kx)*C + c] + bias[c] )
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
-                                                        const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int H, int W, int C) {
+                                                        const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int H, int W, int C, int B) {
     const int chunks = C >> 3;
-    const long long total = (long long)H * W * chunks;
+    const int HW = H * W;
+    const long long total = (long long)B * HW * chunks;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % chunks);
-        const int pix = (int)(i / chunks);
-        const int h = pix / W, w = pix - h * W;
+        const int pix = (int)(i / chunks);           // global pixel over the B images
+        const int img0 = (pix / HW) * HW, lp = pix - img0;
+        const int h = lp / W, w = lp - h * W;
         float acc[8], ctr[8];
         un8(*reinterpret_cast<const uint4*>(bias + c * 8), acc);
 #pragma unroll
@@ -44,7 +46,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restri
                 const int ww = w + kx - 1;
                 if (ww < 0 || ww >= W) continue;
                 float xv[8], wv[8];
-                un8(*reinterpret_cast<const uint4*>(x + ((long long)hh * W + ww) * C + c * 8), xv);
+                un8(*reinterpret_cast<const uint4*>(x + ((long long)img0 + hh * W + ww) * C + c * 8), xv);
                 un8(*reinterpret_cast<const uint4*>(wt + (ky * 3 + kx) * C + c * 8), wv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
@@ -74,12 +76,14 @@ __device__ __forceinline__ float dw_wave_sum(float v) {
 __global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                            const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
                                                            const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b,
-                                                           uint16_t* __restrict__ hout, int H, int W, int C, float eps) {
-    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (pix >= H * W) return;
+                                                           uint16_t* __restrict__ hout, int H, int W, int C, float eps, int B) {
+    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);      // global pixel over the B images
+    const int HW = H * W;
+    if (pix >= B * HW) return;
     const int lane = threadIdx.x & 63;
     const int chunks = C >> 3;
-    const int h = pix / W, w = pix - h * W;
+    const int img0 = (pix / HW) * HW, lp = pix - img0;
+    const int h = lp / W, w = lp - h * W;
     float val[kDwLnChunks][8];
     float s = 0.f;
 #pragma unroll
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __res
                     const int ww = w + kx - 1;
                     if (ww < 0 || ww >= W) continue;
                     float xv[8], wv[8];
-                    un8(*reinterpret_cast<const uint4*>(x + ((long long)hh * W + ww) * C + c * 8), xv);
+                    un8(*reinterpret_cast<const uint4*>(x + ((long long)img0 + hh * W + ww) * C + c * 8), xv);
                     un8(*reinterpret_cast<const uint4*>(wt + (ky * 3 + kx) * C + c * 8), wv);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
@@ -145,52 +149,59 @@ __global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __res
 
 // col[(oy*Wo+ox), (ky*KW+kx)*C + c] = x[oy*s-p+ky, ox*s-p+kx, c]  (0 outside); row stride ldc >= KH*KW*C
 __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ col, int H, int W, int C,
-                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int ldc) {
+                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int ldc, int B) {
     const int chunks = C >> 3;
     const int kk = KH * KW;
-    const long long total = (long long)Ho * Wo * kk * chunks;
+    const int HoWo = Ho * Wo;
+    const long long total = (long long)B * HoWo * kk * chunks;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % chunks);
         long long r = i / chunks;
         const int k = (int)(r % kk);
-        const int opix = (int)(r / kk);
-        const int oy = opix / Wo, ox = opix - oy * Wo;
+        const int opix = (int)(r / kk);              // global output pixel over the B images
+        const int img = opix / HoWo, lp = opix - img * HoWo;
+        const int oy = lp / Wo, ox = lp - oy * Wo;
         const int ky = k / KW, kx = k - ky * KW;
         const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
         uint4 v = uint4{0, 0, 0, 0};
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(x + ((long long)iy * W + ix) * C + c * 8);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const uint4*>(x + ((long long)img * H * W + (long long)iy * W + ix) * C + c * 8);
         *reinterpret_cast<uint4*>(col + (long long)opix * ldc + k * C + c * 8) = v;
     }
 }
 
 // xw[(wy*nWx + wx)*ws*ws + iy*ws + ix, c] = x[wy*ws+iy, wx*ws+ix, c]  (0 when outside HxW)
 __global__ __launch_bounds__(256) void window_partition_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ xw, int H, int W,
-                                                               int C, int ws, int nWy, int nWx) {
+                                                               int C, int ws, int nWy, int nWx, int B) {
     const int chunks = C >> 3;
-    const long long total = (long long)nWy * nWx * ws * ws * chunks;
+    const int nW = nWy * nWx;
+    const long long total = (long long)B * nW * ws * ws * chunks;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % chunks);
         const int row = (int)(i / chunks);
-        const int win = row / (ws * ws), in = row - win * ws * ws;
+        const int gwin = row / (ws * ws), in = row - gwin * ws * ws;
+        const int img = gwin / nW, win = gwin - img * nW;
         const int wy = win / nWx, wx = win - wy * nWx;
         const int iy = in / ws, ix = in - iy * ws;
         const int h = wy * ws + iy, w = wx * ws + ix;
         uint4 v = uint4{0, 0, 0, 0};
-        if (h < H && w < W) v = *reinterpret_cast<const uint4*>(x + ((long long)h * W + w) * C + c * 8);
+        if (h < H && w < W) v = *reinterpret_cast<const uint4*>(x + ((long long)img * H * W + (long long)h * W + w) * C + c * 8);
         *reinterpret_cast<uint4*>(xw + (long long)row * C + c * 8) = v;
     }
 }
 
 // y[h,w,c] = shortcut[h,w,c] + yw[window row of (h,w), c]
 __global__ __launch_bounds__(256) void window_reverse_add_kernel(const uint16_t* __restrict__ yw, const uint16_t* __restrict__ shortcut,
-                                                                 uint16_t* __restrict__ y, int H, int W, int C, int ws, int nWx) {
+                                                                 uint16_t* __restrict__ y, int H, int W, int C, int ws, int nWx, int nW,
+                                                                 int B) {
     const int chunks = C >> 3;
-    const long long total = (long long)H * W * chunks;
+    const int HW = H * W;
+    const long long total = (long long)B * HW * chunks;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % chunks);
         const int pix = (int)(i / chunks);
-        const int h = pix / W, w = pix - h * W;
-        const int row = ((h / ws) * nWx + (w / ws)) * ws * ws + (h % ws) * ws + (w % ws);
+        const int img = pix / HW, lp = pix - img * HW;
+        const int h = lp / W, w = lp - h * W;
+        const int row = (img * nW + (h / ws) * nWx + (w / ws)) * ws * ws + (h % ws) * ws + (w % ws);
         float a[8], b[8];
         un8(*reinterpret_cast<const uint4*>(yw + (long long)row * C + c * 8), a);
         un8(*reinterpret_cast<const uint4*>(shortcut + (long long)pix * C + c * 8), b);
@@ -208,6 +219,8 @@ __global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __rest
     __shared__ float sq[64][33];
     __shared__ float sk[64][33];
     const int g = blockIdx.y, chunk = blockIdx.x, G = gridDim.y;
+    qkv += (long long)blockIdx.z * N * ld;                       // image blockIdx.z of the batch: rows [z*N, (z+1)*N)
+    part += (long long)blockIdx.z * gridDim.x * G * 1024;
     const int tid = threadIdx.x;
     const int ci = tid >> 4, cj = tid & 15;  // thread owns the 2x2 block (2ci..2ci+1, 2cj..2cj+1)
     float a00 = 0.f, a01 = 0.f, a10 = 0.f, a11 = 0.f;
@@ -250,6 +263,8 @@ __global__ __launch_bounds__(1024) void chattn_softmax_kernel(const float* __res
     const int g = blockIdx.x, tid = threadIdx.x;
     const int r = tid >> 5, c = tid & 31;
     const long long stride = (long long)G * 1024;
+    part += (long long)blockIdx.y * n_chunks * G * 1024;         // image blockIdx.y
+    A += (long long)blockIdx.y * G * 1024;
     const float* p = part + ((long long)g * 32 + r) * 32 + c;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     int k = 0;
@@ -277,6 +292,9 @@ __global__ __launch_bounds__(256) void chattn_apply_kernel(const uint16_t* __res
     __shared__ float sA[32][33];
     __shared__ float sv[8][33];
     const int g = blockIdx.y, tid = threadIdx.x;
+    qkv += (long long)blockIdx.z * N * ld;                       // image blockIdx.z
+    out += (long long)blockIdx.z * N * ldo;
+    A += (long long)blockIdx.z * gridDim.y * 1024;
     for (int t = tid; t < 1024; t += 256) sA[t >> 5][t & 31] = A[(long long)g * 1024 + t];
     const int tl = tid >> 5, c = tid & 31;  // 8 tokens per pass, 32 output channels
     for (int n0 = blockIdx.x * 8; n0 < N; n0 += gridDim.x * 8) {
@@ -292,34 +310,38 @@ __global__ __launch_bounds__(256) void chattn_apply_kernel(const uint16_t* __res
 }
 
 // dst[(2y+dy)*2W + 2x+dx, co] = src[y*W + x, (dy*2+dx)*Co + co]
-__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int H, int W, int Co) {
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int H, int W, int Co, int B) {
     const int chunks = Co >> 3;
-    const long long total = (long long)H * W * 4 * chunks;
+    const int HW = H * W;
+    const long long total = (long long)B * HW * 4 * chunks;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % chunks);
         long long r = i / chunks;
         const int q = (int)(r & 3);
         const int pix = (int)(r >> 2);
-        const int y = pix / W, x = pix - y * W;
+        const int img = pix / HW, lp = pix - img * HW;
+        const int y = lp / W, x = lp - y * W;
         const int dy = q >> 1, dx = q & 1;
         const uint4 v = *reinterpret_cast<const uint4*>(src + (long long)pix * 4 * Co + q * Co + c * 8);
-        *reinterpret_cast<uint4*>(dst + ((long long)(2 * y + dy) * (2 * W) + 2 * x + dx) * Co + c * 8) = v;
+        *reinterpret_cast<uint4*>(dst + ((long long)img * 4 * HW + (long long)(2 * y + dy) * (2 * W) + 2 * x + dx) * Co + c * 8) = v;
     }
 }
 
 // y[oy, ox, c] = max over the 2x2 window (floor mode: Ho = H/2, Wo = W/2)
-__global__ __launch_bounds__(256) void maxpool2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int H, int W, int C) {
+__global__ __launch_bounds__(256) void maxpool2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int H, int W, int C, int B) {
     const int Ho = H / 2, Wo = W / 2, chunks = C >> 3;
-    const long long total = (long long)Ho * Wo * chunks;
+    const long long total = (long long)B * Ho * Wo * chunks;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % chunks);
         const int pix = (int)(i / chunks);
-        const int oy = pix / Wo, ox = pix - oy * Wo;
+        const int img = pix / (Ho * Wo), lp = pix - img * (Ho * Wo);
+        const int oy = lp / Wo, ox = lp - oy * Wo;
+        const long long ib = (long long)img * H * W;
         float m[8], t[8];
-        un8(*reinterpret_cast<const uint4*>(x + ((long long)(2 * oy) * W + 2 * ox) * C + c * 8), m);
+        un8(*reinterpret_cast<const uint4*>(x + (ib + (long long)(2 * oy) * W + 2 * ox) * C + c * 8), m);
 #pragma unroll
         for (int q = 1; q < 4; ++q) {
-            un8(*reinterpret_cast<const uint4*>(x + ((long long)(2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C + c * 8), t);
+            un8(*reinterpret_cast<const uint4*>(x + (ib + (long long)(2 * oy + (q >> 1)) * W + 2 * ox + (q & 1)) * C + c * 8), t);
 #pragma unroll
             for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], t[j]);
         }
@@ -329,14 +351,15 @@ __global__ __launch_bounds__(256) void maxpool2_kernel(const uint16_t* __restric
 
 // img: [3, H, W] (bf16 or fp32) -> out [H*W, 8] bf16 (channels 3..7 zero)
 template <typename T>
-__global__ __launch_bounds__(256) void nchw_to_hwc8_kernel(const T* __restrict__ img, uint16_t* __restrict__ out, int H, int W) {
-    const long long total = (long long)H * W;
+__global__ __launch_bounds__(256) void nchw_to_hwc8_kernel(const T* __restrict__ img, uint16_t* __restrict__ out, int H, int W, int B) {
+    const long long HW = (long long)H * W, total = HW * B;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         float f[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const long long b = i / HW, lp = i - b * HW;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            if constexpr (sizeof(T) == 2) f[c] = bf16_to_f32(((const uint16_t*)img)[c * total + i]);
-            else f[c] = ((const float*)img)[c * total + i];
+            if constexpr (sizeof(T) == 2) f[c] = bf16_to_f32(((const uint16_t*)img)[(b * 3 + c) * HW + lp]);
+            else f[c] = ((const float*)img)[(b * 3 + c) * HW + lp];
         }
         *reinterpret_cast<uint4*>(out + i * 8) = pk8(f);
     }
@@ -366,108 +389,110 @@ static inline int grid_for(long long total) {
 
 extern "C" {
 
-int fo1_dwconv3x3_bf16(const void* x, const void* weight9c, const void* bias, void* y, int H, int W, int C, void* stream) {
+int fo1_dwconv3x3_bf16(const void* x, const void* weight9c, const void* bias, void* y, int H, int W, int C, int batch, void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(x && weight9c && bias && y && x != y, "dwconv: NULL operand or in-place call");
-    FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0, "dwconv: bad shape %dx%dx%d", H, W, C);
-    FO1_LAUNCH("dwconv3x3", (double)H * W * C * 4.0, dwconv3x3_kernel, dim3(grid_for((long long)H * W * (C / 8))), dim3(256), 0,
-               (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, H, W, C);
+    FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0 && batch >= 1, "dwconv: bad shape %dx%dx%d x%d", H, W, C, batch);
+    FO1_LAUNCH("dwconv3x3", (double)batch * H * W * C * 4.0, dwconv3x3_kernel, dim3(grid_for((long long)batch * H * W * (C / 8))), dim3(256), 0,
+               (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, H, W, C, batch);
     return FO1_OK;
 }
 
 int fo1_dwconv3x3_ln_bf16(const void* x, const void* weight9c, const void* bias, void* y, const void* ln_weight, const void* ln_bias,
-                          float ln_eps, void* h, int H, int W, int C, void* stream) {
+                          float ln_eps, void* h, int H, int W, int C, int batch, void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(x && weight9c && bias && y && ln_weight && ln_bias && h && x != y && x != h && y != h,
                   "dwconv_ln: NULL operand or aliased buffers");
-    FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 64 * kDwLnChunks * 8, "dwconv_ln: bad shape %dx%dx%d (C <= 2048)", H, W, C);
-    FO1_LAUNCH("dwconv3x3_ln", (double)H * W * C * 6.0, dwconv3x3_ln_kernel, dim3(cdiv(H * W, 4)), dim3(256), 0, (hipStream_t)stream,
+    FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 64 * kDwLnChunks * 8 && batch >= 1, "dwconv_ln: bad shape %dx%dx%d (C <= 2048)", H, W, C);
+    FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel, dim3(cdiv(batch * H * W, 4)), dim3(256), 0, (hipStream_t)stream,
                (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
-               (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps);
+               (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch);
     return FO1_OK;
 }
 
-int fo1_im2col_bf16(const void* x, void* col, int H, int W, int C, int KH, int KW, int stride, int pad, int ld_col, void* stream) {
+int fo1_im2col_bf16(const void* x, void* col, int H, int W, int C, int KH, int KW, int stride, int pad, int ld_col, int batch, void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(x && col, "im2col: NULL operand");
     FO1_CHECK_ARG(C > 0 && C % 8 == 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "im2col: bad parameters");
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
-    FO1_CHECK_ARG(Ho > 0 && Wo > 0 && ld_col >= KH * KW * C && ld_col % 8 == 0, "im2col: bad output shape");
-    FO1_LAUNCH("im2col", (double)Ho * Wo * KH * KW * C * 4.0, im2col_kernel, dim3(grid_for((long long)Ho * Wo * KH * KW * (C / 8))),
-               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)col, H, W, C, KH, KW, stride, pad, Ho, Wo, ld_col);
+    FO1_CHECK_ARG(Ho > 0 && Wo > 0 && ld_col >= KH * KW * C && ld_col % 8 == 0 && batch >= 1, "im2col: bad output shape");
+    FO1_LAUNCH("im2col", (double)batch * Ho * Wo * KH * KW * C * 4.0, im2col_kernel, dim3(grid_for((long long)batch * Ho * Wo * KH * KW * (C / 8))),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)col, H, W, C, KH, KW, stride, pad, Ho, Wo, ld_col, batch);
     return FO1_OK;
 }
 
-int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, void* stream) {
+int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, int batch, void* stream) {
     using namespace fo1;
-    FO1_CHECK_ARG(x && xw && C % 8 == 0 && ws > 0, "window_partition: bad arguments");
+    FO1_CHECK_ARG(x && xw && C % 8 == 0 && ws > 0 && batch >= 1, "window_partition: bad arguments");
     const int nWy = cdiv(H, ws), nWx = cdiv(W, ws);
-    FO1_LAUNCH("window_partition", (double)nWy * nWx * ws * ws * C * 4.0, window_partition_kernel,
-               dim3(grid_for((long long)nWy * nWx * ws * ws * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
-               (uint16_t*)xw, H, W, C, ws, nWy, nWx);
+    FO1_LAUNCH("window_partition", (double)batch * nWy * nWx * ws * ws * C * 4.0, window_partition_kernel,
+               dim3(grid_for((long long)batch * nWy * nWx * ws * ws * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+               (uint16_t*)xw, H, W, C, ws, nWy, nWx, batch);
     return FO1_OK;
 }
 
-int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, int H, int W, int C, int ws, void* stream) {
+int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, int H, int W, int C, int ws, int batch, void* stream) {
     using namespace fo1;
-    FO1_CHECK_ARG(yw && shortcut && y && C % 8 == 0 && ws > 0, "window_reverse: bad arguments");
-    FO1_LAUNCH("window_reverse_add", (double)H * W * C * 6.0, window_reverse_add_kernel, dim3(grid_for((long long)H * W * (C / 8))),
-               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)yw, (const uint16_t*)shortcut, (uint16_t*)y, H, W, C, ws, cdiv(W, ws));
+    FO1_CHECK_ARG(yw && shortcut && y && C % 8 == 0 && ws > 0 && batch >= 1, "window_reverse: bad arguments");
+    FO1_LAUNCH("window_reverse_add", (double)batch * H * W * C * 6.0, window_reverse_add_kernel, dim3(grid_for((long long)batch * H * W * (C / 8))),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)yw, (const uint16_t*)shortcut, (uint16_t*)y, H, W, C, ws, cdiv(W, ws),
+               cdiv(H, ws) * cdiv(W, ws), batch);
     return FO1_OK;
 }
 
-size_t fo1_channel_attention_workspace_bytes(int N, int C) {
+size_t fo1_channel_attention_workspace_bytes(int N, int C, int batch) {
     const int G = C / 32, chunks = fo1::cdiv(N, fo1::kCaTok);
-    return ((size_t)chunks * G * 1024 + (size_t)G * 1024) * sizeof(float);
+    return (size_t)batch * ((size_t)chunks * G * 1024 + (size_t)G * 1024) * sizeof(float);
 }
 
-int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, void* workspace, size_t workspace_bytes,
+// qkv rows [batch * N, 3C]: every image's N tokens form their own 32 x 32 per-group attention matrices
+int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, int batch, void* workspace, size_t workspace_bytes,
                                void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(qkv && out && workspace, "channel_attention: NULL operand");
-    FO1_CHECK_ARG(N > 0 && C > 0 && C % 32 == 0 && ld >= 3 * C && ld % 8 == 0 && ldo >= C, "channel_attention: bad shape N=%d C=%d", N, C);
-    if (workspace_bytes < fo1_channel_attention_workspace_bytes(N, C))
+    FO1_CHECK_ARG(N > 0 && C > 0 && C % 32 == 0 && ld >= 3 * C && ld % 8 == 0 && ldo >= C && batch >= 1, "channel_attention: bad shape N=%d C=%d", N, C);
+    if (workspace_bytes < fo1_channel_attention_workspace_bytes(N, C, batch))
         return set_err(FO1_ERR_WORKSPACE, "channel_attention: workspace too small");
     const int G = C / 32, chunks = cdiv(N, kCaTok);
     float* part = (float*)workspace;
-    float* A = part + (size_t)chunks * G * 1024;
+    float* A = part + (size_t)batch * chunks * G * 1024;
     hipStream_t st = (hipStream_t)stream;
-    FO1_LAUNCH("chattn_gram", (double)N * C * 4.0, chattn_gram_kernel, dim3(chunks, G), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part);
+    FO1_LAUNCH("chattn_gram", (double)batch * N * C * 4.0, chattn_gram_kernel, dim3(chunks, G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part);
     // reference: q * N^-0.5 (modeling_davit.py:165)
-    FO1_LAUNCH("chattn_softmax", (double)chunks * G * 4096.0, chattn_softmax_kernel, dim3(G), dim3(1024), 0, st, (const float*)part, chunks, G,
+    FO1_LAUNCH("chattn_softmax", (double)batch * chunks * G * 4096.0, chattn_softmax_kernel, dim3(G, batch), dim3(1024), 0, st, (const float*)part, chunks, G,
                1.0f / sqrtf((float)N), A);
     int gx = cdiv(N, 8);
     if (gx > 512) gx = 512;
-    FO1_LAUNCH("chattn_apply", (double)N * C * 4.0, chattn_apply_kernel, dim3(gx, G), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C,
+    FO1_LAUNCH("chattn_apply", (double)batch * N * C * 4.0, chattn_apply_kernel, dim3(gx, G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C,
                (const float*)A, (uint16_t*)out, ldo);
     return FO1_OK;
 }
 
-int fo1_pixel_shuffle2_bf16(const void* src, void* dst, int H, int W, int Co, void* stream) {
+int fo1_pixel_shuffle2_bf16(const void* src, void* dst, int H, int W, int Co, int batch, void* stream) {
     using namespace fo1;
-    FO1_CHECK_ARG(src && dst && Co > 0 && Co % 8 == 0, "pixel_shuffle: bad arguments");
-    FO1_LAUNCH("pixel_shuffle2", (double)H * W * 4 * Co * 4.0, pixel_shuffle2_kernel, dim3(grid_for((long long)H * W * 4 * (Co / 8))),
-               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst, H, W, Co);
+    FO1_CHECK_ARG(src && dst && Co > 0 && Co % 8 == 0 && batch >= 1, "pixel_shuffle: bad arguments");
+    FO1_LAUNCH("pixel_shuffle2", (double)batch * H * W * 4 * Co * 4.0, pixel_shuffle2_kernel, dim3(grid_for((long long)batch * H * W * 4 * (Co / 8))),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst, H, W, Co, batch);
     return FO1_OK;
 }
 
-int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, void* stream) {
+int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, int batch, void* stream) {
     using namespace fo1;
-    FO1_CHECK_ARG(x && y && C % 8 == 0 && H >= 2 && W >= 2, "maxpool: bad arguments");
-    FO1_LAUNCH("maxpool2", (double)H * W * C * 2.5, maxpool2_kernel, dim3(grid_for((long long)(H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
-               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, H, W, C);
+    FO1_CHECK_ARG(x && y && C % 8 == 0 && H >= 2 && W >= 2 && batch >= 1, "maxpool: bad arguments");
+    FO1_LAUNCH("maxpool2", (double)batch * H * W * C * 2.5, maxpool2_kernel, dim3(grid_for((long long)batch * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
+               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, H, W, C, batch);
     return FO1_OK;
 }
 
-int fo1_nchw_to_hwc8_bf16(const void* img, int is_f32, void* out, int H, int W, void* stream) {
+int fo1_nchw_to_hwc8_bf16(const void* img, int is_f32, void* out, int H, int W, int batch, void* stream) {
     using namespace fo1;
-    FO1_CHECK_ARG(img && out && H > 0 && W > 0, "nchw_to_hwc8: bad arguments");
+    FO1_CHECK_ARG(img && out && H > 0 && W > 0 && batch >= 1, "nchw_to_hwc8: bad arguments");
     if (is_f32)
-        FO1_LAUNCH("nchw_to_hwc8", (double)H * W * 28.0, nchw_to_hwc8_kernel<float>, dim3(grid_for((long long)H * W)), dim3(256), 0,
-                   (hipStream_t)stream, (const float*)img, (uint16_t*)out, H, W);
+        FO1_LAUNCH("nchw_to_hwc8", (double)batch * H * W * 28.0, nchw_to_hwc8_kernel<float>, dim3(grid_for((long long)batch * H * W)), dim3(256), 0,
+                   (hipStream_t)stream, (const float*)img, (uint16_t*)out, H, W, batch);
     else
-        FO1_LAUNCH("nchw_to_hwc8", (double)H * W * 22.0, nchw_to_hwc8_kernel<uint16_t>, dim3(grid_for((long long)H * W)), dim3(256), 0,
-                   (hipStream_t)stream, (const uint16_t*)img, (uint16_t*)out, H, W);
+        FO1_LAUNCH("nchw_to_hwc8", (double)batch * H * W * 22.0, nchw_to_hwc8_kernel<uint16_t>, dim3(grid_for((long long)batch * H * W)), dim3(256), 0,
+                   (hipStream_t)stream, (const uint16_t*)img, (uint16_t*)out, H, W, batch);
     return FO1_OK;
 }
 

@@ -79,16 +79,16 @@ class DaViT:
             self._items[key] = ops.make_items(segs, self.dev, block=ops.pick_q_block(segs, heads))
         return self._items[key]
 
-    def _conv_ffn(self, x, H, W, d):
+    def _conv_ffn(self, x, H, W, d, B=1):
         """conv2 (depthwise 3x3 + residual) -> LayerNorm -> MLP(+residual); the conv and the norm are one launch."""
-        x, h = ops.dwconv3x3_res_ln(x, d["conv2_w"], d["conv2_b"], H, W, d["fn_w"], d["fn_b"], 1e-5)
+        x, h = ops.dwconv3x3_res_ln(x, d["conv2_w"], d["conv2_b"], H, W, d["fn_w"], d["fn_b"], 1e-5, batch=B)
         h = ops.gemm(h, d["fc1_w"], d["fc1_b"], act=ops.ACT_GELU)
         return ops.gemm(h, d["fc2_w"], d["fc2_b"], residual=x)
 
-    def _spatial(self, x, H, W, C, heads, d):
+    def _spatial(self, x, H, W, C, heads, d, B=1):
         ws = self.cfg["window"]
-        x, h = ops.dwconv3x3_res_ln(x, d["conv1_w"], d["conv1_b"], H, W, d["an_w"], d["an_b"], 1e-5)
-        hw = ops.window_partition(h, H, W, ws)          # zero-padded AFTER the norm, like the reference (:248-251)
+        x, h = ops.dwconv3x3_res_ln(x, d["conv1_w"], d["conv1_b"], H, W, d["an_w"], d["an_b"], 1e-5, batch=B)
+        hw = ops.window_partition(h, H, W, ws, batch=B)   # zero-padded AFTER the norm, like the reference (:248-251)
         qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
         n = hw.shape[0]
         # V^T scratch [C, n padded to 64] from the owner-scoped pool (zero-initialised; the pad columns are never written):
@@ -101,23 +101,24 @@ class DaViT:
         att = ops.attention(qkv[:, :C], qkv[:, C:2 * C], vt, items, heads, heads, hd, float(hd) ** -0.5, False,
                             flops=4.0 * C * n * ws * ws)
         y = ops.gemm(att, d["proj_w"], d["proj_b"])
-        x = ops.window_reverse_add(y, x, H, W, ws)
-        return self._conv_ffn(x, H, W, d)
+        x = ops.window_reverse_add(y, x, H, W, ws, batch=B)
+        return self._conv_ffn(x, H, W, d, B)
 
-    def _channel(self, x, H, W, C, d):
-        x, h = ops.dwconv3x3_res_ln(x, d["conv1_w"], d["conv1_b"], H, W, d["an_w"], d["an_b"], 1e-5)
+    def _channel(self, x, H, W, C, d, B=1):
+        x, h = ops.dwconv3x3_res_ln(x, d["conv1_w"], d["conv1_b"], H, W, d["an_w"], d["an_b"], 1e-5, batch=B)
         qkv = ops.gemm(h, d["qkv_w"], d["qkv_b"])
-        a = ops.channel_attention(qkv, C)
+        a = ops.channel_attention(qkv, C, batch=B)
         x = ops.gemm(a, d["proj_w"], d["proj_b"], residual=x)
-        return self._conv_ffn(x, H, W, d)
+        return self._conv_ffn(x, H, W, d, B)
 
     def forward(self, img: torch.Tensor):
-        """img [3,H,W] or [1,3,H,W] (device, bf16/fp32, CLIP-normalised).  Returns
-        ([4 token-major maps [H_i*W_i, C_i] bf16], [(H_i, W_i)])."""
+        """img [3,H,W] or [B,3,H,W] (device, bf16/fp32, CLIP-normalised; B same-size images in one pass).  Returns
+        ([4 token-major maps [B*H_i*W_i, C_i] bf16 — image b at rows [b*H_i*W_i, (b+1)*H_i*W_i)], [(H_i, W_i)])."""
         cfg = self.cfg
-        if img.dim() == 4:
-            img = img[0]
-        H, W = img.shape[1:]
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        B = img.shape[0]
+        H, W = img.shape[2:]
         x = ops.nchw_to_hwc8(img.contiguous())
         outs, sizes = [], []
         for i, C in enumerate(cfg["dims"]):
@@ -125,13 +126,13 @@ class DaViT:
             k, s, p = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
             if i > 0 and cfg["patch_prenorm"][i]:
                 x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
-            col, H, W = ops.im2col(x, H, W, k, k, s, p, ld=cv["Kp"])
+            col, H, W = ops.im2col(x, H, W, k, k, s, p, ld=cv["Kp"], batch=B)
             x = ops.gemm(col, cv["w"], cv["b"])
             if i == 0 or not cfg["patch_prenorm"][i]:
                 x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
             for blk in self.blocks[i]:
-                x = self._spatial(x, H, W, C, cfg["heads"][i], blk["spatial_block"])
-                x = self._channel(x, H, W, C, blk["channel_block"])
+                x = self._spatial(x, H, W, C, cfg["heads"][i], blk["spatial_block"], B)
+                x = self._channel(x, H, W, C, blk["channel_block"], B)
             outs.append(x)
             sizes.append((H, W))
         return outs, sizes

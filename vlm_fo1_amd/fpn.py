@@ -45,28 +45,30 @@ class SimpleFPN:
                 w1=conv1(s[f"{name}.{a}weight"]), n1=(dv(s[f"{name}.{a}norm.weight"]), dv(s[f"{name}.{a}norm.bias"])),
                 w3=conv3(s[f"{name}.{b}weight"]), n3=(dv(s[f"{name}.{b}norm.weight"]), dv(s[f"{name}.{b}norm.bias"]))))
 
-    def _up(self, x, H, W, t):
+    def _up(self, x, H, W, t, B=1):
         w, b, cout = t
-        return ops.pixel_shuffle2(ops.gemm(x, w, b), H, W, cout), 2 * H, 2 * W
+        return ops.pixel_shuffle2(ops.gemm(x, w, b), H, W, cout, batch=B), 2 * H, 2 * W
 
-    def _head(self, x, H, W, h):
+    def _head(self, x, H, W, h, B=1):
         y = ops.gemm(x, h["w1"])
         y = ops.layernorm(y, h["n1"][0], h["n1"][1], 1e-6)
-        col, _, _ = ops.im2col(y, H, W, 3, 3, 1, 1)
+        col, _, _ = ops.im2col(y, H, W, 3, 3, 1, 1, batch=B)
         y = ops.gemm(col, h["w3"])
         return ops.layernorm(y, h["n3"][0], h["n3"][1], 1e-6)
 
-    def forward(self, x: torch.Tensor, H: int, W: int) -> Tuple[List[torch.Tensor], List[Tuple[int, int]]]:
-        """x [H*W, 1280] token-major bf16 -> 4 token-major maps [.., 512] at (4H,4W), (2H,2W), (H,W), (H/2,W/2)."""
+    def forward(self, x: torch.Tensor, H: int, W: int, batch: int = 1) -> Tuple[List[torch.Tensor], List[Tuple[int, int]]]:
+        """x [batch*H*W, 1280] token-major bf16 (same-size maps stacked) -> 4 token-major maps [batch*.., 512] at (4H,4W),
+        (2H,2W), (H,W), (H/2,W/2); image b owns rows [b*h*w, (b+1)*h*w) of every level."""
+        B = batch
         outs, sizes = [], []
-        y, h1, w1 = self._up(x, H, W, self.t1a)
+        y, h1, w1 = self._up(x, H, W, self.t1a, B)
         y = ops.layernorm(y, self.t1_ln[0], self.t1_ln[1], 1e-6)
         y = ops.bias_act(y, None, 1)
-        y, h1, w1 = self._up(y, h1, w1, self.t1b)
-        outs.append(self._head(y, h1, w1, self.heads[0])); sizes.append((h1, w1))
-        y, h2, w2 = self._up(x, H, W, self.t2)
-        outs.append(self._head(y, h2, w2, self.heads[1])); sizes.append((h2, w2))
-        outs.append(self._head(x, H, W, self.heads[2])); sizes.append((H, W))
-        y = ops.maxpool2(x, H, W)
-        outs.append(self._head(y, H // 2, W // 2, self.heads[3])); sizes.append((H // 2, W // 2))
+        y, h1, w1 = self._up(y, h1, w1, self.t1b, B)
+        outs.append(self._head(y, h1, w1, self.heads[0], B)); sizes.append((h1, w1))
+        y, h2, w2 = self._up(x, H, W, self.t2, B)
+        outs.append(self._head(y, h2, w2, self.heads[1], B)); sizes.append((h2, w2))
+        outs.append(self._head(x, H, W, self.heads[2], B)); sizes.append((H, W))
+        y = ops.maxpool2(x, H, W, batch=B)
+        outs.append(self._head(y, H // 2, W // 2, self.heads[3], B)); sizes.append((H // 2, W // 2))
         return outs, sizes

@@ -80,9 +80,10 @@ class HFREModule:
 
     def __call__(self, aux_multi_level_features: List[torch.Tensor], aux_boxes: Union[torch.Tensor, List[torch.Tensor]],
                  vt_multi_level_features=None, vt_boxes: Union[torch.Tensor, List[torch.Tensor], None] = None,
-                 vt_scale=None) -> torch.Tensor:
+                 vt_scale=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns fp32 [1, N, region_feature_dim] like the reference (:469).  `vt_boxes`
-        may be omitted when `vt_scale=(sx, sy)` is given (vt = aux * scale in-kernel)."""
+        may be omitted when `vt_scale=(sx, sy)` is given (vt = aux * scale in-kernel).  `out`: optional fp32 [N, C_region]
+        row-contiguous destination (the batched engine hands out row slices of one buffer)."""
         L = _lib.load()
         boxes = aux_boxes[0] if isinstance(aux_boxes, (list, tuple)) else aux_boxes
         dev = aux_multi_level_features[0].device
@@ -124,7 +125,12 @@ class HFREModule:
         # scratch from the owner-scoped pool (vlm_fo1_amd/ops.py): never resized in place — a captured graph may hold the pointer
         from . import ops as _ops
         self._ws = _ops._workspace("hfre", dev, max(int(need), 1))
-        out = torch.empty(1, N, off, dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty(1, N, off, dtype=torch.float32, device=dev)
+        else:
+            if out.dtype != torch.float32 or out.shape != (N, off) or out.stride(1) != 1 or out.device != dev:
+                raise ValueError(f"out must be a device fp32 [{N}, {off}] row-major tensor")
+            out = out.unsqueeze(0)
         # reference :446-448 — image size = vt map size / vt spatial scale (python floats)
         pos_w = gw / self.vision_tower_spatial_scale
         pos_h = gh / self.vision_tower_spatial_scale
@@ -132,7 +138,7 @@ class HFREModule:
         rc = L.fo1_hfre_region_pool(arr, len(srcs), boxes.data_ptr(), N,
                                     vtb.data_ptr() if vtb is not None else None, float(sx), float(sy),
                                     self.roi_output_size, 1 if self.apply_position_embedding else 0,
-                                    float(pos_w), float(pos_h), out.data_ptr(), off, off,
+                                    float(pos_w), float(pos_h), out.data_ptr(), out.stride(1), off,
                                     self._ws.data_ptr(), self._ws.numel(), _lib.current_stream_ptr())
         _lib.check(rc, "fo1_hfre_region_pool")
         return out

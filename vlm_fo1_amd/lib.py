@@ -78,17 +78,17 @@ SIGNATURES = {
     "fo1_attention_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,
                                    c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_float, c_int, c_void_p, ctypes.c_double, c_void_p]),
-    "fo1_dwconv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fo1_dwconv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_dwconv3x3_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
-                                      c_void_p]),
-    "fo1_im2col_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "fo1_window_partition_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "fo1_window_reverse_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
-    "fo1_channel_attention_workspace_bytes": (c_size_t, [c_int, c_int]),
-    "fo1_channel_attention_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    "fo1_pixel_shuffle2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "fo1_maxpool2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "fo1_nchw_to_hwc8_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
+                                      c_int, c_void_p]),
+    "fo1_im2col_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_window_partition_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_window_reverse_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_channel_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fo1_channel_attention_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "fo1_pixel_shuffle2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_maxpool2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_nchw_to_hwc8_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fo1_gather_rows_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_void_p]),
 }

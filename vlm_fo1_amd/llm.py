@@ -110,6 +110,8 @@ class QwenLLM:
         c = cfg
         # KV cache: K [layer][kv_head][pos][head_dim]; V^T [layer][kv_head*head_dim][pos] (zeroed: the
         # attention kernel may read up to 3 finite columns past kv_end)
+        self.capacity = c.max_seq
+        self.cache_epoch = 0        # bumped whenever the caches are re-allocated: captured graphs hold the old pointers
         self.kcache = torch.zeros(c.num_layers, c.num_kv_heads, c.max_seq, c.head_dim, dtype=bf, device=self.dev)
         self.vtcache = torch.zeros(c.num_layers, c.num_kv_heads * c.head_dim, c.max_seq, dtype=bf, device=self.dev)
         self.kv_len = 0
@@ -127,6 +129,33 @@ class QwenLLM:
         self._dstate_keep = None
         self._ws_owner = object()   # scratch-buffer key (ops.workspace_scope); FO1Engine overrides it with its own token
 
+    def reserve(self, n_positions: int) -> bool:
+        """Make room for n_positions cache rows (prompt + the tokens a request may generate; a packed batch needs the sum).
+        Grows geometrically and keeps the cached prefix; returns True when the caches moved (graphs that captured the old
+        pointers — this object's decode graph, the engine's prefill graphs — are dropped by the epoch bump).  The reference's
+        HF cache grows without bound (max_position_embeddings 32768+), so a long generation must not fail on a fixed size."""
+        if n_positions <= self.capacity:
+            return False
+        c = self.cfg
+        cap = self.capacity
+        while cap < n_positions:
+            cap *= 2
+        bf = torch.bfloat16
+        k = torch.zeros(c.num_layers, c.num_kv_heads, cap, c.head_dim, dtype=bf, device=self.dev)
+        v = torch.zeros(c.num_layers, c.num_kv_heads * c.head_dim, cap, dtype=bf, device=self.dev)
+        k[:, :, :self.capacity] = self.kcache
+        v[:, :, :self.capacity] = self.vtcache
+        self.kcache, self.vtcache, self.capacity = k, v, cap
+        if self.rope_cos.shape[0] < cap:
+            p = torch.arange(cap).view(1, -1).expand(3, -1)
+            cos_t, sin_t = mrope_tables(p, c.head_dim, c.rope_theta, c.mrope_section)
+            self.rope_cos, self.rope_sin = cos_t.to(self.dev), sin_t.to(self.dev)
+        self._dgraph = None
+        self._item_cache = {}
+        self.cache_epoch += 1
+        torch.cuda.current_stream().synchronize()
+        return True
+
     def replica(self) -> "QwenLLM":
         """Same weights and rope tables (shared, read-only), private per-request state: KV cache, decode state, decode graph.
         For several requests in flight on different streams (FO1Engine.replica)."""
@@ -141,7 +170,10 @@ class QwenLLM:
         r.dplan = torch.zeros_like(self.dplan)
         r._dgraph = None
         r._dstate_keep = None
+        r._item_cache = {}
         r._ws_owner = object()
+        # the zero-fills above ran on the creating thread's current stream; the replica is used from another thread / stream
+        torch.cuda.current_stream().synchronize()
         return r
 
     # ---- splice ------------------------------------------------------------------------------
@@ -189,16 +221,19 @@ class QwenLLM:
         return self.embed_rows(plan.to(self.dev), image_tokens, region_tokens), pos, delta
 
     # ---- transformer -------------------------------------------------------------------------
-    def _forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, collect: Optional[list] = None):
+    def _forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, collect: Optional[list] = None,
+                 items: Optional[torch.Tensor] = None, flops: Optional[float] = None):
         c = self.cfg
         L = x.shape[0]
         H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
         kv_end = pos0 + L
-        if kv_end > c.max_seq:
-            raise ValueError(f"sequence {kv_end} exceeds the KV cache ({c.max_seq})")
-        items = self._items(pos0, kv_end)
+        if kv_end > self.capacity:
+            raise ValueError(f"sequence {kv_end} exceeds the KV cache ({self.capacity}); call reserve() first")
+        if items is None:
+            items = self._items(pos0, kv_end)
         scale = 1.0 / math.sqrt(HD)
-        flops = 4.0 * H * HD * (L * (pos0 + (L + 1) / 2.0))
+        if flops is None:
+            flops = 4.0 * H * HD * (L * (pos0 + (L + 1) / 2.0))
         for li, w in enumerate(self.layers):
             h = ops.rmsnorm(x, w["ln1"], c.rms_norm_eps)
             qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
@@ -217,8 +252,7 @@ class QwenLLM:
         key = (pos0, kv_end)
         it = self._item_cache.get(key)
         if it is None:
-            if len(self._item_cache) > 4096:
-                self._item_cache.clear()
+            # never evict: a captured prefill graph may hold this tensor's pointer (entries are a few hundred bytes each)
             blk = ops.pick_q_block([(pos0, kv_end)], self.cfg.num_heads)
             it = torch.tensor([[q0, min(q0 + blk, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, blk)], dtype=torch.int32).to(self.dev)
             it.q_block = blk
@@ -241,10 +275,72 @@ class QwenLLM:
             self.rope_delta = rope_delta
             return self._head(x)
 
+    # ---- several prompts packed into one pass (the reference's batch-aware splice, omchat_qwen2_5_vl.py:380-416) ----
+    PACK_ALIGN = 4   # the attention kernel reads V^T in 8-byte (4-key) pieces: every sequence starts at a multiple of 4
+
+    def plan_batch(self, prompts: Sequence[Sequence[int]], n_img: Sequence[int], n_regions: Sequence[int],
+                   grids_merged: Sequence[Tuple[int, int]]):
+        """HOST: B prompts -> one packed plan.  Sequence b owns rows [off_b, off_b + Lp_b), Lp_b = L_b rounded up to PACK_ALIGN
+        with dummy rows (token 0) appended AFTER its real rows: causal attention keeps them invisible to every real row.  Image /
+        region indices address the batch-concatenated token tables.  Returns dict(plan int32 [R,2], cos, sin bf16 [R, hd] (host),
+        seqs [(off, L, Lp)], pos [per-sequence [3, L]], delta [per sequence], last int32 [B,2] gather plan of the last real rows)."""
+        c = self.cfg
+        plans, coss, sins, seqs, poss, deltas = [], [], [], [], [], []
+        off = img0 = reg0 = 0
+        for ids, ni, nr, gm in zip(prompts, n_img, n_regions, grids_merged):
+            pl, pos, delta = self.plan_inputs(ids, ni, nr, gm)
+            L = pl.shape[0]
+            Lp = (L + self.PACK_ALIGN - 1) // self.PACK_ALIGN * self.PACK_ALIGN
+            pl = pl.clone()
+            pl[:, 1] += (pl[:, 0] == 1).to(torch.int32) * img0 + (pl[:, 0] == 2).to(torch.int32) * reg0
+            if Lp > L:
+                pl = torch.cat([pl, torch.zeros(Lp - L, 2, dtype=torch.int32)], 0)
+                tail = int(pos.max()) + 1 + torch.arange(Lp - L).view(1, -1).expand(3, -1)
+                pos_p = torch.cat([pos, tail], 1)
+            else:
+                pos_p = pos
+            cs, sn = mrope_tables(pos_p, c.head_dim, c.rope_theta, c.mrope_section)
+            plans.append(pl); coss.append(cs); sins.append(sn)
+            seqs.append((off, L, Lp)); poss.append(pos); deltas.append(delta)
+            off += Lp; img0 += ni; reg0 += nr
+        last = torch.tensor([[0, o + L - 1] for o, L, _ in seqs], dtype=torch.int32).reshape(-1, 2)
+        return dict(plan=torch.cat(plans, 0).contiguous(), cos=torch.cat(coss, 0).contiguous(), sin=torch.cat(sins, 0).contiguous(),
+                    seqs=seqs, pos=poss, delta=deltas, last=last, rows=off)
+
+    def packed_items(self, seqs) -> Tuple[torch.Tensor, float]:
+        key = ("packed", tuple(seqs))
+        hit = self._item_cache.get(key)
+        if hit is None:
+            blk = ops.pick_q_block([(o, o + Lp) for o, _, Lp in seqs], self.cfg.num_heads)
+            rows = [[q0, min(q0 + blk, o + Lp), o, o + Lp] for o, _, Lp in seqs for q0 in range(o, o + Lp, blk)]
+            it = torch.tensor(rows, dtype=torch.int32).to(self.dev)
+            it.q_block = blk
+            fl = 4.0 * self.cfg.num_heads * self.cfg.head_dim * sum(Lp * (Lp + 1) / 2.0 for _, _, Lp in seqs)
+            hit = (it, fl)
+            self._item_cache[key] = hit
+        return hit
+
+    def prefill_packed(self, embeds: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, seqs, last_plan: torch.Tensor,
+                       collect: Optional[list] = None):
+        """DEVICE: embeds [R, d] (packed rows of plan_batch), cos/sin [R, hd] device tables, last_plan int32 [B,2] (device).
+        K / V^T land at cache positions = packed row indices.  Returns (final-norm last hidden [B, d], logits [B, V], next ids
+        int32 [B])."""
+        c = self.cfg
+        items, flops = self.packed_items(seqs)
+        with ops.workspace_scope(self._ws_owner):
+            x = self._forward(embeds, cos, sin, 0, collect, items=items, flops=flops)
+            last = ops.rmsnorm(ops.gather_rows(last_plan, c.hidden_size, x), self.norm, c.rms_norm_eps)
+            logits = ops.gemm(last, self.lm_head)
+            toks = torch.empty(last.shape[0], dtype=torch.int32, device=self.dev)
+            for b in range(last.shape[0]):
+                ops.argmax(logits[b], out=toks[b:b + 1])
+            return last, logits, toks
+
     def _check_room(self):
-        """The device-side decode state indexes the caches blindly: refuse on the host before a step would run past them."""
-        if self.kv_len + 1 > self.cfg.max_seq:
-            raise ValueError(f"sequence {self.kv_len + 1} exceeds the KV cache ({self.cfg.max_seq})")
+        """The device-side decode state indexes the caches blindly: grow them on the host before a step would run past them."""
+        if self.kv_len + 1 > self.capacity:
+            self.reserve(self.kv_len + 1)
+            self.sync_decode_state()
 
     def sync_decode_state(self):
         """Publish (kv_len, rope row, first decode work item) to the device-side decode state."""
@@ -278,7 +374,7 @@ class QwenLLM:
             qkv = ops.gemv(x, w["wqkv"], w["bqkv"], norm_weight=w["ln1"], norm_eps=c.rms_norm_eps)
             ops.decode_qkv_post(qkv, H, KV, HD, self.rope_cos, self.rope_sin, self.dstate, self.kcache[li], self.vtcache[li])
             # split-KV decode attention: chunk count follows the device-side kv length (= dstate[7] = position + 1)
-            att = ops.attention_decode(qkv[:, :H * HD], self.kcache[li], self.vtcache[li], self.dstate[7:8], c.max_seq, H, KV, HD, scale)
+            att = ops.attention_decode(qkv[:, :H * HD], self.kcache[li], self.vtcache[li], self.dstate[7:8], self.capacity, H, KV, HD, scale)
             x = ops.gemv(att, w["wo"], residual=x)
             a = ops.gemv(x, w["wgu"], act=ops.ACT_SWIGLU16, norm_weight=w["ln2"], norm_eps=c.rms_norm_eps)
             x = ops.gemv(a, w["wdown"], residual=x)

@@ -85,7 +85,9 @@ class FO1Engine:
                                vision_tower_spatial_scale=1 / cfg.vit.patch_size,
                                use_simpleFPN_for_vt=cfg.mm_use_simpleFPN_for_vt, aux_vision_tower_spatial_scale=0.25)
         self._dummy_box = torch.tensor([[0., 10., 0., 10.]], device=self.dev)  # omchat_qwen2_5_vl.py:90-91
-        self._graphs = {}
+        import collections
+        self._graphs = collections.OrderedDict()   # signature -> captured prefill graph (LRU, GRAPH_CACHE entries)
+        self._seen = {}                            # signature -> sightings before capture
         # Two-stream tower overlap (DaViT || ViT+FPN) is OFF: measured on MI355X / ROCm 7.2 a forked hipGraph replays at
         # 39.7 ms vs 21.9 ms single-stream (cross-stream joins serialise the node launches), see profiles/README.md.
         self._ws_owner = self.llm._ws_owner = object()   # scratch buffers are keyed by this token (ops.workspace_scope)
@@ -101,7 +103,9 @@ class FO1Engine:
         r.llm = self.llm.replica()
         r.hfre = copy.copy(self.hfre)
         r._ws_owner = r.llm._ws_owner = object()   # scratch buffers are keyed by this token (ops.workspace_scope)
-        r._graphs = {}
+        import collections
+        r._graphs = collections.OrderedDict()
+        r._seen = {}
         r.stage_hook = None
         return r
 
@@ -148,100 +152,203 @@ class FO1Engine:
         self._mark("mm_projector_aux")
         return out
 
-    # ---- one image: everything up to the first generated token -----------------------------------
-    def _device_prefill(self, pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions: bool):
+    # ---- a batch of images: everything up to the first generated token of each ---------------------------------
+    def _regions_batch(self, auxs, aux_stack, boxes, want, vt_last, bp, grids):
+        """encode_regions (:75-108) for every request that has regions -> (region tokens [sum N, d_llm] or None, per-request
+        row ranges).  DaViT / SimpleFPN run ONCE over all images when they share the aux size and the patch grid (rows stacked
+        image by image); otherwise image by image.  The HFRE gather runs per image on views of the stacked maps and writes
+        straight into its rows of one [sum N, C_region] fp32 buffer."""
+        idx = [i for i, w in enumerate(want) if w]
+        if not idx:
+            return None, [(0, 0)] * len(want)
+        p = self.cfg.vit.patch_size
+        n_box = [boxes[i].shape[0] for i in idx]
+        feat = torch.empty(sum(n_box), self.cfg.mm_region_hidden_size, dtype=torch.float32, device=self.dev)
+        uniform = aux_stack is not None and len(idx) == len(want) and len(set(grids)) == 1
+
+        def nchw(t, hw, b=0):  # rows [b*h*w, (b+1)*h*w) of a stacked token-major map -> the NCHW *view* the reference hands to HFRE
+            n = hw[0] * hw[1]
+            return t[b * n:(b + 1) * n].view(1, hw[0], hw[1], t.shape[1]).permute(0, 3, 1, 2)
+
+        groups = [idx] if uniform else [[i] for i in idx]
+        row, ranges = 0, {}
+        for grp in groups:
+            G = len(grp)
+            aux = aux_stack if uniform else auxs[grp[0]].unsqueeze(0)
+            aux_maps, aux_sizes = self.davit.forward(aux)
+            self._mark("davit_large")
+            gh, gw = grids[grp[0]]
+            H, W = auxs[grp[0]].shape[-2:]
+            sh, sw = (gh * p) / H, (gw * p) / W       # reference :94-99 — python-float scales, one fp32 multiply per coordinate
+            if self.fpn is not None:
+                if G == 1:
+                    r0 = bp.row0[grp[0]]
+                    vt = vt_last[r0:r0 + gh * gw]
+                else:
+                    vt = vt_last                      # uniform batch of all requests: the stacked raster maps as they are
+                fpn_maps, fpn_sizes = self.fpn.forward(vt, gh, gw, batch=G)
+                self._mark("simple_fpn")
+            for j, i in enumerate(grp):
+                aux_views = [nchw(t, s, j) for t, s in zip(aux_maps, aux_sizes)]
+                if self.fpn is not None:
+                    fpn_views = [nchw(t, s, j) for t, s in zip(fpn_maps, fpn_sizes)]
+                    self.hfre.simple_fpn = lambda x, v=fpn_views: v
+                    r0 = bp.row0[i]
+                    vt_in = nchw(vt_last[r0:r0 + gh * gw], (gh, gw))
+                else:
+                    vt_in = [nchw(t[bp.row0[i]:bp.row0[i] + gh * gw], (gh, gw)) for t in vt_last]
+                nb = boxes[i].shape[0]
+                self.hfre(aux_views, [boxes[i]], vt_in, None, vt_scale=(sw, sh), out=feat[row:row + nb])
+                ranges[i] = (row, row + nb)
+                row += nb
+            self._mark("hfre_region_pool")
+        out = self.mm_projector_aux(feat.to(torch.bfloat16))                               # :106-107
+        self._mark("mm_projector_aux")
+        return out, [ranges.get(i, (0, 0)) for i in range(len(want))]
+
+    def _device_batch(self, st, meta):
         with ops.workspace_scope(self._ws_owner):
-            return self._device_prefill_impl(pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions)
+            grids = meta["grids"]
+            tokens, feats, bp = self.vit.forward_batch(st["pix"], grids, capture="last" if self.fpn is not None else "all")
+            self._mark("qwen_vit+merger")
+            image_tokens = self.mm_projector(tokens)
+            self._mark("mm_projector")
+            vt_last = feats[-1] if self.fpn is not None else feats
+            region_tokens, ranges = self._regions_batch(st["aux"], st.get("aux_stack"), st["boxes"], meta["want"], vt_last, bp, grids)
+            emb = self.llm.embed_rows(st["plan"], image_tokens, region_tokens)
+            self._mark("splice")
+            last, logits, toks = self.llm.prefill_packed(emb, st["cos"], st["sin"], meta["seqs"], st["last"])
+            self._mark("llm_prefill+lm_head+argmax")
+            return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,
+                        next_tokens=toks, region_ranges=ranges, row0=bp.row0)
 
-    def _device_prefill_impl(self, pix, gh, gw, aux, boxes, plan_dev, cos, sin, want_regions: bool):
-        # The two towers are independent until the HFRE, but running DaViT on a side stream INSIDE one pass was measured
-        # slower (forked hipGraph replay 39.7 ms vs 21.9 ms on ROCm 7.2); overlap comes from independent images on
-        # different streams instead (FO1Engine.replica).
-        image_tokens, vt_feats = self.encode_images(pix, gh, gw)
-        region_tokens = self.encode_regions(aux, boxes, vt_feats, gh, gw) if want_regions else None
-        emb = self.llm.embed_rows(plan_dev, image_tokens, region_tokens)
-        self._mark("splice")
-        last, logits, tok = self.llm.prefill(emb, None, 0, tables=(cos, sin))
-        self._mark("llm_prefill+lm_head+argmax")
-        return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,
-                    next_token=tok)
+    GRAPH_CACHE = 8        # captured prefill graphs kept per engine (LRU); each holds its own activation pool
+    CAPTURE_AFTER = 1      # sightings of a signature before it is captured: one-off shapes (a dataset of ragged images) run eagerly
 
-    def prefill(self, input_ids: Sequence[int], pixel_values: torch.Tensor, grid_hw: Tuple[int, int], aux_image: torch.Tensor,
-                boxes: Optional[torch.Tensor], use_graph: bool = False):
-        """Everything up to the first greedy token.  use_graph=True replays a captured hipGraph of the ~1000
-        kernel launches for this (grid, aux size, #boxes, sequence length) signature: index plans / rope tables
-        are computed on the host and copied into the graph's static input buffers before the replay."""
-        from .llm import mrope_tables
-        gh, gw = grid_hw
+    def prefill_batch(self, requests: Sequence[dict], use_graph: bool = False) -> List[dict]:
+        """requests: dicts with ids (sentinel id list), pix [S,1176], grid (gh, gw), aux [3,H,W], boxes [N,4] or None.
+        All images go through ONE packed pass of every stage (the batch-aware splice of omchat_qwen2_5_vl.py:380-416, done
+        varlen: no padding to the longest prompt).  Returns one dict per request: image_tokens, region_tokens, embeds,
+        last_hidden [1,d], logits [1,V], next_token, position_ids, rope_delta.  use_graph=True replays a captured hipGraph of
+        the pass for this shape signature once the signature has been seen CAPTURE_AFTER times (LRU of GRAPH_CACHE graphs)."""
         m = self.cfg.vit.spatial_merge_size
-        n_img = (gh // m) * (gw // m)
-        want_regions = (boxes is not None) or any(t == DEFAULT_REGION_INDEX for t in input_ids)
-        if boxes is None or boxes.shape[0] == 0:
-            boxes = self._dummy_box
-        n_reg = boxes.shape[0] if want_regions else 0
-        plan, pos, delta = self.llm.plan_inputs(input_ids, n_img, n_reg, (gh // m, gw // m))
-        c = self.cfg.llm
-        cos, sin = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
-        boxes = boxes.to(device=self.dev, dtype=torch.float32)
-        if not use_graph:
-            out = self._device_prefill(pixel_values, gh, gw, aux_image, boxes, plan.to(self.dev), cos.to(self.dev), sin.to(self.dev),
-                                       want_regions)
+        B = len(requests)
+        grids, n_img, n_reg, want, boxes, prompts = [], [], [], [], [], []
+        for r in requests:
+            gh, gw = r["grid"]
+            b = r.get("boxes")
+            w = (b is not None) or any(t == DEFAULT_REGION_INDEX for t in r["ids"])
+            if b is None or b.shape[0] == 0:
+                b = self._dummy_box
+            grids.append((int(gh), int(gw))); n_img.append((gh // m) * (gw // m)); want.append(bool(w))
+            boxes.append(b.to(device=self.dev, dtype=torch.float32)); n_reg.append(b.shape[0] if w else 0); prompts.append(r["ids"])
+        hp = self.llm.plan_batch(prompts, n_img, n_reg, [(g[0] // m, g[1] // m) for g in grids])
+        self.llm.reserve(hp["rows"])
+        meta = dict(grids=tuple(grids), want=tuple(want), seqs=tuple(hp["seqs"]))
+        pix = requests[0]["pix"] if B == 1 else torch.cat([r["pix"].to(self.dev) for r in requests], 0)
+        auxs = [r["aux"] if r["aux"].dim() == 3 else r["aux"][0] for r in requests]
+        host = dict(plan=hp["plan"], cos=hp["cos"], sin=hp["sin"], last=hp["last"])
+        key = (meta["grids"], tuple(tuple(a.shape) for a in auxs), tuple(n_reg), meta["seqs"], meta["want"], pix.dtype, auxs[0].dtype,
+               self.llm.cache_epoch)
+        ent = self._graphs.get(key) if use_graph else None
+        if use_graph and ent is None:
+            seen = self._seen.get(key, 0)
+            if seen >= self.CAPTURE_AFTER:
+                ent = self._capture(key, pix, auxs, boxes, host, meta)
+            else:
+                if len(self._seen) >= 4096:
+                    self._seen.pop(next(iter(self._seen)))
+                self._seen[key] = seen + 1
+        if ent is None:
+            st = dict(pix=pix, aux=auxs, boxes=boxes, **{k: v.to(self.dev) for k, v in host.items()})
+            if len({tuple(a.shape) for a in auxs}) == 1:      # same-size aux images: one DaViT pass over the stack (input staging)
+                st["aux_stack"] = auxs[0].unsqueeze(0) if B == 1 else torch.stack([a.to(self.dev) for a in auxs], 0)
+            res = self._device_batch(st, meta)
         else:
-            key = (gh, gw, tuple(aux_image.shape), n_reg, plan.shape[0], want_regions, pixel_values.dtype, aux_image.dtype)
-            ent = self._graphs.get(key)
-            if ent is None:
-                with ops.graph_lock.capture():   # exclusive: no other thread captures or launches meanwhile
-                    # static input buffers must be ordinary tensors even when the caller runs under
-                    # torch.inference_mode() (the reference's inference.py:46 does): they are updated in place later
-                    with torch.inference_mode(False):
-                        st = dict(pix=pixel_values.clone(), aux=aux_image.clone(), boxes=boxes.clone(), plan=plan.clone().to(self.dev),
-                                  cos=cos.clone().to(self.dev), sin=sin.clone().to(self.dev))
-                    # warm-up on a side stream (allocates every lazily-created scratch buffer), then capture
-                    s = torch.cuda.Stream()
-                    s.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(s):
-                        self._device_prefill(st["pix"], gh, gw, st["aux"], st["boxes"], st["plan"], st["cos"], st["sin"], want_regions)
-                    torch.cuda.current_stream().wait_stream(s)
-                    torch.cuda.synchronize()
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL watchdog threads may touch the runtime meanwhile
-                        res = self._device_prefill(st["pix"], gh, gw, st["aux"], st["boxes"], st["plan"], st["cos"], st["sin"], want_regions)
-                    ent = (g, st, res, [])
-                    self._graphs[key] = ent
+            self._graphs.move_to_end(key)
             g, st, res, keep = ent
-            st["pix"].copy_(pixel_values, non_blocking=pixel_values.is_cuda)   # device -> device; host tensors upload blocking
-            st["aux"].copy_(aux_image, non_blocking=aux_image.is_cuda)
-            st["boxes"].copy_(boxes, non_blocking=boxes.is_cuda)
+            off = 0
+            for r in requests:                      # device -> device slices; host tensors upload blocking
+                n = r["pix"].shape[0]
+                st["pix"][off:off + n].copy_(r["pix"], non_blocking=r["pix"].is_cuda)
+                off += n
+            for d, a in zip(st["aux"], auxs):
+                d.copy_(a, non_blocking=a.is_cuda)
+            for d, b in zip(st["boxes"], boxes):
+                d.copy_(b, non_blocking=True)
             # Host-built inputs: async uploads from pageable tensors.  The runtime stages the bytes at call time (measured: an
-            # event-guarded pinned buffer or a blocking copy serialises graph launch and execution, 31 vs 19 ms per image);
-            # the last few source tensors are kept alive anyway so their memory cannot be re-used under a pending copy.
-            for k, src in (("plan", plan), ("cos", cos), ("sin", sin)):
+            # event-guarded pinned buffer or a blocking copy serialises graph launch and execution); the last few source
+            # tensors are kept alive anyway so their memory cannot be re-used under a pending copy.
+            for k, src in host.items():
                 st[k].copy_(src, non_blocking=True)
-            keep.append((plan, cos, sin))
+            keep.append(host)
             if len(keep) > 8:
                 del keep[0]
             with ops.graph_lock.replay():
                 g.replay()
-            out = dict(res)
-        self.llm.kv_len = plan.shape[0]
-        self.llm.rope_delta = delta
-        out["position_ids"] = pos
-        out["rope_delta"] = delta
+        outs = []
+        for i, (o, L, Lp) in enumerate(hp["seqs"]):
+            r0, r1 = res["region_ranges"][i]
+            i0 = res["row0"][i] // (m * m)
+            outs.append(dict(image_tokens=res["image_tokens"][i0:i0 + n_img[i]],
+                             region_tokens=res["region_tokens"][r0:r1] if res["region_tokens"] is not None and want[i] else None,
+                             embeds=res["embeds"][o:o + L], last_hidden=res["last_hidden"][i:i + 1], logits=res["logits"][i:i + 1],
+                             next_token=res["next_tokens"][i:i + 1], position_ids=hp["pos"][i], rope_delta=hp["delta"][i],
+                             cache_rows=(o, L)))
+        self._last_batch = hp
+        if B == 1:                                   # the single request sits at cache position 0: decode can continue in place
+            self.llm.kv_len = hp["seqs"][0][1]
+            self.llm.rope_delta = hp["delta"][0]
+        return outs
+
+    def _capture(self, key, pix, auxs, boxes, host, meta):
+        with ops.graph_lock.capture():   # exclusive: no other thread captures or launches meanwhile
+            # static input buffers must be ordinary tensors even when the caller runs under torch.inference_mode()
+            # (the reference's inference.py:46 does): they are updated in place later
+            with torch.inference_mode(False):
+                st = dict(pix=pix.clone(), boxes=[b.clone() for b in boxes], **{k: v.clone().to(self.dev) for k, v in host.items()})
+                if len({tuple(a.shape) for a in auxs}) == 1:
+                    st["aux_stack"] = torch.stack([a.to(self.dev) for a in auxs], 0)
+                    st["aux"] = list(st["aux_stack"].unbind(0))       # views: refreshing them refreshes the stack
+                else:
+                    st["aux"] = [a.clone() for a in auxs]
+            s = torch.cuda.Stream()   # warm-up on a side stream (allocates every lazily-created scratch buffer), then capture
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._device_batch(st, meta)
+            torch.cuda.current_stream().wait_stream(s)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL watchdog threads may touch the runtime meanwhile
+                res = self._device_batch(st, meta)
+            ent = (g, st, res, [])
+            self._graphs[key] = ent
+            while len(self._graphs) > self.GRAPH_CACHE:      # LRU: the evicted graph's private pool is released with it
+                self._graphs.popitem(last=False)
+            return ent
+
+    def prefill(self, input_ids: Sequence[int], pixel_values: torch.Tensor, grid_hw: Tuple[int, int], aux_image: torch.Tensor,
+                boxes: Optional[torch.Tensor], use_graph: bool = False):
+        """One image = a batch of one (same kernels, same packed layout)."""
+        out = self.prefill_batch([dict(ids=input_ids, pix=pixel_values, grid=grid_hw, aux=aux_image, boxes=boxes)], use_graph)[0]
+        if boxes is None and not any(t == DEFAULT_REGION_INDEX for t in input_ids):
+            out["region_tokens"] = None
         return out
 
     def generate(self, input_ids: Sequence[int], pixel_values, grid_hw, aux_image, boxes, max_new_tokens: int = 512,
                  stop_ids: Sequence[int] = (), use_graph: bool = False) -> List[int]:
         """Greedy decode (do_sample=False in every reference caller: mm_utils.py:640-654)."""
         out = self.prefill(input_ids, pixel_values, grid_hw, aux_image, boxes, use_graph=use_graph)
+        self.llm.reserve(self.llm.kv_len + max_new_tokens)
         tok = out["next_token"]
         new: List[int] = []
         first = True
         if use_graph:
             self.llm.sync_decode_state()
-        for _ in range(max_new_tokens):
+        for i in range(max_new_tokens):
             t = int(tok.item())
             new.append(t)
-            if t in stop_ids:
+            if t in stop_ids or i + 1 == max_new_tokens:   # no decode step after the last token
                 break
             if use_graph:
                 _, tok = self.llm.decode_step_graph(tok if first else None)

@@ -377,96 +377,102 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.T
 
 
 # ---- DaViT / SimpleFPN / splice helpers -----------------------------------------------------
-def dwconv3x3_res(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int, W: int) -> torch.Tensor:
-    """x [H*W, C] token-major -> x + dwconv3x3(x) (+bias); w9c is the [9, C] tap-major weight."""
+# Every spatial op takes `batch`: that many same-size images stacked along the row dimension ([batch*H*W, C]).
+def dwconv3x3_res(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int, W: int, batch: int = 1) -> torch.Tensor:
+    """x [batch*H*W, C] token-major -> x + dwconv3x3(x) (+bias); w9c is the [9, C] tap-major weight."""
     _chk(x, "x"); _chk(w9c, "w9c"); _chk(bias, "bias")
-    assert x.is_contiguous() and x.shape[0] == H * W and w9c.shape == (9, x.shape[1]) and w9c.is_contiguous()
+    assert x.is_contiguous() and x.shape[0] == batch * H * W and w9c.shape == (9, x.shape[1]) and w9c.is_contiguous()
     y = torch.empty_like(x)
-    _L.check(_L.load().fo1_dwconv3x3_bf16(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), y.data_ptr(), H, W, x.shape[1], _stream()),
+    _L.check(_L.load().fo1_dwconv3x3_bf16(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), y.data_ptr(), H, W, x.shape[1], batch, _stream()),
              "fo1_dwconv3x3_bf16")
     return y
 
 
 def dwconv3x3_res_ln(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int, W: int, ln_w: torch.Tensor, ln_b: torch.Tensor,
-                     eps: float):
+                     eps: float, batch: int = 1):
     """-> (y = x + dwconv3x3(x) + bias, LayerNorm(y)) in one launch (fo1_dwconv3x3_ln_bf16), bit-identical to
     dwconv3x3_res followed by layernorm."""
     _chk(x, "x"); _chk(w9c, "w9c"); _chk(bias, "bias"); _chk(ln_w, "ln_w"); _chk(ln_b, "ln_b")
-    assert x.is_contiguous() and x.shape[0] == H * W and w9c.shape == (9, x.shape[1]) and w9c.is_contiguous()
+    assert x.is_contiguous() and x.shape[0] == batch * H * W and w9c.shape == (9, x.shape[1]) and w9c.is_contiguous()
     y, h = torch.empty_like(x), torch.empty_like(x)
     _L.check(_L.load().fo1_dwconv3x3_ln_bf16(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), y.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
-                                             float(eps), h.data_ptr(), H, W, x.shape[1], _stream()), "fo1_dwconv3x3_ln_bf16")
+                                             float(eps), h.data_ptr(), H, W, x.shape[1], batch, _stream()), "fo1_dwconv3x3_ln_bf16")
     return y, h
 
 
-def im2col(x: torch.Tensor, H: int, W: int, KH: int, KW: int, stride: int, pad: int, ld: Optional[int] = None):
-    """x [H*W, C] -> (col [Ho*Wo, ld>=KH*KW*C] (pad columns zero), Ho, Wo)."""
+def im2col(x: torch.Tensor, H: int, W: int, KH: int, KW: int, stride: int, pad: int, ld: Optional[int] = None, batch: int = 1):
+    """x [batch*H*W, C] -> (col [batch*Ho*Wo, ld>=KH*KW*C] (pad columns zero), Ho, Wo)."""
     _chk(x, "x")
-    assert x.is_contiguous() and x.shape[0] == H * W
+    assert x.is_contiguous() and x.shape[0] == batch * H * W
     C = x.shape[1]
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     K = KH * KW * C
     ld = ld or K
-    col = torch.zeros(Ho * Wo, ld, dtype=torch.bfloat16, device=x.device) if ld != K else \
-        torch.empty(Ho * Wo, ld, dtype=torch.bfloat16, device=x.device)
-    _L.check(_L.load().fo1_im2col_bf16(x.data_ptr(), col.data_ptr(), H, W, C, KH, KW, stride, pad, ld, _stream()), "fo1_im2col_bf16")
+    col = torch.zeros(batch * Ho * Wo, ld, dtype=torch.bfloat16, device=x.device) if ld != K else \
+        torch.empty(batch * Ho * Wo, ld, dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_im2col_bf16(x.data_ptr(), col.data_ptr(), H, W, C, KH, KW, stride, pad, ld, batch, _stream()), "fo1_im2col_bf16")
     return col, Ho, Wo
 
 
-def window_partition(x: torch.Tensor, H: int, W: int, ws: int) -> torch.Tensor:
+def window_partition(x: torch.Tensor, H: int, W: int, ws: int, batch: int = 1) -> torch.Tensor:
     _chk(x, "x")
-    assert x.is_contiguous() and x.shape[0] == H * W
+    assert x.is_contiguous() and x.shape[0] == batch * H * W
     nW = ((H + ws - 1) // ws) * ((W + ws - 1) // ws)
-    xw = torch.empty(nW * ws * ws, x.shape[1], dtype=torch.bfloat16, device=x.device)
-    _L.check(_L.load().fo1_window_partition_bf16(x.data_ptr(), xw.data_ptr(), H, W, x.shape[1], ws, _stream()),
+    xw = torch.empty(batch * nW * ws * ws, x.shape[1], dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_window_partition_bf16(x.data_ptr(), xw.data_ptr(), H, W, x.shape[1], ws, batch, _stream()),
              "fo1_window_partition_bf16")
     return xw
 
 
-def window_reverse_add(yw: torch.Tensor, shortcut: torch.Tensor, H: int, W: int, ws: int) -> torch.Tensor:
+def window_reverse_add(yw: torch.Tensor, shortcut: torch.Tensor, H: int, W: int, ws: int, batch: int = 1) -> torch.Tensor:
     _chk(yw, "yw"); _chk(shortcut, "shortcut")
-    assert yw.is_contiguous() and shortcut.is_contiguous()
+    assert yw.is_contiguous() and shortcut.is_contiguous() and shortcut.shape[0] == batch * H * W
     y = torch.empty_like(shortcut)
-    _L.check(_L.load().fo1_window_reverse_add_bf16(yw.data_ptr(), shortcut.data_ptr(), y.data_ptr(), H, W, shortcut.shape[1], ws,
+    _L.check(_L.load().fo1_window_reverse_add_bf16(yw.data_ptr(), shortcut.data_ptr(), y.data_ptr(), H, W, shortcut.shape[1], ws, batch,
                                                    _stream()), "fo1_window_reverse_add_bf16")
     return y
 
 
-def channel_attention(qkv: torch.Tensor, C: int) -> torch.Tensor:
+def channel_attention(qkv: torch.Tensor, C: int, batch: int = 1) -> torch.Tensor:
+    """qkv [batch*N, 3C]: per image, per 32-channel group attention over the image's own N tokens."""
     _chk(qkv, "qkv")
-    p, ld, N, _ = _rows(qkv, "qkv")
-    need = _L.load().fo1_channel_attention_workspace_bytes(N, C)
+    p, ld, NB, _ = _rows(qkv, "qkv")
+    assert NB % batch == 0 and (batch == 1 or qkv.is_contiguous() or qkv.stride(0) == ld)
+    N = NB // batch
+    need = _L.load().fo1_channel_attention_workspace_bytes(N, C, batch)
     ws = _workspace("channel_attention", qkv.device, need)
-    out = torch.empty(N, C, dtype=torch.bfloat16, device=qkv.device)
-    _L.check(_L.load().fo1_channel_attention_bf16(p, ld, N, C, out.data_ptr(), C, ws.data_ptr(), ws.numel(), _stream()),
+    out = torch.empty(NB, C, dtype=torch.bfloat16, device=qkv.device)
+    _L.check(_L.load().fo1_channel_attention_bf16(p, ld, N, C, out.data_ptr(), C, batch, ws.data_ptr(), ws.numel(), _stream()),
              "fo1_channel_attention_bf16")
     return out
 
 
-def pixel_shuffle2(src: torch.Tensor, H: int, W: int, Co: int) -> torch.Tensor:
+def pixel_shuffle2(src: torch.Tensor, H: int, W: int, Co: int, batch: int = 1) -> torch.Tensor:
     _chk(src, "src")
-    assert src.is_contiguous() and src.shape == (H * W, 4 * Co)
-    dst = torch.empty(4 * H * W, Co, dtype=torch.bfloat16, device=src.device)
-    _L.check(_L.load().fo1_pixel_shuffle2_bf16(src.data_ptr(), dst.data_ptr(), H, W, Co, _stream()), "fo1_pixel_shuffle2_bf16")
+    assert src.is_contiguous() and src.shape == (batch * H * W, 4 * Co)
+    dst = torch.empty(batch * 4 * H * W, Co, dtype=torch.bfloat16, device=src.device)
+    _L.check(_L.load().fo1_pixel_shuffle2_bf16(src.data_ptr(), dst.data_ptr(), H, W, Co, batch, _stream()), "fo1_pixel_shuffle2_bf16")
     return dst
 
 
-def maxpool2(x: torch.Tensor, H: int, W: int) -> torch.Tensor:
+def maxpool2(x: torch.Tensor, H: int, W: int, batch: int = 1) -> torch.Tensor:
     _chk(x, "x")
-    assert x.is_contiguous() and x.shape[0] == H * W
-    y = torch.empty((H // 2) * (W // 2), x.shape[1], dtype=torch.bfloat16, device=x.device)
-    _L.check(_L.load().fo1_maxpool2_bf16(x.data_ptr(), y.data_ptr(), H, W, x.shape[1], _stream()), "fo1_maxpool2_bf16")
+    assert x.is_contiguous() and x.shape[0] == batch * H * W
+    y = torch.empty(batch * (H // 2) * (W // 2), x.shape[1], dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_maxpool2_bf16(x.data_ptr(), y.data_ptr(), H, W, x.shape[1], batch, _stream()), "fo1_maxpool2_bf16")
     return y
 
 
 def nchw_to_hwc8(img: torch.Tensor) -> torch.Tensor:
-    """img [3,H,W] bf16/fp32 -> [H*W, 8] bf16."""
+    """img [3,H,W] or [B,3,H,W] bf16/fp32 -> [B*H*W, 8] bf16."""
     if img.device.type != "cuda":
         raise _L.Fo1Error("nchw_to_hwc8: expected a HIP device tensor")
-    assert img.dim() == 3 and img.shape[0] == 3 and img.is_contiguous() and img.dtype in (torch.bfloat16, torch.float32)
-    H, W = img.shape[1:]
-    out = torch.empty(H * W, 8, dtype=torch.bfloat16, device=img.device)
-    _L.check(_L.load().fo1_nchw_to_hwc8_bf16(img.data_ptr(), 1 if img.dtype == torch.float32 else 0, out.data_ptr(), H, W, _stream()),
+    if img.dim() == 3:
+        img = img.unsqueeze(0)
+    assert img.dim() == 4 and img.shape[1] == 3 and img.is_contiguous() and img.dtype in (torch.bfloat16, torch.float32)
+    B, _, H, W = img.shape
+    out = torch.empty(B * H * W, 8, dtype=torch.bfloat16, device=img.device)
+    _L.check(_L.load().fo1_nchw_to_hwc8_bf16(img.data_ptr(), 1 if img.dtype == torch.float32 else 0, out.data_ptr(), H, W, B, _stream()),
              "fo1_nchw_to_hwc8_bf16")
     return out
 

@@ -91,6 +91,45 @@ class GridPlan:
         self.Sp = _round_up(S, 64)
 
 
+class BatchPlan:
+    """Index plan for several images packed row-wise into ONE pass: image i owns rows [row0[i], row0[i] + S_i) of
+    every activation; windows / full-attention segments, 2-D rope angles and the gather plans are the per-image plans with row
+    offsets added.  Grids may differ from image to image (every op of the ViT is row- or segment-wise)."""
+
+    def __init__(self, plans: Sequence[GridPlan], cfg: ViTConfig, device):
+        unit = cfg.spatial_merge_size ** 2
+        self.grids = [(g.gh, g.gw) for g in plans]
+        self.row0, off = [], 0
+        for g in plans:
+            self.row0.append(off)
+            off += g.S
+        self.S = off
+        self.Sp = _round_up(off, 64)
+
+        def cat_plan(parts, offs):
+            out = []
+            for t, o in zip(parts, offs):
+                t = t.clone()
+                t[:, 1] += o
+                out.append(t)
+            return torch.cat(out, 0).contiguous()
+
+        self.plan_in = cat_plan([g.plan_in for g in plans], self.row0)
+        self.plan_raster = cat_plan([g.plan_raster for g in plans], self.row0)
+        self.plan_tokens = cat_plan([g.plan_tokens for g in plans], [o // unit for o in self.row0])
+        self.cos = torch.cat([g.cos for g in plans], 0).contiguous()
+        self.sin = torch.cat([g.sin for g in plans], 0).contiguous()
+        wins, fulls = [], []
+        for g, o in zip(plans, self.row0):
+            wins += [(a + o, b + o) for a, b in zip(g.cu_window[:-1], g.cu_window[1:])]
+            fulls.append((o, o + g.S))
+        self.cu_window = None
+        self.win_segments, self.full_segments = wins, fulls
+        self.items_win = ops.make_items(wins, device, block=ops.pick_q_block(wins, cfg.num_heads))
+        self.items_full = ops.make_items(fulls, device, block=ops.pick_q_block(fulls, cfg.num_heads))
+        self.gh = self.gw = None
+
+
 class QwenViT:
     def __init__(self, cfg: ViTConfig, state: Dict[str, torch.Tensor], device):
         self.cfg = cfg
@@ -130,6 +169,7 @@ class QwenViT:
         self.m0w, self.m0b = dv(state["merger.mlp.0.weight"]), dv(state["merger.mlp.0.bias"])
         self.m2w, self.m2b = dv(state["merger.mlp.2.weight"]), dv(state["merger.mlp.2.bias"])
         self._plans: Dict[Tuple[int, int], GridPlan] = {}
+        self._bplans: Dict[tuple, BatchPlan] = {}
 
     def plan(self, gh: int, gw: int) -> GridPlan:
         key = (gh, gw)
@@ -137,17 +177,38 @@ class QwenViT:
             self._plans[key] = GridPlan(gh, gw, self.cfg, self.dev)
         return self._plans[key]
 
+    def batch_plan(self, grids: Sequence[Tuple[int, int]]) -> BatchPlan:
+        key = tuple((int(a), int(b)) for a, b in grids)
+        if key not in self._bplans:
+            if len(self._bplans) >= 64:
+                self._bplans.pop(next(iter(self._bplans)))
+            self._bplans[key] = BatchPlan([self.plan(a, b) for a, b in key], self.cfg, self.dev)
+        return self._bplans[key]
+
+    def forward_batch(self, pixel_values: torch.Tensor, grids: Sequence[Tuple[int, int]], capture: str = "all"):
+        """Several images in one pass: pixel_values [sum S_i, 1176] (the images' patch rows concatenated), grids [(gh_i, gw_i)].
+        Returns (image tokens [sum S_i / 4, out_hidden] — image i at rows [row0_i / 4, ...), feature maps [sum S_i, 1280] raster
+        per image at rows [row0_i, row0_i + S_i), plan)."""
+        bp = self.batch_plan(grids)
+        tokens, feats = self._forward(pixel_values, bp, capture)
+        return tokens, feats, bp
+
     def forward(self, pixel_values: torch.Tensor, gh: int, gw: int, capture: str = "all"):
         """pixel_values [S, 1176] (device, bf16, merge-block order as the HF processor emits them).
         Returns (image_tokens [S/4, out_hidden] raster-merged order,
                  feature maps: list of [gh*gw, 1280] raster token-major (all full-attention blocks, or
                  only the last one when capture == "last" — what the SimpleFPN variant consumes))."""
-        c = self.cfg
         g = self.plan(gh, gw)
+        if pixel_values.shape != (g.S, self.k_in):
+            raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match grid {gh}x{gw} (expected [{g.S}, {self.k_in}])")
+        return self._forward(pixel_values, g, capture)
+
+    def _forward(self, pixel_values: torch.Tensor, g, capture: str):
+        c = self.cfg
         S, d, H = g.S, c.hidden_size, c.num_heads
         hd = d // H
         if pixel_values.shape != (S, self.k_in):
-            raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match grid {gh}x{gw} (expected [{S}, {self.k_in}])")
+            raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match the plan (expected [{S}, {self.k_in}])")
         pix = pixel_values.to(torch.bfloat16)
         # window re-order folded into the patch-embed input gather; pad K 1176 -> 1216 (zeros)
         xin = torch.zeros(S, self.k_in_p, dtype=torch.bfloat16, device=self.dev)
@@ -155,9 +216,12 @@ class QwenViT:
         x = ops.gemm(xin, self.patch_w)
         vt = torch.zeros(d, g.Sp, dtype=torch.bfloat16, device=self.dev)  # V^T scratch, reused by every block
         scale = 1.0 / math.sqrt(hd)
-        nwin = len(g.cu_window) - 1
-        fl_win = 4.0 * d * sum((b - a) ** 2 for a, b in zip(g.cu_window[:-1], g.cu_window[1:]))
-        fl_full = 4.0 * d * S * S
+        if g.cu_window is not None:
+            win_seg, full_seg = list(zip(g.cu_window[:-1], g.cu_window[1:])), [(0, S)]
+        else:
+            win_seg, full_seg = g.win_segments, g.full_segments
+        fl_win = 4.0 * d * sum((b - a) ** 2 for a, b in win_seg)
+        fl_full = 4.0 * d * sum((b - a) ** 2 for a, b in full_seg)
         feats: List[torch.Tensor] = []
         for i, w in enumerate(self.blocks):
             full = i in c.fullatt_block_indexes
