@@ -16,14 +16,15 @@ SHAPES = [
     ("fpn3x3_l0", B * 25024, 512, 4608), ("merger1", B * 391, 5120, 5120),
     ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192),
 ]
-VARIANTS = [("auto", 0, 0, 0), ("p8", 0, 5, 1), ("t128x256", 2, 4, 1), ("t128", 2, 1, 1), ("t64x128", 2, 2, 1)]
+VARIANTS = [("auto", 0, 0, 0, 0), ("p8", 0, 5, 1, 0), ("p4", 0, 5, 1, 1)]
 res = []
 for name, M, N, K in SHAPES:
     a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
     ncopy = max(2, min(64, int(640e6 / (N * K * 2)) + 1))
     ws = [(torch.randn(N, K, device="cuda") * 0.05).bfloat16() for _ in range(ncopy)]
     out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    for label, staging, tile, splits in VARIANTS:
+    for label, staging, tile, splits, sched in VARIANTS:
+        L.load().fo1_gemm_set_big_schedule(sched)
         L.load().fo1_gemm_set_variant(staging, tile)
         L.load().fo1_gemm_set_splitk(splits)
         for i in range(3):
@@ -43,4 +44,5 @@ for name, M, N, K in SHAPES:
     del ws
 L.load().fo1_gemm_set_variant(0, 0)
 L.load().fo1_gemm_set_splitk(0)
+L.load().fo1_gemm_set_big_schedule(1)
 json.dump(res, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/gemm_bench_p8.json", "w"))

@@ -105,18 +105,33 @@ def test_build_inputs_splice_and_errors():
         eng.build_inputs(ids, img, reg, (3, 3))
     with pytest.raises(IndexError):                      # token id outside the 512-row embedding table
         eng.build_inputs([1, 2, 512, IMAGE_TOKEN_INDEX], img, None, (2, 3))
-    # KV-cache limits are enforced on the host (the device-side decode state would index past the cache)
+    # The KV cache GROWS on the host before a step would index past it (the reference's HF cache is unbounded; a long generation
+    # must not fail on a fixed size — ADVICE r1): a 128-entry engine decoding past 128 must give exactly what a 512-entry engine gives.
+    big_kw = dict(cfg_kw, max_seq=512)
+    _, _, big = make(big_kw, 4, 0, None)
     emb = torch.randn(126, 256).bfloat16().cuda()
     pos = torch.arange(126).view(1, -1).expand(3, -1)
+    toks = {}
+    for name, e in (("small", eng), ("big", big)):
+        _, _, tok = e.prefill(emb, pos)
+        out = [int(tok.item())]
+        for _ in range(6):                               # positions 126 .. 131: the small engine re-allocates at 128
+            _, _, tok = e.decode_step(tok)
+            out.append(int(tok.item()))
+        toks[name] = out
+    assert eng.capacity >= 132 and eng.cache_epoch == 1 and toks["small"] == toks["big"]
     _, _, tok = eng.prefill(emb, pos)
-    for _ in range(2):                                   # positions 126, 127 fit the 128-entry cache
-        _, _, tok = eng.decode_step(tok)
-    with pytest.raises(ValueError):
-        eng.decode_step(tok)
-    with pytest.raises(ValueError):
-        eng.decode_step_graph(tok)
-    with pytest.raises(ValueError):
-        eng.prefill(torch.randn(129, 256).bfloat16().cuda(), torch.arange(129).view(1, -1).expand(3, -1))
+    eng.sync_decode_state()
+    out = [int(tok.item())]
+    first = True
+    for _ in range(6):
+        _, tok = eng.decode_step_graph(tok if first else None)
+        first = False
+        out.append(int(tok.item()))
+    assert out == toks["big"], "graph-replayed decode after a cache re-allocation"
+    x = torch.randn(700, 256).bfloat16().cuda()       # a prompt longer than the current capacity grows it too
+    eng.prefill(x, torch.arange(700).view(1, -1).expand(3, -1))
+    assert eng.capacity >= 700
 
 
 def test_decode_graph_replay_equals_eager_steps():

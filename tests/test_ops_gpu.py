@@ -458,10 +458,13 @@ P8_SHAPES = [
 ]
 
 
-def test_gemm_p8_256x256():
+@pytest.mark.parametrize("sched", [0, 1])
+def test_gemm_p8_256x256(sched):
+    """sched 0: four phases per K tile; sched 1: two fat phases with the LDS-DMA issued between MFMAs (gemm_bt_p4_kernel)."""
     from vlm_fo1_amd import lib as L, ops
     torch.manual_seed(55)
     try:
+        L.check(L.load().fo1_gemm_set_big_schedule(sched), "schedule")
         for (M, N, K, hb, hr, act, splits) in P8_SHAPES:
             L.check(L.load().fo1_gemm_set_variant(0, 5), "variant")
             L.check(L.load().fo1_gemm_set_splitk(splits), "splitk")
@@ -483,14 +486,17 @@ def test_gemm_p8_256x256():
     finally:
         L.load().fo1_gemm_set_variant(0, 0)
         L.load().fo1_gemm_set_splitk(0)
+        L.load().fo1_gemm_set_big_schedule(1)
 
 
-def test_gemm_p8_swiglu_and_one_hot():
+@pytest.mark.parametrize("sched", [0, 1])
+def test_gemm_p8_swiglu_and_one_hot(sched):
     """(a) the interleaved-SwiGLU epilogue on 32x32 fragments against the unfused reference; (b) an A = one-hot-rows GEMM whose exact
     answer is a row of W: catches any row/column or k-chunk mix-up exactly (no tolerance)."""
     from vlm_fo1_amd import lib as L, ops
     torch.manual_seed(56)
     try:
+        L.check(L.load().fo1_gemm_set_big_schedule(sched), "schedule")
         L.check(L.load().fo1_gemm_set_variant(0, 5), "variant")
         M, K, Fh = 1564, 1280, 3456
         a = (torch.randn(M, K) * 0.5).to(BF).cuda()
@@ -515,3 +521,4 @@ def test_gemm_p8_swiglu_and_one_hot():
         assert torch.equal(got.cpu(), w[:, kk].t().contiguous()), "p8 gemm: one-hot A does not select W columns exactly"
     finally:
         L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_big_schedule(1)

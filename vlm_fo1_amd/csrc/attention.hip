@@ -42,6 +42,10 @@ struct AttnParams {
     const int* dyn_kv_len;                           // optional: kv_end/kv_start of item i derived on device: chunk i of *dyn_kv_len keys
     int kv_chunk;
     int q_range_end;                                 // PARTIAL: number of query heads per KV head
+    // batched decode (PARTIAL): blockIdx.z = sequence; keys [state[z][2], state[z][0]] (decode.hip state layout)
+    const int* seq_state;
+    long long q_seq_stride;                          // Q elements between sequences
+    long long part_seq_stride;                       // floats between sequences in `part`
 };
 
 template <int HD, int NW, bool PARTIAL = false>
@@ -58,11 +62,22 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 
     AttnItem it;
     if (!PARTIAL) it = p.items[blockIdx.x];
+    const uint16_t* Qb = p.Q;
+    float* partb = p.part;
     if (PARTIAL) {
         it.q_start = 0;
-        it.q_end = p.q_range_end;   // chunk blockIdx.x of the first *dyn_kv_len keys; empty chunks leave (m, l) = (-inf, 0)
-        const int kv_len = *p.dyn_kv_len;
-        it.kv_start = blockIdx.x * p.kv_chunk;
+        it.q_end = p.q_range_end;   // chunk blockIdx.x of the sequence's keys; empty chunks leave (m, l) = (-inf, 0)
+        int kv0 = 0, kv_len;
+        if (p.seq_state) {
+            const int* st = p.seq_state + blockIdx.z * 8;
+            kv0 = st[2];
+            kv_len = st[0] + 1;
+            Qb += (long long)blockIdx.z * p.q_seq_stride;
+            partb += (long long)blockIdx.z * p.part_seq_stride;
+        } else {
+            kv_len = *p.dyn_kv_len;
+        }
+        it.kv_start = kv0 + blockIdx.x * p.kv_chunk;
         it.kv_end = min(kv_len, it.kv_start + p.kv_chunk);
         if (it.kv_start >= kv_len) return;
     }
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     // Q fragments (B operand): lane (query ql, k-group g) holds d = c*32 + g*8 .. +8
     bf16x8 qf[NC];
     {
-        const uint16_t* qp = p.Q + (long long)q_ld * p.q_tok + (long long)h * p.q_head;
+        const uint16_t* qp = Qb + (long long)q_ld * p.q_tok + (long long)h * p.q_head;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const int d0 = c * 32 + g * 8;
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 
     if (PARTIAL) {
         if (wave == 0 && q_ok) {
-            float* pr = p.part + (((long long)blockIdx.x * p.Hq + h) * 16 + ql) * (HD + 2);
+            float* pr = partb + (((long long)blockIdx.x * p.Hq + h) * 16 + ql) * (HD + 2);
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
                 *reinterpret_cast<float4*>(pr + db * 16 + g * 4) = float4{o[db][0], o[db][1], o[db][2], o[db][3]};
@@ -240,10 +255,20 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 // out[head, d] = sum_s exp(m_s - M) O_s[d] / sum_s exp(m_s - M) l_s over the valid KV chunks (fixed order)
 template <int HD>
 __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __restrict__ part, const int* __restrict__ dyn_kv_len,
-                                                                 int kv_chunk, int n_kv_heads, int group, uint16_t* __restrict__ out) {
+                                                                 int kv_chunk, int n_kv_heads, int group, uint16_t* __restrict__ out,
+                                                                 const int* __restrict__ seq_state, long long part_seq_stride, long long out_seq_stride) {
     const int head = blockIdx.x, d = threadIdx.x;
     const int kvh = head / group, slot = head - kvh * group;
-    const int n_valid = (*dyn_kv_len + kv_chunk - 1) / kv_chunk;
+    int n_keys;
+    if (seq_state) {   // sequence blockIdx.y of a decode batch
+        const int* st = seq_state + blockIdx.y * 8;
+        n_keys = st[0] + 1 - st[2];
+        part += (long long)blockIdx.y * part_seq_stride;
+        out += (long long)blockIdx.y * out_seq_stride;
+    } else {
+        n_keys = *dyn_kv_len;
+    }
+    const int n_valid = (n_keys + kv_chunk - 1) / kv_chunk;
     float M = -INFINITY;
     for (int s = 0; s < n_valid; ++s) M = fmaxf(M, part[(((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + HD]);
     float num = 0.f, den = 0.f;
@@ -298,6 +323,7 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
     p.n_items = n_items; p.Hq = n_q_heads; p.group = n_q_heads / n_kv_heads;
     p.scale = scale; p.causal = causal; p.q_row_base = (const int*)q_row_base;
     p.part = nullptr; p.dyn_kv_len = nullptr; p.kv_chunk = 0; p.q_range_end = 0;
+    p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
     hipStream_t st = (hipStream_t)stream;
     if (head_dim == 32) return launch_attn<32>(p, q_block, st, flops_hint);
     if (head_dim == 80) return launch_attn<80>(p, q_block, st, flops_hint);
@@ -336,11 +362,51 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
     (void)one_item;
     p.items = nullptr;
     p.q_range_end = group;
+    p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
     hipStream_t st = (hipStream_t)stream;
     FO1_LAUNCH("attn_decode_split", (double)max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
                dim3(p.n_items, n_kv_heads), dim3(256), 0, st, p);
     FO1_LAUNCH("attn_decode_combine", (double)n_q_heads * head_dim * 8.0, attn_decode_combine_kernel<128>, dim3(n_q_heads), dim3(128), 0, st,
-               (const float*)workspace, (const int*)dyn_kv_len, 64, n_kv_heads, group, (uint16_t*)out);
+               (const float*)workspace, (const int*)dyn_kv_len, 64, n_kv_heads, group, (uint16_t*)out, (const int*)nullptr, 0LL, 0LL);
+    return FO1_OK;
+}
+
+// Batched decode attention: B sequences, one new token each (q rows [B, n_q_heads*head_dim]); sequence b attends the cache rows
+// [state[b][2], state[b][0]] (its slot start .. the row just written).  grid = (max chunks per slot, KV heads, B).
+size_t fo1_attention_decode_batch_workspace_bytes(int max_kv_len, int n_kv_heads, int head_dim, int batch) {
+    return (size_t)batch * fo1_attention_decode_workspace_bytes(max_kv_len, n_kv_heads, head_dim);
+}
+
+int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const void* kcache, long long k_tok_stride, long long k_head_stride,
+                                    const void* vtcache, long long vt_row_stride, void* out, long long out_seq_stride, const int32_t* state,
+                                    int batch, int max_kv_len, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(q && kcache && vtcache && out && state && workspace && batch >= 1, "attention_decode_batch: NULL operand");
+    FO1_CHECK_ARG(head_dim == 128, "attention_decode_batch: head_dim %d not built (128)", head_dim);
+    FO1_CHECK_ARG(n_q_heads % n_kv_heads == 0 && n_q_heads / n_kv_heads <= 16, "attention_decode_batch: at most 16 query heads per KV head");
+    FO1_CHECK_ARG(vt_row_stride % 4 == 0 && k_tok_stride % 8 == 0 && k_head_stride % 8 == 0 && q_seq_stride % 8 == 0, "attention_decode_batch: bad strides");
+    if (workspace_bytes < fo1_attention_decode_batch_workspace_bytes(max_kv_len, n_kv_heads, head_dim, batch))
+        return set_err(FO1_ERR_WORKSPACE, "attention_decode_batch: workspace too small");
+    AttnParams p;
+    const int group = n_q_heads / n_kv_heads;
+    p.Q = (const uint16_t*)q; p.q_tok = head_dim; p.q_head = (long long)group * head_dim;
+    p.K = (const uint16_t*)kcache; p.k_tok = k_tok_stride; p.k_head = k_head_stride;
+    p.VT = (const uint16_t*)vtcache; p.vt_row = vt_row_stride;
+    p.O = nullptr; p.o_tok = 0; p.o_head = 0;
+    p.items = nullptr;
+    p.n_items = cdiv(max_kv_len, 64); p.Hq = n_kv_heads; p.group = 1;
+    p.scale = scale; p.causal = 0; p.q_row_base = nullptr;
+    p.part = (float*)workspace; p.dyn_kv_len = nullptr; p.kv_chunk = 64;
+    p.q_range_end = group;
+    p.seq_state = (const int*)state; p.q_seq_stride = q_seq_stride;
+    p.part_seq_stride = (long long)p.n_items * n_kv_heads * 16 * (head_dim + 2);
+    hipStream_t st = (hipStream_t)stream;
+    FO1_LAUNCH("attn_decode_split", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
+               dim3(p.n_items, n_kv_heads, batch), dim3(256), 0, st, p);
+    FO1_LAUNCH("attn_decode_combine", (double)batch * n_q_heads * head_dim * 8.0, attn_decode_combine_kernel<128>, dim3(n_q_heads, batch), dim3(128), 0,
+               st, (const float*)workspace, (const int*)nullptr, 64, n_kv_heads, group, (uint16_t*)out, (const int*)state, p.part_seq_stride,
+               out_seq_stride);
     return FO1_OK;
 }
 

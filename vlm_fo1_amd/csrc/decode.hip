@@ -1,0 +1,497 @@
+// decode.hip — batched greedy decode for gfx950: B sequences advance one token per step through ONE stream of the weights
+// (reference: the 1-token fast path of omchat_qwen2_5_vl.py:143-155, positions modeling_qwen2_5_vl.py:1848-1860,
+// stop rule mm_utils.py:137-181 / HF greedy search).  Everything position-dependent lives in device memory so that one
+// captured hipGraph serves every step of every batch:
+//
+//   per-sequence state  int32[8] = { pos, rope_row, kv_start, finished, n_gen, max_new, -, - }
+//     pos       cache row the NEW token's K / V^T column is written to (= kv_start + tokens so far)
+//     rope_row  row of the [max positions, head_dim] mRoPE table = cache_position + rope_delta (text: t = h = w)
+//     kv_start  first cache row of the sequence's slot; keys attended = [kv_start, pos]
+//
+// Kernels (5 launches per layer):
+//   gemv_batch<MM, MODE>   weight-streaming GEMV for M <= 8 rows: 16-B weight loads straight to VGPRs, x in LDS,
+//                          v_dot2c_f32_bf16, fp32 accumulate; fused RMSNorm prologue; epilogues: bias/residual | interleaved
+//                          SwiGLU | QKV = bias -> bf16 -> mRoPE -> q rows out, K row and V^T column appended to the caches
+//   attention              split-KV partials (attention.hip, PARTIAL mode with per-sequence ranges) + fixed-order combine
+//   argmax_accept          two-stage argmax per row, then ON-DEVICE bookkeeping: record the id, stop check, advance state,
+//                          write the next step's embedding-gather plan — the host never reads a token inside the loop
+#include "common.h"
+
+namespace fo1 {
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
+// streamed-once weights: non-temporal 16-byte load (MI355X_MICROARCH "nt-weights": -18 % issue-to-landed on a decode weight stream)
+__device__ __forceinline__ uint4 load_nt16(const uint16_t* p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return uint4{v.x, v.y, v.z, v.w};
+}
+
+struct GemvBParams {
+    const uint16_t* X;       // [M, ldx]
+    const uint16_t* W;       // [N, ldw]
+    const uint16_t* bias;    // [N] or null
+    const uint16_t* res;     // [M, ldr] or null (plain mode)
+    uint16_t* C;             // [M, ldc]: plain out | SwiGLU out | rotated q rows (QKV mode)
+    int M, N, K, ldx, ldw, ldc, ldr;
+    const uint16_t* norm_w;  // optional fused RMSNorm on x
+    float norm_eps;
+    int kp_chunks;           // 16-B chunks of K staged in LDS at a time
+    // QKV mode
+    int n_q, n_kv;           // heads (head_dim 128)
+    const uint16_t* cos_t; const uint16_t* sin_t;   // [rows, 128] bf16 tables
+    const int* state;        // [M][8]
+    uint16_t* kcache; long long kc_head_stride;      // [n_kv][rows][128]
+    uint16_t* vtcache; long long vt_row_stride;      // [n_kv*128][rows]
+};
+
+__device__ __forceinline__ float gb_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+__device__ __forceinline__ float gb_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float dot8b(const uint4& w, const uint4& x, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.x), *reinterpret_cast<const bf16x2_t*>(&x.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.y), *reinterpret_cast<const bf16x2_t*>(&x.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.z), *reinterpret_cast<const bf16x2_t*>(&x.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.w), *reinterpret_cast<const bf16x2_t*>(&x.w), acc, false);
+    return acc;
+}
+
+enum { GB_PLAIN = 0, GB_SWIGLU = 1, GB_QKV = 2 };
+
+// One unit = 8 weight rows:  plain: 8 consecutive output features;  SwiGLU: 4 gate rows + their up partners 16 rows further
+// (16-row interleaved weights);  QKV: q/k heads -> 4 dims d and their rotary partners d + 64, v head -> 8 consecutive dims.
+// KSPLIT: the 4 waves of a workgroup share ONE unit and split K (deep or few-row projections: every CU streams);
+// otherwise one unit per wave (many-row projections: x is staged once per 32 rows).
+template <int MM, int MODE, bool KSPLIT>
+__global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
+    constexpr int NR = 8, U = 2;
+    extern __shared__ __attribute__((aligned(16))) uint16_t sx[];   // [MM][kp_chunks * 8]
+    __shared__ float s_red[4][NR * MM];
+    __shared__ float s_ss[4];
+    __shared__ float s_rstd[MM];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kch = p.K >> 3;
+    const int unit = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
+    // ---- rows of this unit ----
+    int n_units, rows[NR];
+    const int n_rope = (MODE == GB_QKV) ? (p.n_q + p.n_kv) * 16 : 0;
+    if (MODE == GB_SWIGLU) n_units = p.N / 8;            // 4 features per unit
+    else if (MODE == GB_QKV) n_units = n_rope + p.n_kv * 16;
+    else n_units = (p.N + 7) / 8;
+    const bool unit_ok = unit < n_units;                  // KSPLIT: uniform per workgroup
+    {
+        const int u = unit_ok ? unit : n_units - 1;
+#pragma unroll
+        for (int j = 0; j < NR; ++j) {
+            int r;
+            if (MODE == GB_SWIGLU) { const int f = u * 4 + (j & 3); r = (f >> 4) * 32 + (f & 15) + (j >= 4 ? 16 : 0); }
+            else if (MODE == GB_QKV) {
+                if (u < n_rope) r = (u >> 4) * 128 + (u & 15) * 4 + (j & 3) + (j >= 4 ? 64 : 0);
+                else r = (p.n_q + p.n_kv) * 128 + (u - n_rope) * 8 + j;
+            } else r = u * 8 + j;
+            rows[j] = r < p.N ? r : p.N - 1;              // clamp (result discarded)
+        }
+    }
+    float acc[NR][MM];
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+
+    for (int kp0 = 0; kp0 < kch; kp0 += p.kp_chunks) {
+        const int kpn = min(p.kp_chunks, kch - kp0);
+        if (kp0 > 0) __syncthreads();                     // everyone is done with the previous K piece
+        for (int i = tid; i < MM * kpn; i += 256) {
+            const int m = i / kpn, c = i - m * kpn;
+            *reinterpret_cast<uint4*>(&sx[(m * p.kp_chunks + c) * 8]) =
+                m < p.M ? *reinterpret_cast<const uint4*>(p.X + (long long)m * p.ldx + (kp0 + c) * 8) : uint4{0, 0, 0, 0};
+        }
+        __syncthreads();
+        if (p.norm_w) {
+            // fused Qwen2RMSNorm (modeling_qwen2_5_vl.py:126-140) on the staged rows (K fits one piece: checked by the host):
+            // fp32 variance, bf16(x * rstd), * weight -> bf16
+            for (int m = 0; m < MM; ++m) {
+                float ss = 0.f;
+                for (int c = tid; c < kpn; c += 256) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]);
+                    ss = dot8b(v, v, ss);
+                }
+                ss = gb_wave_sum(ss);
+                if (lane == 0) s_ss[wave] = ss;
+                __syncthreads();
+                if (tid == 0) s_rstd[m] = rsqrtf((s_ss[0] + s_ss[1] + s_ss[2] + s_ss[3]) / (float)p.K + p.norm_eps);
+                __syncthreads();
+            }
+            for (int i = tid; i < MM * kpn; i += 256) {
+                const int m = i / kpn, c = i - m * kpn;
+                const float rstd = s_rstd[m];
+                uint4 v = *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]);
+                const uint4 w = *reinterpret_cast<const uint4*>(p.norm_w + c * 8);
+                uint4 o;
+                o.x = pack_bf16x2(bf16_lo(w.x) * gb_round(bf16_lo(v.x) * rstd), bf16_hi(w.x) * gb_round(bf16_hi(v.x) * rstd));
+                o.y = pack_bf16x2(bf16_lo(w.y) * gb_round(bf16_lo(v.y) * rstd), bf16_hi(w.y) * gb_round(bf16_hi(v.y) * rstd));
+                o.z = pack_bf16x2(bf16_lo(w.z) * gb_round(bf16_lo(v.z) * rstd), bf16_hi(w.z) * gb_round(bf16_hi(v.z) * rstd));
+                o.w = pack_bf16x2(bf16_lo(w.w) * gb_round(bf16_lo(v.w) * rstd), bf16_hi(w.w) * gb_round(bf16_hi(v.w) * rstd));
+                *reinterpret_cast<uint4*>(&sx[(m * p.kp_chunks + c) * 8]) = o;
+            }
+            __syncthreads();
+        }
+        if (unit_ok) {
+            // this wave's chunk range inside the piece
+            const int kq = KSPLIT ? ((kpn + 3) / 4 + 63) / 64 * 64 : kpn;
+            const int c_begin = KSPLIT ? min(kpn, wave * kq) : 0;
+            const int c_end = KSPLIT ? min(kpn, c_begin + kq) : kpn;
+            for (int c0 = c_begin + lane; c0 < c_end; c0 += 64 * U) {
+                uint4 w[NR][U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = c0 + u * 64;
+                    const bool ok = c < c_end;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        w[r][u] = ok ? load_nt16(p.W + (long long)rows[r] * p.ldw + (long long)(kp0 + c) * 8) : uint4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int c = c0 + u * 64;
+                    if (c < c_end) {
+#pragma unroll
+                        for (int m = 0; m < MM; ++m) {
+                            const uint4 xv = *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]);
+#pragma unroll
+                            for (int r = 0; r < NR; ++r) acc[r][m] = dot8b(w[r][u], xv, acc[r][m]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- reduce: every lane of a wave ends with the wave's sums; KSPLIT adds the 4 waves through LDS ----
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int m = 0; m < MM; ++m) acc[r][m] = gb_wave_sum(acc[r][m]);
+    float* red = s_red[KSPLIT ? 0 : wave];   // the unit's NR*MM sums (fp32)
+    if (KSPLIT) {
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int m = 0; m < MM; ++m) s_red[wave][r * MM + m] = acc[r][m];
+        }
+        __syncthreads();
+        if (tid < NR * MM) {
+            const float t = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+            s_red[0][tid] = t;      // each thread reads and writes only its own slot of row 0
+        }
+        __syncthreads();
+        if (wave != 0) return;
+    } else {
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+#pragma unroll
+                for (int m = 0; m < MM; ++m) red[r * MM + m] = acc[r][m];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (!unit_ok) return;
+    // ---- epilogue: lane -> (row slot j, sequence m) ----
+    if (MODE == GB_PLAIN) {
+        if (lane < NR * MM) {
+            const int j = lane / MM, m = lane - j * MM;
+            const int f = unit * 8 + j;
+            if (f < p.N && m < p.M) {
+                float v = red[j * MM + m];
+                if (p.bias) v += bf16_to_f32(p.bias[f]);
+                v = gb_round(v);
+                if (p.res) v += bf16_to_f32(p.res[(long long)m * p.ldr + f]);
+                p.C[(long long)m * p.ldc + f] = f32_to_bf16(v);
+            }
+        }
+    } else if (MODE == GB_SWIGLU) {
+        if (lane < 4 * MM) {
+            const int j = lane / MM, m = lane - j * MM;
+            const int f = unit * 4 + j;
+            if (m < p.M) {
+                float g = red[j * MM + m], u = red[(4 + j) * MM + m];
+                if (p.bias) { g += bf16_to_f32(p.bias[rows[0] + j]); u += bf16_to_f32(p.bias[rows[0] + j + 16]); }
+                g = gb_round(g);
+                u = gb_round(u);
+                p.C[(long long)m * p.ldc + f] = f32_to_bf16(gb_round(g / (1.0f + expf(-g))) * u);
+            }
+        }
+    } else {   // GB_QKV
+        if (unit < n_rope) {
+            if (lane < 4 * MM) {
+                const int j = lane / MM, m = lane - j * MM;
+                if (m < p.M) {
+                    const int head = unit >> 4, d = (unit & 15) * 4 + j;            // d < 64; partner d + 64
+                    const int ra = head * 128 + d, rb_ = ra + 64;
+                    float a = red[j * MM + m], b = red[(4 + j) * MM + m];
+                    if (p.bias) { a += bf16_to_f32(p.bias[ra]); b += bf16_to_f32(p.bias[rb_]); }
+                    a = gb_round(a);                                                 // the bf16 q/k the unfused path stores
+                    b = gb_round(b);
+                    const int* st = p.state + m * 8;
+                    const long long row = st[1];
+                    const float ca = bf16_to_f32(p.cos_t[row * 128 + d]), sa = bf16_to_f32(p.sin_t[row * 128 + d]);
+                    const float cb = bf16_to_f32(p.cos_t[row * 128 + d + 64]), sb = bf16_to_f32(p.sin_t[row * 128 + d + 64]);
+                    const uint16_t oa = f32_to_bf16(gb_round(a * ca) + gb_round(-b * sa));   // rotate_half, three bf16 roundings
+                    const uint16_t ob = f32_to_bf16(gb_round(b * cb) + gb_round(a * sb));
+                    if (head < p.n_q) {
+                        p.C[(long long)m * p.ldc + ra] = oa;
+                        p.C[(long long)m * p.ldc + rb_] = ob;
+                    } else {
+                        uint16_t* kc = p.kcache + (long long)(head - p.n_q) * p.kc_head_stride + (long long)st[0] * 128;
+                        kc[d] = oa;
+                        kc[d + 64] = ob;
+                    }
+                }
+            }
+        } else {
+            if (lane < NR * MM) {
+                const int j = lane / MM, m = lane - j * MM;
+                if (m < p.M) {
+                    const int vrow = (unit - n_rope) * 8 + j;                        // kv_head * 128 + d
+                    float v = red[j * MM + m];
+                    if (p.bias) v += bf16_to_f32(p.bias[(p.n_q + p.n_kv) * 128 + vrow]);
+                    const int* st = p.state + m * 8;
+                    p.vtcache[(long long)vrow * p.vt_row_stride + st[0]] = f32_to_bf16(v);
+                }
+            }
+        }
+    }
+}
+
+template <int MM, int MODE, bool KS>
+static int launch_gemv_b(const GemvBParams& p, const char* name, int n_units, hipStream_t st) {
+    const size_t smem = (size_t)MM * p.kp_chunks * 16;
+    static bool attr = false;
+    if (!attr) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_batch_kernel<MM, MODE, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr = true;
+    }
+    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_batch_kernel<MM, MODE, KS>), dim3(KS ? n_units : cdiv(n_units, 4)), dim3(256), smem, st, p);
+    return FO1_OK;
+}
+
+template <int MM>
+static int dispatch_gemv_b(GemvBParams& p, int mode, hipStream_t st) {
+    // K piece staged in LDS: whole K when MM * K * 2 <= 128 KiB, else the smallest number of equal pieces (multiples of 256 chunks)
+    const int kch = p.K >> 3;
+    int pieces = 1;
+    while ((size_t)MM * cdiv(cdiv(kch, pieces), 256) * 256 * 16 > 128 * 1024) ++pieces;
+    p.kp_chunks = cdiv(cdiv(kch, pieces), 256) * 256;
+    if (p.kp_chunks > kch) p.kp_chunks = kch;
+    if (p.norm_w && p.kp_chunks < kch) return set_err(FO1_ERR_ARG, "gemv_batch: fused RMSNorm needs K to fit one LDS piece (K=%d, M=%d)", p.K, MM);
+    int n_units;
+    if (mode == GB_SWIGLU) n_units = p.N / 8;
+    else if (mode == GB_QKV) n_units = (p.n_q + p.n_kv) * 16 + p.n_kv * 16;
+    else n_units = cdiv(p.N, 8);
+    // every CU should stream: one unit per workgroup (K split over its 4 waves) unless that would make more than ~2048 workgroups
+    const bool ks = n_units <= 1024;
+    if (mode == GB_SWIGLU) return ks ? launch_gemv_b<MM, GB_SWIGLU, true>(p, "gemv_batch_swiglu", n_units, st) : launch_gemv_b<MM, GB_SWIGLU, false>(p, "gemv_batch_swiglu", n_units, st);
+    if (mode == GB_QKV) return launch_gemv_b<MM, GB_QKV, true>(p, "gemv_batch_qkv", n_units, st);
+    return ks ? launch_gemv_b<MM, GB_PLAIN, true>(p, "gemv_batch", n_units, st) : launch_gemv_b<MM, GB_PLAIN, false>(p, "gemv_batch", n_units, st);
+}
+
+static int gemv_b_any(GemvBParams& p, int mode, hipStream_t st) {
+    if (p.M == 1) return dispatch_gemv_b<1>(p, mode, st);
+    if (p.M == 2) return dispatch_gemv_b<2>(p, mode, st);
+    if (p.M <= 4) return dispatch_gemv_b<4>(p, mode, st);
+    return dispatch_gemv_b<8>(p, mode, st);
+}
+
+// ---- argmax over B rows + on-device accept ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void argmax_rows_partial_kernel(const uint16_t* __restrict__ x, long long ldx, int n, float* __restrict__ pv,
+                                                                  int* __restrict__ pi) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    const uint16_t* row = x + (long long)blockIdx.y * ldx;
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int lo = blockIdx.x * per, hi = min(n, lo + per);
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+        const float v = bf16_to_f32(row[i]);
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_v[wave] = best; s_i[wave] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_v[w] > best || (s_v[w] == best && s_i[w] < bi)) { best = s_v[w]; bi = s_i[w]; }
+        pv[blockIdx.y * gridDim.x + blockIdx.x] = best;
+        pi[blockIdx.y * gridDim.x + blockIdx.x] = bi;
+    }
+}
+
+// Greedy-search bookkeeping for sequence b given its next token: record it, test the stop rule (EOS / keyword ids, or the
+// max_new_tokens budget: HF stops AFTER appending the stop token), advance the device state, publish the token as the next
+// step's embedding-gather plan entry.  A finished sequence keeps its state frozen: later steps recompute harmlessly in place.
+__device__ __forceinline__ void accept_token(int tok, int* st, int* plan, int* ids_out, int ids_ld, const int* stop_ids, int n_stop, int* done) {
+    plan[0] = 0;
+    plan[1] = tok;
+    if (st[3]) return;
+    const int n = st[4];
+    ids_out[n] = tok;
+    st[4] = n + 1;
+    bool stop = (n + 1 >= st[5]) || (n + 1 >= ids_ld);
+    for (int i = 0; i < n_stop; ++i) stop = stop || (tok == stop_ids[i]);
+    if (stop) {
+        st[3] = 1;
+        atomicAdd(done, 1);
+    }
+}
+
+// stage 2 of the argmax (one workgroup per row) + accept.  first != 0: the tokens come from `tok_in` (the prefill's argmax)
+// instead of the partials, and the state is NOT advanced past the prompt (the first generated token sits at row pos).
+__global__ __launch_bounds__(128) void argmax_rows_accept_kernel(const float* __restrict__ pv, const int* __restrict__ pi, int np,
+                                                                 const int* __restrict__ tok_in, int* __restrict__ state, int* __restrict__ plan,
+                                                                 int* __restrict__ ids_out, int ids_ld, const int* __restrict__ stop_ids, int n_stop,
+                                                                 int* __restrict__ done) {
+    const int b = blockIdx.x;
+    __shared__ float s_v[2];
+    __shared__ int s_i[2];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    if (!tok_in) {
+        if ((int)threadIdx.x < np) { best = pv[b * np + threadIdx.x]; bi = pi[b * np + threadIdx.x]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+        }
+        if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = best; s_i[threadIdx.x >> 6] = bi; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int tok;
+        int* st = state + b * 8;
+        if (tok_in) {
+            tok = tok_in[b];
+        } else {
+            if (s_v[1] > best || (s_v[1] == best && s_i[1] < bi)) { best = s_v[1]; bi = s_i[1]; }
+            tok = bi;
+            // the step that produced this token consumed row `pos`: the NEXT fed token goes one row further
+            if (!st[3]) { st[0] += 1; st[1] += 1; }
+        }
+        accept_token(tok, st, plan + 2 * b, ids_out + (long long)b * ids_ld, ids_ld, stop_ids, n_stop, done);
+    }
+}
+
+// ---- KV relocation: packed prefill rows -> per-sequence decode slots ---------------------------------------------------
+// K:  dst[l][h][dst0 + t][:] = src[l][h][src0 + t][:]        (rows of 128 bf16, 16-B pieces)
+// VT: dst[l][c][dst0 + t]    = src[l][c][src0 + t]           (c = kv_head*128 + d; src0, dst0 multiples of 4 -> 8-B pieces)
+struct RelocSeq { int src0, dst0, len, pad; };
+__global__ __launch_bounds__(256) void kv_relocate_kernel(const uint16_t* __restrict__ ksrc, uint16_t* __restrict__ kdst, long long ks_layer,
+                                                          long long ks_head, long long kd_layer, long long kd_head,
+                                                          const uint16_t* __restrict__ vsrc, uint16_t* __restrict__ vdst, long long vs_layer,
+                                                          long long vs_row, long long vd_layer, long long vd_row, const RelocSeq* __restrict__ seqs,
+                                                          int n_kv, int n_layers) {
+    const RelocSeq s = seqs[blockIdx.y];
+    const int layer = blockIdx.z;
+    // K: n_kv * len rows of 16 pieces
+    const long long nk = (long long)n_kv * s.len * 16;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nk; i += (long long)gridDim.x * blockDim.x) {
+        const int pc = (int)(i & 15);
+        const long long r = i >> 4;
+        const int t = (int)(r % s.len), h = (int)(r / s.len);
+        *reinterpret_cast<uint4*>(kdst + layer * kd_layer + h * kd_head + (long long)(s.dst0 + t) * 128 + pc * 8) =
+            *reinterpret_cast<const uint4*>(ksrc + layer * ks_layer + h * ks_head + (long long)(s.src0 + t) * 128 + pc * 8);
+    }
+    // V^T: n_kv * 128 rows, ceil(len / 4) pieces of 4 columns (the tail piece may copy up to 3 columns of the source's padding)
+    const int pcs = (s.len + 3) / 4;
+    const long long nv = (long long)n_kv * 128 * pcs;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nv; i += (long long)gridDim.x * blockDim.x) {
+        const int pc = (int)(i % pcs);
+        const long long c = i / pcs;
+        *reinterpret_cast<uint2*>(vdst + layer * vd_layer + c * vd_row + s.dst0 + pc * 4) =
+            *reinterpret_cast<const uint2*>(vsrc + layer * vs_layer + c * vs_row + s.src0 + pc * 4);
+    }
+}
+
+}  // namespace fo1
+
+extern "C" {
+
+// Batched decode projection: C[M<=8, N] = epilogue(rmsnorm?(x) @ W^T), weights streamed once for all M rows.
+// mode 0: bias -> bf16 -> + residual;  mode 1: interleaved SwiGLU (C has N/2 columns);  mode 2: fused QKV:
+//   bias -> bf16 -> mRoPE (table row state[m][1]) -> rotated q rows to C[m, 0 : n_q*128), rotated K row to kcache[kv][state[m][0]],
+//   V to the V^T cache column state[m][0].
+int fo1_gemv_batch_bf16(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, int ldr, void* C, int ldc,
+                        int M, int N, int K, int mode, const void* norm_weight, float norm_eps, int n_q_heads, int n_kv_heads,
+                        const void* cos_table, const void* sin_table, const int32_t* state, void* kcache, long long kcache_head_stride,
+                        void* vtcache, long long vt_row_stride, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && W && (C || mode == 2), "gemv_batch: NULL operand");
+    FO1_CHECK_ARG(M >= 1 && M <= 8 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "gemv_batch: bad shape M=%d N=%d K=%d", M, N, K);
+    FO1_CHECK_ARG(mode >= 0 && mode <= 2, "gemv_batch: mode %d", mode);
+    FO1_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)norm_weight & 15) == 0, "gemv_batch: misaligned operand");
+    if (mode == 1) FO1_CHECK_ARG(N % 32 == 0 && residual == nullptr, "gemv_batch: SwiGLU needs N %% 32 == 0 and no residual");
+    if (mode == 2) {
+        FO1_CHECK_ARG(n_q_heads > 0 && n_kv_heads > 0 && N == (n_q_heads + 2 * n_kv_heads) * 128, "gemv_batch: QKV mode needs N = (n_q + 2 n_kv) * 128");
+        FO1_CHECK_ARG(cos_table && sin_table && state && kcache && vtcache && C && residual == nullptr, "gemv_batch: QKV mode operands");
+    }
+    GemvBParams p;
+    p.X = (const uint16_t*)x; p.W = (const uint16_t*)W; p.bias = (const uint16_t*)bias; p.res = (const uint16_t*)residual; p.C = (uint16_t*)C;
+    p.M = M; p.N = N; p.K = K; p.ldx = ldx; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+    p.norm_w = (const uint16_t*)norm_weight; p.norm_eps = norm_eps; p.kp_chunks = 0;
+    p.n_q = n_q_heads; p.n_kv = n_kv_heads; p.cos_t = (const uint16_t*)cos_table; p.sin_t = (const uint16_t*)sin_table; p.state = (const int*)state;
+    p.kcache = (uint16_t*)kcache; p.kc_head_stride = kcache_head_stride; p.vtcache = (uint16_t*)vtcache; p.vt_row_stride = vt_row_stride;
+    return gemv_b_any(p, mode, (hipStream_t)stream);
+}
+
+// Greedy pick for B logits rows + the on-device bookkeeping of one decode step (see accept_token).
+// logits == NULL: accept `first_tokens` (int32[B], the prefill's argmax) without advancing the positions.
+// scratch: 2 * 128 * B * 4 bytes.  plan: int32[B][2] gather plan for the next step's embedding rows.  done: int32 counter of
+// finished sequences (never reset here).
+int fo1_decode_argmax_accept(const void* logits, long long ld_logits, int n_vocab, int B, const int32_t* first_tokens, int32_t* state,
+                             int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids, int n_stop, int32_t* done, void* scratch,
+                             void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(state && plan && ids_out && done && B >= 1 && B <= 64 && ids_ld > 0 && n_stop >= 0 && (n_stop == 0 || stop_ids), "decode_accept: bad arguments");
+    FO1_CHECK_ARG((logits != nullptr) != (first_tokens != nullptr), "decode_accept: exactly one of logits / first_tokens");
+    hipStream_t st = (hipStream_t)stream;
+    float* pv = (float*)scratch;
+    int* pi = (int*)(pv + 128 * B);
+    if (logits) {
+        FO1_CHECK_ARG(scratch && n_vocab > 0, "decode_accept: scratch / vocab");
+        FO1_LAUNCH("argmax_rows", (double)B * n_vocab * 2.0, argmax_rows_partial_kernel, dim3(128, B), dim3(256), 0, st, (const uint16_t*)logits,
+                   ld_logits, n_vocab, pv, pi);
+    }
+    FO1_LAUNCH("argmax_accept", 1024.0 * B, argmax_rows_accept_kernel, dim3(B), dim3(128), 0, st, (const float*)pv, (const int*)pi, 128,
+               (const int*)first_tokens, (int*)state, (int*)plan, (int*)ids_out, ids_ld, (const int*)stop_ids, n_stop, (int*)done);
+    return FO1_OK;
+}
+
+// Copies every sequence's K rows and V^T columns from the packed prefill positions to its decode slot, all layers, one launch.
+// seqs: device int32[B][4] = {src0, dst0, len, 0}; src0 and dst0 multiples of 4.
+int fo1_kv_relocate(const void* ksrc, void* kdst, long long ks_layer, long long ks_head, long long kd_layer, long long kd_head,
+                    const void* vsrc, void* vdst, long long vs_layer, long long vs_row, long long vd_layer, long long vd_row,
+                    const int32_t* seqs, int B, int max_len, int n_kv_heads, int n_layers, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(ksrc && kdst && vsrc && vdst && seqs && B >= 1 && n_kv_heads >= 1 && n_layers >= 1 && max_len >= 1, "kv_relocate: bad arguments");
+    const long long work = (long long)n_kv_heads * max_len * 16;
+    int gx = (int)((work + 255) / 256);
+    if (gx > 64) gx = 64;
+    FO1_LAUNCH("kv_relocate", (double)B * n_layers * n_kv_heads * max_len * 128 * 8.0, kv_relocate_kernel, dim3(gx, B, n_layers), dim3(256), 0,
+               (hipStream_t)stream, (const uint16_t*)ksrc, (uint16_t*)kdst, ks_layer, ks_head, kd_layer, kd_head, (const uint16_t*)vsrc,
+               (uint16_t*)vdst, vs_layer, vs_row, vd_layer, vd_row, (const RelocSeq*)seqs, n_kv_heads, n_layers);
+    return FO1_OK;
+}
+
+}  // extern "C"

@@ -838,6 +838,171 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
     return FO1_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Same 256 x 256 x 64 tile, same LDS image and DMA groups as gemm_bt_p8_kernel, but TWO fat phases per K tile instead of four:
+//     phase X: quadrants (a0,b0) (a0,b1): ds_read A0 (8) + B0 + B1 (8, kept in registers for phase Y)  | 16 MFMAs
+//     phase Y: quadrants (a1,b0) (a1,b1): ds_read A1 (8)                                               | 16 MFMAs
+// and the LDS-DMA prefetch is issued INSIDE the MFMA segments (one group after every fourth MFMA: a DMA piece costs ~60 cycles
+// between MFMAs vs 100-185 in a segment full of ds_reads), so a load segment is ds_reads only and stays well under the 512 cycles
+// of its partner's MFMA segment.  Half the barriers (4 per K tile), 24 instead of 28 fragment reads.
+//   MFMA-X(t) stages B1, A1 of tile t+1 -> other buffer;  MFMA-Y(t) stages A0, B0 of tile t+2 -> this buffer
+//   (each slot's last ds_read — by either wave half — lies at least one barrier earlier)
+//   waits: end of load-Y(t): vmcnt(2)  -> A0, B0, B1 of tile t+1 landed (its A1 pair may still fly)
+//          end of load-X(t): vmcnt(4)  -> A1 of tile t landed (A0, B0 of tile t+1, issued in MFMA-Y(t-1), may still fly)
+//   and each wait sits one barrier before the first read it guards for EITHER half (the lagging half waits one segment later
+//   than the leading one and still a barrier ahead of the leading half's read).
+// ------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int GROUP = 16384, BUFSZ = 4 * GROUP;       // A0 | A1 | B0 | B1
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUFSZ]
+
+    int tm, tn;
+    tile_coords_grouped(p, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = wave >= 4;
+    const long long bz = blockIdx.y;
+    const uint16_t* A = p.A + bz * p.sA;
+    const uint16_t* W = p.W + bz * p.sW;
+
+    const uint16_t* src[4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = wave * 16 + i * 8 + (lane >> 3);
+            const int cs = ((lane & 7) ^ ((lr >> 1) & 7)) * 8;
+            if (g < 2) {
+                int gm = m0 + (lr >> 6) * 128 + g * 64 + (lr & 63);
+                gm = gm < p.M ? gm : p.M - 1;
+                src[g][i] = A + (long long)gm * p.lda + cs;
+            } else {
+                int gn = n0 + (lr >> 5) * 64 + (g - 2) * 32 + (lr & 31);
+                gn = gn < p.N ? gn : p.N - 1;
+                src[g][i] = W + (long long)gn * p.ldw + cs;
+            }
+        }
+    const int nk_all = p.K / BK;
+    const int kt0 = blockIdx.z * p.kper;
+    const int nk = min(nk_all - kt0, p.kper);
+    auto stage = [&](int g, int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* dst = smem + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;
+            const uint16_t* s = (g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i]) + (long long)(kt0 + kt) * BK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    const int hi = lane >> 5;
+    int a_off[2], a_sw[2];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+        const int lr = wm * 64 + fm * 32 + (lane & 31);
+        a_off[fm] = lr * 128;
+        a_sw[fm] = (lr >> 1) & 7;
+    }
+    const int b_lr = wn * 32 + (lane & 31);
+    const int b_off = b_lr * 128, b_sw = (b_lr >> 1) & 7;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 areg[2][4], breg[2][4];
+
+    // prologue: tile 0 complete; A0, B0 of tile 1 in flight (its B1, A1 are issued in MFMA-X(0))
+    stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+    if (nk > 1) {
+        stage(0, 1, 1); stage(2, 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    FO1_P8_BARRIER();
+    if (late) FO1_P8_BARRIER();
+
+    auto tile = [&](auto BUFC, int t) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const char* base = smem + BUF * BUFSZ;
+        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        auto loadA = [&](int h) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int fm = 0; fm < 2; ++fm)
+                    areg[fm][ks] = *reinterpret_cast<const bf16x8*>(base + h * GROUP + a_off[fm] + (((ks * 2 + hi) ^ a_sw[fm]) << 4));
+        };
+        auto loadB = [&](int h) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                breg[h][ks] = *reinterpret_cast<const bf16x8*>(base + (2 + h) * GROUP + b_off + (((ks * 2 + hi) ^ b_sw) << 4));
+        };
+        auto end_load = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            FO1_P8_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto end_mfma = [&](bool last) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(last && late)) FO1_P8_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#define FO1_P4_MFMA4(AH, KS)                                                                                                       \
+    acc[(AH) * 2 + 0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[0][KS], areg[0][KS], acc[(AH) * 2 + 0][0], 0, 0, 0);       \
+    acc[(AH) * 2 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[0][KS], areg[1][KS], acc[(AH) * 2 + 1][0], 0, 0, 0);       \
+    acc[(AH) * 2 + 0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[1][KS], areg[0][KS], acc[(AH) * 2 + 0][1], 0, 0, 0);       \
+    acc[(AH) * 2 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[1][KS], areg[1][KS], acc[(AH) * 2 + 1][1], 0, 0, 0);
+        // ---- phase X ----
+        loadB(0);
+        loadB(1);
+        loadA(0);
+        // A1 of this tile (issued in MFMA-X(t-1)) must have landed before load-Y; only MFMA-Y(t-1)'s A0, B0 of tile t+1 are newer
+        if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        end_load();
+        __builtin_amdgcn_s_setprio(1);
+        FO1_P4_MFMA4(0, 0)
+        if (more1) stage(3, t + 1, BUF ^ 1);
+        FO1_P4_MFMA4(0, 1)
+        FO1_P4_MFMA4(0, 2)
+        if (more1) stage(1, t + 1, BUF ^ 1);
+        FO1_P4_MFMA4(0, 3)
+        __builtin_amdgcn_s_setprio(0);
+        end_mfma(false);
+        // ---- phase Y ----
+        loadA(1);
+        if (more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        end_load();
+        __builtin_amdgcn_s_setprio(1);
+        FO1_P4_MFMA4(1, 0)
+        if (more2) stage(0, t + 2, BUF);
+        FO1_P4_MFMA4(1, 1)
+        FO1_P4_MFMA4(1, 2)
+        if (more2) stage(2, t + 2, BUF);
+        FO1_P4_MFMA4(1, 3)
+        __builtin_amdgcn_s_setprio(0);
+        end_mfma(!more1);
+#undef FO1_P4_MFMA4
+    };
+    for (int t = 0; t < nk; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
+}
+
+static int g_gemm_big_sched = 1;   // 256x256 kernel schedule: 0 = four phases per K tile (p8), 1 = two fat phases with DMA issued between MFMAs (p4, default: +3..10 % measured, profiles/r02_gemm_bench_p8_v2.log)
+
 // 256 x 256 ping-pong kernel (gemm_bt_p8_kernel)
 static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
     p.tiles_m = cdiv(p.M, 256);
@@ -861,6 +1026,23 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         attr_done = true;
     }
     const int epi = p.splits > 1 ? 4 : p.act;
+    if (g_gemm_big_sched == 1) {
+        static bool attr4 = false;
+        if (!attr4) {
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+            attr4 = true;
+        }
+        const char* n4 = (profile_enabled() && g_gemm_profile_shapes) ? name : "gemm_bt_p4<256,256>";
+        if (epi == 0) FO1_LAUNCH(n4, flops, gemm_bt_p4_kernel<0>, grid, dim3(512), smem, st, p);
+        else if (epi == 1) FO1_LAUNCH(n4, flops, gemm_bt_p4_kernel<1>, grid, dim3(512), smem, st, p);
+        else if (epi == 2) FO1_LAUNCH(n4, flops, gemm_bt_p4_kernel<2>, grid, dim3(512), smem, st, p);
+        else if (epi == 3) FO1_LAUNCH(n4, flops, gemm_bt_p4_kernel<3>, grid, dim3(512), smem, st, p);
+        else FO1_LAUNCH(n4, flops, gemm_bt_p4_kernel<4>, grid, dim3(512), smem, st, p);
+    } else
     if (epi == 0) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<0>, grid, dim3(512), smem, st, p);
     else if (epi == 1) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<1>, grid, dim3(512), smem, st, p);
     else if (epi == 2) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<2>, grid, dim3(512), smem, st, p);
@@ -967,9 +1149,11 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         tile = (t128 >= 768 && nk >= 16) ? 1 : (t64x128 >= 512 ? 2 : 3);   // shallow K (DaViT stage 0, K=256): 64x128 wins
         if (glds && nk >= 16 && (long long)cdiv(p.M, 128) * cdiv(p.N, 256) * batch >= 1024) tile = 4;
         if (splits == 0 && can_split && nk >= 64 && t64x128 < 512) tile = 2;
-        // large M (batched prefill): the 256 x 256 ping-pong kernel once its tiles fill >= 80 % of the rounds they occupy
+        // large M (batched prefill): the 256 x 256 ping-pong kernel once its tiles fill >= 60 % of the rounds they occupy and at
+        // least half the CUs (measured, profiles/r02_gemm_bench_p8_v1.log: LLM o/down at 168 tiles 760 / 1007 TF vs 667 / 684 for the
+        // best small tile; merger 260 tiles = 51 % of two rounds loses, 659 vs 894)
         const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256) * batch;
-        if (glds && nk >= 8 && p.M >= 1024 && t256 >= 205 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.8) tile = 5;
+        if (glds && nk >= 8 && p.M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) tile = 5;
     }
     p.splits = 1;
     p.kper = nk + 1;
@@ -1018,6 +1202,12 @@ int fo1_gemm_set_variant(int staging, int tile) {
     if (staging < 0 || staging > 6 || staging == 5 || tile < 0 || tile > 5) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
     fo1::g_gemm_variant = staging;
     fo1::g_gemm_tile = tile;
+    return FO1_OK;
+}
+
+int fo1_gemm_set_big_schedule(int sched) {
+    if (sched < 0 || sched > 1) return fo1::set_err(FO1_ERR_ARG, "gemm: bad 256x256 schedule %d", sched);
+    fo1::g_gemm_big_sched = sched;
     return FO1_OK;
 }
 

@@ -50,6 +50,7 @@ SIGNATURES = {
                                  c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fo1_gemm_set_variant": (c_int, [c_int, c_int]),
     "fo1_gemm_set_splitk": (c_int, [c_int]),
+    "fo1_gemm_set_big_schedule": (c_int, [c_int]),
     "fo1_gemm_set_gemv": (c_int, [c_int]),
     "fo1_gemm_set_debug": (c_int, [c_int]),
     "fo1_gemm_profile_shapes": (c_int, [c_int]),

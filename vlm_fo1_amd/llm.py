@@ -264,6 +264,7 @@ class QwenLLM:
         """embeds [L, d] bf16 device, pos [3, L] host -> (final-norm last hidden [1, d], logits [1, V], next id tensor).
         `tables` = device (cos, sin) [L, head_dim] bf16 when the caller already uploaded them (graph replay)."""
         c = self.cfg
+        self.reserve(embeds.shape[0])
         if tables is None:
             cos, sin = mrope_tables(pos, c.head_dim, c.rope_theta, c.mrope_section)
             cos, sin = cos.to(self.dev), sin.to(self.dev)
@@ -390,7 +391,7 @@ class QwenLLM:
         if token_id is not None:
             self.dplan.view(-1)[1:2].copy_(token_id.to(torch.int32).view(1), non_blocking=True)
         if self._dgraph is None:
-            with ops.graph_lock.capture():   # exclusive (see ops._CaptureLock)
+            with ops.graph_lock.capture(), torch.inference_mode(False):   # exclusive (see ops._CaptureLock); mode: see FO1Engine._capture
                 snap = self.dstate.clone()
                 plan = self.dplan.clone()
                 s = torch.cuda.Stream()

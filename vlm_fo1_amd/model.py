@@ -302,7 +302,10 @@ class FO1Engine:
         return outs
 
     def _capture(self, key, pix, auxs, boxes, host, meta):
-        with ops.graph_lock.capture():   # exclusive: no other thread captures or launches meanwhile
+        # Captures always run with inference mode OFF: the CUDA generator's graph bookkeeping tensors are created by the first live
+        # capture and updated in place by later ones — if the first ran under the caller's torch.inference_mode() (the reference's
+        # inference.py:46) a later capture outside it fails ("Inplace update to inference tensor outside InferenceMode").
+        with ops.graph_lock.capture(), torch.inference_mode(False):   # exclusive: no other thread captures or launches meanwhile
             # static input buffers must be ordinary tensors even when the caller runs under torch.inference_mode()
             # (the reference's inference.py:46 does): they are updated in place later
             with torch.inference_mode(False):
