@@ -362,7 +362,36 @@ def main():
             td = (time.perf_counter() - td) / K
         dec = dict(ms_per_token=round(td * 1e3, 3), tokens_per_sec=round(1.0 / td, 1), new_tokens_timed=K,
                    weight_stream_floor_ms=round(6.2e9 / 8e12 * 1e3, 3),
-                   images_per_sec_with_64_token_answer=round(1.0 / (single["ms_per_image"] * 1e-3 + 64 * td), 2))
+                   images_per_sec_with_64_token_answer=round(1.0 / (single["ms_per_image"] * 1e-3 + 64 * td), 2),
+                   note="one sequence at a time, host reads every token (the round-1 path)")
+        # batched decode: the sequences of one packed prefill advance together, weights streamed once per step, stop rule on the device
+        Bd = min(B, 8)
+        if use_graph:
+            eng = pipe.eng
+            reqs = pipe.requests[:Bd]
+            eng.prefill_batch(reqs, use_graph=True)
+            eng.prefill_batch(reqs, use_graph=True)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(5):
+                eng.prefill_batch(reqs, use_graph=True)
+            torch.cuda.synchronize()
+            t_pref = (time.perf_counter() - tp) / 5
+            d = eng._decoder()
+            hp = eng._last_batch
+            d.start(hp["seqs"], hp["delta"], eng._last_next_tokens[:Bd], 4096, ())
+            for _ in range(4):
+                d.step(True)
+            torch.cuda.synchronize()
+            tb = time.perf_counter()
+            for _ in range(K):
+                d.step(True)
+            torch.cuda.synchronize()
+            tb = (time.perf_counter() - tb) / K
+            dec["batched"] = dict(sequences=Bd, ms_per_step=round(tb * 1e3, 3), tokens_per_sec=round(Bd / tb, 1),
+                                  prefill_pass_ms=round(t_pref * 1e3, 3),
+                                  images_per_sec_with_64_token_answer=round(Bd / (t_pref + 64 * tb), 2),
+                                  launches_per_layer=5, note="one pass at a time: packed prefill of the batch, then 64 batched decode steps")
 
     # ---- host-side preprocessing of one image (SURVEY 8d "preprocess (CPU)" stage, 8f rank 2): not part of `value` ----
     prep = None

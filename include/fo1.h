@@ -277,6 +277,40 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Batched greedy decode: B <= 8 sequences advance one token per step through ONE stream of the weights, and
+ * every position-dependent quantity lives in device memory, so a single captured hipGraph serves every step.
+ * Reference: decode fast path omchat_qwen2_5_vl.py:143-155, positions modeling_qwen2_5_vl.py:1848-1860, stop rule
+ * mm_utils.py:137-181 + HF greedy search (stop AFTER appending an EOS / keyword id, or at max_new_tokens).
+ *   state: int32[B][8] = { pos, rope_row, kv_start, finished, n_gen, max_new, -, - }
+ *     pos = cache row the fed token's K row / V^T column is written to; keys attended = [kv_start, pos];
+ *     rope_row = row of the [positions, 128] mRoPE tables (cache position + rope delta).
+ *   fo1_gemv_batch_bf16            C[M<=8,N] = epilogue(rmsnorm?(x) W^T): mode 0 bias/residual, 1 interleaved SwiGLU,
+ *                                  2 fused QKV (bias -> bf16 -> mRoPE -> q rows out, K row + V^T column appended at state.pos)
+ *   fo1_attention_decode_batch_bf16  split-KV attention of B one-token queries against their slots
+ *   fo1_decode_argmax_accept       greedy pick per logits row + on-device accept: record id, stop check, advance state,
+ *                                  next step's embedding-gather plan
+ *   fo1_kv_relocate                packed prefill rows -> per-sequence decode slots, all layers in one launch
+ * ---------------------------------------------------------------------- */
+int fo1_gemv_batch_bf16(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, int ldr,
+                        void* C, int ldc, int M, int N, int K, int mode, const void* norm_weight, float norm_eps,
+                        int n_q_heads, int n_kv_heads, const void* cos_table, const void* sin_table,
+                        const int32_t* state, void* kcache, long long kcache_head_stride, void* vtcache,
+                        long long vt_row_stride, void* stream);
+size_t fo1_attention_decode_batch_workspace_bytes(int max_kv_len, int n_kv_heads, int head_dim, int batch);
+int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const void* kcache, long long k_tok_stride,
+                                    long long k_head_stride, const void* vtcache, long long vt_row_stride, void* out,
+                                    long long out_seq_stride, const int32_t* state, int batch, int max_kv_len,
+                                    int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace,
+                                    size_t workspace_bytes, void* stream);
+int fo1_decode_argmax_accept(const void* logits, long long ld_logits, int n_vocab, int B, const int32_t* first_tokens,
+                             int32_t* state, int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids,
+                             int n_stop, int32_t* done, void* scratch, void* stream);
+int fo1_kv_relocate(const void* ksrc, void* kdst, long long ks_layer, long long ks_head, long long kd_layer,
+                    long long kd_head, const void* vsrc, void* vdst, long long vs_layer, long long vs_row,
+                    long long vd_layer, long long vd_row, const int32_t* seqs, int B, int max_len, int n_kv_heads,
+                    int n_layers, void* stream);
+
+/* ------------------------------------------------------------------------
  * Image preprocessing, device side  
  * Replaces, after the host's PIL decode + bicubic resize, the rescale / normalise / layout work of
  *   Qwen2VLImageProcessor (qwen2_5_vl_encoder.py:206-212 -> pixel_values [S, 1176], patches in 2x2 merge-block order,

@@ -16,7 +16,7 @@ SHAPES = [
     ("fpn3x3_l0", B * 25024, 512, 4608), ("merger1", B * 391, 5120, 5120),
     ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192),
 ]
-VARIANTS = [("auto", 0, 0, 0, 0), ("p8", 0, 5, 1, 0), ("p4", 0, 5, 1, 1)]
+VARIANTS = [("p4_frag_epi", 0, 5, 1, 3), ("p4_coal_epi", 0, 5, 1, 1)]
 res = []
 for name, M, N, K in SHAPES:
     a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()

@@ -1,0 +1,7 @@
+#!/bin/bash
+OUT=$(pwd)/gpurun_out/r02_run8; mkdir -p $OUT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 900 python -m pytest tests/test_batched_decode_gpu.py tests/test_ops_gpu.py -k "p8 or batch" -m gpu -q --timeout 800 > $OUT/pytest.log 2>&1; tail -12 $OUT/pytest.log
+timeout 600 python scripts/decode_batch_profile.py 8 > $OUT/decode_b8.log 2>&1; grep -v amdgpu $OUT/decode_b8.log
+timeout 600 python scripts/decode_batch_profile.py 1 > $OUT/decode_b1.log 2>&1; grep -v amdgpu $OUT/decode_b1.log
+timeout 900 python scripts/gemm_bench_p8.py $OUT/gemm_bench.json 8 > $OUT/gemm_bench.log 2>&1; grep -v amdgpu $OUT/gemm_bench.log

@@ -458,9 +458,10 @@ P8_SHAPES = [
 ]
 
 
-@pytest.mark.parametrize("sched", [0, 1])
+@pytest.mark.parametrize("sched", [0, 1, 3])
 def test_gemm_p8_256x256(sched):
-    """sched 0: four phases per K tile; sched 1: two fat phases with the LDS-DMA issued between MFMAs (gemm_bt_p4_kernel)."""
+    """sched bit 0: 0 = four phases per K tile, 1 = two fat phases with the LDS-DMA issued between MFMAs (gemm_bt_p4_kernel);
+    bit 1 set = fragment-shaped epilogue stores instead of the LDS-staged coalesced epilogue."""
     from vlm_fo1_amd import lib as L, ops
     torch.manual_seed(55)
     try:
@@ -489,7 +490,7 @@ def test_gemm_p8_256x256(sched):
         L.load().fo1_gemm_set_big_schedule(1)
 
 
-@pytest.mark.parametrize("sched", [0, 1])
+@pytest.mark.parametrize("sched", [0, 1, 3])
 def test_gemm_p8_swiglu_and_one_hot(sched):
     """(a) the interleaved-SwiGLU epilogue on 32x32 fragments against the unfused reference; (b) an A = one-hot-rows GEMM whose exact
     answer is a row of W: catches any row/column or k-chunk mix-up exactly (no tolerance)."""

@@ -96,8 +96,12 @@ def load_pretrained_model(model_path, load_8bit=False, load_4bit=False, device="
     print(f"Loading weights from {model_path} into the MI355X engine ...")
     model = build_model(config, read_checkpoint(model_path), device, gen_cfg)
     primary = Qwen2VLPatchProcessor(min_pixels=56 * 56, max_pixels=2048 * 2048)            # qwen2_5_vl_encoder.py:179,210
-    aux = CLIPStyleAuxProcessor(size=config.get("aux_image_size", 768),                      # builder.py:65-75
-                                resize_mode=config.get("aux_image_aspect_ratio", "squash"))
+    # The reference builds its CLIPImageProcessor from the module-level img_cfg (davit/configs.py:139-152): the squash size is
+    # ALWAYS 768 x 768 — config.aux_image_size only sets DavitConfig.image_size (davit_aux_encoder.py:41-50) — and a config without
+    # aux_image_aspect_ratio fails at builder.py:70 (plain attribute access), which is reproduced here instead of guessing 'squash'.
+    if "aux_image_aspect_ratio" not in config:
+        raise AttributeError("config has no attribute 'aux_image_aspect_ratio' (reference builder.py:70 reads it without a default)")
+    aux = CLIPStyleAuxProcessor(size=768, resize_mode=config["aux_image_aspect_ratio"])
     # rescale / normalise / patch layout on the GPU from the resized uint8 image (bit-identical to the host path + bf16 cast);
     # FO1_HOST_PREPROCESS=1 keeps the reference's host-side fp32 tensors
     if os.environ.get("FO1_HOST_PREPROCESS") != "1":

@@ -120,32 +120,76 @@ class FO1ForCausalLM:
         return self._vt_aux
 
     # ---- generation ----
+    def _request(self, inputs, images, images_aux, image_grid_thws, bbox_list):
+        """One prepare_inputs(...) kwargs set -> the engine's request dict."""
+        if inputs is None or inputs.dim() != 2 or inputs.shape[0] != 1:
+            raise ValueError("generate: `inputs` must be a [1, L] id tensor (the reference drivers are batch-1)")
+        if not images or image_grid_thws is None:
+            raise ValueError("generate: the engine path needs one image (images / image_grid_thws)")
+        dev = self.device
+        grid = image_grid_thws[0].reshape(-1, 3)[0].tolist()
+        if grid[0] != 1:
+            raise NotImplementedError("video grids (t > 1) are outside the hot path")
+        if not images_aux:
+            raise ValueError("generate: images_aux is required (mm_use_region_index_token checkpoints)")
+        boxes = None
+        if bbox_list is not None and len(bbox_list) > 0 and bbox_list[0] is not None:
+            boxes = bbox_list[0].to(device=dev, dtype=torch.float32)
+        return dict(ids=inputs[0].tolist(), pix=images[0].to(device=dev, dtype=torch.bfloat16), grid=(grid[1], grid[2]),
+                    aux=images_aux[0].to(device=dev, dtype=torch.bfloat16), boxes=boxes)
+
+    def _device_stop_ids(self, stopping_criteria) -> Optional[List[int]]:
+        """EOS ids + the ids of single-token stop keywords (mm_utils.KeywordsStoppingCriteria with `<|im_end|>`): the stop rule the
+        batched decoder evaluates on the device.  None when a criterion cannot be expressed as 'last token in a set'."""
+        ids = list(self.config.eos_ids())
+        for c in (stopping_criteria or []):
+            kws = getattr(c, "keyword_ids", None)
+            if kws is None or any(int(k.numel()) != 1 for k in kws):
+                return None
+            ids += [int(k.reshape(-1)[0]) for k in kws]
+        return sorted(set(ids))
+
+    @torch.no_grad()
+    def generate_many(self, requests_kwargs: List[dict]) -> List[torch.LongTensor]:
+        """Greedy generation for several prepare_inputs(...) kwargs sets at once: the images go through ONE packed prefill pass and
+        the sequences decode together (weights streamed once per step, stop rule on the device).  Each result is [1, L_in + new]
+        exactly as generate() returns it.  max_new_tokens / stopping criteria are taken from the first request (the eval drivers use
+        the same for every item)."""
+        if not requests_kwargs:
+            return []
+        k0 = requests_kwargs[0]
+        if k0.get("do_sample") or (k0.get("temperature") not in (0, 0.0, None)):
+            raise NotImplementedError("sampling is not built; every reference caller decodes greedily (temperature=0)")
+        stop = self._device_stop_ids(k0.get("stopping_criteria"))
+        if stop is None:
+            return [self.generate(**kw) for kw in requests_kwargs]
+        reqs = [self._request(kw.get("inputs"), kw.get("images"), kw.get("images_aux"), kw.get("image_grid_thws"), kw.get("bbox_list"))
+                for kw in requests_kwargs]
+        new = self.engine.generate_batch(reqs, max_new_tokens=int(k0.get("max_new_tokens", 512)), stop_ids=stop, use_graph=self.use_graph)
+        out = []
+        for kw, ids in zip(requests_kwargs, new):
+            inp = kw["inputs"]
+            out.append(torch.cat([inp.to(self.device), torch.tensor([ids], dtype=inp.dtype, device=self.device)], dim=1).to(inp.device))
+        return out
+
     @torch.no_grad()
     def generate(self, inputs=None, images=None, images_aux=None, image_grid_thws=None, bbox_list=None, do_sample=False,
                  temperature=0.0, max_new_tokens=512, streamer=None, top_p=1.0, use_cache=True, stopping_criteria=None,
                  pad_token_id=None, **unused) -> torch.LongTensor:
         """Greedy decoding of one prompt.  Returns [1, L_in + new] like HF generate (the reference slices
-        `output_ids[0, inputs.shape[1]:]`, inference.py:47-48)."""
-        if inputs is None or inputs.dim() != 2 or inputs.shape[0] != 1:
-            raise ValueError("generate: `inputs` must be a [1, L] id tensor (the reference drivers are batch-1)")
+        `output_ids[0, inputs.shape[1]:]`, inference.py:47-48).  Without a streamer and with id-set stop criteria the whole loop
+        runs on the device (BatchDecoder, no per-token host read); otherwise tokens are handed to the host one by one."""
         if do_sample or (temperature not in (0, 0.0, None)):
             raise NotImplementedError("sampling is not built; every reference caller decodes greedily (temperature=0)")
-        if not images or image_grid_thws is None:
-            raise ValueError("generate: the engine path needs one image (images / image_grid_thws)")
+        req = self._request(inputs, images, images_aux, image_grid_thws, bbox_list)
         dev = self.device
-        ids = inputs[0].tolist()
-        pix = images[0].to(device=dev, dtype=torch.bfloat16)
-        grid = image_grid_thws[0].reshape(-1, 3)[0].tolist()
-        if grid[0] != 1:
-            raise NotImplementedError("video grids (t > 1) are outside the hot path")
-        aux = images_aux[0].to(device=dev, dtype=torch.bfloat16) if images_aux else None
-        boxes = None
-        if bbox_list is not None and len(bbox_list) > 0 and bbox_list[0] is not None:
-            boxes = bbox_list[0].to(device=dev, dtype=torch.float32)
-        if aux is None:
-            raise ValueError("generate: images_aux is required (mm_use_region_index_token checkpoints)")
+        stop = self._device_stop_ids(stopping_criteria) if streamer is None else None
+        if stop is not None:
+            ids = self.engine.generate_batch([req], max_new_tokens=int(max_new_tokens), stop_ids=stop, use_graph=self.use_graph)[0]
+            return torch.cat([inputs.to(dev), torch.tensor([ids], dtype=inputs.dtype, device=dev)], dim=1).to(inputs.device)
         eng = self.engine
-        out = eng.prefill(ids, pix, (grid[1], grid[2]), aux, boxes, use_graph=self.use_graph)
+        out = eng.prefill(req["ids"], req["pix"], req["grid"], req["aux"], req["boxes"], use_graph=self.use_graph)
+        eng.llm.reserve(eng.llm.kv_len + int(max_new_tokens))
         tok = out["next_token"]
         eos = set(self.config.eos_ids())
         all_ids = inputs.to(dev)
@@ -154,16 +198,17 @@ class FO1ForCausalLM:
         first = True
         if self.use_graph:
             eng.llm.sync_decode_state()
-        for _ in range(int(max_new_tokens)):
+        n_max = int(max_new_tokens)
+        for i in range(n_max):
             t = tok.to(torch.long).reshape(1, 1)
             all_ids = torch.cat([all_ids, t.to(all_ids.dtype)], dim=1)
             if streamer is not None:
                 streamer.put(t.cpu())
             tid = int(t.item())
-            stop = tid in eos
-            if not stop and stopping_criteria:
-                stop = any(bool(c(all_ids, None)) for c in stopping_criteria)
-            if stop:
+            stop_now = tid in eos
+            if not stop_now and stopping_criteria:
+                stop_now = any(bool(c(all_ids, None)) for c in stopping_criteria)
+            if stop_now or i + 1 == n_max:          # no decode step after the last token
                 break
             if self.use_graph:
                 _, tok = eng.llm.decode_step_graph(tok if first else None)

@@ -269,14 +269,41 @@ __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __
         n_keys = *dyn_kv_len;
     }
     const int n_valid = (n_keys + kv_chunk - 1) / kv_chunk;
-    float M = -INFINITY;
-    for (int s = 0; s < n_valid; ++s) M = fmaxf(M, part[(((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + HD]);
-    float num = 0.f, den = 0.f;
-    for (int s = 0; s < n_valid; ++s) {
+    // (m, l) of every chunk in one parallel load (a serial walk is 2 x n_valid dependent L2 round trips: ~6 us at 12 chunks)
+    __shared__ float s_m[256], s_l[256];
+    for (int s = d; s < min(n_valid, 256); s += HD) {
         const float* pr = part + (((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2);
-        const float w = __expf(pr[HD] - M);
-        num += w * pr[d];
-        den += w * pr[HD + 1];
+        s_m[s] = pr[HD];
+        s_l[s] = pr[HD + 1];
+    }
+    __syncthreads();
+    // n_valid <= 256 in every configuration built (slots <= 16384 rows); larger falls back to the serial walk below
+    float num = 0.f, den = 0.f;
+    if (n_valid <= 256) {
+        float M = -INFINITY;
+        for (int s = 0; s < n_valid; ++s) M = fmaxf(M, s_m[s]);
+        int s = 0;
+        for (; s + 4 <= n_valid; s += 4) {       // four independent loads in flight
+            float v[4], w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = part[(((long long)(s + j) * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + d];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { w[j] = __expf(s_m[s + j] - M); num += w[j] * v[j]; den += w[j] * s_l[s + j]; }
+        }
+        for (; s < n_valid; ++s) {
+            const float w = __expf(s_m[s] - M);
+            num += w * part[(((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + d];
+            den += w * s_l[s];
+        }
+    } else {
+        float M = -INFINITY;
+        for (int s = 0; s < n_valid; ++s) M = fmaxf(M, part[(((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + HD]);
+        for (int s = 0; s < n_valid; ++s) {
+            const float* pr = part + (((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2);
+            const float w = __expf(pr[HD] - M);
+            num += w * pr[d];
+            den += w * pr[HD + 1];
+        }
     }
     out[(long long)head * HD + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
 }

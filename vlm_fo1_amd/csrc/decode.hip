@@ -64,207 +64,216 @@ enum { GB_PLAIN = 0, GB_SWIGLU = 1, GB_QKV = 2 };
 
 // One unit = 8 weight rows:  plain: 8 consecutive output features;  SwiGLU: 4 gate rows + their up partners 16 rows further
 // (16-row interleaved weights);  QKV: q/k heads -> 4 dims d and their rotary partners d + 64, v head -> 8 consecutive dims.
-// KSPLIT: the 4 waves of a workgroup share ONE unit and split K (deep or few-row projections: every CU streams);
-// otherwise one unit per wave (many-row projections: x is staged once per 32 rows).
+// Lane mapping: lane l streams row (l >> 3) of the unit, 16-B chunk (l & 7) + 8 i of K — a load instruction covers 8 rows x 128
+// contiguous bytes — and keeps only MM accumulators; a row's 8 lanes are reduced with three DPP-friendly xor shuffles (a
+// lane-per-chunk mapping would need 6 shuffles for each of 8 x MM sums: 384 ds_bpermute per unit at MM = 8).
+// KSPLIT: the 4 waves of a workgroup share a unit and split K (few-row projections: every CU streams); otherwise one unit per
+// wave.  Workgroups are persistent over units (grid-stride): x is staged (and RMS-normalised) once per workgroup.
 template <int MM, int MODE, bool KSPLIT>
 __global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
-    constexpr int NR = 8, U = 2;
+    constexpr int NR = 8, U = KSPLIT ? 16 : 8;   // 16-B weight loads in flight per lane
     extern __shared__ __attribute__((aligned(16))) uint16_t sx[];   // [MM][kp_chunks * 8]
     __shared__ float s_red[4][NR * MM];
-    __shared__ float s_ss[4];
-    __shared__ float s_rstd[MM];
+    __shared__ float s_rstd[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int jrow = lane >> 3, kslot = lane & 7;
     const int kch = p.K >> 3;
-    const int unit = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
-    // ---- rows of this unit ----
-    int n_units, rows[NR];
     const int n_rope = (MODE == GB_QKV) ? (p.n_q + p.n_kv) * 16 : 0;
+    int n_units;
     if (MODE == GB_SWIGLU) n_units = p.N / 8;            // 4 features per unit
     else if (MODE == GB_QKV) n_units = n_rope + p.n_kv * 16;
     else n_units = (p.N + 7) / 8;
-    const bool unit_ok = unit < n_units;                  // KSPLIT: uniform per workgroup
-    {
-        const int u = unit_ok ? unit : n_units - 1;
-#pragma unroll
-        for (int j = 0; j < NR; ++j) {
-            int r;
-            if (MODE == GB_SWIGLU) { const int f = u * 4 + (j & 3); r = (f >> 4) * 32 + (f & 15) + (j >= 4 ? 16 : 0); }
-            else if (MODE == GB_QKV) {
-                if (u < n_rope) r = (u >> 4) * 128 + (u & 15) * 4 + (j & 3) + (j >= 4 ? 64 : 0);
-                else r = (p.n_q + p.n_kv) * 128 + (u - n_rope) * 8 + j;
-            } else r = u * 8 + j;
-            rows[j] = r < p.N ? r : p.N - 1;              // clamp (result discarded)
-        }
-    }
-    float acc[NR][MM];
-#pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int m = 0; m < MM; ++m) acc[r][m] = 0.f;
+    const bool single_piece = p.kp_chunks >= kch;
 
-    for (int kp0 = 0; kp0 < kch; kp0 += p.kp_chunks) {
-        const int kpn = min(p.kp_chunks, kch - kp0);
-        if (kp0 > 0) __syncthreads();                     // everyone is done with the previous K piece
-        for (int i = tid; i < MM * kpn; i += 256) {
-            const int m = i / kpn, c = i - m * kpn;
-            *reinterpret_cast<uint4*>(&sx[(m * p.kp_chunks + c) * 8]) =
-                m < p.M ? *reinterpret_cast<const uint4*>(p.X + (long long)m * p.ldx + (kp0 + c) * 8) : uint4{0, 0, 0, 0};
+    auto stage_x = [&](int kp0, int kpn) {
+        // thread t owns chunk columns c = t, t + 256, ... of ALL MM rows: MM independent 16-B loads in flight per batch (a
+        // row-major sweep is MM * K / 2048 dependent L2 round trips per thread: 8 x ~0.7 us at M = 8, K = 2048)
+        for (int c = tid; c < kpn; c += 256) {
+            uint4 t[MM];
+#pragma unroll
+            for (int m = 0; m < MM; ++m)
+                t[m] = m < p.M ? *reinterpret_cast<const uint4*>(p.X + (long long)m * p.ldx + (kp0 + c) * 8) : uint4{0, 0, 0, 0};
+#pragma unroll
+            for (int m = 0; m < MM; ++m) *reinterpret_cast<uint4*>(&sx[(m * p.kp_chunks + c) * 8]) = t[m];
         }
         __syncthreads();
         if (p.norm_w) {
             // fused Qwen2RMSNorm (modeling_qwen2_5_vl.py:126-140) on the staged rows (K fits one piece: checked by the host):
-            // fp32 variance, bf16(x * rstd), * weight -> bf16
-            for (int m = 0; m < MM; ++m) {
+            // fp32 variance, bf16(x * rstd), * weight -> bf16.  Wave w reduces rows w, w + 4: no workgroup barrier per row.
+            for (int m = wave; m < MM; m += 4) {
                 float ss = 0.f;
-                for (int c = tid; c < kpn; c += 256) {
+                for (int c = lane; c < kpn; c += 64) {
                     const uint4 v = *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]);
                     ss = dot8b(v, v, ss);
                 }
                 ss = gb_wave_sum(ss);
-                if (lane == 0) s_ss[wave] = ss;
-                __syncthreads();
-                if (tid == 0) s_rstd[m] = rsqrtf((s_ss[0] + s_ss[1] + s_ss[2] + s_ss[3]) / (float)p.K + p.norm_eps);
-                __syncthreads();
+                if (lane == 0) s_rstd[m] = rsqrtf(ss / (float)p.K + p.norm_eps);
             }
-            for (int i = tid; i < MM * kpn; i += 256) {
-                const int m = i / kpn, c = i - m * kpn;
-                const float rstd = s_rstd[m];
-                uint4 v = *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]);
+            __syncthreads();
+            for (int c = tid; c < kpn; c += 256) {       // one norm-weight load per chunk column, then LDS only
                 const uint4 w = *reinterpret_cast<const uint4*>(p.norm_w + c * 8);
-                uint4 o;
-                o.x = pack_bf16x2(bf16_lo(w.x) * gb_round(bf16_lo(v.x) * rstd), bf16_hi(w.x) * gb_round(bf16_hi(v.x) * rstd));
-                o.y = pack_bf16x2(bf16_lo(w.y) * gb_round(bf16_lo(v.y) * rstd), bf16_hi(w.y) * gb_round(bf16_hi(v.y) * rstd));
-                o.z = pack_bf16x2(bf16_lo(w.z) * gb_round(bf16_lo(v.z) * rstd), bf16_hi(w.z) * gb_round(bf16_hi(v.z) * rstd));
-                o.w = pack_bf16x2(bf16_lo(w.w) * gb_round(bf16_lo(v.w) * rstd), bf16_hi(w.w) * gb_round(bf16_hi(v.w) * rstd));
-                *reinterpret_cast<uint4*>(&sx[(m * p.kp_chunks + c) * 8]) = o;
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    const float rstd = s_rstd[m];
+                    const uint4 v = *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]);
+                    uint4 o;
+                    o.x = pack_bf16x2(bf16_lo(w.x) * gb_round(bf16_lo(v.x) * rstd), bf16_hi(w.x) * gb_round(bf16_hi(v.x) * rstd));
+                    o.y = pack_bf16x2(bf16_lo(w.y) * gb_round(bf16_lo(v.y) * rstd), bf16_hi(w.y) * gb_round(bf16_hi(v.y) * rstd));
+                    o.z = pack_bf16x2(bf16_lo(w.z) * gb_round(bf16_lo(v.z) * rstd), bf16_hi(w.z) * gb_round(bf16_hi(v.z) * rstd));
+                    o.w = pack_bf16x2(bf16_lo(w.w) * gb_round(bf16_lo(v.w) * rstd), bf16_hi(w.w) * gb_round(bf16_hi(v.w) * rstd));
+                    *reinterpret_cast<uint4*>(&sx[(m * p.kp_chunks + c) * 8]) = o;
+                }
             }
             __syncthreads();
         }
-        if (unit_ok) {
-            // this wave's chunk range inside the piece
-            const int kq = KSPLIT ? ((kpn + 3) / 4 + 63) / 64 * 64 : kpn;
-            const int c_begin = KSPLIT ? min(kpn, wave * kq) : 0;
-            const int c_end = KSPLIT ? min(kpn, c_begin + kq) : kpn;
-            for (int c0 = c_begin + lane; c0 < c_end; c0 += 64 * U) {
-                uint4 w[NR][U];
+    };
+    if (single_piece) stage_x(0, kch);          // the common case: x staged once for every unit of this workgroup
+
+    const int ustep = KSPLIT ? gridDim.x : gridDim.x * 4;
+    for (int unit = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave; KSPLIT ? unit < n_units : (unit - wave) < n_units; unit += ustep) {
+        const bool unit_ok = unit < n_units;    // non-KSPLIT: the trailing waves of the last workgroup idle but keep the barriers below
+        // ---- this lane's weight row ----
+        int row;
+        {
+            const int u = unit_ok ? unit : n_units - 1, j = jrow;
+            if (MODE == GB_SWIGLU) { const int f = u * 4 + (j & 3); row = (f >> 4) * 32 + (f & 15) + (j >= 4 ? 16 : 0); }
+            else if (MODE == GB_QKV) {
+                if (u < n_rope) row = (u >> 4) * 128 + (u & 15) * 4 + (j & 3) + (j >= 4 ? 64 : 0);
+                else row = (p.n_q + p.n_kv) * 128 + (u - n_rope) * 8 + j;
+            } else row = u * 8 + j;
+            row = row < p.N ? row : p.N - 1;     // clamp (result discarded)
+        }
+        const uint16_t* wrow = p.W + (long long)row * p.ldw;
+        float acc[MM];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = c0 + u * 64;
-                    const bool ok = c < c_end;
+        for (int m = 0; m < MM; ++m) acc[m] = 0.f;
+        for (int kp0 = 0; kp0 < kch; kp0 += p.kp_chunks) {
+            const int kpn = min(p.kp_chunks, kch - kp0);
+            if (!single_piece) {
+                __syncthreads();                 // everyone is done with the previous K piece
+                stage_x(kp0, kpn);
+            }
+            if (unit_ok) {
+                // this wave's chunk range inside the piece (multiples of 8: one chunk per lane of a row group)
+                const int kq = KSPLIT ? ((kpn + 3) / 4 + 7) / 8 * 8 : kpn;
+                const int c_begin = KSPLIT ? min(kpn, wave * kq) : 0;
+                const int c_end = KSPLIT ? min(kpn, c_begin + kq) : kpn;
+                for (int c0 = c_begin + kslot; c0 < c_end; c0 += 8 * U) {
+                    uint4 w[U];
 #pragma unroll
-                    for (int r = 0; r < NR; ++r)
-                        w[r][u] = ok ? load_nt16(p.W + (long long)rows[r] * p.ldw + (long long)(kp0 + c) * 8) : uint4{0, 0, 0, 0};
-                }
+                    for (int u = 0; u < U; ++u) {
+                        const int c = c0 + u * 8;
+                        w[u] = c < c_end ? load_nt16(wrow + (long long)(kp0 + c) * 8) : uint4{0, 0, 0, 0};
+                    }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int c = c0 + u * 64;
-                    if (c < c_end) {
+                    for (int u = 0; u < U; ++u) {
+                        const int c = c0 + u * 8;
+                        if (c < c_end) {
 #pragma unroll
-                        for (int m = 0; m < MM; ++m) {
-                            const uint4 xv = *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]);
-#pragma unroll
-                            for (int r = 0; r < NR; ++r) acc[r][m] = dot8b(w[r][u], xv, acc[r][m]);
+                            for (int m = 0; m < MM; ++m)
+                                acc[m] = dot8b(w[u], *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]), acc[m]);
                         }
                     }
                 }
             }
         }
-    }
-    // ---- reduce: every lane of a wave ends with the wave's sums; KSPLIT adds the 4 waves through LDS ----
+        // ---- reduce the 8 lanes of each row, then (KSPLIT) the 4 waves through LDS ----
 #pragma unroll
-    for (int r = 0; r < NR; ++r)
-#pragma unroll
-        for (int m = 0; m < MM; ++m) acc[r][m] = gb_wave_sum(acc[r][m]);
-    float* red = s_red[KSPLIT ? 0 : wave];   // the unit's NR*MM sums (fp32)
-    if (KSPLIT) {
-        if (lane == 0) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r)
-#pragma unroll
-                for (int m = 0; m < MM; ++m) s_red[wave][r * MM + m] = acc[r][m];
+        for (int m = 0; m < MM; ++m) {
+            acc[m] += __shfl_xor(acc[m], 1, 64);
+            acc[m] += __shfl_xor(acc[m], 2, 64);
+            acc[m] += __shfl_xor(acc[m], 4, 64);
         }
-        __syncthreads();
-        if (tid < NR * MM) {
-            const float t = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
-            s_red[0][tid] = t;      // each thread reads and writes only its own slot of row 0
-        }
-        __syncthreads();
-        if (wave != 0) return;
-    } else {
-        if (lane == 0) {
+        float* red = s_red[KSPLIT ? 0 : wave];   // the unit's NR*MM sums (fp32), index j * MM + m
+        if (KSPLIT) {
+            if (kslot == 0) {
 #pragma unroll
-            for (int r = 0; r < NR; ++r)
-#pragma unroll
-                for (int m = 0; m < MM; ++m) red[r * MM + m] = acc[r][m];
-        }
-        __builtin_amdgcn_wave_barrier();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    if (!unit_ok) return;
-    // ---- epilogue: lane -> (row slot j, sequence m) ----
-    if (MODE == GB_PLAIN) {
-        if (lane < NR * MM) {
-            const int j = lane / MM, m = lane - j * MM;
-            const int f = unit * 8 + j;
-            if (f < p.N && m < p.M) {
-                float v = red[j * MM + m];
-                if (p.bias) v += bf16_to_f32(p.bias[f]);
-                v = gb_round(v);
-                if (p.res) v += bf16_to_f32(p.res[(long long)m * p.ldr + f]);
-                p.C[(long long)m * p.ldc + f] = f32_to_bf16(v);
+                for (int m = 0; m < MM; ++m) s_red[wave][jrow * MM + m] = acc[m];
             }
-        }
-    } else if (MODE == GB_SWIGLU) {
-        if (lane < 4 * MM) {
-            const int j = lane / MM, m = lane - j * MM;
-            const int f = unit * 4 + j;
-            if (m < p.M) {
-                float g = red[j * MM + m], u = red[(4 + j) * MM + m];
-                if (p.bias) { g += bf16_to_f32(p.bias[rows[0] + j]); u += bf16_to_f32(p.bias[rows[0] + j + 16]); }
-                g = gb_round(g);
-                u = gb_round(u);
-                p.C[(long long)m * p.ldc + f] = f32_to_bf16(gb_round(g / (1.0f + expf(-g))) * u);
+            __syncthreads();
+            if (tid < NR * MM) {
+                const float t = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
+                s_red[0][tid] = t;      // each thread reads and writes only its own slot of row 0
             }
+            __syncthreads();
+        } else {
+            if (kslot == 0) {
+#pragma unroll
+                for (int m = 0; m < MM; ++m) red[jrow * MM + m] = acc[m];
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
-    } else {   // GB_QKV
-        if (unit < n_rope) {
-            if (lane < 4 * MM) {
-                const int j = lane / MM, m = lane - j * MM;
-                if (m < p.M) {
-                    const int head = unit >> 4, d = (unit & 15) * 4 + j;            // d < 64; partner d + 64
-                    const int ra = head * 128 + d, rb_ = ra + 64;
-                    float a = red[j * MM + m], b = red[(4 + j) * MM + m];
-                    if (p.bias) { a += bf16_to_f32(p.bias[ra]); b += bf16_to_f32(p.bias[rb_]); }
-                    a = gb_round(a);                                                 // the bf16 q/k the unfused path stores
-                    b = gb_round(b);
-                    const int* st = p.state + m * 8;
-                    const long long row = st[1];
-                    const float ca = bf16_to_f32(p.cos_t[row * 128 + d]), sa = bf16_to_f32(p.sin_t[row * 128 + d]);
-                    const float cb = bf16_to_f32(p.cos_t[row * 128 + d + 64]), sb = bf16_to_f32(p.sin_t[row * 128 + d + 64]);
-                    const uint16_t oa = f32_to_bf16(gb_round(a * ca) + gb_round(-b * sa));   // rotate_half, three bf16 roundings
-                    const uint16_t ob = f32_to_bf16(gb_round(b * cb) + gb_round(a * sb));
-                    if (head < p.n_q) {
-                        p.C[(long long)m * p.ldc + ra] = oa;
-                        p.C[(long long)m * p.ldc + rb_] = ob;
-                    } else {
-                        uint16_t* kc = p.kcache + (long long)(head - p.n_q) * p.kc_head_stride + (long long)st[0] * 128;
-                        kc[d] = oa;
-                        kc[d + 64] = ob;
+        if (unit_ok && (!KSPLIT || wave == 0)) {
+            // ---- epilogue: lane -> (row slot j, sequence m) ----
+            if (MODE == GB_PLAIN) {
+                if (lane < NR * MM) {
+                    const int j = lane / MM, m = lane - j * MM;
+                    const int f = unit * 8 + j;
+                    if (f < p.N && m < p.M) {
+                        float v = red[j * MM + m];
+                        if (p.bias) v += bf16_to_f32(p.bias[f]);
+                        v = gb_round(v);
+                        if (p.res) v += bf16_to_f32(p.res[(long long)m * p.ldr + f]);
+                        p.C[(long long)m * p.ldc + f] = f32_to_bf16(v);
+                    }
+                }
+            } else if (MODE == GB_SWIGLU) {
+                if (lane < 4 * MM) {
+                    const int j = lane / MM, m = lane - j * MM;
+                    const int f = unit * 4 + j;
+                    if (m < p.M) {
+                        const int grow = (f >> 4) * 32 + (f & 15);
+                        float g = red[j * MM + m], u = red[(4 + j) * MM + m];
+                        if (p.bias) { g += bf16_to_f32(p.bias[grow]); u += bf16_to_f32(p.bias[grow + 16]); }
+                        g = gb_round(g);
+                        u = gb_round(u);
+                        p.C[(long long)m * p.ldc + f] = f32_to_bf16(gb_round(g / (1.0f + expf(-g))) * u);
+                    }
+                }
+            } else {   // GB_QKV
+                if (unit < n_rope) {
+                    if (lane < 4 * MM) {
+                        const int j = lane / MM, m = lane - j * MM;
+                        if (m < p.M) {
+                            const int head = unit >> 4, d = (unit & 15) * 4 + j;            // d < 64; partner d + 64
+                            const int ra = head * 128 + d, rb_ = ra + 64;
+                            float a = red[j * MM + m], b = red[(4 + j) * MM + m];
+                            if (p.bias) { a += bf16_to_f32(p.bias[ra]); b += bf16_to_f32(p.bias[rb_]); }
+                            a = gb_round(a);                                                 // the bf16 q/k the unfused path stores
+                            b = gb_round(b);
+                            const int* st = p.state + m * 8;
+                            const long long trow = st[1];
+                            const float ca = bf16_to_f32(p.cos_t[trow * 128 + d]), sa = bf16_to_f32(p.sin_t[trow * 128 + d]);
+                            const float cb = bf16_to_f32(p.cos_t[trow * 128 + d + 64]), sb = bf16_to_f32(p.sin_t[trow * 128 + d + 64]);
+                            const uint16_t oa = f32_to_bf16(gb_round(a * ca) + gb_round(-b * sa));   // rotate_half, three bf16 roundings
+                            const uint16_t ob = f32_to_bf16(gb_round(b * cb) + gb_round(a * sb));
+                            if (head < p.n_q) {
+                                p.C[(long long)m * p.ldc + ra] = oa;
+                                p.C[(long long)m * p.ldc + rb_] = ob;
+                            } else {
+                                uint16_t* kc = p.kcache + (long long)(head - p.n_q) * p.kc_head_stride + (long long)st[0] * 128;
+                                kc[d] = oa;
+                                kc[d + 64] = ob;
+                            }
+                        }
+                    }
+                } else {
+                    if (lane < NR * MM) {
+                        const int j = lane / MM, m = lane - j * MM;
+                        if (m < p.M) {
+                            const int vrow = (unit - n_rope) * 8 + j;                        // kv_head * 128 + d
+                            float v = red[j * MM + m];
+                            if (p.bias) v += bf16_to_f32(p.bias[(p.n_q + p.n_kv) * 128 + vrow]);
+                            const int* st = p.state + m * 8;
+                            p.vtcache[(long long)vrow * p.vt_row_stride + st[0]] = f32_to_bf16(v);
+                        }
                     }
                 }
             }
-        } else {
-            if (lane < NR * MM) {
-                const int j = lane / MM, m = lane - j * MM;
-                if (m < p.M) {
-                    const int vrow = (unit - n_rope) * 8 + j;                        // kv_head * 128 + d
-                    float v = red[j * MM + m];
-                    if (p.bias) v += bf16_to_f32(p.bias[(p.n_q + p.n_kv) * 128 + vrow]);
-                    const int* st = p.state + m * 8;
-                    p.vtcache[(long long)vrow * p.vt_row_stride + st[0]] = f32_to_bf16(v);
-                }
-            }
         }
+        if (KSPLIT) __syncthreads();             // s_red is reused by the next unit
+        else { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     }
 }
 
@@ -276,9 +285,17 @@ static int launch_gemv_b(const GemvBParams& p, const char* name, int n_units, hi
         FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_batch_kernel<MM, MODE, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr = true;
     }
-    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_batch_kernel<MM, MODE, KS>), dim3(KS ? n_units : cdiv(n_units, 4)), dim3(256), smem, st, p);
+    // persistent workgroups (grid-stride over units): x is staged / normalised once per workgroup; <= 4 workgroups per CU
+    int grid = KS ? n_units : cdiv(n_units, 4);
+    if (grid > 512) {   // about two workgroups per CU, every wave the same number of units
+        const int per = cdiv(grid, 512);
+        grid = cdiv(grid, per);
+    }
+    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_batch_kernel<MM, MODE, KS>), dim3(grid), dim3(256), smem, st, p);
     return FO1_OK;
 }
+
+extern int g_gemv_profile_shapes;
 
 template <int MM>
 static int dispatch_gemv_b(GemvBParams& p, int mode, hipStream_t st) {
@@ -295,9 +312,15 @@ static int dispatch_gemv_b(GemvBParams& p, int mode, hipStream_t st) {
     else n_units = cdiv(p.N, 8);
     // every CU should stream: one unit per workgroup (K split over its 4 waves) unless that would make more than ~2048 workgroups
     const bool ks = n_units <= 1024;
-    if (mode == GB_SWIGLU) return ks ? launch_gemv_b<MM, GB_SWIGLU, true>(p, "gemv_batch_swiglu", n_units, st) : launch_gemv_b<MM, GB_SWIGLU, false>(p, "gemv_batch_swiglu", n_units, st);
-    if (mode == GB_QKV) return launch_gemv_b<MM, GB_QKV, true>(p, "gemv_batch_qkv", n_units, st);
-    return ks ? launch_gemv_b<MM, GB_PLAIN, true>(p, "gemv_batch", n_units, st) : launch_gemv_b<MM, GB_PLAIN, false>(p, "gemv_batch", n_units, st);
+    char pname[48];
+    const char* name = mode == GB_SWIGLU ? "gemv_batch_swiglu" : (mode == GB_QKV ? "gemv_batch_qkv" : "gemv_batch");
+    if (profile_enabled() && g_gemv_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemv_b m%d %dx%d mode%d ks%d", p.M, p.N, p.K, mode, (int)ks);
+        name = pname;
+    }
+    if (mode == GB_SWIGLU) return ks ? launch_gemv_b<MM, GB_SWIGLU, true>(p, name, n_units, st) : launch_gemv_b<MM, GB_SWIGLU, false>(p, name, n_units, st);
+    if (mode == GB_QKV) return launch_gemv_b<MM, GB_QKV, true>(p, name, n_units, st);
+    return ks ? launch_gemv_b<MM, GB_PLAIN, true>(p, name, n_units, st) : launch_gemv_b<MM, GB_PLAIN, false>(p, name, n_units, st);
 }
 
 static int gemv_b_any(GemvBParams& p, int mode, hipStream_t st) {

@@ -43,6 +43,7 @@ struct GemmParams {
     float* part;               // fp32 partials [splits][M][N] when splits > 1
     int stages;                // LDS ring depth: 2 = two-stage kernel, 3/4/6 = counted-vmcnt ring
     int debug;                 // ablation (bench only): 1 skip global loads after tile 0, 2 skip MFMA, 4 skip LDS reads + MFMA
+    int coal;                  // 256x256 kernels: epilogue staged through LDS and written as whole 128-byte row segments (16-B stores)
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3 };
@@ -648,6 +649,98 @@ __device__ __forceinline__ void epilogue32(const GemmParams& p, f32x16 (&acc)[MF
     }
 }
 
+// Coalesced epilogue of the 256 x 256 kernels: the wave's 128 x 64 output block goes through its own 16 KiB of the (now idle)
+// LDS image — bias / activation applied in registers, rows written as 8-byte pieces into a 128-B-per-row image whose 16-B slots
+// are XOR-swizzled with the row — and is read back row-wise, 16 B per lane, 8 lanes per row: every global store instruction
+// writes 8 whole 128-byte row segments (the fragment-shaped epilogue stores 8 B per lane to 32 different rows per instruction).
+// The residual is added in the row-wise phase from 16-B loads.  Same arithmetic and rounding points as epilogue32.
+template <int EPI>
+__device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16 (&acc)[4][2], char* region, int m_base, int n_base, int lane,
+                                                     long long offC, long long offR) {
+    const int mi = lane & 31, hi = lane >> 5, hi4 = hi * 4;
+    if constexpr (EPI == ACT_SWIGLU16) {
+        // 32 output columns per wave: 64-B rows, four 16-B slots swizzled with (row & 3)
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int r = mf * 32 + mi;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const int nb = n_base + nf * 32;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int f0 = g * 8 + hi4;
+                    float o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float gt = acc[mf][nf][g * 4 + t], up = acc[mf][nf][8 + g * 4 + t];
+                        if (p.bias && nb < p.N) { gt += bf16_to_f32(p.bias[nb + f0 + t]); up += bf16_to_f32(p.bias[nb + 16 + f0 + t]); }
+                        gt = round_bf16(gt);
+                        up = round_bf16(up);
+                        o[t] = round_bf16(gt / (1.0f + expf(-gt))) * up;
+                    }
+                    uint2 ov;
+                    ov.x = pack_bf16x2(o[0], o[1]);
+                    ov.y = pack_bf16x2(o[2], o[3]);
+                    const int q = nf * 2 + g;
+                    *reinterpret_cast<uint2*>(region + r * 64 + ((q ^ (r & 3)) << 4) + hi * 8) = ov;
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n_out = (n_base >> 1) + (lane & 3) * 8, No = p.N >> 1;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 16 + (lane >> 2), m = m_base + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(region + r * 64 + (((lane & 3) ^ (r & 3)) << 4));
+            if (m < p.M && n_out < No) *reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n_out) = v;
+        }
+    } else {
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int r = mf * 32 + mi;
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n0 = n_base + nf * 32 + g * 8 + hi4;
+                    float v[4] = {acc[mf][nf][g * 4 + 0], acc[mf][nf][g * 4 + 1], acc[mf][nf][g * 4 + 2], acc[mf][nf][g * 4 + 3]};
+                    if (p.bias && n0 < p.N) {
+                        const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + n0);
+                        v[0] += bf16_lo(bv.x); v[1] += bf16_hi(bv.x); v[2] += bf16_lo(bv.y); v[3] += bf16_hi(bv.y);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = round_bf16(v[t]);
+                    if constexpr (EPI != ACT_NONE) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = round_bf16(act_apply_t<EPI>(v[t]));
+                    }
+                    uint2 ov;
+                    ov.x = pack_bf16x2(v[0], v[1]);
+                    ov.y = pack_bf16x2(v[2], v[3]);
+                    const int q = nf * 4 + g;
+                    *reinterpret_cast<uint2*>(region + r * 128 + ((q ^ (r & 7)) << 4) + hi * 8) = ov;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const int n = n_base + (lane & 7) * 8;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 8 + (lane >> 3), m = m_base + r;
+            uint4 v = *reinterpret_cast<const uint4*>(region + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+            if (m < p.M && n < p.N) {
+                if (p.res) {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(p.res + offR + (long long)m * p.ldr + n);
+                    v.x = pack_bf16x2(bf16_lo(v.x) + bf16_lo(rv.x), bf16_hi(v.x) + bf16_hi(rv.x));
+                    v.y = pack_bf16x2(bf16_lo(v.y) + bf16_lo(rv.y), bf16_hi(v.y) + bf16_hi(rv.y));
+                    v.z = pack_bf16x2(bf16_lo(v.z) + bf16_lo(rv.z), bf16_hi(v.z) + bf16_hi(rv.z));
+                    v.w = pack_bf16x2(bf16_lo(v.w) + bf16_lo(rv.w), bf16_hi(v.w) + bf16_hi(rv.w));
+                }
+                *reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n) = v;
+            }
+        }
+    }
+}
+
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bt_p8_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, BK = 64;
@@ -795,6 +888,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p8_kernel(const GemmParams p) 
     for (int t = 0; t < nk; t += 2) {
         tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if constexpr (EPI != 4) {
+        if (p.coal) {   // every wave's LDS reads of the main loop are retired (the last load segment ended at a barrier this wave has passed)
+            epilogue32_coalesced<EPI>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR);
+            return;
+        }
     }
     epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
 }
@@ -998,9 +1097,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
     }
+    if constexpr (EPI != 4) {
+        if (p.coal) {   // every wave's LDS reads of the main loop are retired (the last load segment ended at a barrier this wave has passed)
+            epilogue32_coalesced<EPI>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR);
+            return;
+        }
+    }
     epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
 }
 
+static int g_gemm_coal = 1;        // 256x256 kernels: LDS-staged coalesced epilogue (0 = fragment-shaped stores, for A/B)
 static int g_gemm_big_sched = 1;   // 256x256 kernel schedule: 0 = four phases per K tile (p8), 1 = two fat phases with DMA issued between MFMAs (p4, default: +3..10 % measured, profiles/r02_gemm_bench_p8_v2.log)
 
 // 256 x 256 ping-pong kernel (gemm_bt_p8_kernel)
@@ -1016,6 +1122,11 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         name = pname;
     }
     constexpr int smem = 2 * 4 * 16384;
+    {
+        const int nc = p.act == ACT_SWIGLU16 ? p.N / 2 : p.N;
+        p.coal = g_gemm_coal && nc % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && p.sC % 8 == 0 &&
+                 (p.res == nullptr || (p.ldr % 8 == 0 && ((uintptr_t)p.res & 15) == 0 && p.sR % 8 == 0));
+    }
     static bool attr_done = false;
     if (!attr_done) {
         FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1206,8 +1317,10 @@ int fo1_gemm_set_variant(int staging, int tile) {
 }
 
 int fo1_gemm_set_big_schedule(int sched) {
-    if (sched < 0 || sched > 1) return fo1::set_err(FO1_ERR_ARG, "gemm: bad 256x256 schedule %d", sched);
-    fo1::g_gemm_big_sched = sched;
+    // bit 0: 0 = four phases per K tile, 1 = two fat phases;  bit 1 set = fragment-shaped (un-coalesced) epilogue stores
+    if (sched < 0 || sched > 3) return fo1::set_err(FO1_ERR_ARG, "gemm: bad 256x256 schedule %d", sched);
+    fo1::g_gemm_big_sched = sched & 1;
+    fo1::g_gemm_coal = (sched & 2) ? 0 : 1;
     return FO1_OK;
 }
 
@@ -1268,6 +1381,7 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
     p.C32 = out_f32 ? (float*)C : nullptr;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
     p.sA = p.sW = p.sC = p.sR = 0;
+    p.coal = 0;
     FO1_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "gemm: workspace must be 16-byte aligned");
     if (g_gemm_gemv && M <= 4 && !out_f32 && (size_t)(M > 2 ? 4 : M) * K * 2 <= 150 * 1024 && (act != 3 || N % 32 == 0))
         return gemv_dispatch(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, (hipStream_t)stream, nullptr, 0.f);

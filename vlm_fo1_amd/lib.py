@@ -90,6 +90,16 @@ SIGNATURES = {
     "fo1_pixel_shuffle2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_maxpool2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_nchw_to_hwc8_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fo1_gemv_batch_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong,
+                                    c_void_p]),
+    "fo1_attention_decode_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "fo1_attention_decode_batch_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p,
+                                                c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "fo1_decode_argmax_accept": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
+                                         c_void_p, c_void_p, c_void_p]),
+    "fo1_kv_relocate": (c_int, [c_void_p, c_void_p, c_longlong, c_longlong, c_longlong, c_longlong, c_void_p, c_void_p, c_longlong, c_longlong,
+                                c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_gather_rows_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int,
                                      c_int, c_void_p]),
 }

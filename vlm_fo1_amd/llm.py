@@ -424,3 +424,138 @@ class QwenLLM:
         logits = self._decode_device()
         self.kv_len += 1
         return None, logits, self.dplan.view(-1)[1:2].clone()
+
+
+class BatchDecoder:
+    """Greedy decode of up to 8 sequences at once: the weights are streamed ONCE per step for all sequences
+    (fo1_gemv_batch_bf16), 5 launches per layer, and the whole step — embedding gather, 36 layers, lm_head, argmax, stop check,
+    position bookkeeping — replays as one hipGraph with no host read inside the loop (the host polls a device-side `done` counter
+    every few steps).  Reference semantics: HF greedy search over the 1-token fast path of omchat_qwen2_5_vl.py:143-155;
+    positions = cache position + rope delta (modeling_qwen2_5_vl.py:1848-1860); a sequence stops AFTER its EOS / keyword id has
+    been appended, or at max_new_tokens (mm_utils.py:137-181, 640-654)."""
+    MAX_BATCH = 8
+    IDS_CAP = 4096          # generated ids kept per sequence (every reference caller uses max_new_tokens <= 4096)
+
+    def __init__(self, llm: QwenLLM):
+        self.llm = llm
+        dev = llm.dev
+        B = self.MAX_BATCH
+        # persistent buffers are updated in place for the life of the engine: ordinary tensors even when the first request arrives
+        # under the caller's torch.inference_mode() (the reference's inference.py:46)
+        with torch.inference_mode(False):
+            self.state = torch.zeros(B, 8, dtype=torch.int32, device=dev)
+            self.plan = torch.zeros(B, 2, dtype=torch.int32, device=dev)
+            self.ids = torch.zeros(B, self.IDS_CAP, dtype=torch.int32, device=dev)
+            self.done = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.stop = torch.zeros(16, dtype=torch.int32, device=dev)
+            self.reloc = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+        self.n_stop = 0
+        self.dk = self.dvt = None
+        self.rows = 0
+        self.slot = 0
+        self.B = 0
+        self._graphs: Dict[tuple, tuple] = {}
+        self._keep: list = []
+        self._ws_owner = object()
+
+    def _ensure(self, rows: int):
+        c = self.llm.cfg
+        if rows > self.rows:
+            bf = torch.bfloat16
+            with torch.inference_mode(False):
+                self.dk = torch.zeros(c.num_layers, c.num_kv_heads, rows, c.head_dim, dtype=bf, device=self.llm.dev)
+                self.dvt = torch.zeros(c.num_layers, c.num_kv_heads * c.head_dim, rows, dtype=bf, device=self.llm.dev)
+            self.rows = rows
+            self._graphs = {}
+        if self.llm.rope_cos.shape[0] < rows:
+            p = torch.arange(rows).view(1, -1).expand(3, -1)
+            cos_t, sin_t = mrope_tables(p, c.head_dim, c.rope_theta, c.mrope_section)
+            self.llm.rope_cos, self.llm.rope_sin = cos_t.to(self.llm.dev), sin_t.to(self.llm.dev)
+            self._graphs = {}
+
+    def start(self, seqs, deltas, first_tokens: torch.Tensor, max_new_tokens: int, stop_ids: Sequence[int] = ()):
+        """seqs: [(cache row offset, L, ...)] of the packed prefill that just ran on llm.kcache / llm.vtcache; first_tokens: device
+        int32 [B] (the prefill's greedy picks).  Moves every sequence to its own slot and accepts the first tokens on the device."""
+        llm = self.llm
+        B = len(seqs)
+        if B > self.MAX_BATCH:
+            raise ValueError(f"BatchDecoder handles at most {self.MAX_BATCH} sequences")
+        max_new = max(1, min(int(max_new_tokens), self.IDS_CAP))
+        need = max(L for _, L, *_ in seqs) + max_new + 1
+        slot = 1024
+        while slot < need:
+            slot *= 2
+        self._ensure(B * slot if B * slot > self.rows else self.rows)
+        self.B, self.slot = B, slot
+        reloc = torch.tensor([[o, b * slot, L, 0] for b, (o, L, *_) in enumerate(seqs)], dtype=torch.int32)
+        state = torch.tensor([[b * slot + L, L + d, b * slot, 0, 0, max_new, 0, 0] for b, ((o, L, *_), d) in enumerate(zip(seqs, deltas))],
+                             dtype=torch.int32)
+        stop = torch.tensor(list(stop_ids)[:16] + [0] * (16 - min(16, len(stop_ids))), dtype=torch.int32)
+        self.n_stop = min(16, len(stop_ids))
+        self.reloc[:B].copy_(reloc, non_blocking=True)
+        self.state[:B].copy_(state, non_blocking=True)
+        self.stop.copy_(stop, non_blocking=True)
+        self._keep = [reloc, state, stop]                 # sources of the async uploads stay alive
+        self.done.zero_()
+        with ops.workspace_scope(self._ws_owner):
+            ops.kv_relocate(llm.kcache, self.dk, llm.vtcache, self.dvt, self.reloc[:B], max(L for _, L, *_ in seqs))
+            ops.decode_argmax_accept(None, first_tokens.to(torch.int32).contiguous(), self.state[:B], self.plan[:B], self.ids[:B],
+                                     self.stop[:self.n_stop], self.done)
+
+    def _step_device(self):
+        llm, B = self.llm, self.B
+        c = llm.cfg
+        H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
+        scale = 1.0 / math.sqrt(HD)
+        st = self.state[:B]
+        with ops.workspace_scope(self._ws_owner):
+            x = ops.gather_rows(self.plan[:B], c.hidden_size, llm.embed)
+            for li, w in enumerate(llm.layers):
+                q = ops.gemv_batch(x, w["wqkv"], w["bqkv"], mode=ops.GB_QKV, norm_weight=w["ln1"], norm_eps=c.rms_norm_eps,
+                                   qkv=dict(n_q=H, n_kv=KV, cos=llm.rope_cos, sin=llm.rope_sin, state=st, kcache=self.dk[li], vtcache=self.dvt[li]))
+                att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, self.slot, H, KV, HD, scale)
+                x = ops.gemv_batch(att, w["wo"], residual=x)
+                a = ops.gemv_batch(x, w["wgu"], mode=ops.GB_SWIGLU, norm_weight=w["ln2"], norm_eps=c.rms_norm_eps)
+                x = ops.gemv_batch(a, w["wdown"], residual=x)
+            logits = ops.gemv_batch(x, llm.lm_head, norm_weight=llm.norm, norm_eps=c.rms_norm_eps)
+            ops.decode_argmax_accept(logits, None, st, self.plan[:B], self.ids[:B], self.stop[:self.n_stop], self.done)
+            return logits
+
+    def step(self, use_graph: bool = True):
+        """One token for every live sequence."""
+        if not use_graph:
+            return self._step_device()
+        key = (self.B, self.slot, self.n_stop)
+        ent = self._graphs.get(key)
+        if ent is None:
+            with ops.graph_lock.capture(), torch.inference_mode(False):
+                snap = (self.state.clone(), self.plan.clone(), self.ids.clone(), self.done.clone())
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self._step_device()          # warm-up (allocates scratch); its effects are rolled back below
+                torch.cuda.current_stream().wait_stream(s)
+                torch.cuda.synchronize()
+                for dst, src in zip((self.state, self.plan, self.ids, self.done), snap):
+                    dst.copy_(src)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    logits = self._step_device()
+                ent = (g, logits)
+                self._graphs[key] = ent
+        with ops.graph_lock.replay():
+            ent[0].replay()
+        return ent[1]
+
+    def run(self, max_new_tokens: int, use_graph: bool = True, poll: int = 8) -> List[List[int]]:
+        """Decode until every sequence has stopped (or max_new_tokens).  Returns the generated ids per sequence, the first
+        token (from the prefill) included."""
+        B = self.B
+        max_new = max(1, min(int(max_new_tokens), self.IDS_CAP))
+        for i in range(max_new - 1):
+            if i % poll == 0 and int(self.done.item()) >= B:     # the only host read in the loop, every `poll` steps
+                break
+            self.step(use_graph)
+        n = self.state[:B, 4].cpu().tolist()
+        ids = self.ids[:B, :max(n)].cpu().tolist()
+        return [row[:k] for row, k in zip(ids, n)]

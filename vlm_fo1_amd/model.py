@@ -106,6 +106,7 @@ class FO1Engine:
         import collections
         r._graphs = collections.OrderedDict()
         r._seen = {}
+        r._dec = None
         r.stage_hook = None
         return r
 
@@ -296,10 +297,31 @@ class FO1Engine:
                              next_token=res["next_tokens"][i:i + 1], position_ids=hp["pos"][i], rope_delta=hp["delta"][i],
                              cache_rows=(o, L)))
         self._last_batch = hp
+        self._last_next_tokens = res["next_tokens"]
         if B == 1:                                   # the single request sits at cache position 0: decode can continue in place
             self.llm.kv_len = hp["seqs"][0][1]
             self.llm.rope_delta = hp["delta"][0]
         return outs
+
+    def generate_batch(self, requests: Sequence[dict], max_new_tokens: int = 512, stop_ids: Sequence[int] = (), use_graph: bool = True) -> List[List[int]]:
+        """Greedy generation for a batch of requests: one packed prefill, then the batched decode loop (vlm_fo1_amd.llm.BatchDecoder):
+        weights streamed once per step for all sequences, stop rule and bookkeeping on the device.  Returns the new ids per request
+        (stop token included, like HF generate)."""
+        out: List[List[int]] = []
+        dec = self._decoder()
+        for i in range(0, len(requests), dec.MAX_BATCH):
+            grp = requests[i:i + dec.MAX_BATCH]
+            self.prefill_batch(grp, use_graph=use_graph)
+            hp = self._last_batch
+            dec.start(hp["seqs"], hp["delta"], self._last_next_tokens[:len(grp)], max_new_tokens, stop_ids)
+            out += dec.run(max_new_tokens, use_graph=use_graph)
+        return out
+
+    def _decoder(self):
+        from .llm import BatchDecoder
+        if getattr(self, "_dec", None) is None or self._dec.llm is not self.llm:
+            self._dec = BatchDecoder(self.llm)
+        return self._dec
 
     def _capture(self, key, pix, auxs, boxes, host, meta):
         # Captures always run with inference mode OFF: the CUDA generator's graph bookkeeping tensors are created by the first live

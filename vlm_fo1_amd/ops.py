@@ -321,6 +321,89 @@ def gemv(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return out
 
 
+# ---- batched decode (decode.hip) ------------------------------------------------------------------------------------------
+GB_PLAIN, GB_SWIGLU, GB_QKV = 0, 1, 2
+
+
+def gemv_batch(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+               mode: int = GB_PLAIN, norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 0.0,
+               out: Optional[torch.Tensor] = None, qkv: Optional[dict] = None) -> torch.Tensor:
+    """Decode-step projection for M <= 8 sequences (fo1_gemv_batch_bf16).  qkv (mode GB_QKV): dict(n_q, n_kv, cos, sin, state,
+    kcache [n_kv, rows, 128], vtcache [n_kv*128, rows]) — `out` then receives only the rotated q rows [M, n_q*128]."""
+    _chk(x, "x"); _chk(w, "w")
+    px, ldx, M, K = _rows(x, "x")
+    pw, ldw, N, K2 = _rows(w, "w")
+    assert K == K2 and M <= 8
+    n_out = N // 2 if mode == GB_SWIGLU else (qkv["n_q"] * 128 if mode == GB_QKV else N)
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device)
+    po, ldc, _, _ = _rows(out, "out")
+    pr, ldr = (None, 0)
+    if residual is not None:
+        pr, ldr, _, _ = _rows(residual, "residual")
+    if mode == GB_QKV:
+        kc, vt = qkv["kcache"], qkv["vtcache"]
+        _chk(kc, "kcache"); _chk(vt, "vtcache")
+        assert kc.dim() == 3 and kc.stride(2) == 1 and kc.stride(1) == 128 and qkv["state"].dtype == torch.int32
+        pv, ldv, _, _ = _rows(vt, "vtcache")
+        extra = (qkv["n_q"], qkv["n_kv"], qkv["cos"].data_ptr(), qkv["sin"].data_ptr(), qkv["state"].data_ptr(), kc.data_ptr(), kc.stride(0), pv, ldv)
+    else:
+        extra = (0, 0, None, None, None, None, 0, None, 0)
+    rc = _L.load().fo1_gemv_batch_bf16(px, ldx, pw, ldw, bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc, M, N, K, mode,
+                                       norm_weight.data_ptr() if norm_weight is not None else None, float(norm_eps), *extra, _stream())
+    _L.check(rc, "fo1_gemv_batch_bf16")
+    return out
+
+
+def attention_decode_batch(q: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tensor, state: torch.Tensor, max_kv_len: int,
+                           n_q_heads: int, n_kv_heads: int, head_dim: int, scale: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [B, n_q_heads*head_dim] (one new token per sequence) against the slots described by state int32 [B, 8]."""
+    _chk(q, "q"); _chk(kcache, "kcache"); _chk(vtcache, "vtcache")
+    assert state.dtype == torch.int32 and state.is_contiguous() and kcache.dim() == 3
+    pq, ldq, B, _ = _rows(q, "q")
+    need = _L.load().fo1_attention_decode_batch_workspace_bytes(max_kv_len, n_kv_heads, head_dim, B)
+    ws = _workspace("attn_decode", q.device, need)
+    if out is None:
+        out = torch.empty(B, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
+    po, ldo, _, _ = _rows(out, "out")
+    pv, ldv, _, _ = _rows(vtcache, "vtcache")
+    rc = _L.load().fo1_attention_decode_batch_bf16(pq, ldq, kcache.data_ptr(), kcache.stride(1), kcache.stride(0), pv, ldv, po, ldo,
+                                                   state.data_ptr(), B, max_kv_len, n_q_heads, n_kv_heads, head_dim, float(scale),
+                                                   ws.data_ptr(), ws.numel(), _stream())
+    _L.check(rc, "fo1_attention_decode_batch_bf16")
+    return out
+
+
+def decode_argmax_accept(logits: Optional[torch.Tensor], first_tokens: Optional[torch.Tensor], state: torch.Tensor, plan: torch.Tensor,
+                         ids_out: torch.Tensor, stop_ids: torch.Tensor, done: torch.Tensor) -> None:
+    B = state.shape[0]
+    assert state.dtype == plan.dtype == ids_out.dtype == done.dtype == torch.int32 and ids_out.is_contiguous() and plan.is_contiguous()
+    sc = _workspace("argmax_rows", state.device, 2 * 128 * B * 4)
+    n_stop = int(stop_ids.numel()) if stop_ids is not None else 0
+    if logits is not None:
+        _chk(logits, "logits")
+        pl, ldl, Bl, V = _rows(logits, "logits")
+        assert Bl == B
+    else:
+        pl, ldl, V = None, 0, 0
+        assert first_tokens is not None and first_tokens.dtype == torch.int32 and first_tokens.numel() == B
+    rc = _L.load().fo1_decode_argmax_accept(pl, ldl, V, B, first_tokens.data_ptr() if first_tokens is not None else None, state.data_ptr(),
+                                            plan.data_ptr(), ids_out.data_ptr(), ids_out.shape[1], stop_ids.data_ptr() if n_stop else None, n_stop,
+                                            done.data_ptr(), sc.data_ptr(), _stream())
+    _L.check(rc, "fo1_decode_argmax_accept")
+
+
+def kv_relocate(ksrc: torch.Tensor, kdst: torch.Tensor, vsrc: torch.Tensor, vdst: torch.Tensor, seqs: torch.Tensor, max_len: int) -> None:
+    """k*: [layers, n_kv, rows, 128]; v*: [layers, n_kv*128, rows]; seqs int32 [B, 4] = (src0, dst0, len, 0) on the device."""
+    for t in (ksrc, kdst, vsrc, vdst):
+        _chk(t, "cache")
+    assert ksrc.dim() == 4 and vsrc.dim() == 3 and seqs.dtype == torch.int32 and seqs.is_contiguous()
+    rc = _L.load().fo1_kv_relocate(ksrc.data_ptr(), kdst.data_ptr(), ksrc.stride(0), ksrc.stride(1), kdst.stride(0), kdst.stride(1),
+                                   vsrc.data_ptr(), vdst.data_ptr(), vsrc.stride(0), vsrc.stride(1), vdst.stride(0), vdst.stride(1),
+                                   seqs.data_ptr(), seqs.shape[0], int(max_len), ksrc.shape[1], ksrc.shape[0], _stream())
+    _L.check(rc, "fo1_kv_relocate")
+
+
 def decode_qkv_post(qkv_row: torch.Tensor, n_q_heads: int, n_kv_heads: int, head_dim: int, cos_table: torch.Tensor,
                     sin_table: torch.Tensor, state: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tensor) -> None:
     _chk(qkv_row, "qkv_row"); _chk(kcache, "kcache"); _chk(vtcache, "vtcache")

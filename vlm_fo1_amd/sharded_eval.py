@@ -58,7 +58,9 @@ def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu") -
     rank, world, _ = world_info()
     if world == 1 or not dist.is_initialized():
         return sorted(local, key=lambda r: r[0])
-    dev = torch.device(device)
+    # the collective's tensors live where the backend works: RCCL ("nccl") on this rank's GPU, gloo on the host — whatever the
+    # caller's `device` says (an eval driver started under gloo still passes its cuda device string)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     kmax = max([len(t) for _, t in local if t is not None] + [0])
     meta = torch.tensor([kmax, len(local)], dtype=torch.int64, device=dev)
     dist.all_reduce(meta, op=dist.ReduceOp.MAX)
@@ -101,49 +103,88 @@ def request_workers(model, make_generate: Callable, n: Optional[int] = None) -> 
     return workers
 
 
-def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", progress: Optional[Callable] = None):
-    """Every rank runs `generate(i)` (-> new token ids) on its shard; rank 0 gets [(i, ids|None)] for all items.
+def _fatal(e: BaseException) -> bool:
+    """Errors that must stop the evaluation instead of becoming a per-item error record: out-of-memory (every later item would
+    fail the same way and the run would silently report wrong metrics — ADVICE r1) and a missing HIP library."""
+    if isinstance(e, (MemoryError, torch.cuda.OutOfMemoryError)):
+        return True
+    msg = str(e).lower()
+    return "out of memory" in msg or "hiperroroutofmemory" in msg
 
-    `generate` may be a LIST of callables: one worker thread per callable, each pulling the next item of the rank's shard
-    from a shared queue.  Give every callable its own engine replica + HIP stream (FO1ForCausalLM.replica()): the requests
-    then overlap on the GPU (a batch-1 pass under-fills 256 CUs; one request's decode GEMVs run under another's prefill).
-    The records are sorted by item index afterwards, so the output does not depend on the interleaving."""
+
+def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", progress: Optional[Callable] = None, batch: int = 1):
+    """Every rank runs `generate` on its shard; rank 0 gets [(i, ids|None)] for all items.
+
+    batch == 1: `generate(i)` -> new token ids of item i.  batch > 1: `generate([i0, i1, ...])` -> [ids per item]: up to `batch`
+    items of similar cost go through the engine together (one packed prefill pass, batched decode); when a batched call raises,
+    its items are retried one by one so a single bad item costs only its own record.
+
+    `generate` may be a LIST of callables: one worker thread per callable, each pulling the next item / group of the rank's shard
+    from a shared queue.  Give every callable its own engine replica + HIP stream (FO1ForCausalLM.replica()).  The records are
+    sorted by item index afterwards, so the output does not depend on the interleaving or the grouping."""
     rank, world, _ = world_info()
     mine = assign(costs, world)[rank]
-    it = progress(mine) if progress else mine
     workers = list(generate) if isinstance(generate, (list, tuple)) else [generate]
+    if batch > 1:
+        order = sorted(mine, key=lambda i: (costs[i], i))       # similar prompt lengths share a pass
+        groups = [order[k:k + batch] for k in range(0, len(order), batch)]
+    else:
+        groups = [[i] for i in mine]
+    it = progress(groups) if progress else groups
 
-    def run_one(fn, i):
+    def run_group(fn, grp):
         try:
-            return (i, [int(t) for t in fn(i)])
-        except Exception as e:  # per-item error record instead of the reference's silent `continue`
-            print(f"[rank {rank}] item {i} failed: {type(e).__name__}: {e}")
-            return (i, None)
+            if batch > 1:
+                outs = fn(list(grp))
+                return [(i, [int(t) for t in o]) for i, o in zip(grp, outs)]
+            return [(grp[0], [int(t) for t in fn(grp[0])])]
+        except Exception as e:  # per-item error record instead of the reference's silent `continue` (eval_coco.py:60-65)
+            if _fatal(e):
+                raise
+            if batch > 1 and len(grp) > 1:
+                recs = []
+                for i in grp:
+                    try:
+                        recs.append((i, [int(t) for t in fn([i])[0]]))
+                    except Exception as e1:
+                        if _fatal(e1):
+                            raise
+                        print(f"[rank {rank}] item {i} failed: {type(e1).__name__}: {e1}")
+                        recs.append((i, None))
+                return recs
+            print(f"[rank {rank}] item {grp[0]} failed: {type(e).__name__}: {e}")
+            return [(grp[0], None)]
 
     if len(workers) == 1:
-        local = [run_one(workers[0], i) for i in it]
+        local = [r for g in it for r in run_group(workers[0], g)]
     else:
         import queue
         import threading
-        q: "queue.Queue[int]" = queue.Queue()
-        for i in it:
-            q.put(i)
-        local, lock = [], threading.Lock()
+        q: "queue.Queue" = queue.Queue()
+        for g in it:
+            q.put(g)
+        local, lock, errors = [], threading.Lock(), []
 
         def loop(fn):
             while True:
                 try:
-                    i = q.get_nowait()
+                    g = q.get_nowait()
                 except queue.Empty:
                     return
-                rec = run_one(fn, i)
+                try:
+                    recs = run_group(fn, g)
+                except BaseException as e:   # fatal: stop this worker, re-raised on the main thread
+                    errors.append(e)
+                    return
                 with lock:
-                    local.append(rec)
+                    local.extend(recs)
 
         threads = [threading.Thread(target=loop, args=(fn,), daemon=True) for fn in workers]
         for t in threads:
             t.start()
         for t in threads:
             t.join()
-        local.sort(key=lambda r: r[0])
+        if errors:
+            raise errors[0]
+    local.sort(key=lambda r: r[0])
     return gather_records(local, device)
