@@ -92,6 +92,10 @@ typedef struct fo1_hfre_source {
 
 /* Tuning hook: footprint pixels one workgroup streams per row-slice (0 = auto: 256 up to 48 boxes, else 512). */
 int fo1_hfre_set_pixel_budget(int pixels);
+/* Tuning hook of fo1_hfre_region_pool_ex: unroll = 8 | 16 independent 16-byte loads per lane; chunk = channels per workgroup
+ * (power of two, 64..512); budget = pixels per row slice (0 = keep); grid = workgroups walking the work list (0 = keep).
+ * Process-global; results are bit-identical across unroll / grid (the fp32 sum order depends on budget and chunk only). */
+int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid);
 
 /* Bytes of scratch fo1_hfre_region_pool needs for these sources / n_boxes. */
 size_t fo1_hfre_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes);
@@ -109,6 +113,29 @@ int fo1_hfre_region_pool(
     float* out, int out_ld, int region_dim,          /* device fp32 [n_boxes, out_ld]        */
     void* workspace, size_t workspace_bytes,         /* device scratch                       */
     void* stream);
+
+/* Work-list HFRE for the boxes of `batch` same-geometry images at once: the tap-weight kernel also lists the (box, source, chunk,
+ * slice) tuples that exist, a fixed grid walks that list (no empty workgroups — nine in ten of fo1_hfre_region_pool's are), and the
+ * row finish applies the optional region LayerNorm.  Same arithmetic as fo1_hfre_region_pool; a box's result does not depend on
+ * the other boxes or images of the call.  opts may be NULL (one image, no LayerNorm).  Region LayerNorm =
+ * mm_apply_region_layer_norm (reference hybrid_finegrained_region_encoder.py:365-372): fp32 nn.LayerNorm of the aux block
+ * [0, ln_split) and the vt block [ln_split, region_dim) before the position embedding.
+ * Workspace contract: its first 64 bytes (the work-list counter) must be zero the first time a workspace is used; every call leaves
+ * them zero (the last kernel resets the counter in-stream — no memset node, so the call is safe to capture in a hipGraph). */
+typedef struct fo1_hfre_opts {
+    int32_t batch;                               /* images in this call (>= 1)                                          */
+    const int32_t* box_image;                    /* device int32[n_boxes]: image of each box (NULL when batch == 1)     */
+    long long img_stride[FO1_HFRE_MAX_SOURCES];  /* elements from image b to image b+1 of source i (multiple of 8)      */
+    int32_t ln_on, ln_split;
+    const float* ln_w0; const float* ln_b0;      /* fp32 device, block [0, ln_split)                                    */
+    const float* ln_w1; const float* ln_b1;      /* fp32 device, block [ln_split, region_dim)                           */
+    float ln_eps;
+} fo1_hfre_opts_t;
+size_t fo1_hfre_ex_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes);
+int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, const float* boxes_aux, int n_boxes,
+                               const float* boxes_vt, float vt_scale_x, float vt_scale_y, int roi_size, int pos_mode,
+                               float pos_img_w, float pos_img_h, float* out, int out_ld, int region_dim,
+                               const fo1_hfre_opts_t* opts, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * bf16 GEMM with fused epilogue  (SURVEY §8a rows a2,a4,a5,a8,a9,a11: every nn.Linear /

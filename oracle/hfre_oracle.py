@@ -187,7 +187,8 @@ def hfre_oracle(aux_maps: Sequence[torch.Tensor], aux_boxes: torch.Tensor,
                 vt_maps: Optional[Sequence[torch.Tensor]], vt_boxes: Optional[torch.Tensor],
                 *, region_dim: int, grid_hw, vt_strides: Optional[Sequence[float]] = None,
                 vt_spatial_scale: float = 1 / 14, aux_spatial_scale: float = 0.25,
-                roi_size: int = 7, apply_pos: bool = True, roi_align=None) -> torch.Tensor:
+                roi_size: int = 7, apply_pos: bool = True, roi_align=None, region_ln: Optional[dict] = None,
+                pos_from: str = "vt", vt_only: bool = False) -> torch.Tensor:
     """Supported product configuration (reference :319-363, :368-383, :436-467 with
     use_vision_tower_region_feature=True, combination='concat', strategy 'bbox_based').
 
@@ -199,20 +200,28 @@ def hfre_oracle(aux_maps: Sequence[torch.Tensor], aux_boxes: torch.Tensor,
               boxes by grid*14 (reference :443-448 — under FPN `vt_multi_level_features`
               is the single grid-resolution input map, so the same value).
     Returns fp32 [1,N,region_dim]."""
+    # Variants beyond the default configuration: region_ln = dict(aux_w, aux_b, vt_w, vt_b) applies the reference's fp32
+    # nn.LayerNorm(eps 1e-5) to the aux and the vt block before fusion (:365-372); pos_from='aux' is 'concat_aux_pos' (box
+    # embedding from the aux boxes, normalised by the aux map size / aux scale, :443-455); vt_only is use_vt_region_feature_only
+    # (:293-317: vt block + vt box embedding, no aux tower).
     ra = roi_align or roi_align_c
     aux_boxes = aux_boxes.float()
     vt_boxes = vt_boxes.float()
     H0 = max(f.shape[2] for f in aux_maps)
     W0 = max(f.shape[3] for f in aux_maps)
-    cat = []
-    for lvl, f in enumerate(aux_maps):
-        f = f.float()
-        if lvl != 0:
-            f = F.interpolate(f, size=(H0, W0), mode="bilinear", align_corners=False)
-        cat.append(f)
-    cat = torch.cat(cat, dim=1)
-    aux = ra(cat, [aux_boxes], output_size=roi_size, spatial_scale=aux_spatial_scale)
-    aux = aux.mean(dim=(2, 3)).reshape(1, aux.shape[0], aux.shape[1])
+    aux = None
+    if not vt_only:
+        cat = []
+        for lvl, f in enumerate(aux_maps):
+            f = f.float()
+            if lvl != 0:
+                f = F.interpolate(f, size=(H0, W0), mode="bilinear", align_corners=False)
+            cat.append(f)
+        cat = torch.cat(cat, dim=1)
+        aux = ra(cat, [aux_boxes], output_size=roi_size, spatial_scale=aux_spatial_scale)
+        aux = aux.mean(dim=(2, 3)).reshape(1, aux.shape[0], aux.shape[1])
+        if region_ln is not None:
+            aux = F.layer_norm(aux, (aux.shape[-1],), region_ln["aux_w"].float(), region_ln["aux_b"].float(), 1e-5)
     if vt_strides is not None:
         per = []
         for f, s in zip(vt_maps, vt_strides):
@@ -223,11 +232,16 @@ def hfre_oracle(aux_maps: Sequence[torch.Tensor], aux_boxes: torch.Tensor,
         vcat = torch.cat(list(vt_maps), dim=1).float()
         r = ra(vcat, [vt_boxes], output_size=roi_size, spatial_scale=vt_spatial_scale)
         vt = r.mean(dim=(2, 3)).reshape(1, r.shape[0], r.shape[1])
-    out = torch.cat([aux, vt], dim=-1)
+    if region_ln is not None and not vt_only:
+        vt = F.layer_norm(vt, (vt.shape[-1],), region_ln["vt_w"].float(), region_ln["vt_b"].float(), 1e-5)
+    out = vt if vt_only else torch.cat([aux, vt], dim=-1)
     assert out.shape[-1] == region_dim, (out.shape, region_dim)
     if apply_pos:
         gh, gw = grid_hw
-        out = out + box_pos_embed(vt_boxes, gw / vt_spatial_scale, gh / vt_spatial_scale, region_dim // 4)
+        if pos_from == "aux" and not vt_only:
+            out = out + box_pos_embed(aux_boxes, W0 / aux_spatial_scale, H0 / aux_spatial_scale, region_dim // 4)
+        else:
+            out = out + box_pos_embed(vt_boxes, gw / vt_spatial_scale, gh / vt_spatial_scale, region_dim // 4)
     return out
 
 

@@ -1,0 +1,18 @@
+#!/bin/bash
+OUT=$(pwd)/gpurun_out/r02_run13; mkdir -p $OUT
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+timeout 1800 python -m pytest tests -m gpu -q --timeout 900 > $OUT/pytest.log 2>&1; tail -12 $OUT/pytest.log
+timeout 900 python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err; tail -3 $OUT/bench.err
+python - <<PY
+import json
+d=json.loads(open("$OUT/bench.json").read())
+print("value", d["value"], "ms/step", d["ms_per_step"]); print("decode", d["decode"]); print("single", d["one_image_at_a_time"], d.get("one_pass_at_a_time"))
+r=d["roofline"]; print(r["kernel"], r["achieved"], r["frac"], r["all_gemm_tiles"])
+print(d["stage_kernel_ms"])
+for k,v in r["per_step_ms"].items(): print(f"  {k:28s} {v:8.3f} x{r['launches'][k]}")
+PY
+python - <<PY
+import json
+d=json.loads(open("$OUT/bench.json").read())
+print(json.dumps(d["roofline"].get("hfre"), indent=1))
+PY

@@ -30,14 +30,21 @@ def to_dev(case):
     return d
 
 
-def engine_out(case_dev, use_vt_boxes=True):
+def engine_out(case_dev, use_vt_boxes=True, worklist=None, **variant):
     from vlm_fo1_amd.hfre import HFREModule
     fpn = case_dev["fpn"]
     gh, gw = case_dev["grid_hw"]
-    m = HFREModule(roi_output_size=7, region_feature_dim=case_dev["region_dim"], apply_position_embedding=True,
-                   use_vision_tower_region_feature=True, region_feature_combination="concat",
-                   vision_tower_region_feature_dim=2048 if fpn else 5120, use_simpleFPN_for_vt=fpn,
-                   simple_fpn=(lambda x: case_dev["fpn_maps"]) if fpn else None)
+    kw = dict(roi_output_size=7, region_feature_dim=case_dev["region_dim"], apply_position_embedding=True,
+              use_vision_tower_region_feature=True, region_feature_combination="concat",
+              vision_tower_region_feature_dim=2048 if fpn else 5120, use_simpleFPN_for_vt=fpn,
+              simple_fpn=(lambda x: case_dev["fpn_maps"]) if fpn else None)
+    ln = variant.pop("ln", None)
+    kw.update(variant)
+    m = HFREModule(**kw)
+    if worklist is not None:
+        m.worklist = worklist
+    if ln is not None:
+        m.set_region_norm(*[ln[k].cuda() for k in ("aux_w", "aux_b", "vt_w", "vt_b")])
     vt_in = torch.zeros(1, 1280, gh, gw, dtype=torch.bfloat16, device="cuda") if fpn else case_dev["vt_maps"]
     if use_vt_boxes:
         return m(case_dev["aux_maps"], [case_dev["boxes"]], vt_in, [case_dev["vt_boxes"]]).squeeze(0)
@@ -158,3 +165,106 @@ def test_hfre_linearity_at_max_size():
     sub["boxes"] = case["boxes"][:5]
     sub["vt_boxes"] = case["vt_boxes"][:5]
     torch.testing.assert_close(one[:5].cpu(), oracle_out(sub), rtol=RTOL, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_hfre_worklist_equals_worst_case_grid(name):
+    """The work-list kernels do the same fp32 operations in the same order as the round-1 worst-case-grid kernels when both slice
+    at the same pixel budget: bit-identical.  (The default budgets differ — the work-list form uses one budget for every box
+    count — so the budget is pinned here.)"""
+    from vlm_fo1_amd import lib as L
+    d = to_dev(make_case(name))
+    try:
+        L.check(L.load().fo1_hfre_set_pixel_budget(512), "set budget")
+        a = engine_out(d, worklist=True)
+        b = engine_out(d, worklist=False)
+        again = engine_out(d, worklist=True)
+    finally:
+        L.load().fo1_hfre_set_pixel_budget(0)
+    assert torch.equal(a, b)
+    assert torch.equal(a, again), "the item counter is reset per call; list order does not reach the results"
+
+
+@pytest.mark.parametrize("unroll,chunk,grid", [(16, 512, 2048), (8, 512, 7), (8, 256, 64), (16, 128, 7)])
+def test_hfre_worklist_tuning_invariance(unroll, chunk, grid):
+    """unroll / grid size repartition the work only: bit-identical results (a grid of 7 makes every workgroup walk many items).
+    The chunk width changes how many pixel slots a wave has, i.e. the order of the fp32 pixel sum: equal to re-association."""
+    from vlm_fo1_amd import lib as L
+    d = to_dev(make_case("countbench30_fpn"))
+    ref = engine_out(d, worklist=True)
+    try:
+        L.check(L.load().fo1_hfre_set_tuning(unroll, chunk, 0, grid), "set tuning")
+        got = engine_out(d, worklist=True)
+        again = engine_out(d, worklist=True)
+    finally:
+        L.load().fo1_hfre_set_tuning(8, 512, 0, 4096)
+    assert torch.equal(got, again)
+    if chunk == 512:
+        assert torch.equal(got, ref)
+    else:
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6)
+
+
+def test_hfre_worklist_graph_replay_under_load():
+    """The work-list counter is reset in-stream by the finish kernel (a hipMemsetAsync node in a captured graph faulted on the second
+    replay on ROCm 7.2): a captured call replayed many times next to a busy side stream stays bit-identical."""
+    d = to_dev(make_case("countbench30_fpn"))
+    ref = engine_out(d, worklist=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o = engine_out(d, worklist=True)
+    side = torch.cuda.Stream()
+    a = torch.randn(2048, 2048, device="cuda", dtype=torch.bfloat16)
+    for _ in range(30):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                a @ a
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(o, ref)
+
+
+def test_hfre_variants_vs_reference_golden_and_oracle():
+    """apply_region_layer_norm / concat_aux_pos / use_vt_region_feature_only against the reference HFREModule's outputs
+    (tests/golden/hfre_variants.npz) and the oracle.  LayerNorm divides by the row's std (~0.05 here), which scales the pooling's
+    fp32 re-association error by 1/std: rtol 1e-4, atol 2e-4 for that variant."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_hfre_variant_golden import ln_params
+    case = make_case("demo_fpn")
+    g = np.load(os.path.join(HERE, "golden", "hfre_variants.npz"))
+    assert str(g["checksum"]) == checksum(case)
+    d = to_dev(case)
+    got = engine_out(d, apply_region_layer_norm=True, ln=ln_params()).cpu()
+    torch.testing.assert_close(got, torch.from_numpy(g["ln"]), rtol=1e-4, atol=2e-4)
+    got = engine_out(d, region_feature_combination="concat_aux_pos").cpu()
+    torch.testing.assert_close(got, torch.from_numpy(g["aux_pos"]), rtol=RTOL, atol=ATOL)
+    d2 = dict(d)
+    d2["region_dim"] = 2048
+    got = engine_out(d2, use_vt_region_feature_only=True).cpu()
+    assert got.shape == (case["boxes"].shape[0], 2048)
+    torch.testing.assert_close(got, torch.from_numpy(g["vt_only"]), rtol=RTOL, atol=ATOL)
+
+
+def test_hfre_batched_call_equals_per_image():
+    """batch > 1: the maps of B same-size images stacked, all boxes in one launch with box_image — every box's row is bit-identical
+    to the one-image call (same slices, same order)."""
+    from vlm_fo1_amd.hfre import HFREModule
+    B = 3
+    cases = [_full_size_case(480, 640, n, 100 + i) for i, n in enumerate((100, 37, 1))]
+    devs = [to_dev(c) for c in cases]
+    singles = [engine_out(d, use_vt_boxes=False) for d in devs]
+
+    def stack(key, lvl):
+        tm = torch.stack([d[key][lvl].permute(0, 2, 3, 1)[0] for d in devs]).contiguous()      # [B,H,W,C]
+        return tm[:1].permute(0, 3, 1, 2)                                                      # image-0 view; storage continues
+    aux = [stack("aux_maps", i) for i in range(4)]
+    fpn = [stack("fpn_maps", i) for i in range(4)]
+    boxes = torch.cat([d["boxes"] for d in devs])
+    box_image = torch.cat([torch.full((d["boxes"].shape[0],), i, dtype=torch.int32) for i, d in enumerate(devs)]).cuda()
+    gh, gw = devs[0]["grid_hw"]
+    m = HFREModule(roi_output_size=7, region_feature_dim=5888, apply_position_embedding=True, use_vision_tower_region_feature=True,
+                   vision_tower_region_feature_dim=2048, use_simpleFPN_for_vt=True, simple_fpn=lambda x: fpn)
+    got = m(aux, [boxes], torch.zeros(1, 1280, gh, gw, dtype=torch.bfloat16, device="cuda"), None, vt_scale=devs[0]["vt_scale"],
+            batch=B, box_image=box_image).squeeze(0)
+    assert torch.equal(got, torch.cat(singles))

@@ -5,6 +5,7 @@ kernel's per-axis math (vlm_fo1_amd/csrc/hfre_math.h) through the host harness."
 import ctypes
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -166,3 +167,21 @@ def test_axis_weights_sum_to_one(emul):
         n = emul.hfre_emul_axis(ctypes.c_float(lo), ctypes.c_float(hi), ctypes.c_float(0.25), 7, 200, w)
         assert n >= 1
         assert abs(sum(w) - 1.0) < 1e-5, (lo, hi, sum(w))
+
+
+def test_oracle_variants_vs_reference_golden():
+    """region LayerNorm / concat_aux_pos / vt-only: the oracle's restatement against the reference HFREModule's own outputs
+    (tests/golden/hfre_variants.npz, made by tests/golden/make_hfre_variant_golden.py)."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_hfre_variant_golden import ln_params
+    case = make_case("demo_fpn")
+    g = np.load(os.path.join(HERE, "golden", "hfre_variants.npz"))
+    assert str(g["checksum"]) == checksum(case)
+    kw = dict(grid_hw=case["grid_hw"], vt_strides=[3.5, 7, 14, 28])
+    out = O.hfre_oracle(case["aux_maps"], case["boxes"], case["fpn_maps"], case["vt_boxes"], region_dim=5888, region_ln=ln_params(), **kw)[0]
+    torch.testing.assert_close(out, torch.from_numpy(g["ln"]), rtol=1e-5, atol=1e-5)
+    out = O.hfre_oracle(case["aux_maps"], case["boxes"], case["fpn_maps"], case["vt_boxes"], region_dim=5888, pos_from="aux", **kw)[0]
+    torch.testing.assert_close(out, torch.from_numpy(g["aux_pos"]), rtol=1e-5, atol=1e-5)
+    out = O.hfre_oracle(case["aux_maps"], case["boxes"], case["fpn_maps"], case["vt_boxes"], region_dim=2048, vt_only=True, **kw)[0]
+    torch.testing.assert_close(out, torch.from_numpy(g["vt_only"]), rtol=1e-5, atol=1e-5)

@@ -23,6 +23,8 @@ _PREFIXES = (  # checkpoint prefix -> engine sub-dict   (reference builder.py:11
     ("model.vision_tower.image_tower.", "vit"),
     ("model.vision_tower_aux.image_tower.", "davit"),
     ("model.object_vp_extractor.simple_fpn.", "fpn"),
+    ("model.object_vp_extractor.aux_region_norm.", "proj:aux_region_norm."),     # mm_apply_region_layer_norm (HFRE :175-180)
+    ("model.object_vp_extractor.vt_region_norm.", "proj:vt_region_norm."),
     ("model.mm_projector_aux.", "proj:mm_projector_aux."),
     ("model.mm_projector.", "proj:mm_projector."),
     ("model.embed_tokens.", "llm:embed_tokens."),

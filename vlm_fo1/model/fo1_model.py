@@ -52,12 +52,10 @@ class FO1HFConfig:
         unsupported = []
         if not d.get("mm_use_vision_tower_region_feature", False):
             unsupported.append("mm_use_vision_tower_region_feature=False")
-        if d.get("mm_region_feature_combination", "concat") != "concat":
+        if d.get("mm_region_feature_combination", "concat") not in ("concat", "concat_aux_pos"):
             unsupported.append(f"mm_region_feature_combination={d.get('mm_region_feature_combination')!r}")
         if d.get("mm_pos_embedding_strategy", "bbox_based") != "bbox_based":
             unsupported.append(f"mm_pos_embedding_strategy={d.get('mm_pos_embedding_strategy')!r}")
-        if d.get("mm_use_vt_region_feature_only", False) or d.get("mm_apply_region_layer_norm", False):
-            unsupported.append("vt-only / region layer norm")
         aux = str(d.get("mm_vision_tower_aux", "davit-large"))
         if "davit-large" not in aux:
             unsupported.append(f"mm_vision_tower_aux={aux!r}")
@@ -67,7 +65,10 @@ class FO1HFConfig:
                          mm_projector_aux_type=d.get("mm_projector_aux_type", "linear"),
                          mm_use_simpleFPN_for_vt=bool(d.get("mm_use_simpleFPN_for_vt", False)),
                          mm_region_hidden_size=int(d["mm_region_hidden_size"]), mm_roi_output_size=int(d.get("mm_roi_output_size", 7)),
-                         mm_apply_position_embedding=bool(d.get("mm_apply_position_embedding", True)))
+                         mm_apply_position_embedding=bool(d.get("mm_apply_position_embedding", True)),
+                         mm_apply_region_layer_norm=bool(d.get("mm_apply_region_layer_norm", False)),
+                         mm_region_feature_combination=d.get("mm_region_feature_combination", "concat"),
+                         mm_use_vt_region_feature_only=bool(d.get("mm_use_vt_region_feature_only", False)))
 
     def eos_ids(self) -> List[int]:
         e = self._gen.get("eos_token_id", self._d.get("eos_token_id"))

@@ -52,6 +52,15 @@ struct HfreParams {
     int pixel_budget;
     float* wbuf;        // per (box, source): wy[kHfreWStride] | wx[kHfreWStride] tap weights on the source map
     int* hdr;           // per (box, source): r_lo, r_hi, c_lo, c_hi, rows_per_slice, n_slices, -, -
+    // ---- work-list path (fo1_hfre_region_pool_ex) ----
+    const int* box_image;                       // image of each box (batched call) or nullptr
+    long long img_stride[FO1_HFRE_MAX_SOURCES]; // elements between consecutive images of a source map
+    int* n_items;                               // device counter of work items (zero on entry; the finish kernel re-zeroes it)
+    int2* items;                                // {box, source << 24 | chunk << 12 | slice}: only the slices that exist
+    int items_cap;                              // capacity of the list (worst case); the walk never reads past it
+    int ln_on, ln_split;                        // region LayerNorm (reference :365-372): blocks [0, ln_split) and [ln_split, region_dim)
+    const float* ln_w0; const float* ln_b0; const float* ln_w1; const float* ln_b1;
+    float ln_eps;
 };
 
 constexpr int kHfreWStride = FO1_HFRE_MAX_EXTENT;
@@ -106,6 +115,18 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_weights_kernel(const HfrePa
         h[0] = f.r_lo; h[1] = f.r_hi; h[2] = f.c_lo; h[3] = f.c_hi; h[4] = f.rows_per_slice; h[5] = f.n_slices;
     }
     if (f.n_slices == 0) return;
+    if (p.items != nullptr) {
+        // work list: reserve this (box, source)'s chunk x slice items in one atomic; the order of the list varies run to run, the
+        // results do not (every item owns its partial row, the finish sums in slice order)
+        __shared__ int s_base;
+        const int cnt = f.n_slices * s.nchunks;
+        if (tid == 0) s_base = atomicAdd(p.n_items, cnt);
+        __syncthreads();
+        for (int j = tid; j < cnt; j += kHfreThreads) {
+            const int ch = j / f.n_slices, k = j - ch * f.n_slices;
+            p.items[s_base + j] = make_int2(n, (si << 24) | (ch << 12) | k);
+        }
+    }
     const bool up_y = (s.H != s.roi_H), up_x = (s.W != s.roi_W);
     if (up_y)
         for (int a = f.ay.lo + tid; a <= f.ay.hi; a += kHfreThreads) s_wAy[a - f.ay.lo] = roi_axis_weight(f.ay, a);
@@ -261,7 +282,191 @@ __global__ __launch_bounds__(256) void hfre_finish_kernel(const HfreParams p) {
     p.out[(size_t)n * p.out_ld + c] = v;
 }
 
+// ------------------------------------------------------------------------------------------
+// Work-list form (fo1_hfre_region_pool_ex): the grid of hfre_pool_kernel is sized for the worst case (every box as tall as the map:
+// ~147 workgroups per box at 640x480), of which a typical proposal uses ~15 — nine out of ten workgroups only read their header and
+// leave.  Here hfre_weights_kernel also appends the (box, source, chunk, slice) tuples that exist to a device list, and
+// hfre_pool_items_kernel walks the list grid-stride with a fixed number of workgroups: no empty workgroups, all boxes of all
+// images of a batch in one launch.  hfre_finish2_kernel sums the slices in slice order, applies the region LayerNorm when
+// configured and adds the sine box embedding.  (A single-launch variant — per-box arrival ticket, last workgroup finishes the row —
+// was measured and dropped: in-workgroup tap weights are recomputed by every chunk x slice workgroup and a release per workgroup
+// costs microseconds; 107-127 us vs 59 us for this three-kernel form at 100 boxes, profiles/r02_hfre_sweep.md.)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float hfre_sine(const HfreParams& p, const float* s_box, int c) {
+    // gen_sineembed_for_position (reference :55-103): blocks ordered (y, x, w, h)
+    const int d = p.region_dim / 4;
+    const int qd = c / d, i = c - qd * d;
+    const float coord = (qd == 0) ? s_box[1] : (qd == 1) ? s_box[0] : s_box[qd];
+    const float dim_t = powf(10000.0f, (float)(2 * (i / 2)) / (float)d);
+    const float ang = coord * 6.283185307179586f / dim_t;
+    return (i & 1) ? cosf(ang) : sinf(ang);
+}
+
+// One workgroup (kHfreThreads) finishes output row n.  s_misc: >= FO1_HFRE_MAX_SOURCES ints, s_stat: 8 floats (LDS).
+__device__ __forceinline__ void hfre_finish_row(const HfreParams& p, int n, int seg, int nseg, int* s_misc, float* s_stat) {
+    const int tid = threadIdx.x;
+    if (tid < p.n_sources) s_misc[tid] = p.hdr[((size_t)n * p.n_sources + tid) * 8 + 5];
+    if (tid == 32 && p.pos_mode != 0) {
+        float x1, y1, x2, y2;
+        load_box(p, n, p.pos_mode == 1, x1, y1, x2, y2);
+        x1 = x1 / p.pos_w; x2 = x2 / p.pos_w;       // reference :457-463 — normalise, xyxy -> cxcywh (fp32, same op order)
+        y1 = y1 / p.pos_h; y2 = y2 / p.pos_h;
+        const float w = x2 - x1, h = y2 - y1;
+        s_stat[0] = x1 + w / 2.0f;
+        s_stat[1] = y1 + h / 2.0f;
+        s_stat[2] = w;
+        s_stat[3] = h;
+    }
+    __syncthreads();
+    // the row is processed in the (at most two) LayerNorm blocks; without LayerNorm it is one block
+    const int nblk = (p.ln_on && p.ln_split > 0 && p.ln_split < p.region_dim) ? 2 : 1;
+    for (int b = 0; b < nblk; ++b) {
+        const int c0 = (b == 0) ? 0 : p.ln_split;
+        const int c1 = (nblk == 2 && b == 0) ? p.ln_split : p.region_dim;
+        float mean = 0.f, rstd = 1.f;
+        for (int pass = 0; pass < (p.ln_on ? 3 : 1); ++pass) {
+            // pass 0: slice sums [+ block sum]; pass 1: variance (two-pass, like nn.LayerNorm); pass 2: normalise + emit
+            float part = 0.f;
+            for (int c = c0 + seg * kHfreThreads + tid; c < c1; c += nseg * kHfreThreads) {   // nseg > 1 only without LayerNorm
+                float v = 0.0f;
+                for (int i = 0; i < p.n_sources; ++i) {
+                    const HfreSrcDev& q = p.src[i];
+                    if (c >= q.out_offset && c < q.out_offset + q.C) {
+                        const float* w = p.ws + (size_t)n * p.ws_box_stride + q.ws_off + (c - q.out_offset);
+                        const int nsl = s_misc[i];
+                        for (int kk = 0; kk < nsl; ++kk) v += w[(size_t)kk * q.C];
+                    }
+                }
+                if (!p.ln_on) {
+                    if (p.pos_mode != 0) v += hfre_sine(p, s_stat, c);
+                    p.out[(size_t)n * p.out_ld + c] = v;
+                } else if (pass == 0) {
+                    part += v;
+                } else if (pass == 1) {
+                    part += (v - mean) * (v - mean);
+                } else {
+                    const bool first = (c0 == 0 && p.ln_split > 0);      // block [0, ln_split) -> (w0, b0); otherwise (w1, b1)
+                    const float* lw = first ? p.ln_w0 : p.ln_w1;
+                    const float* lb = first ? p.ln_b0 : p.ln_b1;
+                    float o = (v - mean) * rstd * lw[c - c0] + lb[c - c0];
+                    if (p.pos_mode != 0) o += hfre_sine(p, s_stat, c);
+                    p.out[(size_t)n * p.out_ld + c] = o;
+                }
+            }
+            if (p.ln_on && pass < 2) {
+                // block-wide fixed-order reduction of `part`
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+                __syncthreads();
+                if ((tid & 63) == 0) s_stat[4 + (tid >> 6)] = part;
+                __syncthreads();
+                const float tot = (s_stat[4] + s_stat[5]) + (s_stat[6] + s_stat[7]);
+                if (pass == 0) mean = tot / (float)(c1 - c0);
+                else rstd = rsqrtf(tot / (float)(c1 - c0) + p.ln_eps);
+            }
+        }
+    }
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(kHfreThreads) void hfre_pool_items_kernel(const HfreParams p) {
+    __shared__ float s_wy[FO1_HFRE_MAX_EXTENT];
+    __shared__ float s_wx[FO1_HFRE_MAX_EXTENT];
+    __shared__ float s_red[kHfreWaves][kHfreMaxChunk];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    int n_items = *p.n_items;
+    if (n_items > p.items_cap) n_items = p.items_cap;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const int2 item = p.items[it];
+        const int n = item.x, si = item.y >> 24, chunk_id = (item.y >> 12) & 0xFFF, k = item.y & 0xFFF;
+        const HfreSrcDev& s = p.src[si];
+        const int* h = p.hdr + ((size_t)n * p.n_sources + si) * 8;
+        const int r_lo = h[0], r_hi = h[1], c_lo = h[2], c_hi = h[3], rps = h[4];
+        const int img = p.box_image ? p.box_image[n] : 0;
+        const int row0 = r_lo + k * rps;
+        int row1 = row0 + rps - 1;
+        if (row1 > r_hi) row1 = r_hi;
+        const int nrows = row1 - row0 + 1;
+        const int fw = c_hi - c_lo + 1;
+        const float* gwy = p.wbuf + ((size_t)n * p.n_sources + si) * 2 * kHfreWStride + (row0 - r_lo);
+        const float* gwx = p.wbuf + ((size_t)n * p.n_sources + si) * 2 * kHfreWStride + kHfreWStride;
+        for (int r = tid; r < nrows; r += kHfreThreads) s_wy[r] = gwy[r];
+        for (int c = tid; c < fw; c += kHfreThreads) s_wx[c] = gwx[c];
+        __syncthreads();
+
+        const int lpp = s.chunk >> 3;        // lanes per pixel (8 bf16 = 16 B per lane), power of two
+        const int spw = 64 / lpp;            // pixel slots per wave
+        const int slot = wave * spw + lane / lpp;
+        const int cl = lane & (lpp - 1);
+        const int slots = kHfreWaves * spw;
+        const int npix = nrows * fw;
+        const uint16_t* base = s.data + (long long)img * p.img_stride[si] + (size_t)chunk_id * s.chunk + (size_t)cl * 8;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+        for (int i0 = slot; i0 < npix; i0 += slots * UNROLL) {
+            uint4 v[UNROLL];
+            float w[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const int idx = i0 + u * slots;
+                const bool ok = idx < npix;
+                const int id2 = ok ? idx : i0;
+                const int r = id2 / fw;
+                const int c = id2 - r * fw;
+                w[u] = ok ? s_wy[r] * s_wx[c] : 0.0f;
+                const size_t pix = (size_t)(row0 + r) * s.W + (size_t)(c_lo + c);
+                v[u] = *reinterpret_cast<const uint4*>(base + pix * s.ld);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                acc[0] = fmaf(w[u], bf16_lo(v[u].x), acc[0]);
+                acc[1] = fmaf(w[u], bf16_hi(v[u].x), acc[1]);
+                acc[2] = fmaf(w[u], bf16_lo(v[u].y), acc[2]);
+                acc[3] = fmaf(w[u], bf16_hi(v[u].y), acc[3]);
+                acc[4] = fmaf(w[u], bf16_lo(v[u].z), acc[4]);
+                acc[5] = fmaf(w[u], bf16_hi(v[u].z), acc[5]);
+                acc[6] = fmaf(w[u], bf16_lo(v[u].w), acc[6]);
+                acc[7] = fmaf(w[u], bf16_hi(v[u].w), acc[7]);
+            }
+        }
+        for (int off = 32; off >= lpp; off >>= 1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+        }
+        if (lane < lpp) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s_red[wave][cl * 8 + j] = acc[j];
+        }
+        __syncthreads();
+        float* wsrow = p.ws + (size_t)n * p.ws_box_stride + s.ws_off + (size_t)k * s.C + (size_t)chunk_id * s.chunk;
+        for (int c = tid; c < s.chunk; c += kHfreThreads) {
+            float t = s_red[0][c];
+#pragma unroll
+            for (int wv = 1; wv < kHfreWaves; ++wv) t += s_red[wv][c];
+            wsrow[c] = t;
+        }
+        __syncthreads();   // s_wy / s_wx / s_red are rewritten by the next item
+    }
+}
+
+// grid (n_boxes, nseg): nseg channel segments per row without LayerNorm, 1 with (the statistics need the whole block)
+__global__ __launch_bounds__(kHfreThreads) void hfre_finish2_kernel(const HfreParams p) {
+    __shared__ int s_misc[FO1_HFRE_MAX_SOURCES + 4];
+    __shared__ float s_stat[8];
+    hfre_finish_row(p, blockIdx.x, blockIdx.y, gridDim.y, s_misc, s_stat);
+    // every list walker has finished before this kernel starts: leave the item counter at zero for the next call
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.n_items = 0;
+}
+
 static int g_hfre_pixel_budget = 0;  // 0 = auto
+// work-list path
+static int g_hfre_unroll = 8;        // independent 16-B loads per lane in flight (8 or 16)
+static int g_hfre_chunk = kHfreMaxChunk;   // channels per workgroup (<= kHfreMaxChunk)
+static int g_hfre_v2_budget = 256;   // pixels per slice: one value for every box count, so a box's result does not depend on what
+                                     // else is in the call (batch invariance)
+static int g_hfre_grid = 4096;       // workgroups walking the work list (profiles/r02_hfre_sweep.json)
 
 // workspace = [partials: n_boxes * ws_box_stride floats][weights: n_boxes*n_sources*2*kHfreWStride floats][headers: n_boxes*n_sources*8 ints]
 static size_t hfre_ws_total(const HfreParams& p, int n_sources, int n_boxes) {
@@ -269,7 +474,7 @@ static size_t hfre_ws_total(const HfreParams& p, int n_sources, int n_boxes) {
     return ((size_t)p.ws_box_stride * nb + nb * n_sources * 2 * kHfreWStride) * sizeof(float) + nb * n_sources * 8 * sizeof(int);
 }
 
-static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxes, HfreParams& p, int& total_wgs) {
+static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxes, HfreParams& p, int& total_wgs, bool v2 = false) {
     FO1_CHECK_ARG(sources != nullptr, "hfre: sources is NULL");
     FO1_CHECK_ARG(n_sources >= 1 && n_sources <= FO1_HFRE_MAX_SOURCES, "hfre: n_sources=%d out of [1,%d]", n_sources,
                   FO1_HFRE_MAX_SOURCES);
@@ -277,7 +482,7 @@ static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxe
     p.n_sources = n_sources;
     // measured on MI355X (profiles/r01_hfre.md): per-workgroup streaming is latency-bound (~16 KB in flight), so
     // small slices win until the empty-workgroup count takes over: 256 px up to ~48 boxes, 512 px beyond
-    p.pixel_budget = g_hfre_pixel_budget > 0 ? g_hfre_pixel_budget : (n_boxes <= 48 ? 256 : 512);
+    p.pixel_budget = g_hfre_pixel_budget > 0 ? g_hfre_pixel_budget : (v2 ? g_hfre_v2_budget : (n_boxes <= 48 ? 256 : 512));
     int wg = 0, ws = 0;
     for (int i = 0; i < n_sources; ++i) {
         const fo1_hfre_source_t& s = sources[i];
@@ -294,7 +499,7 @@ static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxe
         d.data = (const uint16_t*)s.data;
         d.H = s.H; d.W = s.W; d.C = s.C; d.ld = s.ld; d.roi_H = s.roi_H; d.roi_W = s.roi_W;
         d.scale = s.spatial_scale; d.box_space = s.box_space; d.out_offset = s.out_offset;
-        int chunk = kHfreMaxChunk;
+        int chunk = v2 ? g_hfre_chunk : kHfreMaxChunk;
         while (s.C % chunk) chunk >>= 1;
         d.chunk = chunk;
         d.nchunks = s.C / chunk;
@@ -317,6 +522,18 @@ extern "C" {
 int fo1_hfre_set_pixel_budget(int pixels) {
     if (pixels != 0 && (pixels < 16 || pixels > 65536)) return fo1::set_err(FO1_ERR_ARG, "hfre: pixel budget %d outside [16,65536] (0 = auto)", pixels);
     fo1::g_hfre_pixel_budget = pixels;
+    return FO1_OK;
+}
+
+// tuning hooks of fo1_hfre_region_pool_ex: unroll 8 | 16 independent loads per lane; chunk = channels per workgroup (64..512, power
+// of two); budget = pixels per slice (0 keeps the current value); grid = workgroups walking the work list (0 keeps)
+int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid) {
+    if ((unroll != 8 && unroll != 16) || chunk < 64 || chunk > fo1::kHfreMaxChunk || (chunk & (chunk - 1)) ||
+        (budget != 0 && (budget < 16 || budget > 65536)) || grid < 0 || grid > (1 << 20))
+        return fo1::set_err(FO1_ERR_ARG, "hfre: set_tuning(unroll=%d, chunk=%d, budget=%d, grid=%d)", unroll, chunk, budget, grid);
+    fo1::g_hfre_unroll = unroll; fo1::g_hfre_chunk = chunk;
+    if (budget) fo1::g_hfre_v2_budget = budget;
+    if (grid) fo1::g_hfre_grid = grid;
     return FO1_OK;
 }
 
@@ -368,6 +585,7 @@ int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const 
     p.ws = (float*)workspace;
     p.wbuf = p.ws + (size_t)p.ws_box_stride * n_boxes;
     p.hdr = (int*)(p.wbuf + (size_t)n_boxes * n_sources * 2 * kHfreWStride);
+    p.items = nullptr; p.n_items = nullptr; p.box_image = nullptr;
     hipStream_t st = (hipStream_t)stream;
     FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreThreads), 0, st, p);
     // algorithmic bytes (SURVEY §8d upper bound): every source map once in bf16 + fp32 output + boxes
@@ -376,6 +594,101 @@ int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const 
     FO1_LAUNCH("hfre_pool", bytes, hfre_pool_kernel, dim3(wgs), dim3(kHfreThreads), 0, st, p);
     FO1_LAUNCH("hfre_finish", (double)n_boxes * region_dim * 8.0, hfre_finish_kernel,
                dim3(cdiv(region_dim, 256), n_boxes), dim3(256), 0, st, p);
+    return FO1_OK;
+}
+
+
+// Work-list variant: same contract as fo1_hfre_region_pool, plus
+//   * batch: boxes of several same-geometry images in one call — box n belongs to image opts->box_image[n] and source i of image b
+//     starts opts->img_stride[i] elements after image b-1's (sources[i].data addresses image 0);
+//   * region LayerNorm (mm_apply_region_layer_norm, reference :365-372): fp32 LayerNorm (biased variance) of the channel blocks
+//     [0, ln_split) with (ln_w0, ln_b0) and [ln_split, region_dim) with (ln_w1, ln_b1) BEFORE the position embedding;
+//     ln_split = 0 / region_dim means one block (vt-only / aux-only configurations).
+// workspace = [64 B: item counter][partials][tap weights][headers][work items].  The counter word must be ZERO when a workspace is
+// first used (the host module's scratch pool zero-fills on allocation); the finish kernel leaves it at zero for the next call.
+static size_t hfre_ex_layout(const fo1::HfreParams& p, int n_sources, int n_boxes, int total_wgs, size_t* off_w, size_t* off_h, size_t* off_i) {
+    const size_t nb = (size_t)(n_boxes > 0 ? n_boxes : 1);
+    size_t o = 64 + (size_t)p.ws_box_stride * nb * sizeof(float);
+    if (off_w) *off_w = o;
+    o += nb * n_sources * 2 * fo1::kHfreWStride * sizeof(float);
+    if (off_h) *off_h = o;
+    o += nb * n_sources * 8 * sizeof(int);
+    if (off_i) *off_i = o;
+    o += (size_t)(total_wgs > 0 ? total_wgs : 1) * sizeof(int2);
+    return o;
+}
+
+size_t fo1_hfre_ex_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes) {
+    fo1::HfreParams p;
+    int wgs = 0;
+    if (fo1::hfre_plan(sources, n_sources, n_boxes, p, wgs, true) != FO1_OK) return 0;
+    return hfre_ex_layout(p, n_sources, n_boxes, wgs, nullptr, nullptr, nullptr);
+}
+
+int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, const float* boxes_aux, int n_boxes,
+                            const float* boxes_vt, float vt_scale_x, float vt_scale_y, int roi_size, int pos_mode, float pos_img_w,
+                            float pos_img_h, float* out, int out_ld, int region_dim, const fo1_hfre_opts_t* opts, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    using namespace fo1;
+    HfreParams p;
+    int wgs = 0;
+    int rc = hfre_plan(sources, n_sources, n_boxes, p, wgs, true);
+    if (rc != FO1_OK) return rc;
+    if (n_boxes == 0) return FO1_OK;
+    FO1_CHECK_ARG(boxes_aux != nullptr && out != nullptr, "hfre: NULL boxes/out");
+    FO1_CHECK_ARG(((uintptr_t)boxes_aux & 15) == 0 && ((uintptr_t)boxes_vt & 15) == 0, "hfre: boxes must be 16-byte aligned");
+    FO1_CHECK_ARG(roi_size >= 1 && roi_size <= 32, "hfre: roi_size=%d", roi_size);
+    FO1_CHECK_ARG(pos_mode >= 0 && pos_mode <= 2, "hfre: pos_mode=%d", pos_mode);
+    FO1_CHECK_ARG(region_dim >= 4 && out_ld >= region_dim, "hfre: region_dim=%d out_ld=%d", region_dim, out_ld);
+    FO1_CHECK_ARG(pos_mode == 0 || (region_dim % 4 == 0 && pos_img_w > 0.f && pos_img_h > 0.f),
+                  "hfre: position embedding needs region_dim %% 4 == 0 and positive image size");
+    for (int i = 0; i < n_sources; ++i) {
+        FO1_CHECK_ARG(sources[i].data != nullptr && ((uintptr_t)sources[i].data & 15) == 0, "hfre: source %d data NULL or not 16-byte aligned", i);
+        FO1_CHECK_ARG(sources[i].out_offset + sources[i].C <= region_dim, "hfre: source %d writes past region_dim", i);
+        FO1_CHECK_ARG(p.src[i].nchunks <= 0xFFF && p.src[i].max_slices <= 0xFFF, "hfre: source %d has too many chunks / slices for a work item", i);
+        p.img_stride[i] = 0;
+    }
+    p.box_image = nullptr;
+    p.ln_on = 0; p.ln_split = 0; p.ln_w0 = p.ln_b0 = p.ln_w1 = p.ln_b1 = nullptr; p.ln_eps = 1e-5f;
+    if (opts) {
+        FO1_CHECK_ARG(opts->batch >= 1, "hfre: batch=%d", opts->batch);
+        FO1_CHECK_ARG(opts->batch == 1 || opts->box_image != nullptr, "hfre: a batched call needs box_image");
+        p.box_image = opts->box_image;
+        for (int i = 0; i < n_sources; ++i) {
+            FO1_CHECK_ARG(opts->img_stride[i] % 8 == 0, "hfre: img_stride[%d] must keep 16-byte alignment", i);
+            p.img_stride[i] = opts->img_stride[i];
+        }
+        if (opts->ln_on) {
+            FO1_CHECK_ARG(opts->ln_split >= 0 && opts->ln_split <= region_dim, "hfre: ln_split=%d", opts->ln_split);
+            FO1_CHECK_ARG((opts->ln_split == 0 || (opts->ln_w0 && opts->ln_b0)) && (opts->ln_split == region_dim || (opts->ln_w1 && opts->ln_b1)),
+                          "hfre: region LayerNorm needs weight and bias for every block");
+            p.ln_on = 1; p.ln_split = opts->ln_split; p.ln_eps = opts->ln_eps;
+            p.ln_w0 = opts->ln_w0; p.ln_b0 = opts->ln_b0; p.ln_w1 = opts->ln_w1; p.ln_b1 = opts->ln_b1;
+        }
+    }
+    size_t off_w = 0, off_h = 0, off_i = 0;
+    const size_t need = hfre_ex_layout(p, n_sources, n_boxes, wgs, &off_w, &off_h, &off_i);
+    if (workspace == nullptr || workspace_bytes < need) return set_err(FO1_ERR_WORKSPACE, "hfre: workspace %zu B < required %zu B", workspace_bytes, need);
+    FO1_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "hfre: workspace must be 16-byte aligned");
+    p.boxes = boxes_aux; p.boxes_vt = boxes_vt; p.n_boxes = n_boxes; p.vsx = vt_scale_x; p.vsy = vt_scale_y;
+    p.P = roi_size; p.pos_mode = pos_mode; p.pos_w = pos_img_w; p.pos_h = pos_img_h;
+    p.out = out; p.out_ld = out_ld; p.region_dim = region_dim;
+    char* wsb = (char*)workspace;
+    p.n_items = (int*)wsb;
+    p.ws = (float*)(wsb + 64);
+    p.wbuf = (float*)(wsb + off_w);
+    p.hdr = (int*)(wsb + off_h);
+    p.items = (int2*)(wsb + off_i);
+    p.items_cap = wgs;
+    hipStream_t st = (hipStream_t)stream;
+    FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreThreads), 0, st, p);
+    double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
+    for (int i = 0; i < n_sources; ++i) bytes += (double)sources[i].H * sources[i].W * sources[i].C * 2.0 * (opts ? opts->batch : 1);
+    const int grid = wgs < g_hfre_grid ? wgs : g_hfre_grid;
+    if (g_hfre_unroll == 16) { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<16>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
+    else                     { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<8>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
+    const int nseg = p.ln_on ? 1 : 4;
+    FO1_LAUNCH("hfre_finish2", (double)n_boxes * region_dim * 8.0, hfre_finish2_kernel, dim3(n_boxes, nseg), dim3(kHfreThreads), 0, st, p);
     return FO1_OK;
 }
 

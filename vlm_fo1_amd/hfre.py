@@ -11,6 +11,7 @@ branch.  Anything else raises NotImplementedError — loudly, no fallback.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional, Sequence, Union
 
 import torch
@@ -18,6 +19,21 @@ import torch
 from . import lib as _lib
 
 FPN_STRIDES = (3.5, 7.0, 14.0, 28.0)  # reference :245
+
+
+_env_applied = False
+
+
+def _apply_env():
+    """FO1_HFRE_UNROLL / FO1_HFRE_CHUNK / FO1_HFRE_BUDGET / FO1_HFRE_GRID tune the gather (A/B hooks, process-global, read once)."""
+    global _env_applied
+    if _env_applied:
+        return
+    _env_applied = True
+    e = os.environ
+    if any(k in e for k in ("FO1_HFRE_UNROLL", "FO1_HFRE_CHUNK", "FO1_HFRE_BUDGET", "FO1_HFRE_GRID")):
+        _lib.check(_lib.load().fo1_hfre_set_tuning(int(e.get("FO1_HFRE_UNROLL", 8)), int(e.get("FO1_HFRE_CHUNK", 512)),
+                                                   int(e.get("FO1_HFRE_BUDGET", 0)), int(e.get("FO1_HFRE_GRID", 0))), "fo1_hfre_set_tuning")
 
 
 def _token_major_bf16(x: torch.Tensor) -> torch.Tensor:
@@ -40,21 +56,27 @@ class HFREModule:
                  vision_tower_spatial_scale: float = 1 / 14, use_simpleFPN_for_vt: bool = False,
                  aux_vision_tower_region_feature_dims: Sequence[int] = (256, 512, 1024, 2048),
                  aux_vision_tower_spatial_scale: float = 0.25, simple_fpn=None):
+        # Built: aux + vt ('concat' / 'concat_aux_pos'), vt only (use_vt_region_feature_only), aux only, with or without SimpleFPN,
+        # 'bbox_based' position embedding, region LayerNorm (reference :365-372).  Not built (the engine refuses loudly): the
+        # 'mean*' / '*_sep_pos' fusions (they need the extra vision_tower_region_feature_projector / hard-coded 2880-5120 splits of
+        # :373-432), per-region MLPs, and feature-map position embeddings (:327-335).
         unsupported = []
-        if use_vt_region_feature_only:
-            unsupported.append("use_vt_region_feature_only")
-        if not use_vision_tower_region_feature:
-            unsupported.append("use_vision_tower_region_feature=False")
-        if region_feature_combination != "concat":
+        if region_feature_combination not in ("concat", "concat_aux_pos"):
             unsupported.append(f"region_feature_combination={region_feature_combination!r}")
         if use_separate_mlp_for_regions:
             unsupported.append("use_separate_mlp_for_regions")
-        if apply_region_layer_norm:
-            unsupported.append("apply_region_layer_norm")
         if apply_position_embedding and pos_embedding_strategy != "bbox_based":
             unsupported.append(f"pos_embedding_strategy={pos_embedding_strategy!r}")
+        if use_vt_region_feature_only and not use_vision_tower_region_feature:
+            unsupported.append("use_vt_region_feature_only without use_vision_tower_region_feature")
         if unsupported:
             raise NotImplementedError("HFRE variant not built for the MI355X engine: " + ", ".join(unsupported))
+        self.use_vt_region_feature_only = use_vt_region_feature_only
+        self.use_vision_tower_region_feature = use_vision_tower_region_feature
+        self.region_feature_combination = region_feature_combination
+        self.apply_region_layer_norm = apply_region_layer_norm
+        self._ln = None          # (aux_w, aux_b, vt_w, vt_b) fp32 device tensors, set_region_norm()
+        self.worklist = os.environ.get("FO1_HFRE_WORKLIST", "1") != "0"   # work-list kernels (0: the round-1 worst-case-grid form, for A/B)
         self.roi_output_size = roi_output_size
         self.region_feature_dim = region_feature_dim
         self.apply_position_embedding = apply_position_embedding
@@ -65,6 +87,12 @@ class HFREModule:
         self.aux_vision_tower_spatial_scale = aux_vision_tower_spatial_scale
         self.simple_fpn = simple_fpn  # callable: [1,1280,gh,gw] -> 4 maps (engine op), when FPN is on
         self._ws = None
+
+    def set_region_norm(self, aux_weight, aux_bias, vt_weight, vt_bias):
+        """nn.LayerNorm parameters of `aux_region_norm` / `vt_region_norm` (reference :175-180); fp32 on the device."""
+        def f(t):
+            return None if t is None else t.detach().to(dtype=torch.float32).contiguous()
+        self._ln = (f(aux_weight), f(aux_bias), f(vt_weight), f(vt_bias))
 
     # -- helpers ---------------------------------------------------------------
     @staticmethod
@@ -78,69 +106,117 @@ class HFREModule:
         ld = tm.stride(2)
         return _lib.HfreSource(tm.data_ptr(), H, W, C, ld, roi_hw[0], roi_hw[1], float(scale), box_space, out_off)
 
-    def __call__(self, aux_multi_level_features: List[torch.Tensor], aux_boxes: Union[torch.Tensor, List[torch.Tensor]],
-                 vt_multi_level_features=None, vt_boxes: Union[torch.Tensor, List[torch.Tensor], None] = None,
-                 vt_scale=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Returns fp32 [1, N, region_feature_dim] like the reference (:469).  `vt_boxes`
-        may be omitted when `vt_scale=(sx, sy)` is given (vt = aux * scale in-kernel).  `out`: optional fp32 [N, C_region]
-        row-contiguous destination (the batched engine hands out row slices of one buffer)."""
+    def pool(self, srcs: list, boxes: torch.Tensor, vt_boxes: Optional[torch.Tensor], vt_scale, pos_hw, out: Optional[torch.Tensor] = None,
+             batch: int = 1, box_image: Optional[torch.Tensor] = None, img_strides: Optional[Sequence[int]] = None,
+             ln_split: Optional[int] = None) -> torch.Tensor:
+        """The C-ABI call.  srcs: HfreSource list (image 0 of every map); boxes fp32 [N,4] (all images' boxes, image of box n =
+        box_image[n]); pos_hw = (pos_h, pos_w) normalisers of the box embedding.  Returns fp32 [1, N, region_feature_dim]."""
         L = _lib.load()
-        boxes = aux_boxes[0] if isinstance(aux_boxes, (list, tuple)) else aux_boxes
-        dev = aux_multi_level_features[0].device
-        if dev.type != "cuda":
-            raise _lib.Fo1Error("HFRE runs on the HIP device only (got %s)" % dev)
-        boxes = boxes.to(device=dev, dtype=torch.float32).contiguous()
+        dev = boxes.device
         N = boxes.shape[0]
-        vtb = None
-        if vt_boxes is not None:
-            vtb = vt_boxes[0] if isinstance(vt_boxes, (list, tuple)) else vt_boxes
-            vtb = vtb.to(device=dev, dtype=torch.float32).contiguous()
-        elif vt_scale is None:
-            raise ValueError("need vt_boxes or vt_scale")
-        keep: list = []
-        srcs = []
-        H0 = max(f.shape[2] for f in aux_multi_level_features)
-        W0 = max(f.shape[3] for f in aux_multi_level_features)
-        off = 0
-        for f in aux_multi_level_features:
-            srcs.append(self._src(f, (H0, W0), self.aux_vision_tower_spatial_scale, 0, off, keep))
-            off += f.shape[1]
-        if self.use_simpleFPN_for_vt:
-            vt_in = vt_multi_level_features  # [1,1280,gh,gw]
-            gh, gw = vt_in.shape[-2:]
-            fpn_maps = self.simple_fpn(vt_in)
-            for f, s in zip(fpn_maps, FPN_STRIDES):
-                srcs.append(self._src(f, f.shape[2:], 1.0 / s, 1, off, keep))
-                off += f.shape[1]
-        else:
-            gh = max(f.shape[-2] for f in vt_multi_level_features)
-            gw = max(f.shape[-1] for f in vt_multi_level_features)
-            for f in vt_multi_level_features:
-                srcs.append(self._src(f, f.shape[2:], self.vision_tower_spatial_scale, 1, off, keep))
-                off += f.shape[1]
+        off = sum(s.C for s in srcs)
         if off != self.region_feature_dim:
             raise ValueError(f"feature channels {off} != region_feature_dim {self.region_feature_dim}")
         arr = (_lib.HfreSource * len(srcs))(*srcs)
-        need = L.fo1_hfre_workspace_bytes(arr, len(srcs), N)
-        # scratch from the owner-scoped pool (vlm_fo1_amd/ops.py): never resized in place — a captured graph may hold the pointer
-        from . import ops as _ops
-        self._ws = _ops._workspace("hfre", dev, max(int(need), 1))
         if out is None:
             out = torch.empty(1, N, off, dtype=torch.float32, device=dev)
         else:
             if out.dtype != torch.float32 or out.shape != (N, off) or out.stride(1) != 1 or out.device != dev:
                 raise ValueError(f"out must be a device fp32 [{N}, {off}] row-major tensor")
             out = out.unsqueeze(0)
-        # reference :446-448 — image size = vt map size / vt spatial scale (python floats)
-        pos_w = gw / self.vision_tower_spatial_scale
-        pos_h = gh / self.vision_tower_spatial_scale
         sx, sy = (vt_scale if vt_scale is not None else (1.0, 1.0))
-        rc = L.fo1_hfre_region_pool(arr, len(srcs), boxes.data_ptr(), N,
-                                    vtb.data_ptr() if vtb is not None else None, float(sx), float(sy),
-                                    self.roi_output_size, 1 if self.apply_position_embedding else 0,
-                                    float(pos_w), float(pos_h), out.data_ptr(), out.stride(1), off,
-                                    self._ws.data_ptr(), self._ws.numel(), _lib.current_stream_ptr())
+        pos_mode = 0
+        if self.apply_position_embedding:
+            pos_mode = 2 if (self.region_feature_combination == "concat_aux_pos" or not self.use_vision_tower_region_feature) else 1
+        from . import ops as _ops
+        use_ln = self.apply_region_layer_norm
+        if use_ln and self._ln is None:
+            raise _lib.Fo1Error("apply_region_layer_norm: call set_region_norm() with the checkpoint's LayerNorm parameters first")
+        if self.worklist or use_ln or batch > 1:
+            _apply_env()
+            need = L.fo1_hfre_ex_workspace_bytes(arr, len(srcs), N)
+            ws = _ops._workspace("hfre_ex", dev, max(int(need), 1))
+            opts = _lib.HfreOpts()
+            opts.batch = batch
+            opts.box_image = box_image.data_ptr() if box_image is not None else None
+            for i in range(8):
+                opts.img_stride[i] = int(img_strides[i]) if (img_strides is not None and i < len(srcs)) else 0
+            opts.ln_on = 1 if use_ln else 0
+            if use_ln:
+                aw, ab, vw, vb = self._ln
+                opts.ln_split = int(ln_split if ln_split is not None else 0)
+                opts.ln_w0, opts.ln_b0 = (aw.data_ptr(), ab.data_ptr()) if aw is not None else (None, None)
+                opts.ln_w1, opts.ln_b1 = (vw.data_ptr(), vb.data_ptr()) if vw is not None else (None, None)
+                opts.ln_eps = 1e-5
+            rc = L.fo1_hfre_region_pool_ex(arr, len(srcs), boxes.data_ptr(), N, vt_boxes.data_ptr() if vt_boxes is not None else None,
+                                              float(sx), float(sy), self.roi_output_size, pos_mode, float(pos_hw[1]), float(pos_hw[0]),
+                                              out.data_ptr(), out.stride(1), off, ctypes.byref(opts), ws.data_ptr(), ws.numel(),
+                                              _lib.current_stream_ptr())
+            _lib.check(rc, "fo1_hfre_region_pool_ex")
+            self._ws = ws
+            return out
+        need = L.fo1_hfre_workspace_bytes(arr, len(srcs), N)
+        # scratch from the owner-scoped pool (vlm_fo1_amd/ops.py): never resized in place — a captured graph may hold the pointer
+        self._ws = _ops._workspace("hfre", dev, max(int(need), 1))
+        rc = L.fo1_hfre_region_pool(arr, len(srcs), boxes.data_ptr(), N, vt_boxes.data_ptr() if vt_boxes is not None else None,
+                                    float(sx), float(sy), self.roi_output_size, pos_mode, float(pos_hw[1]), float(pos_hw[0]),
+                                    out.data_ptr(), out.stride(1), off, self._ws.data_ptr(), self._ws.numel(), _lib.current_stream_ptr())
         _lib.check(rc, "fo1_hfre_region_pool")
         return out
+
+    def __call__(self, aux_multi_level_features: List[torch.Tensor], aux_boxes: Union[torch.Tensor, List[torch.Tensor]],
+                 vt_multi_level_features=None, vt_boxes: Union[torch.Tensor, List[torch.Tensor], None] = None,
+                 vt_scale=None, out: Optional[torch.Tensor] = None, batch: int = 1, box_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Returns fp32 [1, N, region_feature_dim] like the reference (:469).  `vt_boxes` may be omitted when `vt_scale=(sx, sy)` is
+        given (vt = aux * scale in-kernel).  `out`: optional fp32 [N, C_region] row-contiguous destination.  batch > 1: every map
+        tensor holds `batch` same-size images stacked ([1,C,H,W] views of image 0 whose storage continues image by image, H*W*ld
+        elements apart), `aux_boxes` holds all images' boxes and `box_image` (device int32 [N]) the image of each."""
+        boxes = aux_boxes[0] if isinstance(aux_boxes, (list, tuple)) else aux_boxes
+        dev = aux_multi_level_features[0].device if aux_multi_level_features else boxes.device
+        if dev.type != "cuda":
+            raise _lib.Fo1Error("HFRE runs on the HIP device only (got %s)" % dev)
+        boxes = boxes.to(device=dev, dtype=torch.float32).contiguous()
+        vtb = None
+        if vt_boxes is not None:
+            vtb = vt_boxes[0] if isinstance(vt_boxes, (list, tuple)) else vt_boxes
+            vtb = vtb.to(device=dev, dtype=torch.float32).contiguous()
+        elif vt_scale is None and self.use_vision_tower_region_feature:
+            raise ValueError("need vt_boxes or vt_scale")
+        keep: list = []
+        srcs, strides = [], []
+        off = 0
+        H0 = W0 = 0
+        if not self.use_vt_region_feature_only:
+            H0 = max(f.shape[2] for f in aux_multi_level_features)
+            W0 = max(f.shape[3] for f in aux_multi_level_features)
+            for f in aux_multi_level_features:
+                srcs.append(self._src(f, (H0, W0), self.aux_vision_tower_spatial_scale, 0, off, keep))
+                strides.append(f.shape[2] * f.shape[3] * srcs[-1].ld)
+                off += f.shape[1]
+        aux_channels = off
+        gh = gw = 0
+        if self.use_vision_tower_region_feature:
+            if self.use_simpleFPN_for_vt:
+                vt_in = vt_multi_level_features  # [1,1280,gh,gw]
+                gh, gw = vt_in.shape[-2:]
+                fpn_maps = self.simple_fpn(vt_in)
+                for f, st in zip(fpn_maps, FPN_STRIDES):
+                    srcs.append(self._src(f, f.shape[2:], 1.0 / st, 1, off, keep))
+                    strides.append(f.shape[2] * f.shape[3] * srcs[-1].ld)
+                    off += f.shape[1]
+            else:
+                gh = max(f.shape[-2] for f in vt_multi_level_features)
+                gw = max(f.shape[-1] for f in vt_multi_level_features)
+                for f in vt_multi_level_features:
+                    srcs.append(self._src(f, f.shape[2:], self.vision_tower_spatial_scale, 1, off, keep))
+                    strides.append(f.shape[2] * f.shape[3] * srcs[-1].ld)
+                    off += f.shape[1]
+        # reference :446-455 — box normalisers: vt map size / vt scale, or (aux-based embedding) aux map size / aux scale
+        if self.use_vision_tower_region_feature and self.region_feature_combination != "concat_aux_pos":
+            pos_hw = (gh / self.vision_tower_spatial_scale, gw / self.vision_tower_spatial_scale)
+        else:
+            pos_hw = (H0 / self.aux_vision_tower_spatial_scale, W0 / self.aux_vision_tower_spatial_scale)
+        return self.pool(srcs, boxes, vtb, vt_scale, pos_hw, out=out, batch=batch, box_image=box_image, img_strides=strides,
+                         ln_split=aux_channels)
 
     forward = __call__

@@ -26,6 +26,16 @@ class HfreSource(ctypes.Structure):
     ]
 
 
+class HfreOpts(ctypes.Structure):
+    """fo1_hfre_opts_t (include/fo1.h)."""
+    _fields_ = [
+        ("batch", c_int32), ("box_image", c_void_p), ("img_stride", c_longlong * 8),
+        ("ln_on", c_int32), ("ln_split", c_int32),
+        ("ln_w0", c_void_p), ("ln_b0", c_void_p), ("ln_w1", c_void_p), ("ln_b1", c_void_p),
+        ("ln_eps", c_float),
+    ]
+
+
 class ProfileRow(ctypes.Structure):
     """fo1_profile_row_t (include/fo1.h)."""
     _fields_ = [("name", ctypes.c_char * 48), ("calls", ctypes.c_int64), ("total_ms", ctypes.c_double),
@@ -40,10 +50,15 @@ SIGNATURES = {
     "fo1_profile_read": (c_int, [ctypes.POINTER(ProfileRow), c_int, c_int]),
     "fo1_profile_stage": (c_int, [ctypes.c_char_p]),
     "fo1_hfre_set_pixel_budget": (c_int, [c_int]),
+    "fo1_hfre_set_tuning": (c_int, [c_int, c_int, c_int, c_int]),
     "fo1_hfre_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),
     "fo1_hfre_region_pool": (c_int, [ctypes.POINTER(HfreSource), c_int, c_void_p, c_int, c_void_p, c_float, c_float,
                                      c_int, c_int, c_float, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t,
                                      c_void_p]),
+    "fo1_hfre_ex_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),
+    "fo1_hfre_region_pool_ex": (c_int, [ctypes.POINTER(HfreSource), c_int, c_void_p, c_int, c_void_p, c_float, c_float,
+                                           c_int, c_int, c_float, c_float, c_void_p, c_int, c_int, ctypes.POINTER(HfreOpts), c_void_p, c_size_t,
+                                           c_void_p]),
     "fo1_gemm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                               c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_gemm_bf16_ws": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,

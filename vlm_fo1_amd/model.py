@@ -36,6 +36,9 @@ class FO1Config:
     mm_region_hidden_size: int = 5888           # 3840 (aux pyramid) + 4 x 512 (FPN); 8960 without FPN
     mm_roi_output_size: int = 7
     mm_apply_position_embedding: bool = True
+    mm_apply_region_layer_norm: bool = False      # HFRE :365-372: nn.LayerNorm on the aux and the vt block before the box embedding
+    mm_region_feature_combination: str = "concat"  # 'concat' | 'concat_aux_pos'
+    mm_use_vt_region_feature_only: bool = False
 
 
 class Projector:
@@ -80,10 +83,16 @@ class FO1Engine:
         self.mm_projector_aux = Projector(cfg.mm_projector_aux_type, weights["proj"], "mm_projector_aux.", device)
         self.hfre = HFREModule(roi_output_size=cfg.mm_roi_output_size, region_feature_dim=cfg.mm_region_hidden_size,
                                apply_position_embedding=cfg.mm_apply_position_embedding, pos_embedding_strategy="bbox_based",
-                               use_vision_tower_region_feature=True, region_feature_combination="concat",
+                               use_vision_tower_region_feature=True, region_feature_combination=cfg.mm_region_feature_combination,
+                               use_vt_region_feature_only=cfg.mm_use_vt_region_feature_only,
+                               apply_region_layer_norm=cfg.mm_apply_region_layer_norm,
                                vision_tower_region_feature_dim=2048 if cfg.mm_use_simpleFPN_for_vt else 4 * cfg.vit.hidden_size,
                                vision_tower_spatial_scale=1 / cfg.vit.patch_size,
                                use_simpleFPN_for_vt=cfg.mm_use_simpleFPN_for_vt, aux_vision_tower_spatial_scale=0.25)
+        if cfg.mm_apply_region_layer_norm:
+            pw = weights["proj"]
+            g = lambda k: pw[k].to(self.dev) if k in pw else None
+            self.hfre.set_region_norm(g("aux_region_norm.weight"), g("aux_region_norm.bias"), g("vt_region_norm.weight"), g("vt_region_norm.bias"))
         self._dummy_box = torch.tensor([[0., 10., 0., 10.]], device=self.dev)  # omchat_qwen2_5_vl.py:90-91
         import collections
         self._graphs = collections.OrderedDict()   # signature -> captured prefill graph (LRU, GRAPH_CACHE entries)
@@ -125,7 +134,8 @@ class FO1Engine:
 
     def encode_regions(self, aux_image: torch.Tensor, boxes: Optional[torch.Tensor], vt_feats: List[torch.Tensor], gh: int, gw: int):
         """-> region tokens [N, d_llm]  (encode_regions :75-108).  boxes: fp32 [N,4] xyxy in aux-image pixels."""
-        aux_maps, aux_sizes = self.davit.forward(aux_image)
+        # vt-only region features never read the aux pyramid (HFRE :293-317): the DaViT pass is skipped, the result is the same
+        aux_maps, aux_sizes = ([], []) if self.cfg.mm_use_vt_region_feature_only else self.davit.forward(aux_image)
         self._mark("davit_large")
         if boxes is None or boxes.shape[0] == 0:
             boxes = self._dummy_box
@@ -154,7 +164,7 @@ class FO1Engine:
         return out
 
     # ---- a batch of images: everything up to the first generated token of each ---------------------------------
-    def _regions_batch(self, auxs, aux_stack, boxes, want, vt_last, bp, grids):
+    def _regions_batch(self, auxs, aux_stack, boxes, want, vt_last, bp, grids, boxes_cat=None, box_image=None):
         """encode_regions (:75-108) for every request that has regions -> (region tokens [sum N, d_llm] or None, per-request
         row ranges).  DaViT / SimpleFPN run ONCE over all images when they share the aux size and the patch grid (rows stacked
         image by image); otherwise image by image.  The HFRE gather runs per image on views of the stacked maps and writes
@@ -176,7 +186,7 @@ class FO1Engine:
         for grp in groups:
             G = len(grp)
             aux = aux_stack if uniform else auxs[grp[0]].unsqueeze(0)
-            aux_maps, aux_sizes = self.davit.forward(aux)
+            aux_maps, aux_sizes = ([], []) if self.cfg.mm_use_vt_region_feature_only else self.davit.forward(aux)
             self._mark("davit_large")
             gh, gw = grids[grp[0]]
             H, W = auxs[grp[0]].shape[-2:]
@@ -189,6 +199,21 @@ class FO1Engine:
                     vt = vt_last                      # uniform batch of all requests: the stacked raster maps as they are
                 fpn_maps, fpn_sizes = self.fpn.forward(vt, gh, gw, batch=G)
                 self._mark("simple_fpn")
+            if G > 1 and boxes_cat is not None and box_image is not None:
+                # one launch for every box of every image: views of image 0, the kernel steps image by image through the stacks
+                aux_views = [nchw(t, s, 0) for t, s in zip(aux_maps, aux_sizes)]
+                if self.fpn is not None:
+                    fpn_views = [nchw(t, s, 0) for t, s in zip(fpn_maps, fpn_sizes)]
+                    self.hfre.simple_fpn = lambda x, v=fpn_views: v
+                    vt_in = nchw(vt_last[:gh * gw], (gh, gw))
+                else:
+                    vt_in = [nchw(t[:gh * gw], (gh, gw)) for t in vt_last]
+                self.hfre(aux_views, [boxes_cat], vt_in, None, vt_scale=(sw, sh), out=feat, batch=G, box_image=box_image)
+                for i in grp:
+                    ranges[i] = (row, row + boxes[i].shape[0])
+                    row += boxes[i].shape[0]
+                self._mark("hfre_region_pool")
+                continue
             for j, i in enumerate(grp):
                 aux_views = [nchw(t, s, j) for t, s in zip(aux_maps, aux_sizes)]
                 if self.fpn is not None:
@@ -215,7 +240,8 @@ class FO1Engine:
             image_tokens = self.mm_projector(tokens)
             self._mark("mm_projector")
             vt_last = feats[-1] if self.fpn is not None else feats
-            region_tokens, ranges = self._regions_batch(st["aux"], st.get("aux_stack"), st["boxes"], meta["want"], vt_last, bp, grids)
+            region_tokens, ranges = self._regions_batch(st["aux"], st.get("aux_stack"), st["boxes"], meta["want"], vt_last, bp, grids,
+                                                        st.get("boxes_cat"), st.get("box_image"))
             emb = self.llm.embed_rows(st["plan"], image_tokens, region_tokens)
             self._mark("splice")
             last, logits, toks = self.llm.prefill_packed(emb, st["cos"], st["sin"], meta["seqs"], st["last"])
@@ -248,7 +274,8 @@ class FO1Engine:
         meta = dict(grids=tuple(grids), want=tuple(want), seqs=tuple(hp["seqs"]))
         pix = requests[0]["pix"] if B == 1 else torch.cat([r["pix"].to(self.dev) for r in requests], 0)
         auxs = [r["aux"] if r["aux"].dim() == 3 else r["aux"][0] for r in requests]
-        host = dict(plan=hp["plan"], cos=hp["cos"], sin=hp["sin"], last=hp["last"])
+        host = dict(plan=hp["plan"], cos=hp["cos"], sin=hp["sin"], last=hp["last"],
+                    box_image=torch.tensor([i for i, b in enumerate(boxes) for _ in range(b.shape[0])], dtype=torch.int32))
         key = (meta["grids"], tuple(tuple(a.shape) for a in auxs), tuple(n_reg), meta["seqs"], meta["want"], pix.dtype, auxs[0].dtype,
                self.llm.cache_epoch)
         ent = self._graphs.get(key) if use_graph else None
@@ -264,6 +291,8 @@ class FO1Engine:
             st = dict(pix=pix, aux=auxs, boxes=boxes, **{k: v.to(self.dev) for k, v in host.items()})
             if len({tuple(a.shape) for a in auxs}) == 1:      # same-size aux images: one DaViT pass over the stack (input staging)
                 st["aux_stack"] = auxs[0].unsqueeze(0) if B == 1 else torch.stack([a.to(self.dev) for a in auxs], 0)
+                if B > 1:
+                    st["boxes_cat"] = torch.cat(boxes, 0)
             res = self._device_batch(st, meta)
         else:
             self._graphs.move_to_end(key)
@@ -335,6 +364,9 @@ class FO1Engine:
                 if len({tuple(a.shape) for a in auxs}) == 1:
                     st["aux_stack"] = torch.stack([a.to(self.dev) for a in auxs], 0)
                     st["aux"] = list(st["aux_stack"].unbind(0))       # views: refreshing them refreshes the stack
+                    if len(boxes) > 1:
+                        st["boxes_cat"] = torch.cat(st["boxes"], 0)
+                        st["boxes"] = list(st["boxes_cat"].split([b.shape[0] for b in boxes], 0))
                 else:
                     st["aux"] = [a.clone() for a in auxs]
             s = torch.cuda.Stream()   # warm-up on a side stream (allocates every lazily-created scratch buffer), then capture
