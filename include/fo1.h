@@ -303,6 +303,10 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
                               int max_kv_len, int n_q_heads, int n_kv_heads, int head_dim, float scale,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* A/B hook of fo1_gemv_batch_bf16: 0 (default) = a lane streams 1 / 2 / 4 weight rows per chunk position by M (x chunks read from
+ * LDS are shared between them); 1 = always one row.  Results are bit-identical either way.  Process-global. */
+int fo1_gemv_batch_set_rows_per_lane(int rpl);
+
 /* ------------------------------------------------------------------------
  * Batched greedy decode: B <= 8 sequences advance one token per step through ONE stream of the weights, and
  * every position-dependent quantity lives in device memory, so a single captured hipGraph serves every step.

@@ -8,6 +8,9 @@ import bench
 from vlm_fo1_amd import lib as L
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if "FO1_GEMV_RPL" in os.environ:
+    L.check(L.load().fo1_gemv_batch_set_rows_per_lane(int(os.environ["FO1_GEMV_RPL"])), "set_rpl")
+    print("rows per lane setting =", os.environ["FO1_GEMV_RPL"])
 dev = torch.device("cuda", 0)
 cases = [bench.build_workload(dev, n_boxes=100, seed=1234 + i) for i in range(B)]
 pipe = bench.Pipeline(cases[0], dev, inflight=1, batch=B, cases=cases)

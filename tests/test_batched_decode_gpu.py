@@ -88,10 +88,42 @@ def test_batched_decode_vs_alone_vs_oracle_and_stop_rule():
     assert [g[:3] for g in got[True]] == eng.generate_batch(reqs, max_new_tokens=3, use_graph=True)
 
 
-def test_gemv_batch_matches_reference():
-    """fo1_gemv_batch_bf16 (plain / SwiGLU epilogues, fused RMSNorm, K pieces for deep K at M = 8) against torch fp32."""
+@pytest.mark.parametrize("rows_per_lane", [0, 1])
+def test_gemv_batch_matches_reference(rows_per_lane):
+    """fo1_gemv_batch_bf16 (plain / SwiGLU epilogues, fused RMSNorm, K pieces for deep K at M = 8) against torch fp32, with the
+    rows-per-lane blocking by M (0, default) and with one row per lane (1)."""
     from test_ops_gpu import gemm_ref, rb
-    from vlm_fo1_amd import ops
+    from vlm_fo1_amd import lib as L, ops
+    L.check(L.load().fo1_gemv_batch_set_rows_per_lane(rows_per_lane), "set_rows_per_lane")
+    try:
+        _gemv_batch_cases(gemm_ref, rb, ops)
+    finally:
+        L.load().fo1_gemv_batch_set_rows_per_lane(0)
+
+
+def test_gemv_batch_rows_independent_of_batch():
+    """Sequence m's outputs are the same numbers whether it runs alone or with 7 others, and whatever the rows-per-lane blocking:
+    the per-(row, sequence) fp32 sum order is fixed by the shape alone (K segments, K split over waves, 8 lanes per row) — what
+    lets a request decode identically alone and in a batch."""
+    from vlm_fo1_amd import lib as L, ops
+    BF = torch.bfloat16
+    torch.manual_seed(9)
+    for (N, K) in [(2048, 2048), (2048, 11008), (22016 // 4, 2048)]:
+        x = (torch.randn(8, K) * 0.5).to(BF).cuda()
+        w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+        full = ops.gemv_batch(x, w)
+        for m in (0, 3, 7):
+            assert torch.equal(ops.gemv_batch(x[m:m + 1].contiguous(), w)[0], full[m]), (N, K, m)
+        assert torch.equal(ops.gemv_batch(x[:3].contiguous(), w), full[:3])
+        assert torch.equal(ops.gemv_batch(x[:4].contiguous(), w), full[:4])
+        L.check(L.load().fo1_gemv_batch_set_rows_per_lane(1), "set_rows_per_lane")
+        try:
+            assert torch.equal(ops.gemv_batch(x, w), full)
+        finally:
+            L.load().fo1_gemv_batch_set_rows_per_lane(0)
+
+
+def _gemv_batch_cases(gemm_ref, rb, ops):
     BF = torch.bfloat16
     torch.manual_seed(5)
     for (M, N, K, hb, hr) in [(1, 2048, 2048, False, True), (3, 2560, 2048, True, False), (8, 2048, 11008, False, True), (5, 1000, 264, True, True),

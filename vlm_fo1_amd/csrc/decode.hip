@@ -38,6 +38,7 @@ struct GemvBParams {
     const uint16_t* norm_w;  // optional fused RMSNorm on x
     float norm_eps;
     int kp_chunks;           // 16-B chunks of K staged in LDS at a time
+    int canon_chunks;        // canonical K segment (chunks): the K split over waves is per segment, the same for every M
     // QKV mode
     int n_q, n_kv;           // heads (head_dim 128)
     const uint16_t* cos_t; const uint16_t* sin_t;   // [rows, 128] bf16 tables
@@ -69,11 +70,15 @@ enum { GB_PLAIN = 0, GB_SWIGLU = 1, GB_QKV = 2 };
 // lane-per-chunk mapping would need 6 shuffles for each of 8 x MM sums: 384 ds_bpermute per unit at MM = 8).
 // KSPLIT: the 4 waves of a workgroup share a unit and split K (few-row projections: every CU streams); otherwise one unit per
 // wave.  Workgroups are persistent over units (grid-stride): x is staged (and RMS-normalised) once per workgroup.
-template <int MM, int MODE, bool KSPLIT>
+// RPL (rows per lane): a lane streams row j of RPL consecutive units at the same chunk position and shares every x chunk it reads
+// from LDS between them.  At M = 8 one unit per lane reads 8 x-chunks per weight chunk — LDS traffic 8x the weight stream, 9 us
+// for the 90 MB gate/up matrix on its own; RPL = 4 brings it to 2x.  The per-(row, sequence) sum order does not depend on RPL
+// (or on M): a sequence decodes to the same numbers alone and in any batch.
+template <int MM, int MODE, bool KSPLIT, int RPL>
 __global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
-    constexpr int NR = 8, U = KSPLIT ? 16 : 8;   // 16-B weight loads in flight per lane
+    constexpr int NR = 8, U = 8 / RPL;   // 16-B weight loads per row per batch; two batches (register buffers) in flight per lane
     extern __shared__ __attribute__((aligned(16))) uint16_t sx[];   // [MM][kp_chunks * 8]
-    __shared__ float s_red[4][NR * MM];
+    __shared__ float s_red[4][RPL * NR * MM];
     __shared__ float s_rstd[8];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int jrow = lane >> 3, kslot = lane & 7;
@@ -127,71 +132,129 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
             __syncthreads();
         }
     };
-    if (single_piece) stage_x(0, kch);          // the common case: x staged once for every unit of this workgroup
-
-    const int ustep = KSPLIT ? gridDim.x : gridDim.x * 4;
-    for (int unit = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave; KSPLIT ? unit < n_units : (unit - wave) < n_units; unit += ustep) {
-        const bool unit_ok = unit < n_units;    // non-KSPLIT: the trailing waves of the last workgroup idle but keep the barriers below
-        // ---- this lane's weight row ----
+    // this lane's weight row of a unit
+    auto unit_row = [&](int unit) -> const uint16_t* {
+        const int u = unit < n_units ? unit : n_units - 1, j = jrow;
         int row;
-        {
-            const int u = unit_ok ? unit : n_units - 1, j = jrow;
-            if (MODE == GB_SWIGLU) { const int f = u * 4 + (j & 3); row = (f >> 4) * 32 + (f & 15) + (j >= 4 ? 16 : 0); }
-            else if (MODE == GB_QKV) {
-                if (u < n_rope) row = (u >> 4) * 128 + (u & 15) * 4 + (j & 3) + (j >= 4 ? 64 : 0);
-                else row = (p.n_q + p.n_kv) * 128 + (u - n_rope) * 8 + j;
-            } else row = u * 8 + j;
-            row = row < p.N ? row : p.N - 1;     // clamp (result discarded)
-        }
-        const uint16_t* wrow = p.W + (long long)row * p.ldw;
-        float acc[MM];
+        if (MODE == GB_SWIGLU) { const int f = u * 4 + (j & 3); row = (f >> 4) * 32 + (f & 15) + (j >= 4 ? 16 : 0); }
+        else if (MODE == GB_QKV) {
+            if (u < n_rope) row = (u >> 4) * 128 + (u & 15) * 4 + (j & 3) + (j >= 4 ? 64 : 0);
+            else row = (p.n_q + p.n_kv) * 128 + (u - n_rope) * 8 + j;
+        } else row = u * 8 + j;
+        row = row < p.N ? row : p.N - 1;     // clamp (result discarded)
+        return p.W + (long long)row * p.ldw;
+    };
+    // this wave's chunk range inside a K piece of kpn chunks (multiples of 8: one chunk per lane of a row group)
+    auto wave_range = [&](int kpn, int& c_begin, int& c_end) {
+        const int kq = KSPLIT ? ((kpn + 3) / 4 + 7) / 8 * 8 : kpn;
+        c_begin = KSPLIT ? min(kpn, wave * kq) : 0;
+        c_end = KSPLIT ? min(kpn, c_begin + kq) : kpn;
+    };
+    auto wload = [&](const uint16_t* const (&wrow)[RPL], int kp0, int c0, int c_end, uint4 (&w)[RPL][U]) {
 #pragma unroll
-        for (int m = 0; m < MM; ++m) acc[m] = 0.f;
-        for (int kp0 = 0; kp0 < kch; kp0 += p.kp_chunks) {
-            const int kpn = min(p.kp_chunks, kch - kp0);
-            if (!single_piece) {
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 8;
+#pragma unroll
+            for (int q = 0; q < RPL; ++q)
+                w[q][u] = c < c_end ? load_nt16(wrow[q] + (long long)(kp0 + c) * 8) : uint4{0, 0, 0, 0};
+        }
+    };
+    auto wdot = [&](const uint4 (&w)[RPL][U], int xoff, int c0, int c_end, float (&acc)[RPL][MM]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = c0 + u * 8;
+            if (c < c_end) {
+#pragma unroll
+                for (int m = 0; m < MM; ++m) {
+                    const uint4 xv = *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + xoff + c) * 8]);
+#pragma unroll
+                    for (int q = 0; q < RPL; ++q) acc[q][m] = dot8b(w[q][u], xv, acc[q][m]);
+                }
+            }
+        }
+    };
+
+    // work item = RPL consecutive units ("super-unit"); KSPLIT: one per workgroup, else one per wave
+    const int n_super = (n_units + RPL - 1) / RPL;
+    const int sstep = KSPLIT ? gridDim.x : gridDim.x * 4;
+    const int su0 = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
+    // The weight stream does not depend on x: the first batch of 16-byte loads of this wave's first item is issued BEFORE x is
+    // staged and normalised, and every later batch one step ahead of its use (two register buffers), across item boundaries too.
+    uint4 w0[RPL][U], w1[RPL][U];
+    const uint16_t* wrow[RPL];
+    int cb = 0, ce = 0;           // this wave's chunk range in the first K segment (the same for every unit)
+    if (single_piece) {
+        wave_range(min(p.canon_chunks, kch), cb, ce);
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) wrow[q] = unit_row(su0 * RPL + q);
+        wload(wrow, 0, cb + kslot, su0 < n_super ? ce : 0, w0);
+        stage_x(0, kch);          // the common case: x staged once for every unit of this workgroup
+    }
+
+    for (int su = su0; KSPLIT ? su < n_super : (su - wave) < n_super; su += sstep) {
+        const bool su_ok = su < n_super;        // non-KSPLIT: the trailing waves of the last workgroup idle but keep the barriers below
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) wrow[q] = unit_row(su * RPL + q);
+        float acc[RPL][MM];
+#pragma unroll
+        for (int q = 0; q < RPL; ++q)
+#pragma unroll
+            for (int m = 0; m < MM; ++m) acc[q][m] = 0.f;
+        if (single_piece) {
+            // x is resident; K is still walked segment by segment (a segment = what fits LDS at M = 8) with the K split over waves
+            // inside each segment, so that the fp32 sum order is the one of the staged-in-pieces M = 8 launch
+            for (int seg0 = 0; seg0 < kch; seg0 += p.canon_chunks) {
+                int sb_, se_;
+                wave_range(min(p.canon_chunks, kch - seg0), sb_, se_);
+                const int c_end = su_ok ? se_ : 0;
+                if (seg0 != 0) wload(wrow, seg0, sb_ + kslot, c_end, w0);    // (the first segment's first batch is already in flight)
+                for (int c0 = sb_ + kslot; c0 < c_end; c0 += 16 * U) {
+                    wload(wrow, seg0, c0 + 8 * U, c_end, w1);
+                    wdot(w0, seg0, c0, c_end, acc);
+                    wload(wrow, seg0, c0 + 16 * U, c_end, w0);
+                    wdot(w1, seg0, c0 + 8 * U, c_end, acc);
+                }
+            }
+            // next item's first batch goes out before this item's reduction and epilogue
+            const int ns = su + sstep;
+            const uint16_t* nrow[RPL];
+#pragma unroll
+            for (int q = 0; q < RPL; ++q) nrow[q] = unit_row(ns * RPL + q);
+            wload(nrow, 0, cb + kslot, ns < n_super ? ce : 0, w0);
+        } else {
+            for (int kp0 = 0; kp0 < kch; kp0 += p.kp_chunks) {
+                const int kpn = min(p.kp_chunks, kch - kp0);
                 __syncthreads();                 // everyone is done with the previous K piece
                 stage_x(kp0, kpn);
-            }
-            if (unit_ok) {
-                // this wave's chunk range inside the piece (multiples of 8: one chunk per lane of a row group)
-                const int kq = KSPLIT ? ((kpn + 3) / 4 + 7) / 8 * 8 : kpn;
-                const int c_begin = KSPLIT ? min(kpn, wave * kq) : 0;
-                const int c_end = KSPLIT ? min(kpn, c_begin + kq) : kpn;
-                for (int c0 = c_begin + kslot; c0 < c_end; c0 += 8 * U) {
-                    uint4 w[U];
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int c = c0 + u * 8;
-                        w[u] = c < c_end ? load_nt16(wrow + (long long)(kp0 + c) * 8) : uint4{0, 0, 0, 0};
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) {
-                        const int c = c0 + u * 8;
-                        if (c < c_end) {
-#pragma unroll
-                            for (int m = 0; m < MM; ++m)
-                                acc[m] = dot8b(w[u], *reinterpret_cast<const uint4*>(&sx[(m * p.kp_chunks + c) * 8]), acc[m]);
-                        }
+                if (su_ok) {
+                    int c_begin, c_end;
+                    wave_range(kpn, c_begin, c_end);
+                    for (int c0 = c_begin + kslot; c0 < c_end; c0 += 8 * U) {
+                        wload(wrow, kp0, c0, c_end, w0);
+                        wdot(w0, 0, c0, c_end, acc);
                     }
                 }
             }
         }
         // ---- reduce the 8 lanes of each row, then (KSPLIT) the 4 waves through LDS ----
 #pragma unroll
-        for (int m = 0; m < MM; ++m) {
-            acc[m] += __shfl_xor(acc[m], 1, 64);
-            acc[m] += __shfl_xor(acc[m], 2, 64);
-            acc[m] += __shfl_xor(acc[m], 4, 64);
-        }
-        float* red = s_red[KSPLIT ? 0 : wave];   // the unit's NR*MM sums (fp32), index j * MM + m
+        for (int q = 0; q < RPL; ++q)
+#pragma unroll
+            for (int m = 0; m < MM; ++m) {
+                acc[q][m] += __shfl_xor(acc[q][m], 1, 64);
+                acc[q][m] += __shfl_xor(acc[q][m], 2, 64);
+                acc[q][m] += __shfl_xor(acc[q][m], 4, 64);
+            }
+        float* redw = s_red[KSPLIT ? 0 : wave];   // the item's RPL * NR * MM sums (fp32), index (q * NR + j) * MM + m
         if (KSPLIT) {
             if (kslot == 0) {
 #pragma unroll
-                for (int m = 0; m < MM; ++m) s_red[wave][jrow * MM + m] = acc[m];
+                for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) s_red[wave][(q * NR + jrow) * MM + m] = acc[q][m];
             }
             __syncthreads();
-            if (tid < NR * MM) {
+            if (tid < RPL * NR * MM) {
                 const float t = (s_red[0][tid] + s_red[1][tid]) + (s_red[2][tid] + s_red[3][tid]);
                 s_red[0][tid] = t;      // each thread reads and writes only its own slot of row 0
             }
@@ -199,11 +262,18 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
         } else {
             if (kslot == 0) {
 #pragma unroll
-                for (int m = 0; m < MM; ++m) red[jrow * MM + m] = acc[m];
+                for (int q = 0; q < RPL; ++q)
+#pragma unroll
+                    for (int m = 0; m < MM; ++m) redw[(q * NR + jrow) * MM + m] = acc[q][m];
             }
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
+#pragma unroll
+        for (int q = 0; q < RPL; ++q) {
+        const int unit = su * RPL + q;
+        const bool unit_ok = su_ok && unit < n_units;
+        const float* red = redw + q * NR * MM;
         if (unit_ok && (!KSPLIT || wave == 0)) {
             // ---- epilogue: lane -> (row slot j, sequence m) ----
             if (MODE == GB_PLAIN) {
@@ -245,9 +315,9 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
                             const int* st = p.state + m * 8;
                             const long long trow = st[1];
                             const float ca = bf16_to_f32(p.cos_t[trow * 128 + d]), sa = bf16_to_f32(p.sin_t[trow * 128 + d]);
-                            const float cb = bf16_to_f32(p.cos_t[trow * 128 + d + 64]), sb = bf16_to_f32(p.sin_t[trow * 128 + d + 64]);
+                            const float cb2 = bf16_to_f32(p.cos_t[trow * 128 + d + 64]), sb = bf16_to_f32(p.sin_t[trow * 128 + d + 64]);
                             const uint16_t oa = f32_to_bf16(gb_round(a * ca) + gb_round(-b * sa));   // rotate_half, three bf16 roundings
-                            const uint16_t ob = f32_to_bf16(gb_round(b * cb) + gb_round(a * sb));
+                            const uint16_t ob = f32_to_bf16(gb_round(b * cb2) + gb_round(a * sb));
                             if (head < p.n_q) {
                                 p.C[(long long)m * p.ldc + ra] = oa;
                                 p.C[(long long)m * p.ldc + rb_] = ob;
@@ -272,30 +342,33 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
                 }
             }
         }
-        if (KSPLIT) __syncthreads();             // s_red is reused by the next unit
+        }
+        if (KSPLIT) __syncthreads();             // s_red is reused by the next item
         else { __builtin_amdgcn_wave_barrier(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     }
 }
 
-template <int MM, int MODE, bool KS>
+template <int MM, int MODE, bool KS, int RPL>
 static int launch_gemv_b(const GemvBParams& p, const char* name, int n_units, hipStream_t st) {
     const size_t smem = (size_t)MM * p.kp_chunks * 16;
     static bool attr = false;
     if (!attr) {
-        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_batch_kernel<MM, MODE, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_batch_kernel<MM, MODE, KS, RPL>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr = true;
     }
-    // persistent workgroups (grid-stride over units): x is staged / normalised once per workgroup; <= 4 workgroups per CU
-    int grid = KS ? n_units : cdiv(n_units, 4);
-    if (grid > 512) {   // about two workgroups per CU, every wave the same number of units
+    // persistent workgroups (grid-stride over work items): x is staged / normalised once per workgroup; <= 4 workgroups per CU
+    const int n_super = cdiv(n_units, RPL);
+    int grid = KS ? n_super : cdiv(n_super, 4);
+    if (grid > 512) {   // about two workgroups per CU, every wave the same number of items
         const int per = cdiv(grid, 512);
         grid = cdiv(grid, per);
     }
-    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_batch_kernel<MM, MODE, KS>), dim3(grid), dim3(256), smem, st, p);
+    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_batch_kernel<MM, MODE, KS, RPL>), dim3(grid), dim3(256), smem, st, p);
     return FO1_OK;
 }
 
 extern int g_gemv_profile_shapes;
+static int g_gemv_rpl = 0;   // rows per lane: 0 = by M (fo1_gemv_batch_set_rows_per_lane)
 
 template <int MM>
 static int dispatch_gemv_b(GemvBParams& p, int mode, hipStream_t st) {
@@ -305,22 +378,39 @@ static int dispatch_gemv_b(GemvBParams& p, int mode, hipStream_t st) {
     while ((size_t)MM * cdiv(cdiv(kch, pieces), 256) * 256 * 16 > 128 * 1024) ++pieces;
     p.kp_chunks = cdiv(cdiv(kch, pieces), 256) * 256;
     if (p.kp_chunks > kch) p.kp_chunks = kch;
+    {   // canonical segment = the piece an 8-sequence launch stages (independent of this launch's M)
+        int pc = 1;
+        while ((size_t)8 * cdiv(cdiv(kch, pc), 256) * 256 * 16 > 128 * 1024) ++pc;
+        p.canon_chunks = cdiv(cdiv(kch, pc), 256) * 256;
+        if (p.canon_chunks > kch) p.canon_chunks = kch;
+        if (p.kp_chunks < kch) p.kp_chunks = p.canon_chunks;      // staged in pieces: the pieces ARE the canonical segments
+    }
     if (p.norm_w && p.kp_chunks < kch) return set_err(FO1_ERR_ARG, "gemv_batch: fused RMSNorm needs K to fit one LDS piece (K=%d, M=%d)", p.K, MM);
     int n_units;
     if (mode == GB_SWIGLU) n_units = p.N / 8;
     else if (mode == GB_QKV) n_units = (p.n_q + p.n_kv) * 16 + p.n_kv * 16;
     else n_units = cdiv(p.N, 8);
-    // every CU should stream: one unit per workgroup (K split over its 4 waves) unless that would make more than ~2048 workgroups
+    // every CU should stream: one unit per workgroup (K split over its 4 waves) unless that would make more than ~2048 workgroups.
+    // (Decided by the shape alone: the K split fixes the fp32 sum order, which must not depend on M.)
     const bool ks = n_units <= 1024;
+    // rows per lane: many-unit matrices (gate/up, lm_head) 4 at M = 8, 2 at M = 4 (gate/up 35.6 -> 32.8 us, lm_head 139 -> 120 us
+    // at M = 8); the K-split projections stay at 1 — with 2 they have half the workgroups and ran slower (down 22.7 -> 26.5 us)
+    constexpr int RA = MM >= 8 ? 4 : (MM >= 4 ? 2 : 1), RB = 1;
+    const bool one = g_gemv_rpl == 1;
     char pname[48];
     const char* name = mode == GB_SWIGLU ? "gemv_batch_swiglu" : (mode == GB_QKV ? "gemv_batch_qkv" : "gemv_batch");
     if (profile_enabled() && g_gemv_profile_shapes) {
-        snprintf(pname, sizeof pname, "gemv_b m%d %dx%d mode%d ks%d", p.M, p.N, p.K, mode, (int)ks);
+        snprintf(pname, sizeof pname, "gemv_b m%d %dx%d mode%d ks%d r%d", p.M, p.N, p.K, mode, (int)ks, one ? 1 : (ks ? RB : RA));
         name = pname;
     }
-    if (mode == GB_SWIGLU) return ks ? launch_gemv_b<MM, GB_SWIGLU, true>(p, name, n_units, st) : launch_gemv_b<MM, GB_SWIGLU, false>(p, name, n_units, st);
-    if (mode == GB_QKV) return launch_gemv_b<MM, GB_QKV, true>(p, name, n_units, st);
-    return ks ? launch_gemv_b<MM, GB_PLAIN, true>(p, name, n_units, st) : launch_gemv_b<MM, GB_PLAIN, false>(p, name, n_units, st);
+    if (one) {
+        if (mode == GB_SWIGLU) return ks ? launch_gemv_b<MM, GB_SWIGLU, true, 1>(p, name, n_units, st) : launch_gemv_b<MM, GB_SWIGLU, false, 1>(p, name, n_units, st);
+        if (mode == GB_QKV) return launch_gemv_b<MM, GB_QKV, true, 1>(p, name, n_units, st);
+        return ks ? launch_gemv_b<MM, GB_PLAIN, true, 1>(p, name, n_units, st) : launch_gemv_b<MM, GB_PLAIN, false, 1>(p, name, n_units, st);
+    }
+    if (mode == GB_SWIGLU) return ks ? launch_gemv_b<MM, GB_SWIGLU, true, RB>(p, name, n_units, st) : launch_gemv_b<MM, GB_SWIGLU, false, RA>(p, name, n_units, st);
+    if (mode == GB_QKV) return launch_gemv_b<MM, GB_QKV, true, RB>(p, name, n_units, st);
+    return ks ? launch_gemv_b<MM, GB_PLAIN, true, RB>(p, name, n_units, st) : launch_gemv_b<MM, GB_PLAIN, false, RA>(p, name, n_units, st);
 }
 
 static int gemv_b_any(GemvBParams& p, int mode, hipStream_t st) {
@@ -450,6 +540,16 @@ __global__ __launch_bounds__(256) void kv_relocate_kernel(const uint16_t* __rest
 }  // namespace fo1
 
 extern "C" {
+
+
+
+// A/B hook: 1 = one unit (8 weight rows) per lane group whatever M is (the first form of this kernel); 0 = rows per lane by M.
+int fo1_gemv_batch_set_rows_per_lane(int rpl) {
+    if (rpl != 0 && rpl != 1) return fo1::set_err(FO1_ERR_ARG, "gemv_batch_set_rows_per_lane: %d", rpl);
+    fo1::g_gemv_rpl = rpl;
+    return FO1_OK;
+}
+
 
 // Batched decode projection: C[M<=8, N] = epilogue(rmsnorm?(x) @ W^T), weights streamed once for all M rows.
 // mode 0: bias -> bf16 -> + residual;  mode 1: interleaved SwiGLU (C has N/2 columns);  mode 2: fused QKV:

@@ -50,6 +50,7 @@ SIGNATURES = {
     "fo1_profile_read": (c_int, [ctypes.POINTER(ProfileRow), c_int, c_int]),
     "fo1_profile_stage": (c_int, [ctypes.c_char_p]),
     "fo1_hfre_set_pixel_budget": (c_int, [c_int]),
+    "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
     "fo1_hfre_set_tuning": (c_int, [c_int, c_int, c_int, c_int]),
     "fo1_hfre_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),
     "fo1_hfre_region_pool": (c_int, [ctypes.POINTER(HfreSource), c_int, c_void_p, c_int, c_void_p, c_float, c_float,
