@@ -342,6 +342,89 @@ int fo1_kv_relocate(const void* ksrc, void* kdst, long long ks_layer, long long 
                     int n_layers, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Stage-level entries: one call per fused stage, for hosts that do not want to sequence the primitives
+ * themselves.  Every pointer is a device pointer unless marked host; weights are bf16 in the engine's layouts (below); the
+ * caller owns all memory including the workspace (sizes from the *_workspace_bytes queries); calls are asynchronous on
+ * `stream`, allocate nothing, and may be captured in a hipGraph.  Each entry issues exactly the primitive launches of the
+ * Python mirror (vlm_fo1_amd/vit.py, llm.py) — results are bit-identical to it (tests/test_stage_abi_gpu.py).
+ *
+ *   fo1_vit_forward      Qwen2.5-VL vision tower over packed patch rows (one or several images): window-ordered patch embed,
+ *                        `depth` blocks (RMSNorm, QKV, 2-D RoPE, windowed / full attention, proj, SwiGLU MLP), merger; emits the
+ *                        merged image tokens and the raster feature map of every full-attention block asked for.
+ *                        reference: modeling_qwen2_5_vl.py:436-504 (blocks :306-357, merger :140-158) as driven by
+ *                        qwen2_5_vl_encoder.py:37-80,86-158,228-257
+ *   fo1_llm_prefill      36-layer Qwen2.5 decoder over packed prompt rows (varlen causal segments), KV cache written at
+ *                        [pos0, pos0 + rows); last-row final norm + lm_head + greedy pick per sequence.
+ *                        reference: modeling_qwen2_5_vl.py:1014-1095,1126-1242; omchat_qwen2_5_vl.py:143-155
+ *   fo1_llm_decode_step  one token for `batch` sequences (state / plan / stop rule as in the batched decode block above).
+ * ---------------------------------------------------------------------- */
+typedef struct fo1_vit_block {   /* bf16 device pointers; Linear weights [out, in] */
+    const void* n1; const void* n2;                 /* RMSNorm weights [hidden]                                          */
+    const void* wqkv; const void* bqkv;             /* [3 hidden, hidden], [3 hidden]                                    */
+    const void* wo; const void* bo;                 /* [hidden, hidden], [hidden]                                        */
+    const void* wgu; const void* bgu;               /* gate/up interleaved in 16-row groups, rows padded: [2 ff_padded, hidden] */
+    const void* wd; const void* bd;                 /* [hidden, ff_padded] (zero columns beyond ff), [hidden]            */
+} fo1_vit_block_t;
+typedef struct fo1_vit_weights {
+    int32_t depth, hidden, n_heads, ff_padded, k_in, k_in_padded, merge, out_hidden;
+    int32_t n_fullatt; int32_t fullatt[8];          /* indices of the full-attention blocks, ascending                    */
+    const void* patch_w;                            /* [hidden, k_in_padded] (zero columns beyond k_in)                  */
+    const fo1_vit_block_t* blocks;                  /* HOST array [depth]                                                 */
+    const void* ln_q; const void* m0w; const void* m0b; const void* m2w; const void* m2b;   /* merger                    */
+} fo1_vit_weights_t;
+typedef struct fo1_vit_plan {    /* index plan of the packed images (host mirror: vlm_fo1_amd/vit.py GridPlan / BatchPlan) */
+    int32_t S;                                      /* patch rows in this pass (multiple of merge^2)                      */
+    const int32_t* plan_in;                         /* [S][2]   window-order row r reads input row plan_in[r][1]          */
+    const int32_t* plan_raster;                     /* [S][2]   raster row -> window-order row                            */
+    const int32_t* plan_tokens;                     /* [S/4][2] raster-merged token -> window-order merge unit            */
+    const float* cos; const float* sin;             /* [S][head_dim/2] 2-D rope angles in window order                    */
+    const int32_t* items_win; int32_t n_items_win, q_block_win;       /* attention work items (fo1_attention_bf16)       */
+    const int32_t* items_full; int32_t n_items_full, q_block_full;
+    double flops_win, flops_full;                   /* profiler hints                                                     */
+} fo1_vit_plan_t;
+size_t fo1_vit_workspace_bytes(const fo1_vit_weights_t* w, int S);
+int fo1_vit_forward(const fo1_vit_weights_t* w, const fo1_vit_plan_t* plan, const void* pixel_rows /* bf16 [S, ld_pixels] */,
+                    int ld_pixels, void* tokens_out /* bf16 [S/4, out_hidden] */,
+                    void* const* feature_maps_out /* HOST array [n_fullatt] of bf16 [S, hidden] destinations, NULL entries skipped */,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+typedef struct fo1_llm_layer {
+    const void* ln1; const void* ln2;               /* input / post-attention RMSNorm [hidden]                            */
+    const void* wqkv; const void* bqkv;             /* [(n_heads + 2 n_kv) head_dim, hidden] rows q | k | v, and bias     */
+    const void* wo;                                 /* [hidden, n_heads head_dim]                                         */
+    const void* wgu;                                /* gate/up interleaved in 16-row groups [2 intermediate, hidden]      */
+    const void* wdown;                              /* [hidden, intermediate]                                             */
+} fo1_llm_layer_t;
+typedef struct fo1_llm_weights {
+    int32_t n_layers, hidden, n_heads, n_kv_heads, head_dim, intermediate, vocab;
+    float rms_eps;
+    const fo1_llm_layer_t* layers;                  /* HOST array [n_layers]                                              */
+    const void* embed; const void* final_norm; const void* lm_head;    /* [vocab, hidden], [hidden], [vocab, hidden]      */
+} fo1_llm_weights_t;
+typedef struct fo1_kv_cache {    /* K [layer][kv_head][row][head_dim]; V^T [layer][kv_head * head_dim][row]               */
+    void* k; long long k_layer_stride, k_head_stride;                  /* elements                                        */
+    void* vt; long long vt_layer_stride, vt_row_stride;
+    int32_t capacity;                                                  /* rows                                            */
+} fo1_kv_cache_t;
+size_t fo1_llm_prefill_workspace_bytes(const fo1_llm_weights_t* w, int rows, int n_seq);
+int fo1_llm_prefill(const fo1_llm_weights_t* w, const fo1_kv_cache_t* kv,
+                    const void* embeds /* bf16 [rows, ld_embeds]: spliced prompt rows */, int ld_embeds,
+                    const void* cos, const void* sin /* bf16 [rows, head_dim] section-selected mRoPE tables */,
+                    int rows, int pos0,
+                    const int32_t* items, int n_items, int q_block, double attn_flops /* causal segments, fo1_attention_bf16 */,
+                    const int32_t* last_plan /* [n_seq][2] = {0, last row of sequence b} */, int n_seq,
+                    void* hidden_out /* optional bf16 [rows, hidden]: final residual stream */,
+                    void* last_hidden /* bf16 [n_seq, hidden] after the final norm */, void* logits /* bf16 [n_seq, vocab] */,
+                    int32_t* next_ids /* [n_seq] */, void* workspace, size_t workspace_bytes, void* stream);
+size_t fo1_llm_decode_workspace_bytes(const fo1_llm_weights_t* w, int batch, int slot_rows);
+int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots, const void* rope_cos, const void* rope_sin,
+                        int32_t* state, int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids, int n_stop,
+                        int32_t* done, int batch, int slot_rows, void* logits /* bf16 [batch, vocab] */, void* workspace,
+                        size_t workspace_bytes, void* stream);
+/* Zero-fill as a kernel launch (graph-capture safe); p 16-byte aligned, bytes % 16 == 0. */
+int fo1_zero_bytes(void* p, size_t bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * Image preprocessing, device side  
  * Replaces, after the host's PIL decode + bicubic resize, the rescale / normalise / layout work of
  *   Qwen2VLImageProcessor (qwen2_5_vl_encoder.py:206-212 -> pixel_values [S, 1176], patches in 2x2 merge-block order,

@@ -214,6 +214,12 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* __restrict
 
 }  // namespace fo1
 
+namespace fo1 {
+__global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = uint4{0, 0, 0, 0};
+}
+}  // namespace fo1
+
 extern "C" {
 
 static int rownorm_check(const void* x, const void* w, const void* y, int M, int D, int ldx, int ldy) {
@@ -283,6 +289,18 @@ int fo1_argmax_bf16(const void* x, int n, int* out, void* scratch, void* stream)
     int* pi = (int*)(pv + 128);
     FO1_LAUNCH("argmax", (double)n * 2.0, argmax_partial_kernel, dim3(128), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, n, pv, pi);
     FO1_LAUNCH("argmax_final", 1024.0, argmax_final_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, (const float*)pv, (const int*)pi, 128, out);
+    return FO1_OK;
+}
+
+// Zero-fill as a kernel launch (16-byte stores): what the stage entries use instead of hipMemsetAsync, whose graph nodes faulted on
+// replay under stream capture on ROCm 7.2 (profiles/README.md).  p 16-byte aligned, bytes a multiple of 16.
+int fo1_zero_bytes(void* p, size_t bytes, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(p != nullptr && ((uintptr_t)p & 15) == 0 && bytes % 16 == 0, "zero_bytes: pointer / size must be 16-byte aligned");
+    if (bytes == 0) return FO1_OK;
+    const size_t n16 = bytes / 16;
+    const int grid = (int)(n16 / 256 + 1 < 4096 ? n16 / 256 + 1 : 4096);
+    FO1_LAUNCH("zero_bytes", (double)bytes, zero16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4*)p, n16);
     return FO1_OK;
 }
 

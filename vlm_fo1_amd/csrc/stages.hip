@@ -1,0 +1,259 @@
+// stages.hip — stage-level C-ABI entries ("one extern "C" function per fused stage"): the launch sequences of the
+// Qwen2.5-VL vision tower, the LLM prefill and the batched decode step as plain C calls over caller-owned device memory, so that a
+// host that is not Python can drive the hot path.  Each entry issues exactly the primitive launches the Python mirror issues
+// (vlm_fo1_amd/vit.py QwenViT._forward, vlm_fo1_amd/llm.py QwenLLM._forward / prefill_packed, BatchDecoder._step_device) in the
+// same order with the same arguments: results are bit-identical to that path (tests/test_stage_abi_gpu.py), and the calls are
+// asynchronous on the caller's stream and safe to capture in a hipGraph (no allocation, no synchronisation, no memset node).
+//
+// Reference call sites replaced:
+//   fo1_vit_forward      Qwen2_5_VisionTransformerPretrainedModel.forward  modeling_qwen2_5_vl.py:436-504 (blocks :306-357,
+//                        merger :140-158) as driven by qwen2_5_vl_encoder.py:86-158,228-257 (window order, un-window, map capture)
+//   fo1_llm_prefill      Qwen2_5_VLModel.forward over the spliced prompt   modeling_qwen2_5_vl.py:1126-1242 (decoder layer
+//                        :1014-1095, attention :738-802) + last-row lm_head / greedy pick (omchat_qwen2_5_vl.py:143-155,
+//                        modeling_qwen2_5_vl.py:1848-1860)
+//   fo1_llm_decode_step  the 1-token fast path of the same code for B sequences
+#include "common.h"
+
+namespace {
+
+struct Carver {   // bump allocator over the caller's workspace, 256-byte granules
+    char* base;
+    size_t off = 0, cap;
+    Carver(void* p, size_t n) : base((char*)p), cap(n) {}
+    void* take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return base ? base + o : nullptr;
+    }
+};
+
+constexpr size_t kGemmScratch = 64ull << 20;   // split-K partials: the size the Python mirror hands to fo1_gemm_bf16_ws
+
+inline size_t bf16_rows(long long rows, long long cols) { return (size_t)rows * cols * 2; }
+
+#define FO1_TRY(call)                 \
+    do {                              \
+        const int _rc = (call);       \
+        if (_rc != FO1_OK) return _rc; \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Vision tower
+// ---------------------------------------------------------------------------------------------------------------------
+static size_t vit_layout(const fo1_vit_weights_t* w, int S, int Sp, void* ws, size_t ws_bytes, void** xin, void** xa, void** xb, void** h,
+                         void** qkv, void** att, void** a, void** vt, void** m0, void** m1, void** m2, void** gemm_ws) {
+    Carver c(ws, ws_bytes);
+    const int d = w->hidden, u = w->merge * w->merge;
+    *xin = c.take(bf16_rows(S, w->k_in_padded));
+    *xa = c.take(bf16_rows(S, d));
+    *xb = c.take(bf16_rows(S, d));
+    *h = c.take(bf16_rows(S, d));
+    *qkv = c.take(bf16_rows(S, 3 * d));
+    *att = c.take(bf16_rows(S, d));
+    *a = c.take(bf16_rows(S, w->ff_padded));
+    *vt = c.take(bf16_rows(d, Sp));
+    *m0 = c.take(bf16_rows(S, d));
+    *m1 = c.take(bf16_rows(S / u, (long long)u * d));
+    *m2 = c.take(bf16_rows(S / u, w->out_hidden));
+    *gemm_ws = c.take(kGemmScratch);
+    return c.off;
+}
+
+size_t fo1_vit_workspace_bytes(const fo1_vit_weights_t* w, int S) {
+    if (!w || S <= 0) return 0;
+    void* p[12];
+    return vit_layout(w, S, (S + 63) / 64 * 64, nullptr, 0, &p[0], &p[1], &p[2], &p[3], &p[4], &p[5], &p[6], &p[7], &p[8], &p[9], &p[10], &p[11]);
+}
+
+int fo1_vit_forward(const fo1_vit_weights_t* w, const fo1_vit_plan_t* g, const void* pixel_rows, int ld_pixels, void* tokens_out,
+                    void* const* feature_maps_out, void* workspace, size_t workspace_bytes, void* stream) {
+    FO1_CHECK_ARG(w && g && pixel_rows && tokens_out && w->blocks, "vit_forward: NULL argument");
+    const int S = g->S, d = w->hidden, H = w->n_heads, hd = d / H, u = w->merge * w->merge;
+    FO1_CHECK_ARG(S > 0 && S % u == 0 && d % H == 0, "vit_forward: S=%d must be a positive multiple of %d", S, u);
+    FO1_CHECK_ARG(g->plan_in && g->plan_raster && g->plan_tokens && g->cos && g->sin && g->items_win && g->items_full,
+                  "vit_forward: incomplete plan");
+    const int Sp = (S + 63) / 64 * 64;
+    void *xin, *xa, *xb, *h, *qkv, *att, *a, *vt, *m0, *m1, *m2, *gws;
+    const size_t need = vit_layout(w, S, Sp, workspace, workspace_bytes, &xin, &xa, &xb, &h, &qkv, &att, &a, &vt, &m0, &m1, &m2, &gws);
+    if (!workspace || workspace_bytes < need) return fo1::set_err(FO1_ERR_WORKSPACE, "vit_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+    // window re-order folded into the patch-embed input gather; K padded 1176 -> 1216 with zeros; V^T scratch zeroed (the
+    // attention kernel may read up to 3 finite columns past a segment's end)
+    // (a fill kernel, not hipMemsetAsync: memset nodes misbehaved on replay inside captured graphs on ROCm 7.2)
+    FO1_TRY(fo1_zero_bytes(xin, bf16_rows(S, w->k_in_padded), stream));
+    FO1_TRY(fo1_zero_bytes(vt, bf16_rows(d, Sp), stream));
+    FO1_TRY(fo1_gather_rows_bf16(pixel_rows, ld_pixels, nullptr, 0, nullptr, 0, g->plan_in, xin, w->k_in_padded, S, w->k_in, stream));
+    void* x = xa;
+    void* xn = xb;
+    FO1_TRY(fo1_gemm_bf16_ws(xin, w->k_in_padded, w->patch_w, w->k_in_padded, nullptr, nullptr, 0, x, d, S, d, w->k_in_padded, 0, 0, gws, kGemmScratch, stream));
+    const float scale = 1.0f / sqrtf((float)hd);
+    int n_cap = 0;
+    for (int i = 0; i < w->depth; ++i) {
+        const fo1_vit_block_t& b = w->blocks[i];
+        bool full = false;
+        for (int k = 0; k < w->n_fullatt; ++k) full = full || (w->fullatt[k] == i);
+        FO1_TRY(fo1_rmsnorm_bf16(x, d, b.n1, h, d, S, d, 1e-6f, stream));
+        FO1_TRY(fo1_gemm_bf16_ws(h, d, b.wqkv, d, b.bqkv, nullptr, 0, qkv, 3 * d, S, 3 * d, d, 0, 0, gws, kGemmScratch, stream));
+        FO1_TRY(fo1_qkv_post_vit_bf16(qkv, 3 * d, H, hd, g->cos, g->sin, S, vt, Sp, stream));   // 2-D RoPE on q/k + V -> V^T
+        FO1_TRY(fo1_attention_bf16(qkv, 3 * d, hd, (const uint16_t*)qkv + d, 3 * d, hd, vt, Sp, att, d, hd,
+                                   full ? g->items_full : g->items_win, full ? g->n_items_full : g->n_items_win,
+                                   full ? g->q_block_full : g->q_block_win, H, H, hd, scale, 0, nullptr,
+                                   full ? g->flops_full : g->flops_win, stream));
+        FO1_TRY(fo1_gemm_bf16_ws(att, d, b.wo, d, b.bo, x, d, xn, d, S, d, d, 0, 0, gws, kGemmScratch, stream));
+        { void* t = x; x = xn; xn = t; }
+        FO1_TRY(fo1_rmsnorm_bf16(x, d, b.n2, h, d, S, d, 1e-6f, stream));
+        FO1_TRY(fo1_gemm_bf16_ws(h, d, b.wgu, d, b.bgu, nullptr, 0, a, w->ff_padded, S, 2 * w->ff_padded, d, 3, 0, gws, kGemmScratch, stream));
+        FO1_TRY(fo1_gemm_bf16_ws(a, w->ff_padded, b.wd, w->ff_padded, b.bd, x, d, xn, d, S, d, w->ff_padded, 0, 0, gws, kGemmScratch, stream));
+        { void* t = x; x = xn; xn = t; }
+        if (full) {
+            // un-window: the raster token-major map of this full-attention block (qwen2_5_vl_encoder.py:37-80)
+            void* dst = feature_maps_out ? feature_maps_out[n_cap] : nullptr;
+            if (dst) FO1_TRY(fo1_gather_rows_bf16(x, d, nullptr, 0, nullptr, 0, g->plan_raster, dst, d, S, d, stream));
+            ++n_cap;
+        }
+    }
+    // merger: RMSNorm -> [S/4, 4d] -> Linear + GELU -> Linear, then raster-merged token order
+    FO1_TRY(fo1_rmsnorm_bf16(x, d, w->ln_q, m0, d, S, d, 1e-6f, stream));
+    FO1_TRY(fo1_gemm_bf16_ws(m0, u * d, w->m0w, u * d, w->m0b, nullptr, 0, m1, u * d, S / u, u * d, u * d, 1, 0, gws, kGemmScratch, stream));
+    FO1_TRY(fo1_gemm_bf16_ws(m1, u * d, w->m2w, u * d, w->m2b, nullptr, 0, m2, w->out_hidden, S / u, w->out_hidden, u * d, 0, 0, gws, kGemmScratch, stream));
+    FO1_TRY(fo1_gather_rows_bf16(m2, w->out_hidden, nullptr, 0, nullptr, 0, g->plan_tokens, tokens_out, w->out_hidden, S / u, w->out_hidden, stream));
+    return FO1_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LLM prefill
+// ---------------------------------------------------------------------------------------------------------------------
+static size_t llm_prefill_layout(const fo1_llm_weights_t* w, int R, int n_seq, void* ws, size_t ws_bytes, void** xa, void** xb, void** h,
+                                 void** qkv, void** att, void** a, void** last_rows, void** argmax_sc, void** gemm_ws) {
+    Carver c(ws, ws_bytes);
+    const int d = w->hidden, qd = (w->n_heads + 2 * w->n_kv_heads) * w->head_dim;
+    *xa = c.take(bf16_rows(R, d));
+    *xb = c.take(bf16_rows(R, d));
+    *h = c.take(bf16_rows(R, d));
+    *qkv = c.take(bf16_rows(R, qd));
+    *att = c.take(bf16_rows(R, (long long)w->n_heads * w->head_dim));
+    *a = c.take(bf16_rows(R, w->intermediate));
+    *last_rows = c.take(bf16_rows(n_seq, d));
+    *argmax_sc = c.take(4096);
+    *gemm_ws = c.take(kGemmScratch);
+    return c.off;
+}
+
+size_t fo1_llm_prefill_workspace_bytes(const fo1_llm_weights_t* w, int rows, int n_seq) {
+    if (!w || rows <= 0 || n_seq <= 0) return 0;
+    void* p[9];
+    return llm_prefill_layout(w, rows, n_seq, nullptr, 0, &p[0], &p[1], &p[2], &p[3], &p[4], &p[5], &p[6], &p[7], &p[8]);
+}
+
+int fo1_llm_prefill(const fo1_llm_weights_t* w, const fo1_kv_cache_t* kv, const void* embeds, int ld_embeds, const void* cos, const void* sin,
+                    int rows, int pos0, const int32_t* items, int n_items, int q_block, double attn_flops, const int32_t* last_plan,
+                    int n_seq, void* hidden_out, void* last_hidden, void* logits, int32_t* next_ids, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+    FO1_CHECK_ARG(w && kv && embeds && cos && sin && items && last_plan && last_hidden && logits && next_ids && w->layers, "llm_prefill: NULL argument");
+    const int R = rows, d = w->hidden, H = w->n_heads, KV = w->n_kv_heads, HD = w->head_dim, I = w->intermediate;
+    FO1_CHECK_ARG(R > 0 && n_seq > 0 && pos0 >= 0 && pos0 + R <= kv->capacity, "llm_prefill: rows %d at %d exceed the KV cache (%d rows)", R, pos0, kv->capacity);
+    void *xa, *xb, *h, *qkv, *att, *a, *last_rows, *asc, *gws;
+    const size_t need = llm_prefill_layout(w, R, n_seq, workspace, workspace_bytes, &xa, &xb, &h, &qkv, &att, &a, &last_rows, &asc, &gws);
+    if (!workspace || workspace_bytes < need) return fo1::set_err(FO1_ERR_WORKSPACE, "llm_prefill: workspace %zu B < required %zu B", workspace_bytes, need);
+    const int qd = (H + 2 * KV) * HD;
+    const float scale = 1.0f / sqrtf((float)HD);
+    const void* x = embeds;
+    int ldx = ld_embeds;
+    for (int li = 0; li < w->n_layers; ++li) {
+        const fo1_llm_layer_t& L = w->layers[li];
+        uint16_t* kc = (uint16_t*)kv->k + (long long)li * kv->k_layer_stride;
+        uint16_t* vtc = (uint16_t*)kv->vt + (long long)li * kv->vt_layer_stride;
+        FO1_TRY(fo1_rmsnorm_bf16(x, ldx, L.ln1, h, d, R, d, w->rms_eps, stream));
+        FO1_TRY(fo1_gemm_bf16_ws(h, d, L.wqkv, d, L.bqkv, nullptr, 0, qkv, qd, R, qd, d, 0, 0, gws, kGemmScratch, stream));
+        // mRoPE on q/k + K append + V^T, one launch; then causal attention of the packed segments against the cache
+        FO1_TRY(fo1_qkv_post_llm_bf16(qkv, qd, H, KV, HD, cos, sin, R, kc, kv->k_head_stride, vtc, kv->vt_row_stride, pos0, stream));
+        FO1_TRY(fo1_attention_bf16((const uint16_t*)qkv - (long long)pos0 * qd, qd, HD, kc, HD, kv->k_head_stride, vtc, kv->vt_row_stride,
+                                   (uint16_t*)att - (long long)pos0 * H * HD, (long long)H * HD, HD, items, n_items, q_block, H, KV, HD, scale, 1,
+                                   nullptr, attn_flops, stream));
+        // residual stream: x -> xa (after attention) -> xb (after the MLP; the old x is dead by then, so xb may be what held it)
+        FO1_TRY(fo1_gemm_bf16_ws(att, H * HD, L.wo, H * HD, nullptr, x, ldx, xa, d, R, d, H * HD, 0, 0, gws, kGemmScratch, stream));
+        FO1_TRY(fo1_rmsnorm_bf16(xa, d, L.ln2, h, d, R, d, w->rms_eps, stream));
+        FO1_TRY(fo1_gemm_bf16_ws(h, d, L.wgu, d, nullptr, nullptr, 0, a, I, R, 2 * I, d, 3, 0, gws, kGemmScratch, stream));
+        void* dst = (li + 1 == w->n_layers && hidden_out) ? hidden_out : xb;
+        FO1_TRY(fo1_gemm_bf16_ws(a, I, L.wdown, I, nullptr, xa, d, dst, d, R, d, I, 0, 0, gws, kGemmScratch, stream));
+        x = dst;
+        ldx = d;
+    }
+    // last-row head: gather each sequence's final row, final RMSNorm, lm_head, greedy pick
+    FO1_TRY(fo1_gather_rows_bf16(x, ldx, nullptr, 0, nullptr, 0, last_plan, last_rows, d, n_seq, d, stream));
+    FO1_TRY(fo1_rmsnorm_bf16(last_rows, d, w->final_norm, last_hidden, d, n_seq, d, w->rms_eps, stream));
+    FO1_TRY(fo1_gemm_bf16_ws(last_hidden, d, w->lm_head, d, nullptr, nullptr, 0, logits, w->vocab, n_seq, w->vocab, d, 0, 0, gws, kGemmScratch, stream));
+    for (int b = 0; b < n_seq; ++b)
+        FO1_TRY(fo1_argmax_bf16((const uint16_t*)logits + (long long)b * w->vocab, w->vocab, next_ids + b, asc, stream));
+    return FO1_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched decode step
+// ---------------------------------------------------------------------------------------------------------------------
+static size_t llm_decode_layout(const fo1_llm_weights_t* w, int B, int slot_rows, void* ws, size_t ws_bytes, void** xa, void** xb,
+                                void** q, void** att, void** a, void** attn_ws, size_t* attn_bytes, void** argmax_sc) {
+    Carver c(ws, ws_bytes);
+    const int d = w->hidden;
+    *xa = c.take(bf16_rows(B, d));
+    *xb = c.take(bf16_rows(B, d));
+    *q = c.take(bf16_rows(B, (long long)w->n_heads * w->head_dim));
+    *att = c.take(bf16_rows(B, (long long)w->n_heads * w->head_dim));
+    *a = c.take(bf16_rows(B, w->intermediate));
+    *attn_bytes = fo1_attention_decode_batch_workspace_bytes(slot_rows, w->n_kv_heads, w->head_dim, B);
+    *attn_ws = c.take(*attn_bytes);
+    *argmax_sc = c.take((size_t)2 * 128 * B * 4);
+    return c.off;
+}
+
+size_t fo1_llm_decode_workspace_bytes(const fo1_llm_weights_t* w, int batch, int slot_rows) {
+    if (!w || batch <= 0 || slot_rows <= 0) return 0;
+    void* p[7];
+    size_t ab;
+    return llm_decode_layout(w, batch, slot_rows, nullptr, 0, &p[0], &p[1], &p[2], &p[3], &p[4], &p[5], &ab, &p[6]);
+}
+
+int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots, const void* rope_cos, const void* rope_sin, int32_t* state,
+                        int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids, int n_stop, int32_t* done, int batch,
+                        int slot_rows, void* logits, void* workspace, size_t workspace_bytes, void* stream) {
+    FO1_CHECK_ARG(w && slots && rope_cos && rope_sin && state && plan && ids_out && done && logits && w->layers && w->embed, "llm_decode_step: NULL argument");
+    const int B = batch, d = w->hidden, H = w->n_heads, KV = w->n_kv_heads, HD = w->head_dim, I = w->intermediate;
+    FO1_CHECK_ARG(B >= 1 && B <= 8 && HD == 128, "llm_decode_step: batch %d (1..8), head_dim %d (128)", B, HD);
+    void *xa, *xb, *q, *att, *a, *aws, *asc;
+    size_t abytes;
+    const size_t need = llm_decode_layout(w, B, slot_rows, workspace, workspace_bytes, &xa, &xb, &q, &att, &a, &aws, &abytes, &asc);
+    if (!workspace || workspace_bytes < need) return fo1::set_err(FO1_ERR_WORKSPACE, "llm_decode_step: workspace %zu B < required %zu B", workspace_bytes, need);
+    const int qd = (H + 2 * KV) * HD;
+    const float scale = 1.0f / sqrtf((float)HD);
+    // embedding rows of the tokens accepted by the previous step (plan = {0, token id} per sequence)
+    FO1_TRY(fo1_gather_rows_bf16(w->embed, d, nullptr, 0, nullptr, 0, plan, xa, d, B, d, stream));
+    void* x = xa;      // residual stream before attention / after the MLP
+    void* y = xb;      // ... after attention
+    for (int li = 0; li < w->n_layers; ++li) {
+        const fo1_llm_layer_t& L = w->layers[li];
+        uint16_t* kc = (uint16_t*)slots->k + (long long)li * slots->k_layer_stride;
+        uint16_t* vtc = (uint16_t*)slots->vt + (long long)li * slots->vt_layer_stride;
+        // input_layernorm + QKV + bias + mRoPE + K row / V^T column append, one launch; q rows out
+        FO1_TRY(fo1_gemv_batch_bf16(x, d, L.wqkv, d, L.bqkv, nullptr, 0, q, H * HD, B, qd, d, 2, L.ln1, w->rms_eps, H, KV, rope_cos, rope_sin, state, kc,
+                                    slots->k_head_stride, vtc, slots->vt_row_stride, stream));
+        FO1_TRY(fo1_attention_decode_batch_bf16(q, (long long)H * HD, kc, HD, slots->k_head_stride, vtc, slots->vt_row_stride, att, (long long)H * HD, state, B,
+                                                slot_rows, H, KV, HD, scale, aws, abytes, stream));
+        FO1_TRY(fo1_gemv_batch_bf16(att, H * HD, L.wo, H * HD, nullptr, x, d, y, d, B, d, H * HD, 0, nullptr, 0.f, 0, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                                    nullptr, 0, stream));
+        // post_attention_layernorm + gate/up + SwiGLU, one launch; then down + residual
+        FO1_TRY(fo1_gemv_batch_bf16(y, d, L.wgu, d, nullptr, nullptr, 0, a, I, B, 2 * I, d, 1, L.ln2, w->rms_eps, 0, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                                    nullptr, 0, stream));
+        FO1_TRY(fo1_gemv_batch_bf16(a, I, L.wdown, I, nullptr, y, d, x, d, B, d, I, 0, nullptr, 0.f, 0, 0, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0,
+                                    stream));
+    }
+    // final norm + lm_head, greedy pick and on-device accept (stop rule, state advance, next gather plan)
+    FO1_TRY(fo1_gemv_batch_bf16(x, d, w->lm_head, d, nullptr, nullptr, 0, logits, w->vocab, B, w->vocab, d, 0, w->final_norm, w->rms_eps, 0, 0, nullptr, nullptr,
+                                nullptr, nullptr, 0, nullptr, 0, stream));
+    FO1_TRY(fo1_decode_argmax_accept(logits, w->vocab, w->vocab, B, nullptr, state, plan, ids_out, ids_ld, n_stop ? stop_ids : nullptr, n_stop, done, asc, stream));
+    return FO1_OK;
+}
+
+}  // extern "C"

@@ -36,6 +36,45 @@ class HfreOpts(ctypes.Structure):
     ]
 
 
+class VitBlock(ctypes.Structure):
+    """fo1_vit_block_t"""
+    _fields_ = [(n, c_void_p) for n in ("n1", "n2", "wqkv", "bqkv", "wo", "bo", "wgu", "bgu", "wd", "bd")]
+
+
+class VitWeights(ctypes.Structure):
+    """fo1_vit_weights_t"""
+    _fields_ = [("depth", c_int32), ("hidden", c_int32), ("n_heads", c_int32), ("ff_padded", c_int32), ("k_in", c_int32),
+                ("k_in_padded", c_int32), ("merge", c_int32), ("out_hidden", c_int32), ("n_fullatt", c_int32), ("fullatt", c_int32 * 8),
+                ("patch_w", c_void_p), ("blocks", ctypes.POINTER(VitBlock)),
+                ("ln_q", c_void_p), ("m0w", c_void_p), ("m0b", c_void_p), ("m2w", c_void_p), ("m2b", c_void_p)]
+
+
+class VitPlan(ctypes.Structure):
+    """fo1_vit_plan_t"""
+    _fields_ = [("S", c_int32), ("plan_in", c_void_p), ("plan_raster", c_void_p), ("plan_tokens", c_void_p), ("cos", c_void_p), ("sin", c_void_p),
+                ("items_win", c_void_p), ("n_items_win", c_int32), ("q_block_win", c_int32),
+                ("items_full", c_void_p), ("n_items_full", c_int32), ("q_block_full", c_int32),
+                ("flops_win", ctypes.c_double), ("flops_full", ctypes.c_double)]
+
+
+class LlmLayer(ctypes.Structure):
+    """fo1_llm_layer_t"""
+    _fields_ = [(n, c_void_p) for n in ("ln1", "ln2", "wqkv", "bqkv", "wo", "wgu", "wdown")]
+
+
+class LlmWeights(ctypes.Structure):
+    """fo1_llm_weights_t"""
+    _fields_ = [("n_layers", c_int32), ("hidden", c_int32), ("n_heads", c_int32), ("n_kv_heads", c_int32), ("head_dim", c_int32),
+                ("intermediate", c_int32), ("vocab", c_int32), ("rms_eps", c_float), ("layers", ctypes.POINTER(LlmLayer)),
+                ("embed", c_void_p), ("final_norm", c_void_p), ("lm_head", c_void_p)]
+
+
+class KvCache(ctypes.Structure):
+    """fo1_kv_cache_t"""
+    _fields_ = [("k", c_void_p), ("k_layer_stride", c_longlong), ("k_head_stride", c_longlong),
+                ("vt", c_void_p), ("vt_layer_stride", c_longlong), ("vt_row_stride", c_longlong), ("capacity", c_int32)]
+
+
 class ProfileRow(ctypes.Structure):
     """fo1_profile_row_t (include/fo1.h)."""
     _fields_ = [("name", ctypes.c_char * 48), ("calls", ctypes.c_int64), ("total_ms", ctypes.c_double),
@@ -50,6 +89,16 @@ SIGNATURES = {
     "fo1_profile_read": (c_int, [ctypes.POINTER(ProfileRow), c_int, c_int]),
     "fo1_profile_stage": (c_int, [ctypes.c_char_p]),
     "fo1_hfre_set_pixel_budget": (c_int, [c_int]),
+    "fo1_vit_workspace_bytes": (c_size_t, [ctypes.POINTER(VitWeights), c_int]),
+    "fo1_vit_forward": (c_int, [ctypes.POINTER(VitWeights), ctypes.POINTER(VitPlan), c_void_p, c_int, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
+                                c_size_t, c_void_p]),
+    "fo1_llm_prefill_workspace_bytes": (c_size_t, [ctypes.POINTER(LlmWeights), c_int, c_int]),
+    "fo1_llm_prefill": (c_int, [ctypes.POINTER(LlmWeights), ctypes.POINTER(KvCache), c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int,
+                                c_int, ctypes.c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fo1_llm_decode_workspace_bytes": (c_size_t, [ctypes.POINTER(LlmWeights), c_int, c_int]),
+    "fo1_llm_decode_step": (c_int, [ctypes.POINTER(LlmWeights), ctypes.POINTER(KvCache), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
+                                    c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "fo1_zero_bytes": (c_int, [c_void_p, c_size_t, c_void_p]),
     "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
     "fo1_hfre_set_tuning": (c_int, [c_int, c_int, c_int, c_int]),
     "fo1_hfre_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),

@@ -328,6 +328,12 @@ class QwenLLM:
         int32 [B])."""
         c = self.cfg
         items, flops = self.packed_items(seqs)
+        from . import stage_abi
+        if stage_abi.enabled() and collect is None:      # the same launches, sequenced by fo1_llm_prefill (csrc/stages.hip)
+            if embeds.shape[0] > self.capacity:
+                raise ValueError(f"sequence {embeds.shape[0]} exceeds the KV cache ({self.capacity}); call reserve() first")
+            with ops.workspace_scope(self._ws_owner):
+                return stage_abi.llm_stage(self).prefill_packed(embeds, cos, sin, seqs, last_plan)
         with ops.workspace_scope(self._ws_owner):
             x = self._forward(embeds, cos, sin, 0, collect, items=items, flops=flops)
             last = ops.rmsnorm(ops.gather_rows(last_plan, c.hidden_size, x), self.norm, c.rms_norm_eps)
@@ -508,6 +514,10 @@ class BatchDecoder:
         H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
         scale = 1.0 / math.sqrt(HD)
         st = self.state[:B]
+        from . import stage_abi
+        if stage_abi.enabled():      # the same launches, sequenced by fo1_llm_decode_step (csrc/stages.hip)
+            with ops.workspace_scope(self._ws_owner):
+                return stage_abi.llm_stage(llm).decode_step(self)
         with ops.workspace_scope(self._ws_owner):
             x = ops.gather_rows(self.plan[:B], c.hidden_size, llm.embed)
             for li, w in enumerate(llm.layers):

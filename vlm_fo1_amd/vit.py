@@ -209,6 +209,9 @@ class QwenViT:
         hd = d // H
         if pixel_values.shape != (S, self.k_in):
             raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match the plan (expected [{S}, {self.k_in}])")
+        from . import stage_abi
+        if stage_abi.enabled():      # the same launches, sequenced by fo1_vit_forward (csrc/stages.hip)
+            return stage_abi.vit_stage(self).forward(pixel_values, g, capture)
         pix = pixel_values.to(torch.bfloat16)
         # window re-order folded into the patch-embed input gather; pad K 1176 -> 1216 (zeros)
         xin = torch.zeros(S, self.k_in_p, dtype=torch.bfloat16, device=self.dev)
