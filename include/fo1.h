@@ -421,6 +421,53 @@ int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots,
                         int32_t* state, int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids, int n_stop,
                         int32_t* done, int batch, int slot_rows, void* logits /* bf16 [batch, vocab] */, void* workspace,
                         size_t workspace_bytes, void* stream);
+/*   fo1_davit_forward      DaViT-L aux tower over `batch` same-size images: 4 stages of ConvEmbed + (SpatialBlock, ChannelBlock)
+ *                          pairs; emits the four token-major stage maps the HFRE reads.  reference: davit_aux_encoder.py:54-69,
+ *                          davit/modeling_davit.py:102-148 (ConvEmbed), :175-205 (ChannelBlock), :284-330 (SpatialBlock), :478-506
+ *   fo1_simplefpn_forward  ViTDet SimpleFPN on the last ViT map (strides 3.5 / 7 / 14 / 28).  reference: simple_fpn.py:100-216
+ *   fo1_projector_forward  mlpN_gelu connector (mm_projector / mm_projector_aux).  reference: multimodal_projector/builder.py:64-71,103-110 */
+typedef struct fo1_davit_half {   /* one SpatialBlock or ChannelBlock; bf16 device pointers                              */
+    const void* conv1_w; const void* conv1_b; const void* conv2_w; const void* conv2_b;   /* depthwise 3x3, tap-major [9, C], [C] */
+    const void* an_w; const void* an_b;           /* attention pre-norm (LayerNorm)                                      */
+    const void* qkv_w; const void* qkv_b; const void* proj_w; const void* proj_b;
+    const void* fn_w; const void* fn_b;           /* FFN pre-norm                                                        */
+    const void* fc1_w; const void* fc1_b; const void* fc2_w; const void* fc2_b;           /* [4C, C], [C, 4C]             */
+} fo1_davit_half_t;
+typedef struct fo1_davit_block { fo1_davit_half_t spatial, channel; } fo1_davit_block_t;
+typedef struct fo1_davit_stage {
+    int32_t dim, heads, depth, kernel, stride, pad, prenorm, K_padded;   /* ConvEmbed geometry; K_padded = GEMM K (64-multiple) */
+    const void* conv_w; const void* conv_b;       /* [dim, K_padded] rows (ky, kx, cin), zero pad columns; [dim]         */
+    const void* norm_w; const void* norm_b;       /* ConvEmbed LayerNorm (pre: over the input channels; post: over dim)  */
+    const fo1_davit_block_t* blocks;              /* HOST array [depth]                                                  */
+} fo1_davit_stage_t;
+typedef struct fo1_davit_weights { int32_t n_stages, window; fo1_davit_stage_t stages[4]; } fo1_davit_weights_t;
+typedef struct fo1_davit_plan {    /* per image size: window-attention work items of every stage (fo1_attention_bf16)     */
+    int32_t H, W, batch;
+    const int32_t* items[4]; int32_t n_items[4]; int32_t q_block[4];
+} fo1_davit_plan_t;
+size_t fo1_davit_workspace_bytes(const fo1_davit_weights_t* w, const fo1_davit_plan_t* plan);
+int fo1_davit_forward(const fo1_davit_weights_t* w, const fo1_davit_plan_t* plan, const void* images /* [batch, 3, H, W] bf16 or fp32 */,
+                      int images_are_f32, void* const* maps_out /* HOST array [4]: bf16 [batch * H_i * W_i, dim_i] */,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+typedef struct fo1_fpn_head { const void* w1; const void* n1_w; const void* n1_b; const void* w3; const void* n3_w; const void* n3_b; } fo1_fpn_head_t;
+typedef struct fo1_fpn_weights {
+    int32_t c_in, c_up1, c_up2, c_out;            /* 1280, 640, 320, 512                                                 */
+    const void* t1a_w; const void* t1a_b;         /* ConvTranspose2d as GEMM rows (dy, dx, co): [4 c_up1, c_in], bias x4 */
+    const void* t1_ln_w; const void* t1_ln_b;
+    const void* t1b_w; const void* t1b_b;         /* [4 c_up2, c_up1]                                                    */
+    const void* t2_w; const void* t2_b;           /* [4 c_up1, c_in]                                                     */
+    fo1_fpn_head_t heads[4];                      /* 1x1 conv [c_out, C_level], LN, 3x3 conv [c_out, 9 c_out], LN        */
+} fo1_fpn_weights_t;
+size_t fo1_simplefpn_workspace_bytes(const fo1_fpn_weights_t* w, int H, int W, int batch);
+int fo1_simplefpn_forward(const fo1_fpn_weights_t* w, const void* vit_map /* bf16 [batch*H*W, c_in] raster */, int H, int W, int batch,
+                          void* const* maps_out /* HOST array [4]: (4H,4W), (2H,2W), (H,W), (H/2,W/2) x c_out */, void* workspace,
+                          size_t workspace_bytes, void* stream);
+
+typedef struct fo1_projector { int32_t n_layers; int32_t dims[5]; const void* w[4]; const void* b[4]; } fo1_projector_t;
+size_t fo1_projector_workspace_bytes(const fo1_projector_t* p, int rows);
+int fo1_projector_forward(const fo1_projector_t* p, const void* x, int ldx, int rows, void* out, int ld_out, void* workspace,
+                          size_t workspace_bytes, void* stream);
 /* Zero-fill as a kernel launch (graph-capture safe); p 16-byte aligned, bytes % 16 == 0. */
 int fo1_zero_bytes(void* p, size_t bytes, void* stream);
 

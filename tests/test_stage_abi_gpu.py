@@ -53,6 +53,30 @@ def test_vit_forward_entry_bitwise(stage_switch):
     assert torch.equal(t2, t0) and torch.equal(f2[-1], f0[-1])
 
 
+def test_davit_fpn_projector_entries_bitwise(stage_switch):
+    cfg, eng = build()
+    g = torch.Generator().manual_seed(4)
+    img = torch.randn(2, 3, 140, 196, generator=g).bfloat16().cuda()
+    vmap = torch.randn(2 * 10 * 14, 1280, generator=g).bfloat16().cuda()
+    feat = torch.randn(9, cfg.mm_region_hidden_size, generator=g).bfloat16().cuda()
+    stage_switch(False)
+    m0, s0 = eng.davit.forward(img)
+    f0, fs0 = eng.fpn.forward(vmap, 10, 14, batch=2)
+    p0 = eng.mm_projector_aux(feat)
+    stage_switch(True)
+    m1, s1 = eng.davit.forward(img)
+    f1, fs1 = eng.fpn.forward(vmap, 10, 14, batch=2)
+    p1 = eng.mm_projector_aux(feat)
+    assert s0 == s1 and fs0 == fs1
+    assert all(torch.equal(a, b) for a, b in zip(m0, m1)), "DaViT stage maps differ"
+    assert all(torch.equal(a, b) for a, b in zip(f0, f1)), "SimpleFPN maps differ"
+    assert torch.equal(p0, p1)
+    m2, _ = eng.davit.forward(img[0].float())      # fp32 image, batch of one
+    stage_switch(False)
+    m3, _ = eng.davit.forward(img[0].float())
+    assert all(torch.equal(a, b) for a, b in zip(m2, m3))
+
+
 def test_engine_through_stage_entries_bitwise(stage_switch):
     cfg, eng = build()
     reqs = requests()

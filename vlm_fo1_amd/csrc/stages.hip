@@ -89,7 +89,7 @@ int fo1_vit_forward(const fo1_vit_weights_t* w, const fo1_vit_plan_t* g, const v
     void* x = xa;
     void* xn = xb;
     FO1_TRY(fo1_gemm_bf16_ws(xin, w->k_in_padded, w->patch_w, w->k_in_padded, nullptr, nullptr, 0, x, d, S, d, w->k_in_padded, 0, 0, gws, kGemmScratch, stream));
-    const float scale = 1.0f / sqrtf((float)hd);
+    const float scale = (float)(1.0 / sqrt((double)hd));   // rounded once from double, like the Python mirror's argument
     int n_cap = 0;
     for (int i = 0; i < w->depth; ++i) {
         const fo1_vit_block_t& b = w->blocks[i];
@@ -159,7 +159,7 @@ int fo1_llm_prefill(const fo1_llm_weights_t* w, const fo1_kv_cache_t* kv, const 
     const size_t need = llm_prefill_layout(w, R, n_seq, workspace, workspace_bytes, &xa, &xb, &h, &qkv, &att, &a, &last_rows, &asc, &gws);
     if (!workspace || workspace_bytes < need) return fo1::set_err(FO1_ERR_WORKSPACE, "llm_prefill: workspace %zu B < required %zu B", workspace_bytes, need);
     const int qd = (H + 2 * KV) * HD;
-    const float scale = 1.0f / sqrtf((float)HD);
+    const float scale = (float)(1.0 / sqrt((double)HD));
     const void* x = embeds;
     int ldx = ld_embeds;
     for (int li = 0; li < w->n_layers; ++li) {
@@ -227,7 +227,7 @@ int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots,
     const size_t need = llm_decode_layout(w, B, slot_rows, workspace, workspace_bytes, &xa, &xb, &q, &att, &a, &aws, &abytes, &asc);
     if (!workspace || workspace_bytes < need) return fo1::set_err(FO1_ERR_WORKSPACE, "llm_decode_step: workspace %zu B < required %zu B", workspace_bytes, need);
     const int qd = (H + 2 * KV) * HD;
-    const float scale = 1.0f / sqrtf((float)HD);
+    const float scale = (float)(1.0 / sqrt((double)HD));
     // embedding rows of the tokens accepted by the previous step (plan = {0, token id} per sequence)
     FO1_TRY(fo1_gather_rows_bf16(w->embed, d, nullptr, 0, nullptr, 0, plan, xa, d, B, d, stream));
     void* x = xa;      // residual stream before attention / after the MLP
@@ -253,6 +253,269 @@ int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots,
     FO1_TRY(fo1_gemv_batch_bf16(x, d, w->lm_head, d, nullptr, nullptr, 0, logits, w->vocab, B, w->vocab, d, 0, w->final_norm, w->rms_eps, 0, 0, nullptr, nullptr,
                                 nullptr, nullptr, 0, nullptr, 0, stream));
     FO1_TRY(fo1_decode_argmax_accept(logits, w->vocab, w->vocab, B, nullptr, state, plan, ids_out, ids_ld, n_stop ? stop_ids : nullptr, n_stop, done, asc, stream));
+    return FO1_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// DaViT-L aux tower, SimpleFPN, projector MLPs.  One routine serves both the workspace query (dry run: base == NULL, no
+// launches) and the call itself, so the two cannot disagree.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+struct Arena {   // stack allocator over the workspace; dry run when base is NULL (tracks the high-water mark)
+    char* base;
+    size_t off = 0, peak = 0;
+    explicit Arena(void* p) : base((char*)p) {}
+    void* take(size_t bytes) {
+        const size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        if (off > peak) peak = off;
+        return base ? base + o : (void*)(uintptr_t)(o + 256);   // non-NULL placeholder in a dry run (never dereferenced)
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+    bool dry() const { return base == nullptr; }
+};
+#define FO1_RUN(call)                            \
+    do {                                         \
+        if (!A.dry()) {                          \
+            const int _rc = (call);              \
+            if (_rc != FO1_OK) return _rc;       \
+        }                                        \
+    } while (0)
+
+inline int rup(int x, int m) { return (x + m - 1) / m * m; }
+
+// conv2 (depthwise 3x3 + residual) -> LayerNorm -> MLP (+ residual) -> dst      (modeling_davit.py:29-48,72-99,51-69)
+int davit_conv_ffn(Arena& A, const fo1_davit_half_t& d, const void* x, void* tmp_x, void* dst, int n, int H, int W, int C, int B, void* gws, void* stream) {
+    const size_t m = A.mark();
+    void* h = A.take(bf16_rows(n, C));
+    void* h1 = A.take(bf16_rows(n, 4 * C));
+    FO1_RUN(fo1_dwconv3x3_ln_bf16(x, d.conv2_w, d.conv2_b, tmp_x, d.fn_w, d.fn_b, 1e-5f, h, H, W, C, B, stream));
+    FO1_RUN(fo1_gemm_bf16_ws(h, C, d.fc1_w, C, d.fc1_b, nullptr, 0, h1, 4 * C, n, 4 * C, C, 1, 0, gws, kGemmScratch, stream));
+    FO1_RUN(fo1_gemm_bf16_ws(h1, 4 * C, d.fc2_w, 4 * C, d.fc2_b, tmp_x, C, dst, C, n, C, 4 * C, 0, 0, gws, kGemmScratch, stream));
+    A.release(m);
+    return FO1_OK;
+}
+
+int davit_run(Arena& A, const fo1_davit_weights_t* w, const fo1_davit_plan_t* pl, const void* img, int img_is_f32, void* const* outs, void* stream) {
+    const int B = pl->batch, ws = w->window;
+    int H = pl->H, W = pl->W;
+    void* gws = A.take(kGemmScratch);
+    const void* prev = nullptr;   // previous stage's map (rows [B*H*W, Cprev])
+    int Cprev = 8;
+    {
+        void* x0 = A.take(bf16_rows((long long)B * H * W, 8));
+        FO1_RUN(fo1_nchw_to_hwc8_bf16(img, img_is_f32, x0, H, W, B, stream));
+        prev = x0;
+    }
+    for (int i = 0; i < w->n_stages; ++i) {
+        const fo1_davit_stage_t& sg = w->stages[i];
+        const int C = sg.dim, heads = sg.heads, k = sg.kernel, st = sg.stride, pd = sg.pad;
+        const int Ho = (H + 2 * pd - k) / st + 1, Wo = (W + 2 * pd - k) / st + 1;
+        const int n_prev = B * H * W, n = B * Ho * Wo;
+        const size_t stage_mark = A.mark();
+        void* XA = A.take(bf16_rows(n, C));
+        void* XB = A.take(bf16_rows(n, C));
+        {   // ConvEmbed (modeling_davit.py:102-148): [pre-norm] -> conv as im2col + GEMM -> [post-norm]
+            const size_t m = A.mark();
+            const void* src = prev;
+            if (i > 0 && sg.prenorm) {
+                void* ln = A.take(bf16_rows(n_prev, Cprev));
+                FO1_RUN(fo1_layernorm_bf16(prev, Cprev, sg.norm_w, sg.norm_b, ln, Cprev, n_prev, Cprev, 1e-5f, stream));
+                src = ln;
+            }
+            void* col = A.take(bf16_rows(n, sg.K_padded));
+            if (sg.K_padded != k * k * Cprev) FO1_RUN(fo1_zero_bytes(col, bf16_rows(n, sg.K_padded), stream));
+            FO1_RUN(fo1_im2col_bf16(src, col, H, W, Cprev, k, k, st, pd, sg.K_padded, B, stream));
+            if (i == 0 || !sg.prenorm) {
+                FO1_RUN(fo1_gemm_bf16_ws(col, sg.K_padded, sg.conv_w, sg.K_padded, sg.conv_b, nullptr, 0, XB, C, n, C, sg.K_padded, 0, 0, gws, kGemmScratch, stream));
+                FO1_RUN(fo1_layernorm_bf16(XB, C, sg.norm_w, sg.norm_b, XA, C, n, C, 1e-5f, stream));
+            } else {
+                FO1_RUN(fo1_gemm_bf16_ws(col, sg.K_padded, sg.conv_w, sg.K_padded, sg.conv_b, nullptr, 0, XA, C, n, C, sg.K_padded, 0, 0, gws, kGemmScratch, stream));
+            }
+            A.release(m);
+        }
+        H = Ho; W = Wo;
+        // window geometry of this stage; V^T scratch zeroed once per stage (pad columns are never written afterwards)
+        const int nWin = ((H + ws - 1) / ws) * ((W + ws - 1) / ws), nw = B * nWin * ws * ws, nw_pad = rup(nw, 64);
+        void* vt = A.take(bf16_rows(C, nw_pad));
+        FO1_RUN(fo1_zero_bytes(vt, bf16_rows(C, nw_pad), stream));
+        const int hd = C / heads;
+        for (int j = 0; j < sg.depth; ++j) {
+            const fo1_davit_block_t& blk = sg.blocks[j];
+            const bool last = (j + 1 == sg.depth);
+            {   // SpatialBlock (:284-330): conv1 -> window attention (+ residual) -> conv2 -> FFN
+                const fo1_davit_half_t& d = blk.spatial;
+                const size_t m = A.mark();
+                void* h = A.take(bf16_rows(n, C));
+                void* hw = A.take(bf16_rows(nw, C));
+                void* qkv = A.take(bf16_rows(nw, 3 * C));
+                void* att = A.take(bf16_rows(nw, C));
+                void* y = A.take(bf16_rows(nw, C));
+                FO1_RUN(fo1_dwconv3x3_ln_bf16(XA, d.conv1_w, d.conv1_b, XB, d.an_w, d.an_b, 1e-5f, h, H, W, C, B, stream));
+                FO1_RUN(fo1_window_partition_bf16(h, hw, H, W, C, ws, B, stream));   // zero-padded AFTER the norm (:248-251)
+                FO1_RUN(fo1_gemm_bf16_ws(hw, C, d.qkv_w, C, d.qkv_b, nullptr, 0, qkv, 3 * C, nw, 3 * C, C, 0, 0, gws, kGemmScratch, stream));
+                FO1_RUN(fo1_transpose_bf16((const uint16_t*)qkv + 2 * C, 3 * C, vt, nw_pad, 0, nullptr, nw, C, stream));
+                FO1_RUN(fo1_attention_bf16(qkv, 3 * C, hd, (const uint16_t*)qkv + C, 3 * C, hd, vt, nw_pad, att, C, hd, pl->items[i], pl->n_items[i],
+                                           pl->q_block[i], heads, heads, hd, (float)pow((double)hd, -0.5), 0, nullptr, 4.0 * C * nw * ws * ws, stream));
+                FO1_RUN(fo1_gemm_bf16_ws(att, C, d.proj_w, C, d.proj_b, nullptr, 0, y, C, nw, C, C, 0, 0, gws, kGemmScratch, stream));
+                FO1_RUN(fo1_window_reverse_add_bf16(y, XB, XA, H, W, C, ws, B, stream));
+                A.release(m);
+                const int rc = davit_conv_ffn(A, d, XA, XB, XA, n, H, W, C, B, gws, stream);
+                if (rc != FO1_OK) return rc;
+            }
+            {   // ChannelBlock (:175-205): conv1 -> channel attention (+ residual) -> conv2 -> FFN
+                const fo1_davit_half_t& d = blk.channel;
+                const size_t m = A.mark();
+                void* h = A.take(bf16_rows(n, C));
+                void* qkv = A.take(bf16_rows(n, 3 * C));
+                void* a = A.take(bf16_rows(n, C));
+                const size_t cab = fo1_channel_attention_workspace_bytes(n / B, C, B);
+                void* caw = A.take(cab);
+                FO1_RUN(fo1_dwconv3x3_ln_bf16(XA, d.conv1_w, d.conv1_b, XB, d.an_w, d.an_b, 1e-5f, h, H, W, C, B, stream));
+                FO1_RUN(fo1_gemm_bf16_ws(h, C, d.qkv_w, C, d.qkv_b, nullptr, 0, qkv, 3 * C, n, 3 * C, C, 0, 0, gws, kGemmScratch, stream));
+                FO1_RUN(fo1_channel_attention_bf16(qkv, 3 * C, n / B, C, a, C, B, caw, cab, stream));
+                FO1_RUN(fo1_gemm_bf16_ws(a, C, d.proj_w, C, d.proj_b, XB, C, XA, C, n, C, C, 0, 0, gws, kGemmScratch, stream));
+                A.release(m);
+                const int rc = davit_conv_ffn(A, d, XA, XB, last ? outs[i] : XA, n, H, W, C, B, gws, stream);
+                if (rc != FO1_OK) return rc;
+            }
+        }
+        prev = outs[i];
+        Cprev = C;
+        A.release(stage_mark);
+    }
+    return FO1_OK;
+}
+
+// one pyramid head: 1x1 conv -> LN -> 3x3 conv (im2col + GEMM) -> LN       (simple_fpn.py:165-175)
+int fpn_head(Arena& A, const fo1_fpn_head_t& hd, const void* x, int Cin, void* dst, int H, int W, int B, int Cout, void* gws, void* stream) {
+    const size_t m = A.mark();
+    const int n = B * H * W;
+    void* y = A.take(bf16_rows(n, Cout));
+    void* y2 = A.take(bf16_rows(n, Cout));
+    void* col = A.take(bf16_rows(n, 9 * Cout));
+    FO1_RUN(fo1_gemm_bf16_ws(x, Cin, hd.w1, Cin, nullptr, nullptr, 0, y, Cout, n, Cout, Cin, 0, 0, gws, kGemmScratch, stream));
+    FO1_RUN(fo1_layernorm_bf16(y, Cout, hd.n1_w, hd.n1_b, y2, Cout, n, Cout, 1e-6f, stream));
+    FO1_RUN(fo1_im2col_bf16(y2, col, H, W, Cout, 3, 3, 1, 1, 9 * Cout, B, stream));
+    FO1_RUN(fo1_gemm_bf16_ws(col, 9 * Cout, hd.w3, 9 * Cout, nullptr, nullptr, 0, y, Cout, n, Cout, 9 * Cout, 0, 0, gws, kGemmScratch, stream));
+    FO1_RUN(fo1_layernorm_bf16(y, Cout, hd.n3_w, hd.n3_b, dst, Cout, n, Cout, 1e-6f, stream));
+    A.release(m);
+    return FO1_OK;
+}
+
+// ConvTranspose2d(k=2, s=2) = GEMM [n, Cin] x [4 Cout, Cin]^T + pixel shuffle      (simple_fpn.py:141-150)
+int fpn_up(Arena& A, const void* x, int Cin, const void* w, const void* b, int Cout, void* dst, int H, int W, int B, void* gws, void* stream) {
+    const size_t m = A.mark();
+    const int n = B * H * W;
+    void* g = A.take(bf16_rows(n, 4 * Cout));
+    FO1_RUN(fo1_gemm_bf16_ws(x, Cin, w, Cin, b, nullptr, 0, g, 4 * Cout, n, 4 * Cout, Cin, 0, 0, gws, kGemmScratch, stream));
+    FO1_RUN(fo1_pixel_shuffle2_bf16(g, dst, H, W, Cout, B, stream));
+    A.release(m);
+    return FO1_OK;
+}
+
+int fpn_run(Arena& A, const fo1_fpn_weights_t* w, const void* x, int H, int W, int B, void* const* outs, void* stream) {
+    const int Cin = w->c_in, c1 = w->c_up1, c2 = w->c_up2, Co = w->c_out, n = B * H * W;
+    void* gws = A.take(kGemmScratch);
+    int rc;
+    {   // level 0: two 2x up-convolutions (LN + GELU between) -> head at (4H, 4W)
+        const size_t m = A.mark();
+        void* u1 = A.take(bf16_rows(4LL * n, c1));
+        void* u1n = A.take(bf16_rows(4LL * n, c1));
+        void* u2 = A.take(bf16_rows(16LL * n, c2));
+        if ((rc = fpn_up(A, x, Cin, w->t1a_w, w->t1a_b, c1, u1, H, W, B, gws, stream)) != FO1_OK) return rc;
+        FO1_RUN(fo1_layernorm_bf16(u1, c1, w->t1_ln_w, w->t1_ln_b, u1n, c1, 4 * n, c1, 1e-6f, stream));
+        FO1_RUN(fo1_bias_act_bf16(u1n, c1, nullptr, u1, c1, 4 * n, c1, 1, stream));
+        if ((rc = fpn_up(A, u1, c1, w->t1b_w, w->t1b_b, c2, u2, 2 * H, 2 * W, B, gws, stream)) != FO1_OK) return rc;
+        if ((rc = fpn_head(A, w->heads[0], u2, c2, outs[0], 4 * H, 4 * W, B, Co, gws, stream)) != FO1_OK) return rc;
+        A.release(m);
+    }
+    {   // level 1: one up-convolution -> head at (2H, 2W)
+        const size_t m = A.mark();
+        void* u = A.take(bf16_rows(4LL * n, c1));
+        if ((rc = fpn_up(A, x, Cin, w->t2_w, w->t2_b, c1, u, H, W, B, gws, stream)) != FO1_OK) return rc;
+        if ((rc = fpn_head(A, w->heads[1], u, c1, outs[1], 2 * H, 2 * W, B, Co, gws, stream)) != FO1_OK) return rc;
+        A.release(m);
+    }
+    if ((rc = fpn_head(A, w->heads[2], x, Cin, outs[2], H, W, B, Co, gws, stream)) != FO1_OK) return rc;
+    {   // level 3: 2x2 max-pool -> head at (H/2, W/2)
+        const size_t m = A.mark();
+        void* p = A.take(bf16_rows((long long)B * (H / 2) * (W / 2), Cin));
+        FO1_RUN(fo1_maxpool2_bf16(x, p, H, W, Cin, B, stream));
+        if ((rc = fpn_head(A, w->heads[3], p, Cin, outs[3], H / 2, W / 2, B, Co, gws, stream)) != FO1_OK) return rc;
+        A.release(m);
+    }
+    return FO1_OK;
+}
+}  // namespace
+
+size_t fo1_davit_workspace_bytes(const fo1_davit_weights_t* w, const fo1_davit_plan_t* plan) {
+    if (!w || !plan) return 0;
+    Arena A(nullptr);
+    void* outs[4] = {(void*)256, (void*)256, (void*)256, (void*)256};
+    davit_run(A, w, plan, nullptr, 0, outs, nullptr);
+    return A.peak;
+}
+
+int fo1_davit_forward(const fo1_davit_weights_t* w, const fo1_davit_plan_t* plan, const void* images, int images_are_f32, void* const* maps_out,
+                      void* workspace, size_t workspace_bytes, void* stream) {
+    FO1_CHECK_ARG(w && plan && images && maps_out && workspace, "davit_forward: NULL argument");
+    FO1_CHECK_ARG(w->n_stages >= 1 && w->n_stages <= 4 && plan->batch >= 1 && plan->H > 0 && plan->W > 0, "davit_forward: bad geometry");
+    for (int i = 0; i < w->n_stages; ++i) FO1_CHECK_ARG(maps_out[i] && plan->items[i] && w->stages[i].blocks, "davit_forward: stage %d incomplete", i);
+    const size_t need = fo1_davit_workspace_bytes(w, plan);
+    if (workspace_bytes < need) return fo1::set_err(FO1_ERR_WORKSPACE, "davit_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+    Arena A(workspace);
+    return davit_run(A, w, plan, images, images_are_f32, maps_out, stream);
+}
+
+size_t fo1_simplefpn_workspace_bytes(const fo1_fpn_weights_t* w, int H, int W, int batch) {
+    if (!w || H <= 0 || W <= 0 || batch <= 0) return 0;
+    Arena A(nullptr);
+    void* outs[4] = {(void*)256, (void*)256, (void*)256, (void*)256};
+    fpn_run(A, w, nullptr, H, W, batch, outs, nullptr);
+    return A.peak;
+}
+
+int fo1_simplefpn_forward(const fo1_fpn_weights_t* w, const void* vit_map, int H, int W, int batch, void* const* maps_out, void* workspace,
+                          size_t workspace_bytes, void* stream) {
+    FO1_CHECK_ARG(w && vit_map && maps_out && workspace && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && batch >= 1, "simplefpn_forward: bad argument");
+    for (int i = 0; i < 4; ++i) FO1_CHECK_ARG(maps_out[i] != nullptr, "simplefpn_forward: maps_out[%d] is NULL", i);
+    const size_t need = fo1_simplefpn_workspace_bytes(w, H, W, batch);
+    if (workspace_bytes < need) return fo1::set_err(FO1_ERR_WORKSPACE, "simplefpn_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+    Arena A(workspace);
+    return fpn_run(A, w, vit_map, H, W, batch, maps_out, stream);
+}
+
+// mlpN_gelu projector (multimodal_projector/builder.py:64-71,103-110): Linear (+ GELU between layers), rows [M, dims[0]] -> [M, dims[n]]
+size_t fo1_projector_workspace_bytes(const fo1_projector_t* p, int rows) {
+    if (!p || rows <= 0 || p->n_layers < 1 || p->n_layers > 4) return 0;
+    int wide = 0;
+    for (int i = 1; i <= p->n_layers; ++i) wide = p->dims[i] > wide ? p->dims[i] : wide;
+    return 2 * (((size_t)rows * wide * 2 + 255) & ~(size_t)255) + kGemmScratch;
+}
+
+int fo1_projector_forward(const fo1_projector_t* p, const void* x, int ldx, int rows, void* out, int ld_out, void* workspace, size_t workspace_bytes,
+                          void* stream) {
+    FO1_CHECK_ARG(p && x && out && workspace && rows > 0 && p->n_layers >= 1 && p->n_layers <= 4, "projector_forward: bad argument");
+    const size_t need = fo1_projector_workspace_bytes(p, rows);
+    if (workspace_bytes < need) return fo1::set_err(FO1_ERR_WORKSPACE, "projector_forward: workspace %zu B < required %zu B", workspace_bytes, need);
+    int wide = 0;
+    for (int i = 1; i <= p->n_layers; ++i) wide = p->dims[i] > wide ? p->dims[i] : wide;
+    const size_t slab = ((size_t)rows * wide * 2 + 255) & ~(size_t)255;
+    char* base = (char*)workspace;
+    void* gws = base + 2 * slab;
+    const void* cur = x;
+    int ld = ldx;
+    for (int i = 0; i < p->n_layers; ++i) {
+        const bool last = (i + 1 == p->n_layers);
+        void* dst = last ? out : (void*)(base + (i & 1) * slab);
+        const int ldd = last ? ld_out : p->dims[i + 1];
+        FO1_TRY(fo1_gemm_bf16_ws(cur, ld, p->w[i], p->dims[i], p->b[i], nullptr, 0, dst, ldd, rows, p->dims[i + 1], p->dims[i], last ? 0 : 1, 0, gws, kGemmScratch,
+                                 stream));
+        cur = dst;
+        ld = ldd;
+    }
     return FO1_OK;
 }
 

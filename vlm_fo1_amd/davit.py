@@ -115,6 +115,9 @@ class DaViT:
         """img [3,H,W] or [B,3,H,W] (device, bf16/fp32, CLIP-normalised; B same-size images in one pass).  Returns
         ([4 token-major maps [B*H_i*W_i, C_i] bf16 — image b at rows [b*H_i*W_i, (b+1)*H_i*W_i)], [(H_i, W_i)])."""
         cfg = self.cfg
+        from . import stage_abi
+        if stage_abi.enabled():      # the same launches, sequenced by fo1_davit_forward (csrc/stages.hip)
+            return stage_abi.davit_stage(self).forward(img)
         if img.dim() == 3:
             img = img.unsqueeze(0)
         B = img.shape[0]

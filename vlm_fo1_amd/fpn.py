@@ -60,6 +60,9 @@ class SimpleFPN:
         """x [batch*H*W, 1280] token-major bf16 (same-size maps stacked) -> 4 token-major maps [batch*.., 512] at (4H,4W),
         (2H,2W), (H,W), (H/2,W/2); image b owns rows [b*h*w, (b+1)*h*w) of every level."""
         B = batch
+        from . import stage_abi
+        if stage_abi.enabled():      # the same launches, sequenced by fo1_simplefpn_forward (csrc/stages.hip)
+            return stage_abi.fpn_stage(self).forward(x, H, W, B)
         outs, sizes = [], []
         y, h1, w1 = self._up(x, H, W, self.t1a, B)
         y = ops.layernorm(y, self.t1_ln[0], self.t1_ln[1], 1e-6)

@@ -75,6 +75,51 @@ class KvCache(ctypes.Structure):
                 ("vt", c_void_p), ("vt_layer_stride", c_longlong), ("vt_row_stride", c_longlong), ("capacity", c_int32)]
 
 
+_HALF = ("conv1_w", "conv1_b", "conv2_w", "conv2_b", "an_w", "an_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "fn_w", "fn_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")
+
+
+class DavitHalf(ctypes.Structure):
+    """fo1_davit_half_t"""
+    _fields_ = [(n, c_void_p) for n in _HALF]
+
+
+class DavitBlock(ctypes.Structure):
+    """fo1_davit_block_t"""
+    _fields_ = [("spatial", DavitHalf), ("channel", DavitHalf)]
+
+
+class DavitStage(ctypes.Structure):
+    """fo1_davit_stage_t"""
+    _fields_ = [(n, c_int32) for n in ("dim", "heads", "depth", "kernel", "stride", "pad", "prenorm", "K_padded")] + \
+               [(n, c_void_p) for n in ("conv_w", "conv_b", "norm_w", "norm_b")] + [("blocks", ctypes.POINTER(DavitBlock))]
+
+
+class DavitWeights(ctypes.Structure):
+    """fo1_davit_weights_t"""
+    _fields_ = [("n_stages", c_int32), ("window", c_int32), ("stages", DavitStage * 4)]
+
+
+class DavitPlan(ctypes.Structure):
+    """fo1_davit_plan_t"""
+    _fields_ = [("H", c_int32), ("W", c_int32), ("batch", c_int32), ("items", c_void_p * 4), ("n_items", c_int32 * 4), ("q_block", c_int32 * 4)]
+
+
+class FpnHead(ctypes.Structure):
+    """fo1_fpn_head_t"""
+    _fields_ = [(n, c_void_p) for n in ("w1", "n1_w", "n1_b", "w3", "n3_w", "n3_b")]
+
+
+class FpnWeights(ctypes.Structure):
+    """fo1_fpn_weights_t"""
+    _fields_ = [(n, c_int32) for n in ("c_in", "c_up1", "c_up2", "c_out")] + \
+               [(n, c_void_p) for n in ("t1a_w", "t1a_b", "t1_ln_w", "t1_ln_b", "t1b_w", "t1b_b", "t2_w", "t2_b")] + [("heads", FpnHead * 4)]
+
+
+class ProjectorW(ctypes.Structure):
+    """fo1_projector_t"""
+    _fields_ = [("n_layers", c_int32), ("dims", c_int32 * 5), ("w", c_void_p * 4), ("b", c_void_p * 4)]
+
+
 class ProfileRow(ctypes.Structure):
     """fo1_profile_row_t (include/fo1.h)."""
     _fields_ = [("name", ctypes.c_char * 48), ("calls", ctypes.c_int64), ("total_ms", ctypes.c_double),
@@ -99,6 +144,13 @@ SIGNATURES = {
     "fo1_llm_decode_step": (c_int, [ctypes.POINTER(LlmWeights), ctypes.POINTER(KvCache), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fo1_zero_bytes": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "fo1_davit_workspace_bytes": (c_size_t, [ctypes.POINTER(DavitWeights), ctypes.POINTER(DavitPlan)]),
+    "fo1_davit_forward": (c_int, [ctypes.POINTER(DavitWeights), ctypes.POINTER(DavitPlan), c_void_p, c_int, ctypes.POINTER(c_void_p), c_void_p, c_size_t,
+                                  c_void_p]),
+    "fo1_simplefpn_workspace_bytes": (c_size_t, [ctypes.POINTER(FpnWeights), c_int, c_int, c_int]),
+    "fo1_simplefpn_forward": (c_int, [ctypes.POINTER(FpnWeights), c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
+    "fo1_projector_workspace_bytes": (c_size_t, [ctypes.POINTER(ProjectorW), c_int]),
+    "fo1_projector_forward": (c_int, [ctypes.POINTER(ProjectorW), c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
     "fo1_hfre_set_tuning": (c_int, [c_int, c_int, c_int, c_int]),
     "fo1_hfre_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),

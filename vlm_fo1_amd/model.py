@@ -63,6 +63,9 @@ class Projector:
             self.layers.append((dv(state[f"{prefix}{2 * i}.weight"]), dv(state[f"{prefix}{2 * i}.bias"])))
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        from . import stage_abi
+        if stage_abi.enabled():      # the same launches, sequenced by fo1_projector_forward (csrc/stages.hip)
+            return stage_abi.projector_forward(self.layers, x)
         n = len(self.layers)
         for i, (w, b) in enumerate(self.layers):
             x = ops.gemm(x, w, b, act=ops.ACT_GELU if i + 1 < n else ops.ACT_NONE)

@@ -36,6 +36,20 @@ def llm_stage(llm) -> "LlmStage":
     return st
 
 
+def davit_stage(davit) -> "DavitStage":
+    st = getattr(davit, "_stage", None)
+    if st is None:
+        st = davit._stage = DavitStage(davit)
+    return st
+
+
+def fpn_stage(fpn) -> "FpnStage":
+    st = getattr(fpn, "_stage", None)
+    if st is None:
+        st = fpn._stage = FpnStage(fpn)
+    return st
+
+
 def _p(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -157,3 +171,108 @@ class LlmStage:
                                    dec.done.data_ptr(), B, dec.slot, logits.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr())
         _lib.check(rc, "fo1_llm_decode_step")
         return logits
+
+
+class DavitStage:
+    def __init__(self, davit):
+        self.davit = davit
+        cfg = davit.cfg
+        W = _lib.DavitWeights()
+        W.n_stages, W.window = len(cfg["dims"]), cfg["window"]
+        self._blocks = []
+        for i, C in enumerate(cfg["dims"]):
+            cv = davit.convs[i]
+            S = W.stages[i]
+            S.dim, S.heads, S.depth = C, cfg["heads"][i], cfg["depths"][i]
+            S.kernel, S.stride, S.pad = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
+            S.prenorm, S.K_padded = int(cfg["patch_prenorm"][i]), cv["Kp"]
+            S.conv_w, S.conv_b, S.norm_w, S.norm_b = cv["w"].data_ptr(), cv["b"].data_ptr(), cv["nw"].data_ptr(), cv["nb"].data_ptr()
+            arr = (_lib.DavitBlock * S.depth)()
+            for j, blk in enumerate(davit.blocks[i]):
+                for half, name in ((arr[j].spatial, "spatial_block"), (arr[j].channel, "channel_block")):
+                    for k in _lib._HALF:
+                        setattr(half, k, blk[name][k].data_ptr())
+            self._blocks.append(arr)
+            S.blocks = ctypes.cast(arr, ctypes.POINTER(_lib.DavitBlock))
+        self.W = W
+
+    def forward(self, img: torch.Tensor):
+        """Same contract as DaViT.forward: img [B,3,H,W] -> ([4 maps], [(H_i, W_i)])."""
+        L = _lib.load()
+        d, cfg = self.davit, self.davit.cfg
+        if img.dim() == 3:
+            img = img.unsqueeze(0)
+        img = img.contiguous()
+        B, _, H, W = img.shape
+        ws = cfg["window"]
+        P = _lib.DavitPlan()
+        P.H, P.W, P.batch = H, W, B
+        sizes, outs, keep = [], [], []
+        h, w = H, W
+        for i, C in enumerate(cfg["dims"]):
+            k, s, p = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
+            h, w = (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+            sizes.append((h, w))
+            n_win = B * ((h + ws - 1) // ws) * ((w + ws - 1) // ws)
+            items = d._window_items(n_win, ws * ws, cfg["heads"][i])
+            keep.append(items)
+            P.items[i], P.n_items[i], P.q_block[i] = items.data_ptr(), items.shape[0], getattr(items, "q_block", 64)
+            outs.append(torch.empty(B * h * w, C, dtype=torch.bfloat16, device=img.device))
+        arr = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in outs])
+        need = L.fo1_davit_workspace_bytes(ctypes.byref(self.W), ctypes.byref(P))
+        wsb = ops._workspace("stage_davit", img.device, need)
+        rc = L.fo1_davit_forward(ctypes.byref(self.W), ctypes.byref(P), img.data_ptr(), 1 if img.dtype == torch.float32 else 0, arr, wsb.data_ptr(), wsb.numel(),
+                                 _lib.current_stream_ptr())
+        _lib.check(rc, "fo1_davit_forward")
+        self._keep = (img, keep)
+        return outs, sizes
+
+
+class FpnStage:
+    def __init__(self, fpn):
+        self.fpn = fpn
+        W = _lib.FpnWeights()
+        W.c_in = fpn.t1a[0].shape[1]
+        W.c_up1, W.c_up2, W.c_out = fpn.t1a[2], fpn.t1b[2], fpn.heads[0]["w1"].shape[0]
+        assert fpn.t2[2] == W.c_up1
+        W.t1a_w, W.t1a_b = fpn.t1a[0].data_ptr(), fpn.t1a[1].data_ptr()
+        W.t1_ln_w, W.t1_ln_b = fpn.t1_ln[0].data_ptr(), fpn.t1_ln[1].data_ptr()
+        W.t1b_w, W.t1b_b = fpn.t1b[0].data_ptr(), fpn.t1b[1].data_ptr()
+        W.t2_w, W.t2_b = fpn.t2[0].data_ptr(), fpn.t2[1].data_ptr()
+        for i, h in enumerate(fpn.heads):
+            W.heads[i].w1, W.heads[i].n1_w, W.heads[i].n1_b = h["w1"].data_ptr(), h["n1"][0].data_ptr(), h["n1"][1].data_ptr()
+            W.heads[i].w3, W.heads[i].n3_w, W.heads[i].n3_b = h["w3"].data_ptr(), h["n3"][0].data_ptr(), h["n3"][1].data_ptr()
+        self.W = W
+
+    def forward(self, x: torch.Tensor, H: int, W: int, batch: int = 1):
+        L = _lib.load()
+        co = self.W.c_out
+        sizes = [(4 * H, 4 * W), (2 * H, 2 * W), (H, W), (H // 2, W // 2)]
+        outs = [torch.empty(batch * h * w, co, dtype=torch.bfloat16, device=x.device) for h, w in sizes]
+        arr = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in outs])
+        x = x.contiguous()
+        need = L.fo1_simplefpn_workspace_bytes(ctypes.byref(self.W), H, W, batch)
+        wsb = ops._workspace("stage_fpn", x.device, need)
+        rc = L.fo1_simplefpn_forward(ctypes.byref(self.W), x.data_ptr(), H, W, batch, arr, wsb.data_ptr(), wsb.numel(), _lib.current_stream_ptr())
+        _lib.check(rc, "fo1_simplefpn_forward")
+        self._keep = x
+        return outs, sizes
+
+
+def projector_forward(layers, x: torch.Tensor) -> torch.Tensor:
+    """layers: [(weight [out, in], bias [out])] of an mlpN_gelu connector."""
+    L = _lib.load()
+    P = _lib.ProjectorW()
+    P.n_layers = len(layers)
+    P.dims[0] = layers[0][0].shape[1]
+    for i, (w, b) in enumerate(layers):
+        P.dims[i + 1] = w.shape[0]
+        P.w[i], P.b[i] = w.data_ptr(), b.data_ptr()
+    x = x.contiguous()
+    out = torch.empty(x.shape[0], P.dims[P.n_layers], dtype=torch.bfloat16, device=x.device)
+    need = L.fo1_projector_workspace_bytes(ctypes.byref(P), x.shape[0])
+    wsb = ops._workspace("stage_proj", x.device, need)
+    rc = L.fo1_projector_forward(ctypes.byref(P), x.data_ptr(), x.stride(0), x.shape[0], out.data_ptr(), out.stride(0), wsb.data_ptr(), wsb.numel(),
+                                 _lib.current_stream_ptr())
+    _lib.check(rc, "fo1_projector_forward")
+    return out
