@@ -222,18 +222,19 @@ def hfre_algorithmic_bytes(case, region_dim=5888, P=7):
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_traffic.json, written by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs with the
+    (profiles/r02_pmc_traffic.json, written by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs with the
     gfx950 x2 FETCH correction of MI355X_MICROARCH.md applied).  PMC counters cannot be read from inside the process, so the
     bench line carries the committed figure and names its source; null when no PMC pass exists for the kernel."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        row = t["kernels"].get(kernel_name)
-        if row:
-            return row["hbm_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
-    except (OSError, ValueError, KeyError):
-        pass
+    for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):     # newest pass that has the kernel
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
+        try:
+            with open(path) as f:
+                t = json.load(f)
+            row = t["kernels"].get(kernel_name)
+            if row:
+                return row["hbm_bytes_per_launch"], "profiles/" + name
+        except (OSError, ValueError, KeyError):
+            pass
     return None, None
 
 

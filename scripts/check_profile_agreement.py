@@ -13,6 +13,11 @@ for r in csv.DictReader(open(sys.argv[2])):
 
 def rocprof_avg(bench_name):
     pats = {"attn_fwd": r"attn_fwd_kernel<\d+, 4, false>", "rmsnorm": r"rownorm_kernel<0>", "layernorm": r"rownorm_kernel<1>"}
+    m = re.match(r"gemm_bt_p(\d)<", bench_name)
+    if m:
+        sel = [(c, a) for k, (c, a) in stats.items() if f"gemm_bt_p{m.group(1)}_kernel" in k]
+        n = sum(c for c, _ in sel)
+        return sum(c * a for c, a in sel) / n if n else None
     m = re.match(r"gemm_bt_glds<(\d+),(\d+)>", bench_name)
     if m:
         pat = rf"gemm_bt_glds_kernel<{m.group(1)}, {m.group(2)},"

@@ -12,13 +12,21 @@ from collections import defaultdict
 BENCH_NAMES = [
     (r"attn_fwd_kernel<128, 4, false>", "attention_hd128"),
     (r"attn_fwd_kernel<80, 4, false>", "attention_hd80"),
+    (r"hfre_pool_items_kernel", "hfre_pool_items"),
+    (r"hfre_weights_kernel", "hfre_weights"),
+    (r"hfre_finish2_kernel", "hfre_finish2"),
     (r"hfre_pool_kernel", "hfre_pool"),
+    (r"dwconv3x3_ln", "dwconv3x3_ln"),
     (r"rownorm_kernel<0>", "rmsnorm"),
 ]
 
 
 def bench_name(k):
     """rocprofv3 kernel name -> the row name fo1_profile_read / bench.py uses."""
+    if "gemm_bt_p4_kernel" in k:
+        return "gemm_bt_p4<256,256>"
+    if "gemm_bt_p8_kernel" in k:
+        return "gemm_bt_p8<256,256>"
     m = re.search(r"gemm_bt_glds_kernel<(\d+), (\d+)", k)
     if m:
         return f"gemm_bt_glds<{m.group(1)},{m.group(2)}>"
@@ -45,7 +53,7 @@ def main():
     write = fold(sys.argv[2], "WRITE_SIZE")
     out = {"units": "bytes per launch (mean over all launches of the kernel in the run)",
            "corrections": "FETCH_SIZE KB x 1024 x 2 (gfx950 half-count of 16 B/lane reads); WRITE_SIZE KB x 1024",
-           "command": "python bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline (one pass per counter)", "kernels": {}}
+           "command": "python bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline (default workload: 8 images x 100 boxes per pass; one rocprofv3 pass per counter)", "kernels": {}}
     for k, (n, v) in fetch.items():
         if not re.search(r"fo1::", k):
             continue
