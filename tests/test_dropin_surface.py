@@ -197,3 +197,53 @@ def test_aux_processor_matches_reference_clip_processor(mode):
     got = CLIPStyleAuxProcessor(resize_mode=mode).preprocess(img, return_tensors="pt")["pixel_values"][0]
     assert got.shape == ref.shape
     torch.testing.assert_close(got, ref, rtol=0, atol=2e-6)
+
+
+def test_model_max_length_overflow_fails_like_the_reference_splice():
+    """omchat_qwen2_5_vl.py:374-378 cuts the spliced embeddings to tokenizer_model_max_length but not new_input_ids, so the
+    right-padding fill at :411 raises torch's size-mismatch RuntimeError: an over-long prompt never reaches the LLM.  The drop-in
+    raises the same exception type with the same two sizes; prompts within the limit pass; left padding is refused explicitly."""
+    from vlm_fo1.model.fo1_model import FO1ForCausalLM, FO1HFConfig
+    from vlm_fo1_amd.llm import DEFAULT_REGION_INDEX, IMAGE_TOKEN_INDEX
+    m = FO1ForCausalLM.__new__(FO1ForCausalLM)
+    m.config = FO1HFConfig({"tokenizer_model_max_length": 100})
+    ids = [1, 2, IMAGE_TOKEN_INDEX, 3] + [DEFAULT_REGION_INDEX, 7] * 10          # 24 ids, one image sentinel
+    m._check_model_max_length(ids, 77)                                            # 24 + 76 = 100 rows: fits exactly
+    with pytest.raises(RuntimeError, match=r"\(100\) must match the existing size \(101\)"):
+        m._check_model_max_length(ids, 78)
+    # the reference's statement really fails that way
+    import torch
+    with pytest.raises(RuntimeError, match=r"\(100\) must match the existing size \(101\)"):
+        torch.zeros(1, 200, dtype=torch.long)[0, :100] = torch.zeros(101, dtype=torch.long)
+    m.config = FO1HFConfig({"tokenizer_model_max_length": 100, "tokenizer_padding_side": "left"})
+    with pytest.raises(NotImplementedError):
+        m._check_model_max_length(ids, 78)
+    m.config = FO1HFConfig({})
+    m._check_model_max_length(ids, 10 ** 6)                                       # no limit configured: nothing to check
+
+
+def test_chunk_tokenisation_cache_is_transparent():
+    """The per-tokenizer chunk cache returns what the tokenizer returns, calls it once per distinct chunk, and hands
+    out fresh lists (callers extend them)."""
+    from vlm_fo1 import mm_utils
+
+    class Tok:
+        bos_token_id = None
+
+        def __init__(self):
+            self.calls = 0
+
+        def __call__(self, text):
+            self.calls += 1
+            return type("E", (), {"input_ids": [ord(c) for c in text]})()
+
+    tok = Tok()
+    prompt = "a<image>b" + "".join(f"<region{i}><regionfeat>" for i in range(20)) + "c"
+    first = mm_utils.tokenizer_image_region_token(prompt, tok)
+    n = tok.calls
+    again = mm_utils.tokenizer_image_region_token(prompt, tok)
+    assert again == first and tok.calls == n, "second call must be served from the cache"
+    ref = mm_utils.tokenizer_image_region_token(prompt, Tok())       # a fresh tokenizer object: nothing cached
+    assert ref == first
+    first.append(-1)
+    assert mm_utils.tokenizer_image_region_token(prompt, tok)[-1] != -1

@@ -136,8 +136,28 @@ class FO1ForCausalLM:
         boxes = None
         if bbox_list is not None and len(bbox_list) > 0 and bbox_list[0] is not None:
             boxes = bbox_list[0].to(device=dev, dtype=torch.float32)
+        self._check_model_max_length(inputs[0].tolist(), (grid[1] // 2) * (grid[2] // 2))
         return dict(ids=inputs[0].tolist(), pix=images[0].to(device=dev, dtype=torch.bfloat16), grid=(grid[1], grid[2]),
                     aux=images_aux[0].to(device=dev, dtype=torch.bfloat16), boxes=boxes)
+
+    def _check_model_max_length(self, ids, n_image_tokens: int) -> None:
+        """`tokenizer_model_max_length` semantics of the reference splice (omchat_qwen2_5_vl.py:374-378): the spliced embeddings and
+        labels are cut to that length but `new_input_ids` is NOT, so with the default right padding the very next statement
+        (`new_input_ids_padded[i, :cur_len] = cur_new_input_ids`, :411) fails with torch's size-mismatch RuntimeError — an over-long
+        prompt never reaches the LLM.  Same here: same exception type, same sizes in the message.  (Left padding would run the
+        reference on all-BOS ids with text-only positions; that variant is not built.)"""
+        limit = getattr(self.config, "tokenizer_model_max_length", None)
+        if limit is None:
+            return
+        from vlm_fo1_amd.llm import IMAGE_TOKEN_INDEX
+        spliced = len(ids) + sum(n_image_tokens - 1 for t in ids if t == IMAGE_TOKEN_INDEX)      # a <regionfeat> sentinel becomes one row
+        if spliced <= int(limit):
+            return
+        if getattr(self.config, "tokenizer_padding_side", "right") == "left":
+            raise NotImplementedError("prompt longer than tokenizer_model_max_length with left padding is not built")
+        raise RuntimeError(f"The expanded size of the tensor ({int(limit)}) must match the existing size ({spliced}) at non-singleton dimension 0.  "
+                           f"Target sizes: [{int(limit)}].  Tensor sizes: [{spliced}]  (spliced prompt exceeds tokenizer_model_max_length; the "
+                           "reference fails at omchat_qwen2_5_vl.py:411 in the same way)")
 
     def _device_stop_ids(self, stopping_criteria) -> Optional[List[int]]:
         """EOS ids + the ids of single-token stop keywords (mm_utils.KeywordsStoppingCriteria with `<|im_end|>`): the stop rule the
