@@ -367,7 +367,7 @@ def main():
                    note="one sequence at a time, host reads every token (the round-1 path)")
         # device decode loop: the sequences of one packed prefill advance together, weights streamed once per step, stop rule and
         # bookkeeping on the device (no host read per token); measured for one sequence and for the batch
-        Bd = min(B, 8)
+        Bd = min(B, 16)
         if use_graph:
             eng = pipe.eng
 
@@ -404,7 +404,7 @@ def main():
                 dec["batched"] = dict(sequences=Bd, ms_per_step=round(tb * 1e3, 3), tokens_per_sec=round(Bd / tb, 1),
                                       prefill_pass_ms=round(t_pref * 1e3, 3),
                                       images_per_sec_with_64_token_answer=round(Bd / (t_pref + 64 * tb), 2),
-                                      launches_per_layer=6, note="one pass at a time: packed prefill of the batch, then 64 batched decode steps")
+                                      launches_per_layer=5, note="one pass at a time: packed prefill of the batch, then 64 batched decode steps")
 
     # ---- host-side preprocessing of one image (SURVEY 8d "preprocess (CPU)" stage, 8f rank 2): not part of `value` ----
     prep = None

@@ -307,15 +307,24 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
  * LDS are shared between them); 1 = always one row.  Results are bit-identical either way.  Process-global. */
 int fo1_gemv_batch_set_rows_per_lane(int rpl);
 
+/* A/B hooks of the decode step, process-global.
+ * fo1_gemv_batch_set_impl: 1 (default) = MFMA skinny GEMM (csrc/decode_mfma.hip: the sequences ride as the 16 columns of
+ *   v_mfma_f32_16x16x32_bf16, M <= 16, needs N % 4 == 0); 0 = the v_dot2 streaming kernel (M <= 8).  Both keep a
+ *   sequence's numbers independent of the batch it decodes in; the two differ from each other in fp32 summation order.
+ * fo1_attention_decode_set_impl: 1 (default) = one workgroup per (KV head, sequence), tiles round-robin over its waves,
+ *   partials merged in LDS (one launch for slots <= 2048 rows); 0 = 64-key split-KV partials + combine kernel. */
+int fo1_gemv_batch_set_impl(int impl);
+int fo1_attention_decode_set_impl(int impl);
+
 /* ------------------------------------------------------------------------
- * Batched greedy decode: B <= 8 sequences advance one token per step through ONE stream of the weights, and
+ * Batched greedy decode: B <= 16 sequences advance one token per step through ONE stream of the weights, and
  * every position-dependent quantity lives in device memory, so a single captured hipGraph serves every step.
  * Reference: decode fast path omchat_qwen2_5_vl.py:143-155, positions modeling_qwen2_5_vl.py:1848-1860, stop rule
  * mm_utils.py:137-181 + HF greedy search (stop AFTER appending an EOS / keyword id, or at max_new_tokens).
  *   state: int32[B][8] = { pos, rope_row, kv_start, finished, n_gen, max_new, -, - }
  *     pos = cache row the fed token's K row / V^T column is written to; keys attended = [kv_start, pos];
  *     rope_row = row of the [positions, 128] mRoPE tables (cache position + rope delta).
- *   fo1_gemv_batch_bf16            C[M<=8,N] = epilogue(rmsnorm?(x) W^T): mode 0 bias/residual, 1 interleaved SwiGLU,
+ *   fo1_gemv_batch_bf16            C[M<=16,N] = epilogue(rmsnorm?(x) W^T): mode 0 bias/residual, 1 interleaved SwiGLU,
  *                                  2 fused QKV (bias -> bf16 -> mRoPE -> q rows out, K row + V^T column appended at state.pos)
  *   fo1_attention_decode_batch_bf16  split-KV attention of B one-token queries against their slots
  *   fo1_decode_argmax_accept       greedy pick per logits row + on-device accept: record id, stop check, advance state,
@@ -419,7 +428,8 @@ int fo1_llm_prefill(const fo1_llm_weights_t* w, const fo1_kv_cache_t* kv,
 size_t fo1_llm_decode_workspace_bytes(const fo1_llm_weights_t* w, int batch, int slot_rows);
 int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots, const void* rope_cos, const void* rope_sin,
                         int32_t* state, int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids, int n_stop,
-                        int32_t* done, int batch, int slot_rows, void* logits /* bf16 [batch, vocab] */, void* workspace,
+                        int32_t* done, int batch, int slot_rows, int max_kv_len /* bound on any sequence's keys this step, <= slot_rows:
+                        picks the attention geometry */, void* logits /* bf16 [batch, vocab] */, void* workspace,
                         size_t workspace_bytes, void* stream);
 /*   fo1_davit_forward      DaViT-L aux tower over `batch` same-size images: 4 stages of ConvEmbed + (SpatialBlock, ChannelBlock)
  *                          pairs; emits the four token-major stage maps the HFRE reads.  reference: davit_aux_encoder.py:54-69,

@@ -88,17 +88,140 @@ def test_batched_decode_vs_alone_vs_oracle_and_stop_rule():
     assert [g[:3] for g in got[True]] == eng.generate_batch(reqs, max_new_tokens=3, use_graph=True)
 
 
-@pytest.mark.parametrize("rows_per_lane", [0, 1])
-def test_gemv_batch_matches_reference(rows_per_lane):
-    """fo1_gemv_batch_bf16 (plain / SwiGLU epilogues, fused RMSNorm, K pieces for deep K at M = 8) against torch fp32, with the
-    rows-per-lane blocking by M (0, default) and with one row per lane (1)."""
+def test_batched_decode_twelve_sequences_match_alone():
+    """More than 8 sequences per weight stream (the MFMA kernel carries up to 16 as MFMA columns): 12 ragged requests generate, per
+    request, exactly the ids the same path generates for the request alone."""
+    from test_batched_prefill_gpu import make_request
+    cfg, weights, eng = build()
+    reqs = [make_request(100 + i, 96 + 28 * (i % 4), 120 + 28 * (i % 3), 1 + (5 * i) % 9) for i in range(12)]
+    K = 6
+    got = eng.generate_batch(reqs, max_new_tokens=K, use_graph=True)
+    assert [len(g) for g in got] == [K] * 12
+    for i in (0, 5, 11):
+        assert eng.generate_batch([reqs[i]], max_new_tokens=K, use_graph=True)[0] == got[i], f"request {i} decodes differently in a batch of 12"
+
+
+@pytest.mark.parametrize("impl,rows_per_lane", [(1, 0), (0, 0), (0, 1)])
+def test_gemv_batch_matches_reference(impl, rows_per_lane):
+    """fo1_gemv_batch_bf16 (plain / SwiGLU epilogues, fused RMSNorm, K pieces for deep K) against torch fp32: the MFMA skinny GEMM
+    (impl 1, default; also at M = 16) and the v_dot2 kernel (impl 0) with the rows-per-lane blocking by M (0) and one row per lane (1)."""
     from test_ops_gpu import gemm_ref, rb
     from vlm_fo1_amd import lib as L, ops
+    L.check(L.load().fo1_gemv_batch_set_impl(impl), "set_impl")
     L.check(L.load().fo1_gemv_batch_set_rows_per_lane(rows_per_lane), "set_rows_per_lane")
     try:
-        _gemv_batch_cases(gemm_ref, rb, ops)
+        _gemv_batch_cases(gemm_ref, rb, ops, m16=impl == 1)
     finally:
         L.load().fo1_gemv_batch_set_rows_per_lane(0)
+        L.load().fo1_gemv_batch_set_impl(1)
+
+
+def _qkv_case(ops, M, seed=3):
+    """Inputs of one fused-QKV decode projection (Qwen2.5-VL-3B head geometry) + fresh caches."""
+    BF = torch.bfloat16
+    g = torch.Generator().manual_seed(seed)
+    H, KV, HD, K, rows = 16, 2, 128, 2048, 256
+    x = (torch.randn(M, K, generator=g)).to(BF).cuda()
+    w = (torch.randn((H + 2 * KV) * HD, K, generator=g) * 0.05).to(BF).cuda()
+    b = (torch.randn((H + 2 * KV) * HD, generator=g) * 0.1).to(BF).cuda()
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).cuda()
+    ang = torch.rand(rows, HD, generator=g) * 6.28
+    cos, sin = ang.cos().to(BF).cuda(), ang.sin().to(BF).cuda()
+    state = torch.zeros(M, 8, dtype=torch.int32)
+    for m in range(M):
+        state[m, 0] = 5 + 13 * m          # cache row
+        state[m, 1] = 200 - 7 * m         # rope-table row
+    return dict(x=x, w=w, b=b, nw=nw, cos=cos, sin=sin, state=state.cuda(), H=H, KV=KV, HD=HD, rows=rows)
+
+
+def _run_qkv(ops, c):
+    kc = torch.zeros(c["KV"], c["rows"], c["HD"], dtype=torch.bfloat16, device="cuda")
+    vt = torch.zeros(c["KV"] * c["HD"], c["rows"], dtype=torch.bfloat16, device="cuda")
+    q = ops.gemv_batch(c["x"], c["w"], c["b"], mode=ops.GB_QKV, norm_weight=c["nw"], norm_eps=1e-6,
+                       qkv=dict(n_q=c["H"], n_kv=c["KV"], cos=c["cos"], sin=c["sin"], state=c["state"], kcache=kc, vtcache=vt))
+    torch.cuda.synchronize()
+    return q.float().cpu(), kc.float().cpu(), vt.float().cpu()
+
+
+@pytest.mark.parametrize("M", [1, 5, 8, 16])
+def test_gemv_mfma_qkv_matches_reference_and_dot2(M):
+    """Fused QKV epilogue of the MFMA kernel (RMSNorm -> QKV + bias -> bf16 -> mRoPE -> q rows / K row / V^T column at state.pos)
+    against a torch restatement of the reference's rounding points (modeling_qwen2_5_vl.py:126-140, 643-685), and — for M <= 8 —
+    against the v_dot2 kernel (same rounding points, different fp32 summation order)."""
+    from test_ops_gpu import rb
+    from vlm_fo1_amd import lib as L, ops
+    c = _qkv_case(ops, M)
+    q1, k1, v1 = _run_qkv(ops, c)
+    H, KV, HD = c["H"], c["KV"], c["HD"]
+    xf = c["x"].float().cpu()
+    xn = rb(rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)) * c["nw"].float().cpu())
+    qkv = rb(xn @ c["w"].float().cpu().t() + c["b"].float().cpu())
+    st = c["state"].cpu()
+    cos, sin = c["cos"].float().cpu(), c["sin"].float().cpu()
+    scale = qkv.abs().max().item()
+    for m in range(M):
+        pos, tr = int(st[m, 0]), int(st[m, 1])
+        heads = qkv[m, :(H + KV) * HD].view(H + KV, HD)
+        a, b = heads[:, :64], heads[:, 64:]
+        ra = rb(a * cos[tr, :64]) + rb(-b * sin[tr, :64])
+        rbb = rb(b * cos[tr, 64:]) + rb(a * sin[tr, 64:])
+        rot = rb(torch.cat([ra, rbb], -1))
+        assert (q1[m].view(H, HD) - rot[:H]).abs().max().item() <= 2e-2 * scale, f"q rows, sequence {m}"
+        assert (k1[:, pos] - rot[H:]).abs().max().item() <= 2e-2 * scale, f"K row, sequence {m}"
+        assert (v1[:, pos].view(KV, HD) - qkv[m, (H + KV) * HD:].view(KV, HD)).abs().max().item() <= 2e-2 * scale, f"V^T column, sequence {m}"
+    written = torch.zeros(c["rows"], dtype=torch.bool)
+    written[st[:M, 0].long()] = True
+    assert k1[:, ~written].abs().max().item() == 0 and v1[:, ~written].abs().max().item() == 0, "cache rows of other positions touched"
+    if M <= 8:
+        L.check(L.load().fo1_gemv_batch_set_impl(0), "set_impl")
+        try:
+            q0, k0, v0 = _run_qkv(ops, c)
+        finally:
+            L.load().fo1_gemv_batch_set_impl(1)
+        for a, b, what in ((q1, q0, "q"), (k1, k0, "K"), (v1, v0, "V^T")):
+            assert (a - b).abs().max().item() <= 1e-2 * scale, what
+            assert (a == b).float().mean().item() >= 0.97, f"{what}: MFMA and v_dot2 results should agree almost everywhere"
+
+
+def test_attention_decode_workgroup_kernel_matches_split_kernel_and_reference():
+    """Decode attention, one workgroup per (KV head, sequence) (impl 1: tiles round-robin over 8 waves, merged in LDS; 1024-key
+    splits + combine beyond 2048 rows) against the 64-key split-KV kernel (impl 0) and against fp32 softmax(q k^T / sqrt(d)) v,
+    ragged batch, slot starts != 0."""
+    from vlm_fo1_amd import lib as L, ops
+    BF = torch.bfloat16
+    H, KV, HD = 16, 2, 128
+    g = torch.Generator().manual_seed(11)
+    for slot, lens in ((1024, [1, 63, 64, 65, 651, 1024]), (4096, [700, 2049, 4096]), (2048, [1999] * 16)):
+        B = len(lens)
+        rows = B * slot
+        kc = (torch.randn(KV, rows, HD, generator=g)).to(BF).cuda()
+        vt = (torch.randn(KV * HD, rows, generator=g)).to(BF).cuda()
+        q = (torch.randn(B, H * HD, generator=g)).to(BF).cuda()
+        state = torch.zeros(B, 8, dtype=torch.int32)
+        for b, n in enumerate(lens):
+            state[b, 2] = b * slot
+            state[b, 0] = b * slot + n - 1
+        state = state.cuda()
+        scale = HD ** -0.5
+        out = {}
+        for impl in (1, 0):
+            L.check(L.load().fo1_attention_decode_set_impl(impl), "set_impl")
+            try:
+                out[impl] = ops.attention_decode_batch(q, kc, vt, state, slot, H, KV, HD, scale).float().cpu()
+            finally:
+                L.load().fo1_attention_decode_set_impl(1)
+        kf, vf, qf = kc.float().cpu(), vt.float().cpu(), q.float().cpu()
+        for b, n in enumerate(lens):
+            for h in range(H):
+                kv = h // (H // KV)
+                keys = kf[kv, b * slot:b * slot + n]                        # [n, HD]
+                vals = vf[kv * HD:(kv + 1) * HD, b * slot:b * slot + n]     # [HD, n]
+                p = torch.softmax(keys @ qf[b, h * HD:(h + 1) * HD] * scale, 0)
+                ref = vals @ p
+                for impl in (1, 0):
+                    err = (out[impl][b, h * HD:(h + 1) * HD] - ref).abs().max().item()
+                    assert err <= 2e-2, f"impl {impl} slot {slot} seq {b} (n={n}) head {h}: {err:.4g}"
+        assert (out[1] - out[0]).abs().max().item() <= 2e-2
 
 
 def test_gemv_batch_rows_independent_of_batch():
@@ -109,13 +232,17 @@ def test_gemv_batch_rows_independent_of_batch():
     BF = torch.bfloat16
     torch.manual_seed(9)
     for (N, K) in [(2048, 2048), (2048, 11008), (22016 // 4, 2048)]:
-        x = (torch.randn(8, K) * 0.5).to(BF).cuda()
+        x16 = (torch.randn(16, K) * 0.5).to(BF).cuda()
+        x = x16[:8].contiguous()
         w = (torch.randn(N, K) * 0.05).to(BF).cuda()
         full = ops.gemv_batch(x, w)
         for m in (0, 3, 7):
             assert torch.equal(ops.gemv_batch(x[m:m + 1].contiguous(), w)[0], full[m]), (N, K, m)
         assert torch.equal(ops.gemv_batch(x[:3].contiguous(), w), full[:3])
         assert torch.equal(ops.gemv_batch(x[:4].contiguous(), w), full[:4])
+        full16 = ops.gemv_batch(x16, w)                      # 16 sequences (MFMA kernel): 16 staged rows, same sums
+        assert torch.equal(full16[:8], full), (N, K, "M=16 vs M=8")
+        assert torch.equal(ops.gemv_batch(x16[11:12].contiguous(), w)[0], full16[11]), (N, K, "M=1 vs row 11 of 16")
         L.check(L.load().fo1_gemv_batch_set_rows_per_lane(1), "set_rows_per_lane")
         try:
             assert torch.equal(ops.gemv_batch(x, w), full)
@@ -123,11 +250,14 @@ def test_gemv_batch_rows_independent_of_batch():
             L.load().fo1_gemv_batch_set_rows_per_lane(0)
 
 
-def _gemv_batch_cases(gemm_ref, rb, ops):
+def _gemv_batch_cases(gemm_ref, rb, ops, m16=False):
     BF = torch.bfloat16
     torch.manual_seed(5)
-    for (M, N, K, hb, hr) in [(1, 2048, 2048, False, True), (3, 2560, 2048, True, False), (8, 2048, 11008, False, True), (5, 1000, 264, True, True),
-                              (8, 151936 // 8, 2048, False, False)]:
+    shapes = [(1, 2048, 2048, False, True), (3, 2560, 2048, True, False), (8, 2048, 11008, False, True), (5, 1000, 264, True, True),
+              (8, 151936 // 8, 2048, False, False)]
+    if m16:
+        shapes += [(16, 2048, 11008, True, True), (13, 151936 // 8, 2048, False, False), (16, 1000, 264, True, True)]
+    for (M, N, K, hb, hr) in shapes:
         x = (torch.randn(M, K) * 0.5).to(BF).cuda()
         w = (torch.randn(N, K) * 0.05).to(BF).cuda()
         bias = (torch.randn(N) * 0.1).to(BF).cuda() if hb else None
@@ -136,7 +266,7 @@ def _gemv_batch_cases(gemm_ref, rb, ops):
         ref = gemm_ref(x, w, bias, res, 0)
         err = (got.float().cpu() - ref).abs().max().item()
         assert err <= 2e-2 * ref.abs().max().item() + 1e-3, f"gemv_batch {M}x{N}x{K}: max err {err:.4g}"
-    M, K, Fh = 8, 2048, 11008
+    M, K, Fh = (16 if m16 else 8), 2048, 11008
     x = (torch.randn(M, K)).to(BF).cuda()
     nw = (1 + 0.1 * torch.randn(K)).to(BF).cuda()
     wg, wu = (torch.randn(Fh, K) * 0.05).to(BF), (torch.randn(Fh, K) * 0.05).to(BF)

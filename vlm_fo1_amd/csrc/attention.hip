@@ -308,6 +308,190 @@ __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __
     out[(long long)head * HD + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
 }
 
+// ---- decode attention, one workgroup per (KV head, sequence[, KV split]) ---------------------------------------------------
+// The query heads that share a KV head ride as the MFMA columns (GQA: 8 of 16 columns at 16q/2kv).  The NW waves of a workgroup
+// take the 64-key tiles of the range round-robin; every tile goes straight from the cache to MFMA fragments in registers (K rows
+// as the A operand of S^T = K Q^T, V^T pieces as the A operand of O^T = V^T P^T — the same fragment algebra as attn_fwd_kernel,
+// minus the LDS staging: nothing is shared between waves), all 48 loads of a tile in flight at once.  The waves' (O, m, l) meet
+// in LDS and are merged in wave order; with one split the normalised bf16 rows are written directly (ONE launch per layer
+// instead of split + combine), with several the merged partial of each split goes to `part` for attn_decode_combine_kernel.
+struct AttnDecParams {
+    const uint16_t* Q; long long q_seq_stride;       // q rows [B][n_q_heads * 128]
+    const uint16_t* K; long long k_tok, k_head;
+    const uint16_t* VT; long long vt_row;
+    uint16_t* O; long long o_seq_stride;
+    float* part; long long part_seq_stride;          // [split][kv head][16][HD + 2] per sequence
+    const int* seq_state;                            // [B][8] (decode.hip) or null
+    const int* dyn_kv_len;                           // single-sequence form: keys [0, *dyn_kv_len)
+    int n_kv_heads, group, split_keys, n_splits;
+    float scale;
+};
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_decode_wg_kernel(const AttnDecParams p) {
+    constexpr int HD = 128, NC = 4, NDB = 8, PITCH = HD + 4;
+    __shared__ __attribute__((aligned(16))) float sp[NW * 16 * PITCH];
+    const int split = blockIdx.x, kvh = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 15, g = lane >> 4;
+    int kv0 = 0, kv_len;
+    if (p.seq_state) {
+        const int* st = p.seq_state + b * 8;
+        kv0 = st[2];
+        kv_len = st[0] + 1;
+    } else {
+        kv_len = *p.dyn_kv_len;
+    }
+    const int lo = kv0 + split * p.split_keys;
+    const int hi = min(kv_len, lo + p.split_keys);
+    if (lo >= hi) return;                            // (several splits only) the combine pass skips empty splits
+
+    // Q fragments (B operand): lane (query slot ql, k-group g) holds d = c*32 + g*8 .. +8; slots >= group are zero columns
+    bf16x8 qf[NC];
+    {
+        const uint16_t* qp = p.Q + (long long)b * p.q_seq_stride + (long long)(kvh * p.group + (ql < p.group ? ql : 0)) * HD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            uint4 v = *reinterpret_cast<const uint4*>(qp + c * 32 + g * 8);
+            if (ql >= p.group) v = uint4{0, 0, 0, 0};
+            qf[c] = *reinterpret_cast<bf16x8*>(&v);
+        }
+    }
+    f32x4 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const uint16_t* Kb = p.K + (long long)kvh * p.k_head;
+    const uint16_t* VTb = p.VT + (long long)kvh * HD * p.vt_row;
+
+    for (int k0 = lo + wave * 64; k0 < hi; k0 += NW * 64) {
+        // ---- every load of the tile first: K rows (fragment shape: 16 keys x 64 B per instruction), V^T 8-byte pieces ----
+        uint4 kf[4][NC];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const int key = k0 + kt * 16 + ql;
+            const uint16_t* kp = Kb + (long long)(key < hi ? key : hi - 1) * p.k_tok + g * 8;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) kf[kt][c] = *reinterpret_cast<const uint4*>(kp + c * 32);
+        }
+        uint2 vlo[NDB][2], vhi[NDB][2];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const uint16_t* vr = VTb + (long long)(db * 16 + ql) * p.vt_row;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                // a-operand k-slots: j<4 -> key (2*half)*16 + g*4 + j ; j>=4 -> key (2*half+1)*16 + g*4 + (j-4)
+                const int ka = k0 + half * 32 + g * 4, kb2 = ka + 16;
+                vlo[db][half] = *reinterpret_cast<const uint2*>(vr + (ka < hi ? ka : lo));
+                vhi[db][half] = *reinterpret_cast<const uint2*>(vr + (kb2 < hi ? kb2 : lo));
+            }
+        }
+        // ---- S^T = K Q^T ----
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&kf[kt][c]), qf[c], s[kt], 0, 0, 0);
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + kt * 16 + g * 4 + r;
+                const float v = key < hi ? s[kt][r] * p.scale : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run - m_new);
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t w[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = half * 2 + t;
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = (s[kt][r] == -INFINITY) ? 0.f : __expf(s[kt][r] - m_new);
+                    e[r] = bf16_to_f32(f32_to_bf16(e[r]));      // sum what is multiplied into V: the bf16-rounded probabilities
+                    psum += e[r];
+                }
+                w[t * 2 + 0] = pack_bf16x2(e[0], e[1]);
+                w[t * 2 + 1] = pack_bf16x2(e[2], e[3]);
+            }
+            uint4 pk = uint4{w[0], w[1], w[2], w[3]};
+            pf[half] = *reinterpret_cast<bf16x8*>(&pk);
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // ---- O^T = alpha * O^T + V^T P^T (keys past the range carry p = 0 against finite cache contents) ----
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint4 vk = uint4{vlo[db][half].x, vlo[db][half].y, vhi[db][half].x, vhi[db][half].y};
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vk), pf[half], o[db], 0, 0, 0);
+            }
+        }
+    }
+    // ---- the waves' (O, m, l) of query slot ql meet in LDS; o[db][r] = O[slot ql][d = db*16 + g*4 + r] ----
+    {
+        float* pr = sp + (wave * 16 + ql) * PITCH;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) *reinterpret_cast<float4*>(pr + db * 16 + g * 4) = float4{o[db][0], o[db][1], o[db][2], o[db][3]};
+        if (g == 0) { pr[HD] = m_run; pr[HD + 1] = l_run; }
+    }
+    __syncthreads();
+    for (int t = tid; t < p.group * HD; t += NW * 64) {
+        const int slot = t >> 7, d = t & (HD - 1);
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) M = fmaxf(M, sp[(w * 16 + slot) * PITCH + HD]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float mw = sp[(w * 16 + slot) * PITCH + HD];
+            const float wgt = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            num += wgt * sp[(w * 16 + slot) * PITCH + d];
+            den += wgt * sp[(w * 16 + slot) * PITCH + HD + 1];
+        }
+        if (p.n_splits == 1) {
+            p.O[(long long)b * p.o_seq_stride + (long long)(kvh * p.group + slot) * HD + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
+        } else {
+            float* pr = p.part + (long long)b * p.part_seq_stride + (((long long)split * p.n_kv_heads + kvh) * 16 + slot) * (HD + 2);
+            pr[d] = num;
+            if (d == 0) { pr[HD] = M; pr[HD + 1] = den; }
+        }
+    }
+}
+
+int g_attn_decode_impl = 1;   // 1 = attn_decode_wg_kernel, 0 = 64-key split-KV partials + combine (the round-1 form)
+
+// One launch for slots up to 2048 rows (32 tiles over 8 waves); longer slots: 1024-key splits + the fixed-order combine.
+static int launch_attn_decode_wg(AttnDecParams& p, int max_kv_len, int batch, int n_q_heads, hipStream_t st) {
+    constexpr int NW = 8;
+    if (max_kv_len <= 2048) { p.n_splits = 1; p.split_keys = cdiv(max_kv_len, 64) * 64; }
+    else { p.split_keys = 1024; p.n_splits = cdiv(max_kv_len, 1024); }
+    p.part_seq_stride = (long long)p.n_splits * p.n_kv_heads * 16 * (128 + 2);
+    FO1_LAUNCH("attn_decode_wg", (double)batch * max_kv_len * p.n_kv_heads * 128 * 4.0, (attn_decode_wg_kernel<NW>),
+               dim3(p.n_splits, p.n_kv_heads, batch), dim3(NW * 64), 0, st, p);
+    if (p.n_splits > 1)
+        FO1_LAUNCH("attn_decode_combine", (double)batch * n_q_heads * 128 * 8.0, attn_decode_combine_kernel<128>, dim3(n_q_heads, batch), dim3(128), 0,
+                   st, (const float*)p.part, p.dyn_kv_len, p.split_keys, p.n_kv_heads, p.group, p.O, p.seq_state, p.part_seq_stride, p.o_seq_stride);
+    return FO1_OK;
+}
+
 template <int HD>
 static int launch_attn(const AttnParams& p, int q_block, hipStream_t st, double flops) {
     if (q_block == 16)
@@ -376,8 +560,18 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
     if (workspace_bytes < fo1_attention_decode_workspace_bytes(max_kv_len, n_kv_heads, head_dim))
         return set_err(FO1_ERR_WORKSPACE, "attention_decode: workspace too small");
     static const AttnItem* one_item = nullptr;
-    AttnParams p;
     const int group = n_q_heads / n_kv_heads;
+    if (g_attn_decode_impl == 1) {
+        AttnDecParams d;
+        d.Q = (const uint16_t*)q; d.q_seq_stride = 0;
+        d.K = (const uint16_t*)kcache; d.k_tok = k_tok_stride; d.k_head = k_head_stride;
+        d.VT = (const uint16_t*)vtcache; d.vt_row = vt_row_stride;
+        d.O = (uint16_t*)out; d.o_seq_stride = 0;
+        d.part = (float*)workspace; d.seq_state = nullptr; d.dyn_kv_len = (const int*)dyn_kv_len;
+        d.n_kv_heads = n_kv_heads; d.group = group; d.scale = scale;
+        return launch_attn_decode_wg(d, max_kv_len, 1, n_q_heads, (hipStream_t)stream);
+    }
+    AttnParams p;
     p.Q = (const uint16_t*)q; p.q_tok = head_dim; p.q_head = (long long)group * head_dim;   // "queries" walk the heads of a group
     p.K = (const uint16_t*)kcache; p.k_tok = k_tok_stride; p.k_head = k_head_stride;
     p.VT = (const uint16_t*)vtcache; p.vt_row = vt_row_stride;
@@ -398,6 +592,14 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
     return FO1_OK;
 }
 
+// A/B hook: 1 (default) = one workgroup per (KV head, sequence) with the waves' partials merged in LDS; 0 = 64-key split-KV
+// partials + combine kernel.
+int fo1_attention_decode_set_impl(int impl) {
+    if (impl != 0 && impl != 1) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_impl: %d", impl);
+    fo1::g_attn_decode_impl = impl;
+    return FO1_OK;
+}
+
 // Batched decode attention: B sequences, one new token each (q rows [B, n_q_heads*head_dim]); sequence b attends the cache rows
 // [state[b][2], state[b][0]] (its slot start .. the row just written).  grid = (max chunks per slot, KV heads, B).
 size_t fo1_attention_decode_batch_workspace_bytes(int max_kv_len, int n_kv_heads, int head_dim, int batch) {
@@ -415,8 +617,18 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     FO1_CHECK_ARG(vt_row_stride % 4 == 0 && k_tok_stride % 8 == 0 && k_head_stride % 8 == 0 && q_seq_stride % 8 == 0, "attention_decode_batch: bad strides");
     if (workspace_bytes < fo1_attention_decode_batch_workspace_bytes(max_kv_len, n_kv_heads, head_dim, batch))
         return set_err(FO1_ERR_WORKSPACE, "attention_decode_batch: workspace too small");
-    AttnParams p;
     const int group = n_q_heads / n_kv_heads;
+    if (g_attn_decode_impl == 1) {
+        AttnDecParams d;
+        d.Q = (const uint16_t*)q; d.q_seq_stride = q_seq_stride;
+        d.K = (const uint16_t*)kcache; d.k_tok = k_tok_stride; d.k_head = k_head_stride;
+        d.VT = (const uint16_t*)vtcache; d.vt_row = vt_row_stride;
+        d.O = (uint16_t*)out; d.o_seq_stride = out_seq_stride;
+        d.part = (float*)workspace; d.seq_state = (const int*)state; d.dyn_kv_len = nullptr;
+        d.n_kv_heads = n_kv_heads; d.group = group; d.scale = scale;
+        return launch_attn_decode_wg(d, max_kv_len, batch, n_q_heads, (hipStream_t)stream);
+    }
+    AttnParams p;
     p.Q = (const uint16_t*)q; p.q_tok = head_dim; p.q_head = (long long)group * head_dim;
     p.K = (const uint16_t*)kcache; p.k_tok = k_tok_stride; p.k_head = k_head_stride;
     p.VT = (const uint16_t*)vtcache; p.vt_row = vt_row_stride;

@@ -15,7 +15,7 @@
 //   attention              split-KV partials (attention.hip, PARTIAL mode with per-sequence ranges) + fixed-order combine
 //   argmax_accept          two-stage argmax per row, then ON-DEVICE bookkeeping: record the id, stop check, advance state,
 //                          write the next step's embedding-gather plan — the host never reads a token inside the loop
-#include "common.h"
+#include "decode_common.h"
 
 namespace fo1 {
 
@@ -27,25 +27,6 @@ __device__ __forceinline__ uint4 load_nt16(const uint16_t* p) {
     const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
     return uint4{v.x, v.y, v.z, v.w};
 }
-
-struct GemvBParams {
-    const uint16_t* X;       // [M, ldx]
-    const uint16_t* W;       // [N, ldw]
-    const uint16_t* bias;    // [N] or null
-    const uint16_t* res;     // [M, ldr] or null (plain mode)
-    uint16_t* C;             // [M, ldc]: plain out | SwiGLU out | rotated q rows (QKV mode)
-    int M, N, K, ldx, ldw, ldc, ldr;
-    const uint16_t* norm_w;  // optional fused RMSNorm on x
-    float norm_eps;
-    int kp_chunks;           // 16-B chunks of K staged in LDS at a time
-    int canon_chunks;        // canonical K segment (chunks): the K split over waves is per segment, the same for every M
-    // QKV mode
-    int n_q, n_kv;           // heads (head_dim 128)
-    const uint16_t* cos_t; const uint16_t* sin_t;   // [rows, 128] bf16 tables
-    const int* state;        // [M][8]
-    uint16_t* kcache; long long kc_head_stride;      // [n_kv][rows][128]
-    uint16_t* vtcache; long long vt_row_stride;      // [n_kv*128][rows]
-};
 
 __device__ __forceinline__ float gb_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 __device__ __forceinline__ float gb_wave_sum(float v) {
@@ -60,8 +41,6 @@ __device__ __forceinline__ float dot8b(const uint4& w, const uint4& x, float acc
     acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const bf16x2_t*>(&w.w), *reinterpret_cast<const bf16x2_t*>(&x.w), acc, false);
     return acc;
 }
-
-enum { GB_PLAIN = 0, GB_SWIGLU = 1, GB_QKV = 2 };
 
 // One unit = 8 weight rows:  plain: 8 consecutive output features;  SwiGLU: 4 gate rows + their up partners 16 rows further
 // (16-row interleaved weights);  QKV: q/k heads -> 4 dims d and their rotary partners d + 64, v head -> 8 consecutive dims.
@@ -413,7 +392,14 @@ static int dispatch_gemv_b(GemvBParams& p, int mode, hipStream_t st) {
     return ks ? launch_gemv_b<MM, GB_PLAIN, true, RB>(p, name, n_units, st) : launch_gemv_b<MM, GB_PLAIN, false, RA>(p, name, n_units, st);
 }
 
+static int g_gemv_impl = 1;  // 1 = MFMA skinny GEMM (decode_mfma.hip, M <= 16), 0 = the v_dot2 kernel above (M <= 8)
+
 static int gemv_b_any(GemvBParams& p, int mode, hipStream_t st) {
+    // the MFMA kernel moves epilogue operands four features at a time
+    const bool quads = p.N % 4 == 0 && (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 7) == 0)) && ((uintptr_t)p.bias & 7) == 0 &&
+                       ((uintptr_t)p.cos_t & 7) == 0 && ((uintptr_t)p.sin_t & 7) == 0 && ((uintptr_t)p.kcache & 7) == 0;
+    if (g_gemv_impl == 1 && quads) return gemv_mfma_any(p, mode, st);
+    if (p.M > 8) return set_err(FO1_ERR_ARG, "gemv_batch: the v_dot2 kernel handles M <= 8 (M=%d)", p.M);
     if (p.M == 1) return dispatch_gemv_b<1>(p, mode, st);
     if (p.M == 2) return dispatch_gemv_b<2>(p, mode, st);
     if (p.M <= 4) return dispatch_gemv_b<4>(p, mode, st);
@@ -551,7 +537,14 @@ int fo1_gemv_batch_set_rows_per_lane(int rpl) {
 }
 
 
-// Batched decode projection: C[M<=8, N] = epilogue(rmsnorm?(x) @ W^T), weights streamed once for all M rows.
+// A/B hook: 1 (default) = MFMA skinny GEMM (decode_mfma.hip, M <= 16); 0 = the v_dot2 streaming kernel (M <= 8).
+int fo1_gemv_batch_set_impl(int impl) {
+    if (impl != 0 && impl != 1) return fo1::set_err(FO1_ERR_ARG, "gemv_batch_set_impl: %d", impl);
+    fo1::g_gemv_impl = impl;
+    return FO1_OK;
+}
+
+// Batched decode projection: C[M<=16, N] = epilogue(rmsnorm?(x) @ W^T), weights streamed once for all M rows.
 // mode 0: bias -> bf16 -> + residual;  mode 1: interleaved SwiGLU (C has N/2 columns);  mode 2: fused QKV:
 //   bias -> bf16 -> mRoPE (table row state[m][1]) -> rotated q rows to C[m, 0 : n_q*128), rotated K row to kcache[kv][state[m][0]],
 //   V to the V^T cache column state[m][0].
@@ -561,7 +554,7 @@ int fo1_gemv_batch_bf16(const void* x, int ldx, const void* W, int ldw, const vo
                         void* vtcache, long long vt_row_stride, void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(x && W && (C || mode == 2), "gemv_batch: NULL operand");
-    FO1_CHECK_ARG(M >= 1 && M <= 8 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "gemv_batch: bad shape M=%d N=%d K=%d", M, N, K);
+    FO1_CHECK_ARG(M >= 1 && M <= 16 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "gemv_batch: bad shape M=%d N=%d K=%d", M, N, K);
     FO1_CHECK_ARG(mode >= 0 && mode <= 2, "gemv_batch: mode %d", mode);
     FO1_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)norm_weight & 15) == 0, "gemv_batch: misaligned operand");
     if (mode == 1) FO1_CHECK_ARG(N % 32 == 0 && residual == nullptr, "gemv_batch: SwiGLU needs N %% 32 == 0 and no residual");

@@ -1,0 +1,400 @@
+// decode_mfma.hip — weight-streaming skinny GEMM for the decode step on gfx950: C[M <= 16, N] = epilogue(rmsnorm?(x) W^T) with
+// the B sequences of a decode batch riding as the 16 columns of v_mfma_f32_16x16x32_bf16 (reference: the 1-token
+// fast path of omchat_qwen2_5_vl.py:143-155 — q/k/v, o, gate/up, down, lm_head of modeling_qwen2_5_vl.py:731-734,633-635,1876).
+//
+// HBM-bound (every weight byte once, 6.2 GB per token): the kernel is a streaming engine, the matrix cores only keep the
+// arithmetic off the VALU so that 8 or 16 sequences cost what one costs (the v_dot2 kernel of decode.hip spends 32 dot2 + 8
+// LDS reads per 16 weight bytes at M = 8 and runs at 2.5 TB/s; here it is one MFMA per KB of weights).
+//
+//   * a workgroup (8 waves) owns one UNIT = NB blocks of 16 weight rows and walks K in steps of 64 elements; step s belongs
+//     to wave s mod 8 (the K split is fixed by the shape alone, so a sequence's fp32 sum order does not depend on M: it
+//     decodes to the same numbers alone and in any batch);
+//   * weight loads keep the proven streaming shape — straight to VGPRs, non-temporal, one instruction = 8 rows x 128
+//     contiguous bytes, 4 k-steps (up to 8 KB) in flight per wave, issued one K piece ahead and across unit boundaries —
+//     and are turned into MFMA A fragments through a wave-private, XOR-swizzled 2 KB LDS scratch (conflict-free b128 both ways);
+//   * x (M rows) lives in LDS with a (= 32 mod 256)-byte row pitch (conflict-free B-fragment reads), staged 2048 elements of
+//     K at a time; Qwen2RMSNorm (modeling_qwen2_5_vl.py:126-140) is applied to the staged rows when asked;
+//   * the 8 waves' partial accumulators meet in LDS (fixed order), wave 0 runs the epilogue: bias -> bf16 -> (+ residual) |
+//     interleaved SwiGLU | QKV: bias -> bf16 -> mRoPE -> rotated q rows out, K row and V^T column appended to the caches.
+//     Everything the epilogue reads from global memory (bias, residual, rope tables) is requested BEFORE the K loop.
+#include "decode_common.h"
+
+namespace fo1 {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 gm_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float gm_f32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 gm_bf16x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int gm_u32x4;
+
+constexpr int GM_NW = 8;                           // waves per workgroup
+constexpr int GM_NT = GM_NW * 64;
+constexpr int GM_D = 4;                            // k-steps in flight per wave (register stages)
+constexpr int GM_PIECE = GM_NW * GM_D;             // k-steps of x staged at a time (32 x 64 = 2048 elements)
+constexpr int GM_XPITCH = GM_PIECE * 128 + 32;     // bytes per staged x row
+
+__device__ __forceinline__ uint4 gm_load_nt16(const uint16_t* p) {
+    const gm_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gm_u32x4*>(p));
+    return uint4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ float gm_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+__device__ __forceinline__ float gm_dot8(const uint4& a, const uint4& b, float acc) {
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const gm_bf16x2*>(&a.x), *reinterpret_cast<const gm_bf16x2*>(&b.x), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const gm_bf16x2*>(&a.y), *reinterpret_cast<const gm_bf16x2*>(&b.y), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const gm_bf16x2*>(&a.z), *reinterpret_cast<const gm_bf16x2*>(&b.z), acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(*reinterpret_cast<const gm_bf16x2*>(&a.w), *reinterpret_cast<const gm_bf16x2*>(&b.w), acc, false);
+    return acc;
+}
+__device__ __forceinline__ void gm_lds_fence() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// MM: staged x rows (8 or 16).  NB: 16-row weight blocks per unit (SwiGLU / QKV pair two blocks whose rows meet in one lane).
+template <int MM, int MODE, int NB>
+__global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, const int n_units, const int nsteps) {
+    static_assert(MODE == GB_PLAIN || NB == 2, "paired modes use two row blocks");
+    extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
+    unsigned char* const sx = gm_smem;                                   // [MM][GM_XPITCH]
+    unsigned char* const sw = gm_smem + MM * GM_XPITCH;                  // [GM_NW][NB][2048]  weight scratch (wave-private)
+    float* const sred = reinterpret_cast<float*>(sw + GM_NW * NB * 2048);   // [2][GM_NW][NB][64][4]
+    float* const srstd = sred + 2 * GM_NW * NB * 256;                    // [16]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int kch = p.K >> 3;                                            // 16-byte chunks per row
+    const int n_pieces = (nsteps + GM_PIECE - 1) / GM_PIECE;
+    const int lrow = lane >> 3, lch = lane & 7;                          // load shape: row of an 8-row group, chunk of the 128-byte k-step
+    const int fi = lane & 15, fg = lane >> 4;                            // fragment shape: MFMA row / column, k group
+    unsigned char* const swv = sw + wave * (NB * 2048);
+    const int xrow = MM == 16 ? fi : (fi & 7);
+    const int n_rope = MODE == GB_QKV ? (p.n_q + p.n_kv) * 4 : 0;
+
+    auto unit_rows = [&](int u, int (&rb)[NB]) {
+        if (MODE == GB_SWIGLU) {
+            rb[0] = u * 32;
+            rb[NB - 1] = u * 32 + 16;
+        } else if (MODE == GB_QKV) {
+            if (u < n_rope) { rb[0] = (u >> 2) * 128 + (u & 3) * 16; rb[NB - 1] = rb[0] + 64; }
+            else { rb[0] = (p.n_q + p.n_kv) * 128 + (u - n_rope) * 32; rb[NB - 1] = rb[0] + 16; }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) rb[b] = (u * NB + b) * 16;
+        }
+    };
+    auto unit_ptrs = [&](int u, const uint16_t* (&wp)[NB][2]) {
+        int rb[NB];
+        unit_rows(u < n_units ? u : n_units - 1, rb);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                int row = rb[b] + q * 8 + lrow;
+                row = row < p.N ? row : p.N - 1;            // clamp: the surplus rows' results are discarded
+                wp[b][q] = p.W + (long long)row * p.ldw;
+            }
+    };
+    // all four loads of one k-step of this wave; addresses are always valid (chunks past K are clamped: their x is zero in LDS)
+    auto issue = [&](const uint16_t* const (&wp)[NB][2], int s, uint4 (&st)[NB][2]) {
+        int c = s * 8 + lch;
+        c = c < kch ? c : kch - 1;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) st[b][q] = gm_load_nt16(wp[b][q] + (long long)c * 8);
+    };
+    auto consume = [&](const uint4 (&st)[NB][2], int xs, gm_f32x4 (&acc)[NB]) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int rl = q * 8 + lrow;
+                *reinterpret_cast<uint4*>(swv + b * 2048 + rl * 128 + ((lch ^ ((rl >> 1) & 7)) << 4)) = st[b][q];
+            }
+        gm_lds_fence();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 xv = *reinterpret_cast<const uint4*>(sx + xrow * GM_XPITCH + xs * 128 + h * 64 + fg * 16);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                uint4 wv = *reinterpret_cast<const uint4*>(swv + b * 2048 + fi * 128 + (((h * 4 + fg) ^ ((fi >> 1) & 7)) << 4));
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xv), acc[b], 0, 0, 0);
+            }
+        }
+        gm_lds_fence();      // the scratch is rewritten by the next k-step
+    };
+    // x rows of K piece `piece` -> LDS (zero beyond M rows / beyond K), then the fused RMSNorm (single-piece K only: host-checked)
+    auto stage_x = [&](int piece, const uint4& nw) {
+        const int c = tid & 255, gc = piece * 256 + c;
+        const int gcc = gc < kch ? gc : kch - 1;
+        uint4 t[MM / 2];
+#pragma unroll
+        for (int i = 0; i < MM / 2; ++i) {
+            const int m = (tid >> 8) + 2 * i;
+            t[i] = *reinterpret_cast<const uint4*>(p.X + (long long)(m < p.M ? m : p.M - 1) * p.ldx + gcc * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < MM / 2; ++i) {
+            const int m = (tid >> 8) + 2 * i;
+            const bool ok = m < p.M && gc < kch;
+            *reinterpret_cast<uint4*>(sx + m * GM_XPITCH + c * 16) = ok ? t[i] : uint4{0, 0, 0, 0};
+        }
+        __syncthreads();
+        if (p.norm_w) {
+            for (int m = wave; m < MM; m += GM_NW) {
+                float ss = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(sx + m * GM_XPITCH + (lane + 64 * i) * 16);
+                    ss = gm_dot8(v, v, ss);
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+                if (lane == 0) srstd[m] = rsqrtf(ss / (float)p.K + p.norm_eps);
+            }
+            __syncthreads();
+            // fp32 variance, bf16(x * rstd), * weight -> bf16 (the reference's rounding points)
+#pragma unroll
+            for (int i = 0; i < MM / 2; ++i) {
+                const int m = (tid >> 8) + 2 * i;
+                const float rstd = srstd[m];
+                uint4* px = reinterpret_cast<uint4*>(sx + m * GM_XPITCH + c * 16);
+                const uint4 v = *px;
+                uint4 o;
+                o.x = pack_bf16x2(bf16_lo(nw.x) * gm_round(bf16_lo(v.x) * rstd), bf16_hi(nw.x) * gm_round(bf16_hi(v.x) * rstd));
+                o.y = pack_bf16x2(bf16_lo(nw.y) * gm_round(bf16_lo(v.y) * rstd), bf16_hi(nw.y) * gm_round(bf16_hi(v.y) * rstd));
+                o.z = pack_bf16x2(bf16_lo(nw.z) * gm_round(bf16_lo(v.z) * rstd), bf16_hi(nw.z) * gm_round(bf16_hi(v.z) * rstd));
+                o.w = pack_bf16x2(bf16_lo(nw.w) * gm_round(bf16_lo(v.w) * rstd), bf16_hi(nw.w) * gm_round(bf16_hi(v.w) * rstd));
+                *px = o;
+            }
+            __syncthreads();
+        }
+    };
+
+    // ---- prologue: the weight stream does not depend on x — the first unit's first piece is requested before anything else ----
+    uint4 st[GM_D][NB][2];
+    const uint16_t* wcur[NB][2];
+    unit_ptrs(blockIdx.x, wcur);
+    if ((int)blockIdx.x < n_units) {
+#pragma unroll
+        for (int d = 0; d < GM_D; ++d)
+            if (wave + GM_NW * d < nsteps) issue(wcur, wave + GM_NW * d, st[d]);
+    }
+    uint4 nw = uint4{0, 0, 0, 0};
+    if (p.norm_w) {
+        const int c = tid & 255;
+        nw = *reinterpret_cast<const uint4*>(p.norm_w + (c < kch ? c : kch - 1) * 8);
+    }
+    // decode state of this lane's sequence (QKV epilogue): cache row and rope-table row
+    const int n_seq = fi;
+    const bool seq_ok = n_seq < p.M;
+    int pos = 0;
+    long long trow = 0;
+    if (MODE == GB_QKV) {
+        const int* stt = p.state + (seq_ok ? n_seq : 0) * 8;
+        pos = stt[0];
+        trow = stt[1];
+    }
+    if (n_pieces == 1) stage_x(0, nw);
+
+    int it = 0;
+    for (int u = blockIdx.x; u < n_units; u += gridDim.x, ++it) {
+        const int un = u + gridDim.x;
+        const uint16_t* wnext[NB][2];
+        unit_ptrs(un, wnext);
+        int rb[NB];
+        unit_rows(u, rb);
+        // ---- epilogue operands, requested now, used after the K loop (wave 0 only; clamped addresses, always valid) ----
+        uint2 e_bias[NB], e_res[NB], e_cos[2], e_sin[2];    // 4 consecutive bf16 each (N % 4 == 0, ldr % 4 == 0: host-checked)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) e_bias[b] = e_res[b] = uint2{0, 0};
+        e_cos[0] = e_cos[1] = e_sin[0] = e_sin[1] = uint2{0, 0};
+        if (wave == 0) {
+            const int nc = seq_ok ? n_seq : 0;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                int f0 = rb[b] + fg * 4;
+                f0 = f0 + 4 <= p.N ? f0 : p.N - 4;
+                if (p.bias) e_bias[b] = *reinterpret_cast<const uint2*>(p.bias + f0);
+                if (MODE == GB_PLAIN && p.res) e_res[b] = *reinterpret_cast<const uint2*>(p.res + (long long)nc * p.ldr + f0);
+            }
+            if (MODE == GB_QKV && u < n_rope) {
+                const int d0 = (u & 3) * 16 + fg * 4;
+                e_cos[0] = *reinterpret_cast<const uint2*>(p.cos_t + trow * 128 + d0);
+                e_sin[0] = *reinterpret_cast<const uint2*>(p.sin_t + trow * 128 + d0);
+                e_cos[1] = *reinterpret_cast<const uint2*>(p.cos_t + trow * 128 + d0 + 64);
+                e_sin[1] = *reinterpret_cast<const uint2*>(p.sin_t + trow * 128 + d0 + 64);
+            }
+        }
+        gm_f32x4 acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) acc[b] = gm_f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int piece = 0; piece < n_pieces; ++piece) {
+            if (n_pieces > 1) {
+                __syncthreads();             // every wave is done with the previous piece of x
+                stage_x(piece, nw);
+            }
+            const bool last_piece = piece + 1 == n_pieces;
+#pragma unroll
+            for (int d = 0; d < GM_D; ++d) {
+                const int xs = wave + GM_NW * d;              // k-step inside the staged piece
+                const int s = piece * GM_PIECE + xs;
+                if (s < nsteps) consume(st[d], xs, acc);
+                // refill this stage one piece ahead: same unit, or the first piece of this workgroup's next unit
+                if (!last_piece) {
+                    if (s + GM_PIECE < nsteps) issue(wcur, s + GM_PIECE, st[d]);
+                } else if (un < n_units) {
+                    if (xs < nsteps) issue(wnext, xs, st[d]);
+                }
+            }
+        }
+        // ---- the 8 waves' partial sums meet in LDS; double-buffered by unit parity: one barrier per unit ----
+        float* red = sred + (it & 1) * (GM_NW * NB * 256);
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            *reinterpret_cast<float4*>(red + ((wave * NB + b) * 64 + lane) * 4) = float4{acc[b][0], acc[b][1], acc[b][2], acc[b][3]};
+        __syncthreads();
+        if (wave == 0) {
+            auto h4 = [](const uint2& q, int r) -> float { const uint32_t w = (r >> 1) ? q.y : q.x; return (r & 1) ? bf16_hi(w) : bf16_lo(w); };
+            float v[NB][4];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                float4 t[GM_NW];
+#pragma unroll
+                for (int w = 0; w < GM_NW; ++w) t[w] = *reinterpret_cast<const float4*>(red + ((w * NB + b) * 64 + lane) * 4);
+                v[b][0] = ((t[0].x + t[1].x) + (t[2].x + t[3].x)) + ((t[4].x + t[5].x) + (t[6].x + t[7].x));
+                v[b][1] = ((t[0].y + t[1].y) + (t[2].y + t[3].y)) + ((t[4].y + t[5].y) + (t[6].y + t[7].y));
+                v[b][2] = ((t[0].z + t[1].z) + (t[2].z + t[3].z)) + ((t[4].z + t[5].z) + (t[6].z + t[7].z));
+                v[b][3] = ((t[0].w + t[1].w) + (t[2].w + t[3].w)) + ((t[4].w + t[5].w) + (t[6].w + t[7].w));
+            }
+            // v[b][r] = sum_k W[rb[b] + fg*4 + r][k] x[n_seq][k]
+            if (seq_ok) {
+                if (MODE == GB_PLAIN) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const int f0 = rb[b] + fg * 4;
+                        uint16_t o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float x = v[b][r];
+                            if (p.bias) x += h4(e_bias[b], r);
+                            x = gm_round(x);
+                            if (p.res) x += h4(e_res[b], r);
+                            o[r] = f32_to_bf16(x);
+                        }
+                        uint16_t* cp = p.C + (long long)n_seq * p.ldc + f0;
+                        if (f0 < p.N) {
+                            if ((p.ldc & 3) == 0) {
+                                *reinterpret_cast<uint2*>(cp) = uint2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) cp[r] = o[r];
+                            }
+                        }
+                    }
+                } else if (MODE == GB_SWIGLU) {
+                    // rows [32u, 32u+16) = gate of features 16u.., rows [32u+16, 32u+32) = their up partners
+                    uint16_t o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float g = v[0][r], up = v[NB - 1][r];
+                        if (p.bias) { g += h4(e_bias[0], r); up += h4(e_bias[NB - 1], r); }
+                        g = gm_round(g);
+                        up = gm_round(up);
+                        o[r] = f32_to_bf16(gm_round(g / (1.0f + expf(-g))) * up);
+                    }
+                    uint16_t* cp = p.C + (long long)n_seq * p.ldc + u * 16 + fg * 4;
+                    if ((p.ldc & 3) == 0) {
+                        *reinterpret_cast<uint2*>(cp) = uint2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) cp[r] = o[r];
+                    }
+                } else {   // GB_QKV
+                    if (u < n_rope) {
+                        const int head = u >> 2, d0 = (u & 3) * 16 + fg * 4;        // d0 + r < 64, rotary partner d + 64
+                        uint16_t oa[4], ob[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float a = v[0][r], b = v[NB - 1][r];
+                            if (p.bias) { a += h4(e_bias[0], r); b += h4(e_bias[NB - 1], r); }
+                            a = gm_round(a);                                          // the bf16 q/k the unfused path stores
+                            b = gm_round(b);
+                            const float c1 = h4(e_cos[0], r), s1 = h4(e_sin[0], r), c2 = h4(e_cos[1], r), s2 = h4(e_sin[1], r);
+                            oa[r] = f32_to_bf16(gm_round(a * c1) + gm_round(-b * s1));     // rotate_half, three bf16 roundings
+                            ob[r] = f32_to_bf16(gm_round(b * c2) + gm_round(a * s2));
+                        }
+                        const uint2 pa = uint2{(uint32_t)oa[0] | ((uint32_t)oa[1] << 16), (uint32_t)oa[2] | ((uint32_t)oa[3] << 16)};
+                        const uint2 pb = uint2{(uint32_t)ob[0] | ((uint32_t)ob[1] << 16), (uint32_t)ob[2] | ((uint32_t)ob[3] << 16)};
+                        if (head < p.n_q) {
+                            uint16_t* qp = p.C + (long long)n_seq * p.ldc + head * 128 + d0;
+                            if ((p.ldc & 3) == 0) {
+                                *reinterpret_cast<uint2*>(qp) = pa;
+                                *reinterpret_cast<uint2*>(qp + 64) = pb;
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { qp[r] = oa[r]; qp[64 + r] = ob[r]; }
+                            }
+                        } else {
+                            uint16_t* kc = p.kcache + (long long)(head - p.n_q) * p.kc_head_stride + (long long)pos * 128 + d0;
+                            *reinterpret_cast<uint2*>(kc) = pa;
+                            *reinterpret_cast<uint2*>(kc + 64) = pb;
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < NB; ++b)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int vrow = (u - n_rope) * 32 + b * 16 + fg * 4 + r;          // kv_head * 128 + d
+                                float x = v[b][r];
+                                if (p.bias) x += h4(e_bias[b], r);
+                                p.vtcache[(long long)vrow * p.vt_row_stride + pos] = f32_to_bf16(x);
+                            }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) wcur[b][q] = wnext[b][q];
+    }
+}
+
+extern int g_gemv_profile_shapes;
+
+template <int MM, int MODE, int NB>
+static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
+    const size_t smem = (size_t)MM * GM_XPITCH + (size_t)GM_NW * NB * 2048 + (size_t)2 * GM_NW * NB * 1024 + 64;
+    static bool attr = false;
+    if (!attr) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        attr = true;
+    }
+    // persistent workgroups, one per CU (x is staged / normalised once per workgroup when K fits one piece)
+    const int grid = n_units < 256 ? n_units : 256;
+    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_mfma_kernel<MM, MODE, NB>), dim3(grid), dim3(GM_NT), smem, st, p, n_units, nsteps);
+    return FO1_OK;
+}
+
+template <int MM>
+static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
+    const int nsteps = cdiv(p.K, 64);
+    if (p.norm_w && nsteps > GM_PIECE) return set_err(FO1_ERR_ARG, "gemv_batch: fused RMSNorm needs K <= %d (K=%d)", GM_PIECE * 64, p.K);
+    char pname[56];
+    const char* name = mode == GB_SWIGLU ? "gemv_mfma_swiglu" : (mode == GB_QKV ? "gemv_mfma_qkv" : "gemv_mfma");
+    if (profile_enabled() && g_gemv_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemv_mfma m%d %dx%d mode%d", p.M, p.N, p.K, mode);
+        name = pname;
+    }
+    if (mode == GB_SWIGLU) return launch_gemv_mfma<MM, GB_SWIGLU, 2>(p, p.N / 32, nsteps, name, st);
+    if (mode == GB_QKV) return launch_gemv_mfma<MM, GB_QKV, 2>(p, (p.n_q + p.n_kv) * 4 + p.n_kv * 4, nsteps, name, st);
+    // plain: 16-row units for the few-row projections (every CU should stream), 32-row units for lm_head-sized matrices
+    if (p.N >= 8192) return launch_gemv_mfma<MM, GB_PLAIN, 2>(p, cdiv(p.N, 32), nsteps, name, st);
+    return launch_gemv_mfma<MM, GB_PLAIN, 1>(p, cdiv(p.N, 16), nsteps, name, st);
+}
+
+int gemv_mfma_any(GemvBParams& p, int mode, hipStream_t st) {
+    if (p.M <= 8) return dispatch_gemv_mfma<8>(p, mode, st);
+    return dispatch_gemv_mfma<16>(p, mode, st);
+}
+
+}  // namespace fo1

@@ -218,10 +218,11 @@ size_t fo1_llm_decode_workspace_bytes(const fo1_llm_weights_t* w, int batch, int
 
 int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots, const void* rope_cos, const void* rope_sin, int32_t* state,
                         int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids, int n_stop, int32_t* done, int batch,
-                        int slot_rows, void* logits, void* workspace, size_t workspace_bytes, void* stream) {
+                        int slot_rows, int max_kv_len, void* logits, void* workspace, size_t workspace_bytes, void* stream) {
     FO1_CHECK_ARG(w && slots && rope_cos && rope_sin && state && plan && ids_out && done && logits && w->layers && w->embed, "llm_decode_step: NULL argument");
     const int B = batch, d = w->hidden, H = w->n_heads, KV = w->n_kv_heads, HD = w->head_dim, I = w->intermediate;
-    FO1_CHECK_ARG(B >= 1 && B <= 8 && HD == 128, "llm_decode_step: batch %d (1..8), head_dim %d (128)", B, HD);
+    FO1_CHECK_ARG(B >= 1 && B <= 16 && HD == 128, "llm_decode_step: batch %d (1..16), head_dim %d (128)", B, HD);
+    FO1_CHECK_ARG(max_kv_len >= 1 && max_kv_len <= slot_rows, "llm_decode_step: max_kv_len %d outside [1, slot_rows = %d]", max_kv_len, slot_rows);
     void *xa, *xb, *q, *att, *a, *aws, *asc;
     size_t abytes;
     const size_t need = llm_decode_layout(w, B, slot_rows, workspace, workspace_bytes, &xa, &xb, &q, &att, &a, &aws, &abytes, &asc);
@@ -240,7 +241,7 @@ int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots,
         FO1_TRY(fo1_gemv_batch_bf16(x, d, L.wqkv, d, L.bqkv, nullptr, 0, q, H * HD, B, qd, d, 2, L.ln1, w->rms_eps, H, KV, rope_cos, rope_sin, state, kc,
                                     slots->k_head_stride, vtc, slots->vt_row_stride, stream));
         FO1_TRY(fo1_attention_decode_batch_bf16(q, (long long)H * HD, kc, HD, slots->k_head_stride, vtc, slots->vt_row_stride, att, (long long)H * HD, state, B,
-                                                slot_rows, H, KV, HD, scale, aws, abytes, stream));
+                                                max_kv_len, H, KV, HD, scale, aws, abytes, stream));
         FO1_TRY(fo1_gemv_batch_bf16(att, H * HD, L.wo, H * HD, nullptr, x, d, y, d, B, d, H * HD, 0, nullptr, 0.f, 0, 0, nullptr, nullptr, nullptr, nullptr, 0,
                                     nullptr, 0, stream));
         // post_attention_layernorm + gate/up + SwiGLU, one launch; then down + residual

@@ -142,7 +142,7 @@ SIGNATURES = {
                                 c_int, ctypes.c_double, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fo1_llm_decode_workspace_bytes": (c_size_t, [ctypes.POINTER(LlmWeights), c_int, c_int]),
     "fo1_llm_decode_step": (c_int, [ctypes.POINTER(LlmWeights), ctypes.POINTER(KvCache), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                                    c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                    c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fo1_zero_bytes": (c_int, [c_void_p, c_size_t, c_void_p]),
     "fo1_davit_workspace_bytes": (c_size_t, [ctypes.POINTER(DavitWeights), ctypes.POINTER(DavitPlan)]),
     "fo1_davit_forward": (c_int, [ctypes.POINTER(DavitWeights), ctypes.POINTER(DavitPlan), c_void_p, c_int, ctypes.POINTER(c_void_p), c_void_p, c_size_t,
@@ -152,6 +152,8 @@ SIGNATURES = {
     "fo1_projector_workspace_bytes": (c_size_t, [ctypes.POINTER(ProjectorW), c_int]),
     "fo1_projector_forward": (c_int, [ctypes.POINTER(ProjectorW), c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
+    "fo1_gemv_batch_set_impl": (c_int, [c_int]),
+    "fo1_attention_decode_set_impl": (c_int, [c_int]),
     "fo1_hfre_set_tuning": (c_int, [c_int, c_int, c_int, c_int]),
     "fo1_hfre_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),
     "fo1_hfre_region_pool": (c_int, [ctypes.POINTER(HfreSource), c_int, c_void_p, c_int, c_void_p, c_float, c_float,

@@ -433,13 +433,13 @@ class QwenLLM:
 
 
 class BatchDecoder:
-    """Greedy decode of up to 8 sequences at once: the weights are streamed ONCE per step for all sequences
+    """Greedy decode of up to 16 sequences at once: the weights are streamed ONCE per step for all sequences
     (fo1_gemv_batch_bf16), 5 launches per layer, and the whole step — embedding gather, 36 layers, lm_head, argmax, stop check,
     position bookkeeping — replays as one hipGraph with no host read inside the loop (the host polls a device-side `done` counter
     every few steps).  Reference semantics: HF greedy search over the 1-token fast path of omchat_qwen2_5_vl.py:143-155;
     positions = cache position + rope delta (modeling_qwen2_5_vl.py:1848-1860); a sequence stops AFTER its EOS / keyword id has
     been appended, or at max_new_tokens (mm_utils.py:137-181, 640-654)."""
-    MAX_BATCH = 8
+    MAX_BATCH = 16
     IDS_CAP = 4096          # generated ids kept per sequence (every reference caller uses max_new_tokens <= 4096)
 
     def __init__(self, llm: QwenLLM):
@@ -493,6 +493,7 @@ class BatchDecoder:
             slot *= 2
         self._ensure(B * slot if B * slot > self.rows else self.rows)
         self.B, self.slot = B, slot
+        self.len0, self.steps = max(L for _, L, *_ in seqs), 0      # host-side bound on any sequence's keys: len0 + steps + 1
         reloc = torch.tensor([[o, b * slot, L, 0] for b, (o, L, *_) in enumerate(seqs)], dtype=torch.int32)
         state = torch.tensor([[b * slot + L, L + d, b * slot, 0, 0, max_new, 0, 0] for b, ((o, L, *_), d) in enumerate(zip(seqs, deltas))],
                              dtype=torch.int32)
@@ -507,6 +508,15 @@ class BatchDecoder:
             ops.kv_relocate(llm.kcache, self.dk, llm.vtcache, self.dvt, self.reloc[:B], max(L for _, L, *_ in seqs))
             ops.decode_argmax_accept(None, first_tokens.to(torch.int32).contiguous(), self.state[:B], self.plan[:B], self.ids[:B],
                                      self.stop[:self.n_stop], self.done)
+
+    KV_BUCKET = 2048
+
+    def kv_bucket(self) -> int:
+        """Upper bound on the keys any sequence attends in the coming step, rounded up to KV_BUCKET rows (capped by the slot): the
+        attention launch geometry follows it (one workgroup per KV head and sequence up to 2048 keys), so a 4096-token budget does
+        not make every step pay the long-context split.  A new bucket means a new captured graph, once per 2048 generated tokens."""
+        need = self.len0 + self.steps + 1
+        return min(self.slot, -(-need // self.KV_BUCKET) * self.KV_BUCKET)
 
     def _step_device(self):
         llm, B = self.llm, self.B
@@ -523,7 +533,7 @@ class BatchDecoder:
             for li, w in enumerate(llm.layers):
                 q = ops.gemv_batch(x, w["wqkv"], w["bqkv"], mode=ops.GB_QKV, norm_weight=w["ln1"], norm_eps=c.rms_norm_eps,
                                    qkv=dict(n_q=H, n_kv=KV, cos=llm.rope_cos, sin=llm.rope_sin, state=st, kcache=self.dk[li], vtcache=self.dvt[li]))
-                att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, self.slot, H, KV, HD, scale)
+                att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, self.kv_bucket(), H, KV, HD, scale)
                 x = ops.gemv_batch(att, w["wo"], residual=x)
                 a = ops.gemv_batch(x, w["wgu"], mode=ops.GB_SWIGLU, norm_weight=w["ln2"], norm_eps=c.rms_norm_eps)
                 x = ops.gemv_batch(a, w["wdown"], residual=x)
@@ -534,8 +544,10 @@ class BatchDecoder:
     def step(self, use_graph: bool = True):
         """One token for every live sequence."""
         if not use_graph:
-            return self._step_device()
-        key = (self.B, self.slot, self.n_stop)
+            out = self._step_device()
+            self.steps += 1
+            return out
+        key = (self.B, self.slot, self.n_stop, self.kv_bucket())
         ent = self._graphs.get(key)
         if ent is None:
             with ops.graph_lock.capture(), torch.inference_mode(False):
@@ -555,6 +567,7 @@ class BatchDecoder:
                 self._graphs[key] = ent
         with ops.graph_lock.replay():
             ent[0].replay()
+        self.steps += 1
         return ent[1]
 
     def run(self, max_new_tokens: int, use_graph: bool = True, poll: int = 8) -> List[List[int]]:

@@ -168,7 +168,7 @@ class LlmStage:
         C = self.cache_struct(dec.dk, dec.dvt)
         rc = L.fo1_llm_decode_step(ctypes.byref(self.W), ctypes.byref(C), llm.rope_cos.data_ptr(), llm.rope_sin.data_ptr(), dec.state.data_ptr(),
                                    dec.plan.data_ptr(), dec.ids.data_ptr(), dec.ids.shape[1], dec.stop.data_ptr() if dec.n_stop else None, dec.n_stop,
-                                   dec.done.data_ptr(), B, dec.slot, logits.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr())
+                                   dec.done.data_ptr(), B, dec.slot, dec.kv_bucket(), logits.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr())
         _lib.check(rc, "fo1_llm_decode_step")
         return logits
 
