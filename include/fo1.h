@@ -311,8 +311,9 @@ int fo1_gemv_batch_set_rows_per_lane(int rpl);
  * fo1_gemv_batch_set_impl: 1 (default) = MFMA skinny GEMM (csrc/decode_mfma.hip: the sequences ride as the 16 columns of
  *   v_mfma_f32_16x16x32_bf16, M <= 16, needs N % 4 == 0); 0 = the v_dot2 streaming kernel (M <= 8).  Both keep a
  *   sequence's numbers independent of the batch it decodes in; the two differ from each other in fp32 summation order.
- * fo1_attention_decode_set_impl: 1 (default) = one workgroup per (KV head, sequence), tiles round-robin over its waves,
- *   partials merged in LDS (one launch for slots <= 2048 rows); 0 = 64-key split-KV partials + combine kernel. */
+ * fo1_attention_decode_set_impl: 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head,
+ *   sequence), tiles round-robin over its waves, partials merged in LDS (one launch for slots <= 2048 rows; measured slower
+ *   on MI355X: one CU cannot pull a head's K/V^T fast enough). */
 int fo1_gemv_batch_set_impl(int impl);
 int fo1_attention_decode_set_impl(int impl);
 

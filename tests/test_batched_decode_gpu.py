@@ -90,15 +90,26 @@ def test_batched_decode_vs_alone_vs_oracle_and_stop_rule():
 
 def test_batched_decode_twelve_sequences_match_alone():
     """More than 8 sequences per weight stream (the MFMA kernel carries up to 16 as MFMA columns): 12 ragged requests generate, per
-    request, exactly the ids the same path generates for the request alone."""
+    request, exactly the ids the same path generates for the request alone.  The prefill GEMMs are pinned to one tile (as in
+    test_ragged_batch_equals_sequential_bitwise_with_pinned_tile) so that the KV rows a request starts from are the same bits in
+    both runs: what is compared is the decode path's independence of the batch."""
     from test_batched_prefill_gpu import make_request
+    from vlm_fo1_amd import lib as L
     cfg, weights, eng = build()
     reqs = [make_request(100 + i, 96 + 28 * (i % 4), 120 + 28 * (i % 3), 1 + (5 * i) % 9) for i in range(12)]
     K = 6
-    got = eng.generate_batch(reqs, max_new_tokens=K, use_graph=True)
-    assert [len(g) for g in got] == [K] * 12
-    for i in (0, 5, 11):
-        assert eng.generate_batch([reqs[i]], max_new_tokens=K, use_graph=True)[0] == got[i], f"request {i} decodes differently in a batch of 12"
+    try:
+        L.check(L.load().fo1_gemm_set_variant(2, 1), "variant")
+        L.check(L.load().fo1_gemm_set_splitk(1), "splitk")
+        L.check(L.load().fo1_gemm_set_gemv(0), "gemv")
+        got = eng.generate_batch(reqs, max_new_tokens=K, use_graph=True)
+        assert [len(g) for g in got] == [K] * 12
+        for i in (0, 5, 11):
+            assert eng.generate_batch([reqs[i]], max_new_tokens=K, use_graph=True)[0] == got[i], f"request {i} decodes differently in a batch of 12"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_splitk(0)
+        L.load().fo1_gemm_set_gemv(1)
 
 
 @pytest.mark.parametrize("impl,rows_per_lane", [(1, 0), (0, 0), (0, 1)])
@@ -184,8 +195,8 @@ def test_gemv_mfma_qkv_matches_reference_and_dot2(M):
 
 
 def test_attention_decode_workgroup_kernel_matches_split_kernel_and_reference():
-    """Decode attention, one workgroup per (KV head, sequence) (impl 1: tiles round-robin over 8 waves, merged in LDS; 1024-key
-    splits + combine beyond 2048 rows) against the 64-key split-KV kernel (impl 0) and against fp32 softmax(q k^T / sqrt(d)) v,
+    """Decode attention: the 64-key split-KV kernel + combine (impl 0, default) and the one-workgroup-per-(KV head, sequence) kernel
+    (impl 1: tiles round-robin over 8 waves, merged in LDS; 1024-key splits + combine beyond 2048 rows) against fp32 softmax(q k^T / sqrt(d)) v,
     ragged batch, slot starts != 0."""
     from vlm_fo1_amd import lib as L, ops
     BF = torch.bfloat16
@@ -209,7 +220,7 @@ def test_attention_decode_workgroup_kernel_matches_split_kernel_and_reference():
             try:
                 out[impl] = ops.attention_decode_batch(q, kc, vt, state, slot, H, KV, HD, scale).float().cpu()
             finally:
-                L.load().fo1_attention_decode_set_impl(1)
+                L.load().fo1_attention_decode_set_impl(0)
         kf, vf, qf = kc.float().cpu(), vt.float().cpu(), q.float().cpu()
         for b, n in enumerate(lens):
             for h in range(H):

@@ -315,6 +315,10 @@ __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __
 // minus the LDS staging: nothing is shared between waves), all 48 loads of a tile in flight at once.  The waves' (O, m, l) meet
 // in LDS and are merged in wave order; with one split the normalised bf16 rows are written directly (ONE launch per layer
 // instead of split + combine), with several the merged partial of each split goes to `part` for attn_decode_combine_kernel.
+// MEASURED (MI355X, 651-key contexts, gpurun_out/r02_run17): 16.8 us per layer at every batch size against 5.3 + 4.3 us (B = 1) ..
+// 13.0 + 4.5 us (B = 16) for the 64-key split kernel + combine: all of a (KV head, sequence)'s K/V^T (333 KB) funnels through
+// ONE CU in fragment-shaped 64-byte / 8-byte pieces (20 GB/s), where the split kernel spreads 64-key chunks over 22+ CUs and
+// stages them coalesced through LDS.  Kept as an A/B option (fo1_attention_decode_set_impl), not the default.
 struct AttnDecParams {
     const uint16_t* Q; long long q_seq_stride;       // q rows [B][n_q_heads * 128]
     const uint16_t* K; long long k_tok, k_head;
@@ -476,7 +480,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_wg_kernel(const AttnDecPa
     }
 }
 
-int g_attn_decode_impl = 1;   // 1 = attn_decode_wg_kernel, 0 = 64-key split-KV partials + combine (the round-1 form)
+int g_attn_decode_impl = 0;   // 0 = 64-key split-KV partials + combine; 1 = attn_decode_wg_kernel (measured slower: see the note below)
 
 // One launch for slots up to 2048 rows (32 tiles over 8 waves); longer slots: 1024-key splits + the fixed-order combine.
 static int launch_attn_decode_wg(AttnDecParams& p, int max_kv_len, int batch, int n_q_heads, hipStream_t st) {
@@ -592,8 +596,8 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
     return FO1_OK;
 }
 
-// A/B hook: 1 (default) = one workgroup per (KV head, sequence) with the waves' partials merged in LDS; 0 = 64-key split-KV
-// partials + combine kernel.
+// A/B hook: 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence) with the waves'
+// partials merged in LDS (one launch up to 2048 keys; measured slower, see attn_decode_wg_kernel).
 int fo1_attention_decode_set_impl(int impl) {
     if (impl != 0 && impl != 1) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_impl: %d", impl);
     fo1::g_attn_decode_impl = impl;

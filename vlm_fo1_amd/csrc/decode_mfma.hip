@@ -17,6 +17,8 @@
 //   * the 8 waves' partial accumulators meet in LDS (fixed order), wave 0 runs the epilogue: bias -> bf16 -> (+ residual) |
 //     interleaved SwiGLU | QKV: bias -> bf16 -> mRoPE -> rotated q rows out, K row and V^T column appended to the caches.
 //     Everything the epilogue reads from global memory (bias, residual, rope tables) is requested BEFORE the K loop.
+#include <type_traits>
+
 #include "decode_common.h"
 
 namespace fo1 {
@@ -50,7 +52,8 @@ __device__ __forceinline__ void gm_lds_fence() {
 }
 
 // MM: staged x rows (8 or 16).  NB: 16-row weight blocks per unit (SwiGLU / QKV pair two blocks whose rows meet in one lane).
-template <int MM, int MODE, int NB>
+// MP: K spans several staged pieces (deep-K projections); single-piece kernels stage x once and carry no reload logic.
+template <int MM, int MODE, int NB, bool MP>
 __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, const int n_units, const int nsteps) {
     static_assert(MODE == GB_PLAIN || NB == 2, "paired modes use two row blocks");
     extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     const int xrow = MM == 16 ? fi : (fi & 7);
     const int n_rope = MODE == GB_QKV ? (p.n_q + p.n_kv) * 4 : 0;
 
-    auto unit_rows = [&](int u, int (&rb)[NB]) {
+    auto unit_rows = [&](int u, int (&rb)[NB]) __attribute__((always_inline)) {
         if (MODE == GB_SWIGLU) {
             rb[0] = u * 32;
             rb[NB - 1] = u * 32 + 16;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             for (int b = 0; b < NB; ++b) rb[b] = (u * NB + b) * 16;
         }
     };
-    auto unit_ptrs = [&](int u, const uint16_t* (&wp)[NB][2]) {
+    auto unit_ptrs = [&](int u, const uint16_t* (&wp)[NB][2]) __attribute__((always_inline)) {
         int rb[NB];
         unit_rows(u < n_units ? u : n_units - 1, rb);
 #pragma unroll
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             }
     };
     // all four loads of one k-step of this wave; addresses are always valid (chunks past K are clamped: their x is zero in LDS)
-    auto issue = [&](const uint16_t* const (&wp)[NB][2], int s, uint4 (&st)[NB][2]) {
+    auto issue = [&](const uint16_t* const (&wp)[NB][2], int s, uint4 (&st)[NB][2]) __attribute__((always_inline)) {
         int c = s * 8 + lch;
         c = c < kch ? c : kch - 1;
 #pragma unroll
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
             for (int q = 0; q < 2; ++q) st[b][q] = gm_load_nt16(wp[b][q] + (long long)c * 8);
     };
-    auto consume = [&](const uint4 (&st)[NB][2], int xs, gm_f32x4 (&acc)[NB]) {
+    auto consume = [&](const uint4 (&st)[NB][2], int xs, gm_f32x4 (&acc)[NB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -120,16 +123,20 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         }
         gm_lds_fence();      // the scratch is rewritten by the next k-step
     };
-    // x rows of K piece `piece` -> LDS (zero beyond M rows / beyond K), then the fused RMSNorm (single-piece K only: host-checked)
-    auto stage_x = [&](int piece, const uint4& nw) {
+    // x rows of K piece `piece`: global -> registers (clamped addresses, no branch), then registers -> LDS (zero beyond M rows /
+    // beyond K) and the fused RMSNorm (single-piece K only: host-checked).  Split in two so that the loads can be issued BEFORE the
+    // weight refills of the piece in progress: vmcnt retires in order, a younger x load would drain the whole weight pipeline.
+    auto load_x = [&](int piece, uint4 (&t)[MM / 2]) __attribute__((always_inline)) {
         const int c = tid & 255, gc = piece * 256 + c;
         const int gcc = gc < kch ? gc : kch - 1;
-        uint4 t[MM / 2];
 #pragma unroll
         for (int i = 0; i < MM / 2; ++i) {
             const int m = (tid >> 8) + 2 * i;
             t[i] = *reinterpret_cast<const uint4*>(p.X + (long long)(m < p.M ? m : p.M - 1) * p.ldx + gcc * 8);
         }
+    };
+    auto store_x = [&](int piece, const uint4 (&t)[MM / 2], const uint4& nw) __attribute__((always_inline)) {
+        const int c = tid & 255, gc = piece * 256 + c;
 #pragma unroll
         for (int i = 0; i < MM / 2; ++i) {
             const int m = (tid >> 8) + 2 * i;
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             *reinterpret_cast<uint4*>(sx + m * GM_XPITCH + c * 16) = ok ? t[i] : uint4{0, 0, 0, 0};
         }
         __syncthreads();
-        if (p.norm_w) {
+        if (!MP && p.norm_w) {
             for (int m = wave; m < MM; m += GM_NW) {
                 float ss = 0.f;
 #pragma unroll
@@ -168,20 +175,24 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         }
     };
 
-    // ---- prologue: the weight stream does not depend on x — the first unit's first piece is requested before anything else ----
+    // ---- prologue: the weight stream does not depend on x — the first unit's first piece is requested before anything else.
+    // NO branch encloses a global load from here on: hipcc turns a conditionally issued load into "load, then s_waitcnt vmcnt(0) at
+    // the join" (measured: the first form of this loop ran every k-step at full HBM latency, 3.4 TB/s); addresses are clamped to
+    // valid memory instead and the surplus data meets zeros (x beyond K) or is never stored (rows beyond N). ----
+    // x (tiny, L2-resident, needed first) is requested before the weights: waiting for it then leaves the weight loads in flight.
+    const uint16_t* const dummy = p.W;                       // any valid address for the operands a launch does not have
+    uint4 nw;
+    {
+        const int c = tid & 255;
+        nw = *reinterpret_cast<const uint4*>((p.norm_w ? p.norm_w : dummy) + (c < kch ? c : kch - 1) * 8);
+    }
+    uint4 xr[MM / 2];
+    load_x(0, xr);
     uint4 st[GM_D][NB][2];
     const uint16_t* wcur[NB][2];
     unit_ptrs(blockIdx.x, wcur);
-    if ((int)blockIdx.x < n_units) {
 #pragma unroll
-        for (int d = 0; d < GM_D; ++d)
-            if (wave + GM_NW * d < nsteps) issue(wcur, wave + GM_NW * d, st[d]);
-    }
-    uint4 nw = uint4{0, 0, 0, 0};
-    if (p.norm_w) {
-        const int c = tid & 255;
-        nw = *reinterpret_cast<const uint4*>(p.norm_w + (c < kch ? c : kch - 1) * 8);
-    }
+    for (int d = 0; d < GM_D; ++d) issue(wcur, wave + GM_NW * d, st[d]);
     // decode state of this lane's sequence (QKV epilogue): cache row and rope-table row
     const int n_seq = fi;
     const bool seq_ok = n_seq < p.M;
@@ -192,59 +203,68 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         pos = stt[0];
         trow = stt[1];
     }
-    if (n_pieces == 1) stage_x(0, nw);
+    if (!MP) store_x(0, xr, nw);      // single piece: x staged (and normalised) once for every unit of this workgroup
+    const uint16_t* const bias_src = p.bias ? p.bias : dummy;
+    const uint16_t* const res_src = p.res ? p.res : dummy;
+    const long long res_ld = p.res ? p.ldr : 0;
 
-    int it = 0;
-    for (int u = blockIdx.x; u < n_units; u += gridDim.x, ++it) {
-        const int un = u + gridDim.x;
+    // One unit.  PF (compile time): the workgroup has another unit after this one — its first piece is requested while this
+    // unit's last piece is consumed.  The caller peels the last unit, so no load sits under a run-time condition.
+    auto unit_body = [&](int u, int it, auto pf_tag) __attribute__((always_inline)) {
+        constexpr bool PF = decltype(pf_tag)::value;
         const uint16_t* wnext[NB][2];
-        unit_ptrs(un, wnext);
+        if (PF) unit_ptrs(u + gridDim.x, wnext);
         int rb[NB];
         unit_rows(u, rb);
-        // ---- epilogue operands, requested now, used after the K loop (wave 0 only; clamped addresses, always valid) ----
+        // ---- epilogue operands, requested now (every wave: no branch), used after the K loop by wave 0 ----
         uint2 e_bias[NB], e_res[NB], e_cos[2], e_sin[2];    // 4 consecutive bf16 each (N % 4 == 0, ldr % 4 == 0: host-checked)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) e_bias[b] = e_res[b] = uint2{0, 0};
-        e_cos[0] = e_cos[1] = e_sin[0] = e_sin[1] = uint2{0, 0};
-        if (wave == 0) {
+        {
             const int nc = seq_ok ? n_seq : 0;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 int f0 = rb[b] + fg * 4;
                 f0 = f0 + 4 <= p.N ? f0 : p.N - 4;
-                if (p.bias) e_bias[b] = *reinterpret_cast<const uint2*>(p.bias + f0);
-                if (MODE == GB_PLAIN && p.res) e_res[b] = *reinterpret_cast<const uint2*>(p.res + (long long)nc * p.ldr + f0);
+                e_bias[b] = *reinterpret_cast<const uint2*>(bias_src + f0);
+                e_res[b] = MODE == GB_PLAIN ? *reinterpret_cast<const uint2*>(res_src + (long long)nc * res_ld + f0) : uint2{0, 0};
+                if (!p.bias) e_bias[b] = uint2{0, 0};
+                if (!p.res) e_res[b] = uint2{0, 0};
             }
-            if (MODE == GB_QKV && u < n_rope) {
-                const int d0 = (u & 3) * 16 + fg * 4;
+            if (MODE == GB_QKV) {
+                const int d0 = (u & 3) * 16 + fg * 4;        // (V units load a harmless table row too)
                 e_cos[0] = *reinterpret_cast<const uint2*>(p.cos_t + trow * 128 + d0);
                 e_sin[0] = *reinterpret_cast<const uint2*>(p.sin_t + trow * 128 + d0);
                 e_cos[1] = *reinterpret_cast<const uint2*>(p.cos_t + trow * 128 + d0 + 64);
                 e_sin[1] = *reinterpret_cast<const uint2*>(p.sin_t + trow * 128 + d0 + 64);
+            } else {
+                e_cos[0] = e_cos[1] = e_sin[0] = e_sin[1] = uint2{0, 0};
             }
         }
         gm_f32x4 acc[NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[b] = gm_f32x4{0.f, 0.f, 0.f, 0.f};
 
-        for (int piece = 0; piece < n_pieces; ++piece) {
-            if (n_pieces > 1) {
-                __syncthreads();             // every wave is done with the previous piece of x
-                stage_x(piece, nw);
-            }
-            const bool last_piece = piece + 1 == n_pieces;
+        // every piece but the last: consume a k-step, refill its stage with the k-step one piece ahead in the same unit
+        if (MP) {
+            for (int piece = 0; piece + 1 < n_pieces; ++piece) {
+                __syncthreads();                 // every wave is done with the previous piece of x
+                store_x(piece, xr, nw);
+                load_x(piece + 1, xr);           // before this piece's weight refills (in-order vmcnt)
 #pragma unroll
-            for (int d = 0; d < GM_D; ++d) {
-                const int xs = wave + GM_NW * d;              // k-step inside the staged piece
-                const int s = piece * GM_PIECE + xs;
-                if (s < nsteps) consume(st[d], xs, acc);
-                // refill this stage one piece ahead: same unit, or the first piece of this workgroup's next unit
-                if (!last_piece) {
-                    if (s + GM_PIECE < nsteps) issue(wcur, s + GM_PIECE, st[d]);
-                } else if (un < n_units) {
-                    if (xs < nsteps) issue(wnext, xs, st[d]);
+                for (int d = 0; d < GM_D; ++d) {
+                    const int xs = wave + GM_NW * d;              // k-step inside the staged piece
+                    consume(st[d], xs, acc);
+                    issue(wcur, (piece + 1) * GM_PIECE + xs, st[d]);
                 }
             }
+            __syncthreads();
+            store_x(n_pieces - 1, xr, nw);
+            load_x(0, xr);                       // the next unit's first piece (unused after the workgroup's last unit)
+        }
+#pragma unroll
+        for (int d = 0; d < GM_D; ++d) {
+            const int xs = wave + GM_NW * d;
+            consume(st[d], xs, acc);
+            if (PF) issue(wnext, xs, st[d]);                  // the first piece of this workgroup's next unit
         }
         // ---- the 8 waves' partial sums meet in LDS; double-buffered by unit parity: one barrier per unit ----
         float* red = sred + (it & 1) * (GM_NW * NB * 256);
@@ -274,10 +294,9 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                         uint16_t o[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float x = v[b][r];
-                            if (p.bias) x += h4(e_bias[b], r);
+                            float x = v[b][r] + h4(e_bias[b], r);
                             x = gm_round(x);
-                            if (p.res) x += h4(e_res[b], r);
+                            x += h4(e_res[b], r);
                             o[r] = f32_to_bf16(x);
                         }
                         uint16_t* cp = p.C + (long long)n_seq * p.ldc + f0;
@@ -295,8 +314,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                     uint16_t o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float g = v[0][r], up = v[NB - 1][r];
-                        if (p.bias) { g += h4(e_bias[0], r); up += h4(e_bias[NB - 1], r); }
+                        float g = v[0][r] + h4(e_bias[0], r), up = v[NB - 1][r] + h4(e_bias[NB - 1], r);
                         g = gm_round(g);
                         up = gm_round(up);
                         o[r] = f32_to_bf16(gm_round(g / (1.0f + expf(-g))) * up);
@@ -314,8 +332,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                         uint16_t oa[4], ob[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float a = v[0][r], b = v[NB - 1][r];
-                            if (p.bias) { a += h4(e_bias[0], r); b += h4(e_bias[NB - 1], r); }
+                            float a = v[0][r] + h4(e_bias[0], r), b = v[NB - 1][r] + h4(e_bias[NB - 1], r);
                             a = gm_round(a);                                          // the bf16 q/k the unfused path stores
                             b = gm_round(b);
                             const float c1 = h4(e_cos[0], r), s1 = h4(e_sin[0], r), c2 = h4(e_cos[1], r), s2 = h4(e_sin[1], r);
@@ -344,35 +361,45 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int vrow = (u - n_rope) * 32 + b * 16 + fg * 4 + r;          // kv_head * 128 + d
-                                float x = v[b][r];
-                                if (p.bias) x += h4(e_bias[b], r);
-                                p.vtcache[(long long)vrow * p.vt_row_stride + pos] = f32_to_bf16(x);
+                                p.vtcache[(long long)vrow * p.vt_row_stride + pos] = f32_to_bf16(v[b][r] + h4(e_bias[b], r));
                             }
                     }
                 }
             }
         }
+        if (PF) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
+            for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) wcur[b][q] = wnext[b][q];
-    }
+                for (int q = 0; q < 2; ++q) wcur[b][q] = wnext[b][q];
+        }
+    };
+
+    int it = 0, u = blockIdx.x;
+    for (; u + (int)gridDim.x < n_units; u += gridDim.x, ++it) unit_body(u, it, std::true_type{});
+    unit_body(u, it, std::false_type{});      // the workgroup's last unit (grid <= n_units: every workgroup has one)
 }
 
 extern int g_gemv_profile_shapes;
 
-template <int MM, int MODE, int NB>
-static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
+template <int MM, int MODE, int NB, bool MP>
+static int launch_gemv_mfma_mp(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
     const size_t smem = (size_t)MM * GM_XPITCH + (size_t)GM_NW * NB * 2048 + (size_t)2 * GM_NW * NB * 1024 + 64;
     static bool attr = false;
     if (!attr) {
-        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB, MP>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr = true;
     }
     // persistent workgroups, one per CU (x is staged / normalised once per workgroup when K fits one piece)
     const int grid = n_units < 256 ? n_units : 256;
-    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_mfma_kernel<MM, MODE, NB>), dim3(grid), dim3(GM_NT), smem, st, p, n_units, nsteps);
+    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_mfma_kernel<MM, MODE, NB, MP>), dim3(grid), dim3(GM_NT), smem, st, p, n_units, nsteps);
     return FO1_OK;
+}
+
+template <int MM, int MODE, int NB>
+static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
+    if (nsteps > GM_PIECE) return launch_gemv_mfma_mp<MM, MODE, NB, true>(p, n_units, nsteps, name, st);
+    return launch_gemv_mfma_mp<MM, MODE, NB, false>(p, n_units, nsteps, name, st);
 }
 
 template <int MM>
