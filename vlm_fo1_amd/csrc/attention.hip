@@ -496,14 +496,22 @@ static int launch_attn_decode_wg(AttnDecParams& p, int max_kv_len, int batch, in
     return FO1_OK;
 }
 
+extern int g_gemv_profile_shapes;   // gemv.hip: per-shape profile rows (fo1_gemm_profile_shapes)
+
 template <int HD>
 static int launch_attn(const AttnParams& p, int q_block, hipStream_t st, double flops) {
+    char pname[48];
+    const char* name = "attn_fwd";
+    if (profile_enabled() && g_gemv_profile_shapes) {
+        snprintf(pname, sizeof pname, "attn_fwd hd%d q%d items%d heads%d%s", HD, q_block, p.n_items, p.Hq, p.causal ? " causal" : "");
+        name = pname;
+    }
     if (q_block == 16)
-        FO1_LAUNCH("attn_fwd", flops, (attn_fwd_kernel<HD, 1>), dim3(p.n_items, p.Hq), dim3(64), 0, st, p);
+        FO1_LAUNCH(name, flops, (attn_fwd_kernel<HD, 1>), dim3(p.n_items, p.Hq), dim3(64), 0, st, p);
     else if (q_block == 32)
-        FO1_LAUNCH("attn_fwd", flops, (attn_fwd_kernel<HD, 2>), dim3(p.n_items, p.Hq), dim3(128), 0, st, p);
+        FO1_LAUNCH(name, flops, (attn_fwd_kernel<HD, 2>), dim3(p.n_items, p.Hq), dim3(128), 0, st, p);
     else
-        FO1_LAUNCH("attn_fwd", flops, (attn_fwd_kernel<HD, 4>), dim3(p.n_items, p.Hq), dim3(256), 0, st, p);
+        FO1_LAUNCH(name, flops, (attn_fwd_kernel<HD, 4>), dim3(p.n_items, p.Hq), dim3(256), 0, st, p);
     return FO1_OK;
 }
 

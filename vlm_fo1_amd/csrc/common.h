@@ -47,6 +47,25 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(fo1_f32x2{lo, hi}, fo1_bf16x2));
 }
 
+// Activations of the fused epilogues.  Their result is rounded to bf16 (8 significant bits) right away, so the hardware
+// approximations (v_exp_f32, v_rcp_f32: ~1 ulp of fp32) replace the library's expf / erff / IEEE division — ~6 instructions per
+// element instead of ~25-40, in epilogues that run 128 elements per lane (DaViT fc1 + GELU ran at 564 TFLOP/s for that reason).
+// SiLU (Qwen2MLP act_fn, modeling_qwen2_5_vl.py:636):  v * sigmoid(v).
+__device__ __forceinline__ float fo1_silu(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// erf-GELU (nn.GELU(): modeling_davit.py:57, simple_fpn.py:145, multimodal_projector/builder.py:69,108, merger): 0.5 v (1 + erf(v / sqrt 2))
+// with erfc(|x|) from Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute); 1 + erf(x) is formed as erfc(|x|) on the negative
+// side (no cancellation) and 2 - erfc(x) on the positive side.
+__device__ __forceinline__ float fo1_gelu_erf(float v) {
+    const float x = v * 0.70710678118654752440f, ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = poly * t * __expf(-ax * ax);
+    return 0.5f * v * (x >= 0.f ? 2.0f - e : e);
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // ---- optional per-kernel timing (fo1_profile_*) ---------------------------------------

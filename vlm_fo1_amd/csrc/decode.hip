@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
                         if (p.bias) { g += bf16_to_f32(p.bias[grow]); u += bf16_to_f32(p.bias[grow + 16]); }
                         g = gb_round(g);
                         u = gb_round(u);
-                        p.C[(long long)m * p.ldc + f] = f32_to_bf16(gb_round(g / (1.0f + expf(-g))) * u);
+                        p.C[(long long)m * p.ldc + f] = f32_to_bf16(gb_round(fo1_silu(g)) * u);
                     }
                 }
             } else {   // GB_QKV

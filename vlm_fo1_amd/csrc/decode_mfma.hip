@@ -317,7 +317,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                         float g = v[0][r] + h4(e_bias[0], r), up = v[NB - 1][r] + h4(e_bias[NB - 1], r);
                         g = gm_round(g);
                         up = gm_round(up);
-                        o[r] = f32_to_bf16(gm_round(g / (1.0f + expf(-g))) * up);
+                        o[r] = f32_to_bf16(gm_round(fo1_silu(g)) * up);
                     }
                     uint16_t* cp = p.C + (long long)n_seq * p.ldc + u * 16 + fg * 4;
                     if ((p.ldc & 3) == 0) {

@@ -49,8 +49,8 @@ struct GemmParams {
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
-    if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if (act == ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ACT_GELU) return fo1_gelu_erf(v);
+    if (act == ACT_SILU) return fo1_silu(v);
     return v;
 }
 
@@ -89,7 +89,7 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FN][F
                         if (p.bias) { g += bf16_to_f32(p.bias[n0 + r]); u += bf16_to_f32(p.bias[n0 + 16 + r]); }
                         g = round_bf16(g);
                         u = round_bf16(u);
-                        o[r] = round_bf16(g / (1.0f + expf(-g))) * u;
+                        o[r] = round_bf16(fo1_silu(g)) * u;
                     }
                     uint2 ov;
                     ov.x = pack_bf16x2(o[0], o[1]);
@@ -555,8 +555,8 @@ __device__ __forceinline__ void tile_coords_grouped(const GemmParams& p, int& tm
 
 template <int ACT>
 __device__ __forceinline__ float act_apply_t(float v) {
-    if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if constexpr (ACT == ACT_SILU) return v / (1.0f + expf(-v));
+    if constexpr (ACT == ACT_GELU) return fo1_gelu_erf(v);
+    if constexpr (ACT == ACT_SILU) return fo1_silu(v);
     return v;
 }
 
@@ -564,7 +564,7 @@ __device__ __forceinline__ float act_apply_t(float v) {
 //   acc[mf][nf][r] = C[m_base + mf*32 + (lane & 31)][n_base + nf*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)]
 // EPI: 0..2 = bias -> bf16 -> act EPI -> bf16 -> +residual -> bf16 (the reference's rounding points); 3 = interleaved SwiGLU;
 // 4 = raw fp32 partials of this K split.  The variant is a template parameter so that each instantiation's 32 unrolled
-// store groups stay small (erff / expf inlined 128 times blow the unroll budget and push the accumulators to scratch).
+// store groups stay small (the activations inlined 128 times blow the unroll budget and push the accumulators to scratch).
 template <int EPI, int MF, int NF>
 __device__ __forceinline__ void epilogue32(const GemmParams& p, f32x16 (&acc)[MF][NF], int m_base, int n_base, int lane, long long offC,
                                            long long offR, int split) {
@@ -604,7 +604,7 @@ __device__ __forceinline__ void epilogue32(const GemmParams& p, f32x16 (&acc)[MF
                         if (p.bias && nb < p.N) { gt += bf16_to_f32(p.bias[nb + f0 + r]); up += bf16_to_f32(p.bias[nb + 16 + f0 + r]); }
                         gt = round_bf16(gt);
                         up = round_bf16(up);
-                        o[r] = round_bf16(gt / (1.0f + expf(-gt))) * up;
+                        o[r] = round_bf16(fo1_silu(gt)) * up;
                     }
                     uint2 ov;
                     ov.x = pack_bf16x2(o[0], o[1]);
@@ -676,7 +676,7 @@ __device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16
                         if (p.bias && nb < p.N) { gt += bf16_to_f32(p.bias[nb + f0 + t]); up += bf16_to_f32(p.bias[nb + 16 + f0 + t]); }
                         gt = round_bf16(gt);
                         up = round_bf16(up);
-                        o[t] = round_bf16(gt / (1.0f + expf(-gt))) * up;
+                        o[t] = round_bf16(fo1_silu(gt)) * up;
                     }
                     uint2 ov;
                     ov.x = pack_bf16x2(o[0], o[1]);

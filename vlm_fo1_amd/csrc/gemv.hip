@@ -21,8 +21,8 @@ struct GemvParams {
 
 __device__ __forceinline__ float gv_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 __device__ __forceinline__ float gv_act(float v, int act) {
-    if (act == 1) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
-    if (act == 2) return v / (1.0f + expf(-v));
+    if (act == 1) return fo1_gelu_erf(v);
+    if (act == 2) return fo1_silu(v);
     return v;
 }
 __device__ __forceinline__ float gv_wave_sum(float v) {
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemvParams p) {
                 if (p.bias) { g += bf16_to_f32(p.bias[rows[j]]); u += bf16_to_f32(p.bias[rows[4 + j]]); }
                 g = gv_round(g);
                 u = gv_round(u);
-                v = gv_round(g / (1.0f + expf(-g))) * u;
+                v = gv_round(fo1_silu(g)) * u;
             } else {
                 v = acc[j][m];
                 if (p.bias) v += bf16_to_f32(p.bias[f]);

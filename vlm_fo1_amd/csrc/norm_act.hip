@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint16_t* __restrict_
         unpack8(*reinterpret_cast<const uint4*>(gu + (size_t)m * ldgu + F + c * 8), u);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float s = bf16_to_f32(f32_to_bf16(g[j] / (1.0f + expf(-g[j]))));
+            const float s = bf16_to_f32(f32_to_bf16(fo1_silu(g[j])));
             o[j] = s * u[j];
         }
         *reinterpret_cast<uint4*>(out + (size_t)m * ldo + c * 8) = pack8(o);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const uint16_t* __restric
         }
         if (act == 1) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) f[j] = 0.5f * f[j] * (1.0f + erff(f[j] * 0.70710678118654752440f));
+            for (int j = 0; j < 8; ++j) f[j] = fo1_gelu_erf(f[j]);
         }
         *reinterpret_cast<uint4*>(y + (size_t)m * ldy + c * 8) = pack8(f);
     }
