@@ -495,6 +495,23 @@ int fo1_patchify_u8_bf16(const void* image_hwc_u8, int H, int W, const void* lut
                          int patch, int merge, void* stream);
 int fo1_normalize_u8_bf16(const void* image_hwc_u8, int H, int W, const void* lut_bf16, void* out_chw, void* stream);
 
+/* ------------------------------------------------------------------------
+ * Multi-scale deformable attention, forward  (the UPN proposal detector's operator, the reference's only
+ * native code).  Replaces MSDA.ms_deform_attn_forward (detect_tools/upn/ops/src/ms_deform_attn.h:21-36 ->
+ * ops/src/cuda/ms_deform_attn_cuda.cu:25-80 -> ms_deformable_im2col_gpu_kernel, ops/src/cuda/ms_deform_im2col_cuda.cuh:237-299,
+ * bilinear helper :32-84), called by MSDeformAttnFunction.forward (ops/functions/ms_deform_attn_func.py:23-28) from
+ * MSDeformAttn.forward (ops/modules/ms_deform_attn.py:186-202).  The reference's `im2col_step` only batches its launches and
+ * has no counterpart.  Backward (training) is not built: the reference path is inference.
+ *   value [N, S, M, D] (S = sum H_l W_l, level-major); spatial_shapes int64 [L, 2] = (H_l, W_l) and level_start_index
+ *   int64 [L], both ON THE DEVICE as the reference passes them; sampling_loc [N, Lq, M, L, P, 2] = (x, y), the unit square is
+ *   the map, zero padding outside; attn_weight [N, Lq, M, L, P]; out [N, Lq, M * D].  All contiguous.
+ *   dtype 0: everything fp32 (the reference's default);  1: everything fp64 (the reference test's double check);
+ *   2: value / out bf16, sampling_loc / attn_weight fp32 (engine form).  fp32 (fp64 for dtype 1) accumulation in the
+ *   reference's operation order. */
+int fo1_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                               const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
+                               int P, void* out, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT_DIR = os.path.join(HERE, "_build")
 LIB = os.path.join(OUT_DIR, "liboracle.so")
-SOURCES = ["roi_align_ref.c"]
+SOURCES = ["roi_align_ref.c", "msda_ref.c"]
 
 
 def build(force: bool = False) -> str:

@@ -639,3 +639,39 @@ def normalize_u8(image_hwc: torch.Tensor, lut: torch.Tensor) -> torch.Tensor:
     _L.check(_L.load().fo1_normalize_u8_bf16(image_hwc.data_ptr(), H, W, lut.data_ptr(), out.data_ptr(), _stream()),
              "fo1_normalize_u8_bf16")
     return out
+
+
+# ---- multi-scale deformable attention (msda.hip; UPN proposal detector) ----------------------------------
+def ms_deform_attn(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, sampling_locations: torch.Tensor,
+                   attention_weights: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """value [N, S, M, D] (fp32 | fp64 | bf16), spatial_shapes int64 [L, 2] and level_start_index int64 [L] on the device,
+    sampling_locations [N, Lq, M, L, P, 2], attention_weights [N, Lq, M, L, P] (value's dtype; fp32 when value is bf16)
+    -> [N, Lq, M*D] in value's dtype (fo1_ms_deform_attn_forward)."""
+    for t, name in ((value, "value"), (spatial_shapes, "spatial_shapes"), (level_start_index, "level_start_index"),
+                    (sampling_locations, "sampling_locations"), (attention_weights, "attention_weights")):
+        if not t.is_cuda:
+            raise RuntimeError(f"ms_deform_attn: {name} must live on the GPU (no CPU path exists)")
+        if not t.is_contiguous():
+            raise ValueError(f"ms_deform_attn: {name} must be contiguous")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64:
+        raise TypeError("ms_deform_attn: spatial_shapes / level_start_index must be int64 (as the reference passes them)")
+    N, S, M, D = value.shape
+    _, Lq, M2, L, P, two = sampling_locations.shape
+    if M2 != M or two != 2 or tuple(attention_weights.shape) != (N, Lq, M, L, P) or tuple(spatial_shapes.shape) != (L, 2) or level_start_index.numel() != L:
+        raise ValueError("ms_deform_attn: inconsistent shapes")
+    if value.dtype == torch.float32:
+        dt, lt = 0, torch.float32
+    elif value.dtype == torch.float64:
+        dt, lt = 1, torch.float64
+    elif value.dtype == torch.bfloat16:
+        dt, lt = 2, torch.float32
+    else:
+        raise TypeError(f"ms_deform_attn: value dtype {value.dtype} not built (float32, float64, bfloat16)")
+    if sampling_locations.dtype != lt or attention_weights.dtype != lt:
+        raise TypeError(f"ms_deform_attn: sampling_locations / attention_weights must be {lt} for {value.dtype} values")
+    if out is None:
+        out = torch.empty(N, Lq, M * D, dtype=value.dtype, device=value.device)
+    rc = _L.load().fo1_ms_deform_attn_forward(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_locations.data_ptr(),
+                                              attention_weights.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), dt, _stream())
+    _L.check(rc, "fo1_ms_deform_attn_forward")
+    return out
