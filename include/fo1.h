@@ -166,7 +166,10 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
  * (8 waves); split-K 0 auto / n forced; per-shape kernel names in the profile. */
 int fo1_gemm_set_variant(int staging, int tile);
 int fo1_gemm_set_splitk(int splits);
-int fo1_gemm_set_big_schedule(int sched); /* 256x256 kernel: 0 = four phases per K tile, 1 = two fat phases, DMA between MFMAs */
+int fo1_gemm_set_big_schedule(int sched); /* 256x256 kernel, bit field: bit 0 = two fat phases per K tile with the DMA issued between MFMAs
+                                            * (0 = four phases); bit 1 = fragment-shaped epilogue stores (0 = LDS-staged coalesced);
+                                            * bit 2 = persistent tile loop (the next tile's first DMA under the epilogue, when there
+                                            * are more than 256 tiles; bit-identical, measured 2-5 % slower).  Default 1. */
 int fo1_gemm_set_debug(int bits); /* ablation for benches only: 1 no global loads, 2 no MFMA, 4 no LDS reads + MFMA (results invalid) */
 int fo1_gemm_set_gemv(int on);   /* M <= 4 goes to the weight-streaming GEMV kernel (default on) */
 int fo1_gemm_profile_shapes(int on);

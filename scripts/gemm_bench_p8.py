@@ -16,7 +16,7 @@ SHAPES = [
     ("fpn3x3_l0", B * 25024, 512, 4608), ("merger1", B * 391, 5120, 5120),
     ("sq4096", 4096, 4096, 4096), ("sq8192", 8192, 8192, 8192),
 ]
-VARIANTS = [("p4_frag_epi", 0, 5, 1, 3), ("p4_coal_epi", 0, 5, 1, 1)]
+VARIANTS = [("p4_persistent", 0, 5, 1, 1 | 4), ("p4_one_tile", 0, 5, 1, 1), ("p4_persistent", 0, 5, 1, 1 | 4), ("p4_one_tile", 0, 5, 1, 1)]
 res = []
 for name, M, N, K in SHAPES:
     a = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()
@@ -40,7 +40,7 @@ for name, M, N, K in SHAPES:
         ms = e0.elapsed_time(e1) / iters
         tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
         res.append(dict(shape=name, M=M, N=N, K=K, variant=label, us=round(ms * 1e3, 2), tflops=round(tf, 1)))
-        print(f"{name:14s} M={M:6d} N={N:6d} K={K:6d} {label:9s}: {ms*1e3:9.2f} us  {tf:8.1f} TF/s", flush=True)
+        print(f"{name:14s} M={M:6d} N={N:6d} K={K:6d} {label:13s}: {ms*1e3:9.2f} us  {tf:8.1f} TF/s", flush=True)
     del ws
 L.load().fo1_gemm_set_variant(0, 0)
 L.load().fo1_gemm_set_splitk(0)

@@ -529,3 +529,41 @@ def test_gemm_p8_swiglu_and_one_hot(sched):
     finally:
         L.load().fo1_gemm_set_variant(0, 0)
         L.load().fo1_gemm_set_big_schedule(1)
+
+
+def test_gemm_persistent_tile_loop_equals_one_tile_per_workgroup():
+    """gemm_bt_p4p_kernel (256 persistent workgroups, the K loop running on across output tiles, epilogue through 4 KiB LDS strips)
+    against gemm_bt_p4_kernel (one tile per workgroup): the per-tile arithmetic is the same instruction sequence, so the results
+    must be BIT-IDENTICAL — for every epilogue, with ragged M / N edges, for more than 256 tiles (the persistent form's trigger) —
+    and identical run to run (race screen for the hand-over of the LDS image between tiles); plus the usual check against fp32."""
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(57)
+    shapes = [  # M, N, K, bias, residual, act
+        (5216, 22016, 2048, False, False, ops.ACT_SWIGLU16),     # LLM gate/up of an 8-image pass: 1806 tiles, 7 per workgroup
+        (12512, 3840, 1280, True, False, ops.ACT_NONE),          # ViT qkv: 735 tiles
+        (18768, 1280, 3456, True, True, ops.ACT_NONE),           # ViT down + residual (12 images): 370 tiles
+        (9600, 4096, 1024, True, False, ops.ACT_GELU),           # DaViT fc1 + GELU: 608 tiles
+        (6000, 3000, 1280, True, True, ops.ACT_SILU),            # ragged M and N edges: 24 x 12 tiles
+        (7000, 2816, 128, False, True, ops.ACT_NONE),            # two k-tiles only: every k-tile is a hand-over tile
+    ]
+    try:
+        for (M, N, K, hb, hr, act) in shapes:
+            a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+            w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+            bias = (torch.randn(N) * 0.1).to(BF).cuda() if hb else None
+            res = torch.randn(M, N).to(BF).cuda() if hr else None
+            L.check(L.load().fo1_gemm_set_variant(0, 5), "variant")
+            L.check(L.load().fo1_gemm_set_big_schedule(1), "schedule")          # one tile per workgroup (default)
+            one = ops.gemm(a, w, bias, res, act)
+            L.check(L.load().fo1_gemm_set_big_schedule(1 | 4), "schedule")      # persistent tile loop
+            per = ops.gemm(a, w, bias, res, act)
+            assert torch.equal(per, one), f"persistent != one-tile-per-workgroup at {M}x{N}x{K} act={act}: {(per.float() - one.float()).abs().max().item():.4g}"
+            for _ in range(8):
+                assert torch.equal(ops.gemm(a, w, bias, res, act), per), f"persistent gemm {M}x{N}x{K}: two launches differ (race)"
+            if act != ops.ACT_SWIGLU16:
+                ref = gemm_ref(a, w, bias, res, act)
+                err = (per.float().cpu() - ref).abs().max().item()
+                assert err <= 2e-2 * ref.abs().max().item() + 1e-3, f"persistent gemm {M}x{N}x{K}: max err {err:.4g}"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_big_schedule(1)

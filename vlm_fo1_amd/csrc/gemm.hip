@@ -539,9 +539,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // grouped tile order inside each XCD's contiguous run: 8 tile rows x consecutive tile columns, so the ~32 tiles an XCD
 // runs at once share 8 A panels and 4 W panels in its L2
-__device__ __forceinline__ void tile_coords_grouped(const GemmParams& p, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords_grouped_id(const GemmParams& p, int bid, int& tm, int& tn) {
     const int nwg = p.tiles_m * p.tiles_n;
-    const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     constexpr int GM = 8;
@@ -552,6 +551,7 @@ __device__ __forceinline__ void tile_coords_grouped(const GemmParams& p, int& tm
     tm = first + in % gsz;
     tn = in / gsz;
 }
+__device__ __forceinline__ void tile_coords_grouped(const GemmParams& p, int& tm, int& tn) { tile_coords_grouped_id(p, blockIdx.x, tm, tn); }
 
 template <int ACT>
 __device__ __forceinline__ float act_apply_t(float v) {
@@ -1106,6 +1106,283 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
 }
 
+// Coalesced epilogue through a 4 KiB wave-private LDS strip (persistent kernel: the 128 KiB image is busy with the next tile):
+// the wave's 128 x 64 block in four passes of 32 rows.  Same arithmetic, rounding points and store shapes as epilogue32_coalesced.
+template <int EPI>
+__device__ __forceinline__ void epilogue32_strip(const GemmParams& p, f32x16 (&acc)[4][2], char* strip, int m_base, int n_base, int lane,
+                                                 long long offC, long long offR) {
+    const int mi = lane & 31, hi = lane >> 5, hi4 = hi * 4;
+#pragma unroll
+    for (int mf = 0; mf < 4; ++mf) {
+        if constexpr (EPI == ACT_SWIGLU16) {
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf) {
+                const int nb = n_base + nf * 32;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int f0 = g * 8 + hi4;
+                    float o[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        float gt = acc[mf][nf][g * 4 + t], up = acc[mf][nf][8 + g * 4 + t];
+                        if (p.bias && nb < p.N) { gt += bf16_to_f32(p.bias[nb + f0 + t]); up += bf16_to_f32(p.bias[nb + 16 + f0 + t]); }
+                        gt = round_bf16(gt);
+                        up = round_bf16(up);
+                        o[t] = round_bf16(fo1_silu(gt)) * up;
+                    }
+                    uint2 ov;
+                    ov.x = pack_bf16x2(o[0], o[1]);
+                    ov.y = pack_bf16x2(o[2], o[3]);
+                    const int q = nf * 2 + g;
+                    *reinterpret_cast<uint2*>(strip + mi * 64 + ((q ^ (mi & 3)) << 4) + hi * 8) = ov;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int n_out = (n_base >> 1) + (lane & 3) * 8, No = p.N >> 1;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int r = it * 16 + (lane >> 2), m = m_base + mf * 32 + r;
+                const uint4 v = *reinterpret_cast<const uint4*>(strip + r * 64 + (((lane & 3) ^ (r & 3)) << 4));
+                if (m < p.M && n_out < No) *reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n_out) = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the strip is rewritten by the next pass
+        } else {
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n0 = n_base + nf * 32 + g * 8 + hi4;
+                    float v[4] = {acc[mf][nf][g * 4 + 0], acc[mf][nf][g * 4 + 1], acc[mf][nf][g * 4 + 2], acc[mf][nf][g * 4 + 3]};
+                    if (p.bias && n0 < p.N) {
+                        const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + n0);
+                        v[0] += bf16_lo(bv.x); v[1] += bf16_hi(bv.x); v[2] += bf16_lo(bv.y); v[3] += bf16_hi(bv.y);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = round_bf16(v[t]);
+                    if constexpr (EPI != ACT_NONE) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) v[t] = round_bf16(act_apply_t<EPI>(v[t]));
+                    }
+                    uint2 ov;
+                    ov.x = pack_bf16x2(v[0], v[1]);
+                    ov.y = pack_bf16x2(v[2], v[3]);
+                    const int q = nf * 4 + g;
+                    *reinterpret_cast<uint2*>(strip + mi * 128 + ((q ^ (mi & 7)) << 4) + hi * 8) = ov;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const int n = n_base + (lane & 7) * 8;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int r = it * 8 + (lane >> 3), m = m_base + mf * 32 + r;
+                uint4 v = *reinterpret_cast<const uint4*>(strip + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+                if (m < p.M && n < p.N) {
+                    if (p.res) {
+                        const uint4 rv = *reinterpret_cast<const uint4*>(p.res + offR + (long long)m * p.ldr + n);
+                        v.x = pack_bf16x2(bf16_lo(v.x) + bf16_lo(rv.x), bf16_hi(v.x) + bf16_hi(rv.x));
+                        v.y = pack_bf16x2(bf16_lo(v.y) + bf16_lo(rv.y), bf16_hi(v.y) + bf16_hi(rv.y));
+                        v.z = pack_bf16x2(bf16_lo(v.z) + bf16_lo(rv.z), bf16_hi(v.z) + bf16_hi(rv.z));
+                        v.w = pack_bf16x2(bf16_lo(v.w) + bf16_lo(rv.w), bf16_hi(v.w) + bf16_hi(rv.w));
+                    }
+                    *reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the strip is rewritten by the next pass
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// PERSISTENT form of gemm_bt_p4_kernel: one workgroup per CU walks its output tiles (virtual id = blockIdx.x + i * gridDim.x in the
+// same grouped XCD order) and the K loop simply continues into the next tile: the last two k-tiles of a tile stage the first
+// tile and a half of the next one (the DMA source pointers are switched group by group as each group's last use passes), so
+// a tile no longer starts with an exposed DMA round trip and its epilogue (stores, residual loads) overlaps those loads.  The
+// epilogue therefore cannot use the LDS image: it goes through eight 4 KiB strips beside it (160 KiB of LDS in all).
+// Requirements (dispatcher): K / 64 even, no split-K, no batch stride, coalescable C (as epilogue32_coalesced).
+// MEASURED (MI355X, profiles/r02_gemm_persistent_ab.log, interleaved A/B on the packed-pass shapes): bit-identical to the one-tile kernel
+// and 2-5 % SLOWER on every shape with more than 256 tiles (ViT qkv 947 vs 993 TFLOP/s, LLM gate/up 1111 vs 1142, 8192^3 1293 vs 1350):
+// what the hidden prologue gains is lost again — every counted vmcnt wait after the epilogue also waits for the epilogue's own
+// stores (one in-order counter for loads and stores), and the chip is already power-limited in the main loop.  NOT the default;
+// kept selectable (fo1_gemm_set_big_schedule bit 2) with its bit-identity test.
+// ------------------------------------------------------------------------------------------
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bt_p4p_kernel(const GemmParams p) {
+    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int GROUP = 16384, BUFSZ = 4 * GROUP;       // A0 | A1 | B0 | B1
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUFSZ] | 8 epilogue strips of 4 KiB
+
+    const int n_tiles = p.tiles_m * p.tiles_n;
+    int vt = blockIdx.x;                 // virtual tile id; grid % 8 == 0 keeps every tile of this workgroup in its XCD's run
+    int tm, tn;
+    tile_coords_grouped_id(p, vt, tm, tn);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool late = wave >= 4;
+    const long long bz = 0;              // no batch dimension in the persistent form
+    const uint16_t* A = p.A + bz * p.sA;
+    const uint16_t* W = p.W + bz * p.sW;
+
+    const uint16_t* src[4][2];
+    // DMA source pointers of group g (0, 1 = A halves; 2, 3 = W halves) for output tile (tm_, tn_)
+    auto set_src = [&](int g, int tm_, int tn_) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int lr = wave * 16 + i * 8 + (lane >> 3);
+            const int cs = ((lane & 7) ^ ((lr >> 1) & 7)) * 8;
+            if (g < 2) {
+                int gm = tm_ * BM + (lr >> 6) * 128 + g * 64 + (lr & 63);
+                gm = gm < p.M ? gm : p.M - 1;
+                src[g][i] = A + (long long)gm * p.lda + cs;
+            } else {
+                int gn = tn_ * BN + (lr >> 5) * 64 + (g - 2) * 32 + (lr & 31);
+                gn = gn < p.N ? gn : p.N - 1;
+                src[g][i] = W + (long long)gn * p.ldw + cs;
+            }
+        }
+    };
+#pragma unroll
+    for (int g = 0; g < 4; ++g) set_src(g, tm, tn);
+    const int nk = p.K / BK;             // even, >= 2 (host-checked); no split-K in the persistent form
+    constexpr int kt0 = 0;
+    auto stage = [&](int g, int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* dst = smem + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;
+            const uint16_t* s = (g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i]) + (long long)(kt0 + kt) * BK;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    const int hi = lane >> 5;
+    int a_off[2], a_sw[2];
+#pragma unroll
+    for (int fm = 0; fm < 2; ++fm) {
+        const int lr = wm * 64 + fm * 32 + (lane & 31);
+        a_off[fm] = lr * 128;
+        a_sw[fm] = (lr >> 1) & 7;
+    }
+    const int b_lr = wn * 32 + (lane & 31);
+    const int b_off = b_lr * 128, b_sw = (b_lr >> 1) & 7;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    bf16x8 areg[2][4], breg[2][4];
+
+    // prologue: tile 0 complete; A0, B0 of tile 1 in flight (its B1, A1 are issued in MFMA-X(0))
+    stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
+    if (nk > 1) {
+        stage(0, 1, 1); stage(2, 1, 1);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    FO1_P8_BARRIER();
+    if (late) FO1_P8_BARRIER();
+
+    bool has_next = false;
+    int tmn = 0, tnn = 0;
+    // The k-loop runs on ACROSS output tiles: k-tile nk of this tile is k-tile 0 of the workgroup's next tile, staged by the same
+    // schedule (so the next tile starts with its first tile and a half already in LDS, and the hazards are the in-loop ones).
+    auto tile = [&](auto BUFC, int t) {
+        constexpr int BUF = decltype(BUFC)::value;
+        const char* base = smem + BUF * BUFSZ;
+        const bool more1 = t + 1 < nk || has_next, more2 = t + 2 < nk || has_next;
+        const int k1 = t + 1 < nk ? t + 1 : t + 1 - nk, k2 = t + 2 < nk ? t + 2 : t + 2 - nk;
+        if (has_next && t == nk - 1) { set_src(1, tmn, tnn); set_src(3, tmn, tnn); }   // MFMA-X stages A1, B1 of the next tile's k-tile 0
+        auto loadA = [&](int h) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int fm = 0; fm < 2; ++fm)
+                    areg[fm][ks] = *reinterpret_cast<const bf16x8*>(base + h * GROUP + a_off[fm] + (((ks * 2 + hi) ^ a_sw[fm]) << 4));
+        };
+        auto loadB = [&](int h) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                breg[h][ks] = *reinterpret_cast<const bf16x8*>(base + (2 + h) * GROUP + b_off + (((ks * 2 + hi) ^ b_sw) << 4));
+        };
+        auto end_load = [&]() {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            FO1_P8_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto end_mfma = [&](bool last) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(last && late)) FO1_P8_BARRIER();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#define FO1_P4_MFMA4(AH, KS)                                                                                                       \
+    acc[(AH) * 2 + 0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[0][KS], areg[0][KS], acc[(AH) * 2 + 0][0], 0, 0, 0);       \
+    acc[(AH) * 2 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[0][KS], areg[1][KS], acc[(AH) * 2 + 1][0], 0, 0, 0);       \
+    acc[(AH) * 2 + 0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[1][KS], areg[0][KS], acc[(AH) * 2 + 0][1], 0, 0, 0);       \
+    acc[(AH) * 2 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[1][KS], areg[1][KS], acc[(AH) * 2 + 1][1], 0, 0, 0);
+        // ---- phase X ----
+        loadB(0);
+        loadB(1);
+        loadA(0);
+        // A1 of this tile (issued in MFMA-X(t-1)) must have landed before load-Y; only MFMA-Y(t-1)'s A0, B0 of tile t+1 are newer
+        if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        end_load();
+        __builtin_amdgcn_s_setprio(1);
+        FO1_P4_MFMA4(0, 0)
+        if (more1) stage(3, k1, BUF ^ 1);
+        FO1_P4_MFMA4(0, 1)
+        FO1_P4_MFMA4(0, 2)
+        if (more1) stage(1, k1, BUF ^ 1);
+        FO1_P4_MFMA4(0, 3)
+        __builtin_amdgcn_s_setprio(0);
+        end_mfma(false);
+        // ---- phase Y ----
+        if (has_next && t == nk - 2) { set_src(0, tmn, tnn); set_src(2, tmn, tnn); }   // MFMA-Y stages A0, B0 of the next tile from here on
+        loadA(1);
+        if (more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        end_load();
+        __builtin_amdgcn_s_setprio(1);
+        FO1_P4_MFMA4(1, 0)
+        if (more2) stage(0, k2, BUF);
+        FO1_P4_MFMA4(1, 1)
+        FO1_P4_MFMA4(1, 2)
+        if (more2) stage(2, k2, BUF);
+        FO1_P4_MFMA4(1, 3)
+        __builtin_amdgcn_s_setprio(0);
+        // the lagging half skips the last barrier of EVERY output tile (both halves then run their epilogues side by side, as in
+        // the one-tile kernel) and re-enters the stagger with one extra barrier after its epilogue
+        end_mfma(t == nk - 1);
+#undef FO1_P4_MFMA4
+    };
+    for (;;) {
+        const int vnext = vt + gridDim.x;
+        has_next = vnext < n_tiles;
+        if (has_next) tile_coords_grouped_id(p, vnext, tmn, tnn);
+        for (int t = 0; t < nk; t += 2) {
+            tile(std::integral_constant<int, 0>{}, t);
+            tile(std::integral_constant<int, 1>{}, t + 1);
+        }
+        // epilogue through this wave's own 4 KiB strip BESIDE the LDS image (which already holds the next tile's first k-tiles)
+        epilogue32_strip<EPI>(p, acc, smem + 2 * BUFSZ + wave * 4096, tm * BM + wm * 128, tn * BN + wn * 64, lane, bz * p.sC, bz * p.sR);
+        if (!has_next) break;
+        if (late) FO1_P8_BARRIER();
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        vt = vnext;
+        tm = tmn;
+        tn = tnn;
+    }
+}
+
+static int g_gemm_persist = 0;     // 256x256 kernels: 1 = persistent tile loop with the next tile's first DMA under the epilogue (measured 2-5 % SLOWER than one tile per workgroup, see gemm_bt_p4p_kernel)
 static int g_gemm_coal = 1;        // 256x256 kernels: LDS-staged coalesced epilogue (0 = fragment-shaped stores, for A/B)
 static int g_gemm_big_sched = 1;   // 256x256 kernel schedule: 0 = four phases per K tile (p8), 1 = two fat phases with DMA issued between MFMAs (p4, default: +3..10 % measured, profiles/r02_gemm_bench_p8_v2.log)
 
@@ -1137,6 +1414,26 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         attr_done = true;
     }
     const int epi = p.splits > 1 ? 4 : p.act;
+    const int n_tiles = p.tiles_m * p.tiles_n, nk64 = p.K / 64;
+    if (g_gemm_big_sched == 1 && g_gemm_persist && p.splits == 1 && batch == 1 && p.coal && n_tiles > 256 && nk64 >= 2 && nk64 % 2 == 0) {
+        // persistent form: 256 workgroups (one per CU, a multiple of 8: every workgroup stays in its XCD's run of tiles)
+        constexpr int smem_p = 2 * 4 * 16384 + 8 * 4096;
+        static bool attrp = false;
+        if (!attrp) {
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4p_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p));
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4p_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p));
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4p_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p));
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4p_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem_p));
+            attrp = true;
+        }
+        const char* np = (profile_enabled() && g_gemm_profile_shapes) ? name : "gemm_bt_p4p<256,256>";
+        const dim3 gp(256, 1, 1);
+        if (epi == 0) FO1_LAUNCH(np, flops, gemm_bt_p4p_kernel<0>, gp, dim3(512), smem_p, st, p);
+        else if (epi == 1) FO1_LAUNCH(np, flops, gemm_bt_p4p_kernel<1>, gp, dim3(512), smem_p, st, p);
+        else if (epi == 2) FO1_LAUNCH(np, flops, gemm_bt_p4p_kernel<2>, gp, dim3(512), smem_p, st, p);
+        else FO1_LAUNCH(np, flops, gemm_bt_p4p_kernel<3>, gp, dim3(512), smem_p, st, p);
+        return FO1_OK;
+    }
     if (g_gemm_big_sched == 1) {
         static bool attr4 = false;
         if (!attr4) {
@@ -1317,10 +1614,12 @@ int fo1_gemm_set_variant(int staging, int tile) {
 }
 
 int fo1_gemm_set_big_schedule(int sched) {
-    // bit 0: 0 = four phases per K tile, 1 = two fat phases;  bit 1 set = fragment-shaped (un-coalesced) epilogue stores
-    if (sched < 0 || sched > 3) return fo1::set_err(FO1_ERR_ARG, "gemm: bad 256x256 schedule %d", sched);
+    // bit 0: 0 = four phases per K tile, 1 = two fat phases;  bit 1 set = fragment-shaped (un-coalesced) epilogue stores;
+    // bit 2 set = persistent tile loop (gemm_bt_p4p_kernel) instead of one output tile per workgroup
+    if (sched < 0 || sched > 7) return fo1::set_err(FO1_ERR_ARG, "gemm: bad 256x256 schedule %d", sched);
     fo1::g_gemm_big_sched = sched & 1;
     fo1::g_gemm_coal = (sched & 2) ? 0 : 1;
+    fo1::g_gemm_persist = (sched & 4) ? 1 : 0;
     return FO1_OK;
 }
 
