@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--inflight", type=int, default=2, help="independent passes in flight per GPU (engine replicas on their own HIP "
                     "streams); 1 = strictly one pass at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--main-only", action="store_true", help="skip the side measurements (one image / one pass at a time, decode loops, preprocessing): "
+                    "only packed passes of the main workload run — what a rocprofv3 / PMC pass of this command should see, so that its "
+                    "per-kernel averages are over the same launches as the roofline block's")
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed oracle passes (median) after one warm-up pass")
     ap.add_argument("--cpu-decode-tokens", type=int, default=64)
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
@@ -313,7 +316,7 @@ def main():
 
     # ---- side measurements on rank 0 (never `value`): one packed pass at a time, and strictly one image at a time ----
     single = one_pass = None
-    if rank == 0:
+    if rank == 0 and not args.main_only:
         if R > 1 or B > 1:
             for _ in range(3):
                 pipe.step_single(use_graph)
@@ -337,7 +340,7 @@ def main():
 
     # ---- greedy decode through the KV cache (fixed K new tokens, reported separately; not part of `value`) ----
     dec = None
-    if rank == 0:
+    if rank == 0 and not args.main_only:
         K = 32
         out = pipe.step_single(use_graph)
         tok = out["next_token"]
@@ -409,7 +412,7 @@ def main():
 
     # ---- host-side preprocessing of one image (SURVEY 8d "preprocess (CPU)" stage, 8f rank 2): not part of `value` ----
     prep = None
-    if rank == 0:
+    if rank == 0 and not args.main_only:
         import numpy as np
         from PIL import Image
         from vlm_fo1.model.image_processing import CLIPStyleAuxProcessor, Qwen2VLPatchProcessor

@@ -515,6 +515,19 @@ int fo1_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes,
                                const void* sampling_loc, const void* attn_weight, int N, int S, int M, int D, int L, int Lq,
                                int P, void* out, int dtype, void* stream);
 
+/* Fused MSDeformAttn core (the UPN encoder / decoder layers' attention between their Linear layers, ops/modules/ms_deform_attn.py:
+ * 133-202): softmax over each head's L*P logits, sampling locations from the reference points and raw offsets, bilinear gather and
+ * weighted sum in ONE launch — the [N,Lq,M,L,P,2] sampling_locations and [N,Lq,M,L,P] attention_weights tensors never exist.
+ *   value bf16 [N, S, M*D] (value_proj output); offsets_logits fp32 [N, Lq, M*L*P*3] = one GEMM whose weight rows are
+ *   [sampling_offsets (M*L*P*2) | attention_weights (M*L*P)]; reference_points fp32 [N, Lq, L, ref_dim], ref_dim 2 (points:
+ *   loc = ref + off / (W_l, H_l), :150-157) or 4 (boxes cx, cy, w, h: loc = ref[:2] + off / P * ref[2:] * 0.5, :169-175);
+ *   out bf16 [N, Lq, M*D] (input of output_proj).  D % 8 == 0. */
+int fo1_msda_fused_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
+                        const float* offsets_logits, const float* reference_points, int ref_dim, int N, int S, int M, int D, int L,
+                        int Lq, int P, void* out, void* stream);
+/* y = bf16(a + b) over [M, D] bf16 rows (with_pos_embed of the DETR-style layers, encoder/upn_encoder.py:62-63). D % 8 == 0. */
+int fo1_add_bf16(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int M, int D, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

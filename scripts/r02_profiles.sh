@@ -6,11 +6,11 @@ ROOT=$(pwd); OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cut -c1-300 $OUT/bench.json
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $ROOT/bench.py --no-cpu-baseline --steps 12 > $OUT/rocprof.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof1 -o bench -- python $ROOT/bench.py --no-cpu-baseline --inflight 1 --steps 12 > $OUT/rocprof1.log 2>&1
-timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o b -- python $ROOT/bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
-timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o b -- python $ROOT/bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o b -- python $ROOT/bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/pmc_mfma.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $ROOT/bench.py --no-cpu-baseline --main-only --steps 12 > $OUT/rocprof.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof1 -o bench -- python $ROOT/bench.py --no-cpu-baseline --main-only --inflight 1 --steps 12 > $OUT/rocprof1.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o b -- python $ROOT/bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --main-only > $OUT/pmc_fetch.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o b -- python $ROOT/bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --main-only > $OUT/pmc_write.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_mfma -o b -- python $ROOT/bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline --main-only > $OUT/pmc_mfma.log 2>&1
 cd $ROOT
 cp $(find $OUT/prof -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 cp $(find $OUT/prof1 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_inflight1.csv

@@ -1,0 +1,111 @@
+"""Generates tests/golden/upn_ref.npz with the REFERENCE's own UPN modules (detect_tools/upn/models/*, ops/modules/ms_deform_attn.py)
+imported in place from /root/reference (this container only) and run on the CPU in fp32 with the seeded weights / inputs of
+tests/upn_cases.py.
+
+What is stubbed to make the reference importable here (none of it carries arithmetic of the path):
+  mmengine (Registry / build_from_cfg / Config: a 20-line registry), torchvision (import-time only), timm.models.layers
+  (DropPath = identity at inference, to_2tuple, trunc_normal_), and the compiled `MultiScaleDeformableAttention` extension,
+  whose forward is routed to the reference's own pure-torch ms_deform_attn_core_pytorch (ops/functions/ms_deform_attn_func.py:41-61).
+
+usage: python tests/golden/make_upn_golden.py"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import upn_cases as C  # noqa: E402
+
+OUT = os.path.join(HERE, "upn_ref.npz")
+
+
+def reference_upn():
+    """-> the reference's `detect_tools.upn` package, importable on this CPU-only box."""
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class Registry:
+        def __init__(self, name):
+            self.name, self.d = name, {}
+
+        def register_module(self, name=None, force=False, module=None):
+            def deco(cls):
+                self.d[cls.__name__] = cls
+                return cls
+            return deco
+
+        def get(self, k):
+            return self.d[k]
+
+    def build_from_cfg(cfg, registry, default_args=None):
+        cfg = dict(cfg)
+        return registry.get(cfg.pop("type"))(**cfg)
+
+    class Config:
+        @staticmethod
+        def fromfile(path):
+            ns = {}
+            exec(open(path).read(), ns)
+            return types.SimpleNamespace(**{k: v for k, v in ns.items() if not k.startswith("_")})
+
+    stub("mmengine", Registry=Registry, build_from_cfg=build_from_cfg, Config=Config)
+    tv = stub("torchvision")
+    tv._is_tracing = lambda: False
+    tv.ops = stub("torchvision.ops", nms=None)
+    tv.transforms = stub("torchvision.transforms")
+    tv.transforms.functional = stub("torchvision.transforms.functional")
+
+    class DropPath(torch.nn.Module):
+        def __init__(self, p=0.0):
+            super().__init__()
+
+        def forward(self, x):
+            return x
+
+    timm = stub("timm")
+    timm.models = stub("timm.models")
+    timm.models.layers = stub("timm.models.layers", DropPath=DropPath, to_2tuple=lambda x: x if isinstance(x, tuple) else (x, x),
+                              trunc_normal_=torch.nn.init.trunc_normal_)
+    msda = stub("MultiScaleDeformableAttention")
+    for k in [k for k in sys.modules if k == "detect_tools" or k.startswith("detect_tools.")]:
+        del sys.modules[k]                      # this repo's drop-in package must not shadow the reference's
+    sys.path.insert(0, "/root/reference")
+    import detect_tools.upn as U
+    assert U.__file__.startswith("/root/reference"), U.__file__
+    from detect_tools.upn.ops.functions.ms_deform_attn_func import ms_deform_attn_core_pytorch
+    msda.ms_deform_attn_forward = lambda v, s, ls, loc, w, step: ms_deform_attn_core_pytorch(v, s, loc, w)
+    return U
+
+
+def main():
+    U = reference_upn()
+    out = {}
+    # ---- deformable encoder, 2 layers, 5-level pyramid (models/encoder/upn_encoder.py) ----
+    enc = U.build_encoder(dict(type="UPNEncoder", num_layers=2, d_model=C.D_MODEL, use_checkpoint=False, use_transformer_ckpt=False,
+                               encoder_layer_cfg=dict(type="DeformableTransformerEncoderLayer", activation="relu", d_model=C.D_MODEL, dropout=0.0,
+                                                      d_ffn=C.D_FFN, n_heads=C.N_HEADS, n_levels=C.N_LEVELS))).eval()
+    missing, unexpected = enc.load_state_dict(C.encoder_state(2), strict=True), None
+    src, pos = C.encoder_inputs()
+    shapes = torch.as_tensor(C.ENC_SHAPES, dtype=torch.long)
+    ls = torch.as_tensor(C.level_start(C.ENC_SHAPES), dtype=torch.long)
+    with torch.no_grad():
+        hooks, inter = [], {}
+        hooks.append(enc.layers[0].self_attn.register_forward_hook(lambda m, i, o: inter.__setitem__("enc.layer0.self_attn", o.detach().clone())))
+        hooks.append(enc.layers[0].register_forward_hook(lambda m, i, o: inter.__setitem__("enc.layer0", o.detach().clone())))
+        mem = enc(src, pos, shapes, ls, torch.ones(1, C.N_LEVELS, 2), None)
+        for h in hooks:
+            h.remove()
+    out["enc.memory"] = mem.numpy()
+    out.update({k: v.numpy() for k, v in inter.items()})
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes", {k: v.shape for k, v in out.items()})
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,69 @@
+"""Seeded weights and inputs of the UPN (proposal detector) cases — shared by tests/golden/make_upn_golden.py, which feeds them to the
+reference's own modules imported in place, and by the oracle / GPU tests, which regenerate them bit for bit (CPU generator, same
+torch build on both boxes).  All values are bf16-representable fp32, so the engine's bf16 weights ARE the reference's fp32 weights."""
+import math
+
+import torch
+
+D_MODEL, N_HEADS, N_LEVELS, N_POINTS, D_FFN = 256, 8, 5, 4, 2048     # reference configs/upn_large.py
+ENC_SHAPES = [(12, 16), (6, 8), (3, 4), (2, 2), (1, 1)]              # a small 5-level pyramid (S = 257)
+
+
+def _bf(t):
+    return t.bfloat16().float()
+
+
+def level_start(shapes):
+    out = [0]
+    for h, w in shapes[:-1]:
+        out.append(out[-1] + h * w)
+    return out
+
+
+def msda_module_state(g, prefix, d=D_MODEL, M=N_HEADS, L=N_LEVELS, P=N_POINTS):
+    """State of one MSDeformAttn (reference ops/modules/ms_deform_attn.py:70-73): random projections + the reference's own
+    ring-shaped offset bias (:77-90) so that the sampling points spread over several pixels."""
+    thetas = torch.arange(M, dtype=torch.float32) * (2.0 * math.pi / M)
+    grid = torch.stack([thetas.cos(), thetas.sin()], -1)
+    grid = (grid / grid.abs().max(-1, keepdim=True)[0]).view(M, 1, 1, 2).repeat(1, L, P, 1)
+    for i in range(P):
+        grid[:, :, i, :] *= i + 1
+    s = {
+        prefix + "sampling_offsets.weight": torch.randn(M * L * P * 2, d, generator=g) * 0.02,
+        prefix + "sampling_offsets.bias": grid.reshape(-1) + torch.randn(M * L * P * 2, generator=g) * 0.1,
+        prefix + "attention_weights.weight": torch.randn(M * L * P, d, generator=g) * 0.05,
+        prefix + "attention_weights.bias": torch.randn(M * L * P, generator=g) * 0.2,
+        prefix + "value_proj.weight": torch.randn(d, d, generator=g) / 16.0,
+        prefix + "value_proj.bias": torch.randn(d, generator=g) * 0.05,
+        prefix + "output_proj.weight": torch.randn(d, d, generator=g) / 16.0,
+        prefix + "output_proj.bias": torch.randn(d, generator=g) * 0.05,
+    }
+    return {k: _bf(v) for k, v in s.items()}
+
+
+def _norm_state(g, prefix, d):
+    return {prefix + "weight": _bf(1.0 + 0.1 * torch.randn(d, generator=g)), prefix + "bias": _bf(0.1 * torch.randn(d, generator=g))}
+
+
+def encoder_state(n_layers=2, seed=4242, d=D_MODEL, d_ffn=D_FFN):
+    """State dict of the reference's UPNEncoder (models/encoder/upn_encoder.py): layers.{i}.{self_attn.*, norm1, linear1, linear2, norm2}."""
+    g = torch.Generator().manual_seed(seed)
+    s = {}
+    for i in range(n_layers):
+        p = f"layers.{i}."
+        s.update(msda_module_state(g, p + "self_attn."))
+        s.update(_norm_state(g, p + "norm1.", d))
+        s[p + "linear1.weight"] = _bf(torch.randn(d_ffn, d, generator=g) / 16.0)
+        s[p + "linear1.bias"] = _bf(torch.randn(d_ffn, generator=g) * 0.05)
+        s[p + "linear2.weight"] = _bf(torch.randn(d, d_ffn, generator=g) / 45.0)
+        s[p + "linear2.bias"] = _bf(torch.randn(d, generator=g) * 0.05)
+        s.update(_norm_state(g, p + "norm2.", d))
+    return s
+
+
+def encoder_inputs(shapes=ENC_SHAPES, seed=77, d=D_MODEL):
+    g = torch.Generator().manual_seed(seed)
+    S = sum(h * w for h, w in shapes)
+    src = _bf(torch.randn(1, S, d, generator=g))
+    pos = _bf(torch.randn(1, S, d, generator=g) * 0.5)
+    return src, pos

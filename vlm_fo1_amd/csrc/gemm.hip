@@ -46,11 +46,12 @@ struct GemmParams {
     int coal;                  // 256x256 kernels: epilogue staged through LDS and written as whole 128-byte row segments (16-B stores)
 };
 
-enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3 };
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3, ACT_RELU = 5 };   // (4 = the split-K partial epilogue of the 256x256 kernels)
 
 __device__ __forceinline__ float act_apply(float v, int act) {
     if (act == ACT_GELU) return fo1_gelu_erf(v);
     if (act == ACT_SILU) return fo1_silu(v);
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
     return v;
 }
 
@@ -1586,7 +1587,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
     }
     const bool p8_ok = glds && p.C32 == nullptr && p.N % 4 == 0 && p.ldc % 4 == 0 && ((uintptr_t)p.C & 7) == 0 && p.sC % 4 == 0 &&
                        (p.bias == nullptr || ((uintptr_t)p.bias & 7) == 0) &&
-                       (p.res == nullptr || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 7) == 0 && p.sR % 4 == 0)) && (p.act != ACT_SWIGLU16 || p.N % 32 == 0);
+                       (p.res == nullptr || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 7) == 0 && p.sR % 4 == 0)) && (p.act != ACT_SWIGLU16 || p.N % 32 == 0) && p.act <= ACT_SWIGLU16;   // (ReLU: the smaller tiles' run-time activation)
     if (tile == 5 && p8_ok) {
         p.stages = 2;
         return launch_gemm_p8(p, batch, st);
@@ -1664,7 +1665,7 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
     FO1_CHECK_ARG(K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0, "gemm: K, lda, ldw must be multiples of 8 (K=%d lda=%d ldw=%d)", K, lda, ldw);
     FO1_CHECK_ARG(lda >= K && ldw >= K, "gemm: leading dimension too small");
     FO1_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0, "gemm: A/W must be 16-byte aligned");
-    FO1_CHECK_ARG(act >= 0 && act <= 3, "gemm: act=%d", act);
+    FO1_CHECK_ARG((act >= 0 && act <= 3) || act == 5, "gemm: act=%d (0 none, 1 GELU, 2 SiLU, 3 interleaved SwiGLU, 5 ReLU)", act);
     if (act == 3) {
         FO1_CHECK_ARG(!out_f32 && residual == nullptr && N % 32 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 7) == 0,
                       "gemm: swiglu epilogue needs bf16 out, no residual, N %% 32 == 0 (N=%d), ldc %% 4 == 0", N);

@@ -23,6 +23,7 @@ __device__ __forceinline__ float gv_round(float v) { return bf16_to_f32(f32_to_b
 __device__ __forceinline__ float gv_act(float v, int act) {
     if (act == 1) return fo1_gelu_erf(v);
     if (act == 2) return fo1_silu(v);
+    if (act == 5) return fmaxf(v, 0.0f);
     return v;
 }
 __device__ __forceinline__ float gv_wave_sum(float v) {
@@ -229,7 +230,7 @@ int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bi
     FO1_CHECK_ARG(x && W && C, "gemv: NULL operand");
     FO1_CHECK_ARG(M >= 1 && M <= 4 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "gemv: bad shape M=%d N=%d K=%d", M, N, K);
     FO1_CHECK_ARG((size_t)(M > 2 ? 4 : M) * K * 2 <= 150 * 1024, "gemv: x does not fit LDS (M=%d K=%d)", M, K);
-    FO1_CHECK_ARG(act >= 0 && act <= 3 && (act != 3 || (N % 32 == 0 && residual == nullptr)), "gemv: bad act/N");
+    FO1_CHECK_ARG(((act >= 0 && act <= 3) || act == 5) && (act != 3 || (N % 32 == 0 && residual == nullptr)), "gemv: bad act/N");
     FO1_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)norm_weight & 15) == 0, "gemv: misaligned operand");
     return gemv_dispatch(x, ldx, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, (hipStream_t)stream, norm_weight, norm_eps);
 }

@@ -98,6 +98,81 @@ __global__ __launch_bounds__(256) void msda_forward_kernel(const VT* __restrict_
     MsdaVec<VT, VEC>::store(out + item * D + c0, col);
 }
 
+// ---- fused form: softmax + sampling locations + gather in one launch ------------------------------------------------------------
+// MSDeformAttn.forward (ops/modules/ms_deform_attn.py:100-204) materialises sampling_offsets -> sampling_locations [N,Lq,M,L,P,2] and
+// softmax(attention_weights) [N,Lq,M,L,P] between its Linear layers and the operator (42 MB per UPN encoder layer).  Here the
+// operator takes the RAW output of the two Linear layers (one GEMM, fp32: [offsets M*L*P*2 | logits M*L*P] per query) and the
+// reference points, and forms on the fly
+//     loc = ref[l] + off / (W_l, H_l)                         (2-d reference points, :150-157)
+//     loc = ref[l][:2] + off / P * ref[l][2:] * 0.5           (4-d reference boxes, :169-175)
+//     w   = softmax over the head's L*P logits                (:143-147)
+// value / out are bf16 (engine form), everything else fp32.  A thread owns 8 channels of one (query, head); the softmax statistics
+// are recomputed by the D/8 threads of the head (L*P exps, from one cached line).
+template <int RD>
+__global__ __launch_bounds__(256) void msda_fused_kernel(const uint16_t* __restrict__ value, const long long* __restrict__ shapes,
+                                                         const long long* __restrict__ level_start, const float* __restrict__ ol,
+                                                         const float* __restrict__ ref, int S, int M, int D, int L, int Lq, int P,
+                                                         long long total, uint16_t* __restrict__ out) {
+    constexpr int VEC = 8;
+    const int tpi = D / VEC;
+    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const long long item = e / tpi;                            // (n * Lq + q) * M + m
+    const int c0 = (int)(e - item * tpi) * VEC;
+    const int m = (int)(item % M);
+    const long long nq = item / M;                             // n * Lq + q
+    const long long n = nq / Lq;
+    const int LP = L * P;
+    const float* row = ol + nq * ((long long)M * LP * 3);
+    const float* offp = row + (long long)m * LP * 2;           // [L][P][2]
+    const float* lgp = row + (long long)M * LP * 2 + (long long)m * LP;
+    const float* rp = ref + nq * ((long long)L * RD);
+    float mx = -INFINITY;
+    for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lgp[i]);
+    float den = 0.f;
+    for (int i = 0; i < LP; ++i) den += expf(lgp[i] - mx);
+    const float inv_den = 1.0f / den;
+    const long long w_stride = (long long)M * D;
+    float col[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) col[i] = 0.f;
+    for (int l = 0; l < L; ++l) {
+        const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
+        const uint16_t* vb = value + (n * S + level_start[l]) * w_stride + (long long)m * D + c0;
+        const long long h_stride = (long long)W * w_stride;
+        const float rx = rp[l * RD], ry = rp[l * RD + 1];
+        const float rw = RD == 4 ? rp[l * RD + 2] : 0.f, rh = RD == 4 ? rp[l * RD + 3] : 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float ox = offp[(l * P + p) * 2], oy = offp[(l * P + p) * 2 + 1];
+            const float aw = expf(lgp[l * P + p] - mx) * inv_den;
+            float loc_w, loc_h;
+            if (RD == 2) { loc_w = rx + ox / (float)W; loc_h = ry + oy / (float)H; }
+            else { loc_w = rx + ox / (float)P * rw * 0.5f; loc_h = ry + oy / (float)P * rh * 0.5f; }
+            const float h_im = loc_h * H - 0.5f, w_im = loc_w * W - 0.5f;
+            const bool inside = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_low = (int)hf, w_low = (int)wf;
+            const int h_high = h_low + 1, w_high = w_low + 1;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1 - lh, hw = 1 - lw;
+            const bool hl_ok = h_low >= 0 && h_low <= H - 1, hh_ok = h_high >= 0 && h_high <= H - 1;
+            const bool wl_ok = w_low >= 0 && w_low <= W - 1, wh_ok = w_high >= 0 && w_high <= W - 1;
+            const int hl = min(max(h_low, 0), H - 1), hh_i = min(max(h_high, 0), H - 1);
+            const int wl = min(max(w_low, 0), W - 1), wh_i = min(max(w_high, 0), W - 1);
+            float v1[VEC], v2[VEC], v3[VEC], v4[VEC];
+            MsdaVec<uint16_t, VEC>::load(vb + hl * h_stride + wl * w_stride, v1);
+            MsdaVec<uint16_t, VEC>::load(vb + hl * h_stride + wh_i * w_stride, v2);
+            MsdaVec<uint16_t, VEC>::load(vb + hh_i * h_stride + wl * w_stride, v3);
+            MsdaVec<uint16_t, VEC>::load(vb + hh_i * h_stride + wh_i * w_stride, v4);
+            const float w1 = (hl_ok && wl_ok) ? hh * hw : 0.f, w2 = (hl_ok && wh_ok) ? hh * lw : 0.f;
+            const float w3 = (hh_ok && wl_ok) ? lh * hw : 0.f, w4 = (hh_ok && wh_ok) ? lh * lw : 0.f;
+            const float aws = inside ? aw : 0.f;
+#pragma unroll
+            for (int i = 0; i < VEC; ++i) col[i] += (w1 * v1[i] + w2 * v2[i] + w3 * v3[i] + w4 * v4[i]) * aws;
+        }
+    }
+    MsdaVec<uint16_t, VEC>::store(out + item * D + c0, col);
+}
+
 template <typename VT, typename LT, int VEC>
 static int launch_msda(const void* value, const long long* shapes, const long long* start, const void* loc, const void* weight, int N, int S,
                        int M, int D, int L, int Lq, int P, void* out, hipStream_t st) {
@@ -138,6 +213,32 @@ int fo1_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes,
     if (dtype == 1) return launch_msda<double, double, 1>(value, sh, ls, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
     if (D % 8 == 0 && a16) return launch_msda<uint16_t, float, 8>(value, sh, ls, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
     return launch_msda<uint16_t, float, 1>(value, sh, ls, sampling_loc, attn_weight, N, S, M, D, L, Lq, P, out, st);
+}
+
+// Fused MSDeformAttn core (engine form): raw [offsets | logits] rows of the module's two Linear layers + reference points ->
+// attended rows, bf16 values.  offsets_logits fp32 [N, Lq, M*L*P*3] (first M*L*P*2 = sampling_offsets(query) viewed [M][L][P][2],
+// then M*L*P = attention_weights(query) viewed [M][L*P], ops/modules/ms_deform_attn.py:135-147); reference_points fp32
+// [N, Lq, L, ref_dim], ref_dim 2 (points) or 4 (cx, cy, w, h boxes; the default normaliser of :169-175); value bf16 [N, S, M*D];
+// out bf16 [N, Lq, M*D].  D % 8 == 0.
+int fo1_msda_fused_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const float* offsets_logits,
+                        const float* reference_points, int ref_dim, int N, int S, int M, int D, int L, int Lq, int P, void* out, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(value && spatial_shapes && level_start_index && offsets_logits && reference_points && out, "msda_fused: NULL operand");
+    FO1_CHECK_ARG(N > 0 && S > 0 && M > 0 && D > 0 && D % 8 == 0 && L > 0 && L <= 64 && Lq > 0 && P > 0, "msda_fused: bad shape N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d",
+                  N, S, M, D, L, Lq, P);
+    FO1_CHECK_ARG(ref_dim == 2 || ref_dim == 4, "msda_fused: reference points must be 2-d or 4-d (got %d)", ref_dim);
+    FO1_CHECK_ARG((((uintptr_t)value | (uintptr_t)out) & 15) == 0, "msda_fused: value / out must be 16-byte aligned");
+    const long long total = (long long)N * Lq * M * (D / 8);
+    const long long grid = (total + 255) / 256;
+    const double work = (double)N * Lq * M * ((double)L * P * (4.0 * D * 2 + 12.0) + (double)D * 2);
+    hipStream_t st = (hipStream_t)stream;
+    if (ref_dim == 2)
+        FO1_LAUNCH("msda_fused", work, msda_fused_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, (const uint16_t*)value, (const long long*)spatial_shapes,
+                   (const long long*)level_start_index, offsets_logits, reference_points, S, M, D, L, Lq, P, total, (uint16_t*)out);
+    else
+        FO1_LAUNCH("msda_fused", work, msda_fused_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, (const uint16_t*)value, (const long long*)spatial_shapes,
+                   (const long long*)level_start_index, offsets_logits, reference_points, S, M, D, L, Lq, P, total, (uint16_t*)out);
+    return FO1_OK;
 }
 
 }  // extern "C"

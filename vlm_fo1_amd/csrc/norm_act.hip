@@ -137,6 +137,22 @@ __global__ __launch_bounds__(256) void bias_act_kernel(const uint16_t* __restric
     }
 }
 
+// y = bf16(a + b) elementwise over [M, D] rows (DETR-style `with_pos_embed`: tensor + position embedding)
+__global__ __launch_bounds__(256) void add_kernel(const uint16_t* __restrict__ a, int lda, const uint16_t* __restrict__ b, int ldb,
+                                                  uint16_t* __restrict__ y, int ldy, int M, int D) {
+    const int chunks = D >> 3;
+    const long long total = (long long)M * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks), c = (int)(i - (long long)m * chunks);
+        float f[8], g[8];
+        unpack8(*reinterpret_cast<const uint4*>(a + (size_t)m * lda + c * 8), f);
+        unpack8(*reinterpret_cast<const uint4*>(b + (size_t)m * ldb + c * 8), g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] += g[j];
+        *reinterpret_cast<uint4*>(y + (size_t)m * ldy + c * 8) = pack8(f);
+    }
+}
+
 // argmax stage 1: 128 workgroups scan contiguous slices (first index among ties), partial (value, index) to scratch
 __global__ __launch_bounds__(256) void argmax_partial_kernel(const uint16_t* __restrict__ x, int n, float* __restrict__ pv, int* __restrict__ pi) {
     __shared__ float s_v[4];
@@ -274,6 +290,18 @@ int fo1_bias_act_bf16(const void* x, int ldx, const void* bias, void* y, int ldy
     const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     FO1_LAUNCH("bias_act", (double)M * D * 4.0, bias_act_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                (const uint16_t*)x, ldx, (const uint16_t*)bias, (uint16_t*)y, ldy, M, D, act);
+    return FO1_OK;
+}
+
+int fo1_add_bf16(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int M, int D, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(a && b && y, "add: NULL operand");
+    FO1_CHECK_ARG(D > 0 && D % 8 == 0 && lda >= D && ldb >= D && ldy >= D && lda % 8 == 0 && ldb % 8 == 0 && ldy % 8 == 0, "add: bad shape D=%d", D);
+    if (M == 0) return FO1_OK;
+    const long long total = (long long)M * (D / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    FO1_LAUNCH("add", (double)M * D * 6.0, add_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a, lda, (const uint16_t*)b, ldb,
+               (uint16_t*)y, ldy, M, D);
     return FO1_OK;
 }
 

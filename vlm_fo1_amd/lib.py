@@ -144,6 +144,9 @@ SIGNATURES = {
     "fo1_llm_decode_step": (c_int, [ctypes.POINTER(LlmWeights), ctypes.POINTER(KvCache), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fo1_zero_bytes": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "fo1_msda_fused_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                    c_void_p]),
+    "fo1_add_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fo1_ms_deform_attn_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                            c_int, c_void_p]),
     "fo1_davit_workspace_bytes": (c_size_t, [ctypes.POINTER(DavitWeights), ctypes.POINTER(DavitPlan)]),

@@ -13,7 +13,7 @@ import torch
 
 from . import lib as _L
 
-ACT_NONE, ACT_GELU, ACT_SILU, ACT_SWIGLU16 = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_SWIGLU16, ACT_RELU = 0, 1, 2, 3, 5
 
 
 def _chk(t: torch.Tensor, name: str, dtype=torch.bfloat16):
@@ -674,4 +674,41 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes: torch.Tensor, level_star
     rc = _L.load().fo1_ms_deform_attn_forward(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), sampling_locations.data_ptr(),
                                               attention_weights.data_ptr(), N, S, M, D, L, Lq, P, out.data_ptr(), dt, _stream())
     _L.check(rc, "fo1_ms_deform_attn_forward")
+    return out
+
+
+def msda_fused(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, offsets_logits: torch.Tensor,
+               reference_points: torch.Tensor, n_heads: int, n_points: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Fused MSDeformAttn core (fo1_msda_fused_bf16): value bf16 [N, S, C]; offsets_logits fp32 [N, Lq, M*L*P*3]
+    ([sampling_offsets | attention_weights] rows of one GEMM); reference_points fp32 [N, Lq, L, 2 | 4] -> bf16 [N, Lq, C]."""
+    _chk(value, "value")
+    for t, name in ((offsets_logits, "offsets_logits"), (reference_points, "reference_points")):
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError(f"msda_fused: {name} must be a contiguous fp32 GPU tensor")
+    if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64 or not spatial_shapes.is_cuda or not level_start_index.is_cuda:
+        raise TypeError("msda_fused: spatial_shapes / level_start_index must be int64 GPU tensors")
+    N, S, C = value.shape
+    _, Lq, L, RD = reference_points.shape
+    M, P = n_heads, n_points
+    D = C // M
+    if not value.is_contiguous() or tuple(offsets_logits.shape) != (N, Lq, M * L * P * 3) or spatial_shapes.shape[0] != L:
+        raise ValueError("msda_fused: inconsistent shapes")
+    if out is None:
+        out = torch.empty(N, Lq, C, dtype=torch.bfloat16, device=value.device)
+    rc = _L.load().fo1_msda_fused_bf16(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), offsets_logits.data_ptr(),
+                                       reference_points.data_ptr(), RD, N, S, M, D, L, Lq, P, out.data_ptr(), _stream())
+    _L.check(rc, "fo1_msda_fused_bf16")
+    return out
+
+
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = bf16(a + b) over [M, D] rows (fo1_add_bf16)."""
+    _chk(a, "a"); _chk(b, "b")
+    pa, lda, M, D = _rows(a, "a")
+    pb, ldb, Mb, Db = _rows(b, "b")
+    assert (M, D) == (Mb, Db)
+    if out is None:
+        out = torch.empty(M, D, dtype=torch.bfloat16, device=a.device)
+    po, ldo, _, _ = _rows(out, "out")
+    _L.check(_L.load().fo1_add_bf16(pa, lda, pb, ldb, po, ldo, M, D, _stream()), "fo1_add_bf16")
     return out
