@@ -519,14 +519,35 @@ int fo1_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes,
  * 133-202): softmax over each head's L*P logits, sampling locations from the reference points and raw offsets, bilinear gather and
  * weighted sum in ONE launch — the [N,Lq,M,L,P,2] sampling_locations and [N,Lq,M,L,P] attention_weights tensors never exist.
  *   value bf16 [N, S, M*D] (value_proj output); offsets_logits fp32 [N, Lq, M*L*P*3] = one GEMM whose weight rows are
- *   [sampling_offsets (M*L*P*2) | attention_weights (M*L*P)]; reference_points fp32 [N, Lq, L, ref_dim], ref_dim 2 (points:
+ *   [sampling_offsets (M*L*P*2) | attention_weights (M*L*P)]; reference_points fp32 [N, Lq, ref_levels, ref_dim], ref_dim 2 (points:
  *   loc = ref + off / (W_l, H_l), :150-157) or 4 (boxes cx, cy, w, h: loc = ref[:2] + off / P * ref[2:] * 0.5, :169-175);
  *   out bf16 [N, Lq, M*D] (input of output_proj).  D % 8 == 0. */
 int fo1_msda_fused_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index,
-                        const float* offsets_logits, const float* reference_points, int ref_dim, int N, int S, int M, int D, int L,
-                        int Lq, int P, void* out, void* stream);
+                        const float* offsets_logits, const float* reference_points, int ref_levels /* L, or 1 = same at every level */,
+                        int ref_dim, int N, int S, int M, int D, int L, int Lq, int P, void* out, void* stream);
 /* y = bf16(a + b) over [M, D] bf16 rows (with_pos_embed of the DETR-style layers, encoder/upn_encoder.py:62-63). D % 8 == 0. */
 int fo1_add_bf16(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int M, int D, void* stream);
+
+/* ------------------------------------------------------------------------
+ * UPN proposal detector, query selection and decoder helpers (detect_tools/upn/models/...).
+ *   fo1_sine_embed_bf16   gen_sineembed_for_position (utils/detr_utils.py:276-310): ref fp32 [n, dims] (x, y[, w, h]) ->
+ *                         bf16 [n, dims*128], 128-wide blocks ordered (y, x[, w, h]), temperature 10000, scale 2 pi
+ *   fo1_box_refine_f32    mode 0: sigmoid(delta + inverse_sigmoid(ref)) (decoder/upn_decoder.py:336-341, architecture/upn_model.py:
+ *                         110-117; inverse_sigmoid eps 1e-3, utils/detr_utils.py:269-273);  mode 1: delta + ref (encoder
+ *                         proposals in logit space, deformable_transformer.py:299-301);  mode 2: sigmoid(delta + ref) (ref in logit
+ *                         space: the decoder's first reference points, upn_decoder.py:290).  [n, 4] fp32 with row strides
+ *   fo1_mask_rows_bf16    y[m] = keep[m] ? x[m] : 0 (gen_encoder_output_proposals zeroes invalid tokens' memory, detr_utils.py:402-406)
+ *   fo1_topk_desc_f32     torch.topk(scores, k) of deformable_transformer.py:305: indices (and values) of the k largest of
+ *                         scores[i*stride], descending, ties -> lower index; single-workgroup bitonic sort in `workspace`
+ *   fo1_gather_rows_f32   out[i] = table[idx[i]] (fp32 rows; torch.gather of the selected proposals, :311-316)
+ * ---------------------------------------------------------------------- */
+int fo1_sine_embed_bf16(const float* ref, int ld_ref, int n, int dims, void* out, int ld_out, void* stream);
+int fo1_box_refine_f32(const float* delta, int ld_delta, const float* ref, int ld_ref, float* out, int ld_out, int n, int mode, void* stream);
+int fo1_mask_rows_bf16(const void* x, int ldx, const uint8_t* keep, void* y, int ldy, int M, int D, void* stream);
+size_t fo1_topk_workspace_bytes(int n);
+int fo1_topk_desc_f32(const float* scores, int stride, int n, int k, int32_t* idx_out, float* val_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
+int fo1_gather_rows_f32(const float* table, int ld_table, const int32_t* idx, float* out, int ld_out, int n, int D, void* stream);
 
 #ifdef __cplusplus
 }

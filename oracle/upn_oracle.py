@@ -65,3 +65,100 @@ def encoder(state, src, pos, shapes, n_layers, collect=None):
         if collect is not None:
             collect.append(out)
     return out
+
+
+# ---- query selection, decoder, heads ---------------------------------------------------------------------------------------------
+# models/utils/detr_utils.py:269-273 (inverse_sigmoid), :276-310 (gen_sineembed_for_position), :351-415 (gen_encoder_output_proposals)
+# models/architecture/deformable_transformer.py:262-336 (get_two_stage_proposal), models/decoder/upn_decoder.py:98-139, :262-378
+# models/architecture/upn_model.py:96-140 (prediction heads), models/module/contrastive.py (ContrastiveAssign), models/module/mlp.py
+import math
+
+
+def inverse_sigmoid(x, eps=1e-3):
+    x = x.clamp(min=0, max=1)
+    return torch.log(x.clamp(min=eps) / (1 - x).clamp(min=eps))
+
+
+def sine_embed(pos_tensor):
+    scale = 2 * math.pi
+    dim_t = torch.arange(128, dtype=torch.float32)
+    dim_t = 10000 ** (2 * (dim_t // 2) / 128)
+
+    def one(v):
+        p = v[..., None] * scale / dim_t
+        return torch.stack((p[..., 0::2].sin(), p[..., 1::2].cos()), dim=-1).flatten(-2)
+
+    parts = [one(pos_tensor[..., 1]), one(pos_tensor[..., 0])]
+    if pos_tensor.shape[-1] == 4:
+        parts += [one(pos_tensor[..., 2]), one(pos_tensor[..., 3])]
+    return torch.cat(parts, -1)
+
+
+def mlp(state, prefix, x, n):
+    for i in range(n):
+        x = F.linear(x, state[f"{prefix}layers.{i}.weight"], state[f"{prefix}layers.{i}.bias"])
+        if i < n - 1:
+            x = F.relu(x)
+    return x
+
+
+def encoder_output_proposals(shapes):
+    """gen_encoder_output_proposals for one unpadded image: (keep mask [S] bool, proposals in logit space [S, 4], +inf where invalid)."""
+    props = []
+    for lvl, (H, W) in enumerate(shapes):
+        gy, gx = torch.meshgrid(torch.linspace(0, H - 1, H), torch.linspace(0, W - 1, W), indexing="ij")
+        grid = (torch.stack([gx, gy], -1) + 0.5) / torch.tensor([W, H], dtype=torch.float32)
+        wh = torch.ones_like(grid) * 0.05 * (2.0 ** lvl)
+        props.append(torch.cat((grid, wh), -1).view(-1, 4))
+    p = torch.cat(props, 0)
+    valid = ((p > 0.01) & (p < 0.99)).all(-1)
+    logit = torch.log(p / (1 - p))
+    logit = logit.masked_fill(~valid[:, None], float("inf"))
+    return valid, logit
+
+
+def query_selection(state, memory, shapes, n_queries, prompt="fine_grained_prompt"):
+    """-> (scores [S], coords_unsig [S, 4], topk indices [nq], refpoints_unsig [nq, 4]); memory [S, C]."""
+    valid, props = encoder_output_proposals(shapes)
+    om = memory * valid[:, None].to(memory.dtype)
+    om = F.layer_norm(F.linear(om, state["transformer.enc_output.weight"], state["transformer.enc_output.bias"]), (om.shape[-1],),
+                      state["transformer.enc_output_norm.weight"], state["transformer.enc_output_norm.bias"], 1e-5)
+    scores = om @ state[f"transformer.{prompt}.weight"][0]
+    coords = mlp(state, "transformer.enc_out_bbox_embed.", om, 3) + props
+    idx = torch.topk(scores, n_queries)[1]
+    return scores, coords, idx, coords[idx]
+
+
+def decoder(state, memory, shapes, refpoints_unsig, n_layers, n_heads=8, prompt="fine_grained_prompt"):
+    """UPNDecoder.forward + the UPN heads for one image -> (hs [n_layers, nq, C] normed, refs [n_layers + 1, nq, 4], pred_boxes, pred_logits)."""
+    C = memory.shape[-1]
+    level_start = [0]
+    for h, w in shapes[:-1]:
+        level_start.append(level_start[-1] + h * w)
+    L = len(shapes)
+    tgt = state["transformer.tgt_embed.weight"]
+    ref = refpoints_unsig.sigmoid()
+    hs, refs = [], [ref]
+    out = tgt
+    for i in range(n_layers):
+        p = f"transformer.decoder.layers.{i}."
+        ref_in = ref[:, None, :].expand(-1, L, -1)                                   # valid ratios are 1
+        qpos = mlp(state, "transformer.decoder.ref_point_head.", sine_embed(ref_in[:, 0, :]), 2)
+        q = k = out + qpos
+        w, b = state[p + "self_attn.in_proj_weight"], state[p + "self_attn.in_proj_bias"]
+        qh = F.linear(q, w[:C], b[:C]).view(-1, n_heads, C // n_heads).transpose(0, 1)
+        kh = F.linear(k, w[C:2 * C], b[C:2 * C]).view(-1, n_heads, C // n_heads).transpose(0, 1)
+        vh = F.linear(out, w[2 * C:], b[2 * C:]).view(-1, n_heads, C // n_heads).transpose(0, 1)
+        att = torch.softmax(qh @ kh.transpose(1, 2) * (C // n_heads) ** -0.5, -1) @ vh
+        att = F.linear(att.transpose(0, 1).reshape(-1, C), state[p + "self_attn.out_proj.weight"], state[p + "self_attn.out_proj.bias"])
+        out = F.layer_norm(out + att, (C,), state[p + "norm2.weight"], state[p + "norm2.bias"], 1e-5)
+        ca = ms_deform_attn(state, p + "cross_attn.", (out + qpos)[None], ref_in[None].contiguous(), memory[None], shapes, level_start)[0]
+        out = F.layer_norm(out + ca, (C,), state[p + "norm1.weight"], state[p + "norm1.bias"], 1e-5)
+        h = F.relu(F.linear(out, state[p + "linear1.weight"], state[p + "linear1.bias"]))
+        out = F.layer_norm(out + F.linear(h, state[p + "linear2.weight"], state[p + "linear2.bias"]), (C,), state[p + "norm3.weight"], state[p + "norm3.bias"], 1e-5)
+        ref = (mlp(state, "bbox_embed.0.", out, 3) + inverse_sigmoid(ref)).sigmoid()
+        refs.append(ref)
+        hs.append(F.layer_norm(out, (C,), state["transformer.decoder.norm.weight"], state["transformer.decoder.norm.bias"], 1e-5))
+    boxes = (mlp(state, "bbox_embed.0.", hs[-1], 3) + inverse_sigmoid(refs[-2])).sigmoid()
+    logits = hs[-1] @ state[f"transformer.{prompt}.weight"].t()
+    return torch.stack(hs), torch.stack(refs), boxes, logits

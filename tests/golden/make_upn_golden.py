@@ -103,6 +103,54 @@ def main():
             h.remove()
     out["enc.memory"] = mem.numpy()
     out.update({k: v.numpy() for k, v in inter.items()})
+    # ---- the whole deformable transformer + heads: 2 encoder + 2 decoder layers, 30 queries (deformable_transformer.py, upn_model.py) ----
+    cfg = U.inference_wrapper.Config.fromfile("/root/reference/detect_tools/upn/configs/upn_large.py").model
+    cfg["vision_backbone_cfg"]["backbone_cfg"] = "swin_T_224_1k"          # the backbone is bypassed below; a small one builds faster
+    cfg["num_queries"] = cfg["transformer_cfg"]["num_queries"] = C.N_QUERIES_SMALL
+    cfg["transformer_cfg"]["encoder_cfg"]["num_layers"] = 2
+    cfg["transformer_cfg"]["decoder_cfg"]["num_layers"] = 2
+    model = U.build_architecture(cfg).eval()
+    st = C.transformer_state(2, 2, C.N_QUERIES_SMALL)
+    res = model.load_state_dict(st, strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    left = [k for k in res.missing_keys if not (k.startswith("backbone.") or k.startswith("input_proj.") or k == "transformer.level_embed"
+                                                or "ref_point_head_point" in k or "bbox_embed." in k)]
+    assert not left, left
+    for i in range(1, 2):
+        assert model.bbox_embed[i] is model.bbox_embed[0] and model.transformer.decoder.bbox_embed[i] is model.bbox_embed[0]
+    src, pos = C.encoder_inputs(seed=78)
+    rec = {}
+    orig = model.transformer.get_two_stage_proposal
+
+    def spy(memory, mask_flatten, spatial_shapes, ref_dict):
+        rec["memory"] = memory.detach().clone()
+        from detect_tools.upn.models.utils import gen_encoder_output_proposals
+        om, op = gen_encoder_output_proposals(memory, mask_flatten, spatial_shapes, None)
+        om = model.transformer.enc_output_norm(model.transformer.enc_output(om))
+        rec["sel.scores"] = model.transformer.enc_out_class_embed(om, ref_dict).max(-1)[0].detach().clone()
+        rec["sel.coords"] = (model.transformer.enc_out_bbox_embed(om) + op).detach().clone()
+        r = orig(memory, mask_flatten, spatial_shapes, ref_dict)
+        rec["sel.refpoints"] = r[0].detach().clone()
+        return r
+
+    model.transformer.get_two_stage_proposal = spy
+    S = src.shape[1]
+    model.forward_backbone_encoder = lambda samples: (src, pos, ls, shapes, torch.ones(1, C.N_LEVELS, 2), torch.zeros(1, S, dtype=torch.bool))
+    dec_rec = {}
+    hd = model.transformer.decoder.register_forward_hook(lambda m, i, o: dec_rec.__setitem__("o", o))
+    with torch.no_grad():
+        res = model(torch.zeros(1), "fine_grained_prompt")
+    hd.remove()
+    hs, refs = dec_rec["o"]
+    out["tr.memory"] = rec["memory"].numpy()
+    out["tr.sel.scores"] = rec["sel.scores"].numpy()
+    coords = rec["sel.coords"].numpy().copy()
+    out["tr.sel.coords"] = coords
+    out["tr.sel.refpoints"] = rec["sel.refpoints"].numpy()
+    out["tr.hs"] = torch.stack(hs).numpy()                      # [n_dec, 1, nq, 256] (decoder.norm applied)
+    out["tr.refs"] = torch.stack(refs).numpy()                  # [n_dec + 1, 1, nq, 4] sigmoid space
+    out["tr.pred_boxes"] = res["pred_boxes"].numpy()
+    out["tr.pred_logits"] = res["pred_logits"].numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes", {k: v.shape for k, v in out.items()})
 

@@ -21,3 +21,25 @@ def test_deformable_encoder_matches_reference_modules():
     mem = O.encoder(state, src, pos, C.ENC_SHAPES, 2, collect=outs)
     assert (outs[0] - torch.from_numpy(G["enc.layer0"])).abs().max().item() <= 5e-5
     assert (mem - torch.from_numpy(G["enc.memory"])).abs().max().item() <= 1e-4
+
+
+def test_query_selection_decoder_and_heads_match_reference_model():
+    """oracle/upn_oracle.py query_selection + decoder against the reference's DeformableTransformer + UPN heads (2 + 2 layers,
+    30 queries), fed with the reference's own encoder memory."""
+    state = C.transformer_state(2, 2, C.N_QUERIES_SMALL)
+    memory = torch.from_numpy(G["tr.memory"])[0]
+    src, pos = C.encoder_inputs(seed=78)
+    enc_state = {k[len("transformer.encoder."):]: v for k, v in state.items() if k.startswith("transformer.encoder.")}
+    mem2 = O.encoder(enc_state, src, pos, C.ENC_SHAPES, 2)[0]
+    assert (mem2 - memory).abs().max().item() <= 1e-4
+    scores, coords, idx, refp = O.query_selection(state, memory, C.ENC_SHAPES, C.N_QUERIES_SMALL)
+    assert (scores - torch.from_numpy(G["tr.sel.scores"])[0]).abs().max().item() <= 1e-4
+    gc = torch.from_numpy(G["tr.sel.coords"])[0]
+    fin = torch.isfinite(gc)
+    assert torch.equal(fin, torch.isfinite(coords)) and (coords[fin] - gc[fin]).abs().max().item() <= 1e-4
+    assert (refp - torch.from_numpy(G["tr.sel.refpoints"])[0]).abs().max().item() <= 1e-4
+    hs, refs, boxes, logits = O.decoder(state, memory, C.ENC_SHAPES, torch.from_numpy(G["tr.sel.refpoints"])[0], 2)
+    assert (hs - torch.from_numpy(G["tr.hs"])[:, 0]).abs().max().item() <= 2e-4
+    assert (refs - torch.from_numpy(G["tr.refs"])[:, 0]).abs().max().item() <= 1e-5
+    assert (boxes - torch.from_numpy(G["tr.pred_boxes"])[0]).abs().max().item() <= 1e-5
+    assert (logits - torch.from_numpy(G["tr.pred_logits"])[0]).abs().max().item() <= 2e-4

@@ -82,3 +82,54 @@ def test_deformable_encoder_full_size_runs_and_is_finite():
     ms = (time.perf_counter() - t) / 5 * 1e3
     print(f"\nUPN deformable encoder, 6 layers x {S} tokens: {ms:.2f} ms (eager launches)")
     assert torch.isfinite(out.float()).all() and out.shape == (S, 256)
+
+
+def test_topk_kernel_matches_torch_topk():
+    from vlm_fo1_amd import ops
+    g = torch.Generator().manual_seed(8)
+    for n, k, stride in ((257, 30, 1), (22300, 900, 8), (1000, 1000, 1), (5, 3, 2)):
+        x = torch.randn(n * stride, generator=g)
+        x[::max(1, n // 7) * stride] = float("inf")                    # invalid proposals carry +inf coordinates; scores may repeat
+        got_i, got_v = ops.topk_desc(x.cuda(), k, stride=stride, n=n)
+        want_v, want_i = torch.topk(x[::stride][:n], k)
+        assert torch.equal(got_v.cpu(), want_v), (n, k)
+        sel = x[::stride][got_i.cpu().long()]
+        assert torch.equal(sel, want_v)                                # same values in the same order (tie order may differ)
+        assert len(set(got_i.cpu().tolist())) == k
+
+
+def test_query_selection_matches_reference_model():
+    from vlm_fo1_amd.upn import QuerySelector
+    state = C.transformer_state(2, 2, C.N_QUERIES_SMALL)
+    memory = torch.from_numpy(G["tr.memory"])[0]
+    sel = QuerySelector(state, "cuda", C.N_QUERIES_SMALL).forward(memory.bfloat16().cuda(), C.ENC_SHAPES)
+    ref_scores = torch.from_numpy(G["tr.sel.scores"])[0]
+    scores = sel["scores"][:, 0].cpu()
+    assert (scores - ref_scores).abs().max().item() <= 0.02 * ref_scores.abs().max().item() + 0.05
+    gc, coords = torch.from_numpy(G["tr.sel.coords"])[0], sel["coords"].cpu()
+    fin = torch.isfinite(gc)
+    assert torch.equal(fin, torch.isfinite(coords)) and (coords[fin] - gc[fin]).abs().max().item() <= 0.03
+    # the selected set: identical up to swaps among tokens whose reference scores are closer than the bf16 noise
+    want = torch.topk(ref_scores, C.N_QUERIES_SMALL)[1]
+    got = sel["idx"].cpu().long()
+    kth = ref_scores[want[-1]]
+    for t in set(got.tolist()) ^ set(want.tolist()):
+        assert abs(ref_scores[t] - kth) <= 0.1, f"token {t} selected / dropped with a clear margin"
+    assert len(set(got.tolist()) & set(want.tolist())) >= C.N_QUERIES_SMALL - 3
+
+
+def test_decoder_and_heads_match_reference_model():
+    """Teacher-forced on the reference's selected reference boxes: hidden states per layer, refined boxes, final boxes and logits."""
+    from vlm_fo1_amd.upn import DeformableDecoder
+    state = C.transformer_state(2, 2, C.N_QUERIES_SMALL)
+    memory = torch.from_numpy(G["tr.memory"])[0].bfloat16().cuda()
+    dec = DeformableDecoder(state, 2, "cuda", C.N_QUERIES_SMALL)
+    out = dec.forward(memory, C.ENC_SHAPES, torch.from_numpy(G["tr.sel.refpoints"])[0].cuda())
+    for i in range(2):
+        cos, rel = stats(out["hs"][i], torch.from_numpy(G["tr.hs"])[i, 0])
+        assert cos >= 0.999 and rel <= 2.0 ** -4, f"hs[{i}]: min cos {cos:.6f}, rel {rel:.4g}"
+    for i in range(3):
+        assert (out["refs"][i].cpu() - torch.from_numpy(G["tr.refs"])[i, 0]).abs().max().item() <= 0.01, f"reference boxes after layer {i}"
+    assert (out["pred_boxes"].cpu() - torch.from_numpy(G["tr.pred_boxes"])[0]).abs().max().item() <= 0.01
+    lg = torch.from_numpy(G["tr.pred_logits"])[0, :, 0]
+    assert (out["pred_logits"].cpu() - lg).abs().max().item() <= 0.02 * lg.abs().max().item() + 0.1

@@ -67,3 +67,46 @@ def encoder_inputs(shapes=ENC_SHAPES, seed=77, d=D_MODEL):
     src = _bf(torch.randn(1, S, d, generator=g))
     pos = _bf(torch.randn(1, S, d, generator=g) * 0.5)
     return src, pos
+
+
+# ---- the whole deformable transformer + heads (models/architecture/deformable_transformer.py, upn_model.py) ----------------------
+N_QUERIES_SMALL = 30
+
+
+def _mlp_state(g, prefix, dims, scale=None):
+    s = {}
+    for i, (a, b) in enumerate(zip(dims[:-1], dims[1:])):
+        s[f"{prefix}layers.{i}.weight"] = _bf(torch.randn(b, a, generator=g) * (scale or 1.0 / math.sqrt(a)))
+        s[f"{prefix}layers.{i}.bias"] = _bf(torch.randn(b, generator=g) * 0.05)
+    return s
+
+
+def transformer_state(n_enc=2, n_dec=2, n_queries=N_QUERIES_SMALL, seed=777, d=D_MODEL, d_ffn=D_FFN):
+    """State of the reference's UPN model minus backbone / input_proj (keys relative to the UPN module)."""
+    g = torch.Generator().manual_seed(seed)
+    s = {"transformer.encoder." + k: v for k, v in encoder_state(n_enc, seed + 1).items()}
+    for i in range(n_dec):
+        p = f"transformer.decoder.layers.{i}."
+        s.update(msda_module_state(g, p + "cross_attn."))
+        s.update(_norm_state(g, p + "norm1.", d))
+        s[p + "self_attn.in_proj_weight"] = _bf(torch.randn(3 * d, d, generator=g) / 16.0)
+        s[p + "self_attn.in_proj_bias"] = _bf(torch.randn(3 * d, generator=g) * 0.05)
+        s[p + "self_attn.out_proj.weight"] = _bf(torch.randn(d, d, generator=g) / 16.0)
+        s[p + "self_attn.out_proj.bias"] = _bf(torch.randn(d, generator=g) * 0.05)
+        s.update(_norm_state(g, p + "norm2.", d))
+        s[p + "linear1.weight"] = _bf(torch.randn(d_ffn, d, generator=g) / 16.0)
+        s[p + "linear1.bias"] = _bf(torch.randn(d_ffn, generator=g) * 0.05)
+        s[p + "linear2.weight"] = _bf(torch.randn(d, d_ffn, generator=g) / 45.0)
+        s[p + "linear2.bias"] = _bf(torch.randn(d, generator=g) * 0.05)
+        s.update(_norm_state(g, p + "norm3.", d))
+    s.update(_norm_state(g, "transformer.decoder.norm.", d))
+    s.update(_mlp_state(g, "transformer.decoder.ref_point_head.", [2 * d, d, d]))
+    s.update(_mlp_state(g, "bbox_embed.0.", [d, d, d, 4], scale=0.04))                       # shared by every decoder layer
+    s.update(_mlp_state(g, "transformer.enc_out_bbox_embed.", [d, d, d, 4], scale=0.04))     # its own copy (two_stage_bbox_embed_share=False)
+    s["transformer.enc_output.weight"] = _bf(torch.randn(d, d, generator=g) / 16.0)
+    s["transformer.enc_output.bias"] = _bf(torch.randn(d, generator=g) * 0.05)
+    s.update(_norm_state(g, "transformer.enc_output_norm.", d))
+    s["transformer.tgt_embed.weight"] = _bf(torch.randn(n_queries, d, generator=g))
+    s["transformer.fine_grained_prompt.weight"] = _bf(torch.randn(1, d, generator=g))
+    s["transformer.coarse_grained_prompt.weight"] = _bf(torch.randn(1, d, generator=g))
+    return s

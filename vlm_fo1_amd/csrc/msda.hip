@@ -111,8 +111,8 @@ __global__ __launch_bounds__(256) void msda_forward_kernel(const VT* __restrict_
 template <int RD>
 __global__ __launch_bounds__(256) void msda_fused_kernel(const uint16_t* __restrict__ value, const long long* __restrict__ shapes,
                                                          const long long* __restrict__ level_start, const float* __restrict__ ol,
-                                                         const float* __restrict__ ref, int S, int M, int D, int L, int Lq, int P,
-                                                         long long total, uint16_t* __restrict__ out) {
+                                                         const float* __restrict__ ref, int ref_levels, int S, int M, int D, int L, int Lq,
+                                                         int P, long long total, uint16_t* __restrict__ out) {
     constexpr int VEC = 8;
     const int tpi = D / VEC;
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const uint16_t* __restr
     const float* row = ol + nq * ((long long)M * LP * 3);
     const float* offp = row + (long long)m * LP * 2;           // [L][P][2]
     const float* lgp = row + (long long)M * LP * 2 + (long long)m * LP;
-    const float* rp = ref + nq * ((long long)L * RD);
+    const float* rp = ref + nq * ((long long)ref_levels * RD);      // ref_levels == 1: one point / box for every level
     float mx = -INFINITY;
     for (int i = 0; i < LP; ++i) mx = fmaxf(mx, lgp[i]);
     float den = 0.f;
@@ -140,8 +140,9 @@ __global__ __launch_bounds__(256) void msda_fused_kernel(const uint16_t* __restr
         const int H = (int)shapes[2 * l], W = (int)shapes[2 * l + 1];
         const uint16_t* vb = value + (n * S + level_start[l]) * w_stride + (long long)m * D + c0;
         const long long h_stride = (long long)W * w_stride;
-        const float rx = rp[l * RD], ry = rp[l * RD + 1];
-        const float rw = RD == 4 ? rp[l * RD + 2] : 0.f, rh = RD == 4 ? rp[l * RD + 3] : 0.f;
+        const int rl = ref_levels == 1 ? 0 : l;
+        const float rx = rp[rl * RD], ry = rp[rl * RD + 1];
+        const float rw = RD == 4 ? rp[rl * RD + 2] : 0.f, rh = RD == 4 ? rp[rl * RD + 3] : 0.f;
         for (int p = 0; p < P; ++p) {
             const float ox = offp[(l * P + p) * 2], oy = offp[(l * P + p) * 2 + 1];
             const float aw = expf(lgp[l * P + p] - mx) * inv_den;
@@ -218,15 +219,16 @@ int fo1_ms_deform_attn_forward(const void* value, const int64_t* spatial_shapes,
 // Fused MSDeformAttn core (engine form): raw [offsets | logits] rows of the module's two Linear layers + reference points ->
 // attended rows, bf16 values.  offsets_logits fp32 [N, Lq, M*L*P*3] (first M*L*P*2 = sampling_offsets(query) viewed [M][L][P][2],
 // then M*L*P = attention_weights(query) viewed [M][L*P], ops/modules/ms_deform_attn.py:135-147); reference_points fp32
-// [N, Lq, L, ref_dim], ref_dim 2 (points) or 4 (cx, cy, w, h boxes; the default normaliser of :169-175); value bf16 [N, S, M*D];
-// out bf16 [N, Lq, M*D].  D % 8 == 0.
+// [N, Lq, ref_levels, ref_dim], ref_levels = L or 1 (the same point / box at every level: an unpadded image's valid ratios are 1),
+// ref_dim 2 (points) or 4 (cx, cy, w, h boxes; the default normaliser of :169-175); value bf16 [N, S, M*D]; out bf16 [N, Lq, M*D].
 int fo1_msda_fused_bf16(const void* value, const int64_t* spatial_shapes, const int64_t* level_start_index, const float* offsets_logits,
-                        const float* reference_points, int ref_dim, int N, int S, int M, int D, int L, int Lq, int P, void* out, void* stream) {
+                        const float* reference_points, int ref_levels, int ref_dim, int N, int S, int M, int D, int L, int Lq, int P, void* out,
+                        void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(value && spatial_shapes && level_start_index && offsets_logits && reference_points && out, "msda_fused: NULL operand");
     FO1_CHECK_ARG(N > 0 && S > 0 && M > 0 && D > 0 && D % 8 == 0 && L > 0 && L <= 64 && Lq > 0 && P > 0, "msda_fused: bad shape N=%d S=%d M=%d D=%d L=%d Lq=%d P=%d",
                   N, S, M, D, L, Lq, P);
-    FO1_CHECK_ARG(ref_dim == 2 || ref_dim == 4, "msda_fused: reference points must be 2-d or 4-d (got %d)", ref_dim);
+    FO1_CHECK_ARG((ref_dim == 2 || ref_dim == 4) && (ref_levels == 1 || ref_levels == L), "msda_fused: reference points must be 2-d or 4-d, for 1 or L levels (got %d, %d)", ref_dim, ref_levels);
     FO1_CHECK_ARG((((uintptr_t)value | (uintptr_t)out) & 15) == 0, "msda_fused: value / out must be 16-byte aligned");
     const long long total = (long long)N * Lq * M * (D / 8);
     const long long grid = (total + 255) / 256;
@@ -234,10 +236,10 @@ int fo1_msda_fused_bf16(const void* value, const int64_t* spatial_shapes, const 
     hipStream_t st = (hipStream_t)stream;
     if (ref_dim == 2)
         FO1_LAUNCH("msda_fused", work, msda_fused_kernel<2>, dim3((unsigned)grid), dim3(256), 0, st, (const uint16_t*)value, (const long long*)spatial_shapes,
-                   (const long long*)level_start_index, offsets_logits, reference_points, S, M, D, L, Lq, P, total, (uint16_t*)out);
+                   (const long long*)level_start_index, offsets_logits, reference_points, ref_levels, S, M, D, L, Lq, P, total, (uint16_t*)out);
     else
         FO1_LAUNCH("msda_fused", work, msda_fused_kernel<4>, dim3((unsigned)grid), dim3(256), 0, st, (const uint16_t*)value, (const long long*)spatial_shapes,
-                   (const long long*)level_start_index, offsets_logits, reference_points, S, M, D, L, Lq, P, total, (uint16_t*)out);
+                   (const long long*)level_start_index, offsets_logits, reference_points, ref_levels, S, M, D, L, Lq, P, total, (uint16_t*)out);
     return FO1_OK;
 }
 

@@ -680,7 +680,7 @@ def ms_deform_attn(value: torch.Tensor, spatial_shapes: torch.Tensor, level_star
 def msda_fused(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_index: torch.Tensor, offsets_logits: torch.Tensor,
                reference_points: torch.Tensor, n_heads: int, n_points: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Fused MSDeformAttn core (fo1_msda_fused_bf16): value bf16 [N, S, C]; offsets_logits fp32 [N, Lq, M*L*P*3]
-    ([sampling_offsets | attention_weights] rows of one GEMM); reference_points fp32 [N, Lq, L, 2 | 4] -> bf16 [N, Lq, C]."""
+    ([sampling_offsets | attention_weights] rows of one GEMM); reference_points fp32 [N, Lq, L or 1, 2 | 4] -> bf16 [N, Lq, C]."""
     _chk(value, "value")
     for t, name in ((offsets_logits, "offsets_logits"), (reference_points, "reference_points")):
         if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
@@ -688,15 +688,16 @@ def msda_fused(value: torch.Tensor, spatial_shapes: torch.Tensor, level_start_in
     if spatial_shapes.dtype != torch.int64 or level_start_index.dtype != torch.int64 or not spatial_shapes.is_cuda or not level_start_index.is_cuda:
         raise TypeError("msda_fused: spatial_shapes / level_start_index must be int64 GPU tensors")
     N, S, C = value.shape
-    _, Lq, L, RD = reference_points.shape
+    _, Lq, RL, RD = reference_points.shape
+    L = spatial_shapes.shape[0]
     M, P = n_heads, n_points
     D = C // M
-    if not value.is_contiguous() or tuple(offsets_logits.shape) != (N, Lq, M * L * P * 3) or spatial_shapes.shape[0] != L:
+    if not value.is_contiguous() or tuple(offsets_logits.shape) != (N, Lq, M * L * P * 3) or RL not in (1, L):
         raise ValueError("msda_fused: inconsistent shapes")
     if out is None:
         out = torch.empty(N, Lq, C, dtype=torch.bfloat16, device=value.device)
     rc = _L.load().fo1_msda_fused_bf16(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(), offsets_logits.data_ptr(),
-                                       reference_points.data_ptr(), RD, N, S, M, D, L, Lq, P, out.data_ptr(), _stream())
+                                       reference_points.data_ptr(), RL, RD, N, S, M, D, L, Lq, P, out.data_ptr(), _stream())
     _L.check(rc, "fo1_msda_fused_bf16")
     return out
 
@@ -711,4 +712,61 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
         out = torch.empty(M, D, dtype=torch.bfloat16, device=a.device)
     po, ldo, _, _ = _rows(out, "out")
     _L.check(_L.load().fo1_add_bf16(pa, lda, pb, ldb, po, ldo, M, D, _stream()), "fo1_add_bf16")
+    return out
+
+
+# ---- UPN query selection / decoder helpers (upn_ops.hip) -------------------------------------------------------------------
+def _f32(t: torch.Tensor, name: str):
+    if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+        raise TypeError(f"{name} must be a 2-d fp32 GPU tensor with unit column stride")
+    return t.data_ptr(), t.stride(0), t.shape[0], t.shape[1]
+
+
+def sine_embed(ref: torch.Tensor, dims: int = 4) -> torch.Tensor:
+    """fp32 [n, >= dims] (x, y[, w, h]) -> bf16 [n, dims*128] (fo1_sine_embed_bf16)."""
+    p, ld, n, _ = _f32(ref, "ref")
+    out = torch.empty(n, dims * 128, dtype=torch.bfloat16, device=ref.device)
+    _L.check(_L.load().fo1_sine_embed_bf16(p, ld, n, dims, out.data_ptr(), out.stride(0), _stream()), "fo1_sine_embed_bf16")
+    return out
+
+
+def box_refine(delta: torch.Tensor, ref: torch.Tensor, mode: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mode 0: sigmoid(delta[:, :4] + inverse_sigmoid(ref)); mode 1: delta[:, :4] + ref; mode 2: sigmoid(delta[:, :4] + ref).
+    fp32 [n, 4] (fo1_box_refine_f32)."""
+    pd, ldd, n, _ = _f32(delta, "delta")
+    pr, ldr, nr, _ = _f32(ref, "ref")
+    assert n == nr
+    if out is None:
+        out = torch.empty(n, 4, dtype=torch.float32, device=delta.device)
+    po, ldo, _, _ = _f32(out, "out")
+    _L.check(_L.load().fo1_box_refine_f32(pd, ldd, pr, ldr, po, ldo, n, mode, _stream()), "fo1_box_refine_f32")
+    return out
+
+
+def mask_rows(x: torch.Tensor, keep: torch.Tensor) -> torch.Tensor:
+    _chk(x, "x")
+    px, ldx, M, D = _rows(x, "x")
+    assert keep.dtype == torch.uint8 and keep.is_cuda and keep.numel() == M and keep.is_contiguous()
+    y = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_mask_rows_bf16(px, ldx, keep.data_ptr(), y.data_ptr(), y.stride(0), M, D, _stream()), "fo1_mask_rows_bf16")
+    return y
+
+
+def topk_desc(scores: torch.Tensor, k: int, stride: int = 1, n: Optional[int] = None):
+    """scores fp32 (flat; element i at i*stride) -> (indices int32 [k], values fp32 [k]) in descending order (fo1_topk_desc_f32)."""
+    if not scores.is_cuda or scores.dtype != torch.float32 or not scores.is_contiguous():
+        raise TypeError("topk_desc: scores must be a contiguous fp32 GPU tensor")
+    n = scores.numel() // stride if n is None else n
+    ws = _workspace("topk", scores.device, _L.load().fo1_topk_workspace_bytes(n))
+    idx = torch.empty(k, dtype=torch.int32, device=scores.device)
+    val = torch.empty(k, dtype=torch.float32, device=scores.device)
+    _L.check(_L.load().fo1_topk_desc_f32(scores.data_ptr(), stride, n, k, idx.data_ptr(), val.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "fo1_topk_desc_f32")
+    return idx, val
+
+
+def gather_rows_f32(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    pt, ldt, _, D = _f32(table, "table")
+    assert idx.dtype == torch.int32 and idx.is_cuda and idx.is_contiguous()
+    out = torch.empty(idx.numel(), D, dtype=torch.float32, device=table.device)
+    _L.check(_L.load().fo1_gather_rows_f32(pt, ldt, idx.data_ptr(), out.data_ptr(), out.stride(0), idx.numel(), D, _stream()), "fo1_gather_rows_f32")
     return out

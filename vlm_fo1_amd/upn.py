@@ -111,3 +111,159 @@ class DeformableEncoder:
             if collect is not None:
                 collect.append(x)
         return x
+
+
+# ---- query selection, decoder, prediction heads ---------------------------------------------------------------------------------
+# Reference: models/architecture/deformable_transformer.py:262-336 (get_two_stage_proposal), models/utils/detr_utils.py:351-415
+# (gen_encoder_output_proposals), models/decoder/upn_decoder.py:98-139 (layer), :262-378 (UPNDecoder.forward),
+# models/architecture/upn_model.py:96-140 (box / class heads; ContrastiveAssign = dot product with the prompt embedding).
+# Box coordinates stay fp32 end to end (logit-space arithmetic is precision-sensitive near 0 and 1); features are bf16.
+def _pad_rows(w: torch.Tensor, b: Optional[torch.Tensor], rows: int):
+    """zero-pad a small head ([4, C] boxes, [1, C] prompt) to `rows` output features so the fp32 GEMM output rows are 32-byte aligned"""
+    wp = torch.zeros(rows, w.shape[1], dtype=w.dtype)
+    wp[:w.shape[0]] = w
+    bp = None
+    if b is not None:
+        bp = torch.zeros(rows, dtype=b.dtype)
+        bp[:b.shape[0]] = b
+    return wp, bp
+
+
+class _MLP:
+    """models/module/mlp.py: Linear + ReLU ... Linear; the last layer can be emitted in fp32 (box deltas)."""
+
+    def __init__(self, state, prefix, n, device, pad_last: int = 0):
+        self.layers = []
+        for i in range(n):
+            w, b = state[f"{prefix}layers.{i}.weight"], state[f"{prefix}layers.{i}.bias"]
+            if i == n - 1 and pad_last:
+                w, b = _pad_rows(w, b, pad_last)
+            self.layers.append((_dev(w, device), _dev(b, device)))
+
+    def __call__(self, x, last_f32=False):
+        n = len(self.layers)
+        for i, (w, b) in enumerate(self.layers):
+            if i < n - 1:
+                x = ops.gemm(x, w, b, act=ops.ACT_RELU)
+            else:
+                x = ops.gemm(x, w, b, out_f32=last_f32)
+        return x
+
+
+def encoder_output_proposals(shapes: Sequence[Tuple[int, int]]):
+    """gen_encoder_output_proposals for one unpadded image, on the host: (keep uint8 [S], proposals in logit space fp32 [S, 4])."""
+    props = []
+    for lvl, (H, W) in enumerate(shapes):
+        gy, gx = np.meshgrid(np.arange(H, dtype=np.float32), np.arange(W, dtype=np.float32), indexing="ij")
+        grid = (np.stack([gx, gy], -1) + np.float32(0.5)) / np.array([W, H], dtype=np.float32)
+        wh = np.ones_like(grid) * np.float32(0.05) * np.float32(2.0 ** lvl)
+        props.append(np.concatenate([grid, wh], -1).reshape(-1, 4))
+    p = torch.from_numpy(np.concatenate(props, 0).astype(np.float32))
+    valid = ((p > 0.01) & (p < 0.99)).all(-1)
+    logit = torch.log(p / (1 - p)).masked_fill(~valid[:, None], float("inf"))
+    return valid.to(torch.uint8), logit
+
+
+class QuerySelector:
+    """Two-stage proposal generation: per-token score (contrast with the universal prompt) and box, top-k tokens -> decoder reference boxes."""
+
+    def __init__(self, state, device="cuda", n_queries: int = 900, prefix: str = "transformer."):
+        self.dev = torch.device(device)
+        self.nq = n_queries
+        self.w_enc, self.b_enc = _dev(state[prefix + "enc_output.weight"], self.dev), _dev(state[prefix + "enc_output.bias"], self.dev)
+        self.nw, self.nb = _dev(state[prefix + "enc_output_norm.weight"], self.dev), _dev(state[prefix + "enc_output_norm.bias"], self.dev)
+        self.box = _MLP(state, prefix + "enc_out_bbox_embed.", 3, self.dev, pad_last=8)
+        self.prompts = {k: _dev(_pad_rows(state[f"{prefix}{k}.weight"], None, 8)[0], self.dev) for k in ("fine_grained_prompt", "coarse_grained_prompt")}
+        self._plans = {}
+
+    def plan(self, shapes):
+        key = tuple(shapes)
+        if key not in self._plans:
+            keep, props = encoder_output_proposals(shapes)
+            self._plans[key] = (keep.to(self.dev), props.to(self.dev).contiguous())
+        return self._plans[key]
+
+    def forward(self, memory: torch.Tensor, shapes, prompt_type: str = "fine_grained_prompt") -> dict:
+        keep, props = self.plan(shapes)
+        S = memory.shape[0]
+        om = ops.mask_rows(memory, keep)
+        om = ops.layernorm(ops.gemm(om, self.w_enc, self.b_enc), self.nw, self.nb, 1e-5)
+        sc = ops.gemm(om, self.prompts[prompt_type], out_f32=True)                 # [S, 8] fp32, column 0 = the score
+        coords = ops.box_refine(self.box(om, last_f32=True), props, mode=1)        # logit space; +inf rows for invalid proposals
+        idx, val = ops.topk_desc(sc, min(self.nq, S), stride=8, n=S)
+        return dict(scores=sc, coords=coords, idx=idx, topk_scores=val, refpoints=ops.gather_rows_f32(coords, idx))
+
+
+class DeformableDecoder:
+    """UPNDecoder (6 x DeformableTransformerDecoderLayer in configs/upn_large.py) + the box / class heads for one image."""
+
+    def __init__(self, state, n_layers: int, device="cuda", n_queries: int = 900, n_heads: int = 8, n_levels: int = 5, n_points: int = 4,
+                 prefix: str = "transformer."):
+        self.dev = torch.device(device)
+        self.nq, self.H, self.L = n_queries, n_heads, n_levels
+        d = prefix + "decoder."
+        self.layers = []
+        for i in range(n_layers):
+            p = f"{d}layers.{i}."
+            C = state[p + "self_attn.out_proj.weight"].shape[0]
+            wi, bi = state[p + "self_attn.in_proj_weight"], state[p + "self_attn.in_proj_bias"]
+            self.layers.append(dict(
+                cross=MSDeformAttnWeights(state, p + "cross_attn.", self.dev, n_heads, n_levels, n_points),
+                w_qk=_dev(wi[:2 * C], self.dev), b_qk=_dev(bi[:2 * C], self.dev), w_v=_dev(wi[2 * C:], self.dev), b_v=_dev(bi[2 * C:], self.dev),
+                w_o=_dev(state[p + "self_attn.out_proj.weight"], self.dev), b_o=_dev(state[p + "self_attn.out_proj.bias"], self.dev),
+                n1=(_dev(state[p + "norm1.weight"], self.dev), _dev(state[p + "norm1.bias"], self.dev)),
+                n2=(_dev(state[p + "norm2.weight"], self.dev), _dev(state[p + "norm2.bias"], self.dev)),
+                n3=(_dev(state[p + "norm3.weight"], self.dev), _dev(state[p + "norm3.bias"], self.dev)),
+                w1=_dev(state[p + "linear1.weight"], self.dev), b1=_dev(state[p + "linear1.bias"], self.dev),
+                w2=_dev(state[p + "linear2.weight"], self.dev), b2=_dev(state[p + "linear2.bias"], self.dev)))
+        self.C = C
+        self.norm = (_dev(state[d + "norm.weight"], self.dev), _dev(state[d + "norm.bias"], self.dev))
+        self.ref_head = _MLP(state, d + "ref_point_head.", 2, self.dev)
+        self.bbox = _MLP(state, "bbox_embed.0.", 3, self.dev, pad_last=8)          # shared by the layers and the final head (dec_pred_bbox_embed_share)
+        self.tgt = _dev(state[prefix + "tgt_embed.weight"], self.dev)
+        self.prompts = {k: _dev(_pad_rows(state[f"{prefix}{k}.weight"], None, 8)[0], self.dev) for k in ("fine_grained_prompt", "coarse_grained_prompt")}
+        self.items = ops.make_items([(0, n_queries)], self.dev, block=64)
+        self.zero8 = torch.zeros(n_queries, 8, dtype=torch.float32, device=self.dev)
+        self._plans = {}
+
+    def plan(self, shapes):
+        key = tuple(shapes)
+        if key not in self._plans:
+            start = [0]
+            for h, w in shapes[:-1]:
+                start.append(start[-1] + h * w)
+            self._plans[key] = (torch.tensor(shapes, dtype=torch.int64, device=self.dev), torch.tensor(start, dtype=torch.int64, device=self.dev))
+        return self._plans[key]
+
+    def forward(self, memory: torch.Tensor, shapes, refpoints_unsig: torch.Tensor, prompt_type: str = "fine_grained_prompt") -> dict:
+        """memory bf16 [S, C]; refpoints_unsig fp32 [nq, 4] (logit space) -> hs (decoder.norm applied) per layer, reference boxes per layer,
+        pred_boxes fp32 [nq, 4] (cx, cy, w, h in [0, 1]) and pred_logits fp32 [nq]."""
+        nq, C, H = self.nq, self.C, self.H
+        if tuple(refpoints_unsig.shape) != (nq, 4) or refpoints_unsig.dtype != torch.float32:
+            raise ValueError("DeformableDecoder: refpoints must be fp32 [n_queries, 4]")
+        shapes_dev, start_dev = self.plan(shapes)
+        ref = ops.box_refine(self.zero8, refpoints_unsig.contiguous(), mode=2)      # sigmoid
+        refs, hs = [ref], []
+        out = self.tgt
+        n_pad = (nq + 63) // 64 * 64
+        vt = ops._workspace(f"upn_dec_vt_{C}x{n_pad}", self.dev, C * n_pad * 2)[:C * n_pad * 2].view(BF).view(C, n_pad)
+        hd = C // H
+        for ly in self.layers:
+            qpos = self.ref_head(ops.sine_embed(ref, 4))                             # conditional query position from the current boxes
+            q = ops.add(out, qpos)
+            qk = ops.gemm(q, ly["w_qk"], ly["b_qk"])                                # self-attention: q = k = tgt + pos, v = tgt
+            v = ops.gemm(out, ly["w_v"], ly["b_v"])
+            ops.transpose_into(v, vt, 0)
+            att = ops.attention(qk[:, :C], qk[:, C:], vt, self.items, H, H, hd, float(hd) ** -0.5, False, flops=4.0 * C * nq * nq)
+            out = ops.layernorm(ops.gemm(att, ly["w_o"], ly["b_o"], residual=out), ly["n2"][0], ly["n2"][1], 1e-5)
+            q = ops.add(out, qpos)                                                   # cross-attention into the image memory
+            y = ly["cross"].attend(q, ref.view(1, nq, 1, 4), memory, shapes_dev, start_dev, residual=out)
+            out = ops.layernorm(y, ly["n1"][0], ly["n1"][1], 1e-5)
+            h = ops.gemm(out, ly["w1"], ly["b1"], act=ops.ACT_RELU)
+            out = ops.layernorm(ops.gemm(h, ly["w2"], ly["b2"], residual=out), ly["n3"][0], ly["n3"][1], 1e-5)
+            ref = ops.box_refine(self.bbox(out, last_f32=True), ref, mode=0)         # iterative box refinement
+            refs.append(ref)
+            hs.append(ops.layernorm(out, self.norm[0], self.norm[1], 1e-5))
+        boxes = ops.box_refine(self.bbox(hs[-1], last_f32=True), refs[-2], mode=0)
+        logits = ops.gemm(hs[-1], self.prompts[prompt_type], out_f32=True)
+        return dict(hs=hs, refs=refs, pred_boxes=boxes, pred_logits=logits[:, 0])
