@@ -529,6 +529,31 @@ int fo1_msda_fused_bf16(const void* value, const int64_t* spatial_shapes, const 
 int fo1_add_bf16(const void* a, int lda, const void* b, int ldb, void* y, int ldy, int M, int D, void* stream);
 
 /* ------------------------------------------------------------------------
+ * UPN proposal detector, Swin-L backbone pieces (detect_tools/upn/models/backbone/swin.py).
+ *   fo1_attention_window_bias_bf16   W-MSA / SW-MSA (:136-175): fo1_attention_bf16 over windows + fp32 bias [heads][wlen][wlen]
+ *                                    (the relative-position bias gathered per layer at load) + the shifted-window mask (-100
+ *                                    between shift regions, BasicLayer.forward :446-466) computed from the window's place
+ *   fo1_swin_window_partition_bf16   pad to the window multiple (zeros, AFTER norm1 as the reference), cyclic shift (torch.roll by
+ *                                    -shift), window_partition (:42-55, :273-296) in one gather; xw [batch*nW*ws*ws, C]
+ *   fo1_swin_window_reverse_add_bf16 window_reverse + inverse shift + crop + residual add (:299-313)
+ *   fo1_patch_merge_bf16             PatchMerging's gather [x(2i,2j) | x(2i+1,2j) | x(2i,2j+1) | x(2i+1,2j+1)], zero beyond an odd edge
+ *                                    (:333-352); out [batch*ceil(H/2)*ceil(W/2), 4C]
+ *   fo1_groupnorm_tokens_bf16        nn.GroupNorm(groups, C) of input_proj (architecture/upn_model.py:246-262) on a token-major map
+ * ---------------------------------------------------------------------- */
+int fo1_attention_window_bias_bf16(const void* Q, long long q_tok_stride, long long q_head_stride, const void* K, long long k_tok_stride,
+                                   long long k_head_stride, const void* VT, long long vt_row_stride, void* O, long long o_tok_stride,
+                                   long long o_head_stride, const int32_t* items, int n_items, int q_block, int n_heads, int head_dim,
+                                   float scale, const float* bias, int wlen, int ws, int shift, int nwy, int nwx, double flops_hint,
+                                   void* stream);
+int fo1_swin_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, int shift, int batch, void* stream);
+int fo1_swin_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, int H, int W, int C, int ws, int shift, int batch,
+                                     void* stream);
+int fo1_patch_merge_bf16(const void* x, void* out, int H, int W, int C, int batch, void* stream);
+size_t fo1_groupnorm_tokens_workspace_bytes(int S, int groups);
+int fo1_groupnorm_tokens_bf16(const void* x, int ldx, int S, int C, int groups, const void* weight, const void* bias, float eps, void* y,
+                              int ldy, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * UPN proposal detector, query selection and decoder helpers (detect_tools/upn/models/...).
  *   fo1_sine_embed_bf16   gen_sineembed_for_position (utils/detr_utils.py:276-310): ref fp32 [n, dims] (x, y[, w, h]) ->
  *                         bf16 [n, dims*128], 128-wide blocks ordered (y, x[, w, h]), temperature 10000, scale 2 pi

@@ -162,3 +162,126 @@ def decoder(state, memory, shapes, refpoints_unsig, n_layers, n_heads=8, prompt=
     boxes = (mlp(state, "bbox_embed.0.", hs[-1], 3) + inverse_sigmoid(refs[-2])).sigmoid()
     logits = hs[-1] @ state[f"transformer.{prompt}.weight"].t()
     return torch.stack(hs), torch.stack(refs), boxes, logits
+
+
+# ---- Swin backbone, position embedding, input projections ---------------------------------------------------------------------------
+# models/backbone/swin.py: PatchEmbed :484-522, SwinTransformerBlock.forward :259-318, WindowAttention.forward :136-175,
+# PatchMerging.forward :333-357, BasicLayer.forward :440-481 (shift mask), SwinTransformer.forward :700-744
+# models/utils/detr_utils.py:110-148 (PositionEmbeddingSineHW), models/architecture/upn_model.py:143-216 (forward_backbone_encoder)
+def _rel_pos_index(ws):
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+def _shift_mask(Hp, Wp, ws, shift):
+    img = torch.zeros(Hp, Wp)
+    cnt = 0
+    for hs in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+        for wsl in (slice(0, -ws), slice(-ws, -shift), slice(-shift, None)):
+            img[hs, wsl] = cnt
+            cnt += 1
+    mw = img.view(Hp // ws, ws, Wp // ws, ws).permute(0, 2, 1, 3).reshape(-1, ws * ws)
+    m = mw[:, None, :] - mw[:, :, None]
+    return m.masked_fill(m != 0, -100.0).masked_fill(m == 0, 0.0)
+
+
+def swin_block(state, p, x, H, W, heads, ws, shift, rel_index):
+    C = x.shape[-1]
+    h = F.layer_norm(x, (C,), state[p + "norm1.weight"], state[p + "norm1.bias"], 1e-5).view(H, W, C)
+    Hp, Wp = -(-H // ws) * ws, -(-W // ws) * ws
+    h = F.pad(h, (0, 0, 0, Wp - W, 0, Hp - H))
+    if shift:
+        h = torch.roll(h, (-shift, -shift), (0, 1))
+    win = h.view(Hp // ws, ws, Wp // ws, ws, C).permute(0, 2, 1, 3, 4).reshape(-1, ws * ws, C)
+    qkv = F.linear(win, state[p + "attn.qkv.weight"], state[p + "attn.qkv.bias"]).view(-1, ws * ws, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    att = (qkv[0] * (C // heads) ** -0.5) @ qkv[1].transpose(-2, -1)
+    att = att + state[p + "attn.relative_position_bias_table"][rel_index.view(-1)].view(ws * ws, ws * ws, -1).permute(2, 0, 1)[None]
+    if shift:
+        att = att + _shift_mask(Hp, Wp, ws, shift)[:, None]
+    o = (torch.softmax(att, -1) @ qkv[2]).transpose(1, 2).reshape(-1, ws * ws, C)
+    o = F.linear(o, state[p + "attn.proj.weight"], state[p + "attn.proj.bias"])
+    o = o.view(Hp // ws, Wp // ws, ws, ws, C).permute(0, 2, 1, 3, 4).reshape(Hp, Wp, C)
+    if shift:
+        o = torch.roll(o, (shift, shift), (0, 1))
+    x = x + o[:H, :W].reshape(H * W, C)
+    h = F.layer_norm(x, (C,), state[p + "norm2.weight"], state[p + "norm2.bias"], 1e-5)
+    h = F.linear(F.gelu(F.linear(h, state[p + "mlp.fc1.weight"], state[p + "mlp.fc1.bias"])), state[p + "mlp.fc2.weight"], state[p + "mlp.fc2.bias"])
+    return x + h
+
+
+def swin_forward(state, img, depths, heads, ws, prefix="backbone.model.backbone."):
+    """img [3, H, W] -> ([token-major normed stage outputs [H_l*W_l, C_l]], [(H_l, W_l)])."""
+    _, H, W = img.shape
+    x = F.pad(img, (0, (4 - W % 4) % 4, 0, (4 - H % 4) % 4))[None]
+    x = F.conv2d(x, state[prefix + "patch_embed.proj.weight"], state[prefix + "patch_embed.proj.bias"], stride=4)
+    H, W = x.shape[2:]
+    x = x[0].flatten(1).t()
+    x = F.layer_norm(x, (x.shape[-1],), state[prefix + "patch_embed.norm.weight"], state[prefix + "patch_embed.norm.bias"], 1e-5)
+    rel = _rel_pos_index(ws)
+    outs, sizes = [], []
+    for i, depth in enumerate(depths):
+        C = x.shape[-1]
+        for j in range(depth):
+            x = swin_block(state, f"{prefix}layers.{i}.blocks.{j}.", x, H, W, heads[i], ws, 0 if j % 2 == 0 else ws // 2, rel)
+        outs.append(F.layer_norm(x, (C,), state[f"{prefix}norm{i}.weight"], state[f"{prefix}norm{i}.bias"], 1e-5))
+        sizes.append((H, W))
+        if i < len(depths) - 1:
+            g = F.pad(x.view(H, W, C), (0, 0, 0, W % 2, 0, H % 2))
+            g = torch.cat([g[0::2, 0::2], g[1::2, 0::2], g[0::2, 1::2], g[1::2, 1::2]], -1)
+            H, W = g.shape[:2]
+            g = g.reshape(H * W, 4 * C)
+            p = f"{prefix}layers.{i}.downsample."
+            x = F.linear(F.layer_norm(g, (4 * C,), state[p + "norm.weight"], state[p + "norm.bias"], 1e-5), state[p + "reduction.weight"])
+    return outs, sizes
+
+
+def position_embedding(H, W, num_pos_feats=128, temp_h=20, temp_w=20):
+    """PositionEmbeddingSineHW with normalize=True on an unpadded H x W map -> [H*W, 2*num_pos_feats] (pos_y | pos_x)."""
+    scale, eps = 2 * math.pi, 1e-6
+    y = torch.arange(1, H + 1, dtype=torch.float32)[:, None].expand(H, W)
+    x = torch.arange(1, W + 1, dtype=torch.float32)[None, :].expand(H, W)
+    y = y / (y[-1:, :] + eps) * scale
+    x = x / (x[:, -1:] + eps) * scale
+    d = torch.arange(num_pos_feats, dtype=torch.float32)
+    dx = temp_w ** (2 * (d // 2) / num_pos_feats)
+    dy = temp_h ** (2 * (d // 2) / num_pos_feats)
+    px, py = x[:, :, None] / dx, y[:, :, None] / dy
+    px = torch.stack((px[:, :, 0::2].sin(), px[:, :, 1::2].cos()), 3).flatten(2)
+    py = torch.stack((py[:, :, 0::2].sin(), py[:, :, 1::2].cos()), 3).flatten(2)
+    return torch.cat((py, px), 2).reshape(H * W, -1)
+
+
+def backbone_encoder_inputs(state, feats, sizes, n_levels=5, groups=32):
+    """input_proj (1x1 conv + GroupNorm per backbone level, 3x3 stride-2 conv + GroupNorm for the extra level), sine position
+    embedding + level embedding, flattened level-major -> (src [S, 256], pos [S, 256], shapes)."""
+    srcs, shapes = [], []
+    for l, (f, (H, W)) in enumerate(zip(feats, sizes)):
+        m = f.t().reshape(1, -1, H, W)
+        s = F.group_norm(F.conv2d(m, state[f"input_proj.{l}.0.weight"], state[f"input_proj.{l}.0.bias"]), groups, state[f"input_proj.{l}.1.weight"],
+                         state[f"input_proj.{l}.1.bias"], 1e-5)
+        srcs.append(s)
+        shapes.append((H, W))
+    for l in range(len(feats), n_levels):
+        inp = feats[-1].t().reshape(1, -1, *sizes[-1]) if l == len(feats) else srcs[-1]
+        s = F.group_norm(F.conv2d(inp, state[f"input_proj.{l}.0.weight"], state[f"input_proj.{l}.0.bias"], stride=2, padding=1), groups,
+                         state[f"input_proj.{l}.1.weight"], state[f"input_proj.{l}.1.bias"], 1e-5)
+        srcs.append(s)
+        shapes.append(tuple(s.shape[2:]))
+    src = torch.cat([s[0].flatten(1).t() for s in srcs], 0)
+    pos = torch.cat([position_embedding(H, W) + state["transformer.level_embed"][l][None] for l, (H, W) in enumerate(shapes)], 0)
+    return src, pos, shapes
+
+
+def detect(state, img, depths, heads, ws, n_enc, n_dec, n_queries, prompt="fine_grained_prompt"):
+    """The whole UPN forward for one image -> (pred_boxes [nq, 4] cxcywh in [0, 1], pred_logits [nq])."""
+    feats, sizes = swin_forward(state, img, depths, heads, ws)
+    src, pos, shapes = backbone_encoder_inputs(state, feats, sizes)
+    enc_state = {k[len("transformer.encoder."):]: v for k, v in state.items() if k.startswith("transformer.encoder.")}
+    memory = encoder(enc_state, src[None], pos[None], shapes, n_enc)[0]
+    _, _, _, refp = query_selection(state, memory, shapes, n_queries, prompt)
+    _, _, boxes, logits = decoder(state, memory, shapes, refp, n_dec, prompt=prompt)
+    return boxes, logits[:, 0]

@@ -151,6 +151,42 @@ def main():
     out["tr.refs"] = torch.stack(refs).numpy()                  # [n_dec + 1, 1, nq, 4] sigmoid space
     out["tr.pred_boxes"] = res["pred_boxes"].numpy()
     out["tr.pred_logits"] = res["pred_logits"].numpy()
+    # ---- the whole detector: Swin-L widths at depths [2, 2, 2, 2] + input projections + 2/2-layer transformer, 100 x 136 image ----
+    cfg = U.inference_wrapper.Config.fromfile("/root/reference/detect_tools/upn/configs/upn_large.py").model
+    cfg["vision_backbone_cfg"]["backbone_cfg"] = dict(type="SwinTransformer", pretrain_img_size=384, embed_dim=C.SWIN_EMBED, depths=C.SWIN_DEPTHS_SMALL,
+                                                      num_heads=C.SWIN_HEADS, window_size=C.SWIN_WINDOW, out_indices=(0, 1, 2, 3), dilation=False,
+                                                      use_checkpoint=False)
+    cfg["num_queries"] = cfg["transformer_cfg"]["num_queries"] = C.N_QUERIES_SMALL
+    cfg["transformer_cfg"]["encoder_cfg"]["num_layers"] = 2
+    cfg["transformer_cfg"]["decoder_cfg"]["num_layers"] = 2
+    model = U.build_architecture(cfg).eval()
+    res = model.load_state_dict(C.upn_state(), strict=False)
+    assert not res.unexpected_keys, res.unexpected_keys
+    left = [k for k in res.missing_keys if not ("relative_position_index" in k or "ref_point_head_point" in k or "bbox_embed." in k)]
+    assert not left, left
+    from detect_tools.upn.models.module import nested_tensor_from_tensor_list
+    img = C.test_image()
+    feats = {}
+    hk = model.backbone.model.backbone.register_forward_hook(lambda m, i, o: feats.update({k: v.tensors.detach().clone() for k, v in o.items()}))
+    orig_fbe = model.forward_backbone_encoder
+    fbe = {}
+
+    def spy_fbe(samples):
+        r = orig_fbe(samples)
+        fbe["src"], fbe["pos"], fbe["shapes"] = r[0].detach().clone(), r[1].detach().clone(), r[3].clone()
+        return r
+
+    model.forward_backbone_encoder = spy_fbe
+    with torch.no_grad():
+        res = model(nested_tensor_from_tensor_list([img]), "fine_grained_prompt")
+    hk.remove()
+    for l in range(4):
+        out[f"full.swin{l}"] = feats[l][0].flatten(1).t().contiguous().numpy().astype(np.float16)      # token-major [H*W, C]
+    out["full.src"] = fbe["src"][0].numpy().astype(np.float16)
+    out["full.pos"] = fbe["pos"][0].numpy().astype(np.float16)
+    out["full.shapes"] = fbe["shapes"].numpy()
+    out["full.pred_boxes"] = res["pred_boxes"][0].numpy()
+    out["full.pred_logits"] = res["pred_logits"][0, :, 0].numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes", {k: v.shape for k, v in out.items()})
 

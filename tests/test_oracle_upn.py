@@ -43,3 +43,22 @@ def test_query_selection_decoder_and_heads_match_reference_model():
     assert (refs - torch.from_numpy(G["tr.refs"])[:, 0]).abs().max().item() <= 1e-5
     assert (boxes - torch.from_numpy(G["tr.pred_boxes"])[0]).abs().max().item() <= 1e-5
     assert (logits - torch.from_numpy(G["tr.pred_logits"])[0]).abs().max().item() <= 2e-4
+
+
+def test_swin_backbone_input_projection_and_whole_detector_match_reference_model():
+    """Swin-L widths at depths [2, 2, 2, 2] on a 100 x 136 image (ragged against the 4-pixel patch grid's windows: padding, cyclic
+    shift and the shift mask are all exercised), input projections + position embeddings, and the whole forward down to the boxes."""
+    state = C.upn_state()
+    img = C.test_image()
+    feats, sizes = O.swin_forward(state, img, C.SWIN_DEPTHS_SMALL, C.SWIN_HEADS, C.SWIN_WINDOW)
+    assert sizes == [(25, 34), (13, 17), (7, 9), (4, 5)]
+    for l, f in enumerate(feats):
+        ref = torch.from_numpy(G[f"full.swin{l}"]).float()
+        assert (f - ref).abs().max().item() <= 4e-3 * max(1.0, ref.abs().max().item()), f"swin stage {l}"      # golden stored in fp16
+    src, pos, shapes = O.backbone_encoder_inputs(state, feats, sizes)
+    assert [list(s) for s in shapes] == G["full.shapes"].tolist()
+    assert (src - torch.from_numpy(G["full.src"]).float()).abs().max().item() <= 1e-2
+    assert (pos - torch.from_numpy(G["full.pos"]).float()).abs().max().item() <= 5e-3
+    boxes, logits = O.detect(state, img, C.SWIN_DEPTHS_SMALL, C.SWIN_HEADS, C.SWIN_WINDOW, 2, 2, C.N_QUERIES_SMALL)
+    assert (boxes - torch.from_numpy(G["full.pred_boxes"])).abs().max().item() <= 1e-4
+    assert (logits - torch.from_numpy(G["full.pred_logits"])).abs().max().item() <= 1e-3

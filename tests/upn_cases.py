@@ -110,3 +110,65 @@ def transformer_state(n_enc=2, n_dec=2, n_queries=N_QUERIES_SMALL, seed=777, d=D
     s["transformer.fine_grained_prompt.weight"] = _bf(torch.randn(1, d, generator=g))
     s["transformer.coarse_grained_prompt.weight"] = _bf(torch.randn(1, d, generator=g))
     return s
+
+
+# ---- Swin-L backbone (true widths, reduced depth) + input projections: the whole detector -----------------------------------------
+SWIN_EMBED, SWIN_HEADS, SWIN_WINDOW = 192, [6, 12, 24, 48], 12          # reference swin_L_384_22k (backbone/wrapper.py:286-292)
+SWIN_DEPTHS_SMALL = [2, 2, 2, 2]                                         # reference: [2, 2, 18, 2]
+IMG_SMALL = (100, 136)                                                   # H, W of the test image: ragged against the patch (4) and the window (12)
+
+
+def swin_state(depths=SWIN_DEPTHS_SMALL, seed=99, embed=SWIN_EMBED, heads=SWIN_HEADS, ws=SWIN_WINDOW, prefix="backbone.model.backbone."):
+    g = torch.Generator().manual_seed(seed)
+    s = {prefix + "patch_embed.proj.weight": _bf(torch.randn(embed, 3, 4, 4, generator=g) * 0.15),
+         prefix + "patch_embed.proj.bias": _bf(torch.randn(embed, generator=g) * 0.05)}
+    s.update(_norm_state(g, prefix + "patch_embed.norm.", embed))
+    for i, depth in enumerate(depths):
+        C = embed * 2 ** i
+        for j in range(depth):
+            p = f"{prefix}layers.{i}.blocks.{j}."
+            s.update(_norm_state(g, p + "norm1.", C))
+            s[p + "attn.relative_position_bias_table"] = _bf(torch.randn((2 * ws - 1) ** 2, heads[i], generator=g) * 0.5)
+            s[p + "attn.qkv.weight"] = _bf(torch.randn(3 * C, C, generator=g) / math.sqrt(C))
+            s[p + "attn.qkv.bias"] = _bf(torch.randn(3 * C, generator=g) * 0.05)
+            s[p + "attn.proj.weight"] = _bf(torch.randn(C, C, generator=g) / math.sqrt(C) * 0.5)
+            s[p + "attn.proj.bias"] = _bf(torch.randn(C, generator=g) * 0.05)
+            s.update(_norm_state(g, p + "norm2.", C))
+            s[p + "mlp.fc1.weight"] = _bf(torch.randn(4 * C, C, generator=g) / math.sqrt(C))
+            s[p + "mlp.fc1.bias"] = _bf(torch.randn(4 * C, generator=g) * 0.05)
+            s[p + "mlp.fc2.weight"] = _bf(torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C) * 0.5)
+            s[p + "mlp.fc2.bias"] = _bf(torch.randn(C, generator=g) * 0.05)
+        if i < len(depths) - 1:
+            p = f"{prefix}layers.{i}.downsample."
+            s[p + "reduction.weight"] = _bf(torch.randn(2 * C, 4 * C, generator=g) / math.sqrt(4 * C))
+            s.update(_norm_state(g, p + "norm.", 4 * C))
+        s.update(_norm_state(g, f"{prefix}norm{i}.", C))
+    return s
+
+
+def input_proj_state(seed=55, embed=SWIN_EMBED, d=D_MODEL):
+    g = torch.Generator().manual_seed(seed)
+    s = {}
+    chans = [embed * 2 ** i for i in range(4)]
+    for l, c in enumerate(chans):
+        s[f"input_proj.{l}.0.weight"] = _bf(torch.randn(d, c, 1, 1, generator=g) / math.sqrt(c))
+        s[f"input_proj.{l}.0.bias"] = _bf(torch.randn(d, generator=g) * 0.05)
+        s.update(_norm_state(g, f"input_proj.{l}.1.", d))
+    s["input_proj.4.0.weight"] = _bf(torch.randn(d, chans[-1], 3, 3, generator=g) / math.sqrt(9 * chans[-1]))
+    s["input_proj.4.0.bias"] = _bf(torch.randn(d, generator=g) * 0.05)
+    s.update(_norm_state(g, "input_proj.4.1.", d))
+    s["transformer.level_embed"] = _bf(torch.randn(N_LEVELS, d, generator=g))
+    return s
+
+
+def upn_state(depths=SWIN_DEPTHS_SMALL, n_enc=2, n_dec=2, n_queries=N_QUERIES_SMALL):
+    s = transformer_state(n_enc, n_dec, n_queries)
+    s.update(swin_state(depths))
+    s.update(input_proj_state())
+    return s
+
+
+def test_image(hw=IMG_SMALL, seed=21):
+    """Normalised image tensor [3, H, W] (what UPNWrapper.transform_image hands to the model), bf16-representable."""
+    g = torch.Generator().manual_seed(seed)
+    return _bf(torch.randn(3, hw[0], hw[1], generator=g))

@@ -46,6 +46,11 @@ struct AttnParams {
     const int* seq_state;
     long long q_seq_stride;                          // Q elements between sequences
     long long part_seq_stride;                       // floats between sequences in `part`
+    // window attention with an additive bias (Swin: relative position bias + shifted-window mask, backbone/swin.py:150-175):
+    // bias fp32 [Hq][wlen][wlen], indexed by the query / key position inside the item's kv range (= one window of wlen tokens)
+    const float* bias;
+    int wlen;
+    int sw_ws, sw_shift, sw_nwy, sw_nwx;             // sw_shift > 0: -100 between tokens of different shift regions (:446-466)
 };
 
 template <int HD, int NW, bool PARTIAL = false>
@@ -88,6 +93,27 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     const bool q_ok = q_idx < it.q_end;
     const int q_base = p.q_row_base ? *p.q_row_base : 0;
     const int q_ld = (q_ok ? q_idx : it.q_end - 1) - q_base;
+    // additive bias (and shift regions) of this window: row of the lane's query, region id of every token of the window
+    __shared__ unsigned char s_reg[256];
+    const float* bias_row = nullptr;
+    int rid_q = 0;
+    if (!PARTIAL && p.bias) {
+        const int ql_loc = (q_ok ? q_idx : it.q_end - 1) - it.kv_start;
+        bias_row = p.bias + ((long long)h * p.wlen + ql_loc) * p.wlen;
+        if (p.sw_shift > 0) {
+            const int win = (it.kv_start / p.wlen) % (p.sw_nwy * p.sw_nwx);
+            const int wy = win / p.sw_nwx, wx = win - wy * p.sw_nwx;
+            const int Hp = p.sw_nwy * p.sw_ws, Wp = p.sw_nwx * p.sw_ws;
+            for (int t = tid; t < p.wlen; t += NT) {
+                const int y = wy * p.sw_ws + t / p.sw_ws, x = wx * p.sw_ws + t % p.sw_ws;
+                const int ry = y < Hp - p.sw_ws ? 0 : (y < Hp - p.sw_shift ? 1 : 2);
+                const int rx = x < Wp - p.sw_ws ? 0 : (x < Wp - p.sw_shift ? 1 : 2);
+                s_reg[t] = (unsigned char)(ry * 3 + rx);
+            }
+            __syncthreads();
+            rid_q = s_reg[ql_loc];
+        }
+    }
 
     // Q fragments (B operand): lane (query ql, k-group g) holds d = c*32 + g*8 .. +8
     bf16x8 qf[NC];
@@ -177,7 +203,12 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int key = k0 + kt * 16 + g * 4 + r;
                 const bool ok = key < kv_hi && (!p.causal || key <= q_idx);
-                const float v = ok ? s[kt][r] * p.scale : -INFINITY;
+                float v = ok ? s[kt][r] * p.scale : -INFINITY;
+                if (!PARTIAL && bias_row && ok) {
+                    const int kl = key - it.kv_start;
+                    v += bias_row[kl];
+                    if (p.sw_shift > 0 && s_reg[kl] != rid_q) v += -100.0f;
+                }
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
@@ -519,12 +550,13 @@ static int launch_attn(const AttnParams& p, int q_block, hipStream_t st, double 
 
 extern "C" {
 
-int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_stride,
+static int attention_entry(const void* Q, long long q_tok_stride, long long q_head_stride,
                        const void* K, long long k_tok_stride, long long k_head_stride,
                        const void* VT, long long vt_row_stride,
                        void* O, long long o_tok_stride, long long o_head_stride,
                        const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads, int head_dim,
-                       float scale, int causal, const int32_t* q_row_base, double flops_hint, void* stream) {
+                       float scale, int causal, const int32_t* q_row_base, double flops_hint, void* stream,
+                       const float* bias, int wlen, int sw_ws, int sw_shift, int sw_nwy, int sw_nwx) {
     using namespace fo1;
     if (n_items == 0) return FO1_OK;
     FO1_CHECK_ARG(Q && K && VT && O && items, "attention: NULL operand");
@@ -547,10 +579,36 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
     p.scale = scale; p.causal = causal; p.q_row_base = (const int*)q_row_base;
     p.part = nullptr; p.dyn_kv_len = nullptr; p.kv_chunk = 0; p.q_range_end = 0;
     p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
+    p.bias = bias; p.wlen = wlen; p.sw_ws = sw_ws; p.sw_shift = sw_shift; p.sw_nwy = sw_nwy; p.sw_nwx = sw_nwx;
     hipStream_t st = (hipStream_t)stream;
     if (head_dim == 32) return launch_attn<32>(p, q_block, st, flops_hint);
     if (head_dim == 80) return launch_attn<80>(p, q_block, st, flops_hint);
     return launch_attn<128>(p, q_block, st, flops_hint);
+}
+
+int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_stride,
+                       const void* K, long long k_tok_stride, long long k_head_stride,
+                       const void* VT, long long vt_row_stride,
+                       void* O, long long o_tok_stride, long long o_head_stride,
+                       const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads, int head_dim,
+                       float scale, int causal, const int32_t* q_row_base, double flops_hint, void* stream) {
+    return attention_entry(Q, q_tok_stride, q_head_stride, K, k_tok_stride, k_head_stride, VT, vt_row_stride, O, o_tok_stride, o_head_stride, items, n_items,
+                           q_block, n_q_heads, n_kv_heads, head_dim, scale, causal, q_row_base, flops_hint, stream, nullptr, 0, 0, 0, 0, 0);
+}
+
+// Window attention with an additive bias (Swin W-MSA / SW-MSA, backbone/swin.py:136-175): softmax(q k^T scale + bias[head][i][j]
+// (+ -100 between tokens of different shift regions)) v.  Every item's kv range is one window of `wlen` tokens (<= 256), windows
+// stored consecutively (image-major, row-major over the nwy x nwx windows of an image); bias fp32 [n_heads][wlen][wlen];
+// shift > 0 turns the shifted-window mask on (regions of BasicLayer.forward :446-466, computed from the window's place).
+int fo1_attention_window_bias_bf16(const void* Q, long long q_tok_stride, long long q_head_stride, const void* K, long long k_tok_stride,
+                                   long long k_head_stride, const void* VT, long long vt_row_stride, void* O, long long o_tok_stride,
+                                   long long o_head_stride, const int32_t* items, int n_items, int q_block, int n_heads, int head_dim, float scale,
+                                   const float* bias, int wlen, int ws, int shift, int nwy, int nwx, double flops_hint, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(bias && wlen > 0 && wlen <= 256 && ws > 0 && ws * ws == wlen && shift >= 0 && shift < ws && nwy > 0 && nwx > 0,
+                  "attention_window_bias: bad window geometry (wlen=%d ws=%d shift=%d)", wlen, ws, shift);
+    return attention_entry(Q, q_tok_stride, q_head_stride, K, k_tok_stride, k_head_stride, VT, vt_row_stride, O, o_tok_stride, o_head_stride, items, n_items,
+                           q_block, n_heads, n_heads, head_dim, scale, 0, nullptr, flops_hint, stream, bias, wlen, ws, shift, nwy, nwx);
 }
 
 // Decode-step attention for ONE new token against the KV cache, split over KV chunks of 64 keys
@@ -596,6 +654,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
     p.items = nullptr;
     p.q_range_end = group;
     p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
+    p.bias = nullptr; p.wlen = 0; p.sw_ws = p.sw_shift = p.sw_nwy = p.sw_nwx = 0;
     hipStream_t st = (hipStream_t)stream;
     FO1_LAUNCH("attn_decode_split", (double)max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
                dim3(p.n_items, n_kv_heads), dim3(256), 0, st, p);
@@ -652,6 +711,7 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     p.q_range_end = group;
     p.seq_state = (const int*)state; p.q_seq_stride = q_seq_stride;
     p.part_seq_stride = (long long)p.n_items * n_kv_heads * 16 * (head_dim + 2);
+    p.bias = nullptr; p.wlen = 0; p.sw_ws = p.sw_shift = p.sw_nwy = p.sw_nwx = 0;
     hipStream_t st = (hipStream_t)stream;
     FO1_LAUNCH("attn_decode_split", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
                dim3(p.n_items, n_kv_heads, batch), dim3(256), 0, st, p);

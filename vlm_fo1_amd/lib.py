@@ -144,6 +144,14 @@ SIGNATURES = {
     "fo1_llm_decode_step": (c_int, [ctypes.POINTER(LlmWeights), ctypes.POINTER(KvCache), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
                                     c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
     "fo1_zero_bytes": (c_int, [c_void_p, c_size_t, c_void_p]),
+    "fo1_attention_window_bias_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong,
+                                               c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                               ctypes.c_double, c_void_p]),
+    "fo1_swin_window_partition_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_swin_window_reverse_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_patch_merge_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_groupnorm_tokens_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "fo1_groupnorm_tokens_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "fo1_sine_embed_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "fo1_box_refine_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "fo1_mask_rows_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

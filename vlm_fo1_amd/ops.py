@@ -770,3 +770,60 @@ def gather_rows_f32(table: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
     out = torch.empty(idx.numel(), D, dtype=torch.float32, device=table.device)
     _L.check(_L.load().fo1_gather_rows_f32(pt, ldt, idx.data_ptr(), out.data_ptr(), out.stride(0), idx.numel(), D, _stream()), "fo1_gather_rows_f32")
     return out
+
+
+# ---- Swin backbone pieces (swin_ops.hip, attention.hip) ------------------------------------------------------------------------
+def attention_window_bias(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_heads: int, head_dim: int, scale: float,
+                          bias: torch.Tensor, ws: int, shift: int, nwy: int, nwx: int, flops: float = 0.0) -> torch.Tensor:
+    """Swin W-MSA / SW-MSA over consecutive windows of ws*ws tokens (fo1_attention_window_bias_bf16); bias fp32 [heads, ws*ws, ws*ws]."""
+    _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt")
+    wlen = ws * ws
+    if not bias.is_cuda or bias.dtype != torch.float32 or tuple(bias.shape) != (n_heads, wlen, wlen) or not bias.is_contiguous():
+        raise TypeError("attention_window_bias: bias must be a contiguous fp32 GPU tensor [heads, ws*ws, ws*ws]")
+    pq, ldq, L, _ = _rows(q, "q")
+    pk, ldk, _, _ = _rows(k, "k")
+    pv, ldv, _, _ = _rows(vt, "vt")
+    out = torch.empty(L, n_heads * head_dim, dtype=torch.bfloat16, device=q.device)
+    rc = _L.load().fo1_attention_window_bias_bf16(pq, ldq, head_dim, pk, ldk, head_dim, pv, ldv, out.data_ptr(), out.stride(0), head_dim, items.data_ptr(),
+                                                  items.shape[0], getattr(items, "q_block", 64), n_heads, head_dim, float(scale), bias.data_ptr(), wlen, ws,
+                                                  shift, nwy, nwx, float(flops), _stream())
+    _L.check(rc, "fo1_attention_window_bias_bf16")
+    return out
+
+
+def swin_window_partition(x: torch.Tensor, H: int, W: int, ws: int, shift: int, batch: int = 1) -> torch.Tensor:
+    _chk(x, "x")
+    assert x.is_contiguous() and x.shape[0] == batch * H * W
+    C = x.shape[1]
+    nwy, nwx = -(-H // ws), -(-W // ws)
+    xw = torch.empty(batch * nwy * nwx * ws * ws, C, dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_swin_window_partition_bf16(x.data_ptr(), xw.data_ptr(), H, W, C, ws, shift, batch, _stream()), "fo1_swin_window_partition_bf16")
+    return xw
+
+
+def swin_window_reverse_add(yw: torch.Tensor, shortcut: torch.Tensor, H: int, W: int, ws: int, shift: int, batch: int = 1) -> torch.Tensor:
+    _chk(yw, "yw"); _chk(shortcut, "shortcut")
+    assert yw.is_contiguous() and shortcut.is_contiguous() and shortcut.shape[0] == batch * H * W
+    y = torch.empty_like(shortcut)
+    _L.check(_L.load().fo1_swin_window_reverse_add_bf16(yw.data_ptr(), shortcut.data_ptr(), y.data_ptr(), H, W, shortcut.shape[1], ws, shift, batch, _stream()),
+             "fo1_swin_window_reverse_add_bf16")
+    return y
+
+
+def patch_merge(x: torch.Tensor, H: int, W: int, batch: int = 1) -> torch.Tensor:
+    _chk(x, "x")
+    assert x.is_contiguous() and x.shape[0] == batch * H * W
+    C = x.shape[1]
+    out = torch.empty(batch * ((H + 1) // 2) * ((W + 1) // 2), 4 * C, dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_patch_merge_bf16(x.data_ptr(), out.data_ptr(), H, W, C, batch, _stream()), "fo1_patch_merge_bf16")
+    return out
+
+
+def groupnorm_tokens(x: torch.Tensor, groups: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    _chk(x, "x"); _chk(weight, "weight"); _chk(bias, "bias")
+    px, ldx, S, C = _rows(x, "x")
+    y = torch.empty(S, C, dtype=torch.bfloat16, device=x.device)
+    ws = _workspace("groupnorm", x.device, _L.load().fo1_groupnorm_tokens_workspace_bytes(S, groups))
+    _L.check(_L.load().fo1_groupnorm_tokens_bf16(px, ldx, S, C, groups, weight.data_ptr(), bias.data_ptr(), float(eps), y.data_ptr(), y.stride(0), ws.data_ptr(),
+                                                 ws.numel(), _stream()), "fo1_groupnorm_tokens_bf16")
+    return y

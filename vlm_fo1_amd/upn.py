@@ -267,3 +267,196 @@ class DeformableDecoder:
         boxes = ops.box_refine(self.bbox(hs[-1], last_f32=True), refs[-2], mode=0)
         logits = ops.gemm(hs[-1], self.prompts[prompt_type], out_f32=True)
         return dict(hs=hs, refs=refs, pred_boxes=boxes, pred_logits=logits[:, 0])
+
+
+# ---- Swin-L backbone ----------------------------------------------------------------------------------------------------------------
+# Reference: models/backbone/swin.py (PatchEmbed :484-522, SwinTransformerBlock :259-318, WindowAttention :136-175, PatchMerging
+# :333-357, BasicLayer :440-481, SwinTransformer.forward :700-744).  Same launch shape per block as the DaViT spatial block of the
+# main path: LayerNorm -> pad + cyclic shift + window partition (one gather) -> qkv GEMM -> window attention with the relative-position
+# bias and the shift mask inside the MFMA kernel -> proj GEMM -> reverse + un-shift + crop + residual (one gather) -> LayerNorm ->
+# fc1 + GELU -> fc2 + residual.  The bias table is expanded to a dense fp32 [heads, 144, 144] per block once at load.
+def _round_up(a: int, b: int) -> int:
+    return (a + b - 1) // b * b
+
+
+def _rel_pos_index(ws: int) -> torch.Tensor:
+    coords = torch.stack(torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")).flatten(1)
+    rel = (coords[:, :, None] - coords[:, None, :]).permute(1, 2, 0).contiguous()
+    rel[:, :, 0] += ws - 1
+    rel[:, :, 1] += ws - 1
+    rel[:, :, 0] *= 2 * ws - 1
+    return rel.sum(-1)
+
+
+class SwinBackbone:
+    def __init__(self, state: Dict[str, torch.Tensor], depths: Sequence[int], heads: Sequence[int], window: int, device="cuda",
+                 prefix: str = "backbone.model.backbone."):
+        self.dev = torch.device(device)
+        self.depths, self.heads, self.ws = list(depths), list(heads), window
+        w = state[prefix + "patch_embed.proj.weight"]                       # [C0, 3, 4, 4]
+        self.C0 = w.shape[0]
+        wp = torch.zeros(self.C0, 4, 4, 8, dtype=w.dtype)                   # im2col order [ky][kx][c], image staged with 8 channels
+        wp[..., :3] = w.permute(0, 2, 3, 1)
+        self.pe_w, self.pe_b = _dev(wp.reshape(self.C0, 128), self.dev), _dev(state[prefix + "patch_embed.proj.bias"], self.dev)
+        self.pe_n = (_dev(state[prefix + "patch_embed.norm.weight"], self.dev), _dev(state[prefix + "patch_embed.norm.bias"], self.dev))
+        rel = _rel_pos_index(window).view(-1)
+        wl = window * window
+        self.stages = []
+        for i, depth in enumerate(self.depths):
+            blocks = []
+            for j in range(depth):
+                p = f"{prefix}layers.{i}.blocks.{j}."
+                bias = state[p + "attn.relative_position_bias_table"].float()[rel].view(wl, wl, -1).permute(2, 0, 1).contiguous()
+                blocks.append(dict(
+                    n1=(_dev(state[p + "norm1.weight"], self.dev), _dev(state[p + "norm1.bias"], self.dev)),
+                    n2=(_dev(state[p + "norm2.weight"], self.dev), _dev(state[p + "norm2.bias"], self.dev)),
+                    qkv_w=_dev(state[p + "attn.qkv.weight"], self.dev), qkv_b=_dev(state[p + "attn.qkv.bias"], self.dev),
+                    proj_w=_dev(state[p + "attn.proj.weight"], self.dev), proj_b=_dev(state[p + "attn.proj.bias"], self.dev),
+                    fc1_w=_dev(state[p + "mlp.fc1.weight"], self.dev), fc1_b=_dev(state[p + "mlp.fc1.bias"], self.dev),
+                    fc2_w=_dev(state[p + "mlp.fc2.weight"], self.dev), fc2_b=_dev(state[p + "mlp.fc2.bias"], self.dev),
+                    bias=bias.to(self.dev), shift=0 if j % 2 == 0 else window // 2))
+            st = dict(blocks=blocks, norm=(_dev(state[f"{prefix}norm{i}.weight"], self.dev), _dev(state[f"{prefix}norm{i}.bias"], self.dev)))
+            if i < len(self.depths) - 1:
+                p = f"{prefix}layers.{i}.downsample."
+                st["merge"] = dict(n=(_dev(state[p + "norm.weight"], self.dev), _dev(state[p + "norm.bias"], self.dev)), w=_dev(state[p + "reduction.weight"], self.dev))
+            self.stages.append(st)
+        self._items: Dict[tuple, torch.Tensor] = {}
+
+    def _window_items(self, n_windows: int, heads: int):
+        key = (n_windows, heads)
+        if key not in self._items:
+            wl = self.ws * self.ws
+            segs = [(i * wl, (i + 1) * wl) for i in range(n_windows)]
+            self._items[key] = ops.make_items(segs, self.dev, block=ops.pick_q_block(segs, heads))
+        return self._items[key]
+
+    def _block(self, x, H, W, C, heads, b):
+        ws, shift = self.ws, b["shift"]
+        h = ops.layernorm(x, b["n1"][0], b["n1"][1], 1e-5)
+        hw = ops.swin_window_partition(h, H, W, ws, shift)
+        qkv = ops.gemm(hw, b["qkv_w"], b["qkv_b"])
+        n = hw.shape[0]
+        n_pad = _round_up(n, 64)
+        vt = ops._workspace(f"swin_vt_{C}x{n_pad}", self.dev, C * n_pad * 2)[:C * n_pad * 2].view(BF).view(C, n_pad)
+        ops.transpose_into(qkv[:, 2 * C:], vt, 0)
+        hd = C // heads
+        nwy, nwx = -(-H // ws), -(-W // ws)
+        att = ops.attention_window_bias(qkv[:, :C], qkv[:, C:2 * C], vt, self._window_items(nwy * nwx, heads), heads, hd, float(hd) ** -0.5, b["bias"], ws, shift,
+                                        nwy, nwx, flops=4.0 * C * n * ws * ws)
+        y = ops.gemm(att, b["proj_w"], b["proj_b"])
+        x = ops.swin_window_reverse_add(y, x, H, W, ws, shift)
+        h = ops.layernorm(x, b["n2"][0], b["n2"][1], 1e-5)
+        h = ops.gemm(h, b["fc1_w"], b["fc1_b"], act=ops.ACT_GELU)
+        return ops.gemm(h, b["fc2_w"], b["fc2_b"], residual=x)
+
+    def forward(self, img: torch.Tensor):
+        """img [3, H, W] on the device (normalised, fp32 or bf16) -> ([token-major normed stage outputs bf16 [H_l*W_l, C_l]], [(H_l, W_l)])."""
+        if not img.is_cuda or img.dim() != 3:
+            raise TypeError("SwinBackbone: image must be a [3, H, W] GPU tensor (no CPU path exists)")
+        _, H, W = img.shape
+        Hp, Wp = _round_up(H, 4), _round_up(W, 4)
+        if (Hp, Wp) != (H, W):                                  # PatchEmbed pads right / bottom with zeros to the patch multiple (:506-509)
+            pad = torch.zeros(3, Hp, Wp, dtype=img.dtype, device=img.device)
+            pad[:, :H, :W].copy_(img)
+            img = pad
+        x = ops.nchw_to_hwc8(img.contiguous())
+        col, H, W = ops.im2col(x, Hp, Wp, 4, 4, 4, 0)
+        x = ops.layernorm(ops.gemm(col, self.pe_w, self.pe_b), self.pe_n[0], self.pe_n[1], 1e-5)
+        feats, sizes = [], []
+        C = self.C0
+        for i, st in enumerate(self.stages):
+            for b in st["blocks"]:
+                x = self._block(x, H, W, C, self.heads[i], b)
+            feats.append(ops.layernorm(x, st["norm"][0], st["norm"][1], 1e-5))
+            sizes.append((H, W))
+            if "merge" in st:
+                g = ops.patch_merge(x, H, W)
+                H, W = (H + 1) // 2, (W + 1) // 2
+                x = ops.gemm(ops.layernorm(g, st["merge"]["n"][0], st["merge"]["n"][1], 1e-5), st["merge"]["w"])
+                C *= 2
+        return feats, sizes
+
+
+def position_embedding_sine_hw(H: int, W: int, num_pos_feats: int = 128, temp_h: float = 20.0, temp_w: float = 20.0) -> torch.Tensor:
+    """PositionEmbeddingSineHW (utils/detr_utils.py:110-148; normalize=True, temperatures 20 in configs/upn_large.py) on an unpadded map:
+    fp32 [H*W, 2*num_pos_feats] (pos_y | pos_x), computed on the host (a function of the shape only)."""
+    scale, eps = 2 * np.pi, 1e-6
+    y = np.arange(1, H + 1, dtype=np.float32)[:, None].repeat(W, 1)
+    x = np.arange(1, W + 1, dtype=np.float32)[None, :].repeat(H, 0)
+    y = y / (y[-1:, :] + np.float32(eps)) * np.float32(scale)
+    x = x / (x[:, -1:] + np.float32(eps)) * np.float32(scale)
+    d = np.arange(num_pos_feats, dtype=np.float32)
+    dx = np.float32(temp_w) ** (2 * (d // 2) / np.float32(num_pos_feats))
+    dy = np.float32(temp_h) ** (2 * (d // 2) / np.float32(num_pos_feats))
+    px, py = x[:, :, None] / dx, y[:, :, None] / dy
+    px = np.stack((np.sin(px[:, :, 0::2]), np.cos(px[:, :, 1::2])), 3).reshape(H, W, -1)
+    py = np.stack((np.sin(py[:, :, 0::2]), np.cos(py[:, :, 1::2])), 3).reshape(H, W, -1)
+    return torch.from_numpy(np.concatenate((py, px), 2).reshape(H * W, -1).astype(np.float32))
+
+
+class InputProjection:
+    """upn_model.py:143-216: 1x1 conv + GroupNorm(32) per backbone level, 3x3 stride-2 conv + GroupNorm for the extra level, then the
+    level-major flatten with (sine position + level) embeddings."""
+
+    def __init__(self, state, device="cuda", n_levels: int = 5, groups: int = 32):
+        self.dev = torch.device(device)
+        self.groups, self.n_levels = groups, n_levels
+        self.proj = []
+        l = 0
+        while f"input_proj.{l}.0.weight" in state:
+            w = state[f"input_proj.{l}.0.weight"]
+            k = w.shape[-1]
+            wg = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)                # [Cout][ky][kx][Cin] (im2col order)
+            self.proj.append(dict(k=k, w=_dev(wg, self.dev), b=_dev(state[f"input_proj.{l}.0.bias"], self.dev),
+                                  gw=_dev(state[f"input_proj.{l}.1.weight"], self.dev), gb=_dev(state[f"input_proj.{l}.1.bias"], self.dev)))
+            l += 1
+        self.level_embed = state["transformer.level_embed"].float()
+        self._pos: Dict[tuple, torch.Tensor] = {}
+
+    def forward(self, feats: List[torch.Tensor], sizes: List[Tuple[int, int]]):
+        srcs, shapes = [], []
+        for l, (f, (H, W)) in enumerate(zip(feats, sizes)):
+            pr = self.proj[l]
+            srcs.append(ops.groupnorm_tokens(ops.gemm(f, pr["w"], pr["b"]), self.groups, pr["gw"], pr["gb"], 1e-5))
+            shapes.append((H, W))
+        for l in range(len(feats), self.n_levels):
+            pr = self.proj[l]
+            inp, (H, W) = (feats[-1], sizes[-1]) if l == len(feats) else (srcs[-1], shapes[-1])
+            col, Ho, Wo = ops.im2col(inp, H, W, 3, 3, 2, 1)
+            srcs.append(ops.groupnorm_tokens(ops.gemm(col, pr["w"], pr["b"]), self.groups, pr["gw"], pr["gb"], 1e-5))
+            shapes.append((Ho, Wo))
+        key = tuple(shapes)
+        if key not in self._pos:
+            pos = torch.cat([position_embedding_sine_hw(H, W) + self.level_embed[l][None] for l, (H, W) in enumerate(shapes)], 0)
+            self._pos[key] = pos.to(device=self.dev, dtype=BF).contiguous()
+        S = sum(h * w for h, w in shapes)
+        src = torch.empty(S, srcs[0].shape[1], dtype=BF, device=self.dev)    # level-major flatten (row copies into one buffer)
+        r = 0
+        for s in srcs:
+            src[r:r + s.shape[0]].copy_(s)
+            r += s.shape[0]
+        return src, self._pos[key], shapes
+
+
+class UPNEngine:
+    """The whole UPN forward for one image: Swin-L -> input projections -> deformable encoder -> query selection -> decoder -> heads
+    (models/architecture/upn_model.py:86-140).  configs/upn_large.py: depths [2, 2, 18, 2], 6 + 6 layers, 900 queries."""
+
+    def __init__(self, state, device="cuda", depths=(2, 2, 18, 2), heads=(6, 12, 24, 48), window: int = 12, n_enc: int = 6, n_dec: int = 6,
+                 n_queries: int = 900):
+        self.backbone = SwinBackbone(state, depths, heads, window, device)
+        self.proj = InputProjection(state, device)
+        self.encoder = DeformableEncoder(state, "transformer.encoder.", n_enc, device)
+        self.selector = QuerySelector(state, device, n_queries)
+        self.decoder = DeformableDecoder(state, n_dec, device, n_queries)
+
+    def forward(self, img: torch.Tensor, prompt_type: str = "fine_grained_prompt") -> dict:
+        if prompt_type not in ("fine_grained_prompt", "coarse_grained_prompt"):
+            raise ValueError("prompt_type must be 'fine_grained_prompt' or 'coarse_grained_prompt' (inference_wrapper.py:51-52)")
+        feats, sizes = self.backbone.forward(img)
+        src, pos, shapes = self.proj.forward(feats, sizes)
+        memory = self.encoder.forward(src, pos, shapes)
+        sel = self.selector.forward(memory, shapes, prompt_type)
+        out = self.decoder.forward(memory, shapes, sel["refpoints"], prompt_type)
+        return dict(pred_boxes=out["pred_boxes"], pred_logits=out["pred_logits"], feats=feats, sizes=sizes, src=src, pos=pos, shapes=shapes,
+                    memory=memory, selection=sel)
