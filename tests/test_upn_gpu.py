@@ -184,3 +184,33 @@ def test_whole_detector_boxes_match_reference_model():
     assert (forced["pred_boxes"].cpu() - rb).abs().max().item() <= 0.02, "teacher-forced decoder over the engine's memory"
     again = eng.forward(C.test_image().cuda())
     assert torch.equal(again["pred_boxes"], out["pred_boxes"])
+
+
+def test_upn_wrapper_contract_and_full_size_model():
+    """The drop-in UPNWrapper at the reference's real configuration (configs/upn_large.py: Swin-L depths [2, 2, 18, 2], 6 + 6 layers, 900
+    queries) on an 800-short-side image: inference() returns what the reference's does (boxes [1, 900, 4] in original pixels sorted by
+    score, scores [1, 900, 1] in [0, 1]), filter() thresholds + NMS; timing printed for the record (random weights: no accuracy claim)."""
+    import time
+    from PIL import Image
+    from detect_tools.upn import UPNWrapper
+    state = C.upn_state(depths=[2, 2, 18, 2], n_enc=6, n_dec=6, n_queries=900)
+    w = UPNWrapper(state, "cuda")
+    rng = np.random.default_rng(5)
+    img = Image.fromarray(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8), "RGB")
+    res = w.inference([img], "fine_grained_prompt")
+    assert res["original_xyxy_boxes"].shape == (1, 900, 4) and tuple(res["scores"].shape) == (1, 900, 1)
+    sc = res["scores"][0, :, 0]
+    assert torch.isfinite(sc).all() and (sc[:-1] >= sc[1:]).all() and 0 <= float(sc.min()) and float(sc.max()) <= 1
+    assert np.isfinite(res["original_xyxy_boxes"]).all()
+    flt = w.filter(res, min_score=float(sc[100]), nms_value=0.8)
+    assert len(flt["original_xyxy_boxes"]) == 1 and 1 <= len(flt["original_xyxy_boxes"][0]) <= 101
+    assert all(len(b) == 4 and all(isinstance(v, int) for v in b) for b in flt["original_xyxy_boxes"][0])
+    assert flt["scores"][0] == sorted(flt["scores"][0], reverse=True)
+    x = w.transform_image(img)
+    assert tuple(x.shape) == (3, 800, 1066)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(3):
+        w.model.forward(x)
+    torch.cuda.synchronize()
+    print(f"\nUPN (Swin-L 2-2-18-2 + 6/6 deformable layers, 900 queries) on 800 x 1066: {(time.perf_counter() - t) / 3 * 1e3:.1f} ms per image (eager launches)")
