@@ -1,0 +1,38 @@
+"""HFRE three-kernel form, per-kernel times (library event pairs) at 1 / 8 / 12 images x 100 boxes: scalar finish (round-2 first form)
+vs the 16-byte finish; outputs compared bitwise.  usage: hfre_ab.py [out.json]"""
+import json, os, sys
+import torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+from hfre_sweep_build import build                              # noqa: E402
+from vlm_fo1_amd import lib as L                                # noqa: E402
+
+lib = L.load()
+res = []
+for B in (1, 8, 12):
+    m, call, out = build(B)
+    m.worklist = True
+    outs = {}
+    for name, unroll in (("finish_vec", 8), ("finish_scalar", 8 | 32)):
+        L.check(lib.fo1_hfre_set_tuning(unroll, 512, 256, 4096), "set_tuning")
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        L.profile(True)
+        for _ in range(20):
+            call()
+        torch.cuda.synchronize()
+        rows = L.profile_rows(reset=True)
+        L.profile(False)
+        outs[name] = out.clone()
+        per = {r["name"]: round(r["total_ms"] / r["calls"] * 1e3, 2) for r in rows}
+        tot = round(sum(per.values()), 2)
+        bytes_ = [r for r in rows if r["name"] == "hfre_pool_items"][0]["total_work"] / 20
+        res.append(dict(B=B, cfg=name, us=per, us_total=tot, us_per_image=round(tot / B, 2), full_map_bytes=bytes_,
+                        gbps_full_map=round(bytes_ / tot / 1e3, 1)))
+        print(res[-1], flush=True)
+    print(f"B={B}: vec == scalar bitwise: {torch.equal(outs['finish_vec'], outs['finish_scalar'])}", flush=True)
+    res.append(dict(B=B, bitwise_vec_equals_scalar=bool(torch.equal(outs['finish_vec'], outs['finish_scalar']))))
+lib.fo1_hfre_set_tuning(8, 512, 256, 4096)
+if len(sys.argv) > 1:
+    json.dump(res, open(sys.argv[1], "w"), indent=1)

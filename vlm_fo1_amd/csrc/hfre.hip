@@ -22,6 +22,8 @@ namespace fo1 {
 
 constexpr int kHfreThreads = 256;
 constexpr int kHfreWaves = kHfreThreads / 64;
+constexpr int kHfreWThreads = 64;    // hfre_weights_kernel: one wave per (box, source) — a latency chain (box load, atomic, two phases), so
+                                     // what matters is how many are resident: 6 000 workgroups at 12 images x 100 boxes
 constexpr int kHfreMaxChunk = 512;   // channels per workgroup (64 lanes x 8 bf16)
 constexpr int kHfreUnroll = 8;
 
@@ -55,15 +57,22 @@ struct HfreParams {
     // ---- work-list path (fo1_hfre_region_pool_ex) ----
     const int* box_image;                       // image of each box (batched call) or nullptr
     long long img_stride[FO1_HFRE_MAX_SOURCES]; // elements between consecutive images of a source map
-    int* n_items;                               // device counter of work items (zero on entry; the finish kernel re-zeroes it)
-    int2* items;                                // {box, source << 24 | chunk << 12 | slice}: only the slices that exist
-    int items_cap;                              // capacity of the list (worst case); the walk never reads past it
+    int* n_items;                               // kHfreBuckets device counters of work items, kHfreCtrStride ints apart (zero on entry; the
+                                                // finish kernel re-zeroes them).  ONE counter serialises: 6 000 returning atomics on one
+                                                // address cost 123 us at 12 images x 100 boxes (profiles/r02_bench_default.json, hfre_weights)
+    int2* items;                                // {box, source << 24 | chunk << 12 | slice}: only the slices that exist; bucket b owns
+                                                // [b * items_cap, (b + 1) * items_cap)
+    int items_cap;                              // capacity of ONE bucket (worst case); the walk never reads past it
     int ln_on, ln_split;                        // region LayerNorm (reference :365-372): blocks [0, ln_split) and [ln_split, region_dim)
     const float* ln_w0; const float* ln_b0; const float* ln_w1; const float* ln_b1;
     float ln_eps;
+    float* dimt;                                // work-list path: dim_t table of the sine embedding, region_dim / 8 entries (written by
+                                                // hfre_weights_kernel, read by hfre_finish_vec_kernel); nullptr = powf per element
 };
 
 constexpr int kHfreWStride = FO1_HFRE_MAX_EXTENT;
+constexpr int kHfreBuckets = 64;      // work-list buckets: (box, source) pair q appends to bucket q % 64
+constexpr int kHfreCtrStride = 64;    // ints between bucket counters (256 B: one counter per memory channel line)
 
 struct Footprint {
     RoiAxis ay, ax;
@@ -103,7 +112,7 @@ __device__ __forceinline__ Footprint hfre_footprint(const HfreParams& p, const H
 // Stage 1: one workgroup per (box, source) builds the per-axis tap weights on the source map once
 // (roi_align taps composed with the bilinear-upsample taps) and a small header; every pooling workgroup of
 // that (box, source) then just loads them.
-__global__ __launch_bounds__(kHfreThreads) void hfre_weights_kernel(const HfreParams p) {
+__global__ __launch_bounds__(kHfreWThreads) void hfre_weights_kernel(const HfreParams p) {
     __shared__ float s_wAy[FO1_HFRE_MAX_EXTENT];
     __shared__ float s_wAx[FO1_HFRE_MAX_EXTENT];
     const int n = blockIdx.x / p.n_sources, si = blockIdx.x - n * p.n_sources;
@@ -114,31 +123,39 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_weights_kernel(const HfrePa
     if (tid == 0) {
         h[0] = f.r_lo; h[1] = f.r_hi; h[2] = f.c_lo; h[3] = f.c_hi; h[4] = f.rows_per_slice; h[5] = f.n_slices;
     }
+    if (p.dimt != nullptr && p.pos_mode != 0) {
+        // dim_t[j] = 10000^(2j / d) of gen_sineembed_for_position (reference :55-103): a function of the channel pair only
+        const int d = p.region_dim / 4;
+        for (int j = blockIdx.x * kHfreWThreads + tid; j < d / 2; j += gridDim.x * kHfreWThreads)
+            p.dimt[j] = powf(10000.0f, (float)(2 * j) / (float)d);
+    }
     if (f.n_slices == 0) return;
     if (p.items != nullptr) {
         // work list: reserve this (box, source)'s chunk x slice items in one atomic; the order of the list varies run to run, the
         // results do not (every item owns its partial row, the finish sums in slice order)
         __shared__ int s_base;
         const int cnt = f.n_slices * s.nchunks;
-        if (tid == 0) s_base = atomicAdd(p.n_items, cnt);
+        const int bucket = blockIdx.x % kHfreBuckets;
+        if (tid == 0) s_base = atomicAdd(p.n_items + bucket * kHfreCtrStride, cnt);
         __syncthreads();
-        for (int j = tid; j < cnt; j += kHfreThreads) {
+        int2* list = p.items + (size_t)bucket * p.items_cap;
+        for (int j = tid; j < cnt; j += kHfreWThreads) {
             const int ch = j / f.n_slices, k = j - ch * f.n_slices;
-            p.items[s_base + j] = make_int2(n, (si << 24) | (ch << 12) | k);
+            if (s_base + j < p.items_cap) list[s_base + j] = make_int2(n, (si << 24) | (ch << 12) | k);
         }
     }
     const bool up_y = (s.H != s.roi_H), up_x = (s.W != s.roi_W);
     if (up_y)
-        for (int a = f.ay.lo + tid; a <= f.ay.hi; a += kHfreThreads) s_wAy[a - f.ay.lo] = roi_axis_weight(f.ay, a);
+        for (int a = f.ay.lo + tid; a <= f.ay.hi; a += kHfreWThreads) s_wAy[a - f.ay.lo] = roi_axis_weight(f.ay, a);
     if (up_x)
-        for (int a = f.ax.lo + tid; a <= f.ax.hi; a += kHfreThreads) s_wAx[a - f.ax.lo] = roi_axis_weight(f.ax, a);
+        for (int a = f.ax.lo + tid; a <= f.ax.hi; a += kHfreWThreads) s_wAx[a - f.ax.lo] = roi_axis_weight(f.ax, a);
     __syncthreads();
     float* wy = p.wbuf + (size_t)blockIdx.x * 2 * kHfreWStride;
     float* wx = wy + kHfreWStride;
     const int fh = f.r_hi - f.r_lo + 1, fw = f.c_hi - f.c_lo + 1;
-    for (int r = tid; r < fh; r += kHfreThreads)
+    for (int r = tid; r < fh; r += kHfreWThreads)
         wy[r] = up_y ? upsample_axis_weight(f.r_lo + r, s_wAy, f.ay.lo, f.ay.hi, s.H, s.roi_H) : roi_axis_weight(f.ay, f.r_lo + r);
-    for (int c = tid; c < fw; c += kHfreThreads)
+    for (int c = tid; c < fw; c += kHfreWThreads)
         wx[c] = up_x ? upsample_axis_weight(f.c_lo + c, s_wAx, f.ax.lo, f.ax.hi, s.W, s.roi_W) : roi_axis_weight(f.ax, f.c_lo + c);
 }
 
@@ -373,12 +390,27 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_pool_items_kernel(const Hfr
     __shared__ float s_wy[FO1_HFRE_MAX_EXTENT];
     __shared__ float s_wx[FO1_HFRE_MAX_EXTENT];
     __shared__ float s_red[kHfreWaves][kHfreMaxChunk];
+    __shared__ int s_end[kHfreBuckets];            // inclusive prefix of the bucket counts
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    int n_items = *p.n_items;
-    if (n_items > p.items_cap) n_items = p.items_cap;
+    if (tid < kHfreBuckets) {
+        int c = p.n_items[tid * kHfreCtrStride];
+        if (c > p.items_cap) c = p.items_cap;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(c, o, 64);
+            if (lane >= o) c += t;
+        }
+        s_end[tid] = c;
+    }
+    __syncthreads();
+    const int n_items = s_end[kHfreBuckets - 1];
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const int2 item = p.items[it];
+        int b = 0;                                 // first bucket whose inclusive prefix exceeds `it` (uniform over the workgroup)
+#pragma unroll
+        for (int o = kHfreBuckets / 2; o > 0; o >>= 1)
+            if (s_end[b + o - 1] <= it) b += o;
+        const int2 item = p.items[(size_t)b * p.items_cap + (it - (b ? s_end[b - 1] : 0))];
         const int n = item.x, si = item.y >> 24, chunk_id = (item.y >> 12) & 0xFFF, k = item.y & 0xFFF;
         const HfreSrcDev& s = p.src[si];
         const int* h = p.hdr + ((size_t)n * p.n_sources + si) * 8;
@@ -457,7 +489,63 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_finish2_kernel(const HfrePa
     __shared__ float s_stat[8];
     hfre_finish_row(p, blockIdx.x, blockIdx.y, gridDim.y, s_misc, s_stat);
     // every list walker has finished before this kernel starts: leave the item counter at zero for the next call
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.n_items = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < kHfreBuckets) p.n_items[threadIdx.x * kHfreCtrStride] = 0;
+}
+
+// Vector form of the finish without LayerNorm: a thread owns 4 consecutive output channels (one 16-byte load per slice, the loads of 4
+// slices in flight, one 16-byte store), grid (n_boxes, ceil(region_dim / 1024)); same additions in the same order as
+// hfre_finish_row, dim_t from the table hfre_weights_kernel wrote.  Needs region_dim % 16 == 0 and 4-aligned source offsets.
+__global__ __launch_bounds__(kHfreThreads) void hfre_finish_vec_kernel(const HfreParams p) {
+    __shared__ int s_nsl[FO1_HFRE_MAX_SOURCES];
+    __shared__ float s_box[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (n == 0 && blockIdx.y == 0 && tid < kHfreBuckets) p.n_items[tid * kHfreCtrStride] = 0;   // every list walker has finished
+    if (tid < p.n_sources) s_nsl[tid] = p.hdr[((size_t)n * p.n_sources + tid) * 8 + 5];
+    if (tid == 32 && p.pos_mode != 0) {
+        float x1, y1, x2, y2;
+        load_box(p, n, p.pos_mode == 1, x1, y1, x2, y2);
+        x1 = x1 / p.pos_w; x2 = x2 / p.pos_w;       // reference :457-463 — normalise, xyxy -> cxcywh (fp32, same op order)
+        y1 = y1 / p.pos_h; y2 = y2 / p.pos_h;
+        const float w = x2 - x1, h = y2 - y1;
+        s_box[0] = x1 + w / 2.0f;
+        s_box[1] = y1 + h / 2.0f;
+        s_box[2] = w;
+        s_box[3] = h;
+    }
+    __syncthreads();
+    const int c = (blockIdx.y * kHfreThreads + tid) * 4;
+    if (c >= p.region_dim) return;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < p.n_sources; ++i) {
+        const HfreSrcDev& q = p.src[i];
+        if (c >= q.out_offset && c < q.out_offset + q.C) {
+            const float* w = p.ws + (size_t)n * p.ws_box_stride + q.ws_off + (c - q.out_offset);
+            const int nsl = s_nsl[i];
+            for (int k0 = 0; k0 < nsl; k0 += 4) {
+                float4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int kc = (k0 + u < nsl) ? k0 + u : nsl - 1;      // clamped address: no load under a branch
+                    t[u] = *reinterpret_cast<const float4*>(w + (size_t)kc * q.C);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool ok = k0 + u < nsl;
+                    v.x = ok ? v.x + t[u].x : v.x; v.y = ok ? v.y + t[u].y : v.y;
+                    v.z = ok ? v.z + t[u].z : v.z; v.w = ok ? v.w + t[u].w : v.w;
+                }
+            }
+        }
+    }
+    if (p.pos_mode != 0) {
+        const int d = p.region_dim / 4;
+        const int qd = c / d, i = c - qd * d;                // i % 4 == 0: channels (i, i+1) share dim_t[i/2], (i+2, i+3) dim_t[i/2+1]
+        const float coord = (qd == 0) ? s_box[1] : (qd == 1) ? s_box[0] : s_box[qd];
+        const float2 dt = *reinterpret_cast<const float2*>(p.dimt + (i >> 1));
+        const float a0 = coord * 6.283185307179586f / dt.x, a1 = coord * 6.283185307179586f / dt.y;
+        v.x += sinf(a0); v.y += cosf(a0); v.z += sinf(a1); v.w += cosf(a1);
+    }
+    *reinterpret_cast<float4*>(p.out + (size_t)n * p.out_ld + c) = v;
 }
 
 static int g_hfre_pixel_budget = 0;  // 0 = auto
@@ -466,6 +554,7 @@ static int g_hfre_unroll = 8;        // independent 16-B loads per lane in fligh
 static int g_hfre_chunk = kHfreMaxChunk;   // channels per workgroup (<= kHfreMaxChunk)
 static int g_hfre_v2_budget = 256;   // pixels per slice: one value for every box count, so a box's result does not depend on what
                                      // else is in the call (batch invariance)
+static int g_hfre_finish_vec = 1;     // 16-byte finish (A/B: fo1_hfre_set_tuning unroll | 32 turns it off)
 static int g_hfre_grid = 4096;       // workgroups walking the work list (profiles/r02_hfre_sweep.json)
 
 // workspace = [partials: n_boxes * ws_box_stride floats][weights: n_boxes*n_sources*2*kHfreWStride floats][headers: n_boxes*n_sources*8 ints]
@@ -528,6 +617,8 @@ int fo1_hfre_set_pixel_budget(int pixels) {
 // tuning hooks of fo1_hfre_region_pool_ex: unroll 8 | 16 independent loads per lane; chunk = channels per workgroup (64..512, power
 // of two); budget = pixels per slice (0 keeps the current value); grid = workgroups walking the work list (0 keeps)
 int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid) {
+    fo1::g_hfre_finish_vec = (unroll & 32) ? 0 : 1;    // A/B: unroll | 32 = scalar finish
+    unroll &= ~32;
     if ((unroll != 8 && unroll != 16) || chunk < 64 || chunk > fo1::kHfreMaxChunk || (chunk & (chunk - 1)) ||
         (budget != 0 && (budget < 16 || budget > 65536)) || grid < 0 || grid > (1 << 20))
         return fo1::set_err(FO1_ERR_ARG, "hfre: set_tuning(unroll=%d, chunk=%d, budget=%d, grid=%d)", unroll, chunk, budget, grid);
@@ -585,9 +676,9 @@ int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const 
     p.ws = (float*)workspace;
     p.wbuf = p.ws + (size_t)p.ws_box_stride * n_boxes;
     p.hdr = (int*)(p.wbuf + (size_t)n_boxes * n_sources * 2 * kHfreWStride);
-    p.items = nullptr; p.n_items = nullptr; p.box_image = nullptr;
+    p.items = nullptr; p.n_items = nullptr; p.box_image = nullptr; p.dimt = nullptr;
     hipStream_t st = (hipStream_t)stream;
-    FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreThreads), 0, st, p);
+    FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreWThreads), 0, st, p);
     // algorithmic bytes (SURVEY §8d upper bound): every source map once in bf16 + fp32 output + boxes
     double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
     for (int i = 0; i < n_sources; ++i) bytes += (double)sources[i].H * sources[i].W * sources[i].C * 2.0;
@@ -604,17 +695,30 @@ int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const 
 //   * region LayerNorm (mm_apply_region_layer_norm, reference :365-372): fp32 LayerNorm (biased variance) of the channel blocks
 //     [0, ln_split) with (ln_w0, ln_b0) and [ln_split, region_dim) with (ln_w1, ln_b1) BEFORE the position embedding;
 //     ln_split = 0 / region_dim means one block (vt-only / aux-only configurations).
-// workspace = [64 B: item counter][partials][tap weights][headers][work items].  The counter word must be ZERO when a workspace is
-// first used (the host module's scratch pool zero-fills on allocation); the finish kernel leaves it at zero for the next call.
+// workspace = [16 KB: 64 item counters, 256 B apart][partials][tap weights][headers][work items: 64 buckets].  The counters must be ZERO
+// when a workspace is first used (the host module's scratch pool zero-fills on allocation); the finish kernel leaves them at zero for
+// the next call.
+static constexpr size_t kHfreExCtr = (size_t)fo1::kHfreBuckets * fo1::kHfreCtrStride * sizeof(int);
+static constexpr size_t kHfreExHead = kHfreExCtr + 16384;     // + dim_t table (region_dim / 8 floats: region_dim <= 32768)
+static int hfre_bucket_cap(const fo1::HfreParams& p, int n_sources, int n_boxes) {
+    int max_item = 1;
+    for (int i = 0; i < n_sources; ++i) {
+        const int m = p.src[i].nchunks * p.src[i].max_slices;
+        if (m > max_item) max_item = m;
+    }
+    const long long pairs = (long long)(n_boxes > 0 ? n_boxes : 1) * n_sources;
+    return (int)((pairs + fo1::kHfreBuckets - 1) / fo1::kHfreBuckets) * max_item;
+}
 static size_t hfre_ex_layout(const fo1::HfreParams& p, int n_sources, int n_boxes, int total_wgs, size_t* off_w, size_t* off_h, size_t* off_i) {
     const size_t nb = (size_t)(n_boxes > 0 ? n_boxes : 1);
-    size_t o = 64 + (size_t)p.ws_box_stride * nb * sizeof(float);
+    size_t o = kHfreExHead + (size_t)p.ws_box_stride * nb * sizeof(float);
     if (off_w) *off_w = o;
     o += nb * n_sources * 2 * fo1::kHfreWStride * sizeof(float);
     if (off_h) *off_h = o;
     o += nb * n_sources * 8 * sizeof(int);
     if (off_i) *off_i = o;
-    o += (size_t)(total_wgs > 0 ? total_wgs : 1) * sizeof(int2);
+    (void)total_wgs;
+    o += (size_t)fo1::kHfreBuckets * hfre_bucket_cap(p, n_sources, n_boxes) * sizeof(int2);
     return o;
 }
 
@@ -675,20 +779,28 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
     p.out = out; p.out_ld = out_ld; p.region_dim = region_dim;
     char* wsb = (char*)workspace;
     p.n_items = (int*)wsb;
-    p.ws = (float*)(wsb + 64);
+    p.ws = (float*)(wsb + kHfreExHead);
+    p.dimt = (float*)(wsb + kHfreExCtr);
     p.wbuf = (float*)(wsb + off_w);
     p.hdr = (int*)(wsb + off_h);
     p.items = (int2*)(wsb + off_i);
-    p.items_cap = wgs;
+    p.items_cap = hfre_bucket_cap(p, n_sources, n_boxes);
     hipStream_t st = (hipStream_t)stream;
-    FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreThreads), 0, st, p);
+    FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreWThreads), 0, st, p);
     double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
     for (int i = 0; i < n_sources; ++i) bytes += (double)sources[i].H * sources[i].W * sources[i].C * 2.0 * (opts ? opts->batch : 1);
     const int grid = wgs < g_hfre_grid ? wgs : g_hfre_grid;
     if (g_hfre_unroll == 16) { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<16>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
     else                     { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<8>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
-    const int nseg = p.ln_on ? 1 : 4;
-    FO1_LAUNCH("hfre_finish2", (double)n_boxes * region_dim * 8.0, hfre_finish2_kernel, dim3(n_boxes, nseg), dim3(kHfreThreads), 0, st, p);
+    bool vec = !p.ln_on && region_dim % 16 == 0 && region_dim <= 32768 && out_ld % 4 == 0 && ((uintptr_t)out & 15) == 0 && g_hfre_finish_vec;
+    for (int i = 0; i < n_sources; ++i) vec = vec && sources[i].out_offset % 4 == 0;
+    if (vec) {
+        FO1_LAUNCH("hfre_finish2", (double)n_boxes * region_dim * 8.0, hfre_finish_vec_kernel, dim3(n_boxes, cdiv(region_dim, 4 * kHfreThreads)),
+                   dim3(kHfreThreads), 0, st, p);
+    } else {
+        const int nseg = p.ln_on ? 1 : 4;
+        FO1_LAUNCH("hfre_finish2", (double)n_boxes * region_dim * 8.0, hfre_finish2_kernel, dim3(n_boxes, nseg), dim3(kHfreThreads), 0, st, p);
+    }
     return FO1_OK;
 }
 
