@@ -1,5 +1,5 @@
 """Decode-step A/B on the GPU box: per-kernel time (library event pairs, eager) and graph-replay time per step for every combination of
-the GEMV implementation (1 = MFMA skinny GEMM, 0 = v_dot2) and the decode-attention implementation (1 = workgroup per head, 0 = 64-key
+the GEMV implementation (1 = MFMA skinny GEMM, 3 = the same without the 8-row units at M <= 8, 0 = v_dot2) and the decode-attention implementation (1 = workgroup per head, 0 = 64-key
 split + combine), at several batch sizes, one model build.
 usage: decode_ab.py [out.json] [B ...]      (default B = 1 8 16)"""
 import json
@@ -24,9 +24,9 @@ lib = L.load()
 results = []
 for B in batches:
     reqs = pipe.requests[:B]
-    for gemv_impl, attn_impl in ((1, 0), (0, 0)):
-        if gemv_impl == 0 and B > 8:
-            continue
+    for gemv_impl, attn_impl in ((1, 0), (3, 0)):
+        if gemv_impl == 3 and B > 8:
+            continue      # 3 = MFMA without the 8-row units (they only exist at M <= 8)
         L.check(lib.fo1_gemv_batch_set_impl(gemv_impl), "gemv impl")
         L.check(lib.fo1_attention_decode_set_impl(attn_impl), "attn impl")
         eng.prefill_batch(reqs, use_graph=False)

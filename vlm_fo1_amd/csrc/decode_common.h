@@ -28,6 +28,7 @@ struct GemvBParams {
 enum { GB_PLAIN = 0, GB_SWIGLU = 1, GB_QKV = 2 };
 
 // decode_mfma.hip
+extern int g_gemv_half;   // decode_mfma.hip: 8-row units at M <= 8
 int gemv_mfma_any(GemvBParams& p, int mode, hipStream_t st);
 
 }  // namespace fo1

@@ -17,6 +17,12 @@
 //   * the 8 waves' partial accumulators meet in LDS (fixed order), wave 0 runs the epilogue: bias -> bf16 -> (+ residual) |
 //     interleaved SwiGLU | QKV: bias -> bf16 -> mRoPE -> rotated q rows out, K row and V^T column appended to the caches.
 //     Everything the epilogue reads from global memory (bias, residual, rope tables) is requested BEFORE the K loop.
+//   * every row's sum is built the same way in every variant: a wave adds its k-steps s = wave + 8d into TWO chains (d even /
+//     d odd), then chain A + chain B, then the 8 waves in a fixed tree.  That is what lets the HALF variant exist: for M <= 8 the
+//     MFMA's 16 columns are only half used, so a unit can be 8 weight rows with the even-d k-step in fragment rows 0-7 /
+//     columns 0-7 and the odd-d k-step in rows 8-15 / columns 8-15 (D's off-diagonal 8x8 blocks are ignored).  The few-row
+//     projections (o, down: N = 2048 -> 128 units of 16 rows, half the CUs idle, 2.8 TB/s; q/k/v: 80 units) then fill the chip
+//     with 256 / 160 units, without any cross-workgroup reduction and with bit-identical sums.
 #include <type_traits>
 
 #include "decode_common.h"
@@ -30,9 +36,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int gm_u32x4;
 
 constexpr int GM_NW = 8;                           // waves per workgroup
 constexpr int GM_NT = GM_NW * 64;
-constexpr int GM_D = 4;                            // k-steps in flight per wave (register stages)
-constexpr int GM_PIECE = GM_NW * GM_D;             // k-steps of x staged at a time (32 x 64 = 2048 elements)
-constexpr int GM_XPITCH = GM_PIECE * 128 + 32;     // bytes per staged x row
+constexpr int GM_D = 4;                            // k-steps in flight per wave (register stages), full variant
+constexpr int GM_PIECE = GM_NW * GM_D;             // k-steps of x staged at a time (32 x 64 = 2048 elements), full variant
 
 __device__ __forceinline__ uint4 gm_load_nt16(const uint16_t* p) {
     const gm_u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const gm_u32x4*>(p));
@@ -53,33 +58,45 @@ __device__ __forceinline__ void gm_lds_fence() {
 
 // MM: staged x rows (8 or 16).  NB: 16-row weight blocks per unit (SwiGLU / QKV pair two blocks whose rows meet in one lane).
 // MP: K spans several staged pieces (deep-K projections); single-piece kernels stage x once and carry no reload logic.
-template <int MM, int MODE, int NB, bool MP>
+// HALF: 8-row blocks, a register stage = the k-step pair (s, s + 8) of those rows (M <= 8 only; no SwiGLU form).
+template <int MM, int MODE, int NB, bool MP, bool HALF>
 __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, const int n_units, const int nsteps) {
     static_assert(MODE == GB_PLAIN || NB == 2, "paired modes use two row blocks");
+    static_assert(!HALF || (MM == 8 && MODE != GB_SWIGLU), "HALF: M <= 8, plain or QKV");
+    constexpr int PD = (HALF && !MP) ? 2 : 4;                            // register stages per wave = stages per staged piece
+    constexpr int SSTEP = HALF ? 16 : 8;                                 // k-step distance between a wave's consecutive stages
+    constexpr int PSTEPS = SSTEP * PD;                                   // k-steps of x staged at a time: 32 (64: HALF && MP)
+    constexpr int XPITCH = PSTEPS * 128 + 32;                            // bytes per staged x row (= 32 mod 256)
+    constexpr int CPR = PSTEPS * 8;                                      // 16-byte chunks per staged x row
+    constexpr int RPP = GM_NT / CPR;                                     // x rows per pass of the workgroup (2 or 1)
+    constexpr int XL = MM / RPP;                                         // x loads per thread and piece
+    constexpr int RB = HALF ? 8 : 16;                                    // weight rows per block
     extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
-    unsigned char* const sx = gm_smem;                                   // [MM][GM_XPITCH]
-    unsigned char* const sw = gm_smem + MM * GM_XPITCH;                  // [GM_NW][NB][2048]  weight scratch (wave-private)
+    unsigned char* const sx = gm_smem;                                   // [MM][XPITCH]
+    unsigned char* const sw = gm_smem + MM * XPITCH;                     // [GM_NW][NB][2048]  weight scratch (wave-private)
     float* const sred = reinterpret_cast<float*>(sw + GM_NW * NB * 2048);   // [2][GM_NW][NB][64][4]
     float* const srstd = sred + 2 * GM_NW * NB * 256;                    // [16]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kch = p.K >> 3;                                            // 16-byte chunks per row
-    const int n_pieces = (nsteps + GM_PIECE - 1) / GM_PIECE;
+    const int n_pieces = (nsteps + PSTEPS - 1) / PSTEPS;
     const int lrow = lane >> 3, lch = lane & 7;                          // load shape: row of an 8-row group, chunk of the 128-byte k-step
     const int fi = lane & 15, fg = lane >> 4;                            // fragment shape: MFMA row / column, k group
     unsigned char* const swv = sw + wave * (NB * 2048);
     const int xrow = MM == 16 ? fi : (fi & 7);
-    const int n_rope = MODE == GB_QKV ? (p.n_q + p.n_kv) * 4 : 0;
+    const int n_rope = MODE == GB_QKV ? (p.n_q + p.n_kv) * (64 / RB) : 0;
+    const int xsel = (HALF && fi >= 8) ? 8 * 128 : 0;                    // HALF: columns 8-15 take the pair's second k-step
 
     auto unit_rows = [&](int u, int (&rb)[NB]) __attribute__((always_inline)) {
         if (MODE == GB_SWIGLU) {
             rb[0] = u * 32;
             rb[NB - 1] = u * 32 + 16;
         } else if (MODE == GB_QKV) {
-            if (u < n_rope) { rb[0] = (u >> 2) * 128 + (u & 3) * 16; rb[NB - 1] = rb[0] + 64; }
-            else { rb[0] = (p.n_q + p.n_kv) * 128 + (u - n_rope) * 32; rb[NB - 1] = rb[0] + 16; }
+            constexpr int UPH = 64 / RB;                     // units per head: RB rotary-pair rows each
+            if (u < n_rope) { rb[0] = (u / UPH) * 128 + (u % UPH) * RB; rb[NB - 1] = rb[0] + 64; }
+            else { rb[0] = (p.n_q + p.n_kv) * 128 + (u - n_rope) * (2 * RB); rb[NB - 1] = rb[0] + RB; }
         } else {
 #pragma unroll
-            for (int b = 0; b < NB; ++b) rb[b] = (u * NB + b) * 16;
+            for (int b = 0; b < NB; ++b) rb[b] = (u * NB + b) * RB;
         }
     };
     auto unit_ptrs = [&](int u, const uint16_t* (&wp)[NB][2]) __attribute__((always_inline)) {
@@ -89,19 +106,23 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                int row = rb[b] + q * 8 + lrow;
+                int row = rb[b] + (HALF ? 0 : q * 8) + lrow;  // HALF: both loads fetch the block's 8 rows (k-steps s and s + 8)
                 row = row < p.N ? row : p.N - 1;            // clamp: the surplus rows' results are discarded
                 wp[b][q] = p.W + (long long)row * p.ldw;
             }
     };
     // all four loads of one k-step of this wave; addresses are always valid (chunks past K are clamped: their x is zero in LDS)
     auto issue = [&](const uint16_t* const (&wp)[NB][2], int s, uint4 (&st)[NB][2]) __attribute__((always_inline)) {
-        int c = s * 8 + lch;
-        c = c < kch ? c : kch - 1;
+        int c[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            c[q] = (s + (HALF ? q * 8 : 0)) * 8 + lch;
+            c[q] = c[q] < kch ? c[q] : kch - 1;
+        }
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) st[b][q] = gm_load_nt16(wp[b][q] + (long long)c * 8);
+            for (int q = 0; q < 2; ++q) st[b][q] = gm_load_nt16(wp[b][q] + (long long)c[q] * 8);
     };
     auto consume = [&](const uint4 (&st)[NB][2], int xs, gm_f32x4 (&acc)[NB]) __attribute__((always_inline)) {
 #pragma unroll
@@ -114,7 +135,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         gm_lds_fence();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            uint4 xv = *reinterpret_cast<const uint4*>(sx + xrow * GM_XPITCH + xs * 128 + h * 64 + fg * 16);
+            uint4 xv = *reinterpret_cast<const uint4*>(sx + xrow * XPITCH + xs * 128 + xsel + h * 64 + fg * 16);
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 uint4 wv = *reinterpret_cast<const uint4*>(swv + b * 2048 + fi * 128 + (((h * 4 + fg) ^ ((fi >> 1) & 7)) << 4));
@@ -126,22 +147,22 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     // x rows of K piece `piece`: global -> registers (clamped addresses, no branch), then registers -> LDS (zero beyond M rows /
     // beyond K) and the fused RMSNorm (single-piece K only: host-checked).  Split in two so that the loads can be issued BEFORE the
     // weight refills of the piece in progress: vmcnt retires in order, a younger x load would drain the whole weight pipeline.
-    auto load_x = [&](int piece, uint4 (&t)[MM / 2]) __attribute__((always_inline)) {
-        const int c = tid & 255, gc = piece * 256 + c;
+    auto load_x = [&](int piece, uint4 (&t)[XL]) __attribute__((always_inline)) {
+        const int c = tid % CPR, gc = piece * CPR + c;
         const int gcc = gc < kch ? gc : kch - 1;
 #pragma unroll
-        for (int i = 0; i < MM / 2; ++i) {
-            const int m = (tid >> 8) + 2 * i;
+        for (int i = 0; i < XL; ++i) {
+            const int m = tid / CPR + RPP * i;
             t[i] = *reinterpret_cast<const uint4*>(p.X + (long long)(m < p.M ? m : p.M - 1) * p.ldx + gcc * 8);
         }
     };
-    auto store_x = [&](int piece, const uint4 (&t)[MM / 2], const uint4& nw) __attribute__((always_inline)) {
-        const int c = tid & 255, gc = piece * 256 + c;
+    auto store_x = [&](int piece, const uint4 (&t)[XL], const uint4& nw) __attribute__((always_inline)) {
+        const int c = tid % CPR, gc = piece * CPR + c;
 #pragma unroll
-        for (int i = 0; i < MM / 2; ++i) {
-            const int m = (tid >> 8) + 2 * i;
+        for (int i = 0; i < XL; ++i) {
+            const int m = tid / CPR + RPP * i;
             const bool ok = m < p.M && gc < kch;
-            *reinterpret_cast<uint4*>(sx + m * GM_XPITCH + c * 16) = ok ? t[i] : uint4{0, 0, 0, 0};
+            *reinterpret_cast<uint4*>(sx + m * XPITCH + c * 16) = ok ? t[i] : uint4{0, 0, 0, 0};
         }
         __syncthreads();
         if (!MP && p.norm_w) {
@@ -149,7 +170,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                 float ss = 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(sx + m * GM_XPITCH + (lane + 64 * i) * 16);
+                    const uint4 v = *reinterpret_cast<const uint4*>(sx + m * XPITCH + (lane + 64 * i) * 16);
                     ss = gm_dot8(v, v, ss);
                 }
 #pragma unroll
@@ -159,10 +180,10 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             __syncthreads();
             // fp32 variance, bf16(x * rstd), * weight -> bf16 (the reference's rounding points)
 #pragma unroll
-            for (int i = 0; i < MM / 2; ++i) {
-                const int m = (tid >> 8) + 2 * i;
+            for (int i = 0; i < XL; ++i) {             // (!MP: 256 chunks per row, two rows per pass)
+                const int m = tid / CPR + RPP * i;
                 const float rstd = srstd[m];
-                uint4* px = reinterpret_cast<uint4*>(sx + m * GM_XPITCH + c * 16);
+                uint4* px = reinterpret_cast<uint4*>(sx + m * XPITCH + c * 16);
                 const uint4 v = *px;
                 uint4 o;
                 o.x = pack_bf16x2(bf16_lo(nw.x) * gm_round(bf16_lo(v.x) * rstd), bf16_hi(nw.x) * gm_round(bf16_hi(v.x) * rstd));
@@ -186,16 +207,16 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         const int c = tid & 255;
         nw = *reinterpret_cast<const uint4*>((p.norm_w ? p.norm_w : dummy) + (c < kch ? c : kch - 1) * 8);
     }
-    uint4 xr[MM / 2];
+    uint4 xr[XL];
     load_x(0, xr);
-    uint4 st[GM_D][NB][2];
+    uint4 st[PD][NB][2];
     const uint16_t* wcur[NB][2];
     unit_ptrs(blockIdx.x, wcur);
 #pragma unroll
-    for (int d = 0; d < GM_D; ++d) issue(wcur, wave + GM_NW * d, st[d]);
+    for (int d = 0; d < PD; ++d) issue(wcur, wave + SSTEP * d, st[d]);
     // decode state of this lane's sequence (QKV epilogue): cache row and rope-table row
     const int n_seq = fi;
-    const bool seq_ok = n_seq < p.M;
+    const bool seq_ok = n_seq < p.M && (!HALF || fg < 2);        // HALF: fragment rows 8-15 are chain B, folded into lanes fg < 2
     int pos = 0;
     long long trow = 0;
     if (MODE == GB_QKV) {
@@ -230,7 +251,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                 if (!p.res) e_res[b] = uint2{0, 0};
             }
             if (MODE == GB_QKV) {
-                const int d0 = (u & 3) * 16 + fg * 4;        // (V units load a harmless table row too)
+                const int d0 = ((u % (64 / RB)) * RB + fg * 4) & 63;        // (V units / HALF's unused lanes load a harmless table row too)
                 e_cos[0] = *reinterpret_cast<const uint2*>(p.cos_t + trow * 128 + d0);
                 e_sin[0] = *reinterpret_cast<const uint2*>(p.sin_t + trow * 128 + d0);
                 e_cos[1] = *reinterpret_cast<const uint2*>(p.cos_t + trow * 128 + d0 + 64);
@@ -239,9 +260,12 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                 e_cos[0] = e_cos[1] = e_sin[0] = e_sin[1] = uint2{0, 0};
             }
         }
-        gm_f32x4 acc[NB];
+        // two chains per row: k-steps wave + 8d with d even / d odd (full: stages alternate; HALF: rows 0-7 / 8-15 of one stage)
+        gm_f32x4 accs[2][NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) acc[b] = gm_f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < NB; ++b) accs[0][b] = accs[1][b] = gm_f32x4{0.f, 0.f, 0.f, 0.f};
+        gm_f32x4 (&acc)[NB] = accs[0];
+        gm_f32x4 (&acc2)[NB] = accs[1];
 
         // every piece but the last: consume a k-step, refill its stage with the k-step one piece ahead in the same unit
         if (MP) {
@@ -250,10 +274,10 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                 store_x(piece, xr, nw);
                 load_x(piece + 1, xr);           // before this piece's weight refills (in-order vmcnt)
 #pragma unroll
-                for (int d = 0; d < GM_D; ++d) {
-                    const int xs = wave + GM_NW * d;              // k-step inside the staged piece
-                    consume(st[d], xs, acc);
-                    issue(wcur, (piece + 1) * GM_PIECE + xs, st[d]);
+                for (int d = 0; d < PD; ++d) {
+                    const int xs = wave + SSTEP * d;              // k-step inside the staged piece
+                    consume(st[d], xs, accs[HALF ? 0 : (d & 1)]);
+                    issue(wcur, (piece + 1) * PSTEPS + xs, st[d]);
                 }
             }
             __syncthreads();
@@ -261,10 +285,20 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             load_x(0, xr);                       // the next unit's first piece (unused after the workgroup's last unit)
         }
 #pragma unroll
-        for (int d = 0; d < GM_D; ++d) {
-            const int xs = wave + GM_NW * d;
-            consume(st[d], xs, acc);
+        for (int d = 0; d < PD; ++d) {
+            const int xs = wave + SSTEP * d;
+            consume(st[d], xs, accs[HALF ? 0 : (d & 1)]);
             if (PF) issue(wnext, xs, st[d]);                  // the first piece of this workgroup's next unit
+        }
+        // chain A + chain B.  HALF: chain B of (row r, sequence n) sits in lane + 40 (fragment row r + 8, column n + 8)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (HALF) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc2[b][r] = __shfl(acc[b][r], (lane + 40) & 63, 64);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[b][r] += acc2[b][r];
         }
         // ---- the 8 waves' partial sums meet in LDS; double-buffered by unit parity: one barrier per unit ----
         float* red = sred + (it & 1) * (GM_NW * NB * 256);
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                     }
                 } else {   // GB_QKV
                     if (u < n_rope) {
-                        const int head = u >> 2, d0 = (u & 3) * 16 + fg * 4;        // d0 + r < 64, rotary partner d + 64
+                        const int head = u / (64 / RB), d0 = (u % (64 / RB)) * RB + fg * 4;        // d0 + r < 64, rotary partner d + 64
                         uint16_t oa[4], ob[4];
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -360,7 +394,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
                         for (int b = 0; b < NB; ++b)
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int vrow = (u - n_rope) * 32 + b * 16 + fg * 4 + r;          // kv_head * 128 + d
+                                const int vrow = (u - n_rope) * (2 * RB) + b * RB + fg * 4 + r;          // kv_head * 128 + d
                                 p.vtcache[(long long)vrow * p.vt_row_stride + pos] = f32_to_bf16(v[b][r] + h4(e_bias[b], r));
                             }
                     }
@@ -382,25 +416,28 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 
 extern int g_gemv_profile_shapes;
 
-template <int MM, int MODE, int NB, bool MP>
+template <int MM, int MODE, int NB, bool MP, bool HALF>
 static int launch_gemv_mfma_mp(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
-    const size_t smem = (size_t)MM * GM_XPITCH + (size_t)GM_NW * NB * 2048 + (size_t)2 * GM_NW * NB * 1024 + 64;
+    constexpr int xpitch = (HALF ? 16 : 8) * ((HALF && !MP) ? 2 : 4) * 128 + 32;
+    const size_t smem = (size_t)MM * xpitch + (size_t)GM_NW * NB * 2048 + (size_t)2 * GM_NW * NB * 1024 + 64;
     static bool attr = false;
     if (!attr) {
-        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB, MP>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB, MP, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr = true;
     }
     // persistent workgroups, one per CU (x is staged / normalised once per workgroup when K fits one piece)
     const int grid = n_units < 256 ? n_units : 256;
-    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_mfma_kernel<MM, MODE, NB, MP>), dim3(grid), dim3(GM_NT), smem, st, p, n_units, nsteps);
+    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_mfma_kernel<MM, MODE, NB, MP, HALF>), dim3(grid), dim3(GM_NT), smem, st, p, n_units, nsteps);
     return FO1_OK;
 }
 
-template <int MM, int MODE, int NB>
+template <int MM, int MODE, int NB, bool HALF = false>
 static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
-    if (nsteps > GM_PIECE) return launch_gemv_mfma_mp<MM, MODE, NB, true>(p, n_units, nsteps, name, st);
-    return launch_gemv_mfma_mp<MM, MODE, NB, false>(p, n_units, nsteps, name, st);
+    if (nsteps > GM_PIECE) return launch_gemv_mfma_mp<MM, MODE, NB, true, HALF>(p, n_units, nsteps, name, st);
+    return launch_gemv_mfma_mp<MM, MODE, NB, false, HALF>(p, n_units, nsteps, name, st);
 }
+
+int g_gemv_half = 1;     // M <= 8: 8-row units for the few-row projections (A/B: fo1_gemv_batch_set_impl(1 | 2) turns it off)
 
 template <int MM>
 static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
@@ -413,6 +450,11 @@ static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
         name = pname;
     }
     if (mode == GB_SWIGLU) return launch_gemv_mfma<MM, GB_SWIGLU, 2>(p, p.N / 32, nsteps, name, st);
+    if constexpr (MM == 8) {
+        // M <= 8: half of the MFMA's columns are free — 8-row units with the k-step pair in the two halves (same sums, see the header)
+        if (g_gemv_half && mode == GB_QKV) return launch_gemv_mfma<8, GB_QKV, 2, true>(p, (p.n_q + p.n_kv) * 8 + p.n_kv * 8, nsteps, name, st);
+        if (g_gemv_half && mode == GB_PLAIN && p.N <= 4096) return launch_gemv_mfma<8, GB_PLAIN, 1, true>(p, cdiv(p.N, 8), nsteps, name, st);
+    }
     if (mode == GB_QKV) return launch_gemv_mfma<MM, GB_QKV, 2>(p, (p.n_q + p.n_kv) * 4 + p.n_kv * 4, nsteps, name, st);
     // plain: 16-row units for the few-row projections (every CU should stream), 32-row units for lm_head-sized matrices
     if (p.N >= 8192) return launch_gemv_mfma<MM, GB_PLAIN, 2>(p, cdiv(p.N, 32), nsteps, name, st);
