@@ -54,7 +54,7 @@ struct AttnParams {
 };
 
 template <int HD, int NW, bool PARTIAL = false>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(const AttnParams p) {
     constexpr int NT = NW * 64;
     constexpr int HDP = (HD + 31) / 32 * 32;  // head dim padded to the MFMA K step
     constexpr int NC = HDP / 32;              // 32-wide d chunks for QK^T
@@ -131,7 +131,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
     f32x4 o[NDB];
 #pragma unroll
     for (int i = 0; i < NDB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;       // m_run in base-2 units: max of c1 * score
+    const float sl2 = p.scale * 1.44269504088896f;
 
     int kv_hi = it.kv_end;
     if (p.causal && it.q_end < kv_hi) kv_hi = it.q_end;  // keys beyond the last query are never attended
@@ -185,38 +186,74 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         if (k0 + KB < kv_hi) gload(k0 + KB);
 
         // ---- S^T = K Q^T : 4 key sub-tiles of 16 ----
+        // Every fragment read of the tile is issued before the first MFMA (and the V^T fragments before the softmax): left to itself
+        // hipcc ping-pongs two fragment registers, "ds_read, s_waitcnt lgkmcnt(1), mfma" 4 x NC times, and the loop runs at LDS
+        // latency (MFMA busy 8 %, profiles/r02_mfma_busy.json).  sched_barrier(0) pins the read block in front of the MFMA block.
         f32x4 s[4];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt) {
-            s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int c = 0; c < NC; ++c) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(&sK[(kt * 16 + ql) * LDKR + c * 32 + g * 8]);
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[c], s[kt], 0, 0, 0);
-            }
+        for (int kh = 0; kh < 2; ++kh) {         // two batches of 2 x NC fragments: the whole tile at once costs an occupancy step
+            bf16x8 kf[2][NC];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) kf[kt][c] = *reinterpret_cast<const bf16x8*>(&sK[((kh * 2 + kt) * 16 + ql) * LDKR + c * 32 + g * 8]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    s[kh * 2 + kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[c], s[kh * 2 + kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // s[kt][r] = score(key = k0 + kt*16 + g*4 + r, query = q_idx)
-        float mx = -INFINITY;
+        // V^T fragments of the first key half: in flight while the softmax runs.  a-operand k-slots: j<4 -> key (2*half)*16 + g*4 + j ;
+        // j>=4 -> key (2*half+1)*16 + g*4 + (j-4)
+        uint2 vlo[NDB], vhi[NDB];
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int db = 0; db < NDB; ++db) {
+            const uint16_t* vr = &sVT[(db * 16 + ql) * LDVT + g * 4];
+            vlo[db] = *reinterpret_cast<const uint2*>(vr);
+            vhi[db] = *reinterpret_cast<const uint2*>(vr + 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // s[kt][r] = score(key = k0 + kt*16 + g*4 + r, query = q_idx), raw (unscaled).
+        // The softmax runs in base 2 on c1 * s (c1 = scale * log2 e): one v_fma + one v_exp per score, the mask only on the tiles that
+        // need one (the last tile of the range, the causal diagonal; wave-uniform), no bf16 round trip for the row sum (flash-attention
+        // sums the fp32 probabilities too) — the VALU, not the MFMA, bounded this loop (profiles/README.md, MFMA busy 8 %).
+        float c1 = sl2;
+        const bool need_mask = (k0 + KB > kv_hi) || (p.causal && k0 + KB - 1 > it.q_start + wave * 16);
+        if (!PARTIAL && bias_row) {
+            c1 = 1.44269504088896f;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = k0 + kt * 16 + g * 4 + r;
-                const bool ok = key < kv_hi && (!p.causal || key <= q_idx);
-                float v = ok ? s[kt][r] * p.scale : -INFINITY;
-                if (!PARTIAL && bias_row && ok) {
-                    const int kl = key - it.kv_start;
-                    v += bias_row[kl];
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + g * 4 + r;
+                    const bool ok = key < kv_hi && (!p.causal || key <= q_idx);
+                    const int kl = ok ? key - it.kv_start : 0;
+                    float v = s[kt][r] * p.scale + bias_row[kl];
                     if (p.sw_shift > 0 && s_reg[kl] != rid_q) v += -100.0f;
+                    s[kt][r] = ok ? v : -INFINITY;
                 }
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
+        } else if (need_mask) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kt * 16 + g * 4 + r;
+                    const bool ok = key < kv_hi && (!p.causal || key <= q_idx);
+                    s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                }
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])), fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
+        const float m_new = fmaxf(m_run, mx * c1);               // running max of c1 * s (c1 > 0)
         // a query with no valid key yet (only possible for padding lanes) keeps everything at zero
-        const float alpha = (m_new == -INFINITY) ? 1.0f : __expf(m_run - m_new);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);   // m_run = -inf -> 0 (o and l are zero then anyway)
         float psum = 0.f;
         bf16x8 pf[2];
 #pragma unroll
@@ -228,9 +265,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
                 float e[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    e[r] = (s[kt][r] == -INFINITY) ? 0.f : __expf(s[kt][r] - m_new);
-                    // sum what is actually multiplied into V: the bf16-rounded probabilities
-                    e[r] = bf16_to_f32(f32_to_bf16(e[r]));
+                    e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c1, -m_use));   // masked: exp2(-inf) = 0
                     psum += e[r];
                 }
                 w[t * 2 + 0] = pack_bf16x2(e[0], e[1]);
@@ -243,19 +278,30 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
         psum += __shfl_xor(psum, 32, 64);
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        const bool rescale = __any(alpha != 1.0f);               // wave-uniform: later tiles rarely move the maximum
         // ---- O^T = alpha * O^T + V^T P^T ----
+        if (rescale) {
 #pragma unroll
-        for (int db = 0; db < NDB; ++db) {
-            o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha;
+            for (int db = 0; db < NDB; ++db) { o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha; }
+        }
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                // a-operand k-slots: j<4 -> key (2*half)*16 + g*4 + j ; j>=4 -> key (2*half+1)*16 + g*4 + (j-4)
-                const uint16_t* vr = &sVT[(db * 16 + ql) * LDVT + half * 32 + g * 4];
-                const uint2 lo = *reinterpret_cast<const uint2*>(vr);
-                const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);
-                uint4 vk = uint4{lo.x, lo.y, hi.x, hi.y};
-                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vk), pf[half], o[db], 0, 0, 0);
+        for (int half = 0; half < 2; ++half) {
+            uint4 vk[NDB];
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) vk[db] = uint4{vlo[db].x, vlo[db].y, vhi[db].x, vhi[db].y};
+            if (half == 0) {                     // second key half: requested before the first half's MFMAs
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const uint16_t* vr = &sVT[(db * 16 + ql) * LDVT + 32 + g * 4];
+                    vlo[db] = *reinterpret_cast<const uint2*>(vr);
+                    vhi[db] = *reinterpret_cast<const uint2*>(vr + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vk[db]), pf[half], o[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
@@ -265,7 +311,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
                 *reinterpret_cast<float4*>(pr + db * 16 + g * 4) = float4{o[db][0], o[db][1], o[db][2], o[db][3]};
-            if (g == 0) { pr[HD] = m_run; pr[HD + 1] = l_run; }
+            if (g == 0) { pr[HD] = m_run * 0.6931471805599453f; pr[HD + 1] = l_run; }   // the combine kernel works in natural units
         }
         return;
     }
