@@ -258,6 +258,9 @@ def main():
     ap.add_argument("--cpu-reps", type=int, default=3, help="timed oracle passes (median) after one warm-up pass")
     ap.add_argument("--cpu-decode-tokens", type=int, default=64)
     ap.add_argument("--eager", action="store_true", help="launch kernels one by one instead of replaying the hipGraph")
+    ap.add_argument("--fp8", nargs="?", const="all", default=None, choices=["all", "mlp", "llm-mlp"], help="SECONDARY measurement (BASELINE configs[4] names fp8 MFMA): W8A8 e4m3 for the ViT / LLM "
+                    "qkv, gate/up and down projections of the packed pass (FO1Engine.enable_fp8); the line says so in `dtype` — the "
+                    "default run is bf16 like the reference")
     ap.add_argument("--profile-shapes", action="store_true", help="per-shape GEMM rows in roofline.per_step_ms")
     args = ap.parse_args()
 
@@ -289,6 +292,11 @@ def main():
     case = cases[0]
     R = max(1, args.inflight)
     pipe = Pipeline(case, dev, inflight=R, batch=B, cases=cases)
+    n_fp8 = 0
+    if args.fp8:
+        n_fp8 = pipe.eng.enable_fp8(args.fp8)
+        for e in pipe.engs[1:]:
+            e._graphs.clear(); e._seen.clear()
 
     use_graph = not args.eager
     for slot in range(R):
@@ -523,7 +531,7 @@ def main():
         n_img = args.steps * world * B
         out = dict(metric="images/sec", value=n_img / el, unit="images/s", n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=el / args.steps * 1e3, higher_is_better=True, scaling="weak",
-                   vs_baseline=None, dtype="bf16", data="synthetic",
+                   vs_baseline=None, dtype=("fp8-e4m3 linears, preset %s (%d weights; bf16 elsewhere)" % (args.fp8, n_fp8)) if args.fp8 else "bf16", data="synthetic",
                    region_tokens_per_sec=n_img * args.boxes / el,
                    config=dict(workload=f"{'BASELINE metric config (100 boxes/img, COCO-typical 640x480)' if (img_hw == (480, 640) and args.boxes == 100) else ('BASELINE configs[1]' if (img_hw == (480, 640) and args.boxes == 32) else 'non-default geometry')}: 1 image "
                                         f"{img_hw[1]}x{img_hw[0]} (S={case['grid'][0] * case['grid'][1]} patches) x {args.boxes} proposals "

@@ -161,6 +161,18 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
                      const void* residual, int ldr, void* C, int ldc,
                      int M, int N, int K, int act, int out_f32,
                      void* workspace, size_t workspace_bytes, void* stream);
+/* ----------------------------------------------------------------------
+ * fp8 linear — BASELINE configs[4] ("fp8 MFMA").  The reference has no fp8 path (it runs bf16 everywhere, builder.py:40-46):
+ * this is the W8A8 form of the same nn.Linear call sites, per-token activation scales x per-output-channel weight scales.
+ *   fo1_quantize_rows_e4m3: q[m, :] = e4m3fn(clamp(x[m, :] / scales[m], +-448)), scales[m] = absmax(x[m, :]) / 448 (1 for a zero
+ *     row); OCP e4m3fn, round to nearest even.  x bf16 [M, K] (ldx elements), q bytes [M, K] (ldq bytes), K % 8 == 0.
+ *   fo1_gemm_fp8: C[M, N] = epilogue((Aq Wq^T) * scale_a[m] * scale_w[n]): v_mfma_scale_f32_32x32x64_f8f6f4 with unit block
+ *     scales, fp32 accumulation, the bf16 epilogues of fo1_gemm_bf16 (act 0 none, 1 GELU, 2 SiLU, 3 interleaved SwiGLU; bias,
+ *     residual).  K % 128 == 0, lda / ldw % 16 == 0 (bytes), operands 16-byte aligned, each operand < 4 GB.
+ * ---------------------------------------------------------------------- */
+int fo1_quantize_rows_e4m3(const void* x, long long ldx, int M, int K, void* q, long long ldq, float* scales, void* stream);
+int fo1_gemm_fp8(const void* Aq, int lda, const float* scale_a, const void* Wq, int ldw, const float* scale_w, const void* bias,
+                 const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* stream);
 /* Tuning hooks: staging 0 auto / 1 register-staged / 2 LDS-DMA two-stage / 3, 4, 6 LDS-DMA ring of that depth
  * (counted vmcnt; 6 only for the 64x64 tile, else 4); tile 0 auto / 1 128x128 / 2 64x128 / 3 64x64 / 4 128x256
  * (8 waves); split-K 0 auto / n forced; per-shape kernel names in the profile. */

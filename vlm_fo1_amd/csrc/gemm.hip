@@ -28,6 +28,8 @@ namespace fo1 {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+typedef __attribute__((ext_vector_type(8))) int v8i32;
+
 struct GemmParams {
     const uint16_t* A;
     const uint16_t* W;
@@ -44,6 +46,9 @@ struct GemmParams {
     int stages;                // LDS ring depth: 2 = two-stage kernel, 3/4/6 = counted-vmcnt ring
     int debug;                 // ablation (bench only): 1 skip global loads after tile 0, 2 skip MFMA, 4 skip LDS reads + MFMA
     int coal;                  // 256x256 kernels: epilogue staged through LDS and written as whole 128-byte row segments (16-B stores)
+    // fp8 (fo1_gemm_fp8): A and W are OCP e4m3 bytes, C = (A W^T) * scale_m[m] * scale_n[n] before the epilogue
+    const float* scale_m;
+    const float* scale_n;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3, ACT_RELU = 5 };   // (4 = the split-K partial epilogue of the 256x256 kernels)
@@ -952,9 +957,15 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
 //   and each wait sits one barrier before the first read it guards for EITHER half (the lagging half waits one segment later
 //   than the leading one and still a barrier ahead of the leading half's read).
 // ------------------------------------------------------------------------------------------
-template <int EPI>
+// FP8: the same byte geometry (a K tile = 128 B per row = 128 e4m3 elements), v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales
+// (E8M0 127) — twice the K per MFMA at twice the rate: 16 MFMAs of 64 cycles per K tile where bf16 issues 32 of 32 cycles, so the DMA
+// schedule and every wait count carry over.  A lane's 32 operand bytes are two 16-B slots of the same swizzled LDS image; A and B
+// fragments are read the same way, so the operands' common k order inside a lane does not matter.
+template <int EPI, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) {
-    constexpr int BM = 256, BN = 256, BK = 64;
+    constexpr int BM = 256, BN = 256, ES = FP8 ? 1 : 2, BK = 128 / ES;
+    using frag_t = std::conditional_t<FP8, v8i32, bf16x8>;
+    constexpr int NKS = FP8 ? 2 : 4;                    // MFMA k-steps per K tile
     constexpr int GROUP = 16384, BUFSZ = 4 * GROUP;       // A0 | A1 | B0 | B1
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUFSZ]
 
@@ -966,24 +977,27 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     const int wm = wave >> 2, wn = wave & 3;
     const bool late = wave >= 4;
     const long long bz = blockIdx.y;
-    const uint16_t* A = p.A + bz * p.sA;
-    const uint16_t* W = p.W + bz * p.sW;
+    const char* A = reinterpret_cast<const char*>(p.A) + bz * p.sA * ES;
+    const char* W = reinterpret_cast<const char*>(p.W) + bz * p.sW * ES;
 
-    const uint16_t* src[4][2];
+    // per-lane source of each DMA piece.  FP8: 32-bit byte offsets from the (uniform) matrix bases — the 8 x 8-byte pointers are what
+    // pushes that variant (8-register operand tuples) over 256 VGPRs; fo1_gemm_fp8 bounds the matrices to 4 GB
+    using src_t = std::conditional_t<FP8, uint32_t, const char*>;
+    src_t src[4][2];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int lr = wave * 16 + i * 8 + (lane >> 3);
-            const int cs = ((lane & 7) ^ ((lr >> 1) & 7)) * 8;
+            const int cs = ((lane & 7) ^ ((lr >> 1) & 7)) * 16;      // bytes
             if (g < 2) {
                 int gm = m0 + (lr >> 6) * 128 + g * 64 + (lr & 63);
                 gm = gm < p.M ? gm : p.M - 1;
-                src[g][i] = A + (long long)gm * p.lda + cs;
+                if constexpr (FP8) src[g][i] = (uint32_t)gm * (uint32_t)p.lda + cs; else src[g][i] = A + (long long)gm * p.lda * ES + cs;
             } else {
                 int gn = n0 + (lr >> 5) * 64 + (g - 2) * 32 + (lr & 31);
                 gn = gn < p.N ? gn : p.N - 1;
-                src[g][i] = W + (long long)gn * p.ldw + cs;
+                if constexpr (FP8) src[g][i] = (uint32_t)gn * (uint32_t)p.ldw + cs; else src[g][i] = W + (long long)gn * p.ldw * ES + cs;
             }
         }
     const int nk_all = p.K / BK;
@@ -993,7 +1007,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             char* dst = smem + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;
-            const uint16_t* s = (g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i]) + (long long)(kt0 + kt) * BK;
+            const src_t so = g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i];
+            const char* s;
+            if constexpr (FP8) {
+                // uniform base (+ K-tile offset) in SGPRs, the lane's 32-bit offset in one VGPR: the saddr form of global_load_lds.
+                // The empty asm keeps hipcc from re-associating this into eight hoisted 64-bit per-lane pointers.
+                const char* ub = (g < 2 ? A : W) + (long long)(kt0 + kt) * 128;
+                asm volatile("" : "+s"(ub));
+                s = ub + so;
+            } else {
+                s = so + (long long)(kt0 + kt) * 128;
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
@@ -1009,6 +1033,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     }
     const int b_lr = wn * 32 + (lane & 31);
     const int b_off = b_lr * 128, b_sw = (b_lr >> 1) & 7;
+    const int a_base8 = a_off[0] + (((hi * 2) ^ a_sw[0]) << 4), b_base8 = b_off + (((hi * 2) ^ b_sw) << 4);   // FP8 fragment bases
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -1017,7 +1042,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    bf16x8 areg[2][4], breg[2][4];
+    frag_t areg[2][NKS], breg[2][NKS];
 
     // prologue: tile 0 complete; A0, B0 of tile 1 in flight (its B1, A1 are issued in MFMA-X(0))
     stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
@@ -1034,17 +1059,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         constexpr int BUF = decltype(BUFC)::value;
         const char* base = smem + BUF * BUFSZ;
         const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        // FP8: every fragment address derives from ONE register per operand (row * 128 + ((hi * 2) ^ swizzle) * 16): the k-step flips
+        // bit 6, the second 16-B slot bit 4, groups / buffers / the second 32-row block are constants.  The empty asm makes the
+        // base opaque per use — otherwise hipcc keeps all ~40 derived addresses live in registers and spills (a reload waits
+        // vmcnt(0), which also drains the LDS-DMA prefetch: measured 2x slower).
+        auto frag8 = [&](int vbase, int imm, int ks) __attribute__((always_inline)) -> v8i32 {
+            int t = vbase;
+            asm volatile("" : "+v"(t));
+            const int a0 = (t ^ (ks << 6)) + imm;
+            const uint4 lo = *reinterpret_cast<const uint4*>(smem + a0);
+            const uint4 up = *reinterpret_cast<const uint4*>(smem + (a0 ^ 16));
+            return v8i32{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
+        };
         auto loadA = [&](int h) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+            for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-                for (int fm = 0; fm < 2; ++fm)
-                    areg[fm][ks] = *reinterpret_cast<const bf16x8*>(base + h * GROUP + a_off[fm] + (((ks * 2 + hi) ^ a_sw[fm]) << 4));
+                for (int fm = 0; fm < 2; ++fm) {
+                    if constexpr (FP8) areg[fm][ks] = frag8(a_base8, BUF * BUFSZ + h * GROUP + fm * 4096, ks);
+                    else areg[fm][ks] = *reinterpret_cast<const bf16x8*>(base + h * GROUP + a_off[fm] + (((ks * 2 + hi) ^ a_sw[fm]) << 4));
+                }
         };
         auto loadB = [&](int h) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                breg[h][ks] = *reinterpret_cast<const bf16x8*>(base + (2 + h) * GROUP + b_off + (((ks * 2 + hi) ^ b_sw) << 4));
+            for (int ks = 0; ks < NKS; ++ks) {
+                if constexpr (FP8) breg[h][ks] = frag8(b_base8, BUF * BUFSZ + (2 + h) * GROUP, ks);
+                else breg[h][ks] = *reinterpret_cast<const bf16x8*>(base + (2 + h) * GROUP + b_off + (((ks * 2 + hi) ^ b_sw) << 4));
+            }
+        };
+        auto mm = [&](const frag_t& b, const frag_t& a, f32x16& c) __attribute__((always_inline)) {
+            if constexpr (FP8) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+            else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
         };
         auto end_load = [&]() {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1057,11 +1102,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
             if (!(last && late)) FO1_P8_BARRIER();
             __builtin_amdgcn_sched_barrier(0);
         };
-#define FO1_P4_MFMA4(AH, KS)                                                                                                       \
-    acc[(AH) * 2 + 0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[0][KS], areg[0][KS], acc[(AH) * 2 + 0][0], 0, 0, 0);       \
-    acc[(AH) * 2 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[0][KS], areg[1][KS], acc[(AH) * 2 + 1][0], 0, 0, 0);       \
-    acc[(AH) * 2 + 0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[1][KS], areg[0][KS], acc[(AH) * 2 + 0][1], 0, 0, 0);       \
-    acc[(AH) * 2 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(breg[1][KS], areg[1][KS], acc[(AH) * 2 + 1][1], 0, 0, 0);
+#define FO1_P4_MFMA2A(AH, KS)                                     \
+    mm(breg[0][KS], areg[0][KS], acc[(AH) * 2 + 0][0]);           \
+    mm(breg[0][KS], areg[1][KS], acc[(AH) * 2 + 1][0]);
+#define FO1_P4_MFMA2B(AH, KS)                                     \
+    mm(breg[1][KS], areg[0][KS], acc[(AH) * 2 + 0][1]);           \
+    mm(breg[1][KS], areg[1][KS], acc[(AH) * 2 + 1][1]);
+#define FO1_P4_MFMA4(AH, KS) FO1_P4_MFMA2A(AH, KS) FO1_P4_MFMA2B(AH, KS)
         // ---- phase X ----
         loadB(0);
         loadB(1);
@@ -1071,12 +1118,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         end_load();
         __builtin_amdgcn_s_setprio(1);
-        FO1_P4_MFMA4(0, 0)
-        if (more1) stage(3, t + 1, BUF ^ 1);
-        FO1_P4_MFMA4(0, 1)
-        FO1_P4_MFMA4(0, 2)
-        if (more1) stage(1, t + 1, BUF ^ 1);
-        FO1_P4_MFMA4(0, 3)
+        if constexpr (FP8) {
+            FO1_P4_MFMA2A(0, 0)
+            if (more1) stage(3, t + 1, BUF ^ 1);
+            FO1_P4_MFMA2B(0, 0)
+            FO1_P4_MFMA2A(0, 1)
+            if (more1) stage(1, t + 1, BUF ^ 1);
+            FO1_P4_MFMA2B(0, 1)
+        } else {
+            FO1_P4_MFMA4(0, 0)
+            if (more1) stage(3, t + 1, BUF ^ 1);
+            FO1_P4_MFMA4(0, 1)
+            FO1_P4_MFMA4(0, NKS - 2)
+            if (more1) stage(1, t + 1, BUF ^ 1);
+            FO1_P4_MFMA4(0, NKS - 1)
+        }
         __builtin_amdgcn_s_setprio(0);
         end_mfma(false);
         // ---- phase Y ----
@@ -1084,19 +1140,48 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         if (more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         end_load();
         __builtin_amdgcn_s_setprio(1);
-        FO1_P4_MFMA4(1, 0)
-        if (more2) stage(0, t + 2, BUF);
-        FO1_P4_MFMA4(1, 1)
-        FO1_P4_MFMA4(1, 2)
-        if (more2) stage(2, t + 2, BUF);
-        FO1_P4_MFMA4(1, 3)
+        if constexpr (FP8) {
+            FO1_P4_MFMA2A(1, 0)
+            if (more2) stage(0, t + 2, BUF);
+            FO1_P4_MFMA2B(1, 0)
+            FO1_P4_MFMA2A(1, 1)
+            if (more2) stage(2, t + 2, BUF);
+            FO1_P4_MFMA2B(1, 1)
+        } else {
+            FO1_P4_MFMA4(1, 0)
+            if (more2) stage(0, t + 2, BUF);
+            FO1_P4_MFMA4(1, 1)
+            FO1_P4_MFMA4(1, NKS - 2)
+            if (more2) stage(2, t + 2, BUF);
+            FO1_P4_MFMA4(1, NKS - 1)
+        }
         __builtin_amdgcn_s_setprio(0);
         end_mfma(!more1);
 #undef FO1_P4_MFMA4
+#undef FO1_P4_MFMA2A
+#undef FO1_P4_MFMA2B
     };
     for (int t = 0; t < nk; t += 2) {
         tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if constexpr (FP8) {
+        // dequantise: acc[mf][nf][r] = C[m][n] with m = m_base + mf*32 + (lane & 31), n = n_base + nf*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+        const int mb = m0 + wm * 128 + (lane & 31), nb = n0 + wn * 64 + hi * 4;
+#pragma unroll
+        for (int mf = 0; mf < 4; ++mf) {
+            const int m = mb + mf * 32;
+            const float sm = p.scale_m[m < p.M ? m : p.M - 1];
+#pragma unroll
+            for (int nf = 0; nf < 2; ++nf)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nb + nf * 32 + g * 8;
+                    const float4 sn = *reinterpret_cast<const float4*>(p.scale_n + (n + 4 <= p.N ? n : p.N - 4));
+                    acc[mf][nf][g * 4 + 0] *= sm * sn.x; acc[mf][nf][g * 4 + 1] *= sm * sn.y;
+                    acc[mf][nf][g * 4 + 2] *= sm * sn.z; acc[mf][nf][g * 4 + 3] *= sm * sn.w;
+                }
+        }
     }
     if constexpr (EPI != 4) {
         if (p.coal) {   // every wave's LDS reads of the main loop are retired (the last load segment ended at a barrier this wave has passed)
@@ -1465,6 +1550,75 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
     return FO1_OK;
 }
 
+// fp8 form of the 256 x 256 two-phase kernel (fo1_gemm_fp8)
+static int launch_gemm_p4_fp8(GemmParams& p, hipStream_t st) {
+    p.tiles_m = cdiv(p.M, 256);
+    p.tiles_n = cdiv(p.N, 256);
+    const dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
+    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    char pname[56];
+    const char* name = "gemm_fp8_p4<256,256>";
+    if (profile_enabled() && g_gemm_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemm_fp8 %dx%dx%d t256x256", p.M, p.N, p.K);
+        name = pname;
+    }
+    constexpr int smem = 2 * 4 * 16384;
+    {
+        const int nc = p.act == ACT_SWIGLU16 ? p.N / 2 : p.N;
+        p.coal = g_gemm_coal && nc % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 &&
+                 (p.res == nullptr || (p.ldr % 8 == 0 && ((uintptr_t)p.res & 15) == 0));
+    }
+    static bool attr = false;
+    if (!attr) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
+    }
+    if (p.act == 0) FO1_LAUNCH(name, flops, (gemm_bt_p4_kernel<0, true>), grid, dim3(512), smem, st, p);
+    else if (p.act == 1) FO1_LAUNCH(name, flops, (gemm_bt_p4_kernel<1, true>), grid, dim3(512), smem, st, p);
+    else if (p.act == 2) FO1_LAUNCH(name, flops, (gemm_bt_p4_kernel<2, true>), grid, dim3(512), smem, st, p);
+    else FO1_LAUNCH(name, flops, (gemm_bt_p4_kernel<3, true>), grid, dim3(512), smem, st, p);
+    return FO1_OK;
+}
+
+// One workgroup per row: absmax -> scale = absmax / 448 (1 for an all-zero row) -> q = e4m3(clamp(x / scale, +-448)), RNE (v_cvt_pk_fp8_f32:
+// OCP e4m3fn on gfx950).  The same routine quantises activations per token and weights per output channel.
+__global__ __launch_bounds__(256) void quantize_rows_e4m3_kernel(const uint16_t* __restrict__ x, long long ldx, int K, uint8_t* __restrict__ q,
+                                                                  long long ldq, float* __restrict__ scales) {
+    __shared__ float s_red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const uint16_t* xr = x + (long long)row * ldx;
+    const int nch = K >> 3;
+    float amax = 0.f;
+    for (int c = tid; c < nch; c += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(xr + c * 8);
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16_lo(v.x)), fabsf(bf16_hi(v.x))), fmaxf(fabsf(bf16_lo(v.y)), fabsf(bf16_hi(v.y)))));
+        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16_lo(v.z)), fabsf(bf16_hi(v.z))), fmaxf(fabsf(bf16_lo(v.w)), fabsf(bf16_hi(v.w)))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    if ((tid & 63) == 0) s_red[tid >> 6] = amax;
+    __syncthreads();
+    amax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (tid == 0) scales[row] = scale;
+    uint8_t* qr = q + (long long)row * ldq;
+    for (int c = tid; c < nch; c += 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(xr + c * 8);       // (L2 hit: the row was just read)
+        float f[8] = {bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y), bf16_lo(v.z), bf16_hi(v.z), bf16_lo(v.w), bf16_hi(v.w)};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = fminf(fmaxf(f[i] / scale, -448.0f), 448.0f);
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+        *reinterpret_cast<uint2*>(qr + c * 8) = uint2{(uint32_t)w0, (uint32_t)w1};
+    }
+}
+
 template <int BM, int BN, int NS>
 static int launch_ring(GemmParams& p, const char* name, double flops, dim3 grid, hipStream_t st) {
     static_assert((NS - 2) * ((BM + BN) / 32) <= 63, "vmcnt is a 6-bit counter");
@@ -1682,10 +1836,52 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
     p.sA = p.sW = p.sC = p.sR = 0;
     p.coal = 0;
+    p.scale_m = p.scale_n = nullptr;
     FO1_CHECK_ARG(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "gemm: workspace must be 16-byte aligned");
     if (g_gemm_gemv && M <= 4 && !out_f32 && (size_t)(M > 2 ? 4 : M) * K * 2 <= 150 * 1024 && (act != 3 || N % 32 == 0))
         return gemv_dispatch(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, (hipStream_t)stream, nullptr, 0.f);
     return gemm_dispatch(p, 1, (hipStream_t)stream, (float*)workspace, workspace_bytes);
+}
+
+// fp8 linear (BASELINE configs[4], "fp8 MFMA"): C[M,N] = epilogue((Aq Wq^T) * scale_a[m] * scale_w[n]) with OCP e4m3 operands, fp32
+// accumulation on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), bf16 output; epilogues as fo1_gemm_bf16 (act 0..3).
+// Aq [M, K] / Wq [N, K] bytes with lda / ldw in elements (= bytes); K % 128 == 0.  The reference has no fp8 path: the bar is the
+// oracle's dequantised fp32 product (tests/test_fp8_gpu.py) and the tolerance table against the bf16 engine in DESIGN.md.
+int fo1_gemm_fp8(const void* Aq, int lda, const float* scale_a, const void* Wq, int ldw, const float* scale_w, const void* bias,
+                 const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* stream) {
+    using namespace fo1;
+    if (M == 0 || N == 0) return FO1_OK;
+    FO1_CHECK_ARG(Aq && Wq && C && scale_a && scale_w, "gemm_fp8: NULL operand");
+    FO1_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm_fp8: bad shape M=%d N=%d K=%d", M, N, K);
+    FO1_CHECK_ARG(K % 128 == 0 && lda % 16 == 0 && ldw % 16 == 0 && lda >= K && ldw >= K, "gemm_fp8: K %% 128, lda / ldw %% 16 (K=%d lda=%d ldw=%d)", K, lda, ldw);
+    FO1_CHECK_ARG(((uintptr_t)Aq & 15) == 0 && ((uintptr_t)Wq & 15) == 0 && ((uintptr_t)scale_w & 15) == 0, "gemm_fp8: operands must be 16-byte aligned");
+    FO1_CHECK_ARG(act >= 0 && act <= 3, "gemm_fp8: act=%d (0 none, 1 GELU, 2 SiLU, 3 interleaved SwiGLU)", act);
+    FO1_CHECK_ARG(N % 4 == 0 && ldc % 4 == 0 && ((uintptr_t)C & 7) == 0, "gemm_fp8: N, ldc %% 4, C 8-byte aligned");
+    FO1_CHECK_ARG((long long)M * lda < (1LL << 32) && (long long)N * ldw < (1LL << 32), "gemm_fp8: operands larger than 4 GB");
+    FO1_CHECK_ARG(bias == nullptr || ((uintptr_t)bias & 7) == 0, "gemm_fp8: bias alignment");
+    FO1_CHECK_ARG(residual == nullptr || (ldr % 4 == 0 && ((uintptr_t)residual & 7) == 0 && ldr >= N), "gemm_fp8: residual layout");
+    if (act == 3) FO1_CHECK_ARG(residual == nullptr && N % 32 == 0 && ldc >= N / 2, "gemm_fp8: swiglu epilogue needs no residual, N %% 32 == 0, ldc >= N/2");
+    else FO1_CHECK_ARG(ldc >= N, "gemm_fp8: ldc too small");
+    GemmParams p;
+    p.A = (const uint16_t*)Aq; p.W = (const uint16_t*)Wq; p.bias = (const uint16_t*)bias; p.res = (const uint16_t*)residual;
+    p.C = (uint16_t*)C; p.C32 = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr; p.act = act;
+    p.sA = p.sW = p.sC = p.sR = 0;
+    p.splits = 1; p.kper = K / 128 + 1; p.part = nullptr; p.stages = 2; p.debug = 0; p.coal = 0;
+    p.scale_m = scale_a; p.scale_n = scale_w;
+    return launch_gemm_p4_fp8(p, (hipStream_t)stream);
+}
+
+// Row-wise e4m3 quantisation of a bf16 matrix: q[m, :] = e4m3(x[m, :] / scales[m]), scales[m] = absmax(x[m, :]) / 448.
+int fo1_quantize_rows_e4m3(const void* x, long long ldx, int M, int K, void* q, long long ldq, float* scales, void* stream) {
+    using namespace fo1;
+    if (M == 0) return FO1_OK;
+    FO1_CHECK_ARG(x && q && scales, "quantize_rows: NULL operand");
+    FO1_CHECK_ARG(M > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K, "quantize_rows: K, ldx, ldq %% 8 (K=%d)", K);
+    FO1_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)q & 7) == 0, "quantize_rows: alignment");
+    FO1_LAUNCH("quantize_rows_e4m3", (double)M * K * 3.0, quantize_rows_e4m3_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t*)x, ldx, K, (uint8_t*)q, ldq, scales);
+    return FO1_OK;
 }
 
 }  // extern "C"

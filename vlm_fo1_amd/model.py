@@ -122,6 +122,34 @@ class FO1Engine:
         r.stage_hook = None
         return r
 
+    # ---- fp8 linears (BASELINE configs[4]) -------------------------------------------------------
+    FP8_PRESETS = {"all": ("vit.wqkv", "vit.wgu", "vit.wd", "llm.wqkv", "llm.wgu", "llm.wdown"),
+                   "mlp": ("vit.wgu", "vit.wd", "llm.wgu", "llm.wdown"),        # attention projections stay bf16
+                   "llm-mlp": ("llm.wgu", "llm.wdown")}
+    FP8_DEFAULT = FP8_PRESETS["all"]
+
+    def enable_fp8(self, which: Sequence[str] = FP8_DEFAULT) -> int:
+        """W8A8 e4m3 for the named projections of every ViT block / LLM layer in the packed pass (products with >= ops.FP8_MIN_ROWS
+        rows; decode and small products keep the bf16 weights): weights are quantised per output channel once, activations per
+        token in front of each product.  Not the reference's numerics (it has no fp8 path): DESIGN.md section 10 holds the
+        measured deviation table.  Captured graphs are dropped.  Returns the number of weights registered."""
+        n = 0
+        if isinstance(which, str):
+            which = self.FP8_PRESETS[which]
+        for name in which:
+            part, key = name.split(".")
+            layers = self.vit.blocks if part == "vit" else self.llm.layers
+            for w in layers:
+                n += int(ops.register_fp8_weight(w[key]))
+        self._graphs.clear()
+        self._seen.clear()
+        return n
+
+    def disable_fp8(self) -> None:
+        ops.clear_fp8_weights()
+        self._graphs.clear()
+        self._seen.clear()
+
     def _mark(self, stage: str):
         """Stage boundary for measurement (bench.py sets `stage_hook` in its eager profiling pass only)."""
         if self.stage_hook is not None:

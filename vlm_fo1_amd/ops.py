@@ -149,11 +149,83 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if bias is not None:
         _chk(bias, "bias")
         assert bias.numel() == N and bias.is_contiguous()
+    if _fp8_weights and not out_f32 and M >= FP8_MIN_ROWS:
+        fw = _fp8_weights.get((pw, N, K))
+        if fw is not None:
+            aq, sa = quantize_rows_fp8(a)
+            return gemm_fp8(aq, sa, fw, bias, residual, act, out)
     ws = _gemm_workspace(a.device)
     rc = _L.load().fo1_gemm_bf16_ws(pa, lda, pw, ldw, bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc,
                                     M, N, K, act, 1 if out_f32 else 0, ws.data_ptr(), ws.numel(), _stream())
     _L.check(rc, "fo1_gemm_bf16_ws")
     return out
+
+
+# ---- fp8 linear (BASELINE configs[4]) ---------------------------------------------------------------------------------------
+class Fp8Weight:
+    """Per-output-channel e4m3 copy of an nn.Linear weight: q uint8 [N, K], scale fp32 [N]."""
+    __slots__ = ("q", "scale")
+
+    def __init__(self, q: torch.Tensor, scale: torch.Tensor):
+        self.q, self.scale = q, scale
+
+
+_fp8_weights = {}            # (data_ptr, N, K) of a registered bf16 weight -> Fp8Weight
+FP8_MIN_ROWS = 512           # below this the 256 x 256 fp8 tile is mostly padding: the bf16 kernels run
+
+
+def quantize_rows_fp8(x: torch.Tensor, q: Optional[torch.Tensor] = None, scales: Optional[torch.Tensor] = None):
+    """(q uint8 [M, K], scales fp32 [M]) = row-wise e4m3 quantisation of a bf16 matrix (fo1_quantize_rows_e4m3)."""
+    _chk(x, "x")
+    px, ldx, M, K = _rows(x, "x")
+    if q is None:
+        q = torch.empty(M, K, dtype=torch.uint8, device=x.device)
+    if scales is None:
+        scales = torch.empty(M, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().fo1_quantize_rows_e4m3(px, ldx, M, K, q.data_ptr(), q.stride(0), scales.data_ptr(), _stream()), "fo1_quantize_rows_e4m3")
+    return q, scales
+
+
+def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, w: Fp8Weight, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+             act: int = ACT_NONE, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = epilogue((aq @ w.q^T) * sa[:, None] * w.scale[None, :])  (fo1_gemm_fp8)."""
+    M, K = aq.shape
+    N = w.q.shape[0]
+    if aq.dtype != torch.uint8 or w.q.dtype != torch.uint8 or w.q.shape[1] != K or not aq.is_cuda:
+        raise ValueError("gemm_fp8: uint8 device operands with equal K")
+    n_out = N // 2 if act == ACT_SWIGLU16 else N
+    if out is None:
+        out = torch.empty(M, n_out, dtype=torch.bfloat16, device=aq.device)
+    po, ldc, Mo, No = _rows(out, "out")
+    assert (Mo, No) == (M, n_out)
+    pr, ldr = (None, 0)
+    if residual is not None:
+        _chk(residual, "residual")
+        pr, ldr, Mr, Nr = _rows(residual, "residual")
+        assert (Mr, Nr) == (M, N)
+    if bias is not None:
+        _chk(bias, "bias")
+        assert bias.numel() == N and bias.is_contiguous()
+    rc = _L.load().fo1_gemm_fp8(aq.data_ptr(), aq.stride(0), sa.data_ptr(), w.q.data_ptr(), w.q.stride(0), w.scale.data_ptr(),
+                                bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc, M, N, K, act, _stream())
+    _L.check(rc, "fo1_gemm_fp8")
+    return out
+
+
+def register_fp8_weight(w: torch.Tensor) -> bool:
+    """Quantise a bf16 [N, K] weight and let gemm() route large-M products with it through the fp8 kernel.  The bf16 tensor stays
+    (decode and small-M products keep using it).  False when the shape does not qualify (K % 128, N % 4)."""
+    _chk(w, "w")
+    pw, ldw, N, K = _rows(w, "w")
+    if K % 128 or N % 4:
+        return False
+    q, s = quantize_rows_fp8(w)
+    _fp8_weights[(pw, N, K)] = Fp8Weight(q, s)
+    return True
+
+
+def clear_fp8_weights() -> None:
+    _fp8_weights.clear()
 
 
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:
