@@ -246,9 +246,12 @@ def main():
     ap.add_argument("--boxes", type=int, default=100, help="proposals per image (default 100 = the configuration BASELINE.json's metric is quoted on; 32 = configs[1])")
     ap.add_argument("--image", default="480x640", help="HxW of the synthetic image (default = BASELINE configs[1]; 1344x1344 with "
                     "--boxes 100 is the high-resolution configuration's geometry)")
-    ap.add_argument("--batch", type=int, default=12, help="images packed into ONE pass of every stage (varlen batched prefill); a step is "
-                    "one such pass; 1 = one image per pass (latency mode).  12 (default): the LLM down projection is 31 x 8 = 248 tiles of "
-                    "256 x 256 on 256 CUs (8 images: 168 tiles, a third of the chip idle for that GEMM; measured 125.4 vs 120.5 images/s)")
+    ap.add_argument("--batch", type=int, default=25, help="images packed into ONE pass of every stage (varlen batched prefill); a step is "
+                    "one such pass; 1 = one image per pass (latency mode).  The 256 x 256 GEMM tiles run in rounds of 256 (one per CU), so "
+                    "the pass size sets how full the last round of every product is: 25 (default) makes the LLM o / down projections "
+                    "64 x 8 = 512 tiles = exactly two rounds and the ViT products 94-99 %% full (model + sweep: profiles/r02_batch_sweep.md; "
+                    "12 = 248 tiles = one round for the LLM but 72 %% for ViT proj / down: 125.3 images/s, dominant GEMM 1029 TFLOP/s, against "
+                    "128.3 / 1105 at 25; 8: 120.5)")
     ap.add_argument("--inflight", type=int, default=2, help="independent passes in flight per GPU (engine replicas on their own HIP "
                     "streams); 1 = strictly one pass at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
