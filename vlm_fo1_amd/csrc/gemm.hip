@@ -29,6 +29,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 typedef __attribute__((ext_vector_type(8))) int v8i32;
+typedef __attribute__((ext_vector_type(4))) unsigned int v4u32;
 
 struct GemmParams {
     const uint16_t* A;
@@ -698,7 +699,11 @@ __device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16
         for (int it = 0; it < 8; ++it) {
             const int r = it * 16 + (lane >> 2), m = m_base + r;
             const uint4 v = *reinterpret_cast<const uint4*>(region + r * 64 + (((lane & 3) ^ (r & 3)) << 4));
-            if (m < p.M && n_out < No) *reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n_out) = v;
+            if (m < p.M && n_out < No && !(p.debug & 8)) {
+                uint4* dst = reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n_out);
+                if (p.coal == 2) __builtin_nontemporal_store(*reinterpret_cast<const v4u32*>(&v), reinterpret_cast<v4u32*>(dst));
+                else *dst = v;
+            }
         }
     } else {
 #pragma unroll
@@ -741,7 +746,11 @@ __device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16
                     v.z = pack_bf16x2(bf16_lo(v.z) + bf16_lo(rv.z), bf16_hi(v.z) + bf16_hi(rv.z));
                     v.w = pack_bf16x2(bf16_lo(v.w) + bf16_lo(rv.w), bf16_hi(v.w) + bf16_hi(rv.w));
                 }
-                *reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n) = v;
+                if (!(p.debug & 8)) {
+                    uint4* dst = reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n);
+                    if (p.coal == 2) __builtin_nontemporal_store(*reinterpret_cast<const v4u32*>(&v), reinterpret_cast<v4u32*>(dst));
+                    else *dst = v;
+                }
             }
         }
     }
@@ -1002,7 +1011,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         }
     const int nk_all = p.K / BK;
     const int kt0 = blockIdx.z * p.kper;
-    const int nk = min(nk_all - kt0, p.kper);
+    const int nk = (p.debug & 16) ? 1 : min(nk_all - kt0, p.kper);      // (ablation: one K tile = prologue + epilogue only)
     auto stage = [&](int g, int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -1470,6 +1479,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4p_kernel(const GemmParams p)
 
 static int g_gemm_persist = 0;     // 256x256 kernels: 1 = persistent tile loop with the next tile's first DMA under the epilogue (measured 2-5 % SLOWER than one tile per workgroup, see gemm_bt_p4p_kernel)
 static int g_gemm_coal = 1;        // 256x256 kernels: LDS-staged coalesced epilogue (0 = fragment-shaped stores, for A/B)
+static int g_gemm_nt_store = 0;    // 256x256 kernels: non-temporal stores in the coalesced epilogue (A/B)
 static int g_gemm_big_sched = 1;   // 256x256 kernel schedule: 0 = four phases per K tile (p8), 1 = two fat phases with DMA issued between MFMAs (p4, default: +3..10 % measured, profiles/r02_gemm_bench_p8_v2.log)
 
 // 256 x 256 ping-pong kernel (gemm_bt_p8_kernel)
@@ -1489,6 +1499,7 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         const int nc = p.act == ACT_SWIGLU16 ? p.N / 2 : p.N;
         p.coal = g_gemm_coal && nc % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && p.sC % 8 == 0 &&
                  (p.res == nullptr || (p.ldr % 8 == 0 && ((uintptr_t)p.res & 15) == 0 && p.sR % 8 == 0));
+        if (p.coal && g_gemm_nt_store) p.coal = 2;
     }
     static bool attr_done = false;
     if (!attr_done) {
@@ -1771,7 +1782,8 @@ int fo1_gemm_set_variant(int staging, int tile) {
 int fo1_gemm_set_big_schedule(int sched) {
     // bit 0: 0 = four phases per K tile, 1 = two fat phases;  bit 1 set = fragment-shaped (un-coalesced) epilogue stores;
     // bit 2 set = persistent tile loop (gemm_bt_p4p_kernel) instead of one output tile per workgroup
-    if (sched < 0 || sched > 7) return fo1::set_err(FO1_ERR_ARG, "gemm: bad 256x256 schedule %d", sched);
+    if (sched < 0 || sched > 15) return fo1::set_err(FO1_ERR_ARG, "gemm: bad 256x256 schedule %d", sched);
+    fo1::g_gemm_nt_store = (sched & 8) ? 1 : 0;      // bit 3: non-temporal epilogue stores (A/B)
     fo1::g_gemm_big_sched = sched & 1;
     fo1::g_gemm_coal = (sched & 2) ? 0 : 1;
     fo1::g_gemm_persist = (sched & 4) ? 1 : 0;
