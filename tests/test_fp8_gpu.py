@@ -30,6 +30,15 @@ def test_quantize_rows_bit_exact():
     assert torch.equal(q.cpu(), q_ref)
 
 
+def test_quantize_rows_long_row():
+    """K > 12288: past the chunks a thread keeps in registers (the tail is re-read)."""
+    ops = _ops()
+    x = _bf(40, 13312, seed=12, scale=2.0)
+    q, s = ops.quantize_rows_fp8(x.cuda())
+    q_ref, s_ref = F.quantize_rows_e4m3(x.float())
+    assert torch.equal(s.cpu(), s_ref) and torch.equal(q.cpu(), q_ref)
+
+
 def test_quantize_rows_strided_view():
     ops = _ops()
     x = _bf(64, 512, seed=2)

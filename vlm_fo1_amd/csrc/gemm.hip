@@ -1602,12 +1602,21 @@ __global__ __launch_bounds__(256) void quantize_rows_e4m3_kernel(const uint16_t*
     const int row = blockIdx.x, tid = threadIdx.x;
     const uint16_t* xr = x + (long long)row * ldx;
     const int nch = K >> 3;
+    constexpr int RC = 6;                       // 16-byte chunks a thread keeps in registers (K <= 12288: the row is read once)
+    uint4 keep[RC];
     float amax = 0.f;
-    for (int c = tid; c < nch; c += 256) {
-        const uint4 v = *reinterpret_cast<const uint4*>(xr + c * 8);
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16_lo(v.x)), fabsf(bf16_hi(v.x))), fmaxf(fabsf(bf16_lo(v.y)), fabsf(bf16_hi(v.y)))));
-        amax = fmaxf(amax, fmaxf(fmaxf(fabsf(bf16_lo(v.z)), fabsf(bf16_hi(v.z))), fmaxf(fabsf(bf16_lo(v.w)), fabsf(bf16_hi(v.w)))));
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+        const int c = tid + i * 256;
+        keep[i] = c < nch ? *reinterpret_cast<const uint4*>(xr + c * 8) : uint4{0, 0, 0, 0};
     }
+    auto amax8 = [](const uint4& v, float a) __attribute__((always_inline)) {
+        a = fmaxf(a, fmaxf(fmaxf(fabsf(bf16_lo(v.x)), fabsf(bf16_hi(v.x))), fmaxf(fabsf(bf16_lo(v.y)), fabsf(bf16_hi(v.y)))));
+        return fmaxf(a, fmaxf(fmaxf(fabsf(bf16_lo(v.z)), fabsf(bf16_hi(v.z))), fmaxf(fabsf(bf16_lo(v.w)), fabsf(bf16_hi(v.w)))));
+    };
+#pragma unroll
+    for (int i = 0; i < RC; ++i) amax = amax8(keep[i], amax);
+    for (int c = tid + RC * 256; c < nch; c += 256) amax = amax8(*reinterpret_cast<const uint4*>(xr + c * 8), amax);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
     if ((tid & 63) == 0) s_red[tid >> 6] = amax;
@@ -1616,8 +1625,7 @@ __global__ __launch_bounds__(256) void quantize_rows_e4m3_kernel(const uint16_t*
     const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
     if (tid == 0) scales[row] = scale;
     uint8_t* qr = q + (long long)row * ldq;
-    for (int c = tid; c < nch; c += 256) {
-        const uint4 v = *reinterpret_cast<const uint4*>(xr + c * 8);       // (L2 hit: the row was just read)
+    auto quant8 = [&](const uint4& v, int c) __attribute__((always_inline)) {
         float f[8] = {bf16_lo(v.x), bf16_hi(v.x), bf16_lo(v.y), bf16_hi(v.y), bf16_lo(v.z), bf16_hi(v.z), bf16_lo(v.w), bf16_hi(v.w)};
 #pragma unroll
         for (int i = 0; i < 8; ++i) f[i] = fminf(fmaxf(f[i] / scale, -448.0f), 448.0f);
@@ -1627,7 +1635,13 @@ __global__ __launch_bounds__(256) void quantize_rows_e4m3_kernel(const uint16_t*
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
         w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
         *reinterpret_cast<uint2*>(qr + c * 8) = uint2{(uint32_t)w0, (uint32_t)w1};
+    };
+#pragma unroll
+    for (int i = 0; i < RC; ++i) {
+        const int c = tid + i * 256;
+        if (c < nch) quant8(keep[i], c);
     }
+    for (int c = tid + RC * 256; c < nch; c += 256) quant8(*reinterpret_cast<const uint4*>(xr + c * 8), c);   // (L2 hit: just read)
 }
 
 template <int BM, int BN, int NS>
