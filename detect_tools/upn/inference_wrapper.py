@@ -68,6 +68,7 @@ class UPNWrapper:
         state = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state.items()}      # clean_state_dict (utils/detr_utils.py:220-226)
         self.device = torch.device(device)
         self.model = UPNEngine(state, device, **engine_kwargs)
+        self.use_graph = True
         self._lut = None
 
     # ---- reference API ----------------------------------------------------------------------------------------------------------------
@@ -82,9 +83,10 @@ class UPNWrapper:
     def _inference(self, input_images: List[torch.Tensor], prompt_type: str):
         boxes, logits = [], []
         for img in input_images:                          # the engine runs one image per pass (the reference pads a batch into a NestedTensor)
-            out = self.model.forward(img, prompt_type)
-            boxes.append(out["pred_boxes"])
-            logits.append(out["pred_logits"][:, None])
+            # one hipGraph per image size from its second sighting on (torch.stack below copies the graph's static outputs)
+            out = self.model.forward_graph(img, prompt_type) if self.use_graph else self.model.forward(img, prompt_type)
+            boxes.append(out["pred_boxes"].clone())
+            logits.append(out["pred_logits"][:, None].clone())
         return dict(pred_boxes=torch.stack(boxes), pred_logits=torch.stack(logits))
 
     def construct_input(self, image: List[Union[str, Image.Image]]):

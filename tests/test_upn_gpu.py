@@ -213,4 +213,20 @@ def test_upn_wrapper_contract_and_full_size_model():
     for _ in range(3):
         w.model.forward(x)
     torch.cuda.synchronize()
-    print(f"\nUPN (Swin-L 2-2-18-2 + 6/6 deformable layers, 900 queries) on 800 x 1066: {(time.perf_counter() - t) / 3 * 1e3:.1f} ms per image (eager launches)")
+    eager_ms = (time.perf_counter() - t) / 3 * 1e3
+    ref = w.model.forward(x)
+    ref = (ref["pred_boxes"].clone(), ref["pred_logits"].clone())
+    for _ in range(3):                                     # sighting, capture, replay
+        got = w.model.forward_graph(x)
+    assert torch.equal(got["pred_boxes"], ref[0]) and torch.equal(got["pred_logits"], ref[1]), "graph replay != eager"
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(5):
+        w.model.forward_graph(x)
+    torch.cuda.synchronize()
+    graph_ms = (time.perf_counter() - t) / 5 * 1e3
+    print(f"\nUPN (Swin-L 2-2-18-2 + 6/6 deformable layers, 900 queries) on 800 x 1066: {eager_ms:.1f} ms per image eager, "
+          f"{graph_ms:.1f} ms as one hipGraph replay")
+    res2 = w.inference([img], "fine_grained_prompt")       # (second sighting of this size: captured; third: replayed)
+    res3 = w.inference([img], "fine_grained_prompt")
+    assert np.array_equal(res2["original_xyxy_boxes"], res["original_xyxy_boxes"]) and np.array_equal(res3["original_xyxy_boxes"], res["original_xyxy_boxes"])

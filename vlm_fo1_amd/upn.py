@@ -449,6 +449,48 @@ class UPNEngine:
         self.encoder = DeformableEncoder(state, "transformer.encoder.", n_enc, device)
         self.selector = QuerySelector(state, device, n_queries)
         self.decoder = DeformableDecoder(state, n_dec, device, n_queries)
+        import collections
+        self._graphs = collections.OrderedDict()     # (image shape, prompt type) -> (hipGraph, static image, outputs): LRU of GRAPH_CACHE
+        self._seen = {}
+        self._ws_owner = object()                    # scratch buffers are keyed by this token (ops.workspace_scope)
+
+    GRAPH_CACHE = 4
+    CAPTURE_AFTER = 1       # a size is captured on its second sighting (the first call also builds the per-size host plans)
+
+    def forward_graph(self, img: torch.Tensor, prompt_type: str = "fine_grained_prompt") -> dict:
+        """forward() replayed as ONE hipGraph per (image size, prompt type): the detector is ~1 900 small launches per image, most of
+        them launch-bound when issued one by one.  Returns pred_boxes / pred_logits (static buffers of the graph: valid until the
+        next call for the same size).  Same kernels, same order: bit-identical to forward() (tests/test_upn_gpu.py)."""
+        key = (tuple(img.shape), prompt_type)
+        ent = self._graphs.get(key)
+        if ent is None:
+            n = self._seen.get(key, 0)
+            self._seen[key] = n + 1
+            if n < self.CAPTURE_AFTER:
+                with ops.workspace_scope(self._ws_owner):
+                    return self.forward(img, prompt_type)
+            with ops.graph_lock.capture(), torch.inference_mode(False), ops.workspace_scope(self._ws_owner):
+                static = img.clone()
+                side = torch.cuda.Stream()           # warm-up on a side stream (allocates every lazily-created scratch buffer), then capture
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    self.forward(static, prompt_type)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = self.forward(static, prompt_type)
+                ent = (g, static, dict(pred_boxes=out["pred_boxes"], pred_logits=out["pred_logits"]))
+                self._graphs[key] = ent
+                while len(self._graphs) > self.GRAPH_CACHE:
+                    self._graphs.popitem(last=False)
+        else:
+            self._graphs.move_to_end(key)
+        g, static, out = ent
+        static.copy_(img)
+        with ops.graph_lock.replay():
+            g.replay()
+        return out
 
     def forward(self, img: torch.Tensor, prompt_type: str = "fine_grained_prompt") -> dict:
         if prompt_type not in ("fine_grained_prompt", "coarse_grained_prompt"):
