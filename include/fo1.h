@@ -171,6 +171,10 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
  *     residual).  K % 128 == 0, lda / ldw % 16 == 0 (bytes), operands 16-byte aligned, each operand < 4 GB.
  * ---------------------------------------------------------------------- */
 int fo1_quantize_rows_e4m3(const void* x, long long ldx, int M, int K, void* q, long long ldq, float* scales, void* stream);
+/* Qwen2RMSNorm (modeling_qwen2_5_vl.py:126-140) + the quantiser above in one launch: bit-identical to fo1_rmsnorm_bf16 followed by
+ * fo1_quantize_rows_e4m3, the bf16 row never reaches memory. */
+int fo1_rmsnorm_quant_e4m3(const void* x, int ldx, const void* weight, int M, int D, float eps, void* q, long long ldq, float* scales,
+                           void* stream);
 int fo1_gemm_fp8(const void* Aq, int lda, const float* scale_a, const void* Wq, int ldw, const float* scale_w, const void* bias,
                  const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* stream);
 /* Tuning hooks: staging 0 auto / 1 register-staged / 2 LDS-DMA two-stage / 3, 4, 6 LDS-DMA ring of that depth

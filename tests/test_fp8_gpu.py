@@ -98,6 +98,33 @@ def test_gemm_fp8_epilogues(act):
     _check(got, want, rare=1e-2 if act == 3 else 5e-3, mag=mag)
 
 
+@pytest.mark.parametrize("M,D", [(300, 1280), (1000, 2048), (37, 4096)])
+def test_rmsnorm_quant_equals_rmsnorm_then_quantize(M, D):
+    ops = _ops()
+    x = _bf(M, D, seed=20, scale=2.0).cuda()
+    x[5] = 0
+    w = (1.0 + 0.1 * torch.randn(D, generator=torch.Generator().manual_seed(21))).bfloat16().cuda()
+    q, s = ops.rmsnorm_quant_fp8(x, w, 1e-6)
+    q2, s2 = ops.quantize_rows_fp8(ops.rmsnorm(x, w, 1e-6))
+    assert torch.equal(s, s2) and torch.equal(q, q2)
+
+
+def test_norm_linear_is_the_two_calls_in_bf16_and_the_fused_pair_in_fp8():
+    ops = _ops()
+    M, N, K = 1024, 2560, 2048
+    x, w = _bf(M, K, seed=22).cuda(), _bf(N, K, seed=23, scale=0.05).cuda()
+    nw, bias = _bf(K, seed=24).cuda(), _bf(N, seed=25).cuda()
+    ref = ops.gemm(ops.rmsnorm(x, nw, 1e-6), w, bias)
+    assert torch.equal(ops.norm_linear(x, nw, 1e-6, w, bias), ref)
+    try:
+        assert ops.register_fp8_weight(w)
+        got = ops.norm_linear(x, nw, 1e-6, w, bias)
+        two = ops.gemm(ops.rmsnorm(x, nw, 1e-6), w, bias)          # norm, stand-alone quantiser, fp8 product
+    finally:
+        ops.clear_fp8_weights()
+    assert torch.equal(got, two)
+
+
 def test_gemm_routes_registered_weights_and_tracks_bf16():
     ops = _ops()
     M, N, K = 2000, 2560, 2048

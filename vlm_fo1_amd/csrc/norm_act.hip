@@ -234,6 +234,71 @@ namespace fo1 {
 __global__ __launch_bounds__(256) void zero16_kernel(uint4* __restrict__ p, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) p[i] = uint4{0, 0, 0, 0};
 }
+// RMSNorm whose output goes straight to the fp8 linear that consumes it (fo1_gemm_fp8): y = Qwen2RMSNorm(x) exactly as rownorm_kernel<0>
+// computes it (fp32 variance, bf16(x * rstd) * w -> bf16), then fo1_quantize_rows_e4m3's arithmetic on the bf16 row (scale = absmax / 448,
+// q = e4m3(clamp(y / scale))) — bit-identical to the two launches, without the bf16 row ever reaching memory.  One wave per row.
+__global__ __launch_bounds__(256) void rmsnorm_quant_e4m3_kernel(const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ w,
+                                                                  uint8_t* __restrict__ q, long long ldq, float* __restrict__ scales,
+                                                                  int M, int D, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int nchunk = D >> 3;
+    const uint16_t* xr = x + (size_t)row * ldx;
+    uint4 v[kMaxChunksPerLane];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            v[i] = *reinterpret_cast<const uint4*>(xr + c * 8);
+            float f[8];
+            unpack8(v[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+        }
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            float f[8], wf[8], o[8];
+            unpack8(v[i], f);
+            unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = wf[j] * bf16_to_f32(f32_to_bf16(f[j] * rstd));
+            v[i] = pack8(o);                              // the bf16 row rmsnorm would have written
+            unpack8(v[i], o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(o[j]));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o, 64));
+    const float scale = amax > 0.f ? amax / 448.0f : 1.0f;
+    if (lane == 0) scales[row] = scale;
+    uint8_t* qr = q + (long long)row * ldq;
+#pragma unroll
+    for (int i = 0; i < kMaxChunksPerLane; ++i) {
+        const int c = lane + i * 64;
+        if (c < nchunk) {
+            float f[8];
+            unpack8(v[i], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) f[j] = fminf(fmaxf(f[j] / scale, -448.0f), 448.0f);
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            *reinterpret_cast<uint2*>(qr + c * 8) = uint2{(uint32_t)w0, (uint32_t)w1};
+        }
+    }
+}
+
 }  // namespace fo1
 
 extern "C" {
@@ -253,6 +318,20 @@ int fo1_rmsnorm_bf16(const void* x, int ldx, const void* weight, void* y, int ld
     if (M == 0) return FO1_OK;
     FO1_LAUNCH("rmsnorm", (double)M * D * 4.0, rownorm_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream,
                (const uint16_t*)x, ldx, (const uint16_t*)weight, (const uint16_t*)nullptr, (uint16_t*)y, ldy, M, D, eps);
+    return FO1_OK;
+}
+
+// RMSNorm + row-wise e4m3 quantisation in one launch (the fp8 linears' producer; bit-identical to fo1_rmsnorm_bf16 followed by
+// fo1_quantize_rows_e4m3).  q bytes [M, D] (ldq bytes), scales fp32 [M].
+int fo1_rmsnorm_quant_e4m3(const void* x, int ldx, const void* weight, int M, int D, float eps, void* q, long long ldq, float* scales,
+                           void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && weight && q && scales, "rmsnorm_quant: NULL operand");
+    FO1_CHECK_ARG(M >= 0 && D > 0 && D % 8 == 0 && D <= 4096, "rmsnorm_quant: D=%d must be a multiple of 8 and <= 4096", D);
+    FO1_CHECK_ARG(ldx >= D && ldx % 8 == 0 && ldq >= D && ldq % 8 == 0 && ((uintptr_t)q & 7) == 0, "rmsnorm_quant: bad leading dimensions");
+    if (M == 0) return FO1_OK;
+    FO1_LAUNCH("rmsnorm_quant_e4m3", (double)M * D * 3.0, rmsnorm_quant_e4m3_kernel, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream,
+               (const uint16_t*)x, ldx, (const uint16_t*)weight, (uint8_t*)q, ldq, scales, M, D, eps);
     return FO1_OK;
 }
 

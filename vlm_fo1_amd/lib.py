@@ -187,6 +187,7 @@ SIGNATURES = {
     "fo1_gemm_bf16_ws": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                  c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "fo1_quantize_rows_e4m3": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_longlong, c_void_p, c_void_p]),
+    "fo1_rmsnorm_quant_e4m3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_longlong, c_void_p, c_void_p]),
     "fo1_gemm_fp8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                              c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_gemm_set_variant": (c_int, [c_int, c_int]),

@@ -235,14 +235,12 @@ class QwenLLM:
         if flops is None:
             flops = 4.0 * H * HD * (L * (pos0 + (L + 1) / 2.0))
         for li, w in enumerate(self.layers):
-            h = ops.rmsnorm(x, w["ln1"], c.rms_norm_eps)
-            qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
+            qkv = ops.norm_linear(x, w["ln1"], c.rms_norm_eps, w["wqkv"], w["bqkv"])
             ops.qkv_post_llm(qkv, H, KV, HD, cos, sin, self.kcache[li], self.vtcache[li], pos0)   # mRoPE + K append + V^T, one launch
             att = ops.attention_strided(qkv[:, :H * HD], q_row0=pos0, k=self.kcache[li], vt=self.vtcache[li], items=items,
                                         n_q_heads=H, n_kv_heads=KV, head_dim=HD, scale=scale, causal=True, flops=flops)
             x = ops.gemm(att, w["wo"], residual=x)
-            h = ops.rmsnorm(x, w["ln2"], c.rms_norm_eps)
-            a = ops.gemm(h, w["wgu"], act=ops.ACT_SWIGLU16)   # gate/up GEMM with the SwiGLU fused into its epilogue
+            a = ops.norm_linear(x, w["ln2"], c.rms_norm_eps, w["wgu"], act=ops.ACT_SWIGLU16)   # gate/up GEMM, SwiGLU in its epilogue
             x = ops.gemm(a, w["wdown"], residual=x)
             if collect is not None:
                 collect.append(x)

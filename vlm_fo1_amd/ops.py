@@ -212,6 +212,31 @@ def gemm_fp8(aq: torch.Tensor, sa: torch.Tensor, w: Fp8Weight, bias: Optional[to
     return out
 
 
+def rmsnorm_quant_fp8(x: torch.Tensor, weight: torch.Tensor, eps: float):
+    """(q uint8 [M, D], scales fp32 [M]) = quantize_rows_fp8(rmsnorm(x, weight, eps)) in one launch (fo1_rmsnorm_quant_e4m3)."""
+    _chk(x, "x"); _chk(weight, "weight")
+    px, ldx, M, D = _rows(x, "x")
+    q = torch.empty(M, D, dtype=torch.uint8, device=x.device)
+    scales = torch.empty(M, dtype=torch.float32, device=x.device)
+    _L.check(_L.load().fo1_rmsnorm_quant_e4m3(px, ldx, weight.data_ptr(), M, D, float(eps), q.data_ptr(), q.stride(0), scales.data_ptr(), _stream()),
+             "fo1_rmsnorm_quant_e4m3")
+    return q, scales
+
+
+def norm_linear(x: torch.Tensor, norm_w: torch.Tensor, eps: float, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                act: int = ACT_NONE) -> torch.Tensor:
+    """gemm(rmsnorm(x, norm_w, eps), w, bias, act=act): the RMSNorm -> nn.Linear pair of every ViT block / LLM layer
+    (modeling_qwen2_5_vl.py:317-331, 1066-1090).  bf16: exactly those two calls.  When `w` is registered for fp8 and the product is
+    large enough, the norm emits the e4m3 row + scale directly (no bf16 row, no separate quantiser launch)."""
+    if _fp8_weights and x.shape[0] >= FP8_MIN_ROWS:
+        pw, ldw, N, K = _rows(w, "w")
+        fw = _fp8_weights.get((pw, N, K))
+        if fw is not None:
+            q, s = rmsnorm_quant_fp8(x, norm_w, eps)
+            return gemm_fp8(q, s, fw, bias, None, act)
+    return gemm(rmsnorm(x, norm_w, eps), w, bias, act=act)
+
+
 def register_fp8_weight(w: torch.Tensor) -> bool:
     """Quantise a bf16 [N, K] weight and let gemm() route large-M products with it through the fp8 kernel.  The bf16 tensor stays
     (decode and small-M products keep using it).  False when the shape does not qualify (K % 128, N % 4)."""

@@ -228,14 +228,12 @@ class QwenViT:
         feats: List[torch.Tensor] = []
         for i, w in enumerate(self.blocks):
             full = i in c.fullatt_block_indexes
-            h = ops.rmsnorm(x, w["n1"], 1e-6)
-            qkv = ops.gemm(h, w["wqkv"], w["bqkv"])
+            qkv = ops.norm_linear(x, w["n1"], 1e-6, w["wqkv"], w["bqkv"])
             ops.qkv_post_vit(qkv, H, hd, g.cos, g.sin, vt)   # 2-D RoPE on q/k + V -> V^T, one launch
             att = ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
                                 flops=fl_full if full else fl_win)
             x = ops.gemm(att, w["wo"], w["bo"], residual=x)
-            h = ops.rmsnorm(x, w["n2"], 1e-6)
-            a = ops.gemm(h, w["wgu"], w["bgu"], act=ops.ACT_SWIGLU16)
+            a = ops.norm_linear(x, w["n2"], 1e-6, w["wgu"], w["bgu"], act=ops.ACT_SWIGLU16)
             x = ops.gemm(a, w["wd"], w["bd"], residual=x)
             if full and (capture == "all" or i == c.fullatt_block_indexes[-1]):
                 feats.append(ops.gather_rows(g.plan_raster, d, x))
