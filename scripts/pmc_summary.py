@@ -53,7 +53,7 @@ def main():
     write = fold(sys.argv[2], "WRITE_SIZE")
     out = {"units": "bytes per launch (mean over all launches of the kernel in the run)",
            "corrections": "FETCH_SIZE KB x 1024 x 2 (gfx950 half-count of 16 B/lane reads); WRITE_SIZE KB x 1024",
-           "command": "python bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline (default workload: 12 images x 100 boxes per pass; one rocprofv3 pass per counter)", "kernels": {}}
+           "command": "python bench.py --eager --inflight 1 --steps 2 --warmup 1 --no-cpu-baseline (default workload: 25 images x 100 boxes per pass; one rocprofv3 pass per counter)", "kernels": {}}
     for k, (n, v) in fetch.items():
         if not re.search(r"fo1::", k):
             continue

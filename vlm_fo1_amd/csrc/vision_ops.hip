@@ -73,14 +73,20 @@ __device__ __forceinline__ float dw_wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// PPW pixels per wave (C = 256 fills only half a wave's lanes with one pixel).  All 18 loads of a chunk are issued together: taps outside
+// the map read a clamped (valid) address and meet a zero weight — fmaf(x, 0, acc) leaves acc as it was, so the sums are the ones the
+// branchy form produced (a load under a branch costs a vmcnt(0) at the join: nine dependent L2 round trips per pixel, 3 TB/s).
+template <int PPW>
 __global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                            const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
                                                            const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b,
                                                            uint16_t* __restrict__ hout, int H, int W, int C, float eps, int B) {
-    const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);      // global pixel over the B images
+    constexpr int LPP = 64 / PPW;                              // lanes per pixel
+    const int lane = threadIdx.x & 63, sub = lane % LPP;
     const int HW = H * W;
-    if (pix >= B * HW) return;
-    const int lane = threadIdx.x & 63;
+    int pix = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;      // global pixel over the B images
+    const bool live = pix < B * HW;
+    if (!live) pix = B * HW - 1;                               // (keeps the half-wave shuffles well defined; nothing is stored)
     const int chunks = C >> 3;
     const int img0 = (pix / HW) * HW, lp = pix - img0;
     const int h = lp / W, w = lp - h * W;
@@ -88,55 +94,65 @@ __global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __res
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < kDwLnChunks; ++i) {
-        const int c = lane + i * 64;
+        const int c = sub + i * LPP;
         if (c < chunks) {
             float acc[8], ctr[8];
             un8(*reinterpret_cast<const uint4*>(bias + c * 8), acc);
+            uint4 xr[9], wr[9];
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int hh = h + ky - 1;
-                if (hh < 0 || hh >= H) continue;
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int ww = w + kx - 1;
-                    if (ww < 0 || ww >= W) continue;
-                    float xv[8], wv[8];
-                    un8(*reinterpret_cast<const uint4*>(x + ((long long)img0 + hh * W + ww) * C + c * 8), xv);
-                    un8(*reinterpret_cast<const uint4*>(wt + (ky * 3 + kx) * C + c * 8), wv);
+                    const int hh = h + ky - 1, ww = w + kx - 1;
+                    const bool ok = hh >= 0 && hh < H && ww >= 0 && ww < W;
+                    const int hc = hh < 0 ? 0 : (hh >= H ? H - 1 : hh), wc = ww < 0 ? 0 : (ww >= W ? W - 1 : ww);
+                    xr[ky * 3 + kx] = *reinterpret_cast<const uint4*>(x + ((long long)img0 + hc * W + wc) * C + c * 8);
+                    const uint4 wq = *reinterpret_cast<const uint4*>(wt + (ky * 3 + kx) * C + c * 8);
+                    wr[ky * 3 + kx] = ok ? wq : uint4{0, 0, 0, 0};
+                }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
-                    if (ky == 1 && kx == 1) {
+            for (int t = 0; t < 9; ++t) {
+                float xv[8], wv[8];
+                un8(xr[t], xv);
+                un8(wr[t], wv);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) ctr[j] = xv[j];
-                    }
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
+                if (t == 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ctr[j] = xv[j];
                 }
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[j] = ctr[j] + rbf(acc[j]);
             const uint4 packed = pk8(acc);
-            *reinterpret_cast<uint4*>(y + (long long)pix * C + c * 8) = packed;
+            if (live) *reinterpret_cast<uint4*>(y + (long long)pix * C + c * 8) = packed;
             un8(packed, val[i]);              // LayerNorm sees the bf16 values that were stored
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += val[i][j];
         }
     }
-    s = dw_wave_sum(s);
+    auto psum = [](float v) __attribute__((always_inline)) {     // over the LPP lanes of this pixel (the 64-lane tree minus its zero halves)
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    s = psum(s);
     const float mean = s / (float)C;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < kDwLnChunks; ++i) {
-        const int c = lane + i * 64;
+        const int c = sub + i * LPP;
         if (c < chunks) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = val[i][j] - mean; q += d * d; }
         }
     }
-    q = dw_wave_sum(q);
+    q = psum(q);
     const float rstd = rsqrtf(q / (float)C + eps);
 #pragma unroll
     for (int i = 0; i < kDwLnChunks; ++i) {
-        const int c = lane + i * 64;
-        if (c < chunks) {
+        const int c = sub + i * LPP;
+        if (c < chunks && live) {
             float wf[8], bf[8], o[8];
             un8(*reinterpret_cast<const uint4*>(ln_w + c * 8), wf);
             un8(*reinterpret_cast<const uint4*>(ln_b + c * 8), bf);
@@ -404,9 +420,20 @@ int fo1_dwconv3x3_ln_bf16(const void* x, const void* weight9c, const void* bias,
     FO1_CHECK_ARG(x && weight9c && bias && y && ln_weight && ln_bias && h && x != y && x != h && y != h,
                   "dwconv_ln: NULL operand or aliased buffers");
     FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 64 * kDwLnChunks * 8 && batch >= 1, "dwconv_ln: bad shape %dx%dx%d (C <= 2048)", H, W, C);
-    FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel, dim3(cdiv(batch * H * W, 4)), dim3(256), 0, (hipStream_t)stream,
-               (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
-               (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch);
+    const int chunks = C / 8, npix = batch * H * W;
+    if (chunks <= 16) {
+        FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<4>, dim3(cdiv(npix, 16)), dim3(256), 0, (hipStream_t)stream,
+                   (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
+                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch);
+    } else if (chunks <= 32) {
+        FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<2>, dim3(cdiv(npix, 8)), dim3(256), 0, (hipStream_t)stream,
+                   (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
+                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch);
+    } else {
+        FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<1>, dim3(cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream,
+                   (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
+                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch);
+    }
     return FO1_OK;
 }
 
