@@ -109,4 +109,9 @@ def load_pretrained_model(model_path, load_8bit=False, load_4bit=False, device="
     if os.environ.get("FO1_HOST_PREPROCESS") != "1":
         primary.device = aux.device = model.device
     model.eval()
+    # The engine's object graph (weight tables, plans, captured graphs) is long-lived: move it out of the cyclic GC's reach so that a
+    # generation-2 sweep does not stall request submission (~0.2 s every few dozen passes, profiles/r02_sustained_b25.log).
+    import gc
+    gc.collect()
+    gc.freeze()
     return tokenizer, model, (primary, aux)
