@@ -1741,7 +1741,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         // least half the CUs (measured, profiles/r02_gemm_bench_p8_v1.log: LLM o/down at 168 tiles 760 / 1007 TF vs 667 / 684 for the
         // best small tile; merger 260 tiles = 51 % of two rounds loses, 659 vs 894)
         const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256) * batch;
-        if (glds && nk >= 8 && p.M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) tile = 5;
+        if (glds && nk >= 4 && p.M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) tile = 5;
     }
     p.splits = 1;
     p.kper = nk + 1;
