@@ -185,8 +185,11 @@ int fo1_gemm_set_splitk(int splits);
 int fo1_gemm_set_big_schedule(int sched); /* 256x256 kernel, bit field: bit 0 = two fat phases per K tile with the DMA issued between MFMAs
                                             * (0 = four phases); bit 1 = fragment-shaped epilogue stores (0 = LDS-staged coalesced);
                                             * bit 2 = persistent tile loop (the next tile's first DMA under the epilogue, when there
-                                            * are more than 256 tiles; bit-identical, measured 2-5 % slower).  Default 1. */
-int fo1_gemm_set_debug(int bits); /* ablation for benches only: 1 no global loads, 2 no MFMA, 4 no LDS reads + MFMA (results invalid) */
+                                            * are more than 256 tiles; bit-identical, measured 2-5 % slower); bit 3 = non-temporal
+                                            * epilogue stores (no effect measured).  Default 1. */
+int fo1_gemm_set_debug(int bits); /* ablation for benches only (results invalid): 1 no global loads, 2 no MFMA, 4 no LDS reads + MFMA;
+                                   * 256x256 two-phase kernel: 8 epilogue computed but not stored, 16 one K tile per output tile
+                                   * (profiles/r02_gemm_t0_study.md) */
 int fo1_gemm_set_gemv(int on);   /* M <= 4 goes to the weight-streaming GEMV kernel (default on) */
 int fo1_gemm_profile_shapes(int on);
 

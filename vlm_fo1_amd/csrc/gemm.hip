@@ -1740,6 +1740,8 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         // large M (batched prefill): the 256 x 256 ping-pong kernel once its tiles fill >= 60 % of the rounds they occupy and at
         // least half the CUs (measured, profiles/r02_gemm_bench_p8_v1.log: LLM o/down at 168 tiles 760 / 1007 TF vs 667 / 684 for the
         // best small tile; merger 260 tiles = 51 % of two rounds loses, 659 vs 894)
+        // K >= 256 (nk >= 4): with the two-phase schedule and the coalesced epilogue even four K tiles per output tile beat the 64 x 128
+        // tile (DaViT stage 0 at 25 images: ~400 vs 211 TFLOP/s); the first threshold (nk >= 8) dated from the four-phase kernel
         const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256) * batch;
         if (glds && nk >= 4 && p.M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) tile = 5;
     }
