@@ -140,13 +140,18 @@ class FO1Engine:
             part, key = name.split(".")
             layers = self.vit.blocks if part == "vit" else self.llm.layers
             for w in layers:
-                n += int(ops.register_fp8_weight(w[key]))
+                k = ops.register_fp8_weight(w[key])
+                if k is not None:
+                    self._fp8_keys = getattr(self, "_fp8_keys", []) + [k]
+                    n += 1
         self._graphs.clear()
         self._seen.clear()
         return n
 
     def disable_fp8(self) -> None:
-        ops.clear_fp8_weights()
+        """Back to bf16 for the weights THIS engine registered (replicas share weights and therefore the routing)."""
+        ops.clear_fp8_weights(getattr(self, "_fp8_keys", []))
+        self._fp8_keys = []
         self._graphs.clear()
         self._seen.clear()
 

@@ -163,11 +163,12 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
 
 # ---- fp8 linear (BASELINE configs[4]) ---------------------------------------------------------------------------------------
 class Fp8Weight:
-    """Per-output-channel e4m3 copy of an nn.Linear weight: q uint8 [N, K], scale fp32 [N]."""
-    __slots__ = ("q", "scale")
+    """Per-output-channel e4m3 copy of an nn.Linear weight: q uint8 [N, K], scale fp32 [N].  `src` keeps the bf16 tensor it was made
+    from alive: the routing table is keyed by that tensor's address, which must not be handed to another allocation meanwhile."""
+    __slots__ = ("q", "scale", "src")
 
-    def __init__(self, q: torch.Tensor, scale: torch.Tensor):
-        self.q, self.scale = q, scale
+    def __init__(self, q: torch.Tensor, scale: torch.Tensor, src: Optional[torch.Tensor] = None):
+        self.q, self.scale, self.src = q, scale, src
 
 
 _fp8_weights = {}            # (data_ptr, N, K) of a registered bf16 weight -> Fp8Weight
@@ -237,20 +238,26 @@ def norm_linear(x: torch.Tensor, norm_w: torch.Tensor, eps: float, w: torch.Tens
     return gemm(rmsnorm(x, norm_w, eps), w, bias, act=act)
 
 
-def register_fp8_weight(w: torch.Tensor) -> bool:
+def register_fp8_weight(w: torch.Tensor):
     """Quantise a bf16 [N, K] weight and let gemm() route large-M products with it through the fp8 kernel.  The bf16 tensor stays
-    (decode and small-M products keep using it).  False when the shape does not qualify (K % 128, N % 4)."""
+    (decode and small-M products keep using it).  Returns the routing key (truthy), or None when the shape does not qualify
+    (K % 128, N % 4)."""
     _chk(w, "w")
     pw, ldw, N, K = _rows(w, "w")
     if K % 128 or N % 4:
-        return False
+        return None
     q, s = quantize_rows_fp8(w)
-    _fp8_weights[(pw, N, K)] = Fp8Weight(q, s)
-    return True
+    _fp8_weights[(pw, N, K)] = Fp8Weight(q, s, w)
+    return (pw, N, K)
 
 
-def clear_fp8_weights() -> None:
-    _fp8_weights.clear()
+def clear_fp8_weights(keys=None) -> None:
+    """Drop the given routing keys (an engine's own registrations), or every registration."""
+    if keys is None:
+        _fp8_weights.clear()
+    else:
+        for k in keys:
+            _fp8_weights.pop(k, None)
 
 
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -465,6 +465,8 @@ class UPNEngine:
         ent = self._graphs.get(key)
         if ent is None:
             n = self._seen.get(key, 0)
+            if len(self._seen) >= 4096:                  # bounded: a dataset has thousands of distinct image sizes
+                self._seen.pop(next(iter(self._seen)))
             self._seen[key] = n + 1
             if n < self.CAPTURE_AFTER:
                 with ops.workspace_scope(self._ws_owner):
