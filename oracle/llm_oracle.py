@@ -12,9 +12,10 @@ model half of the hot path, following the reference's vendored file
     Qwen2_5_VLModel.forward           :1126-1242
     get_rope_index                    :1546-1701
 and the splice of vlm_fo1/model/language_model/omchat_qwen2_5_vl.py:291-373.
-The vendored LLM half does not construct under the installed transformers 5.x, so
-this restatement is pinned against the installed HF `Qwen2_5_VLTextModel` (same architecture)
-in tests/test_oracle_llm.py — "parity pinned to HF, not to the vendored copy".
+Pinned in tests/test_oracle_llm.py against the reference's OWN vendored `Qwen2_5_VLModel` run in place on the CPU (prefill and the
+KV-cache greedy decode path; oracle/reference_loader.py:vendored_llm builds it under the installed transformers 5 with two construction
+shims — the rope initialiser key and pad_token_id — none in the arithmetic), and against the installed HF `Qwen2_5_VLTextModel`
+(same architecture; the two produce bit-identical fp32 outputs, which is also how tests/golden/llm_ref.npz is generated).
 
 State-dict keys are the checkpoint's (`layers.{i}.self_attn.q_proj.weight`, ...).
 """

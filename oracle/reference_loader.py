@@ -38,6 +38,29 @@ def vendored_qwen():
     return _cache["qwen"]
 
 
+def vendored_llm(**cfg_kwargs):
+    """The reference's OWN vendored `Qwen2_5_VLModel` (the LLM half of modeling_qwen2_5_vl.py:1097-1242: decoder layers :1014-1095,
+    mRoPE :603-685, attention :738-1004) built on the CPU with sdpa attention.  Two shims for the installed transformers 5, neither of
+    which touches the arithmetic under test:
+      * `ROPE_INIT_FUNCTIONS["default"]` — transformers 5 dropped the key the vendored rotary module looks up (:578); the shim is the
+        published default initialiser, inv_freq = theta^(-2i/d), attention scaling 1;
+      * `config.pad_token_id = None` — read by `nn.Embedding(padding_idx=...)` at :1105, absent from the new config class.
+    cfg_kwargs: Qwen2_5_VLConfig text fields (vocab_size, hidden_size, ..., rope_scaling={"type": "mrope", "mrope_section": [...]})."""
+    import torch
+    ref = vendored_qwen()
+
+    def _default_rope(config, device=None, **kw):
+        dim = getattr(config, "head_dim", None) or config.hidden_size // config.num_attention_heads
+        inv = 1.0 / (config.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.int64).float() / dim))
+        return inv, 1.0
+
+    ref.ROPE_INIT_FUNCTIONS.setdefault("default", _default_rope)
+    cfg = ref.Qwen2_5_VLConfig(**cfg_kwargs)
+    cfg.pad_token_id = None
+    cfg._attn_implementation = "sdpa"
+    return ref.Qwen2_5_VLModel(cfg).eval()
+
+
 def vendored_davit():
     """The reference DaViT (modeling_davit.py) with a 2-symbol shim for timm (init/regulariser only)."""
     if "davit" not in _cache:

@@ -1,6 +1,5 @@
 """Generates tests/golden/{vit,davit,fpn,llm}_ref.npz: outputs of the REFERENCE's own modules (imported in place from
-/root/reference; the LLM from the installed HF Qwen2_5_VLTextModel because the vendored LLM half does not construct under this
-transformers) at TRUE channel widths and reduced depth, fp32 on the CPU, on seeded inputs.  Weights are NOT stored: they come from
+/root/reference — the LLM too: the vendored Qwen2_5_VLModel, see llm()) at TRUE channel widths and reduced depth, fp32 on the CPU, on seeded inputs.  Weights are NOT stored: they come from
 the CPU-seeded `random_*_state` helpers of oracle/, which reproduce bit-identically anywhere, so the goldens hold outputs only.
 tests/test_golden_towers.py (CPU: oracle vs golden) and tests/test_golden_towers_gpu.py (HIP engine vs golden) consume them —
 neither needs /root/reference.
@@ -81,16 +80,15 @@ def fpn():
 
 
 def llm():
-    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as M
-    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLTextConfig
+    """The reference's OWN vendored Qwen2_5_VLModel (modeling_qwen2_5_vl.py:1097-1242) run in place: oracle/reference_loader.py:vendored_llm
+    builds it under the installed transformers with two construction shims (rope initialiser key, pad_token_id), none in the arithmetic."""
     c = LLM
-    cfg = Qwen2_5_VLTextConfig(vocab_size=c["vocab"], hidden_size=2048, intermediate_size=11008, num_hidden_layers=c["layers"],
-                               num_attention_heads=16, num_key_value_heads=2, max_position_embeddings=4096, rms_norm_eps=1e-6,
-                               rope_theta=1e6, bos_token_id=None, eos_token_id=None, pad_token_id=None,
-                               rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]}, tie_word_embeddings=True)
-    m = M.Qwen2_5_VLTextModel(cfg).eval()
+    m = R.vendored_llm(vocab_size=c["vocab"], hidden_size=2048, intermediate_size=11008, num_hidden_layers=c["layers"],
+                       num_attention_heads=16, num_key_value_heads=2, max_position_embeddings=4096, rms_norm_eps=1e-6,
+                       rope_theta=1e6, rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]}, tie_word_embeddings=True)
     sd = LO.random_llm_state(c["layers"], 2048, 16, 2, 128, 11008, c["vocab"], seed=c["seed"])
-    m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    res = m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
     x, pos = llm_input()
     with torch.no_grad():
         ref = m(inputs_embeds=x.float()[None], position_ids=pos[:, None, :]).last_hidden_state[0]
@@ -102,4 +100,6 @@ def llm():
 if __name__ == "__main__":
     assert R.available(), "/root/reference is needed to generate the goldens"
     torch.set_num_threads(8)
-    vit(); davit(); fpn(); llm()
+    only = sys.argv[1:] or ["vit", "davit", "fpn", "llm"]
+    for name in only:
+        {"vit": vit, "davit": davit, "fpn": fpn, "llm": llm}[name]()

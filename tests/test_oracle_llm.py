@@ -1,6 +1,6 @@
-"""CPU tests pinning oracle/llm_oracle.py: against the installed HF Qwen2_5_VLTextModel (the vendored
-LLM half does not construct under this transformers), and get_rope_index against the reference's own
-vendored function called unbound (it is pure index arithmetic)."""
+"""CPU tests pinning oracle/llm_oracle.py: against the reference's own vendored Qwen2_5_VLModel run in place (prefill and KV-cache
+decode; oracle/reference_loader.py:vendored_llm), against the installed HF Qwen2_5_VLTextModel, and get_rope_index against the
+reference's own vendored function called unbound (it is pure index arithmetic)."""
 import types
 
 import pytest
@@ -32,6 +32,58 @@ def test_llm_oracle_matches_hf_text_model():
         ref = m(inputs_embeds=x[None], position_ids=pos[:, None, :]).last_hidden_state[0]
     got = LO.llm_forward(sd, x, pos, bf16_rope_tables=False, **tiny_cfg())
     torch.testing.assert_close(got, ref, rtol=2e-4, atol=2e-4)
+
+
+def _vendored_tiny():
+    return R.vendored_llm(vocab_size=512, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+                          num_key_value_heads=1, max_position_embeddings=1024, rms_norm_eps=1e-6, rope_theta=1e6,
+                          rope_scaling={"type": "mrope", "mrope_section": [16, 24, 24]}, tie_word_embeddings=True)
+
+
+@pytest.mark.skipif(not R.available(), reason="/root/reference not present")
+def test_llm_oracle_matches_the_reference_s_own_vendored_model():
+    """The oracle against the reference's vendored Qwen2_5_VLModel (modeling_qwen2_5_vl.py:1097-1242) run in place on the CPU — two
+    construction shims for transformers 5, none in the arithmetic (oracle/reference_loader.py:vendored_llm)."""
+    m = _vendored_tiny()
+    sd = LO.random_llm_state(2, 256, 2, 1, 128, 512, 512, seed=3)
+    res = m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    for L, nb, grid in ((40, 7, (3, 5)), (95, 20, (5, 7))):
+        torch.manual_seed(L)
+        x = torch.randn(L, 256).bfloat16().float()
+        pos, _ = LO.rope_index(nb, grid, L - nb - grid[0] * grid[1])
+        with torch.no_grad():
+            ref = m(inputs_embeds=x[None], position_ids=pos[:, None, :]).last_hidden_state[0]
+        got = LO.llm_forward(sd, x, pos, bf16_rope_tables=False, **tiny_cfg())
+        torch.testing.assert_close(got, ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.skipif(not R.available(), reason="/root/reference not present")
+def test_llm_oracle_kv_cache_decode_matches_the_vendored_model():
+    """Greedy continuation through the KV cache: the vendored model's own 1-token path (cache_position + rope delta,
+    omchat_qwen2_5_vl.py:143-155) against the oracle's cached decode, hidden state per step."""
+    m = _vendored_tiny()
+    sd = LO.random_llm_state(2, 256, 2, 1, 128, 512, 512, seed=4)
+    m.load_state_dict({k: v.float() for k, v in sd.items()}, strict=True)
+    L, nb, grid = 40, 7, (3, 5)
+    torch.manual_seed(1)
+    x = torch.randn(L, 256).bfloat16().float()
+    pos, delta = LO.rope_index(nb, grid, L - nb - grid[0] * grid[1])
+    emb = sd["embed_tokens.weight"].float()
+    with torch.no_grad():
+        out = m(inputs_embeds=x[None], position_ids=pos[:, None, :], use_cache=True)
+        past = out.past_key_values
+        hid, cache = LO.llm_forward_cached(sd, x, pos, None, bf16_rope_tables=False, **tiny_cfg())   # (the fp32 model keeps fp32 tables)
+        torch.testing.assert_close(hid, out.last_hidden_state[0], rtol=2e-5, atol=2e-5)
+        tok = 11
+        for step in range(4):
+            p = L + step + delta
+            pid = torch.full((3, 1, 1), p, dtype=torch.long)
+            out = m(inputs_embeds=emb[tok:tok + 1][None], position_ids=pid, past_key_values=past, use_cache=True)
+            past = out.past_key_values
+            hid, cache = LO.llm_forward_cached(sd, emb[tok:tok + 1], torch.full((3, 1), p, dtype=torch.long), cache, bf16_rope_tables=False, **tiny_cfg())
+            torch.testing.assert_close(hid, out.last_hidden_state[0], rtol=2e-5, atol=2e-5)
+            tok = int((hid[-1] @ emb.t()).argmax())
 
 
 @pytest.mark.skipif(not R.available(), reason="/root/reference not present")
