@@ -4,6 +4,8 @@ supports beyond the default one:
   ln          apply_region_layer_norm=True      (aux_region_norm / vt_region_norm with seeded weights; reference :365-372)
   aux_pos     region_feature_combination='concat_aux_pos'   (box embedding from the aux boxes; :443-455)
   vt_only     use_vt_region_feature_only=True   (:293-317; region_feature_dim = 2048)
+  fm_pos      pos_embedding_strategy='feature_map_based'    (2-D sine table added to every aux level, no box embedding; :327-335)
+  hybrid      pos_embedding_strategy='hybrid'               (both)
 
     python tests/golden/make_hfre_variant_golden.py
 """
@@ -40,6 +42,10 @@ def run(case, variant):
     elif variant == "vt_only":
         kw["use_vt_region_feature_only"] = True
         kw["region_feature_dim"] = 2048
+    elif variant == "fm_pos":
+        kw["pos_embedding_strategy"] = "feature_map_based"
+    elif variant == "hybrid":
+        kw["pos_embedding_strategy"] = "hybrid"
     torch.manual_seed(0)
     m = HFREModule(**kw)
     if variant == "ln":
@@ -63,7 +69,7 @@ def run(case, variant):
 def main():
     case = make_case("demo_fpn")
     blobs = dict(checksum=checksum(case))
-    for v in ("ln", "aux_pos", "vt_only"):
+    for v in ("ln", "aux_pos", "vt_only", "fm_pos", "hybrid"):
         out = run(case, v)
         blobs[v] = out.numpy()
         print(v, tuple(out.shape))

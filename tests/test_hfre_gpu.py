@@ -244,6 +244,12 @@ def test_hfre_variants_vs_reference_golden_and_oracle():
     got = engine_out(d2, use_vt_region_feature_only=True).cpu()
     assert got.shape == (case["boxes"].shape[0], 2048)
     torch.testing.assert_close(got, torch.from_numpy(g["vt_only"]), rtol=RTOL, atol=ATOL)
+    # feature-map position embedding (reference :327-335): a bf16 table added to every aux level before pooling; 'hybrid' keeps the box
+    # embedding too.  The table is built on the host with the reference's expression, so the bf16 sums are the reference's.
+    for name, strategy in (("fm_pos", "feature_map_based"), ("hybrid", "hybrid")):
+        got = engine_out(d, pos_embedding_strategy=strategy).cpu()
+        torch.testing.assert_close(got, torch.from_numpy(g[name]), rtol=RTOL, atol=ATOL)
+    assert not torch.equal(torch.from_numpy(g["fm_pos"]), torch.from_numpy(g["hybrid"]))
 
 
 def test_hfre_batched_call_equals_per_image():

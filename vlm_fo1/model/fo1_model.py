@@ -54,7 +54,7 @@ class FO1HFConfig:
             unsupported.append("mm_use_vision_tower_region_feature=False")
         if d.get("mm_region_feature_combination", "concat") not in ("concat", "concat_aux_pos"):
             unsupported.append(f"mm_region_feature_combination={d.get('mm_region_feature_combination')!r}")
-        if d.get("mm_pos_embedding_strategy", "bbox_based") != "bbox_based":
+        if d.get("mm_pos_embedding_strategy", "bbox_based") not in ("bbox_based", "feature_map_based", "hybrid"):
             unsupported.append(f"mm_pos_embedding_strategy={d.get('mm_pos_embedding_strategy')!r}")
         aux = str(d.get("mm_vision_tower_aux", "davit-large"))
         if "davit-large" not in aux:
@@ -66,6 +66,7 @@ class FO1HFConfig:
                          mm_use_simpleFPN_for_vt=bool(d.get("mm_use_simpleFPN_for_vt", False)),
                          mm_region_hidden_size=int(d["mm_region_hidden_size"]), mm_roi_output_size=int(d.get("mm_roi_output_size", 7)),
                          mm_apply_position_embedding=bool(d.get("mm_apply_position_embedding", True)),
+                         mm_pos_embedding_strategy=d.get("mm_pos_embedding_strategy", "bbox_based"),
                          mm_apply_region_layer_norm=bool(d.get("mm_apply_region_layer_norm", False)),
                          mm_region_feature_combination=d.get("mm_region_feature_combination", "concat"),
                          mm_use_vt_region_feature_only=bool(d.get("mm_use_vt_region_feature_only", False)))

@@ -57,15 +57,16 @@ class HFREModule:
                  aux_vision_tower_region_feature_dims: Sequence[int] = (256, 512, 1024, 2048),
                  aux_vision_tower_spatial_scale: float = 0.25, simple_fpn=None):
         # Built: aux + vt ('concat' / 'concat_aux_pos'), vt only (use_vt_region_feature_only), aux only, with or without SimpleFPN,
-        # 'bbox_based' position embedding, region LayerNorm (reference :365-372).  Not built (the engine refuses loudly): the
-        # 'mean*' / '*_sep_pos' fusions (they need the extra vision_tower_region_feature_projector / hard-coded 2880-5120 splits of
-        # :373-432), per-region MLPs, and feature-map position embeddings (:327-335).
+        # 'bbox_based' / 'feature_map_based' / 'hybrid' position embedding (reference :327-335, :436-467), region LayerNorm (:365-372).
+        # Not built (the engine refuses loudly): the 'mean*' / '*_sep_pos' fusions and per-region MLPs — with DaViT-L's 3840 aux
+        # channels the reference itself cannot run them (mean adds a [N,3840] to a [N,2048|5120] tensor, *_sep_pos adds a 2880-wide
+        # embedding, the MLPs are Linear(2048, .) on 3840 inputs: :373-432, :184-196).
         unsupported = []
         if region_feature_combination not in ("concat", "concat_aux_pos"):
             unsupported.append(f"region_feature_combination={region_feature_combination!r}")
         if use_separate_mlp_for_regions:
             unsupported.append("use_separate_mlp_for_regions")
-        if apply_position_embedding and pos_embedding_strategy != "bbox_based":
+        if pos_embedding_strategy not in ("bbox_based", "feature_map_based", "hybrid"):
             unsupported.append(f"pos_embedding_strategy={pos_embedding_strategy!r}")
         if use_vt_region_feature_only and not use_vision_tower_region_feature:
             unsupported.append("use_vt_region_feature_only without use_vision_tower_region_feature")
@@ -80,6 +81,8 @@ class HFREModule:
         self.roi_output_size = roi_output_size
         self.region_feature_dim = region_feature_dim
         self.apply_position_embedding = apply_position_embedding
+        self.pos_embedding_strategy = pos_embedding_strategy
+        self._fm_pos = {}          # (H, W, C, batch, device) -> bf16 [batch*H*W, C] feature-map position table
         self.vision_tower_region_feature_dim = vision_tower_region_feature_dim
         self.vision_tower_spatial_scale = vision_tower_spatial_scale
         self.use_simpleFPN_for_vt = use_simpleFPN_for_vt
@@ -95,6 +98,33 @@ class HFREModule:
         self._ln = (f(aux_weight), f(aux_bias), f(vt_weight), f(vt_bias))
 
     # -- helpers ---------------------------------------------------------------
+    def _feature_map_pos(self, H: int, W: int, C: int, batch: int, device) -> torch.Tensor:
+        """generate_2d_position_embedding (reference :9-52) as token-major bf16 rows [batch*H*W, C]: y | x halves, each sin / cos
+        interleaved over dim // 4 frequencies, coordinates normalised to [0, 1).  fp32 on the host with the reference's expression,
+        cast like `pos_embed.to(feature.dtype)` (:208)."""
+        key = (H, W, C, batch, str(device))
+        t = self._fm_pos.get(key)
+        if t is None:
+            import math
+            y = torch.arange(H, dtype=torch.float32) / H
+            x = torch.arange(W, dtype=torch.float32) / W
+            yg, xg = torch.meshgrid(y, x, indexing="ij")
+            q = C // 4
+            dim_t = torch.arange(q, dtype=torch.float32)
+            dim_t = 10000 ** (2 * (dim_t // 2) / q) if q > 0 else torch.tensor([1.0])
+            px = (xg.unsqueeze(-1) * (2 * math.pi)) / dim_t
+            py = (yg.unsqueeze(-1) * (2 * math.pi)) / dim_t
+            px = torch.stack((px.sin(), px.cos()), dim=-1).flatten(-2)
+            py = torch.stack((py.sin(), py.cos()), dim=-1).flatten(-2)
+            pe = torch.cat([py, px], dim=-1).reshape(H * W, -1)
+            if pe.shape[1] != C:
+                raise _lib.Fo1Error(f"feature-map position embedding: channel count {C} is not a multiple of 4")
+            t = pe.to(torch.bfloat16).repeat(batch, 1).contiguous().to(device)
+            if len(self._fm_pos) >= 64:
+                self._fm_pos.pop(next(iter(self._fm_pos)))
+            self._fm_pos[key] = t
+        return t
+
     @staticmethod
     def _src(x: torch.Tensor, roi_hw, scale: float, box_space: int, out_off: int, keep: list):
         x = _token_major_bf16(x)
@@ -126,7 +156,7 @@ class HFREModule:
             out = out.unsqueeze(0)
         sx, sy = (vt_scale if vt_scale is not None else (1.0, 1.0))
         pos_mode = 0
-        if self.apply_position_embedding:
+        if self.apply_position_embedding and self.pos_embedding_strategy in ("bbox_based", "hybrid"):     # reference :438-440
             pos_mode = 2 if (self.region_feature_combination == "concat_aux_pos" or not self.use_vision_tower_region_feature) else 1
         from . import ops as _ops
         use_ln = self.apply_region_layer_norm
@@ -189,7 +219,23 @@ class HFREModule:
         if not self.use_vt_region_feature_only:
             H0 = max(f.shape[2] for f in aux_multi_level_features)
             W0 = max(f.shape[3] for f in aux_multi_level_features)
+            fm_pos = self.apply_position_embedding and self.pos_embedding_strategy in ("feature_map_based", "hybrid")
             for f in aux_multi_level_features:
+                if fm_pos:
+                    # reference :327-335 / :198-211: feature + pos_embed.to(feature.dtype), a bf16 add on every aux level BEFORE the
+                    # fp32 upsample / roi_align (so it is not linear in the pooled result: the sum is rounded to bf16 first)
+                    from . import ops as _ops
+                    f = _token_major_bf16(f)
+                    _, C, H, W = f.shape
+                    rows = f.permute(0, 2, 3, 1)
+                    if not rows.is_contiguous():
+                        rows = rows.contiguous()
+                    if batch > 1 and rows.untyped_storage().nbytes() < (rows.storage_offset() + batch * H * W * C) * 2:
+                        raise _lib.Fo1Error("feature-map position embedding: the stacked maps of a batched call must be contiguous")
+                    rows = rows.as_strided((batch * H * W, C), (C, 1)) if batch > 1 else rows.reshape(H * W, C)
+                    summed = _ops.add(rows, self._feature_map_pos(H, W, C, batch, rows.device))
+                    keep.append(summed)
+                    f = summed[:H * W].view(1, H, W, C).permute(0, 3, 1, 2)        # image-0 view; storage continues image by image
                 srcs.append(self._src(f, (H0, W0), self.aux_vision_tower_spatial_scale, 0, off, keep))
                 strides.append(f.shape[2] * f.shape[3] * srcs[-1].ld)
                 off += f.shape[1]

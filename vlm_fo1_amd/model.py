@@ -36,6 +36,7 @@ class FO1Config:
     mm_region_hidden_size: int = 5888           # 3840 (aux pyramid) + 4 x 512 (FPN); 8960 without FPN
     mm_roi_output_size: int = 7
     mm_apply_position_embedding: bool = True
+    mm_pos_embedding_strategy: str = "bbox_based"      # 'bbox_based' | 'feature_map_based' | 'hybrid' (omchat_arch.py:21)
     mm_apply_region_layer_norm: bool = False      # HFRE :365-372: nn.LayerNorm on the aux and the vt block before the box embedding
     mm_region_feature_combination: str = "concat"  # 'concat' | 'concat_aux_pos'
     mm_use_vt_region_feature_only: bool = False
@@ -85,7 +86,7 @@ class FO1Engine:
         self.mm_projector = Projector(cfg.mm_projector_type, weights["proj"], "mm_projector.", device)
         self.mm_projector_aux = Projector(cfg.mm_projector_aux_type, weights["proj"], "mm_projector_aux.", device)
         self.hfre = HFREModule(roi_output_size=cfg.mm_roi_output_size, region_feature_dim=cfg.mm_region_hidden_size,
-                               apply_position_embedding=cfg.mm_apply_position_embedding, pos_embedding_strategy="bbox_based",
+                               apply_position_embedding=cfg.mm_apply_position_embedding, pos_embedding_strategy=cfg.mm_pos_embedding_strategy,
                                use_vision_tower_region_feature=True, region_feature_combination=cfg.mm_region_feature_combination,
                                use_vt_region_feature_only=cfg.mm_use_vt_region_feature_only,
                                apply_region_layer_norm=cfg.mm_apply_region_layer_norm,
