@@ -4,10 +4,13 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one image through every hot-path stage the engine implements (listed in
-config.stages), inputs already resident in HBM.  N>1: images shard across ranks with no
-data-path collective (weak scaling); value = images all ranks processed / max-over-ranks
-time.  Prints ONE JSON line on rank 0.
+One "step" = ONE packed pass of `--batch` (default 25) different images through every hot-path stage the engine implements
+(listed in config.stages: both towers, FPN, HFRE, connectors, splice, 36-layer LLM prefill, first greedy token), inputs already
+resident in HBM; `--inflight` (default 2) passes are in flight on their own HIP streams.  value = images / second.  N>1: images
+shard across ranks with no data-path collective (weak scaling); value = images all ranks processed / max-over-ranks time.
+Prints ONE JSON line on rank 0 with `roofline` (dominant kernel, live dispatch timestamps), `cpu_baseline` (the oracle at full depth
+on this box's host cores, N = 1 only) and side measurements (one pass / one image at a time, decode loops, preprocessing;
+`--main-only` skips them).  `--fp8` is a secondary, opt-in measurement (e4m3 linears); the default line is bf16.
 """
 import argparse
 import json
