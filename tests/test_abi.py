@@ -57,3 +57,24 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(L.Fo1Error):
         L.load()
+
+
+def test_plain_c_host_builds_against_the_header_and_drives_the_library(tmp_path):
+    """include/fo1.h is valid C99 (a non-Python integrator's compiler sees it), and a C program with no Python / torch in the process
+    loads the library, sizes a workspace and gets an argument error back as (rc < 0, fo1_last_error() text) — tests/host_emul/abi_host.c."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    hdr = tmp_path / "hdr.c"
+    hdr.write_text('#include "fo1.h"\nint main(void) { return 0; }\n')
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(hdr)], check=True)
+    exe = tmp_path / "abi_host"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-I", inc, os.path.join(root, "tests", "host_emul", "abi_host.c"), "-o", str(exe), "-ldl"], check=True)
+    so = os.path.join(root, "vlm_fo1_amd", "libfo1hip.so")
+    r = subprocess.run([str(exe), so], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rc=-1" in r.stdout and "NULL boxes" in r.stdout
