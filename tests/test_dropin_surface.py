@@ -247,3 +247,25 @@ def test_chunk_tokenisation_cache_is_transparent():
     assert ref == first
     first.append(-1)
     assert mm_utils.tokenizer_image_region_token(prompt, tok)[-1] != -1
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="/root/reference not present")
+@pytest.mark.parametrize("script", ["inference.py", "scripts/inference_with_upn.py", "scripts/run_upn.py", "evaluation/eval_coco.py",
+                                    "evaluation/eval_countbench.py"])
+def test_every_name_the_reference_drivers_import_exists_in_the_drop_in(script):
+    """The reference's driver scripts run unmodified against this repo's `vlm_fo1` / `detect_tools` packages: every
+    `from vlm_fo1... import name` / `from detect_tools... import name` they contain resolves here (callables stay callables)."""
+    import ast
+    import importlib
+    src = open(os.path.join("/root/reference", script)).read()
+    checked = 0
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.ImportFrom) and node.module and node.module.split(".")[0] in ("vlm_fo1", "detect_tools"):
+            mod = importlib.import_module(node.module)
+            assert os.path.abspath(mod.__file__).startswith(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), mod.__file__
+            for a in node.names:
+                if a.name == "*":
+                    continue
+                assert hasattr(mod, a.name), f"{script}: {node.module}.{a.name} is missing from the drop-in"
+                checked += 1
+    assert checked > 0
