@@ -183,12 +183,28 @@ def box_pos_embed(boxes: torch.Tensor, img_w: float, img_h: float, d: int) -> to
 # HFRE — literal restatement of HFREModule.__call__ for the supported variants
 #   concat (+/- SimpleFPN on the vt branch), bbox_based position embedding.
 # --------------------------------------------------------------------------
+def feature_map_pos_embed(H: int, W: int, C: int) -> torch.Tensor:
+    """generate_2d_position_embedding (reference :11-52): [H, W, C] fp32 — y half then x half, each sin / cos interleaved over
+    C // 4 frequencies, coordinates normalised to [0, 1)."""
+    y = torch.arange(H, dtype=torch.float32) / H
+    x = torch.arange(W, dtype=torch.float32) / W
+    yg, xg = torch.meshgrid(y, x, indexing="ij")
+    q = C // 4
+    dim_t = torch.arange(q, dtype=torch.float32)
+    dim_t = 10000 ** (2 * (dim_t // 2) / q) if q > 0 else torch.tensor([1.0])
+    px = xg.unsqueeze(-1) * (2 * math.pi) / dim_t
+    py = yg.unsqueeze(-1) * (2 * math.pi) / dim_t
+    px = torch.stack((px.sin(), px.cos()), dim=-1).flatten(-2)
+    py = torch.stack((py.sin(), py.cos()), dim=-1).flatten(-2)
+    return torch.cat([py, px], dim=-1)
+
+
 def hfre_oracle(aux_maps: Sequence[torch.Tensor], aux_boxes: torch.Tensor,
                 vt_maps: Optional[Sequence[torch.Tensor]], vt_boxes: Optional[torch.Tensor],
                 *, region_dim: int, grid_hw, vt_strides: Optional[Sequence[float]] = None,
                 vt_spatial_scale: float = 1 / 14, aux_spatial_scale: float = 0.25,
                 roi_size: int = 7, apply_pos: bool = True, roi_align=None, region_ln: Optional[dict] = None,
-                pos_from: str = "vt", vt_only: bool = False) -> torch.Tensor:
+                pos_from: str = "vt", vt_only: bool = False, aux_only: bool = False, strategy: str = "bbox_based") -> torch.Tensor:
     """Supported product configuration (reference :319-363, :368-383, :436-467 with
     use_vision_tower_region_feature=True, combination='concat', strategy 'bbox_based').
 
@@ -204,15 +220,30 @@ def hfre_oracle(aux_maps: Sequence[torch.Tensor], aux_boxes: torch.Tensor,
     # nn.LayerNorm(eps 1e-5) to the aux and the vt block before fusion (:365-372); pos_from='aux' is 'concat_aux_pos' (box
     # embedding from the aux boxes, normalised by the aux map size / aux scale, :443-455); vt_only is use_vt_region_feature_only
     # (:293-317: vt block + vt box embedding, no aux tower).
+    # aux_only is use_vision_tower_region_feature=False — NOT a restatement: the reference raises UnboundLocalError there (`out_box_feat`
+    # is never bound, :456/:469; tests/golden/hfre_variants.npz `aux_only_error`).  It states the engine's labelled extension: the
+    # reference's aux block (:319-366, pinned through the `nopos` golden) + the box embedding of the else-branch at :449-455 (aux
+    # boxes / aux map size / aux scale) with region_dim = 3840.
     ra = roi_align or roi_align_c
     aux_boxes = aux_boxes.float()
+    if aux_only:
+        assert not vt_only
+        vt_maps, vt_boxes, pos_from = None, aux_boxes, "aux"
     vt_boxes = vt_boxes.float()
     H0 = max(f.shape[2] for f in aux_maps)
     W0 = max(f.shape[3] for f in aux_maps)
     aux = None
+    # strategy 'feature_map_based' / 'hybrid' (:327-335, :206-227): `feature + pos_embed.to(feature.dtype)` on every aux level in the
+    # maps' own dtype (bf16 on the product path) BEFORE the fp32 upsample; 'feature_map_based' then skips the box embedding (:438-440).
+    # The vt-only branch ignores the strategy (:293-317).
+    fm = strategy in ("feature_map_based", "hybrid") and apply_pos and not vt_only
+    box_pos = apply_pos and (vt_only or strategy in ("bbox_based", "hybrid"))
     if not vt_only:
         cat = []
         for lvl, f in enumerate(aux_maps):
+            if fm:
+                _, C, H, W = f.shape
+                f = f + feature_map_pos_embed(H, W, C).permute(2, 0, 1).unsqueeze(0).to(f.dtype)
             f = f.float()
             if lvl != 0:
                 f = F.interpolate(f, size=(H0, W0), mode="bilinear", align_corners=False)
@@ -222,7 +253,9 @@ def hfre_oracle(aux_maps: Sequence[torch.Tensor], aux_boxes: torch.Tensor,
         aux = aux.mean(dim=(2, 3)).reshape(1, aux.shape[0], aux.shape[1])
         if region_ln is not None:
             aux = F.layer_norm(aux, (aux.shape[-1],), region_ln["aux_w"].float(), region_ln["aux_b"].float(), 1e-5)
-    if vt_strides is not None:
+    if aux_only:
+        vt = None
+    elif vt_strides is not None:
         per = []
         for f, s in zip(vt_maps, vt_strides):
             r = ra(f.float(), [vt_boxes], output_size=roi_size, spatial_scale=1.0 / s)
@@ -232,11 +265,11 @@ def hfre_oracle(aux_maps: Sequence[torch.Tensor], aux_boxes: torch.Tensor,
         vcat = torch.cat(list(vt_maps), dim=1).float()
         r = ra(vcat, [vt_boxes], output_size=roi_size, spatial_scale=vt_spatial_scale)
         vt = r.mean(dim=(2, 3)).reshape(1, r.shape[0], r.shape[1])
-    if region_ln is not None and not vt_only:
+    if region_ln is not None and not vt_only and not aux_only:
         vt = F.layer_norm(vt, (vt.shape[-1],), region_ln["vt_w"].float(), region_ln["vt_b"].float(), 1e-5)
-    out = vt if vt_only else torch.cat([aux, vt], dim=-1)
+    out = vt if vt_only else (aux if aux_only else torch.cat([aux, vt], dim=-1))
     assert out.shape[-1] == region_dim, (out.shape, region_dim)
-    if apply_pos:
+    if box_pos:
         gh, gw = grid_hw
         if pos_from == "aux" and not vt_only:
             out = out + box_pos_embed(aux_boxes, W0 / aux_spatial_scale, H0 / aux_spatial_scale, region_dim // 4)

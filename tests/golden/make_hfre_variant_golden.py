@@ -6,6 +6,11 @@ supports beyond the default one:
   vt_only     use_vt_region_feature_only=True   (:293-317; region_feature_dim = 2048)
   fm_pos      pos_embedding_strategy='feature_map_based'    (2-D sine table added to every aux level, no box embedding; :327-335)
   hybrid      pos_embedding_strategy='hybrid'               (both)
+  vt_only_ln      vt-only + apply_region_layer_norm=True    (the vt-only branch returns BEFORE any LayerNorm, :293-317: == vt_only)
+  vt_only_fm_pos  vt-only + 'feature_map_based'             (the vt-only branch tests apply_position_embedding alone: == vt_only)
+  nopos       apply_position_embedding=False                (the pure [aux | vt] pooled blocks; the aux block pins the aux-only extension)
+  aux_only_error  use_vision_tower_region_feature=False     (the reference's default value): the exception the reference raises —
+                  `out_box_feat` is never bound on that path, UnboundLocalError for every input
 
     python tests/golden/make_hfre_variant_golden.py
 """
@@ -46,13 +51,27 @@ def run(case, variant):
         kw["pos_embedding_strategy"] = "feature_map_based"
     elif variant == "hybrid":
         kw["pos_embedding_strategy"] = "hybrid"
+    elif variant in ("vt_only_ln", "vt_only_fm_pos"):
+        kw["use_vt_region_feature_only"] = True
+        kw["region_feature_dim"] = 2048
+        if variant == "vt_only_ln":
+            kw["apply_region_layer_norm"] = True
+        else:
+            kw["pos_embedding_strategy"] = "feature_map_based"
+    elif variant == "nopos":
+        kw["apply_position_embedding"] = False
+    elif variant == "aux_only":
+        kw["use_vision_tower_region_feature"] = False
+        kw["region_feature_dim"] = 3840
     torch.manual_seed(0)
     m = HFREModule(**kw)
-    if variant == "ln":
+    if variant in ("ln", "vt_only_ln"):
         p = ln_params()
-        with torch.no_grad():
-            m.aux_region_norm.weight.copy_(p["aux_w"]); m.aux_region_norm.bias.copy_(p["aux_b"])
-            m.vt_region_norm.weight.copy_(p["vt_w"]); m.vt_region_norm.bias.copy_(p["vt_b"])
+        with torch.no_grad():           # the reference builds only the norms its configuration can reach
+            if hasattr(m, "aux_region_norm"):
+                m.aux_region_norm.weight.copy_(p["aux_w"]); m.aux_region_norm.bias.copy_(p["aux_b"])
+            if hasattr(m, "vt_region_norm"):
+                m.vt_region_norm.weight.copy_(p["vt_w"]); m.vt_region_norm.bias.copy_(p["vt_b"])
 
     class _Fixed(torch.nn.Module):
         def forward(self, x):
@@ -69,10 +88,16 @@ def run(case, variant):
 def main():
     case = make_case("demo_fpn")
     blobs = dict(checksum=checksum(case))
-    for v in ("ln", "aux_pos", "vt_only", "fm_pos", "hybrid"):
+    for v in ("ln", "aux_pos", "vt_only", "fm_pos", "hybrid", "vt_only_ln", "vt_only_fm_pos", "nopos"):
         out = run(case, v)
         blobs[v] = out.numpy()
         print(v, tuple(out.shape))
+    try:
+        run(case, "aux_only")
+        blobs["aux_only_error"] = np.array("none")
+    except Exception as e:            # noqa: BLE001 — the exception type IS the datum
+        blobs["aux_only_error"] = np.array(type(e).__name__)
+    print("aux_only ->", blobs["aux_only_error"])
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "hfre_variants.npz"), **blobs)
 
 

@@ -252,6 +252,40 @@ def test_hfre_variants_vs_reference_golden_and_oracle():
     assert not torch.equal(torch.from_numpy(g["fm_pos"]), torch.from_numpy(g["hybrid"]))
 
 
+def test_hfre_vt_only_with_ln_or_fm_strategy_and_aux_only():
+    """ADVICE r2 + the aux-only route.  vt-only: the reference's branch (:293-317) ignores region LayerNorm and the embedding
+    strategy — engine == the reference's own outputs for those configurations (== plain vt-only).  aux-only
+    (use_vision_tower_region_feature=False): the reference raises UnboundLocalError (golden `aux_only_error`); the engine's extension
+    against the oracle's statement of it (pinned piecewise in tests/test_oracle_hfre.py), with and without region LayerNorm."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_hfre_variant_golden import ln_params
+    case = make_case("demo_fpn")
+    g = np.load(os.path.join(HERE, "golden", "hfre_variants.npz"))
+    d = to_dev(case)
+    d2 = dict(d)
+    d2["region_dim"] = 2048
+    got = engine_out(d2, use_vt_region_feature_only=True, apply_region_layer_norm=True, ln=ln_params()).cpu()
+    torch.testing.assert_close(got, torch.from_numpy(g["vt_only_ln"]), rtol=RTOL, atol=ATOL)
+    got = engine_out(d2, use_vt_region_feature_only=True, pos_embedding_strategy="feature_map_based").cpu()
+    torch.testing.assert_close(got, torch.from_numpy(g["vt_only_fm_pos"]), rtol=RTOL, atol=ATOL)
+    assert str(g["aux_only_error"]) == "UnboundLocalError"
+    from vlm_fo1_amd.hfre import HFREModule
+    for ln in (None, ln_params()):
+        m = HFREModule(roi_output_size=7, region_feature_dim=3840, apply_position_embedding=True, use_vision_tower_region_feature=False,
+                       apply_region_layer_norm=ln is not None)
+        if ln is not None:
+            m.set_region_norm(ln["aux_w"].cuda(), ln["aux_b"].cuda(), None, None)
+        got = m(d["aux_maps"], [d["boxes"]]).squeeze(0).cpu()
+        ref = O.hfre_oracle(case["aux_maps"], case["boxes"], None, None, region_dim=3840, aux_only=True, region_ln=ln, grid_hw=case["grid_hw"])[0]
+        assert got.shape == (case["boxes"].shape[0], 3840)
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-4 if ln is not None else ATOL)
+    # no embedding: exactly the aux block of the reference's no-embedding output
+    m = HFREModule(roi_output_size=7, region_feature_dim=3840, apply_position_embedding=False, use_vision_tower_region_feature=False)
+    got = m(d["aux_maps"], [d["boxes"]]).squeeze(0).cpu()
+    torch.testing.assert_close(got, torch.from_numpy(g["nopos"])[:, :3840], rtol=RTOL, atol=ATOL)
+
+
 def test_hfre_batched_call_equals_per_image():
     """batch > 1: the maps of B same-size images stacked, all boxes in one launch with box_image — every box's row is bit-identical
     to the one-image call (same slices, same order)."""

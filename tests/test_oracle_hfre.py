@@ -185,3 +185,49 @@ def test_oracle_variants_vs_reference_golden():
     torch.testing.assert_close(out, torch.from_numpy(g["aux_pos"]), rtol=1e-5, atol=1e-5)
     out = O.hfre_oracle(case["aux_maps"], case["boxes"], case["fpn_maps"], case["vt_boxes"], region_dim=2048, vt_only=True, **kw)[0]
     torch.testing.assert_close(out, torch.from_numpy(g["vt_only"]), rtol=1e-5, atol=1e-5)
+    for name, strategy in (("fm_pos", "feature_map_based"), ("hybrid", "hybrid")):      # 2-D table on the aux levels (:327-335)
+        out = O.hfre_oracle(case["aux_maps"], case["boxes"], case["fpn_maps"], case["vt_boxes"], region_dim=5888, strategy=strategy, **kw)[0]
+        torch.testing.assert_close(out, torch.from_numpy(g[name]), rtol=1e-5, atol=1e-5)
+
+
+def test_vt_only_ignores_layernorm_and_strategy_like_the_reference():
+    """the reference's vt-only branch (:293-317) returns before any region LayerNorm and adds the vt box embedding whenever
+    apply_position_embedding is set, whatever the strategy: its outputs with LN on / with 'feature_map_based' equal plain vt-only."""
+    import numpy as np
+    g = np.load(os.path.join(HERE, "golden", "hfre_variants.npz"))
+    assert np.array_equal(g["vt_only_ln"], g["vt_only"]) and np.array_equal(g["vt_only_fm_pos"], g["vt_only"])
+    case = make_case("demo_fpn")
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_hfre_variant_golden import ln_params
+    out = O.hfre_oracle(case["aux_maps"], case["boxes"], case["fpn_maps"], case["vt_boxes"], region_dim=2048, vt_only=True,
+                        region_ln=ln_params(), grid_hw=case["grid_hw"], vt_strides=[3.5, 7, 14, 28])[0]
+    torch.testing.assert_close(out, torch.from_numpy(g["vt_only_ln"]), rtol=1e-5, atol=1e-5)
+
+
+def test_aux_only_reference_raises_and_extension_is_pinned_piecewise():
+    """mm_use_vision_tower_region_feature=False (the reference's default VALUE): the reference's HFRE never binds `out_box_feat` and
+    raises UnboundLocalError — recorded by the golden generator and, when /root/reference is present, re-run here.  The engine's
+    aux-only extension = the reference's aux block (equal to the first 3840 channels of the reference's no-embedding output) + the
+    reference's own sine embedding of the aux boxes (gen_sineembed_for_position, :55-103)."""
+    import numpy as np
+    g = np.load(os.path.join(HERE, "golden", "hfre_variants.npz"))
+    assert str(g["aux_only_error"]) == "UnboundLocalError"
+    case = make_case("demo_fpn")
+    out = O.hfre_oracle(case["aux_maps"], case["boxes"], None, None, region_dim=3840, aux_only=True, grid_hw=case["grid_hw"])[0]
+    nopos = O.hfre_oracle(case["aux_maps"], case["boxes"], None, None, region_dim=3840, aux_only=True, apply_pos=False, grid_hw=case["grid_hw"])[0]
+    torch.testing.assert_close(nopos, torch.from_numpy(g["nopos"])[:, :3840], rtol=1e-5, atol=1e-5)
+    H0, W0 = case["aux_maps"][0].shape[-2:]
+    emb = O.box_pos_embed(case["boxes"].float(), W0 / 0.25, H0 / 0.25, 3840 // 4)
+    torch.testing.assert_close(out, nopos + emb[0], rtol=0, atol=0)
+    if O.reference_available():
+        HFREModule, _, sine = O.load_reference_hfre()
+        m = HFREModule(roi_output_size=7, region_feature_dim=3840, apply_position_embedding=True, use_vision_tower_region_feature=False,
+                       aux_vision_tower_spatial_scale=0.25, aux_vision_tower_region_feature_dims=[256, 512, 1024, 2048])
+        with pytest.raises(UnboundLocalError):
+            m(case["aux_maps"], [case["boxes"].clone()])
+        # the embedding half against the reference's own function
+        b = case["boxes"].float().clone()
+        b[:, [0, 2]] /= W0 / 0.25
+        b[:, [1, 3]] /= H0 / 0.25
+        b[:, 2] -= b[:, 0]; b[:, 3] -= b[:, 1]; b[:, 0] += b[:, 2] / 2; b[:, 1] += b[:, 3] / 2
+        torch.testing.assert_close((out - nopos), sine(b.unsqueeze(0), 3840 // 4)[0], rtol=1e-5, atol=1e-6)

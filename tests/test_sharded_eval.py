@@ -96,3 +96,42 @@ def test_worker_threads_give_the_single_worker_result():
     # no GPU / no replica(): request_workers degrades to one worker
     w = SE.request_workers(object(), lambda m, s: fake_generate, n=3)
     assert len(w) == 1
+
+
+def oom_generate(i):
+    if i == 4:
+        raise MemoryError("HIP out of memory (simulated)")
+    return [i]
+
+
+def _worker_fatal(rank, world, port, n, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    SE.init_distributed("gloo")
+    try:
+        SE.run_sharded(n, [1.0] * n, oom_generate, device="cpu")
+        q.put((rank, "no error"))
+    except SE.RemoteRankFailed:
+        q.put((rank, "remote"))
+    except MemoryError:
+        q.put((rank, "own"))
+    torch.distributed.destroy_process_group()
+
+
+def test_fatal_error_on_one_rank_stops_every_rank():
+    """an out-of-memory error on one rank used to be re-raised there only, leaving the other rank blocked in the gather.
+    Now the flag rides on the size exchange: the failing rank raises its own exception, the other RemoteRankFailed, both exit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_fatal, args=(r, 2, port, 9, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    owner = [r for r in range(2) if 4 in SE.assign([1.0] * 9, 2)[r]][0]
+    assert got[owner] == "own" and got[1 - owner] == "remote"
+    # single process: the fatal error surfaces as itself
+    with pytest.raises(MemoryError):
+        SE.run_sharded(9, [1.0] * 9, oom_generate, device="cpu")

@@ -50,8 +50,16 @@ class FO1HFConfig:
                         temporal_patch_size=vis.get("temporal_patch_size", 2), in_channels=vis.get("in_channels", vis.get("in_chans", 3)),
                         window_size=vis.get("window_size", 112), fullatt_block_indexes=tuple(vis.get("fullatt_block_indexes", (7, 15, 23, 31))))
         unsupported = []
-        if not d.get("mm_use_vision_tower_region_feature", False):
-            unsupported.append("mm_use_vision_tower_region_feature=False")
+        use_vt = bool(d.get("mm_use_vision_tower_region_feature", False))       # reference default: omchat_arch.py:23
+        if not use_vt:
+            # The reference itself cannot run this value: HFREModule.__call__ never binds `out_box_feat` without the vt branch and
+            # raises UnboundLocalError (hybrid_finegrained_region_encoder.py:456/469; pinned by tests/test_oracle_hfre.py).  The
+            # engine's aux-only route is the evident reading (aux block + aux-box embedding) — loadable, labelled as an extension.
+            import warnings
+            warnings.warn("mm_use_vision_tower_region_feature=False: the reference's HFRE raises UnboundLocalError for this configuration; "
+                          "the engine runs its aux-only extension (aux region block + box embedding from the aux boxes)", stacklevel=2)
+            if d.get("mm_use_vt_region_feature_only", False):
+                unsupported.append("mm_use_vt_region_feature_only without mm_use_vision_tower_region_feature")
         if d.get("mm_region_feature_combination", "concat") not in ("concat", "concat_aux_pos"):
             unsupported.append(f"mm_region_feature_combination={d.get('mm_region_feature_combination')!r}")
         if d.get("mm_pos_embedding_strategy", "bbox_based") not in ("bbox_based", "feature_map_based", "hybrid"):
@@ -69,7 +77,8 @@ class FO1HFConfig:
                          mm_pos_embedding_strategy=d.get("mm_pos_embedding_strategy", "bbox_based"),
                          mm_apply_region_layer_norm=bool(d.get("mm_apply_region_layer_norm", False)),
                          mm_region_feature_combination=d.get("mm_region_feature_combination", "concat"),
-                         mm_use_vt_region_feature_only=bool(d.get("mm_use_vt_region_feature_only", False)))
+                         mm_use_vt_region_feature_only=bool(d.get("mm_use_vt_region_feature_only", False)),
+                         mm_use_vision_tower_region_feature=use_vt)
 
     def eos_ids(self) -> List[int]:
         e = self._gen.get("eos_token_id", self._d.get("eos_token_id"))
@@ -169,7 +178,14 @@ class FO1ForCausalLM:
             if kws is None or any(int(k.numel()) != 1 for k in kws):
                 return None
             ids += [int(k.reshape(-1)[0]) for k in kws]
-        return sorted(set(ids))
+        ids = sorted(set(ids))
+        from vlm_fo1_amd.llm import BatchDecoder
+        return ids if len(ids) <= BatchDecoder.MAX_STOP else None     # more ids than the device rule holds: host loop, nothing dropped
+
+    @staticmethod
+    def _fits_device_loop(max_new_tokens) -> bool:
+        from vlm_fo1_amd.llm import BatchDecoder
+        return int(max_new_tokens) <= BatchDecoder.IDS_CAP
 
     @torch.no_grad()
     def generate_many(self, requests_kwargs: List[dict]) -> List[torch.LongTensor]:
@@ -183,8 +199,13 @@ class FO1ForCausalLM:
         if k0.get("do_sample") or (k0.get("temperature") not in (0, 0.0, None)):
             raise NotImplementedError("sampling is not built; every reference caller decodes greedily (temperature=0)")
         stop = self._device_stop_ids(k0.get("stopping_criteria"))
-        if stop is None:
+        if stop is None or not self._fits_device_loop(k0.get("max_new_tokens", 512)):
             return [self.generate(**kw) for kw in requests_kwargs]
+        for kw in requests_kwargs[1:]:       # one budget and one stop rule per packed batch: refuse a mixed batch rather than apply the first's
+            if int(kw.get("max_new_tokens", 512)) != int(k0.get("max_new_tokens", 512)) or \
+                    self._device_stop_ids(kw.get("stopping_criteria")) != stop or kw.get("do_sample") or \
+                    (kw.get("temperature") not in (0, 0.0, None)):
+                raise ValueError("generate_many: every request of a batch must share max_new_tokens, stopping criteria and greedy decoding")
         reqs = [self._request(kw.get("inputs"), kw.get("images"), kw.get("images_aux"), kw.get("image_grid_thws"), kw.get("bbox_list"))
                 for kw in requests_kwargs]
         new = self.engine.generate_batch(reqs, max_new_tokens=int(k0.get("max_new_tokens", 512)), stop_ids=stop, use_graph=self.use_graph)
@@ -206,7 +227,7 @@ class FO1ForCausalLM:
         req = self._request(inputs, images, images_aux, image_grid_thws, bbox_list)
         dev = self.device
         stop = self._device_stop_ids(stopping_criteria) if streamer is None else None
-        if stop is not None:
+        if stop is not None and self._fits_device_loop(max_new_tokens):
             ids = self.engine.generate_batch([req], max_new_tokens=int(max_new_tokens), stop_ids=stop, use_graph=self.use_graph)[0]
             return torch.cat([inputs.to(dev), torch.tensor([ids], dtype=inputs.dtype, device=dev)], dim=1).to(inputs.device)
         eng = self.engine

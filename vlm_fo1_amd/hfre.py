@@ -56,7 +56,7 @@ class HFREModule:
                  vision_tower_spatial_scale: float = 1 / 14, use_simpleFPN_for_vt: bool = False,
                  aux_vision_tower_region_feature_dims: Sequence[int] = (256, 512, 1024, 2048),
                  aux_vision_tower_spatial_scale: float = 0.25, simple_fpn=None):
-        # Built: aux + vt ('concat' / 'concat_aux_pos'), vt only (use_vt_region_feature_only), aux only, with or without SimpleFPN,
+        # Built: aux + vt ('concat' / 'concat_aux_pos'), vt only (use_vt_region_feature_only), aux only (see below), with or without SimpleFPN,
         # 'bbox_based' / 'feature_map_based' / 'hybrid' position embedding (reference :327-335, :436-467), region LayerNorm (:365-372).
         # Not built (the engine refuses loudly): the 'mean*' / '*_sep_pos' fusions and per-region MLPs — with DaViT-L's 3840 aux
         # channels the reference itself cannot run them (mean adds a [N,3840] to a [N,2048|5120] tensor, *_sep_pos adds a 2880-wide
@@ -72,6 +72,11 @@ class HFREModule:
             unsupported.append("use_vt_region_feature_only without use_vision_tower_region_feature")
         if unsupported:
             raise NotImplementedError("HFRE variant not built for the MI355X engine: " + ", ".join(unsupported))
+        # use_vision_tower_region_feature=False (the reference's DEFAULT, omchat_arch.py:23): the reference's own __call__ never binds
+        # `out_box_feat` on that path (:368 is the only place the hybrid branch assigns it) and raises UnboundLocalError at :456 / :469
+        # for every input — tests/test_oracle_hfre.py runs the reference in place to pin that.  Here the aux-only route computes what
+        # the surrounding code evidently means: out = the aux block (:319-366), plus the box embedding from the AUX boxes normalised by
+        # the aux map size / aux scale (the else-branch at :449-455), region LayerNorm = aux_region_norm only.  A labelled extension.
         self.use_vt_region_feature_only = use_vt_region_feature_only
         self.use_vision_tower_region_feature = use_vision_tower_region_feature
         self.region_feature_combination = region_feature_combination
@@ -156,10 +161,14 @@ class HFREModule:
             out = out.unsqueeze(0)
         sx, sy = (vt_scale if vt_scale is not None else (1.0, 1.0))
         pos_mode = 0
-        if self.apply_position_embedding and self.pos_embedding_strategy in ("bbox_based", "hybrid"):     # reference :438-440
+        if self.use_vt_region_feature_only:
+            # reference :293-317 — the vt-only branch tests `apply_position_embedding` ALONE (whatever the strategy says, the vt box
+            # embedding is added) and returns before any region LayerNorm
+            pos_mode = 1 if self.apply_position_embedding else 0
+        elif self.apply_position_embedding and self.pos_embedding_strategy in ("bbox_based", "hybrid"):     # reference :438-440
             pos_mode = 2 if (self.region_feature_combination == "concat_aux_pos" or not self.use_vision_tower_region_feature) else 1
         from . import ops as _ops
-        use_ln = self.apply_region_layer_norm
+        use_ln = self.apply_region_layer_norm and not self.use_vt_region_feature_only
         if use_ln and self._ln is None:
             raise _lib.Fo1Error("apply_region_layer_norm: call set_region_norm() with the checkpoint's LayerNorm parameters first")
         if self.worklist or use_ln or batch > 1:

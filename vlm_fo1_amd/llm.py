@@ -127,7 +127,7 @@ class QwenLLM:
         self.dplan = torch.zeros(1, 2, dtype=torch.int32, device=self.dev)     # gather plan of the one new token: (0, token id)
         self._dgraph = None
         self._dstate_keep = None
-        self._ws_owner = object()   # scratch-buffer key (ops.workspace_scope); FO1Engine overrides it with its own token
+        self._ws_owner = ops.new_owner(self)   # scratch-buffer key (ops.workspace_scope); FO1Engine overrides it with its own token
 
     def reserve(self, n_positions: int) -> bool:
         """Make room for n_positions cache rows (prompt + the tokens a request may generate; a packed batch needs the sum).
@@ -147,14 +147,24 @@ class QwenLLM:
         v[:, :, :self.capacity] = self.vtcache
         self.kcache, self.vtcache, self.capacity = k, v, cap
         if self.rope_cos.shape[0] < cap:
-            p = torch.arange(cap).view(1, -1).expand(3, -1)
-            cos_t, sin_t = mrope_tables(p, c.head_dim, c.rope_theta, c.mrope_section)
-            self.rope_cos, self.rope_sin = cos_t.to(self.dev), sin_t.to(self.dev)
+            self.grow_rope(cap)
         self._dgraph = None
         self._item_cache = {}
         self.cache_epoch += 1
         torch.cuda.current_stream().synchronize()
         return True
+
+    def grow_rope(self, rows: int) -> None:
+        """Text-position rope table (t = h = w) with at least `rows` rows.  Re-allocating it invalidates every captured graph that read
+        the old table: the single-sequence decode graph is dropped here, callers drop their own (BatchDecoder._ensure)."""
+        c = self.cfg
+        if self.rope_cos.shape[0] >= rows:
+            return
+        p = torch.arange(rows).view(1, -1).expand(3, -1)
+        cos_t, sin_t = mrope_tables(p, c.head_dim, c.rope_theta, c.mrope_section)
+        self.rope_cos, self.rope_sin = cos_t.to(self.dev), sin_t.to(self.dev)
+        self._dgraph = None
+        self.rope_epoch = getattr(self, "rope_epoch", 0) + 1
 
     def replica(self) -> "QwenLLM":
         """Same weights and rope tables (shared, read-only), private per-request state: KV cache, decode state, decode graph.
@@ -171,7 +181,7 @@ class QwenLLM:
         r._dgraph = None
         r._dstate_keep = None
         r._item_cache = {}
-        r._ws_owner = object()
+        r._ws_owner = ops.new_owner(r)
         # the zero-fills above ran on the creating thread's current stream; the replica is used from another thread / stream
         torch.cuda.current_stream().synchronize()
         return r
@@ -439,6 +449,7 @@ class BatchDecoder:
     been appended, or at max_new_tokens (mm_utils.py:137-181, 640-654)."""
     MAX_BATCH = 16
     IDS_CAP = 4096          # generated ids kept per sequence (every reference caller uses max_new_tokens <= 4096)
+    MAX_STOP = 16           # stop ids the device-side rule compares against
 
     def __init__(self, llm: QwenLLM):
         self.llm = llm
@@ -451,7 +462,7 @@ class BatchDecoder:
             self.plan = torch.zeros(B, 2, dtype=torch.int32, device=dev)
             self.ids = torch.zeros(B, self.IDS_CAP, dtype=torch.int32, device=dev)
             self.done = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.stop = torch.zeros(16, dtype=torch.int32, device=dev)
+            self.stop = torch.zeros(self.MAX_STOP, dtype=torch.int32, device=dev)
             self.reloc = torch.zeros(B, 4, dtype=torch.int32, device=dev)
         self.n_stop = 0
         self.dk = self.dvt = None
@@ -460,9 +471,9 @@ class BatchDecoder:
         self.B = 0
         self._graphs: Dict[tuple, tuple] = {}
         self._keep: list = []
-        self._ws_owner = object()
+        self._ws_owner = ops.new_owner(self)
 
-    def _ensure(self, rows: int):
+    def _ensure(self, rows: int, slot: int):
         c = self.llm.cfg
         if rows > self.rows:
             bf = torch.bfloat16
@@ -471,10 +482,11 @@ class BatchDecoder:
                 self.dvt = torch.zeros(c.num_layers, c.num_kv_heads * c.head_dim, rows, dtype=bf, device=self.llm.dev)
             self.rows = rows
             self._graphs = {}
-        if self.llm.rope_cos.shape[0] < rows:
-            p = torch.arange(rows).view(1, -1).expand(3, -1)
-            cos_t, sin_t = mrope_tables(p, c.head_dim, c.rope_theta, c.mrope_section)
-            self.llm.rope_cos, self.llm.rope_sin = cos_t.to(self.llm.dev), sin_t.to(self.llm.dev)
+        # The rope table is indexed by POSITION (state[1] = L + rope delta + steps < slot), never by cache row: it needs `slot` rows,
+        # not B * slot.  When it does grow, every graph that baked the old pointers in goes: this decoder's and the
+        # single-sequence decode graph of the llm (the streamer path would otherwise replay against freed memory).
+        if self.llm.rope_cos.shape[0] < slot:
+            self.llm.grow_rope(slot)
             self._graphs = {}
 
     def start(self, seqs, deltas, first_tokens: torch.Tensor, max_new_tokens: int, stop_ids: Sequence[int] = ()):
@@ -484,19 +496,25 @@ class BatchDecoder:
         B = len(seqs)
         if B > self.MAX_BATCH:
             raise ValueError(f"BatchDecoder handles at most {self.MAX_BATCH} sequences")
-        max_new = max(1, min(int(max_new_tokens), self.IDS_CAP))
+        # no silent truncation: the HF-like contract is "exactly these stop ids, exactly this budget"
+        stop_ids = sorted(set(int(t) for t in stop_ids))
+        if len(stop_ids) > self.MAX_STOP:
+            raise ValueError(f"BatchDecoder evaluates at most {self.MAX_STOP} stop ids on the device (got {len(stop_ids)}); use the host loop")
+        if int(max_new_tokens) > self.IDS_CAP:
+            raise ValueError(f"BatchDecoder keeps at most {self.IDS_CAP} generated ids per sequence (max_new_tokens={int(max_new_tokens)}); use the host loop")
+        max_new = max(1, int(max_new_tokens))
         need = max(L for _, L, *_ in seqs) + max_new + 1
         slot = 1024
         while slot < need:
             slot *= 2
-        self._ensure(B * slot if B * slot > self.rows else self.rows)
+        self._ensure(max(B * slot, self.rows), slot)
         self.B, self.slot = B, slot
         self.len0, self.steps = max(L for _, L, *_ in seqs), 0      # host-side bound on any sequence's keys: len0 + steps + 1
         reloc = torch.tensor([[o, b * slot, L, 0] for b, (o, L, *_) in enumerate(seqs)], dtype=torch.int32)
         state = torch.tensor([[b * slot + L, L + d, b * slot, 0, 0, max_new, 0, 0] for b, ((o, L, *_), d) in enumerate(zip(seqs, deltas))],
                              dtype=torch.int32)
-        stop = torch.tensor(list(stop_ids)[:16] + [0] * (16 - min(16, len(stop_ids))), dtype=torch.int32)
-        self.n_stop = min(16, len(stop_ids))
+        stop = torch.tensor(stop_ids + [0] * (self.MAX_STOP - len(stop_ids)), dtype=torch.int32)
+        self.n_stop = len(stop_ids)
         self.reloc[:B].copy_(reloc, non_blocking=True)
         self.state[:B].copy_(state, non_blocking=True)
         self.stop.copy_(stop, non_blocking=True)
@@ -572,7 +590,7 @@ class BatchDecoder:
         """Decode until every sequence has stopped (or max_new_tokens).  Returns the generated ids per sequence, the first
         token (from the prefill) included."""
         B = self.B
-        max_new = max(1, min(int(max_new_tokens), self.IDS_CAP))
+        max_new = max(1, min(int(max_new_tokens), self.IDS_CAP))      # start() has already refused a larger budget
         for i in range(max_new - 1):
             if i % poll == 0 and int(self.done.item()) >= B:     # the only host read in the loop, every `poll` steps
                 break

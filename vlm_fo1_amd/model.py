@@ -40,6 +40,9 @@ class FO1Config:
     mm_apply_region_layer_norm: bool = False      # HFRE :365-372: nn.LayerNorm on the aux and the vt block before the box embedding
     mm_region_feature_combination: str = "concat"  # 'concat' | 'concat_aux_pos'
     mm_use_vt_region_feature_only: bool = False
+    # False = region features from the aux tower only (the reference's default value, omchat_arch.py:23 — a configuration the
+    # reference itself cannot run: its HFRE raises UnboundLocalError, see vlm_fo1_amd/hfre.py; built here as a labelled extension)
+    mm_use_vision_tower_region_feature: bool = True
 
 
 class Projector:
@@ -81,13 +84,18 @@ class FO1Engine:
         self.dev = torch.device(device)
         self.vit = QwenViT(cfg.vit, weights["vit"], device)
         self.davit = DaViT(weights["davit"], device)
-        self.fpn = SimpleFPN(weights["fpn"], device) if cfg.mm_use_simpleFPN_for_vt else None
+        self.use_vt = bool(cfg.mm_use_vision_tower_region_feature)
+        if cfg.mm_use_vt_region_feature_only and not self.use_vt:
+            raise NotImplementedError("mm_use_vt_region_feature_only needs mm_use_vision_tower_region_feature")
+        self.fpn = SimpleFPN(weights["fpn"], device) if (cfg.mm_use_simpleFPN_for_vt and self.use_vt) else None
+        # which ViT hidden states the region branch reads: none (aux-only), the last full-attention map (FPN) or all four (:82-85)
+        self.capture = "none" if not self.use_vt else ("last" if self.fpn is not None else "all")
         self.llm = QwenLLM(cfg.llm, weights["llm"], device, lm_head=weights["llm"].get("lm_head.weight"))
         self.mm_projector = Projector(cfg.mm_projector_type, weights["proj"], "mm_projector.", device)
         self.mm_projector_aux = Projector(cfg.mm_projector_aux_type, weights["proj"], "mm_projector_aux.", device)
         self.hfre = HFREModule(roi_output_size=cfg.mm_roi_output_size, region_feature_dim=cfg.mm_region_hidden_size,
                                apply_position_embedding=cfg.mm_apply_position_embedding, pos_embedding_strategy=cfg.mm_pos_embedding_strategy,
-                               use_vision_tower_region_feature=True, region_feature_combination=cfg.mm_region_feature_combination,
+                               use_vision_tower_region_feature=self.use_vt, region_feature_combination=cfg.mm_region_feature_combination,
                                use_vt_region_feature_only=cfg.mm_use_vt_region_feature_only,
                                apply_region_layer_norm=cfg.mm_apply_region_layer_norm,
                                vision_tower_region_feature_dim=2048 if cfg.mm_use_simpleFPN_for_vt else 4 * cfg.vit.hidden_size,
@@ -103,7 +111,7 @@ class FO1Engine:
         self._seen = {}                            # signature -> sightings before capture
         # Two-stream tower overlap (DaViT || ViT+FPN) is OFF: measured on MI355X / ROCm 7.2 a forked hipGraph replays at
         # 39.7 ms vs 21.9 ms single-stream (cross-stream joins serialise the node launches), see profiles/README.md.
-        self._ws_owner = self.llm._ws_owner = object()   # scratch buffers are keyed by this token (ops.workspace_scope)
+        self._ws_owner = self.llm._ws_owner = ops.new_owner(self)   # scratch buffers are keyed by this token (ops.workspace_scope)
         self.stage_hook = None   # callable(stage_name) at stage boundaries; measurement only, never set while capturing a graph
 
     # ---- encoders ------------------------------------------------------------------------------
@@ -115,7 +123,7 @@ class FO1Engine:
         r = copy.copy(self)
         r.llm = self.llm.replica()
         r.hfre = copy.copy(self.hfre)
-        r._ws_owner = r.llm._ws_owner = object()   # scratch buffers are keyed by this token (ops.workspace_scope)
+        r._ws_owner = r.llm._ws_owner = ops.new_owner(r)   # scratch buffers are keyed by this token (ops.workspace_scope)
         import collections
         r._graphs = collections.OrderedDict()
         r._seen = {}
@@ -163,7 +171,7 @@ class FO1Engine:
 
     def encode_images(self, pixel_values: torch.Tensor, gh: int, gw: int):
         """-> (image tokens [S/4, d_llm], captured ViT maps (token-major raster))  (encode_images :44-72)."""
-        tokens, feats = self.vit.forward(pixel_values, gh, gw, capture="last" if self.fpn is not None else "all")
+        tokens, feats = self.vit.forward(pixel_values, gh, gw, capture=self.capture)
         self._mark("qwen_vit+merger")
         out = self.mm_projector(tokens)
         self._mark("mm_projector")
@@ -186,7 +194,9 @@ class FO1Engine:
             return t.view(1, hw[0], hw[1], t.shape[1]).permute(0, 3, 1, 2)
 
         aux_views = [nchw(t, s) for t, s in zip(aux_maps, aux_sizes)]
-        if self.fpn is not None:
+        if not self.use_vt:
+            vt_in = None                                # aux-only region features (reference :109-126)
+        elif self.fpn is not None:
             fpn_maps, fpn_sizes = self.fpn.forward(vt_feats[-1], gh, gw)
             self._mark("simple_fpn")
             fpn_views = [nchw(t, s) for t, s in zip(fpn_maps, fpn_sizes)]
@@ -239,7 +249,9 @@ class FO1Engine:
             if G > 1 and boxes_cat is not None and box_image is not None:
                 # one launch for every box of every image: views of image 0, the kernel steps image by image through the stacks
                 aux_views = [nchw(t, s, 0) for t, s in zip(aux_maps, aux_sizes)]
-                if self.fpn is not None:
+                if not self.use_vt:
+                    vt_in = None
+                elif self.fpn is not None:
                     fpn_views = [nchw(t, s, 0) for t, s in zip(fpn_maps, fpn_sizes)]
                     self.hfre.simple_fpn = lambda x, v=fpn_views: v
                     vt_in = nchw(vt_last[:gh * gw], (gh, gw))
@@ -253,7 +265,9 @@ class FO1Engine:
                 continue
             for j, i in enumerate(grp):
                 aux_views = [nchw(t, s, j) for t, s in zip(aux_maps, aux_sizes)]
-                if self.fpn is not None:
+                if not self.use_vt:
+                    vt_in = None
+                elif self.fpn is not None:
                     fpn_views = [nchw(t, s, j) for t, s in zip(fpn_maps, fpn_sizes)]
                     self.hfre.simple_fpn = lambda x, v=fpn_views: v
                     r0 = bp.row0[i]
@@ -272,11 +286,11 @@ class FO1Engine:
     def _device_batch(self, st, meta):
         with ops.workspace_scope(self._ws_owner):
             grids = meta["grids"]
-            tokens, feats, bp = self.vit.forward_batch(st["pix"], grids, capture="last" if self.fpn is not None else "all")
+            tokens, feats, bp = self.vit.forward_batch(st["pix"], grids, capture=self.capture)
             self._mark("qwen_vit+merger")
             image_tokens = self.mm_projector(tokens)
             self._mark("mm_projector")
-            vt_last = feats[-1] if self.fpn is not None else feats
+            vt_last = None if not self.use_vt else (feats[-1] if self.fpn is not None else feats)
             region_tokens, ranges = self._regions_batch(st["aux"], st.get("aux_stack"), st["boxes"], meta["want"], vt_last, bp, grids,
                                                         st.get("boxes_cat"), st.get("box_image"))
             emb = self.llm.embed_rows(st["plan"], image_tokens, region_tokens)
@@ -307,7 +321,11 @@ class FO1Engine:
             grids.append((int(gh), int(gw))); n_img.append((gh // m) * (gw // m)); want.append(bool(w))
             boxes.append(b.to(device=self.dev, dtype=torch.float32)); n_reg.append(b.shape[0] if w else 0); prompts.append(r["ids"])
         hp = self.llm.plan_batch(prompts, n_img, n_reg, [(g[0] // m, g[1] // m) for g in grids])
-        self.llm.reserve(hp["rows"])
+        if self.llm.reserve(hp["rows"]):
+            # the caches moved (cache_epoch bumped): every captured pass holds dead pointers and is unreachable by key — release the
+            # graphs and their private activation pools now instead of waiting for 8 new captures to evict them
+            self._graphs.clear()
+            self._seen.clear()
         meta = dict(grids=tuple(grids), want=tuple(want), seqs=tuple(hp["seqs"]))
         pix = requests[0]["pix"] if B == 1 else torch.cat([r["pix"].to(self.dev) for r in requests], 0)
         auxs = [r["aux"] if r["aux"].dim() == 3 else r["aux"][0] for r in requests]

@@ -123,6 +123,24 @@ def _workspace(kind: str, device, nbytes: int) -> torch.Tensor:
     return ws
 
 
+def release_workspaces(owner) -> int:
+    """Drop every scratch buffer keyed by `owner` (an engine / decoder that is gone: its graphs, the only other holders of the raw
+    pointers, went with it).  Returns the number of buffers released."""
+    dead = [k for k in _ws_pool if k[2] == ("owner", owner)]
+    for k in dead:
+        del _ws_pool[k]
+    return len(dead)
+
+
+def new_owner(holder):
+    """A scratch-pool owner token whose buffers are released when `holder` (the engine / decoder using it) is collected: repeated
+    engine or replica creation must not leak device memory."""
+    import weakref
+    token = object()
+    weakref.finalize(holder, release_workspaces, token)
+    return token
+
+
 def _gemm_workspace(device) -> torch.Tensor:
     """fp32 scratch for split-K partials, 64 MiB."""
     return _workspace("gemm", device, 64 * 1024 * 1024)

@@ -52,19 +52,33 @@ def assign(costs: Sequence[float], world: int) -> List[List[int]]:
     return shards
 
 
-def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu") -> Optional[List[Tuple[int, Optional[List[int]]]]]:
+class RemoteRankFailed(RuntimeError):
+    """Another rank hit a fatal error (out of memory, missing library): this rank stops too instead of blocking in the gather."""
+
+
+def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu",
+                   fatal: Optional[BaseException] = None) -> Optional[List[Tuple[int, Optional[List[int]]]]]:
     """local: [(item_idx, token ids or None on error)].  Returns the merged list sorted by item_idx on rank 0
-    (None elsewhere).  One all_reduce(MAX) for the record width/count + one all_gather of int32 records."""
+    (None elsewhere).  One all_reduce(MAX) for the record width / count / fatal flag + one all_gather of int32 records.
+    `fatal`: the exception that stopped this rank's shard, if any — the flag travels with the size exchange, so EVERY rank raises
+    (the failing one its own exception, the others RemoteRankFailed) before anyone enters the all_gather: a multi-GPU eval stops
+    instead of hanging until the RCCL watchdog fires."""
     rank, world, _ = world_info()
     if world == 1 or not dist.is_initialized():
+        if fatal is not None:
+            raise fatal
         return sorted(local, key=lambda r: r[0])
     # the collective's tensors live where the backend works: RCCL ("nccl") on this rank's GPU, gloo on the host — whatever the
     # caller's `device` says (an eval driver started under gloo still passes its cuda device string)
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     kmax = max([len(t) for _, t in local if t is not None] + [0])
-    meta = torch.tensor([kmax, len(local)], dtype=torch.int64, device=dev)
+    meta = torch.tensor([kmax, len(local), 1 if fatal is not None else 0], dtype=torch.int64, device=dev)
     dist.all_reduce(meta, op=dist.ReduceOp.MAX)
     kmax, nmax = int(meta[0]), int(meta[1])
+    if int(meta[2]):
+        if fatal is not None:
+            raise fatal
+        raise RemoteRankFailed(f"[rank {rank}] another rank stopped on a fatal error; no records were gathered")
     rec = torch.full((nmax, 2 + kmax), -2, dtype=torch.int32, device=dev)   # -2 = padding row
     for j, (idx, toks) in enumerate(local):
         rec[j, 0] = idx
@@ -121,7 +135,13 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
 
     `generate` may be a LIST of callables: one worker thread per callable, each pulling the next item / group of the rank's shard
     from a shared queue.  Give every callable its own engine replica + HIP stream (FO1ForCausalLM.replica()).  The records are
-    sorted by item index afterwards, so the output does not depend on the interleaving or the grouping."""
+    sorted by item index afterwards, so the output ORDER does not depend on the interleaving or the grouping.  The token ids of an
+    item are the same in any grouping only as far as the prefill kernels are invariant to the pass's row count: the GEMM tile /
+    split-K choice follows M, so a batch-8 pass can differ from a batch-1 pass at bf16 rounding level (a packed pass is bit-identical
+    to the one-image passes when the tile is pinned, tests/test_batched_prefill_gpu.py); decode is grouping-invariant.
+
+    A fatal error (out of memory, missing library) on one rank stops ALL ranks: the failing rank raises its exception, the others
+    RemoteRankFailed — nobody is left waiting in the gather."""
     rank, world, _ = world_info()
     mine = assign(costs, world)[rank]
     workers = list(generate) if isinstance(generate, (list, tuple)) else [generate]
@@ -155,15 +175,21 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
             print(f"[rank {rank}] item {grp[0]} failed: {type(e).__name__}: {e}")
             return [(grp[0], None)]
 
+    fatal: Optional[BaseException] = None
+    local: list = []
     if len(workers) == 1:
-        local = [r for g in it for r in run_group(workers[0], g)]
+        try:
+            for g in it:
+                local.extend(run_group(workers[0], g))
+        except Exception as e:      # only fatal ones get here (run_group turns the rest into error records)
+            fatal = e
     else:
         import queue
         import threading
         q: "queue.Queue" = queue.Queue()
         for g in it:
             q.put(g)
-        local, lock, errors = [], threading.Lock(), []
+        lock, errors = threading.Lock(), []
 
         def loop(fn):
             while True:
@@ -185,6 +211,6 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
         for t in threads:
             t.join()
         if errors:
-            raise errors[0]
+            fatal = errors[0]
     local.sort(key=lambda r: r[0])
-    return gather_records(local, device)
+    return gather_records(local, device, fatal=fatal)

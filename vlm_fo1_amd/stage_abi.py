@@ -98,7 +98,7 @@ class VitStage:
         u = c.spatial_merge_size ** 2
         tokens = torch.empty(g.S // u, c.out_hidden_size, dtype=torch.bfloat16, device=dev)
         nf = len(c.fullatt_block_indexes)
-        want = list(range(nf)) if capture == "all" else [nf - 1]
+        want = list(range(nf)) if capture == "all" else ([] if capture == "none" else [nf - 1])    # null slots are not written
         feats = [torch.empty(g.S, c.hidden_size, dtype=torch.bfloat16, device=dev) for _ in want]
         arr = (ctypes.c_void_p * nf)()
         for t, k in zip(feats, want):

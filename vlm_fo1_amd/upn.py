@@ -452,7 +452,7 @@ class UPNEngine:
         import collections
         self._graphs = collections.OrderedDict()     # (image shape, prompt type) -> (hipGraph, static image, outputs): LRU of GRAPH_CACHE
         self._seen = {}
-        self._ws_owner = object()                    # scratch buffers are keyed by this token (ops.workspace_scope)
+        self._ws_owner = ops.new_owner(self)         # scratch buffers are keyed by this token (ops.workspace_scope)
 
     GRAPH_CACHE = 4
     CAPTURE_AFTER = 1       # a size is captured on its second sighting (the first call also builds the per-size host plans)

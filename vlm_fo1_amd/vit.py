@@ -197,7 +197,7 @@ class QwenViT:
         """pixel_values [S, 1176] (device, bf16, merge-block order as the HF processor emits them).
         Returns (image_tokens [S/4, out_hidden] raster-merged order,
                  feature maps: list of [gh*gw, 1280] raster token-major (all full-attention blocks, or
-                 only the last one when capture == "last" — what the SimpleFPN variant consumes))."""
+                 only the last one when capture == "last" — what the SimpleFPN variant consumes; none when capture == "none"))."""
         g = self.plan(gh, gw)
         if pixel_values.shape != (g.S, self.k_in):
             raise ValueError(f"pixel_values {tuple(pixel_values.shape)} does not match grid {gh}x{gw} (expected [{g.S}, {self.k_in}])")
@@ -235,7 +235,7 @@ class QwenViT:
             x = ops.gemm(att, w["wo"], w["bo"], residual=x)
             a = ops.norm_linear(x, w["n2"], 1e-6, w["wgu"], w["bgu"], act=ops.ACT_SWIGLU16)
             x = ops.gemm(a, w["wd"], w["bd"], residual=x)
-            if full and (capture == "all" or i == c.fullatt_block_indexes[-1]):
+            if full and capture != "none" and (capture == "all" or i == c.fullatt_block_indexes[-1]):
                 feats.append(ops.gather_rows(g.plan_raster, d, x))
         u = c.spatial_merge_size ** 2
         m = ops.rmsnorm(x, self.ln_q, 1e-6).view(S // u, u * d)
