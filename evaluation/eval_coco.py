@@ -43,33 +43,35 @@ def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=
 
     batch = max(1, int(os.environ.get("FO1_BATCH", "8")))     # images per packed pass (prefill + batched decode); 1 = the reference's loop
 
-    def make_generate(m, stream):
-        def inputs_of(i):
-            d = data_list[i]
-            messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(img_folder, d["image"])}},
-                                                     {"type": "text", "text": d["conversations"][0]["value"]}],
-                         "bbox_list": d["bbox_list"]}]
-            kw = prepare_inputs(model_id, m, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
-                                temperature=0.0, do_sample=False)
-            kw["streamer"] = None
-            return kw
+    def inputs_of(i):
+        """Host side of one item (a1): PIL decode / resize, tokenisation, uploads.  Runs on the prefetch threads, ahead of the GPU."""
+        d = data_list[i]
+        messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(img_folder, d["image"])}},
+                                                 {"type": "text", "text": d["conversations"][0]["value"]}],
+                     "bbox_list": d["bbox_list"]}]
+        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
+                            temperature=0.0, do_sample=False)
+        kw["streamer"] = None
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()      # uploads / device preprocessing done before another stream consumes them
+        return kw
 
-        def generate(i):
+    def make_generate(m, stream):
+        def generate(i, kw):
             with torch.cuda.stream(stream):
-                kw = inputs_of(i)
                 out = m.generate(**kw)
                 return out[0, kw["inputs"].shape[1]:].tolist()
 
-        def generate_group(idxs):
+        def generate_group(idxs, kws):
             with torch.cuda.stream(stream):
-                kws = [inputs_of(i) for i in idxs]
                 outs = m.generate_many(kws)
                 return [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(outs, kws)]
         return generate_group if batch > 1 else generate
 
     generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 2)
-    costs = [len(d["bbox_list"]) + 64 for d in data_list]     # boxes drive prompt length; image size unknown before load
-    merged = SE.run_sharded(len(data_list), costs, generate, device=device if world > 1 else "cpu", batch=batch)
+    # cost = f(pixels, N) (SURVEY 8e): the image header gives the size without decoding; a missing file falls back to the box count
+    costs = [SE.item_cost(*SE.image_size(os.path.join(img_folder, d["image"])), len(d["bbox_list"])) for d in data_list]
+    merged = SE.run_sharded(len(data_list), costs, generate, device=device if world > 1 else "cpu", batch=batch, prepare=inputs_of)
     if rank != 0:
         return
     res = []

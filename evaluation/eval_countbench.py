@@ -32,32 +32,34 @@ def eval_countbench(data_path, image_path, model_id, device):
 
     batch = max(1, int(os.environ.get("FO1_BATCH", "8")))     # images per packed pass (prefill + batched decode); 1 = the reference's loop
 
-    def make_generate(m, stream):
-        def inputs_of(i):
-            item = data[i]
-            messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(image_path, item["image"])}},
-                                                     {"type": "text", "text": item["question"]}], "bbox_list": item["bboxes"]}]
-            kw = prepare_inputs(model_id, m, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
-                                temperature=0.0, do_sample=False)
-            kw["streamer"] = None
-            return kw
+    def inputs_of(i):
+        """Host side of one item (a1): PIL decode / resize, tokenisation, uploads.  Runs on the prefetch threads, ahead of the GPU."""
+        item = data[i]
+        messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(image_path, item["image"])}},
+                                                 {"type": "text", "text": item["question"]}], "bbox_list": item["bboxes"]}]
+        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
+                            temperature=0.0, do_sample=False)
+        kw["streamer"] = None
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()      # uploads / device preprocessing done before another stream consumes them
+        return kw
 
-        def generate(i):
+    def make_generate(m, stream):
+        def generate(i, kw):
             with torch.cuda.stream(stream):
-                kw = inputs_of(i)
                 out = m.generate(**kw)
                 return out[0, kw["inputs"].shape[1]:].tolist()
 
-        def generate_group(idxs):
+        def generate_group(idxs, kws):
             with torch.cuda.stream(stream):
-                kws = [inputs_of(i) for i in idxs]
                 outs = m.generate_many(kws)
                 return [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(outs, kws)]
         return generate_group if batch > 1 else generate
 
     generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 2)
-    costs = [len(item["bboxes"]) + 64 for item in data]
-    merged = SE.run_sharded(len(data), costs, generate, device=device if world > 1 else "cpu", batch=batch)
+    # cost = f(pixels, N) (SURVEY 8e): the image header gives the size without decoding; a missing file falls back to the box extent
+    costs = [SE.item_cost(*SE.image_size(os.path.join(image_path, item["image"]), item["bboxes"]), len(item["bboxes"])) for item in data]
+    merged = SE.run_sharded(len(data), costs, generate, device=device if world > 1 else "cpu", batch=batch, prepare=inputs_of)
     if rank != 0:
         return None
     correct = total = 0

@@ -1,0 +1,147 @@
+"""Generates tests/golden/fulldepth_ref_<case>.npz: outputs of the REFERENCE's own modules at FULL DEPTH on the seeded workloads of
+tests/fulldepth_case.py — the pin behind "decoded ids are bit-identical" and "engine-bf16 vs reference-bf16" (VERDICT r2 #2).
+
+Run in the build container only (needs /root/reference; nothing of it is copied — the modules are imported in place):
+
+    python tests/golden/make_fulldepth_ref.py [metric demo]        # ~25 min for `metric` on 8 cores (the bf16 pass dominates)
+
+What runs, per case, once in fp32 and (metric only) once the way the reference executes, `model.to(bfloat16)` (builder.py:140-141):
+  * vendored Qwen2_5_VisionTransformer + the reference's custom_forward / VisionFeaturesGather (qwen2_5_vl_encoder.py:37-158)
+  * reference DaViT (modeling_davit.py), reference SimpleFP (simple_fpn.py)
+  * the reference's OWN HFREModule (hybrid_finegrained_region_encoder.py:275-469; roi_align = oracle/roi_align_ref.c, torchvision is not
+    installed) driven exactly as encode_regions does (omchat_qwen2_5_vl.py:75-108: vt box scaling, .to(tower dtype), mm_projector_aux)
+  * splice + get_rope_index (oracle/llm_oracle.py, pinned to the reference's functions by tests/test_oracle_splice.py / test_oracle_llm.py)
+  * the reference's OWN vendored Qwen2_5_VLModel (oracle/reference_loader.vendored_llm) for the prefill and a K = 16 greedy
+    continuation through its DynamicCache (the 1-token path of omchat_qwen2_5_vl.py:143-155; position = cache length + rope delta,
+    modeling_qwen2_5_vl.py:1848-1860), logits = hidden @ lm_head^T (omchat_qwen2_5_vl.py:38).
+Stored: decoded ids (the bf16 pass teacher-forced on the fp32 ids), per-step top-8 logits, last-row hidden, region tokens (fp16), sampled image-token rows and HFRE
+rows, the weight checksums (RNG drift is detected, not silently compared)."""
+import os
+import sys
+import time
+from unittest import mock
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+import fulldepth_case as FC  # noqa: E402
+from measure_bf16_floor import build_modules, noop  # noqa: E402
+from oracle import hfre_oracle as HO, llm_oracle as LO, reference_loader as R  # noqa: E402
+
+log = lambda s: print(time.strftime("%H:%M:%S"), s, flush=True)
+
+
+def build_llm(cfg, W):
+    l = cfg.llm
+    with mock.patch("torch.nn.init.normal_", noop), mock.patch("torch.nn.init.kaiming_uniform_", noop), mock.patch("torch.nn.init.uniform_", noop):
+        m = R.vendored_llm(vocab_size=l.vocab_size, hidden_size=l.hidden_size, intermediate_size=l.intermediate_size,
+                           num_hidden_layers=l.num_layers, num_attention_heads=l.num_heads, num_key_value_heads=l.num_kv_heads,
+                           max_position_embeddings=32768, rms_norm_eps=l.rms_norm_eps, rope_theta=l.rope_theta,
+                           rope_scaling={"type": "mrope", "mrope_section": list(l.mrope_section)}, tie_word_embeddings=False)
+    sd = {k: v.float() for k, v in W["llm"].items() if k != "lm_head.weight"}
+    res = m.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    return m
+
+
+def reference_pass(mods, llm, hfre, case, cfg, W, dtype, K, forced=None, top_of=None):
+    """forced: ids fed back instead of this pass's own argmax (the bf16 pass is teacher-forced on the fp32 pass's ids so that all K
+    steps stay comparable); top_of [K, 8]: the entries whose logits are recorded (the fp32 pass's top-8) instead of this pass's own."""
+    gh, gw = case["grid"]
+    H, Wd = case["img_hw"]
+    ids, boxes = case["groups"][0]
+    out = {}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        vit, enc = mods["vit"].to(dtype), mods["enc"]
+        gather = enc.VisionFeaturesGather()
+        vit.vision_features_gather = gather
+        tokens = enc.custom_forward(vit, case["pix"].to(dtype), torch.tensor([[1, gh, gw]]))
+        maps = gather.extract_multi_level_features()[0]
+        img_tok = mods["proj"]["mm_projector"].to(dtype)(tokens)                       # encode_images :44-72
+        log(f"{dtype}: vit {time.perf_counter() - t0:.0f}s")
+        t0 = time.perf_counter()
+        aux = mods["davit"].to(dtype).forward_features(case["aux"].to(dtype).unsqueeze(0))["image_features"]
+        log(f"{dtype}: davit {time.perf_counter() - t0:.0f}s")
+        # encode_regions :75-108 with mm_use_simpleFPN_for_vt: the last captured map, boxes scaled per axis, HFRE, cast, projector
+        hfre.simple_fpn = mods["fpn"].to(dtype)
+        b = boxes.to(torch.float32)
+        vt_boxes = b * torch.tensor([(gw * 14) / Wd, (gh * 14) / H, (gw * 14) / Wd, (gh * 14) / H])
+        feat = hfre(aux_multi_level_features=aux, vt_multi_level_features=maps[-1], aux_boxes=[b.clone()], vt_boxes=[vt_boxes.clone()]).squeeze(0)
+        reg = mods["proj"]["mm_projector_aux"].to(dtype)(feat.to(dtype))
+        emb_w = W["llm"]["embed_tokens.weight"].to(dtype)
+        emb, nb, na = LO.splice(torch.tensor(ids), emb_w, img_tok, reg)
+        pos, delta = LO.rope_index(nb, (gh // 2, gw // 2), na)
+        t0 = time.perf_counter()
+        llm = llm.to(dtype)
+        head = W["llm"]["lm_head.weight"].to(dtype)
+        o = llm(inputs_embeds=emb.to(dtype)[None], position_ids=pos[:, None, :], use_cache=True)
+        past, last = o.past_key_values, o.last_hidden_state[0, -1:]
+        out["last_hidden"] = last.float().numpy()
+        log(f"{dtype}: llm prefill {time.perf_counter() - t0:.0f}s (L = {emb.shape[0]})")
+        t0 = time.perf_counter()
+        dec_ids, top_i, top_v = [], [], []
+        L = emb.shape[0]
+        for step in range(K):
+            lg = (last @ head.t()).float()[0]
+            tv, ti = lg.topk(8)
+            dec_ids.append(int(ti[0]))
+            if top_of is not None:
+                ti = torch.from_numpy(top_of[step]); tv = lg[ti]
+            top_i.append(ti.numpy()); top_v.append(tv.numpy())
+            if step + 1 == K:
+                break
+            p = L + step + delta
+            fed = dec_ids[-1] if forced is None else int(forced[step])
+            o = llm(inputs_embeds=emb_w[fed:fed + 1][None], position_ids=torch.full((3, 1, 1), p, dtype=torch.long),
+                    past_key_values=past, use_cache=True)
+            past, last = o.past_key_values, o.last_hidden_state[0, -1:]
+        log(f"{dtype}: {K} greedy steps {time.perf_counter() - t0:.0f}s ids {dec_ids}")
+    out.update(ids=np.array(dec_ids, dtype=np.int64), top_ids=np.stack(top_i), top_vals=np.stack(top_v),
+               region_tokens=reg.float().numpy().astype(np.float16), image_tokens_rows=img_tok.float()[::8].numpy().astype(np.float16),
+               hfre_rows=feat.float()[:8].numpy(), rope_delta=np.array(delta), L=np.array(L))
+    return out
+
+
+def main():
+    assert R.available(), "/root/reference is needed"
+    torch.set_num_threads(int(os.environ.get("REF_THREADS", str(len(os.sched_getaffinity(0))))))
+    names = sys.argv[1:] or ["metric", "demo"]
+    cfg = FC.full_config()
+    small = bool(os.environ.get("REF_SMALL"))        # quick functional check of this script (output not committed)
+    if small:
+        cfg.vit.depth, cfg.vit.fullatt_block_indexes, cfg.llm.num_layers, cfg.llm.vocab_size = 2, (1,), 2, 4096
+    log("cpu weights ...")
+    W, cks = FC.cpu_weights(cfg)
+    log(f"checksums {cks}")
+    mods = build_modules(cfg, W, with_llm=False)
+    llm = build_llm(cfg, W)
+    HFREModule, _, _ = HO.load_reference_hfre()
+    hfre = HFREModule(roi_output_size=7, region_feature_dim=5888, apply_position_embedding=True, pos_embedding_strategy="bbox_based",
+                      use_vt_region_feature_only=False, use_vision_tower_region_feature=True, region_feature_combination="concat",
+                      apply_region_layer_norm=False, vision_tower_region_feature_dim=2048, vision_tower_spatial_scale=1 / 14,
+                      use_simpleFPN_for_vt=True, aux_vision_tower_spatial_scale=0.25, aux_vision_tower_region_feature_dims=[256, 512, 1024, 2048])
+    for name in names:
+        case = FC.build_case(name)
+        if small:
+            case["groups"] = [([t if t < 0 else t % 4096 for t in ids], b) for ids, b in case["groups"]]
+        blobs = {f"cks_{k}": np.array(v) for k, v in cks.items()}
+        for tag, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            if tag == "bf16" and name != "metric" and not os.environ.get("REF_BF16_ALL"):
+                continue
+            if tag == "fp32":
+                r = reference_pass(mods, llm, hfre, case, cfg, W, dtype, FC.K_DECODE)
+            else:       # teacher-forced on the fp32 ids, logits recorded at the fp32 pass's top-8 entries
+                r = reference_pass(mods, llm, hfre, case, cfg, W, dtype, FC.K_DECODE, forced=blobs["fp32_ids"], top_of=blobs["fp32_top_ids"])
+            blobs.update({f"{tag}_{k}": v for k, v in r.items()})
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"fulldepth_ref_{name}{'_small' if small else ''}.npz"), **blobs)
+        log(f"wrote fulldepth_ref_{name}.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -38,7 +38,7 @@ def metrics(got, ref):
                 rms_rel=float((got - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()))
 
 
-def build_modules(cfg, W):
+def build_modules(cfg, W, with_llm=True):
     qwen, enc = R.vendored_qwen(), R.vendored_vit_encoder()
     vc = qwen.Qwen2_5_VLVisionConfig(depth=cfg.vit.depth, hidden_size=1280, hidden_act="silu", intermediate_size=3420, num_heads=16,
                                      in_channels=3, patch_size=14, spatial_merge_size=2, temporal_patch_size=2, window_size=112,
@@ -58,6 +58,8 @@ def build_modules(cfg, W):
     _, SimpleFP, _ = HO.load_reference_hfre()
     fpn = SimpleFP(out_channels=512, norm="LN", square_pad=0, dim=1280, stride=14).eval()
     fpn.load_state_dict({k: v.float() for k, v in W["fpn"].items()}, strict=True)
+    if not with_llm:
+        return dict(vit=vit, enc=enc, davit=davit, fpn=fpn, llm=None, proj=_projectors(W))
     from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as M
     from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLTextConfig
     lc = Qwen2_5_VLTextConfig(vocab_size=cfg.llm.vocab_size, hidden_size=2048, intermediate_size=11008, num_hidden_layers=cfg.llm.num_layers,
@@ -67,6 +69,11 @@ def build_modules(cfg, W):
     with mock.patch("torch.nn.init.normal_", noop), mock.patch("torch.nn.init.kaiming_uniform_", noop), mock.patch("torch.nn.init.uniform_", noop):
         llm = M.Qwen2_5_VLTextModel(lc).eval()
     llm.load_state_dict({k: v.float() for k, v in W["llm"].items()}, strict=True)
+    return dict(vit=vit, enc=enc, davit=davit, fpn=fpn, llm=llm, proj=_projectors(W))
+
+
+def _projectors(W):
+    """mlp2x_gelu as build_vision_projector(_aux) builds it (multimodal_projector/builder.py:64-71,103-110)."""
     proj = {}
     for name in ("mm_projector", "mm_projector_aux"):
         w0, w2 = W["proj"][name + ".0.weight"], W["proj"][name + ".2.weight"]
@@ -74,7 +81,7 @@ def build_modules(cfg, W):
         m.load_state_dict({"0.weight": w0.float(), "0.bias": W["proj"][name + ".0.bias"].float(),
                            "2.weight": w2.float(), "2.bias": W["proj"][name + ".2.bias"].float()})
         proj[name] = m
-    return dict(vit=vit, enc=enc, davit=davit, fpn=fpn, llm=llm, proj=proj)
+    return proj
 
 
 def one_pass(mods, case, cfg, dtype, embed_w, log):

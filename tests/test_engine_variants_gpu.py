@@ -64,6 +64,19 @@ def oracle_towers(sd, cfg, aux_mode):
     return _cache["vit"], _cache[("davit", aux_mode)]
 
 
+def cpu_state_cached(weights):
+    """fp32 CPU copies; the (large) tower parts are converted once — same seed, same draw order, same tensors (spot-checked)."""
+    import composed_oracle as CO
+    if "towers" not in _cache:
+        _cache["towers"] = {k: {n: t.float().cpu() for n, t in weights[k].items()} for k in ("vit", "davit", "fpn")}
+    tw = _cache["towers"]
+    for part, name in (("vit", "merger.mlp.2.bias"), ("davit", "convs.3.proj.bias"), ("fpn", "simfp_4.2.norm.bias")):
+        assert torch.equal(weights[part][name].float().cpu(), tw[part][name]), "tower weights changed between variants"
+    sd = dict(tw)
+    sd.update(CO.cpu_state({k: weights[k] for k in ("llm", "proj")}))
+    return sd
+
+
 def check(got, ref, what, cos_min=0.999, rel_max=2 ** -4):
     got, ref = got.float().cpu(), ref.float()
     assert got.shape == ref.shape, f"{what}: shape {tuple(got.shape)} vs {tuple(ref.shape)}"
@@ -85,7 +98,7 @@ def run_variant(cfg, aux_mode, with_boxes, region_ln=None):
         boxes = None
     n = 0 if boxes is None else boxes.shape[0]
     ids = synthetic_prompt(n, vocab=4096, seed=2)
-    sd = CO.cpu_state(weights)
+    sd = cpu_state_cached(weights)
     (o_tok, o_maps), o_aux = oracle_towers(sd, cfg, aux_mode)
     o_img = CO.projector(o_tok, sd["proj"], "mm_projector.", cfg.mm_projector_type)
     o_feat = CO.region_features(sd, cfg, o_aux, o_maps, boxes, GH, GW, AUX[aux_mode], region_ln=region_ln)

@@ -12,7 +12,9 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-need2 = pytest.mark.skipif(not torch.cuda.is_available() or torch.cuda.device_count() < 2, reason="needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+_NDEV = torch.cuda.device_count() if torch.cuda.is_available() else 0
+need2 = pytest.mark.skipif(_NDEV < 2, reason=f"RCCL tests skipped: this box exposes {_NDEV} GPU(s), they need >= 2 (RCCL refuses two ranks on one "
+                           "device; the gloo world-2 tests in tests/test_sharded_eval.py cover the same control flow on CPU)")
 
 WORKER = r'''
 import os, sys, json

@@ -135,3 +135,51 @@ def test_fatal_error_on_one_rank_stops_every_rank():
     # single process: the fatal error surfaces as itself
     with pytest.raises(MemoryError):
         SE.run_sharded(9, [1.0] * 9, oom_generate, device="cpu")
+
+
+def test_prefetcher_runs_ahead_in_order_and_keeps_per_item_errors():
+    """run_sharded(prepare=...): the host side of every item is prepared ahead of its consumption on helper threads, handed to
+    `generate` as its second argument, a failing prepare becomes that item's error record, and nothing is prepared twice."""
+    import threading
+    import time
+    n = 29
+    prepared, lock = [], threading.Lock()
+
+    def prepare(i):
+        time.sleep(0.002)
+        with lock:
+            prepared.append(i)
+        if i == 7:
+            raise ValueError("bad image")
+        return {"i": i, "payload": [i] * 3}
+
+    def gen(i, kw):
+        assert kw["i"] == i
+        return fake_generate(i) if i != 5 else (_ for _ in ()).throw(RuntimeError("boom"))
+
+    def gen_group(idxs, kws):
+        assert [k["i"] for k in kws] == list(idxs)
+        if 5 in idxs:
+            raise RuntimeError("boom")
+        return [fake_generate(i) for i in idxs]
+
+    want = [(i, None if i in (5, 7) else fake_generate(i)) for i in range(n)]
+    assert SE.run_sharded(n, [1.0 + (i % 3) for i in range(n)], gen, prepare=prepare) == want
+    assert sorted(prepared) == list(range(n))
+    prepared.clear()
+    got = SE.run_sharded(n, [1.0 + (i % 3) for i in range(n)], gen_group, batch=4, prepare=prepare, prefetch_depth=6)
+    assert got == want
+    # group retries re-prepare only the items of failed groups (their first result was consumed)
+    assert set(prepared) == set(range(n))
+    # two worker threads sharing one prefetcher
+    got = SE.run_sharded(n, [1.0] * n, [gen, gen], prepare=prepare)
+    assert got == want
+
+
+def test_item_cost_orders_by_pixels_and_boxes():
+    c = SE.item_cost
+    assert c(640, 480, 100) > c(640, 480, 10) > c(320, 240, 10)
+    assert c(4000, 3000, 10) == c(2048, 1536, 10)            # long side capped at 2048 like mm_utils.py:447-455
+    assert c(640, 480, 100, aux="squash") > c(640, 480, 100)  # 768 x 768 aux image > 640 x 480
+    assert 5000 < c(640, 480, 100) < 9000                     # ~7 TFLOP for the metric configuration (SURVEY 8d)
+    assert SE.image_size("/nonexistent.jpg", [[0, 0, 99, 49]]) == (99, 49) and SE.image_size("/nonexistent.jpg") == (640, 480)

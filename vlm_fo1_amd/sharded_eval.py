@@ -117,6 +117,79 @@ def request_workers(model, make_generate: Callable, n: Optional[int] = None) -> 
     return workers
 
 
+def item_cost(width: int, height: int, n_boxes: int, aux: str = "dynamic", new_tokens: int = 64) -> float:
+    """Estimated work of one item in GFLOP-equivalents from (pixels, N) — SURVEY §8e's cost key.  Mirrors the path's own sizing:
+    long side capped at 2048 (mm_utils.py:447-455), smart-resize to multiples of 28 (S patches), `dynamic` aux = the resized image
+    or `squash` 768x768; the coefficients are the dense flop of each stage per unit: ViT 1.26 GF per patch (+ full
+    attention), DaViT-L 2.5 MF per aux pixel, SimpleFPN 0.13 GF per patch, LLM prefill 5.5 GF per row (S/4 image rows + 2 per
+    box + ~60 text), decode `new_tokens` x 6.2 GB of weights priced at the 400 flop/byte machine balance."""
+    from vlm_fo1.model.image_processing import smart_resize
+    w, h = max(int(width), 1), max(int(height), 1)
+    if max(w, h) > 2048:
+        r = 2048.0 / max(w, h)
+        w, h = max(int(w * r), 1), max(int(h * r), 1)
+    try:
+        rh, rw = smart_resize(h, w, 28, 56 * 56, 2048 * 2048)
+    except ValueError:
+        rh, rw = max(28, h // 28 * 28), max(28, w // 28 * 28)
+    S = (rh // 14) * (rw // 14)
+    aux_px = 768 * 768 if aux == "squash" else w * h
+    rows = S // 4 + 2 * int(n_boxes) + 60
+    vit = 1.26 * S + 4 * (4.0 * S * S * 1280) / 1e9          # 28 windowed blocks are linear in S; 4 full-attention blocks are not
+    llm = 5.5 * rows + 36 * (2.0 * rows * rows * 2048) / 1e9
+    return vit + 2.5e-3 * aux_px + 0.13 * S + llm + new_tokens * 6.2 * 0.4
+
+
+def image_size(path: str, boxes=None):
+    """(width, height) from the image header (PIL reads it lazily, no decode); when the file cannot be opened: the extent of the
+    item's boxes, else a COCO-typical 640 x 480 — the cost model must never stop an evaluation."""
+    try:
+        from PIL import Image
+        with Image.open(path) as im:
+            return im.size
+    except Exception:
+        if boxes:
+            return max(int(max(b[2] for b in boxes)), 1), max(int(max(b[3] for b in boxes)), 1)
+        return 640, 480
+
+
+class Prefetcher:
+    """Runs `prepare(i)` (PIL decode / resize, tokenisation, uploads: host work of a1) on helper threads up to `depth` items ahead of
+    the consumer, in the order the items will be consumed — the per-rank prefetch thread of SURVEY §8e: at > 100 images/s per GPU the
+    host side of an item costs more than its share of a packed pass.  `get(i)` returns prepare(i)'s result or re-raises its
+    exception (so a bad image becomes that item's error record, as before).  Results are handed over once; memory is bounded by
+    `depth` prepared items."""
+
+    def __init__(self, prepare: Callable, order: Sequence[int], depth: int = 16, threads: int = 2):
+        from concurrent.futures import ThreadPoolExecutor
+        import threading
+        self._prepare, self._order, self._depth = prepare, list(order), max(1, int(depth))
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(threads)), thread_name_prefix="fo1-prefetch")
+        self._fut, self._next, self._taken = {}, 0, 0
+        self._lock = threading.Lock()
+        self._fill()
+
+    def _fill(self):
+        with self._lock:
+            while self._next < len(self._order) and self._next - self._taken < self._depth:
+                i = self._order[self._next]
+                if i not in self._fut:
+                    self._fut[i] = self._pool.submit(self._prepare, i)
+                self._next += 1
+
+    def get(self, i: int):
+        with self._lock:
+            f = self._fut.pop(i, None)
+            self._taken += 1
+        self._fill()
+        if f is None:                      # not scheduled (a retry after a failed group, or out-of-order use): do it now
+            return self._prepare(i)
+        return f.result()
+
+    def close(self):
+        self._pool.shutdown(wait=False, cancel_futures=True)
+
+
 def _fatal(e: BaseException) -> bool:
     """Errors that must stop the evaluation instead of becoming a per-item error record: out-of-memory (every later item would
     fail the same way and the run would silently report wrong metrics — ADVICE r1) and a missing HIP library."""
@@ -126,7 +199,8 @@ def _fatal(e: BaseException) -> bool:
     return "out of memory" in msg or "hiperroroutofmemory" in msg
 
 
-def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", progress: Optional[Callable] = None, batch: int = 1):
+def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", progress: Optional[Callable] = None, batch: int = 1,
+                prepare: Optional[Callable] = None, prefetch_depth: int = 16, prefetch_threads: int = 2):
     """Every rank runs `generate` on its shard; rank 0 gets [(i, ids|None)] for all items.
 
     batch == 1: `generate(i)` -> new token ids of item i.  batch > 1: `generate([i0, i1, ...])` -> [ids per item]: up to `batch`
@@ -141,7 +215,11 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
     to the one-image passes when the tile is pinned, tests/test_batched_prefill_gpu.py); decode is grouping-invariant.
 
     A fatal error (out of memory, missing library) on one rank stops ALL ranks: the failing rank raises its exception, the others
-    RemoteRankFailed — nobody is left waiting in the gather."""
+    RemoteRankFailed — nobody is left waiting in the gather.
+
+    `prepare(i)`: optional host-side preparation of item i (image decode / resize / tokenisation / upload).  When given it runs on
+    a Prefetcher ahead of the GPU work and `generate` receives the prepared object(s) as a second argument: `generate(i, prepared)`
+    or `generate([i0, ...], [prepared0, ...])`."""
     rank, world, _ = world_info()
     mine = assign(costs, world)[rank]
     workers = list(generate) if isinstance(generate, (list, tuple)) else [generate]
@@ -151,13 +229,19 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
     else:
         groups = [[i] for i in mine]
     it = progress(groups) if progress else groups
+    pf = Prefetcher(prepare, [i for g in groups for i in g], prefetch_depth, prefetch_threads) if prepare is not None else None
+
+    def call(fn, grp, single):
+        if pf is None:
+            return fn(grp[0]) if single else fn(list(grp))
+        return fn(grp[0], pf.get(grp[0])) if single else fn(list(grp), [pf.get(i) for i in grp])
 
     def run_group(fn, grp):
         try:
             if batch > 1:
-                outs = fn(list(grp))
+                outs = call(fn, grp, False)
                 return [(i, [int(t) for t in o]) for i, o in zip(grp, outs)]
-            return [(grp[0], [int(t) for t in fn(grp[0])])]
+            return [(grp[0], [int(t) for t in call(fn, grp, True)])]
         except Exception as e:  # per-item error record instead of the reference's silent `continue` (eval_coco.py:60-65)
             if _fatal(e):
                 raise
@@ -165,7 +249,7 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
                 recs = []
                 for i in grp:
                     try:
-                        recs.append((i, [int(t) for t in fn([i])[0]]))
+                        recs.append((i, [int(t) for t in call(fn, [i], False)[0]]))
                     except Exception as e1:
                         if _fatal(e1):
                             raise
@@ -212,5 +296,7 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
             t.join()
         if errors:
             fatal = errors[0]
+    if pf is not None:
+        pf.close()
     local.sort(key=lambda r: r[0])
     return gather_records(local, device, fatal=fatal)
