@@ -84,6 +84,44 @@ class Pipeline:
         return self.eng.prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
 
 
+def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode_tokens=0, row_budget=None):
+    """Dataset-shaped side measurement (BASELINE configs[2] / configs[3]): the items of `name`
+    (bench_workloads.py: the reference's CountBench / Pixmo fixtures verbatim, or COCO-like sizes x 100 boxes) with their OWN image
+    sizes and box counts, packed by cost into passes of <= `batch` images / `row_budget` ViT rows, `inflight` passes in flight.
+    Every pass has a new shape signature, so passes launch eagerly (no graph replay).  One untimed sweep (scratch allocation, index
+    plans), then one timed sweep.  `uniform_equivalent_images_per_sec` prices the same work in metric-configuration images
+    (1564 patches each) so it can be read against `value`."""
+    import bench_workloads as BW
+    dev = pipe.eng.dev
+    reqs, geos = BW.build_requests(name, dev, limit=n_items, aux_mode=aux_mode)
+    groups = BW.pack(geos, batch=batch, row_budget=row_budget or (batch * 1564 * 3 // 2))
+    need = max(sum(len(reqs[i]["ids"]) + geos[i]["S"] // 4 + 8 for i in g) for g in groups)
+    for e in pipe.engs:
+        e.llm.reserve(need)
+
+    def sweep():
+        for k, g in enumerate(groups):
+            slot = k % inflight
+            with torch.cuda.stream(pipe.streams[slot]):
+                grp = [reqs[i] for i in g]
+                if decode_tokens:
+                    pipe.engs[slot].generate_batch(grp, max_new_tokens=decode_tokens, use_graph=True)
+                else:
+                    pipe.engs[slot].prefill_batch(grp, use_graph=True)
+        torch.cuda.synchronize()
+
+    sweep()
+    t0 = time.perf_counter()
+    sweep()
+    el = time.perf_counter() - t0
+    patches = sum(g["S"] for g in geos)
+    out = dict(BW.summary(geos), name=name, aux=aux_mode, passes=len(groups), images_per_pass_max=batch, passes_in_flight=inflight,
+               seconds=round(el, 3), images_per_sec=round(len(reqs) / el, 2), region_tokens_per_sec=round(sum(g["n"] for g in geos) / el, 1),
+               uniform_equivalent_images_per_sec=round(patches / 1564.0 / el, 2), launch="eager (every pass is a new shape signature)",
+               what="prefill to the first greedy token" if not decode_tokens else f"prefill + {decode_tokens}-token batched greedy decode")
+    return out
+
+
 def cpu_baseline(case, pipe, reps=3, decode_tokens=64):
     """The oracle (a port of the reference's operators: oracle/*.py, torch fp32) of the same stages on this box's host cores, at
     FULL depth (32 ViT blocks, 36 LLM layers): warm-up 1 pass, then the median of `reps` passes, plus `decode_tokens` greedy
@@ -268,6 +306,11 @@ def main():
                     "qkv, gate/up and down projections of the packed pass (FO1Engine.enable_fp8); the line says so in `dtype` — the "
                     "default run is bf16 like the reference")
     ap.add_argument("--profile-shapes", action="store_true", help="per-shape GEMM rows in roofline.per_step_ms")
+    ap.add_argument("--dataset", default="countbench", choices=["countbench", "pixmo", "coco-like", "none"], help="dataset-shaped side measurement "
+                    "reported in the line's `dataset` block (ragged image sizes and box counts: the reference's CountBench / Pixmo fixtures "
+                    "verbatim, or COCO-like sizes x 100 boxes); `none` skips it")
+    ap.add_argument("--dataset-items", type=int, default=150, help="items of the dataset to run (0 = all)")
+    ap.add_argument("--dataset-aux", default="dynamic", choices=["dynamic", "squash"], help="aux image sizing (config aux_image_aspect_ratio)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -433,6 +476,12 @@ def main():
                                       images_per_sec_with_64_token_answer=round(Bd / (t_pref + 64 * tb), 2),
                                       launches_per_layer=5, note="one pass at a time: packed prefill of the batch, then 64 batched decode steps")
 
+    # ---- dataset-shaped workload (ragged sizes / variable N): not part of `value` ----
+    dset = None
+    if rank == 0 and not args.main_only and args.dataset != "none":
+        dset = dataset_run(pipe, args.dataset, args.dataset_items or None, B, R, aux_mode=args.dataset_aux)
+        dset["vs_uniform_headline"] = round(dset["uniform_equivalent_images_per_sec"] / (args.steps * B / el), 3)
+
     # ---- host-side preprocessing of one image (SURVEY 8d "preprocess (CPU)" stage, 8f rank 2): not part of `value` ----
     prep = None
     if rank == 0 and not args.main_only:
@@ -558,7 +607,7 @@ def main():
                                       (f"; {R} passes in flight on {R} HIP streams (engine replicas share weights)" if R > 1 else "; one pass at a time"),
                                images_per_step=B, passes_in_flight=R, global_batch=B * world,
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
-                   one_image_at_a_time=single, one_pass_at_a_time=one_pass, decode=dec, preprocess=prep, roofline=roof)
+                   one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
         if roof is not None:
             # stage times (sum of kernel execution time per stage, eager pass) and the two region-token rates
             out["stage_kernel_ms"] = stage_ms
