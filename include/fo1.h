@@ -309,6 +309,31 @@ int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out,
                                size_t workspace_bytes, void* stream);
 int fo1_pixel_shuffle2_bf16(const void* src, void* dst, int H, int W, int Co, int batch, void* stream);
 int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, int batch, void* stream);
+/* ---- ragged image batches (SURVEY 8f-3 on real datasets: CountBench / Pixmo / COCO images all differ in size) ----
+ * The same kernels over images of DIFFERENT sizes packed row-wise into one map: `segs` is a DEVICE table of n_img records, one
+ * workgroup column per image; every image is processed with exactly the arithmetic of the one-image call, so a ragged packed pass is
+ * bit-identical to the one-image passes.  Record fields (per operator: `in_*` describes the operand, `out_*` the result):
+ *   dwconv_ln / window_reverse / channel attention   in_row0 = first row of the image, H, W   (channel attention: H = its token count)
+ *   im2col / maxpool                                 in_row0, H, W -> out_row0, Ho, Wo
+ *   window_partition                                 in_row0, H, W -> out_row0 = first window row, Ho x Wo = windows down / across
+ *   window_reverse_add                               out_row0 = first window row (yw), Ho x Wo = windows; in_row0 = pixels (shortcut, y)
+ *   pixel_shuffle2                                   in_row0 (rows of [., 4*Co]), H, W -> out_row0 (rows of [., Co], 4*H*W of them)
+ * max_* sizes the launch (largest image), total_* is the work figure of the profile rows.  The reference runs its towers image by
+ * image (davit_aux_encoder.py:54-69, one forward per list element). */
+typedef struct fo1_img_seg { int32_t in_row0, H, W, out_row0, Ho, Wo, aux0, aux1; } fo1_img_seg;
+int fo1_dwconv3x3_ln_var_bf16(const void* x, const void* weight9c, const void* bias, void* y, const void* ln_weight, const void* ln_bias,
+                              float ln_eps, void* h, const void* segs, int n_img, int max_pixels, long long total_pixels, int C, void* stream);
+int fo1_im2col_var_bf16(const void* x, void* col, const void* segs, int n_img, int max_out_pixels, long long total_out_pixels, int C, int KH, int KW,
+                        int stride, int pad, int ld_col, void* stream);
+int fo1_window_partition_var_bf16(const void* x, void* xw, const void* segs, int n_img, int max_window_rows, long long total_window_rows, int C,
+                                  int ws, void* stream);
+int fo1_window_reverse_add_var_bf16(const void* yw, const void* shortcut, void* y, const void* segs, int n_img, int max_pixels, long long total_pixels,
+                                    int C, int ws, void* stream);
+size_t fo1_channel_attention_var_workspace_bytes(int max_tokens, int C, int n_img);
+int fo1_channel_attention_var_bf16(const void* qkv, int ld, const void* segs, int n_img, int max_tokens, long long total_tokens, int C, void* out,
+                                   int ldo, void* workspace, size_t workspace_bytes, void* stream);
+int fo1_pixel_shuffle2_var_bf16(const void* src, void* dst, const void* segs, int n_img, int max_pixels, long long total_pixels, int Co, void* stream);
+int fo1_maxpool2_var_bf16(const void* x, void* y, const void* segs, int n_img, int max_out_pixels, long long total_out_pixels, int C, void* stream);
 /* img: [batch, 3, H, W] */
 int fo1_nchw_to_hwc8_bf16(const void* img, int is_f32, void* out, int H, int W, int batch, void* stream);
 int fo1_gather_rows_bf16(const void* table0, int ld0, const void* table1, int ld1, const void* table2,

@@ -24,6 +24,11 @@ __device__ __forceinline__ uint4 pk8(const float (&f)[8]) {
 }
 __device__ __forceinline__ float rbf(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
+// Ragged image batches (images of DIFFERENT sizes packed row-wise into one map, include/fo1.h fo1_img_seg): when `segs` is given,
+// workgroup column blockIdx.y works on image blockIdx.y alone — its own H x W, its rows starting at in_row0 / out_row0 — with exactly
+// the per-image arithmetic of the same-size path (B = 1), so a packed ragged pass is bit-identical to the one-image passes.
+struct ImgSeg { int in_row0, H, W, out_row0, Ho, Wo, a0, a1; };
+
 // y[h,w,c] = x[h,w,c] + bf16( sum_{ky,kx} x[h+ky-1, w+kx-1, c] * wt[(ky*3+kx)*C + c] + bias[c] )
 __global__ __launch_bounds__(256) void dwconv3x3_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                         const uint16_t* __restrict__ bias, uint16_t* __restrict__ y, int H, int W, int C, int B) {
@@ -80,9 +85,16 @@ template <int PPW>
 __global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
                                                            const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
                                                            const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b,
-                                                           uint16_t* __restrict__ hout, int H, int W, int C, float eps, int B) {
+                                                           uint16_t* __restrict__ hout, int H, int W, int C, float eps, int B,
+                                                           const ImgSeg* __restrict__ segs) {
     constexpr int LPP = 64 / PPW;                              // lanes per pixel
     const int lane = threadIdx.x & 63, sub = lane % LPP;
+    if (segs) {
+        const ImgSeg sg = segs[blockIdx.y];
+        H = sg.H; W = sg.W; B = 1;
+        x += (long long)sg.in_row0 * C; y += (long long)sg.in_row0 * C; hout += (long long)sg.in_row0 * C;
+        if ((long long)blockIdx.x * 4 * PPW >= (long long)H * W) return;     // whole workgroup past this image (uniform: no shuffle is split)
+    }
     const int HW = H * W;
     int pix = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;      // global pixel over the B images
     const bool live = pix < B * HW;
@@ -165,7 +177,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __res
 
 // col[(oy*Wo+ox), (ky*KW+kx)*C + c] = x[oy*s-p+ky, ox*s-p+kx, c]  (0 outside); row stride ldc >= KH*KW*C
 __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ col, int H, int W, int C,
-                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int ldc, int B) {
+                                                     int KH, int KW, int stride, int pad, int Ho, int Wo, int ldc, int B,
+                                                     const ImgSeg* __restrict__ segs) {
+    if (segs) {
+        const ImgSeg sg = segs[blockIdx.y];
+        H = sg.H; W = sg.W; Ho = sg.Ho; Wo = sg.Wo; B = 1;
+        x += (long long)sg.in_row0 * C; col += (long long)sg.out_row0 * ldc;
+    }
     const int chunks = C >> 3;
     const int kk = KH * KW;
     const int HoWo = Ho * Wo;
@@ -187,7 +205,12 @@ __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict_
 
 // xw[(wy*nWx + wx)*ws*ws + iy*ws + ix, c] = x[wy*ws+iy, wx*ws+ix, c]  (0 when outside HxW)
 __global__ __launch_bounds__(256) void window_partition_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ xw, int H, int W,
-                                                               int C, int ws, int nWy, int nWx, int B) {
+                                                               int C, int ws, int nWy, int nWx, int B, const ImgSeg* __restrict__ segs) {
+    if (segs) {
+        const ImgSeg sg = segs[blockIdx.y];                      // Ho / Wo = window counts, out_row0 = first window row of the image
+        H = sg.H; W = sg.W; nWy = sg.Ho; nWx = sg.Wo; B = 1;
+        x += (long long)sg.in_row0 * C; xw += (long long)sg.out_row0 * C;
+    }
     const int chunks = C >> 3;
     const int nW = nWy * nWx;
     const long long total = (long long)B * nW * ws * ws * chunks;
@@ -208,7 +231,12 @@ __global__ __launch_bounds__(256) void window_partition_kernel(const uint16_t* _
 // y[h,w,c] = shortcut[h,w,c] + yw[window row of (h,w), c]
 __global__ __launch_bounds__(256) void window_reverse_add_kernel(const uint16_t* __restrict__ yw, const uint16_t* __restrict__ shortcut,
                                                                  uint16_t* __restrict__ y, int H, int W, int C, int ws, int nWx, int nW,
-                                                                 int B) {
+                                                                 int B, const ImgSeg* __restrict__ segs) {
+    if (segs) {
+        const ImgSeg sg = segs[blockIdx.y];
+        H = sg.H; W = sg.W; nWx = sg.Wo; nW = sg.Ho * sg.Wo; B = 1;
+        yw += (long long)sg.out_row0 * C; shortcut += (long long)sg.in_row0 * C; y += (long long)sg.in_row0 * C;
+    }
     const int chunks = C >> 3;
     const int HW = H * W;
     const long long total = (long long)B * HW * chunks;
@@ -231,11 +259,18 @@ __global__ __launch_bounds__(256) void window_reverse_add_kernel(const uint16_t*
 // qkv: [N, 3C] rows = [q | k | v].  Phase 1: partial Gram matrices over token chunks.
 //   part[chunk][g][c][c'] = sum_{n in chunk} q[n, g*32+c] * k[n, g*32+c']      (fp32)
 constexpr int kCaTok = 512;  // tokens per chunk
-__global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, float* __restrict__ part,
+                                                          const ImgSeg* __restrict__ segs) {
     __shared__ float sq[64][33];
     __shared__ float sk[64][33];
     const int g = blockIdx.y, chunk = blockIdx.x, G = gridDim.y;
-    qkv += (long long)blockIdx.z * N * ld;                       // image blockIdx.z of the batch: rows [z*N, (z+1)*N)
+    if (segs) {                                                  // ragged: image z has its own token count (H = N_z) and first row
+        N = segs[blockIdx.z].H;
+        qkv += (long long)segs[blockIdx.z].in_row0 * ld;
+        if (chunk * kCaTok >= N) return;                         // gridDim.x covers the LARGEST image's chunks
+    } else {
+        qkv += (long long)blockIdx.z * N * ld;                   // image blockIdx.z of the batch: rows [z*N, (z+1)*N)
+    }
     part += (long long)blockIdx.z * gridDim.x * G * 1024;
     const int tid = threadIdx.x;
     const int ci = tid >> 4, cj = tid & 15;  // thread owns the 2x2 block (2ci..2ci+1, 2cj..2cj+1)
@@ -275,11 +310,16 @@ __global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __rest
 // One 1024-thread workgroup per group: thread (r, c) sums its element over the chunks in a fixed order
 // (4 independent loads in flight), rows are 32-lane halves of a wave.
 __global__ __launch_bounds__(1024) void chattn_softmax_kernel(const float* __restrict__ part, int n_chunks, int G, float scale,
-                                                              float* __restrict__ A) {
+                                                              float* __restrict__ A, const ImgSeg* __restrict__ segs) {
     const int g = blockIdx.x, tid = threadIdx.x;
     const int r = tid >> 5, c = tid & 31;
     const long long stride = (long long)G * 1024;
-    part += (long long)blockIdx.y * n_chunks * G * 1024;         // image blockIdx.y
+    part += (long long)blockIdx.y * n_chunks * G * 1024;         // image blockIdx.y (n_chunks = the allocation's chunk slots per image)
+    if (segs) {                                                  // ragged: this image's own chunk count and q * N^-0.5 (modeling_davit.py:165)
+        const int N = segs[blockIdx.y].H;
+        n_chunks = (N + kCaTok - 1) / kCaTok;
+        scale = 1.0f / sqrtf((float)N);
+    }
     A += (long long)blockIdx.y * G * 1024;
     const float* p = part + ((long long)g * 32 + r) * 32 + c;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -304,12 +344,18 @@ __global__ __launch_bounds__(1024) void chattn_softmax_kernel(const float* __res
 
 // Phase 3: out[n, g*32 + c] = bf16( sum_c' A[g][c][c'] * v[n, g*32 + c'] )
 __global__ __launch_bounds__(256) void chattn_apply_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, const float* __restrict__ A,
-                                                           uint16_t* __restrict__ out, int ldo) {
+                                                           uint16_t* __restrict__ out, int ldo, const ImgSeg* __restrict__ segs) {
     __shared__ float sA[32][33];
     __shared__ float sv[8][33];
     const int g = blockIdx.y, tid = threadIdx.x;
-    qkv += (long long)blockIdx.z * N * ld;                       // image blockIdx.z
-    out += (long long)blockIdx.z * N * ldo;
+    if (segs) {
+        N = segs[blockIdx.z].H;
+        qkv += (long long)segs[blockIdx.z].in_row0 * ld;
+        out += (long long)segs[blockIdx.z].in_row0 * ldo;
+    } else {
+        qkv += (long long)blockIdx.z * N * ld;                   // image blockIdx.z
+        out += (long long)blockIdx.z * N * ldo;
+    }
     A += (long long)blockIdx.z * gridDim.y * 1024;
     for (int t = tid; t < 1024; t += 256) sA[t >> 5][t & 31] = A[(long long)g * 1024 + t];
     const int tl = tid >> 5, c = tid & 31;  // 8 tokens per pass, 32 output channels
@@ -326,7 +372,13 @@ __global__ __launch_bounds__(256) void chattn_apply_kernel(const uint16_t* __res
 }
 
 // dst[(2y+dy)*2W + 2x+dx, co] = src[y*W + x, (dy*2+dx)*Co + co]
-__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int H, int W, int Co, int B) {
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int H, int W, int Co, int B,
+                                                             const ImgSeg* __restrict__ segs) {
+    if (segs) {
+        const ImgSeg sg = segs[blockIdx.y];
+        H = sg.H; W = sg.W; B = 1;
+        src += (long long)sg.in_row0 * 4 * Co; dst += (long long)sg.out_row0 * Co;
+    }
     const int chunks = Co >> 3;
     const int HW = H * W;
     const long long total = (long long)B * HW * 4 * chunks;
@@ -344,7 +396,13 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const uint16_t* __r
 }
 
 // y[oy, ox, c] = max over the 2x2 window (floor mode: Ho = H/2, Wo = W/2)
-__global__ __launch_bounds__(256) void maxpool2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int H, int W, int C, int B) {
+__global__ __launch_bounds__(256) void maxpool2_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ y, int H, int W, int C, int B,
+                                                       const ImgSeg* __restrict__ segs) {
+    if (segs) {
+        const ImgSeg sg = segs[blockIdx.y];
+        H = sg.H; W = sg.W; B = 1;
+        x += (long long)sg.in_row0 * C; y += (long long)sg.out_row0 * C;
+    }
     const int Ho = H / 2, Wo = W / 2, chunks = C >> 3;
     const long long total = (long long)B * Ho * Wo * chunks;
     for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -424,15 +482,15 @@ int fo1_dwconv3x3_ln_bf16(const void* x, const void* weight9c, const void* bias,
     if (chunks <= 16) {
         FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<4>, dim3(cdiv(npix, 16)), dim3(256), 0, (hipStream_t)stream,
                    (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
-                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch);
+                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch, (const ImgSeg*)nullptr);
     } else if (chunks <= 32) {
         FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<2>, dim3(cdiv(npix, 8)), dim3(256), 0, (hipStream_t)stream,
                    (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
-                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch);
+                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch, (const ImgSeg*)nullptr);
     } else {
         FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<1>, dim3(cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream,
                    (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
-                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch);
+                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch, (const ImgSeg*)nullptr);
     }
     return FO1_OK;
 }
@@ -444,7 +502,7 @@ int fo1_im2col_bf16(const void* x, void* col, int H, int W, int C, int KH, int K
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (W + 2 * pad - KW) / stride + 1;
     FO1_CHECK_ARG(Ho > 0 && Wo > 0 && ld_col >= KH * KW * C && ld_col % 8 == 0 && batch >= 1, "im2col: bad output shape");
     FO1_LAUNCH("im2col", (double)batch * Ho * Wo * KH * KW * C * 4.0, im2col_kernel, dim3(grid_for((long long)batch * Ho * Wo * KH * KW * (C / 8))),
-               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)col, H, W, C, KH, KW, stride, pad, Ho, Wo, ld_col, batch);
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)col, H, W, C, KH, KW, stride, pad, Ho, Wo, ld_col, batch, (const ImgSeg*)nullptr);
     return FO1_OK;
 }
 
@@ -454,7 +512,7 @@ int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int 
     const int nWy = cdiv(H, ws), nWx = cdiv(W, ws);
     FO1_LAUNCH("window_partition", (double)batch * nWy * nWx * ws * ws * C * 4.0, window_partition_kernel,
                dim3(grid_for((long long)batch * nWy * nWx * ws * ws * (C / 8))), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
-               (uint16_t*)xw, H, W, C, ws, nWy, nWx, batch);
+               (uint16_t*)xw, H, W, C, ws, nWy, nWx, batch, (const ImgSeg*)nullptr);
     return FO1_OK;
 }
 
@@ -463,7 +521,7 @@ int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, i
     FO1_CHECK_ARG(yw && shortcut && y && C % 8 == 0 && ws > 0 && batch >= 1, "window_reverse: bad arguments");
     FO1_LAUNCH("window_reverse_add", (double)batch * H * W * C * 6.0, window_reverse_add_kernel, dim3(grid_for((long long)batch * H * W * (C / 8))),
                dim3(256), 0, (hipStream_t)stream, (const uint16_t*)yw, (const uint16_t*)shortcut, (uint16_t*)y, H, W, C, ws, cdiv(W, ws),
-               cdiv(H, ws) * cdiv(W, ws), batch);
+               cdiv(H, ws) * cdiv(W, ws), batch, (const ImgSeg*)nullptr);
     return FO1_OK;
 }
 
@@ -484,14 +542,14 @@ int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out,
     float* part = (float*)workspace;
     float* A = part + (size_t)batch * chunks * G * 1024;
     hipStream_t st = (hipStream_t)stream;
-    FO1_LAUNCH("chattn_gram", (double)batch * N * C * 4.0, chattn_gram_kernel, dim3(chunks, G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part);
+    FO1_LAUNCH("chattn_gram", (double)batch * N * C * 4.0, chattn_gram_kernel, dim3(chunks, G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part, (const ImgSeg*)nullptr);
     // reference: q * N^-0.5 (modeling_davit.py:165)
     FO1_LAUNCH("chattn_softmax", (double)batch * chunks * G * 4096.0, chattn_softmax_kernel, dim3(G, batch), dim3(1024), 0, st, (const float*)part, chunks, G,
-               1.0f / sqrtf((float)N), A);
+               1.0f / sqrtf((float)N), A, (const ImgSeg*)nullptr);
     int gx = cdiv(N, 8);
     if (gx > 512) gx = 512;
     FO1_LAUNCH("chattn_apply", (double)batch * N * C * 4.0, chattn_apply_kernel, dim3(gx, G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C,
-               (const float*)A, (uint16_t*)out, ldo);
+               (const float*)A, (uint16_t*)out, ldo, (const ImgSeg*)nullptr);
     return FO1_OK;
 }
 
@@ -499,7 +557,7 @@ int fo1_pixel_shuffle2_bf16(const void* src, void* dst, int H, int W, int Co, in
     using namespace fo1;
     FO1_CHECK_ARG(src && dst && Co > 0 && Co % 8 == 0 && batch >= 1, "pixel_shuffle: bad arguments");
     FO1_LAUNCH("pixel_shuffle2", (double)batch * H * W * 4 * Co * 4.0, pixel_shuffle2_kernel, dim3(grid_for((long long)batch * H * W * 4 * (Co / 8))),
-               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst, H, W, Co, batch);
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst, H, W, Co, batch, (const ImgSeg*)nullptr);
     return FO1_OK;
 }
 
@@ -507,7 +565,7 @@ int fo1_maxpool2_bf16(const void* x, void* y, int H, int W, int C, int batch, vo
     using namespace fo1;
     FO1_CHECK_ARG(x && y && C % 8 == 0 && H >= 2 && W >= 2 && batch >= 1, "maxpool: bad arguments");
     FO1_LAUNCH("maxpool2", (double)batch * H * W * C * 2.5, maxpool2_kernel, dim3(grid_for((long long)batch * (H / 2) * (W / 2) * (C / 8))), dim3(256), 0,
-               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, H, W, C, batch);
+               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, H, W, C, batch, (const ImgSeg*)nullptr);
     return FO1_OK;
 }
 
@@ -531,6 +589,108 @@ int fo1_gather_rows_bf16(const void* table0, int ld0, const void* table1, int ld
     FO1_LAUNCH("gather_rows", (double)R * D * 4.0, gather_rows_kernel, dim3(grid_for((long long)R * (D / 8))), dim3(256), 0,
                (hipStream_t)stream, (const uint16_t*)table0, (const uint16_t*)table1, (const uint16_t*)table2, ld0, ld1, ld2, plan,
                (uint16_t*)out, ldo, R, D);
+    return FO1_OK;
+}
+
+// ---- ragged image batches: the same kernels, one workgroup column per image (fo1_img_seg table in device memory) ----------------
+static int check_segs(const void* segs, int n_img, const char* what) {
+    using namespace fo1;
+    FO1_CHECK_ARG(segs && n_img >= 1 && n_img <= 65535, "%s: need a device fo1_img_seg table with 1..65535 images", what);
+    return FO1_OK;
+}
+
+int fo1_dwconv3x3_ln_var_bf16(const void* x, const void* weight9c, const void* bias, void* y, const void* ln_weight, const void* ln_bias,
+                              float ln_eps, void* h, const void* segs, int n_img, int max_pixels, long long total_pixels, int C, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && weight9c && bias && y && ln_weight && ln_bias && h && x != y && x != h && y != h, "dwconv_ln_var: NULL operand or aliased buffers");
+    if (int rc = check_segs(segs, n_img, "dwconv_ln_var")) return rc;
+    FO1_CHECK_ARG(max_pixels > 0 && C > 0 && C % 8 == 0 && C <= 64 * kDwLnChunks * 8, "dwconv_ln_var: bad shape (C <= 2048)");
+    const int chunks = C / 8;
+    const ImgSeg* sg = (const ImgSeg*)segs;
+    const double work = (double)total_pixels * C * 6.0;
+#define FO1_DWLN_VAR(PPW, PIXPB) \
+    FO1_LAUNCH("dwconv3x3_ln", work, dwconv3x3_ln_kernel<PPW>, dim3(cdiv(max_pixels, PIXPB), n_img), dim3(256), 0, (hipStream_t)stream, \
+               (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight, \
+               (const uint16_t*)ln_bias, (uint16_t*)h, 0, 0, C, ln_eps, 1, sg)
+    if (chunks <= 16) { FO1_DWLN_VAR(4, 16); } else if (chunks <= 32) { FO1_DWLN_VAR(2, 8); } else { FO1_DWLN_VAR(1, 4); }
+#undef FO1_DWLN_VAR
+    return FO1_OK;
+}
+
+int fo1_im2col_var_bf16(const void* x, void* col, const void* segs, int n_img, int max_out_pixels, long long total_out_pixels, int C, int KH, int KW,
+                        int stride, int pad, int ld_col, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && col, "im2col_var: NULL operand");
+    if (int rc = check_segs(segs, n_img, "im2col_var")) return rc;
+    FO1_CHECK_ARG(C > 0 && C % 8 == 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0 && ld_col >= KH * KW * C && ld_col % 8 == 0 && max_out_pixels > 0,
+                  "im2col_var: bad parameters");
+    FO1_LAUNCH("im2col", (double)total_out_pixels * KH * KW * C * 4.0, im2col_kernel, dim3(grid_for((long long)max_out_pixels * KH * KW * (C / 8)), n_img),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)col, 0, 0, C, KH, KW, stride, pad, 0, 0, ld_col, 1, (const ImgSeg*)segs);
+    return FO1_OK;
+}
+
+int fo1_window_partition_var_bf16(const void* x, void* xw, const void* segs, int n_img, int max_window_rows, long long total_window_rows, int C, int ws,
+                                  void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && xw && C % 8 == 0 && ws > 0 && max_window_rows > 0, "window_partition_var: bad arguments");
+    if (int rc = check_segs(segs, n_img, "window_partition_var")) return rc;
+    FO1_LAUNCH("window_partition", (double)total_window_rows * C * 4.0, window_partition_kernel, dim3(grid_for((long long)max_window_rows * (C / 8)), n_img),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)xw, 0, 0, C, ws, 0, 0, 1, (const ImgSeg*)segs);
+    return FO1_OK;
+}
+
+int fo1_window_reverse_add_var_bf16(const void* yw, const void* shortcut, void* y, const void* segs, int n_img, int max_pixels, long long total_pixels,
+                                    int C, int ws, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(yw && shortcut && y && C % 8 == 0 && ws > 0 && max_pixels > 0, "window_reverse_var: bad arguments");
+    if (int rc = check_segs(segs, n_img, "window_reverse_var")) return rc;
+    FO1_LAUNCH("window_reverse_add", (double)total_pixels * C * 6.0, window_reverse_add_kernel, dim3(grid_for((long long)max_pixels * (C / 8)), n_img),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)yw, (const uint16_t*)shortcut, (uint16_t*)y, 0, 0, C, ws, 0, 0, 1, (const ImgSeg*)segs);
+    return FO1_OK;
+}
+
+size_t fo1_channel_attention_var_workspace_bytes(int max_tokens, int C, int n_img) { return fo1_channel_attention_workspace_bytes(max_tokens, C, n_img); }
+
+// qkv rows of n_img images of different token counts (segs[i].H = N_i tokens from row segs[i].in_row0): every image its own 32 x 32
+// per-group attention matrices and its own q * N_i^-0.5
+int fo1_channel_attention_var_bf16(const void* qkv, int ld, const void* segs, int n_img, int max_tokens, long long total_tokens, int C, void* out, int ldo,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(qkv && out && workspace, "channel_attention_var: NULL operand");
+    if (int rc = check_segs(segs, n_img, "channel_attention_var")) return rc;
+    FO1_CHECK_ARG(max_tokens > 0 && C > 0 && C % 32 == 0 && ld >= 3 * C && ld % 8 == 0 && ldo >= C, "channel_attention_var: bad shape");
+    if (workspace_bytes < fo1_channel_attention_workspace_bytes(max_tokens, C, n_img))
+        return set_err(FO1_ERR_WORKSPACE, "channel_attention_var: workspace too small");
+    const int G = C / 32, chunks = cdiv(max_tokens, kCaTok);
+    float* part = (float*)workspace;
+    float* A = part + (size_t)n_img * chunks * G * 1024;
+    hipStream_t st = (hipStream_t)stream;
+    const ImgSeg* sg = (const ImgSeg*)segs;
+    FO1_LAUNCH("chattn_gram", (double)total_tokens * C * 4.0, chattn_gram_kernel, dim3(chunks, G, n_img), dim3(256), 0, st, (const uint16_t*)qkv, ld, 0, C, part, sg);
+    FO1_LAUNCH("chattn_softmax", (double)n_img * chunks * G * 4096.0, chattn_softmax_kernel, dim3(G, n_img), dim3(1024), 0, st, (const float*)part, chunks, G,
+               0.f, A, sg);
+    int gx = cdiv(max_tokens, 8);
+    if (gx > 512) gx = 512;
+    FO1_LAUNCH("chattn_apply", (double)total_tokens * C * 4.0, chattn_apply_kernel, dim3(gx, G, n_img), dim3(256), 0, st, (const uint16_t*)qkv, ld, 0, C,
+               (const float*)A, (uint16_t*)out, ldo, sg);
+    return FO1_OK;
+}
+
+int fo1_pixel_shuffle2_var_bf16(const void* src, void* dst, const void* segs, int n_img, int max_pixels, long long total_pixels, int Co, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(src && dst && Co > 0 && Co % 8 == 0 && max_pixels > 0, "pixel_shuffle_var: bad arguments");
+    if (int rc = check_segs(segs, n_img, "pixel_shuffle_var")) return rc;
+    FO1_LAUNCH("pixel_shuffle2", (double)total_pixels * 4 * Co * 4.0, pixel_shuffle2_kernel, dim3(grid_for((long long)max_pixels * 4 * (Co / 8)), n_img),
+               dim3(256), 0, (hipStream_t)stream, (const uint16_t*)src, (uint16_t*)dst, 0, 0, Co, 1, (const ImgSeg*)segs);
+    return FO1_OK;
+}
+
+int fo1_maxpool2_var_bf16(const void* x, void* y, const void* segs, int n_img, int max_out_pixels, long long total_out_pixels, int C, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(x && y && C % 8 == 0 && max_out_pixels > 0, "maxpool_var: bad arguments");
+    if (int rc = check_segs(segs, n_img, "maxpool_var")) return rc;
+    FO1_LAUNCH("maxpool2", (double)total_out_pixels * 4 * C * 2.5, maxpool2_kernel, dim3(grid_for((long long)max_out_pixels * (C / 8)), n_img), dim3(256), 0,
+               (hipStream_t)stream, (const uint16_t*)x, (uint16_t*)y, 0, 0, C, 1, (const ImgSeg*)segs);
     return FO1_OK;
 }
 

@@ -111,6 +111,72 @@ class DaViT:
         x = ops.gemm(a, d["proj_w"], d["proj_b"], residual=x)
         return self._conv_ffn(x, H, W, d, B)
 
+    # ---- ragged batches: images of different sizes in ONE pass (row-wise packing, per-image geometry tables) ------------------------
+    def ragged_plan(self, sizes: Sequence[Tuple[int, int]]) -> "RaggedAuxPlan":
+        key = tuple((int(h), int(w)) for h, w in sizes)
+        plans = self.__dict__.setdefault("_rplans", {})
+        pl = plans.get(key)
+        if pl is None:
+            if len(plans) >= 64:
+                plans.pop(next(iter(plans)))
+            pl = plans[key] = RaggedAuxPlan(key, self.cfg, self.dev)
+        return pl
+
+    def _conv_ffn_var(self, x, pix, d):
+        x, h = ops.dwconv3x3_res_ln_var(x, d["conv2_w"], d["conv2_b"], pix, d["fn_w"], d["fn_b"], 1e-5)
+        h = ops.gemm(h, d["fc1_w"], d["fc1_b"], act=ops.ACT_GELU)
+        return ops.gemm(h, d["fc2_w"], d["fc2_b"], residual=x)
+
+    def _spatial_var(self, x, lv, C, heads, d):
+        ws = self.cfg["window"]
+        x, h = ops.dwconv3x3_res_ln_var(x, d["conv1_w"], d["conv1_b"], lv["pix"], d["an_w"], d["an_b"], 1e-5)
+        hw = ops.window_partition_var(h, lv["win"], ws)         # per image zero-padded AFTER the norm, like the reference (:248-251)
+        qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
+        n = hw.shape[0]
+        n_pad = _round_up(n, 64)
+        vt = ops._workspace(f"davit_vt_{C}x{n_pad}", x.device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
+        ops.transpose_into(qkv[:, 2 * C:], vt, 0)
+        hd = C // heads
+        items = self._window_items(n // (ws * ws), ws * ws, heads)
+        att = ops.attention(qkv[:, :C], qkv[:, C:2 * C], vt, items, heads, heads, hd, float(hd) ** -0.5, False, flops=4.0 * C * n * ws * ws)
+        y = ops.gemm(att, d["proj_w"], d["proj_b"])
+        x = ops.window_reverse_add_var(y, x, lv["win"], ws)
+        return self._conv_ffn_var(x, lv["pix"], d)
+
+    def _channel_var(self, x, lv, C, d):
+        x, h = ops.dwconv3x3_res_ln_var(x, d["conv1_w"], d["conv1_b"], lv["pix"], d["an_w"], d["an_b"], 1e-5)
+        qkv = ops.gemm(h, d["qkv_w"], d["qkv_b"])
+        a = ops.channel_attention_var(qkv, C, lv["tok"])
+        x = ops.gemm(a, d["proj_w"], d["proj_b"], residual=x)
+        return self._conv_ffn_var(x, lv["pix"], d)
+
+    def forward_ragged(self, imgs: Sequence[torch.Tensor]):
+        """imgs: [3,H_b,W_b] device tensors of DIFFERENT sizes -> ([4 token-major maps [sum_b H_ib*W_ib, C_i] bf16, image b at rows
+        plan.row0[i][b] ...], plan (RaggedAuxPlan: per level sizes[i][b], row0[i][b])).  Same launches as forward(), every GEMM /
+        LayerNorm over the rows of ALL images, the spatial kernels per image through the geometry tables: each image's maps are
+        bit-identical to its one-image pass when the GEMM tile is pinned (tests/test_ragged_towers_gpu.py).  The reference runs the
+        tower image by image (davit_aux_encoder.py:54-69)."""
+        cfg = self.cfg
+        plan = self.ragged_plan([tuple(im.shape[-2:]) for im in imgs])
+        x = torch.empty(plan.total_in, 8, dtype=torch.bfloat16, device=self.dev)
+        for im, r0, (H, W) in zip(imgs, plan.in_row0, plan.in_sizes):
+            ops.nchw_to_hwc8(im.contiguous(), out=x[r0:r0 + H * W])
+        outs = []
+        for i, C in enumerate(cfg["dims"]):
+            cv, lv = self.convs[i], plan.levels[i]
+            k, s, p = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
+            if i > 0 and cfg["patch_prenorm"][i]:
+                x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
+            col = ops.im2col_var(x, lv["conv"], k, k, s, p, ld=cv["Kp"])
+            x = ops.gemm(col, cv["w"], cv["b"])
+            if i == 0 or not cfg["patch_prenorm"][i]:
+                x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
+            for blk in self.blocks[i]:
+                x = self._spatial_var(x, lv, C, cfg["heads"][i], blk["spatial_block"])
+                x = self._channel_var(x, lv, C, blk["channel_block"])
+            outs.append(x)
+        return outs, plan
+
     def forward(self, img: torch.Tensor):
         """img [3,H,W] or [B,3,H,W] (device, bf16/fp32, CLIP-normalised; B same-size images in one pass).  Returns
         ([4 token-major maps [B*H_i*W_i, C_i] bf16 — image b at rows [b*H_i*W_i, (b+1)*H_i*W_i)], [(H_i, W_i)])."""
@@ -139,3 +205,44 @@ class DaViT:
             outs.append(x)
             sizes.append((H, W))
         return outs, sizes
+
+
+class RaggedAuxPlan:
+    """Geometry tables (ops.ImgSegs) of a ragged DaViT pass over images of sizes [(H_b, W_b)]: per stage i the conv-embed table
+    (previous level -> this level), the pixel table, the window table (ws = 12: windows down / across, first window row) and the
+    token table of the channel attention.  sizes[i][b] = (H_ib, W_ib), row0[i][b] = first row of image b in the level-i map."""
+
+    def __init__(self, sizes, cfg, device):
+        self.in_sizes = list(sizes)
+        self.in_row0, off = [], 0
+        for H, W in sizes:
+            self.in_row0.append(off)
+            off += H * W
+        self.total_in = off
+        ws = cfg["window"]
+        self.sizes, self.row0, self.levels = [], [], []
+        prev_sizes, prev_row0 = self.in_sizes, self.in_row0
+        for i in range(len(cfg["dims"])):
+            k, s, p = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
+            cur = [((H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1) for H, W in prev_sizes]
+            r0, off = [], 0
+            for h, w in cur:
+                r0.append(off)
+                off += h * w
+            npx = [h * w for h, w in cur]
+            nwin = [(-(-h // ws), -(-w // ws)) for h, w in cur]
+            wr0, woff = [], 0
+            for a, b in nwin:
+                wr0.append(woff)
+                woff += a * b * ws * ws
+            pin = [h * w for h, w in prev_sizes]
+            conv = ops.ImgSegs([(pr, ph, pw, r, h, w) for pr, (ph, pw), r, (h, w) in zip(prev_row0, prev_sizes, r0, cur)], device,
+                               max(pin), sum(pin), max(npx), sum(npx))
+            pix = ops.ImgSegs([(r, h, w) for r, (h, w) in zip(r0, cur)], device, max(npx), sum(npx), max(npx), sum(npx))
+            win = ops.ImgSegs([(r, h, w, wr, a, b) for r, (h, w), wr, (a, b) in zip(r0, cur, wr0, nwin)], device, max(npx), sum(npx),
+                              max(a * b * ws * ws for a, b in nwin), woff)
+            tok = ops.ImgSegs([(r, n) for r, n in zip(r0, npx)], device, max(npx), sum(npx), max(npx), sum(npx))
+            self.levels.append(dict(conv=conv, pix=pix, win=win, tok=tok))
+            self.sizes.append(cur)
+            self.row0.append(r0)
+            prev_sizes, prev_row0 = cur, r0

@@ -56,6 +56,46 @@ class SimpleFPN:
         y = ops.gemm(col, h["w3"])
         return ops.layernorm(y, h["n3"][0], h["n3"][1], 1e-6)
 
+    # ---- ragged batches: maps of different grids packed row-wise ----------------------------------------------------------------
+    def ragged_plan(self, grids, row0) -> "RaggedFpnPlan":
+        key = (tuple((int(a), int(b)) for a, b in grids), tuple(int(r) for r in row0))
+        plans = self.__dict__.setdefault("_rplans", {})
+        pl = plans.get(key)
+        if pl is None:
+            if len(plans) >= 64:
+                plans.pop(next(iter(plans)))
+            pl = plans[key] = RaggedFpnPlan(key[0], key[1], self.dev)
+        return pl
+
+    def _head_var(self, x, sg, h):
+        y = ops.gemm(x, h["w1"])
+        y = ops.layernorm(y, h["n1"][0], h["n1"][1], 1e-6)
+        col = ops.im2col_var(y, sg, 3, 3, 1, 1)
+        y = ops.gemm(col, h["w3"])
+        return ops.layernorm(y, h["n3"][0], h["n3"][1], 1e-6)
+
+    def forward_ragged(self, x: torch.Tensor, grids, row0):
+        """x [sum gh_b*gw_b, 1280] token-major raster maps of images with DIFFERENT grids (image b at rows row0[b]...) -> (4 maps
+        [sum .., 512], plan with sizes[l][b] / row0[l][b]).  Same launches as forward(); every image bit-identical to its own pass."""
+        pl = self.ragged_plan(grids, row0)
+
+        def up(y, sg, t):
+            w, b, cout = t
+            return ops.pixel_shuffle2_var(ops.gemm(y, w, b), sg, cout)
+
+        outs = []
+        y = up(x, pl.up_1a, self.t1a)
+        y = ops.layernorm(y, self.t1_ln[0], self.t1_ln[1], 1e-6)
+        y = ops.bias_act(y, None, 1)
+        y = up(y, pl.up_1b, self.t1b)
+        outs.append(self._head_var(y, pl.conv[0], self.heads[0]))
+        y = up(x, pl.up_1a, self.t2)
+        outs.append(self._head_var(y, pl.conv[1], self.heads[1]))
+        outs.append(self._head_var(x, pl.conv[2], self.heads[2]))
+        y = ops.maxpool2_var(x, pl.pool)
+        outs.append(self._head_var(y, pl.conv[3], self.heads[3]))
+        return outs, pl
+
     def forward(self, x: torch.Tensor, H: int, W: int, batch: int = 1) -> Tuple[List[torch.Tensor], List[Tuple[int, int]]]:
         """x [batch*H*W, 1280] token-major bf16 (same-size maps stacked) -> 4 token-major maps [batch*.., 512] at (4H,4W),
         (2H,2W), (H,W), (H/2,W/2); image b owns rows [b*h*w, (b+1)*h*w) of every level."""
@@ -75,3 +115,43 @@ class SimpleFPN:
         y = ops.maxpool2(x, H, W, batch=B)
         outs.append(self._head(y, H // 2, W // 2, self.heads[3], B)); sizes.append((H // 2, W // 2))
         return outs, sizes
+
+
+class RaggedFpnPlan:
+    """Geometry tables of a ragged SimpleFPN pass: grids[b] = (gh, gw) of image b whose raster map starts at row0[b] of the input.
+    sizes[l][b] / row0[l][b] describe output level l (strides 3.5, 7, 14, 28: 4x, 2x, 1x, 1/2 of the grid)."""
+
+    def __init__(self, grids, row0, device):
+        B = len(grids)
+
+        def pack(sz):
+            r, off = [], 0
+            for h, w in sz:
+                r.append(off)
+                off += h * w
+            return r, off
+
+        g1 = list(grids)
+        g2 = [(2 * h, 2 * w) for h, w in g1]
+        g4 = [(4 * h, 4 * w) for h, w in g1]
+        gh = [(h // 2, w // 2) for h, w in g1]
+        r1 = list(row0)
+        n1 = [h * w for h, w in g1]
+        self.contiguous_input = all(r1[i] + n1[i] == (r1[i + 1] if i + 1 < B else r1[i] + n1[i]) for i in range(B)) and r1[0] == 0
+        if not self.contiguous_input:
+            raise ValueError("SimpleFPN.forward_ragged: the images' rows must be packed back to back (vit.BatchPlan order)")
+        r2, t2 = pack(g2)
+        r4, t4 = pack(g4)
+        rh, th = pack(gh)
+        n2, n4, nh = [h * w for h, w in g2], [h * w for h, w in g4], [h * w for h, w in gh]
+        S = ops.ImgSegs
+        self.up_1a = S([(a, h, w, b) for a, (h, w), b in zip(r1, g1, r2)], device, max(n1), sum(n1), max(n2), t2)        # grid -> 2x
+        self.up_1b = S([(a, h, w, b) for a, (h, w), b in zip(r2, g2, r4)], device, max(n2), t2, max(n4), t4)             # 2x -> 4x
+        self.pool = S([(a, h, w, b, h // 2, w // 2) for a, (h, w), b in zip(r1, g1, rh)], device, max(n1), sum(n1), max(nh), th)
+
+        def same(rr, gg, nn, tot):      # 3x3 / stride 1 / pad 1: output geometry = input geometry
+            return S([(a, h, w, a, h, w) for a, (h, w) in zip(rr, gg)], device, max(nn), tot, max(nn), tot)
+
+        self.conv = [same(r4, g4, n4, t4), same(r2, g2, n2, t2), same(r1, g1, n1, sum(n1)), same(rh, gh, nh, th)]
+        self.sizes = [g4, g2, g1, gh]
+        self.row0 = [r4, r2, r1, rh]

@@ -232,6 +232,15 @@ SIGNATURES = {
     "fo1_pixel_shuffle2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_maxpool2_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_nchw_to_hwc8_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "fo1_dwconv3x3_ln_var_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int,
+                                          c_longlong, c_int, c_void_p]),
+    "fo1_im2col_var_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_window_partition_var_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_int, c_void_p]),
+    "fo1_window_reverse_add_var_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_int, c_void_p]),
+    "fo1_channel_attention_var_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fo1_channel_attention_var_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_longlong, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "fo1_pixel_shuffle2_var_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_void_p]),
+    "fo1_maxpool2_var_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_longlong, c_int, c_void_p]),
     "fo1_gemv_batch_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong,
                                     c_void_p]),

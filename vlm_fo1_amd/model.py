@@ -228,8 +228,55 @@ class FO1Engine:
             n = hw[0] * hw[1]
             return t[b * n:(b + 1) * n].view(1, hw[0], hw[1], t.shape[1]).permute(0, 3, 1, 2)
 
-        groups = [idx] if uniform else [[i] for i in idx]
         row, ranges = 0, {}
+        if not uniform and len(idx) > 1 and self.RAGGED_TOWERS:
+            # images of different sizes: DaViT / SimpleFPN still run ONCE over all of them (rows packed image by image, the spatial
+            # kernels read per-image geometry tables: davit.forward_ragged / fpn.forward_ragged); HFRE per image on views of its rows
+            sel_aux = [auxs[i] for i in idx]
+            if self.cfg.mm_use_vt_region_feature_only:
+                aux_maps, aplan = [], None
+            else:
+                aux_maps, aplan = self.davit.forward_ragged(sel_aux)
+            self._mark("davit_large")
+            fplan = None
+            if self.fpn is not None:
+                if len(idx) == len(want):
+                    vt_sel, r0s = vt_last, [bp.row0[i] for i in idx]
+                else:       # only the requests that have regions: their raster maps, packed back to back
+                    parts = [vt_last[bp.row0[i]:bp.row0[i] + grids[i][0] * grids[i][1]] for i in idx]
+                    vt_sel, r0s, o = torch.cat(parts, 0), [], 0
+                    for t in parts:
+                        r0s.append(o)
+                        o += t.shape[0]
+                fpn_maps, fplan = self.fpn.forward_ragged(vt_sel, [grids[i] for i in idx], r0s)
+                self._mark("simple_fpn")
+
+            def view(t, r0, hw):
+                return t[r0:r0 + hw[0] * hw[1]].view(1, hw[0], hw[1], t.shape[1]).permute(0, 3, 1, 2)
+
+            for j, i in enumerate(idx):
+                gh, gw = grids[i]
+                H, W = auxs[i].shape[-2:]
+                sh, sw = (gh * p) / H, (gw * p) / W
+                aux_views = [view(t, aplan.row0[l][j], aplan.sizes[l][j]) for l, t in enumerate(aux_maps)]
+                r0 = bp.row0[i]
+                if not self.use_vt:
+                    vt_in = None
+                elif self.fpn is not None:
+                    fv = [view(t, fplan.row0[l][j], fplan.sizes[l][j]) for l, t in enumerate(fpn_maps)]
+                    self.hfre.simple_fpn = lambda x, v=fv: v
+                    vt_in = nchw(vt_last[r0:r0 + gh * gw], (gh, gw))
+                else:
+                    vt_in = [nchw(t[r0:r0 + gh * gw], (gh, gw)) for t in vt_last]
+                nb = boxes[i].shape[0]
+                self.hfre(aux_views, [boxes[i]], vt_in, None, vt_scale=(sw, sh), out=feat[row:row + nb])
+                ranges[i] = (row, row + nb)
+                row += nb
+            self._mark("hfre_region_pool")
+            out = self.mm_projector_aux(feat.to(torch.bfloat16))                               # :106-107
+            self._mark("mm_projector_aux")
+            return out, [ranges.get(i, (0, 0)) for i in range(len(want))]
+        groups = [idx] if uniform else [[i] for i in idx]
         for grp in groups:
             G = len(grp)
             aux = aux_stack if uniform else auxs[grp[0]].unsqueeze(0)
@@ -300,6 +347,7 @@ class FO1Engine:
             return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,
                         next_tokens=toks, region_ranges=ranges, row0=bp.row0)
 
+    RAGGED_TOWERS = True   # images of different sizes share one DaViT / SimpleFPN pass (False: image by image, the round-2 path; A/B)
     GRAPH_CACHE = 8        # captured prefill graphs kept per engine (LRU); each holds its own activation pool
     CAPTURE_AFTER = 1      # sightings of a signature before it is captured: one-off shapes (a dataset of ragged images) run eagerly
 

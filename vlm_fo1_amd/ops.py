@@ -668,15 +668,108 @@ def maxpool2(x: torch.Tensor, H: int, W: int, batch: int = 1) -> torch.Tensor:
     return y
 
 
-def nchw_to_hwc8(img: torch.Tensor) -> torch.Tensor:
-    """img [3,H,W] or [B,3,H,W] bf16/fp32 -> [B*H*W, 8] bf16."""
+# ---- ragged image batches: images of different sizes packed row-wise (include/fo1.h fo1_img_seg) ---------------------------------
+class ImgSegs:
+    """Per-operator geometry table of a ragged batch: host rows [(in_row0, H, W, out_row0, Ho, Wo)] -> device int32 [n, 8] + the sizes
+    the launch needs (largest image, totals).  Built once per batch signature (the tower plans cache them)."""
+
+    def __init__(self, rows, device, max_in: int, total_in: int, max_out: int, total_out: int):
+        t = torch.zeros(len(rows), 8, dtype=torch.int32)
+        for i, r in enumerate(rows):
+            t[i, :len(r)] = torch.tensor(r, dtype=torch.int32)
+        self.dev = t.to(device)
+        self.n = len(rows)
+        self.max_in, self.total_in, self.max_out, self.total_out = int(max_in), int(total_in), int(max_out), int(total_out)
+
+    @property
+    def ptr(self):
+        return self.dev.data_ptr()
+
+
+def dwconv3x3_res_ln_var(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, sg: ImgSegs, ln_w: torch.Tensor, ln_b: torch.Tensor, eps: float):
+    _chk(x, "x"); _chk(w9c, "w9c"); _chk(bias, "bias"); _chk(ln_w, "ln_w"); _chk(ln_b, "ln_b")
+    assert x.is_contiguous() and x.shape[0] == sg.total_in and w9c.shape == (9, x.shape[1]) and w9c.is_contiguous()
+    y, h = torch.empty_like(x), torch.empty_like(x)
+    _L.check(_L.load().fo1_dwconv3x3_ln_var_bf16(x.data_ptr(), w9c.data_ptr(), bias.data_ptr(), y.data_ptr(), ln_w.data_ptr(), ln_b.data_ptr(),
+                                                 float(eps), h.data_ptr(), sg.ptr, sg.n, sg.max_in, sg.total_in, x.shape[1], _stream()),
+             "fo1_dwconv3x3_ln_var_bf16")
+    return y, h
+
+
+def im2col_var(x: torch.Tensor, sg: ImgSegs, KH: int, KW: int, stride: int, pad: int, ld: Optional[int] = None) -> torch.Tensor:
+    _chk(x, "x")
+    assert x.is_contiguous() and x.shape[0] == sg.total_in
+    C = x.shape[1]
+    K = KH * KW * C
+    ld = ld or K
+    col = torch.zeros(sg.total_out, ld, dtype=torch.bfloat16, device=x.device) if ld != K else \
+        torch.empty(sg.total_out, ld, dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_im2col_var_bf16(x.data_ptr(), col.data_ptr(), sg.ptr, sg.n, sg.max_out, sg.total_out, C, KH, KW, stride, pad, ld, _stream()),
+             "fo1_im2col_var_bf16")
+    return col
+
+
+def window_partition_var(x: torch.Tensor, sg: ImgSegs, ws: int) -> torch.Tensor:
+    _chk(x, "x")
+    assert x.is_contiguous() and x.shape[0] == sg.total_in
+    xw = torch.empty(sg.total_out, x.shape[1], dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_window_partition_var_bf16(x.data_ptr(), xw.data_ptr(), sg.ptr, sg.n, sg.max_out, sg.total_out, x.shape[1], ws, _stream()),
+             "fo1_window_partition_var_bf16")
+    return xw
+
+
+def window_reverse_add_var(yw: torch.Tensor, shortcut: torch.Tensor, sg: ImgSegs, ws: int) -> torch.Tensor:
+    _chk(yw, "yw"); _chk(shortcut, "shortcut")
+    assert yw.is_contiguous() and shortcut.is_contiguous() and shortcut.shape[0] == sg.total_in and yw.shape[0] == sg.total_out
+    y = torch.empty_like(shortcut)
+    _L.check(_L.load().fo1_window_reverse_add_var_bf16(yw.data_ptr(), shortcut.data_ptr(), y.data_ptr(), sg.ptr, sg.n, sg.max_in, sg.total_in,
+                                                       shortcut.shape[1], ws, _stream()), "fo1_window_reverse_add_var_bf16")
+    return y
+
+
+def channel_attention_var(qkv: torch.Tensor, C: int, sg: ImgSegs) -> torch.Tensor:
+    """qkv [sum N_i, 3C]: per image, per 32-channel group attention over the image's own N_i tokens (sg rows: (row0, N_i))."""
+    _chk(qkv, "qkv")
+    p, ld, NB, _ = _rows(qkv, "qkv")
+    assert NB == sg.total_in
+    need = _L.load().fo1_channel_attention_var_workspace_bytes(sg.max_in, C, sg.n)
+    ws = _workspace("channel_attention", qkv.device, need)
+    out = torch.empty(NB, C, dtype=torch.bfloat16, device=qkv.device)
+    _L.check(_L.load().fo1_channel_attention_var_bf16(p, ld, sg.ptr, sg.n, sg.max_in, sg.total_in, C, out.data_ptr(), C, ws.data_ptr(), ws.numel(),
+                                                      _stream()), "fo1_channel_attention_var_bf16")
+    return out
+
+
+def pixel_shuffle2_var(src: torch.Tensor, sg: ImgSegs, Co: int) -> torch.Tensor:
+    _chk(src, "src")
+    assert src.is_contiguous() and src.shape == (sg.total_in, 4 * Co)
+    dst = torch.empty(sg.total_out, Co, dtype=torch.bfloat16, device=src.device)
+    _L.check(_L.load().fo1_pixel_shuffle2_var_bf16(src.data_ptr(), dst.data_ptr(), sg.ptr, sg.n, sg.max_in, sg.total_in, Co, _stream()),
+             "fo1_pixel_shuffle2_var_bf16")
+    return dst
+
+
+def maxpool2_var(x: torch.Tensor, sg: ImgSegs) -> torch.Tensor:
+    _chk(x, "x")
+    assert x.is_contiguous() and x.shape[0] == sg.total_in
+    y = torch.empty(sg.total_out, x.shape[1], dtype=torch.bfloat16, device=x.device)
+    _L.check(_L.load().fo1_maxpool2_var_bf16(x.data_ptr(), y.data_ptr(), sg.ptr, sg.n, sg.max_out, sg.total_out, x.shape[1], _stream()),
+             "fo1_maxpool2_var_bf16")
+    return y
+
+
+def nchw_to_hwc8(img: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """img [3,H,W] or [B,3,H,W] bf16/fp32 -> [B*H*W, 8] bf16 (into `out` when given: the image's rows of a packed ragged batch)."""
     if img.device.type != "cuda":
         raise _L.Fo1Error("nchw_to_hwc8: expected a HIP device tensor")
     if img.dim() == 3:
         img = img.unsqueeze(0)
     assert img.dim() == 4 and img.shape[1] == 3 and img.is_contiguous() and img.dtype in (torch.bfloat16, torch.float32)
     B, _, H, W = img.shape
-    out = torch.empty(B * H * W, 8, dtype=torch.bfloat16, device=img.device)
+    if out is None:
+        out = torch.empty(B * H * W, 8, dtype=torch.bfloat16, device=img.device)
+    else:
+        assert out.shape == (B * H * W, 8) and out.is_contiguous() and out.dtype == torch.bfloat16
     _L.check(_L.load().fo1_nchw_to_hwc8_bf16(img.data_ptr(), 1 if img.dtype == torch.float32 else 0, out.data_ptr(), H, W, B, _stream()),
              "fo1_nchw_to_hwc8_bf16")
     return out
