@@ -122,6 +122,71 @@ def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode
     return out
 
 
+def end_to_end_run(pipe, cases, steps, K=64):
+    """END-TO-END images/s ("images completed / wall time", decode K reported) in ONE timed loop per pass of len(cases)
+    images: resized uint8 images in pinned host memory -> upload -> device preprocessing of both towers (patchify / normalise,
+    fo1_patchify_u8_bf16 / fo1_normalize_u8_bf16) -> ONE packed prefill pass -> K greedy tokens per image in the batched device decode
+    loop (groups of BatchDecoder.MAX_BATCH sequences, stop rule on the device; random weights never emit a stop id, so every image
+    decodes exactly K tokens) -> generated ids on the host.  One host thread per engine replica / HIP stream (generate_batch blocks
+    on the ids), `len(pipe.engs)` passes in flight.  Outside: JPEG decode and the bicubic resize (PIL, host: the job of
+    sharded_eval.Prefetcher's threads) and tokenisation (cached prefix)."""
+    import threading
+    import numpy as np
+    from vlm_fo1.model.image_processing import IMAGENET_MEAN, IMAGENET_STD, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD, normalise_lut
+    from vlm_fo1_amd import ops
+    dev = pipe.eng.dev
+    rng = np.random.default_rng(7)
+    hosts = []
+    for c in cases:
+        H, W = c["img_hw"]
+        gh, gw = c["grid"]
+        prim = torch.from_numpy(rng.integers(0, 256, (gh * 14, gw * 14, 3), dtype=np.uint8)).pin_memory()     # after smart-resize
+        aux = torch.from_numpy(rng.integers(0, 256, (H, W, 3), dtype=np.uint8)).pin_memory()                   # 'dynamic': the image itself
+        hosts.append((prim, aux))
+    lut_p = normalise_lut(OPENAI_CLIP_MEAN, OPENAI_CLIP_STD).to(dev)
+    lut_a = normalise_lut(IMAGENET_MEAN, IMAGENET_STD).to(dev)
+    n_tok = [0]
+
+    def one_pass(slot):
+        eng = pipe.engs[slot]
+        with torch.cuda.stream(pipe.streams[slot]):
+            reqs = []
+            for c, (prim, aux) in zip(cases, hosts):
+                pu, au = prim.to(dev, non_blocking=True), aux.to(dev, non_blocking=True)
+                reqs.append(dict(ids=c["ids"], pix=ops.patchify_u8(pu, lut_p, 14, 2), grid=c["grid"], aux=ops.normalize_u8(au, lut_a), boxes=c["dev"]["boxes"]))
+            ids = eng.generate_batch(reqs, max_new_tokens=K, use_graph=True)
+            assert all(len(t) == K for t in ids)
+            return sum(len(t) for t in ids)
+
+    R = len(pipe.engs)
+    for slot in range(R):           # untimed: captures the decode graphs, sizes the decoder's slots
+        one_pass(slot)
+    torch.cuda.synchronize()
+    per = max(1, steps // R)
+
+    def worker(slot):
+        torch.cuda.set_device(dev)
+        for _ in range(per):
+            n = one_pass(slot)
+            n_tok[0] += n
+
+    t0 = time.perf_counter()
+    th = [threading.Thread(target=worker, args=(s,)) for s in range(R)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    n_img = per * R * len(cases)
+    from vlm_fo1_amd.llm import BatchDecoder
+    return dict(images_per_sec=round(n_img / el, 2), new_tokens_per_image=K, generated_tokens_per_sec=round(n_tok[0] / el, 1),
+                ms_per_pass=round(el / (per * R) * 1e3 * R, 3), passes_timed=per * R, images_per_pass=len(cases), passes_in_flight=R,
+                decode_group=BatchDecoder.MAX_BATCH,
+                includes=["uint8 upload (pinned)", "device preprocessing (both towers)", "packed prefill", f"{K}-token batched greedy decode", "ids to host"],
+                excludes=["JPEG decode + bicubic resize (host prefetch threads)", "tokenisation (cached prefix)"])
+
+
 def cpu_baseline(case, pipe, reps=3, decode_tokens=64):
     """The oracle (a port of the reference's operators: oracle/*.py, torch fp32) of the same stages on this box's host cores, at
     FULL depth (32 ViT blocks, 36 LLM layers): warm-up 1 pass, then the median of `reps` passes, plus `decode_tokens` greedy
@@ -476,6 +541,11 @@ def main():
                                       images_per_sec_with_64_token_answer=round(Bd / (t_pref + 64 * tb), 2),
                                       launches_per_layer=5, note="one pass at a time: packed prefill of the batch, then 64 batched decode steps")
 
+    # ---- end to end: upload + device preprocessing + packed prefill + 64-token batched decode + ids on the host, one timed loop ----
+    e2e = None
+    if rank == 0 and not args.main_only and use_graph:
+        e2e = end_to_end_run(pipe, cases, steps=max(4, min(args.steps, 12)), K=64)
+
     # ---- dataset-shaped workload (ragged sizes / variable N): not part of `value` ----
     dset = None
     if rank == 0 and not args.main_only and args.dataset != "none":
@@ -607,7 +677,7 @@ def main():
                                       (f"; {R} passes in flight on {R} HIP streams (engine replicas share weights)" if R > 1 else "; one pass at a time"),
                                images_per_step=B, passes_in_flight=R, global_batch=B * world,
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
-                   one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
+                   end_to_end=e2e, one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
         if roof is not None:
             # stage times (sum of kernel execution time per stage, eager pass) and the two region-token rates
             out["stage_kernel_ms"] = stage_ms

@@ -112,6 +112,34 @@ def test_batched_decode_twelve_sequences_match_alone():
         L.load().fo1_gemm_set_gemv(1)
 
 
+def test_twenty_requests_one_prefill_pass_two_decode_groups():
+    """More requests than the decode loop's 16 MFMA columns: generate_batch runs ONE packed prefill pass over all 20, then decodes them
+    in groups of 16 + 4 out of the same prefill cache (the later group's prompt K / V must survive the first group's decode).  Per
+    request the ids equal the request decoded alone (prefill tile pinned, as above); the stop rule applies per sequence in both groups."""
+    from test_batched_prefill_gpu import make_request
+    from vlm_fo1_amd import lib as L
+    cfg, weights, eng = build()
+    reqs = [make_request(200 + i, 96 + 28 * (i % 4), 120 + 28 * (i % 3), 1 + (5 * i) % 9) for i in range(20)]
+    K = 6
+    try:
+        L.check(L.load().fo1_gemm_set_variant(2, 1), "variant")
+        L.check(L.load().fo1_gemm_set_splitk(1), "splitk")
+        L.check(L.load().fo1_gemm_set_gemv(0), "gemv")
+        got = eng.generate_batch(reqs, max_new_tokens=K, use_graph=True)
+        assert [len(g) for g in got] == [K] * 20
+        for i in (0, 15, 16, 19):
+            assert eng.generate_batch([reqs[i]], max_new_tokens=K, use_graph=True)[0] == got[i], f"request {i} decodes differently in a batch of 20"
+        stop = got[17][2]
+        out = eng.generate_batch(reqs, max_new_tokens=K, stop_ids=[stop], use_graph=True)
+        for b, ids in enumerate(out):
+            cut = got[b].index(stop) + 1 if stop in got[b] else K
+            assert ids == got[b][:cut], f"sequence {b}: stop rule gave {ids}, expected {got[b][:cut]}"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_splitk(0)
+        L.load().fo1_gemm_set_gemv(1)
+
+
 @pytest.mark.parametrize("impl,rows_per_lane", [(1, 0), (0, 0), (0, 1)])
 def test_gemv_batch_matches_reference(impl, rows_per_lane):
     """fo1_gemv_batch_bf16 (plain / SwiGLU epilogues, fused RMSNorm, K pieces for deep K) against torch fp32: the MFMA skinny GEMM

@@ -347,6 +347,7 @@ class FO1Engine:
             return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,
                         next_tokens=toks, region_ranges=ranges, row0=bp.row0)
 
+    PREFILL_MAX = 32       # requests per packed prefill pass of generate_batch
     RAGGED_TOWERS = True   # images of different sizes share one DaViT / SimpleFPN pass (False: image by image, the round-2 path; A/B)
     GRAPH_CACHE = 8        # captured prefill graphs kept per engine (LRU); each holds its own activation pool
     CAPTURE_AFTER = 1      # sightings of a signature before it is captured: one-off shapes (a dataset of ragged images) run eagerly
@@ -441,12 +442,17 @@ class FO1Engine:
         (stop token included, like HF generate)."""
         out: List[List[int]] = []
         dec = self._decoder()
-        for i in range(0, len(requests), dec.MAX_BATCH):
-            grp = requests[i:i + dec.MAX_BATCH]
-            self.prefill_batch(grp, use_graph=use_graph)
+        for i in range(0, len(requests), self.PREFILL_MAX):
+            grp = requests[i:i + self.PREFILL_MAX]
+            self.prefill_batch(grp, use_graph=use_graph)          # ONE packed pass for the whole group (its GEMMs see every image's rows)
             hp = self._last_batch
-            dec.start(hp["seqs"], hp["delta"], self._last_next_tokens[:len(grp)], max_new_tokens, stop_ids)
-            out += dec.run(max_new_tokens, use_graph=use_graph)
+            first = self._last_next_tokens
+            # the decode loop takes MAX_BATCH sequences at a time (the MFMA's 16 columns); each group is relocated out of the
+            # prefill cache into the decoder's slots, so the later groups' prompt K / V stay where the prefill left them
+            for j in range(0, len(grp), dec.MAX_BATCH):
+                k = min(j + dec.MAX_BATCH, len(grp))
+                dec.start(hp["seqs"][j:k], hp["delta"][j:k], first[j:k], max_new_tokens, stop_ids)
+                out += dec.run(max_new_tokens, use_graph=use_graph)
         return out
 
     def _decoder(self):
