@@ -94,7 +94,9 @@ def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode
     import bench_workloads as BW
     dev = pipe.eng.dev
     reqs, geos = BW.build_requests(name, dev, limit=n_items, aux_mode=aux_mode)
-    groups = BW.pack(geos, batch=batch, row_budget=row_budget or (batch * 1564 * 3 // 2))
+    # packing policy (profiles/r03_ragged_profile_countbench.json): up to 64 images and ~40k ViT rows per pass — the uniform pass's
+    # row count; small images then still give the GEMMs a full M (25 thumbnails per pass left 3/4 of the tiles empty)
+    groups = BW.pack(geos, batch=max(batch, 64), row_budget=row_budget or 40000)
     need = max(sum(len(reqs[i]["ids"]) + geos[i]["S"] // 4 + 8 for i in g) for g in groups)
     for e in pipe.engs:
         e.llm.reserve(need)
@@ -107,7 +109,7 @@ def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode
                 if decode_tokens:
                     pipe.engs[slot].generate_batch(grp, max_new_tokens=decode_tokens, use_graph=True)
                 else:
-                    pipe.engs[slot].prefill_batch(grp, use_graph=True)
+                    pipe.engs[slot].prefill_batch(grp, use_graph=False)   # a dataset's signatures do not repeat: nothing to replay
         torch.cuda.synchronize()
 
     sweep()
@@ -118,6 +120,7 @@ def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode
     out = dict(BW.summary(geos), name=name, aux=aux_mode, passes=len(groups), images_per_pass_max=batch, passes_in_flight=inflight,
                seconds=round(el, 3), images_per_sec=round(len(reqs) / el, 2), region_tokens_per_sec=round(sum(g["n"] for g in geos) / el, 1),
                uniform_equivalent_images_per_sec=round(patches / 1564.0 / el, 2), launch="eager (every pass is a new shape signature)",
+               packing="<= 64 images and <= 40k ViT rows per pass, items sorted by cost",
                what="prefill to the first greedy token" if not decode_tokens else f"prefill + {decode_tokens}-token batched greedy decode")
     return out
 

@@ -36,7 +36,7 @@ def main():
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 t0 = time.perf_counter()
                 e0.record()
-                pipe.eng.prefill_batch(grp, use_graph=True)
+                pipe.eng.prefill_batch(grp, use_graph=False)
                 e1.record()
                 t_host = time.perf_counter() - t0
                 torch.cuda.synchronize()
@@ -49,7 +49,7 @@ def main():
         def sweep2():
             for k, g in enumerate(groups):
                 with torch.cuda.stream(pipe.streams[k % 2]):
-                    pipe.engs[k % 2].prefill_batch([reqs[i] for i in g], use_graph=True)
+                    pipe.engs[k % 2].prefill_batch([reqs[i] for i in g], use_graph=False)
             torch.cuda.synchronize()
         sweep2()
         t0 = time.perf_counter()
