@@ -99,7 +99,9 @@ def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode
     groups = BW.pack(geos, batch=max(batch, 64), row_budget=row_budget or 40000)
     need = max(sum(len(reqs[i]["ids"]) + geos[i]["S"] // 4 + 8 for i in g) for g in groups)
     for e in pipe.engs:
-        e.llm.reserve(need)
+        if e.llm.reserve(need):
+            e._graphs.clear()
+            e._seen.clear()
 
     def sweep():
         for k, g in enumerate(groups):
@@ -117,7 +119,7 @@ def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode
     sweep()
     el = time.perf_counter() - t0
     patches = sum(g["S"] for g in geos)
-    out = dict(BW.summary(geos), name=name, aux=aux_mode, passes=len(groups), images_per_pass_max=batch, passes_in_flight=inflight,
+    out = dict(BW.summary(geos), name=name, aux=aux_mode, passes=len(groups), images_per_pass_max=max(batch, 64), passes_in_flight=inflight,
                seconds=round(el, 3), images_per_sec=round(len(reqs) / el, 2), region_tokens_per_sec=round(sum(g["n"] for g in geos) / el, 1),
                uniform_equivalent_images_per_sec=round(patches / 1564.0 / el, 2), launch="eager (every pass is a new shape signature)",
                packing="<= 64 images and <= 40k ViT rows per pass, items sorted by cost",
