@@ -24,9 +24,9 @@ lib = L.load()
 results = []
 for B in batches:
     reqs = pipe.requests[:B]
-    for gemv_impl, attn_impl in ((1, 0), (3, 0)):
-        if gemv_impl == 3 and B > 8:
-            continue      # 3 = MFMA without the 8-row units (they only exist at M <= 8)
+    for gemv_impl, attn_impl in ((1, 0), (5, 0)):
+        if gemv_impl == 5 and B <= 8:
+            continue      # 5 = without round 3's 8-row units for 9..16 sequences (R8); at M <= 8 nothing changes
         L.check(lib.fo1_gemv_batch_set_impl(gemv_impl), "gemv impl")
         L.check(lib.fo1_attention_decode_set_impl(attn_impl), "attn impl")
         eng.prefill_batch(reqs, use_graph=False)

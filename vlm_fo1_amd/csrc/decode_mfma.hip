@@ -23,6 +23,12 @@
 //     columns 0-7 and the odd-d k-step in rows 8-15 / columns 8-15 (D's off-diagonal 8x8 blocks are ignored).  The few-row
 //     projections (o, down: N = 2048 -> 128 units of 16 rows, half the CUs idle, 2.8 TB/s; q/k/v: 80 units) then fill the chip
 //     with 256 / 160 units, without any cross-workgroup reduction and with bit-identical sums.
+//   * R8 (round 3): the same 8-row units for 9..16 sequences.  All 16 MFMA columns carry sequences there, so the k-step pair (s, s + 8)
+//     of a stage is two MFMAs: fragment rows 0-7 hold the 8 weight rows at k-step s (rows 8-15: the s + 8 data, their D rows are
+//     ignored), then the fragment is read with rows swapped (fi ^ 8) for k-step s + 8.  Half of every MFMA is idle — the matrix cores
+//     are not what a weight stream waits for — and o / down / q,k,v run on 256 / 256 / 160 workgroups instead of 128 / 128 / 80
+//     (down at 16 sequences: 18.9 us = 2.4 TB/s before).  Chain A = first k-step of each pair, chain B = second: the same sets, the
+//     same order, the same bits as the other variants.
 #include <type_traits>
 
 #include "decode_common.h"
@@ -59,18 +65,20 @@ __device__ __forceinline__ void gm_lds_fence() {
 // MM: staged x rows (8 or 16).  NB: 16-row weight blocks per unit (SwiGLU / QKV pair two blocks whose rows meet in one lane).
 // MP: K spans several staged pieces (deep-K projections); single-piece kernels stage x once and carry no reload logic.
 // HALF: 8-row blocks, a register stage = the k-step pair (s, s + 8) of those rows (M <= 8 only; no SwiGLU form).
-template <int MM, int MODE, int NB, bool MP, bool HALF>
+template <int MM, int MODE, int NB, bool MP, bool HALF, bool R8 = false>
 __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, const int n_units, const int nsteps) {
     static_assert(MODE == GB_PLAIN || NB == 2, "paired modes use two row blocks");
     static_assert(!HALF || (MM == 8 && MODE != GB_SWIGLU), "HALF: M <= 8, plain or QKV");
-    constexpr int PD = (HALF && !MP) ? 2 : 4;                            // register stages per wave = stages per staged piece
-    constexpr int SSTEP = HALF ? 16 : 8;                                 // k-step distance between a wave's consecutive stages
+    static_assert(!R8 || (MM == 16 && MODE != GB_SWIGLU && !HALF), "R8: 9..16 sequences, plain or QKV");
+    constexpr bool H8 = HALF || R8;                                      // 8-row blocks, a stage = the k-step pair (s, s + 8)
+    constexpr int PD = R8 ? 2 : ((HALF && !MP) ? 2 : 4);                 // register stages per wave = stages per staged piece
+    constexpr int SSTEP = H8 ? 16 : 8;                                   // k-step distance between a wave's consecutive stages
     constexpr int PSTEPS = SSTEP * PD;                                   // k-steps of x staged at a time: 32 (64: HALF && MP)
     constexpr int XPITCH = PSTEPS * 128 + 32;                            // bytes per staged x row (= 32 mod 256)
     constexpr int CPR = PSTEPS * 8;                                      // 16-byte chunks per staged x row
     constexpr int RPP = GM_NT / CPR;                                     // x rows per pass of the workgroup (2 or 1)
     constexpr int XL = MM / RPP;                                         // x loads per thread and piece
-    constexpr int RB = HALF ? 8 : 16;                                    // weight rows per block
+    constexpr int RB = H8 ? 8 : 16;                                      // weight rows per block
     extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
     unsigned char* const sx = gm_smem;                                   // [MM][XPITCH]
     unsigned char* const sw = gm_smem + MM * XPITCH;                     // [GM_NW][NB][2048]  weight scratch (wave-private)
@@ -106,7 +114,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         for (int b = 0; b < NB; ++b)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                int row = rb[b] + (HALF ? 0 : q * 8) + lrow;  // HALF: both loads fetch the block's 8 rows (k-steps s and s + 8)
+                int row = rb[b] + (H8 ? 0 : q * 8) + lrow;    // 8-row blocks: both loads fetch the block's 8 rows (k-steps s and s + 8)
                 row = row < p.N ? row : p.N - 1;            // clamp: the surplus rows' results are discarded
                 wp[b][q] = p.W + (long long)row * p.ldw;
             }
@@ -116,7 +124,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         int c[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            c[q] = (s + (HALF ? q * 8 : 0)) * 8 + lch;
+            c[q] = (s + (H8 ? q * 8 : 0)) * 8 + lch;
             c[q] = c[q] < kch ? c[q] : kch - 1;
         }
 #pragma unroll
@@ -124,7 +132,8 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
             for (int q = 0; q < 2; ++q) st[b][q] = gm_load_nt16(wp[b][q] + (long long)c[q] * 8);
     };
-    auto consume = [&](const uint4 (&st)[NB][2], int xs, gm_f32x4 (&acc)[NB]) __attribute__((always_inline)) {
+    // acc: the chain this stage adds to (R8: chain A = the pair's first k-step; accb = chain B = its second)
+    auto consume = [&](const uint4 (&st)[NB][2], int xs, gm_f32x4 (&acc)[NB], gm_f32x4 (&accb)[NB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -140,6 +149,15 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             for (int b = 0; b < NB; ++b) {
                 uint4 wv = *reinterpret_cast<const uint4*>(swv + b * 2048 + fi * 128 + (((h * 4 + fg) ^ ((fi >> 1) & 7)) << 4));
                 acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xv), acc[b], 0, 0, 0);
+            }
+            if (R8) {     // the pair's second k-step: scratch rows 8-15 read as fragment rows 0-7 (fi ^ 8), x one k-step-pair half further
+                const int fj = fi ^ 8;
+                uint4 xw = *reinterpret_cast<const uint4*>(sx + xrow * XPITCH + (xs + 8) * 128 + h * 64 + fg * 16);
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    uint4 wv = *reinterpret_cast<const uint4*>(swv + b * 2048 + fj * 128 + (((h * 4 + fg) ^ ((fj >> 1) & 7)) << 4));
+                    accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xw), accb[b], 0, 0, 0);
+                }
             }
         }
         gm_lds_fence();      // the scratch is rewritten by the next k-step
@@ -216,7 +234,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     for (int d = 0; d < PD; ++d) issue(wcur, wave + SSTEP * d, st[d]);
     // decode state of this lane's sequence (QKV epilogue): cache row and rope-table row
     const int n_seq = fi;
-    const bool seq_ok = n_seq < p.M && (!HALF || fg < 2);        // HALF: fragment rows 8-15 are chain B, folded into lanes fg < 2
+    const bool seq_ok = n_seq < p.M && (!H8 || fg < 2);          // 8-row blocks: D rows 8-15 are chain B (HALF, folded into lanes fg < 2) or unused (R8)
     int pos = 0;
     long long trow = 0;
     if (MODE == GB_QKV) {
@@ -276,7 +294,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
                 for (int d = 0; d < PD; ++d) {
                     const int xs = wave + SSTEP * d;              // k-step inside the staged piece
-                    consume(st[d], xs, accs[HALF ? 0 : (d & 1)]);
+                    consume(st[d], xs, accs[H8 ? 0 : (d & 1)], accs[1]);
                     issue(wcur, (piece + 1) * PSTEPS + xs, st[d]);
                 }
             }
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
             const int xs = wave + SSTEP * d;
-            consume(st[d], xs, accs[HALF ? 0 : (d & 1)]);
+            consume(st[d], xs, accs[H8 ? 0 : (d & 1)], accs[1]);
             if (PF) issue(wnext, xs, st[d]);                  // the first piece of this workgroup's next unit
         }
         // chain A + chain B.  HALF: chain B of (row r, sequence n) sits in lane + 40 (fragment row r + 8, column n + 8)
@@ -416,28 +434,30 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 
 extern int g_gemv_profile_shapes;
 
-template <int MM, int MODE, int NB, bool MP, bool HALF>
+template <int MM, int MODE, int NB, bool MP, bool HALF, bool R8 = false>
 static int launch_gemv_mfma_mp(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
-    constexpr int xpitch = (HALF ? 16 : 8) * ((HALF && !MP) ? 2 : 4) * 128 + 32;
+    constexpr int pd = R8 ? 2 : ((HALF && !MP) ? 2 : 4);
+    constexpr int xpitch = ((HALF || R8) ? 16 : 8) * pd * 128 + 32;
     const size_t smem = (size_t)MM * xpitch + (size_t)GM_NW * NB * 2048 + (size_t)2 * GM_NW * NB * 1024 + 64;
     static bool attr = false;
     if (!attr) {
-        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB, MP, HALF>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB, MP, HALF, R8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
         attr = true;
     }
     // persistent workgroups, one per CU (x is staged / normalised once per workgroup when K fits one piece)
     const int grid = n_units < 256 ? n_units : 256;
-    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_mfma_kernel<MM, MODE, NB, MP, HALF>), dim3(grid), dim3(GM_NT), smem, st, p, n_units, nsteps);
+    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_mfma_kernel<MM, MODE, NB, MP, HALF, R8>), dim3(grid), dim3(GM_NT), smem, st, p, n_units, nsteps);
     return FO1_OK;
 }
 
-template <int MM, int MODE, int NB, bool HALF = false>
+template <int MM, int MODE, int NB, bool HALF = false, bool R8 = false>
 static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
-    if (nsteps > GM_PIECE) return launch_gemv_mfma_mp<MM, MODE, NB, true, HALF>(p, n_units, nsteps, name, st);
-    return launch_gemv_mfma_mp<MM, MODE, NB, false, HALF>(p, n_units, nsteps, name, st);
+    constexpr int piece = R8 ? 32 : GM_PIECE;        // k-steps of x staged at a time (R8 stages 2 pairs per wave)
+    if (nsteps > piece) return launch_gemv_mfma_mp<MM, MODE, NB, true, HALF, R8>(p, n_units, nsteps, name, st);
+    return launch_gemv_mfma_mp<MM, MODE, NB, false, HALF, R8>(p, n_units, nsteps, name, st);
 }
 
-int g_gemv_half = 1;     // M <= 8: 8-row units for the few-row projections (A/B: fo1_gemv_batch_set_impl(1 | 2) turns it off)
+int g_gemv_half = 3;     // bit 0: M <= 8 8-row units (HALF); bit 1: 9..16 sequences 8-row units (R8) — few-row projections (A/B: fo1_gemv_batch_set_impl)
 
 template <int MM>
 static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
@@ -452,8 +472,14 @@ static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
     if (mode == GB_SWIGLU) return launch_gemv_mfma<MM, GB_SWIGLU, 2>(p, p.N / 32, nsteps, name, st);
     if constexpr (MM == 8) {
         // M <= 8: half of the MFMA's columns are free — 8-row units with the k-step pair in the two halves (same sums, see the header)
-        if (g_gemv_half && mode == GB_QKV) return launch_gemv_mfma<8, GB_QKV, 2, true>(p, (p.n_q + p.n_kv) * 8 + p.n_kv * 8, nsteps, name, st);
-        if (g_gemv_half && mode == GB_PLAIN && p.N <= 4096) return launch_gemv_mfma<8, GB_PLAIN, 1, true>(p, cdiv(p.N, 8), nsteps, name, st);
+        if ((g_gemv_half & 1) && mode == GB_QKV) return launch_gemv_mfma<8, GB_QKV, 2, true>(p, (p.n_q + p.n_kv) * 8 + p.n_kv * 8, nsteps, name, st);
+        if ((g_gemv_half & 1) && mode == GB_PLAIN && p.N <= 4096) return launch_gemv_mfma<8, GB_PLAIN, 1, true>(p, cdiv(p.N, 8), nsteps, name, st);
+    }
+    if constexpr (MM == 16) {
+        // 9..16 sequences: 8-row units with both k-steps of a pair as separate MFMAs (R8, see the header) — the few-row projections
+        // fill the chip like they do at M <= 8; bit 2 of fo1_gemv_batch_set_impl's half switch (g_gemv_half & 2 == 0) turns it off
+        if ((g_gemv_half & 2) && mode == GB_QKV) return launch_gemv_mfma<16, GB_QKV, 2, false, true>(p, (p.n_q + p.n_kv) * 8 + p.n_kv * 8, nsteps, name, st);
+        if ((g_gemv_half & 2) && mode == GB_PLAIN && p.N <= 4096) return launch_gemv_mfma<16, GB_PLAIN, 1, false, true>(p, cdiv(p.N, 8), nsteps, name, st);
     }
     if (mode == GB_QKV) return launch_gemv_mfma<MM, GB_QKV, 2>(p, (p.n_q + p.n_kv) * 4 + p.n_kv * 4, nsteps, name, st);
     // plain: 16-row units for the few-row projections (every CU should stream), 32-row units for lm_head-sized matrices
