@@ -39,14 +39,27 @@ def build_workload(device, n_boxes=100, img_hw=(480, 640), seed=1234):
     gh, gw = round(H / 28) * 2, round(W / 28) * 2
     pix = torch.randn(gh * gw, 1176, generator=g).bfloat16()        # normalised patches, HF processor layout
     aux = torch.randn(3, H, W, generator=g).bfloat16()               # CLIP-normalised aux image ('dynamic': no resize)
-    it = [x for x in box_fixtures()["countbench"] if len(x["bboxes"]) >= n_boxes][0]
-    b = torch.tensor(it["bboxes"], dtype=torch.float32)[:n_boxes]
-    ex, ey = it["extent"]
-    b = b * torch.tensor([W / ex, H / ey, W / ex, H / ey])
-    ids = synthetic_prompt(n_boxes, n_text=60, seed=seed)
+    fx = box_fixtures()
+    if n_boxes <= 100:
+        it = [x for x in fx["countbench"] if len(x["bboxes"]) >= n_boxes][0]
+        b = torch.tensor(it["bboxes"], dtype=torch.float32)[:n_boxes]
+        ex, ey = it["extent"]
+        b = b * torch.tensor([W / ex, H / ey, W / ex, H / ey])
+    else:
+        # more proposals than the reference's cap of 100 features per prompt (mm_utils.py:600; a longer prompt IndexErrors at
+        # omchat_qwen2_5_vl.py:361): the boxes of several fixture items, run as ceil(N / 100) prompts of <= 100 over the SAME image
+        chunks = []
+        for it in sorted(fx["countbench"] + fx["pixmo"], key=lambda x: -len(x["bboxes"])):
+            ex, ey = it["extent"]
+            chunks.append(torch.tensor(it["bboxes"], dtype=torch.float32)[:100] * torch.tensor([W / ex, H / ey, W / ex, H / ey]))
+        b = torch.cat(chunks)[:n_boxes]
+        assert b.shape[0] == n_boxes, f"the fixtures hold {torch.cat(chunks).shape[0]} boxes, {n_boxes} asked"
+    ids = synthetic_prompt(min(n_boxes, 100), n_text=60, seed=seed)
     case = dict(pix=pix, aux=aux, boxes=b, ids=ids, grid=(gh, gw), img_hw=img_hw)
     if device is not None:
         case["dev"] = dict(pix=pix.to(device), aux=aux.to(device), boxes=b.to(device))
+    if n_boxes > 100:
+        case["prompts"] = [(synthetic_prompt(min(100, n_boxes - k), n_text=60, seed=seed + k), b[k:k + 100]) for k in range(0, n_boxes, 100)]
     return case
 
 
@@ -68,18 +81,28 @@ class Pipeline:
         self.batch = batch
         # `batch` DIFFERENT images of the same geometry per step (cases[i]); packed into one pass of every stage
         self.cases = cases if cases is not None else [case] * batch
-        self.requests = [dict(ids=c["ids"], pix=c["dev"]["pix"], grid=c["grid"], aux=c["dev"]["aux"], boxes=c["dev"]["boxes"]) for c in self.cases]
+        self.requests = []
+        for ci, c in enumerate(self.cases):
+            if "prompts" in c:      # several prompts over one image (> 100 proposals): the towers run once per image (image_id)
+                for ids, bx in c["prompts"]:
+                    self.requests.append(dict(ids=ids, pix=c["dev"]["pix"], grid=c["grid"], aux=c["dev"]["aux"], boxes=bx.to(device), image_id=ci))
+            else:
+                self.requests.append(dict(ids=c["ids"], pix=c["dev"]["pix"], grid=c["grid"], aux=c["dev"]["aux"], boxes=c["dev"]["boxes"]))
+        self.multi_prompt = any("prompts" in c for c in self.cases)
 
     def step(self, graph=True, slot=0):
         """One step = one packed pass over `batch` images (batch 1: one image)."""
         with torch.cuda.stream(self.streams[slot]):
-            if self.batch == 1:
+            if self.batch == 1 and not self.multi_prompt:
                 d = self.case["dev"]
                 return self.engs[slot].prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
             return self.engs[slot].prefill_batch(self.requests, use_graph=graph)
 
     def step_single(self, graph=True):
         """Latency mode: ONE image through the same stages (a batch of one)."""
+        if self.multi_prompt:
+            n = len(self.cases[0]["prompts"])
+            return self.eng.prefill_batch(self.requests[:n], use_graph=graph)
         d = self.case["dev"]
         return self.eng.prefill(self.case["ids"], d["pix"], self.case["grid"], d["aux"], d["boxes"], use_graph=graph)
 
@@ -357,7 +380,7 @@ def main():
     ap.add_argument("--boxes", type=int, default=100, help="proposals per image (default 100 = the configuration BASELINE.json's metric is quoted on; 32 = configs[1])")
     ap.add_argument("--image", default="480x640", help="HxW of the synthetic image (default = BASELINE configs[1]; 1344x1344 with "
                     "--boxes 100 is the high-resolution configuration's geometry)")
-    ap.add_argument("--batch", type=int, default=25, help="images packed into ONE pass of every stage (varlen batched prefill); a step is "
+    ap.add_argument("--batch", type=int, default=0, help="images packed into ONE pass of every stage (varlen batched prefill; 0 = 25 at the metric configuration, scaled by patches per image otherwise); a step is "
                     "one such pass; 1 = one image per pass (latency mode).  The 256 x 256 GEMM tiles run in rounds of 256 (one per CU), so "
                     "the pass size sets how full the last round of every product is: 25 (default) makes the LLM o / down projections "
                     "64 x 8 = 512 tiles = exactly two rounds and the ViT products 94-99 %% full (model + sweep: profiles/r02_batch_sweep.md; "
@@ -406,7 +429,13 @@ def main():
     from vlm_fo1_amd import lib as L
     L.load()
     img_hw = tuple(int(v) for v in args.image.lower().split("x"))
+    S_img = (round(img_hw[0] / 28) * 2) * (round(img_hw[1] / 28) * 2)
+    if args.batch <= 0:       # default: the pass size that keeps ~39k ViT rows per pass (25 images at the metric configuration)
+        args.batch = max(1, round(25 * 1564 / S_img))
     B = max(1, args.batch)
+    if args.boxes > 100:      # several prompts per image: the one-sequence side measurements and the one-prompt CPU leg do not apply
+        args.main_only = True
+        args.no_cpu_baseline = True
     cases = [build_workload(dev, n_boxes=args.boxes, img_hw=img_hw, seed=1234 + rank * 1000 + i) for i in range(B)]
     case = cases[0]
     R = max(1, args.inflight)
@@ -672,10 +701,12 @@ def main():
                    warmup=args.warmup, ms_per_step=el / args.steps * 1e3, higher_is_better=True, scaling="weak",
                    vs_baseline=None, dtype=("fp8-e4m3 linears, preset %s (%d weights; bf16 elsewhere)" % (args.fp8, n_fp8)) if args.fp8 else "bf16", data="synthetic",
                    region_tokens_per_sec=n_img * args.boxes / el,
-                   config=dict(workload=f"{'BASELINE metric config (100 boxes/img, COCO-typical 640x480)' if (img_hw == (480, 640) and args.boxes == 100) else ('BASELINE configs[1]' if (img_hw == (480, 640) and args.boxes == 32) else 'non-default geometry')}: 1 image "
+                   config=dict(workload=f"{'BASELINE metric config (100 boxes/img, COCO-typical 640x480)' if (img_hw == (480, 640) and args.boxes == 100) else ('BASELINE configs[1]' if (img_hw == (480, 640) and args.boxes == 32) else ('BASELINE configs[4] geometry (high-res dual encoder, 300 proposals/image)' if (img_hw == (1344, 1344) and args.boxes == 300) else 'non-default geometry'))}: 1 image "
                                         f"{img_hw[1]}x{img_hw[0]} (S={case['grid'][0] * case['grid'][1]} patches) x {args.boxes} proposals "
-                                        f"(CountBench UPN boxes), Qwen2.5-VL-3B + DaViT-L + SimpleFPN true shapes, prompt "
-                                        f"{len(case['ids']) - 1 + case['grid'][0] * case['grid'][1] // 4} tokens after splice, prefill to the first greedy token",
+                                        f"(CountBench / Pixmo UPN boxes" + (f", run as {len(case['prompts'])} prompts of <= 100 over the one image: the reference caps region features at 100 per prompt, "
+                                        "mm_utils.py:600 — towers once per image, one LLM sequence per prompt" if "prompts" in case else "") + "), Qwen2.5-VL-3B + DaViT-L + SimpleFPN true shapes, prompt "
+                                        f"{len(case['ids']) - 1 + case['grid'][0] * case['grid'][1] // 4} tokens after splice, prefill to the first greedy token" +
+                                        (" of every prompt" if "prompts" in case else ""),
                                stages=Pipeline.stages,
                                launch=("eager" if args.eager else "hipGraph replay (1 graph per shape signature)") +
                                       f"; a step = ONE packed pass over {B} different images (varlen batched prefill: rows of all images in every GEMM)" +
@@ -683,6 +714,9 @@ def main():
                                images_per_step=B, passes_in_flight=R, global_batch=B * world,
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
                    end_to_end=e2e, one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
+        if args.fp8:
+            out["fp8_note"] = ("W8A8 e4m3 linears are an MI355X-side lever BASELINE configs[4] names; the reference has no fp8 path, so this mode's parity is "
+                               "UNPINNED (deviation table against the bf16 engine: DESIGN.md section 10, tests/test_fp8_engine_gpu.py)")
         if roof is not None:
             # stage times (sum of kernel execution time per stage, eager pass) and the two region-token rates
             out["stage_kernel_ms"] = stage_ms

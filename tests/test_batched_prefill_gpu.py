@@ -113,3 +113,47 @@ def test_graph_cache_is_bounded_and_one_off_shapes_run_eagerly():
             else:
                 assert torch.equal(o["logits"], outs[i])
     assert len(eng._graphs) == 2
+
+
+def test_prompts_sharing_one_image_run_the_towers_once_and_match_separate_requests():
+    """BASELINE configs[4]: 300 proposals = 3 prompts of 100 over ONE image (the reference caps region features at 100 per prompt,
+    mm_utils.py:600, and would run the whole model three times).  Requests with the same `image_id` share the image: ViT / DaViT /
+    SimpleFPN run once, every prompt's <image> block reads the same token rows, HFRE pools each prompt's boxes on the shared maps.
+    Per prompt the result is bit-identical to the same prompt sent as its own request (tile pinned), also mixed with another image."""
+    from vlm_fo1_amd import lib as L
+    eng = make_engine(seed=12)
+    base = make_request(70, 420, 300, 30)
+    other = make_request(71, 500, 399, 9)
+    g = torch.Generator().manual_seed(5)
+    from vlm_fo1_amd.model import synthetic_prompt
+    prompts = []
+    for k in range(3):
+        b = base["boxes"][k * 10:(k + 1) * 10]
+        prompts.append(dict(ids=synthetic_prompt(10, vocab=4096, seed=80 + k), pix=base["pix"], grid=base["grid"], aux=base["aux"], boxes=b))
+    try:
+        L.check(L.load().fo1_gemm_set_variant(2, 1), "variant")
+        L.check(L.load().fo1_gemm_set_splitk(1), "splitk")
+        L.check(L.load().fo1_gemm_set_gemv(0), "gemv")
+        sep = [clone(eng.prefill_batch([r])[0]) for r in prompts + [other]]
+        shared = [dict(r, image_id="img-a") for r in prompts]
+        calls = []
+        orig = eng.vit.forward_batch
+        eng.vit.forward_batch = lambda pix, grids, capture="all": (calls.append(len(grids)), orig(pix, grids, capture))[1]
+        got = eng.prefill_batch(shared + [other])
+        eng.vit.forward_batch = orig
+        assert calls == [2], f"two unique images in the pass, the ViT saw {calls}"
+        for i, (a, b) in enumerate(zip(sep, got)):
+            for k in KEYS:
+                assert torch.equal(a[k], b[k]), f"prompt {i}: {k} differs between the shared-image pass and the separate request"
+        # graph replay of the shared-image pass
+        for _ in range(3):
+            rep = eng.prefill_batch(shared + [other], use_graph=True)
+        for a, b in zip(got, rep):
+            for k in KEYS:
+                assert torch.equal(a[k], b[k])
+        with pytest.raises(ValueError):
+            eng.prefill_batch([dict(prompts[0], image_id="x"), dict(other, image_id="x")])
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_splitk(0)
+        L.load().fo1_gemm_set_gemv(1)

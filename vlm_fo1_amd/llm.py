@@ -288,7 +288,7 @@ class QwenLLM:
     PACK_ALIGN = 4   # the attention kernel reads V^T in 8-byte (4-key) pieces: every sequence starts at a multiple of 4
 
     def plan_batch(self, prompts: Sequence[Sequence[int]], n_img: Sequence[int], n_regions: Sequence[int],
-                   grids_merged: Sequence[Tuple[int, int]]):
+                   grids_merged: Sequence[Tuple[int, int]], img_base: Optional[Sequence[int]] = None):
         """HOST: B prompts -> one packed plan.  Sequence b owns rows [off_b, off_b + Lp_b), Lp_b = L_b rounded up to PACK_ALIGN
         with dummy rows (token 0) appended AFTER its real rows: causal attention keeps them invisible to every real row.  Image /
         region indices address the batch-concatenated token tables.  Returns dict(plan int32 [R,2], cos, sin bf16 [R, hd] (host),
@@ -296,7 +296,9 @@ class QwenLLM:
         c = self.cfg
         plans, coss, sins, seqs, poss, deltas = [], [], [], [], [], []
         off = img0 = reg0 = 0
-        for ids, ni, nr, gm in zip(prompts, n_img, n_regions, grids_merged):
+        for b, (ids, ni, nr, gm) in enumerate(zip(prompts, n_img, n_regions, grids_merged)):
+            if img_base is not None:      # several prompts over ONE image: they all address that image's rows of the token table
+                img0 = int(img_base[b])
             pl, pos, delta = self.plan_inputs(ids, ni, nr, gm)
             L = pl.shape[0]
             Lp = (L + self.PACK_ALIGN - 1) // self.PACK_ALIGN * self.PACK_ALIGN

@@ -211,120 +211,127 @@ class FO1Engine:
         return out
 
     # ---- a batch of images: everything up to the first generated token of each ---------------------------------
-    def _regions_batch(self, auxs, aux_stack, boxes, want, vt_last, bp, grids, boxes_cat=None, box_image=None):
-        """encode_regions (:75-108) for every request that has regions -> (region tokens [sum N, d_llm] or None, per-request
-        row ranges).  DaViT / SimpleFPN run ONCE over all images when they share the aux size and the patch grid (rows stacked
-        image by image); otherwise image by image.  The HFRE gather runs per image on views of the stacked maps and writes
-        straight into its rows of one [sum N, C_region] fp32 buffer."""
+    def _regions_batch(self, auxs, aux_stack, boxes, want, vt_last, bp, grids, img_of, boxes_cat=None, box_image=None):
+        """encode_regions (:75-108) for every request that has regions -> (region tokens [sum N, d_llm] or None, per-request row
+        ranges).  `auxs` / `grids` / `bp` describe the UNIQUE images of the pass, `img_of[r]` the image of request r (several prompts
+        may share one image: BASELINE configs[4]'s 300 proposals are 3 prompts of 100 over one image — the towers run once per
+        image).  DaViT / SimpleFPN run ONCE over all images: stacked when they share the aux size and the patch grid, packed row-wise
+        with per-image geometry tables when they do not (forward_ragged).  The HFRE gather is one launch for every box of every
+        image in the stacked case, one call per request on views of its image's rows otherwise; it writes straight into the
+        request's rows of one [sum N, C_region] fp32 buffer."""
         idx = [i for i, w in enumerate(want) if w]
         if not idx:
             return None, [(0, 0)] * len(want)
         p = self.cfg.vit.patch_size
-        n_box = [boxes[i].shape[0] for i in idx]
-        feat = torch.empty(sum(n_box), self.cfg.mm_region_hidden_size, dtype=torch.float32, device=self.dev)
-        uniform = aux_stack is not None and len(idx) == len(want) and len(set(grids)) == 1
+        feat = torch.empty(sum(boxes[i].shape[0] for i in idx), self.cfg.mm_region_hidden_size, dtype=torch.float32, device=self.dev)
+        imgs = sorted({img_of[i] for i in idx})                 # unique images that feed the region branch
+        all_imgs = len(imgs) == len(auxs)
+        uniform = aux_stack is not None and all_imgs and len(set(grids)) == 1 and len(idx) == len(want)
+        vt_only = self.cfg.mm_use_vt_region_feature_only
 
-        def nchw(t, hw, b=0):  # rows [b*h*w, (b+1)*h*w) of a stacked token-major map -> the NCHW *view* the reference hands to HFRE
-            n = hw[0] * hw[1]
-            return t[b * n:(b + 1) * n].view(1, hw[0], hw[1], t.shape[1]).permute(0, 3, 1, 2)
+        def nchw(t, hw, r0=0):  # rows [r0, r0 + h*w) of a token-major map -> the NCHW *view* the reference hands to HFRE
+            return t[r0:r0 + hw[0] * hw[1]].view(1, hw[0], hw[1], t.shape[1]).permute(0, 3, 1, 2)
 
-        row, ranges = 0, {}
-        if not uniform and len(idx) > 1 and self.RAGGED_TOWERS:
-            # images of different sizes: DaViT / SimpleFPN still run ONCE over all of them (rows packed image by image, the spatial
-            # kernels read per-image geometry tables: davit.forward_ragged / fpn.forward_ragged); HFRE per image on views of its rows
-            sel_aux = [auxs[i] for i in idx]
-            if self.cfg.mm_use_vt_region_feature_only:
-                aux_maps, aplan = [], None
+        def scales(u):          # reference :94-99 — python-float scales, one fp32 multiply per coordinate
+            gh, gw = grids[u]
+            H, W = auxs[u].shape[-2:]
+            return (gw * p) / W, (gh * p) / H
+
+        def ranges_in_order():
+            row, rg = 0, {}
+            for i in idx:
+                rg[i] = (row, row + boxes[i].shape[0])
+                row += boxes[i].shape[0]
+            return rg
+
+        ranges = ranges_in_order()
+
+        def hfre_request(i, aux_views, fpn_views, vt_views):
+            """One request's boxes on views of its image's maps -> its rows of `feat`."""
+            u = img_of[i]
+            if not self.use_vt:
+                vt_in = None
+            elif self.fpn is not None:
+                self.hfre.simple_fpn = lambda x, v=fpn_views: v
+                vt_in = vt_views
             else:
-                aux_maps, aplan = self.davit.forward_ragged(sel_aux)
+                vt_in = vt_views
+            r0, r1 = ranges[i]
+            self.hfre(aux_views, [boxes[i]], vt_in, None, vt_scale=scales(u), out=feat[r0:r1])
+
+        if uniform:
+            G = len(auxs)
+            aux_maps, aux_sizes = ([], []) if vt_only else self.davit.forward(aux_stack)
             self._mark("davit_large")
-            fplan = None
+            gh, gw = grids[0]
+            n = gh * gw
             if self.fpn is not None:
-                if len(idx) == len(want):
-                    vt_sel, r0s = vt_last, [bp.row0[i] for i in idx]
-                else:       # only the requests that have regions: their raster maps, packed back to back
-                    parts = [vt_last[bp.row0[i]:bp.row0[i] + grids[i][0] * grids[i][1]] for i in idx]
+                fpn_maps, fpn_sizes = self.fpn.forward(vt_last, gh, gw, batch=G)
+                self._mark("simple_fpn")
+            if G > 1 and boxes_cat is not None and box_image is not None:
+                # one launch for every box of every request: views of image 0, the kernel steps image by image through the stacks
+                aux_views = [nchw(t, s) for t, s in zip(aux_maps, aux_sizes)]
+                if not self.use_vt:
+                    vt_in = None
+                elif self.fpn is not None:
+                    fv = [nchw(t, s) for t, s in zip(fpn_maps, fpn_sizes)]
+                    self.hfre.simple_fpn = lambda x, v=fv: v
+                    vt_in = nchw(vt_last, (gh, gw))
+                else:
+                    vt_in = [nchw(t, (gh, gw)) for t in vt_last]
+                self.hfre(aux_views, [boxes_cat], vt_in, None, vt_scale=scales(0), out=feat, batch=G, box_image=box_image)
+            else:
+                for i in idx:
+                    u = img_of[i]
+                    aux_views = [nchw(t, s, u * s[0] * s[1]) for t, s in zip(aux_maps, aux_sizes)]
+                    fv = [nchw(t, s, u * s[0] * s[1]) for t, s in zip(fpn_maps, fpn_sizes)] if self.fpn is not None else None
+                    vv = None if not self.use_vt else (nchw(vt_last, (gh, gw), u * n) if self.fpn is not None else [nchw(t, (gh, gw), u * n) for t in vt_last])
+                    hfre_request(i, aux_views, fv, vv)
+            self._mark("hfre_region_pool")
+        elif len(imgs) > 1 and self.RAGGED_TOWERS:
+            # images of different sizes: DaViT / SimpleFPN still run ONCE over all of them (rows packed image by image, the spatial
+            # kernels read per-image geometry tables: davit.forward_ragged / fpn.forward_ragged)
+            aux_maps, aplan = ([], None) if vt_only else self.davit.forward_ragged([auxs[u] for u in imgs])
+            self._mark("davit_large")
+            fpn_maps, fplan = [], None
+            if self.fpn is not None:
+                if all_imgs:
+                    vt_sel, r0s = vt_last, [bp.row0[u] for u in imgs]
+                else:       # only the images that have regions: their raster maps, packed back to back
+                    parts = [vt_last[bp.row0[u]:bp.row0[u] + grids[u][0] * grids[u][1]] for u in imgs]
                     vt_sel, r0s, o = torch.cat(parts, 0), [], 0
                     for t in parts:
                         r0s.append(o)
                         o += t.shape[0]
-                fpn_maps, fplan = self.fpn.forward_ragged(vt_sel, [grids[i] for i in idx], r0s)
+                fpn_maps, fplan = self.fpn.forward_ragged(vt_sel, [grids[u] for u in imgs], r0s)
                 self._mark("simple_fpn")
-
-            def view(t, r0, hw):
-                return t[r0:r0 + hw[0] * hw[1]].view(1, hw[0], hw[1], t.shape[1]).permute(0, 3, 1, 2)
-
-            for j, i in enumerate(idx):
-                gh, gw = grids[i]
-                H, W = auxs[i].shape[-2:]
-                sh, sw = (gh * p) / H, (gw * p) / W
-                aux_views = [view(t, aplan.row0[l][j], aplan.sizes[l][j]) for l, t in enumerate(aux_maps)]
-                r0 = bp.row0[i]
-                if not self.use_vt:
-                    vt_in = None
-                elif self.fpn is not None:
-                    fv = [view(t, fplan.row0[l][j], fplan.sizes[l][j]) for l, t in enumerate(fpn_maps)]
-                    self.hfre.simple_fpn = lambda x, v=fv: v
-                    vt_in = nchw(vt_last[r0:r0 + gh * gw], (gh, gw))
-                else:
-                    vt_in = [nchw(t[r0:r0 + gh * gw], (gh, gw)) for t in vt_last]
-                nb = boxes[i].shape[0]
-                self.hfre(aux_views, [boxes[i]], vt_in, None, vt_scale=(sw, sh), out=feat[row:row + nb])
-                ranges[i] = (row, row + nb)
-                row += nb
+            slot = {u: j for j, u in enumerate(imgs)}
+            for i in idx:
+                u = img_of[i]
+                j = slot[u]
+                gh, gw = grids[u]
+                aux_views = [nchw(t, aplan.sizes[l][j], aplan.row0[l][j]) for l, t in enumerate(aux_maps)]
+                fv = [nchw(t, fplan.sizes[l][j], fplan.row0[l][j]) for l, t in enumerate(fpn_maps)] if self.fpn is not None else None
+                r0 = bp.row0[u]
+                vv = None if not self.use_vt else (nchw(vt_last, (gh, gw), r0) if self.fpn is not None else [nchw(t, (gh, gw), r0) for t in vt_last])
+                hfre_request(i, aux_views, fv, vv)
             self._mark("hfre_region_pool")
-            out = self.mm_projector_aux(feat.to(torch.bfloat16))                               # :106-107
-            self._mark("mm_projector_aux")
-            return out, [ranges.get(i, (0, 0)) for i in range(len(want))]
-        groups = [idx] if uniform else [[i] for i in idx]
-        for grp in groups:
-            G = len(grp)
-            aux = aux_stack if uniform else auxs[grp[0]].unsqueeze(0)
-            aux_maps, aux_sizes = ([], []) if self.cfg.mm_use_vt_region_feature_only else self.davit.forward(aux)
-            self._mark("davit_large")
-            gh, gw = grids[grp[0]]
-            H, W = auxs[grp[0]].shape[-2:]
-            sh, sw = (gh * p) / H, (gw * p) / W       # reference :94-99 — python-float scales, one fp32 multiply per coordinate
-            if self.fpn is not None:
-                if G == 1:
-                    r0 = bp.row0[grp[0]]
-                    vt = vt_last[r0:r0 + gh * gw]
-                else:
-                    vt = vt_last                      # uniform batch of all requests: the stacked raster maps as they are
-                fpn_maps, fpn_sizes = self.fpn.forward(vt, gh, gw, batch=G)
-                self._mark("simple_fpn")
-            if G > 1 and boxes_cat is not None and box_image is not None:
-                # one launch for every box of every image: views of image 0, the kernel steps image by image through the stacks
-                aux_views = [nchw(t, s, 0) for t, s in zip(aux_maps, aux_sizes)]
-                if not self.use_vt:
-                    vt_in = None
-                elif self.fpn is not None:
-                    fpn_views = [nchw(t, s, 0) for t, s in zip(fpn_maps, fpn_sizes)]
-                    self.hfre.simple_fpn = lambda x, v=fpn_views: v
-                    vt_in = nchw(vt_last[:gh * gw], (gh, gw))
-                else:
-                    vt_in = [nchw(t[:gh * gw], (gh, gw)) for t in vt_last]
-                self.hfre(aux_views, [boxes_cat], vt_in, None, vt_scale=(sw, sh), out=feat, batch=G, box_image=box_image)
-                for i in grp:
-                    ranges[i] = (row, row + boxes[i].shape[0])
-                    row += boxes[i].shape[0]
-                self._mark("hfre_region_pool")
-                continue
-            for j, i in enumerate(grp):
-                aux_views = [nchw(t, s, j) for t, s in zip(aux_maps, aux_sizes)]
-                if not self.use_vt:
-                    vt_in = None
-                elif self.fpn is not None:
-                    fpn_views = [nchw(t, s, j) for t, s in zip(fpn_maps, fpn_sizes)]
-                    self.hfre.simple_fpn = lambda x, v=fpn_views: v
-                    r0 = bp.row0[i]
-                    vt_in = nchw(vt_last[r0:r0 + gh * gw], (gh, gw))
-                else:
-                    vt_in = [nchw(t[bp.row0[i]:bp.row0[i] + gh * gw], (gh, gw)) for t in vt_last]
-                nb = boxes[i].shape[0]
-                self.hfre(aux_views, [boxes[i]], vt_in, None, vt_scale=(sw, sh), out=feat[row:row + nb])
-                ranges[i] = (row, row + nb)
-                row += nb
+        else:
+            for u in imgs:       # image by image (one image with regions, or RAGGED_TOWERS off: the round-2 path, kept for A/B)
+                aux_maps, aux_sizes = ([], []) if vt_only else self.davit.forward(auxs[u].unsqueeze(0))
+                self._mark("davit_large")
+                gh, gw = grids[u]
+                r0 = bp.row0[u]
+                fv = None
+                if self.fpn is not None:
+                    fpn_maps, fpn_sizes = self.fpn.forward(vt_last[r0:r0 + gh * gw], gh, gw, batch=1)
+                    self._mark("simple_fpn")
+                    fv = [nchw(t, s) for t, s in zip(fpn_maps, fpn_sizes)]
+                aux_views = [nchw(t, s) for t, s in zip(aux_maps, aux_sizes)]
+                vv = None if not self.use_vt else (nchw(vt_last, (gh, gw), r0) if self.fpn is not None else [nchw(t, (gh, gw), r0) for t in vt_last])
+                for i in idx:
+                    if img_of[i] == u:
+                        hfre_request(i, aux_views, fv, vv)
             self._mark("hfre_region_pool")
         out = self.mm_projector_aux(feat.to(torch.bfloat16))                               # :106-107
         self._mark("mm_projector_aux")
@@ -339,7 +346,7 @@ class FO1Engine:
             self._mark("mm_projector")
             vt_last = None if not self.use_vt else (feats[-1] if self.fpn is not None else feats)
             region_tokens, ranges = self._regions_batch(st["aux"], st.get("aux_stack"), st["boxes"], meta["want"], vt_last, bp, grids,
-                                                        st.get("boxes_cat"), st.get("box_image"))
+                                                        meta["img_of"], st.get("boxes_cat"), st.get("box_image"))
             emb = self.llm.embed_rows(st["plan"], image_tokens, region_tokens)
             self._mark("splice")
             last, logits, toks = self.llm.prefill_packed(emb, st["cos"], st["sin"], meta["seqs"], st["last"])
@@ -360,6 +367,24 @@ class FO1Engine:
         the pass for this shape signature once the signature has been seen CAPTURE_AFTER times (LRU of GRAPH_CACHE graphs)."""
         m = self.cfg.vit.spatial_merge_size
         B = len(requests)
+        # unique images of the pass: requests that carry the same `image_id` (any hashable) share ONE image — its towers run once
+        # and every such prompt's <image> block addresses the same rows of the image-token table (configs[4]: 300 proposals =
+        # 3 prompts of 100 over one image; the reference would run the whole model three times)
+        img_of, first_of, seen_ids = [], [], {}
+        for i, r in enumerate(requests):
+            iid = r.get("image_id")
+            if iid is None or iid not in seen_ids:
+                if iid is not None:
+                    seen_ids[iid] = len(first_of)
+                img_of.append(len(first_of))
+                first_of.append(i)
+            else:
+                u = seen_ids[iid]
+                f = requests[first_of[u]]
+                if tuple(f["grid"]) != tuple(r["grid"]) or f["pix"].shape != r["pix"].shape or f["aux"].shape != r["aux"].shape:
+                    raise ValueError(f"requests with image_id {iid!r} describe different images")
+                img_of.append(u)
+        U = len(first_of)
         grids, n_img, n_reg, want, boxes, prompts = [], [], [], [], [], []
         for r in requests:
             gh, gw = r["grid"]
@@ -369,18 +394,24 @@ class FO1Engine:
                 b = self._dummy_box
             grids.append((int(gh), int(gw))); n_img.append((gh // m) * (gw // m)); want.append(bool(w))
             boxes.append(b.to(device=self.dev, dtype=torch.float32)); n_reg.append(b.shape[0] if w else 0); prompts.append(r["ids"])
-        hp = self.llm.plan_batch(prompts, n_img, n_reg, [(g[0] // m, g[1] // m) for g in grids])
+        ugrids = [grids[i] for i in first_of]
+        tok_base, o = [], 0
+        for i in first_of:
+            tok_base.append(o)
+            o += n_img[i]
+        hp = self.llm.plan_batch(prompts, n_img, n_reg, [(g[0] // m, g[1] // m) for g in grids], img_base=[tok_base[u] for u in img_of])
         if self.llm.reserve(hp["rows"]):
             # the caches moved (cache_epoch bumped): every captured pass holds dead pointers and is unreachable by key — release the
             # graphs and their private activation pools now instead of waiting for 8 new captures to evict them
             self._graphs.clear()
             self._seen.clear()
-        meta = dict(grids=tuple(grids), want=tuple(want), seqs=tuple(hp["seqs"]))
-        pix = requests[0]["pix"] if B == 1 else torch.cat([r["pix"].to(self.dev) for r in requests], 0)
-        auxs = [r["aux"] if r["aux"].dim() == 3 else r["aux"][0] for r in requests]
+        meta = dict(grids=tuple(ugrids), want=tuple(want), seqs=tuple(hp["seqs"]), img_of=tuple(img_of))
+        ureqs = [requests[i] for i in first_of]
+        pix = ureqs[0]["pix"] if U == 1 else torch.cat([r["pix"].to(self.dev) for r in ureqs], 0)
+        auxs = [r["aux"] if r["aux"].dim() == 3 else r["aux"][0] for r in ureqs]
         host = dict(plan=hp["plan"], cos=hp["cos"], sin=hp["sin"], last=hp["last"],
-                    box_image=torch.tensor([i for i, b in enumerate(boxes) for _ in range(b.shape[0])], dtype=torch.int32))
-        key = (meta["grids"], tuple(tuple(a.shape) for a in auxs), tuple(n_reg), meta["seqs"], meta["want"], pix.dtype, auxs[0].dtype,
+                    box_image=torch.tensor([img_of[i] for i, b in enumerate(boxes) if want[i] for _ in range(b.shape[0])] or [0], dtype=torch.int32))
+        key = (meta["grids"], tuple(tuple(a.shape) for a in auxs), tuple(n_reg), meta["seqs"], meta["want"], meta["img_of"], pix.dtype, auxs[0].dtype,
                self.llm.cache_epoch)
         ent = self._graphs.get(key) if use_graph else None
         if use_graph and ent is None:
@@ -394,15 +425,15 @@ class FO1Engine:
         if ent is None:
             st = dict(pix=pix, aux=auxs, boxes=boxes, **{k: v.to(self.dev) for k, v in host.items()})
             if len({tuple(a.shape) for a in auxs}) == 1:      # same-size aux images: one DaViT pass over the stack (input staging)
-                st["aux_stack"] = auxs[0].unsqueeze(0) if B == 1 else torch.stack([a.to(self.dev) for a in auxs], 0)
-                if B > 1:
+                st["aux_stack"] = auxs[0].unsqueeze(0) if U == 1 else torch.stack([a.to(self.dev) for a in auxs], 0)
+                if U > 1 and all(want):
                     st["boxes_cat"] = torch.cat(boxes, 0)
             res = self._device_batch(st, meta)
         else:
             self._graphs.move_to_end(key)
             g, st, res, keep = ent
             off = 0
-            for r in requests:                      # device -> device slices; host tensors upload blocking
+            for r in ureqs:                         # device -> device slices; host tensors upload blocking
                 n = r["pix"].shape[0]
                 st["pix"][off:off + n].copy_(r["pix"], non_blocking=r["pix"].is_cuda)
                 off += n
@@ -423,7 +454,7 @@ class FO1Engine:
         outs = []
         for i, (o, L, Lp) in enumerate(hp["seqs"]):
             r0, r1 = res["region_ranges"][i]
-            i0 = res["row0"][i] // (m * m)
+            i0 = res["row0"][img_of[i]] // (m * m)
             outs.append(dict(image_tokens=res["image_tokens"][i0:i0 + n_img[i]],
                              region_tokens=res["region_tokens"][r0:r1] if res["region_tokens"] is not None and want[i] else None,
                              embeds=res["embeds"][o:o + L], last_hidden=res["last_hidden"][i:i + 1], logits=res["logits"][i:i + 1],
@@ -473,7 +504,7 @@ class FO1Engine:
                 if len({tuple(a.shape) for a in auxs}) == 1:
                     st["aux_stack"] = torch.stack([a.to(self.dev) for a in auxs], 0)
                     st["aux"] = list(st["aux_stack"].unbind(0))       # views: refreshing them refreshes the stack
-                    if len(boxes) > 1:
+                    if len(auxs) > 1 and all(meta["want"]):
                         st["boxes_cat"] = torch.cat(st["boxes"], 0)
                         st["boxes"] = list(st["boxes_cat"].split([b.shape[0] for b in boxes], 0))
                 else:
