@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FO1_ABI_VERSION 2
+#define FO1_ABI_VERSION 3   /* 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -130,6 +130,9 @@ typedef struct fo1_hfre_opts {
     const float* ln_w0; const float* ln_b0;      /* fp32 device, block [0, ln_split)                                    */
     const float* ln_w1; const float* ln_b1;      /* fp32 device, block [ln_split, region_dim)                           */
     float ln_eps;
+    void* out_bf16; int32_t out_bf16_ld;         /* optional: the rows ALSO written as bf16 (round to nearest even) — the cast
+                                                    encode_regions applies before mm_projector_aux (omchat_qwen2_5_vl.py:106);
+                                                    device bf16 [n_boxes, ld >= region_dim], ld % 4 == 0; NULL = fp32 only      */
 } fo1_hfre_opts_t;
 size_t fo1_hfre_ex_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes);
 int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, const float* boxes_aux, int n_boxes,

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version():
-    assert L.load().fo1_abi_version() == 2
+    assert L.load().fo1_abi_version() == 3
 
 
 def test_hfre_argument_errors():

@@ -286,6 +286,28 @@ def test_hfre_vt_only_with_ln_or_fm_strategy_and_aux_only():
     torch.testing.assert_close(got, torch.from_numpy(g["nopos"])[:, :3840], rtol=RTOL, atol=ATOL)
 
 
+def test_hfre_bf16_second_destination_is_the_rne_cast_of_the_fp32_rows():
+    """encode_regions casts the fp32 region features to the tower dtype before mm_projector_aux (omchat_qwen2_5_vl.py:106); the finish
+    kernel writes that cast itself (fo1_hfre_opts_t.out_bf16): bit-identical to torch's .to(bfloat16), with and without LayerNorm."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_hfre_variant_golden import ln_params
+    from vlm_fo1_amd.hfre import HFREModule
+    case = make_case("demo_fpn")
+    d = to_dev(case)
+    gh, gw = d["grid_hw"]
+    for ln in (None, ln_params()):
+        m = HFREModule(roi_output_size=7, region_feature_dim=5888, apply_position_embedding=True, use_vision_tower_region_feature=True,
+                       vision_tower_region_feature_dim=2048, use_simpleFPN_for_vt=True, simple_fpn=lambda x: d["fpn_maps"],
+                       apply_region_layer_norm=ln is not None)
+        if ln is not None:
+            m.set_region_norm(*[ln[k].cuda() for k in ("aux_w", "aux_b", "vt_w", "vt_b")])
+        n = d["boxes"].shape[0]
+        o16 = torch.zeros(n, 5888, dtype=torch.bfloat16, device="cuda")
+        o32 = m(d["aux_maps"], [d["boxes"]], torch.zeros(1, 1280, gh, gw, dtype=torch.bfloat16, device="cuda"), [d["vt_boxes"]], out_bf16=o16).squeeze(0)
+        assert torch.equal(o16, o32.to(torch.bfloat16))
+
+
 def test_hfre_batched_call_equals_per_image():
     """batch > 1: the maps of B same-size images stacked, all boxes in one launch with box_image — every box's row is bit-identical
     to the one-image call (same slices, same order)."""

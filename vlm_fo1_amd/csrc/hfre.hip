@@ -66,6 +66,8 @@ struct HfreParams {
     int ln_on, ln_split;                        // region LayerNorm (reference :365-372): blocks [0, ln_split) and [ln_split, region_dim)
     const float* ln_w0; const float* ln_b0; const float* ln_w1; const float* ln_b1;
     float ln_eps;
+    uint16_t* out_bf16; int out_bf16_ld;        // optional second destination: the same rows cast to bf16 (RNE) — what encode_regions does
+                                                // before mm_projector_aux (omchat_qwen2_5_vl.py:106): the cast rides in the finish kernel
     float* dimt;                                // work-list path: dim_t table of the sine embedding, region_dim / 8 entries (written by
                                                 // hfre_weights_kernel, read by hfre_finish_vec_kernel); nullptr = powf per element
 };
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(256) void hfre_finish_kernel(const HfreParams p) {
         v += (i & 1) ? cosf(ang) : sinf(ang);
     }
     p.out[(size_t)n * p.out_ld + c] = v;
+    if (p.out_bf16) p.out_bf16[(size_t)n * p.out_bf16_ld + c] = f32_to_bf16(v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -357,6 +360,7 @@ __device__ __forceinline__ void hfre_finish_row(const HfreParams& p, int n, int 
                 if (!p.ln_on) {
                     if (p.pos_mode != 0) v += hfre_sine(p, s_stat, c);
                     p.out[(size_t)n * p.out_ld + c] = v;
+                    if (p.out_bf16) p.out_bf16[(size_t)n * p.out_bf16_ld + c] = f32_to_bf16(v);
                 } else if (pass == 0) {
                     part += v;
                 } else if (pass == 1) {
@@ -368,6 +372,7 @@ __device__ __forceinline__ void hfre_finish_row(const HfreParams& p, int n, int 
                     float o = (v - mean) * rstd * lw[c - c0] + lb[c - c0];
                     if (p.pos_mode != 0) o += hfre_sine(p, s_stat, c);
                     p.out[(size_t)n * p.out_ld + c] = o;
+                    if (p.out_bf16) p.out_bf16[(size_t)n * p.out_bf16_ld + c] = f32_to_bf16(o);
                 }
             }
             if (p.ln_on && pass < 2) {
@@ -546,6 +551,12 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_finish_vec_kernel(const Hfr
         v.x += sinf(a0); v.y += cosf(a0); v.z += sinf(a1); v.w += cosf(a1);
     }
     *reinterpret_cast<float4*>(p.out + (size_t)n * p.out_ld + c) = v;
+    if (p.out_bf16) {
+        uint2 b;
+        b.x = pack_bf16x2(v.x, v.y);
+        b.y = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2*>(p.out_bf16 + (size_t)n * p.out_bf16_ld + c) = b;
+    }
 }
 
 static int g_hfre_pixel_budget = 0;  // 0 = auto
@@ -672,6 +683,7 @@ int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const 
     p.pos_h = pos_img_h;
     p.out = out;
     p.out_ld = out_ld;
+    p.out_bf16 = nullptr; p.out_bf16_ld = 0;
     p.region_dim = region_dim;
     p.ws = (float*)workspace;
     p.wbuf = p.ws + (size_t)p.ws_box_stride * n_boxes;
@@ -754,6 +766,7 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
     }
     p.box_image = nullptr;
     p.ln_on = 0; p.ln_split = 0; p.ln_w0 = p.ln_b0 = p.ln_w1 = p.ln_b1 = nullptr; p.ln_eps = 1e-5f;
+    p.out_bf16 = nullptr; p.out_bf16_ld = 0;
     if (opts) {
         FO1_CHECK_ARG(opts->batch >= 1, "hfre: batch=%d", opts->batch);
         FO1_CHECK_ARG(opts->batch == 1 || opts->box_image != nullptr, "hfre: a batched call needs box_image");
@@ -761,6 +774,11 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
         for (int i = 0; i < n_sources; ++i) {
             FO1_CHECK_ARG(opts->img_stride[i] % 8 == 0, "hfre: img_stride[%d] must keep 16-byte alignment", i);
             p.img_stride[i] = opts->img_stride[i];
+        }
+        if (opts->out_bf16) {
+            FO1_CHECK_ARG(opts->out_bf16_ld >= region_dim && opts->out_bf16_ld % 4 == 0 && ((uintptr_t)opts->out_bf16 & 7) == 0,
+                          "hfre: out_bf16 needs ld >= region_dim, ld %% 4 == 0 and 8-byte alignment");
+            p.out_bf16 = (uint16_t*)opts->out_bf16; p.out_bf16_ld = opts->out_bf16_ld;
         }
         if (opts->ln_on) {
             FO1_CHECK_ARG(opts->ln_split >= 0 && opts->ln_split <= region_dim, "hfre: ln_split=%d", opts->ln_split);

@@ -143,7 +143,7 @@ class HFREModule:
 
     def pool(self, srcs: list, boxes: torch.Tensor, vt_boxes: Optional[torch.Tensor], vt_scale, pos_hw, out: Optional[torch.Tensor] = None,
              batch: int = 1, box_image: Optional[torch.Tensor] = None, img_strides: Optional[Sequence[int]] = None,
-             ln_split: Optional[int] = None) -> torch.Tensor:
+             ln_split: Optional[int] = None, out_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The C-ABI call.  srcs: HfreSource list (image 0 of every map); boxes fp32 [N,4] (all images' boxes, image of box n =
         box_image[n]); pos_hw = (pos_h, pos_w) normalisers of the box embedding.  Returns fp32 [1, N, region_feature_dim]."""
         L = _lib.load()
@@ -171,7 +171,9 @@ class HFREModule:
         use_ln = self.apply_region_layer_norm and not self.use_vt_region_feature_only
         if use_ln and self._ln is None:
             raise _lib.Fo1Error("apply_region_layer_norm: call set_region_norm() with the checkpoint's LayerNorm parameters first")
-        if self.worklist or use_ln or batch > 1:
+        if out_bf16 is not None and (out_bf16.dtype != torch.bfloat16 or out_bf16.shape != (N, off) or out_bf16.stride(1) != 1 or out_bf16.device != dev):
+            raise ValueError(f"out_bf16 must be a device bf16 [{N}, {off}] row-major tensor")
+        if self.worklist or use_ln or batch > 1 or out_bf16 is not None:
             _apply_env()
             need = L.fo1_hfre_ex_workspace_bytes(arr, len(srcs), N)
             ws = _ops._workspace("hfre_ex", dev, max(int(need), 1))
@@ -187,6 +189,8 @@ class HFREModule:
                 opts.ln_w0, opts.ln_b0 = (aw.data_ptr(), ab.data_ptr()) if aw is not None else (None, None)
                 opts.ln_w1, opts.ln_b1 = (vw.data_ptr(), vb.data_ptr()) if vw is not None else (None, None)
                 opts.ln_eps = 1e-5
+            if out_bf16 is not None:
+                opts.out_bf16, opts.out_bf16_ld = out_bf16.data_ptr(), out_bf16.stride(0)
             rc = L.fo1_hfre_region_pool_ex(arr, len(srcs), boxes.data_ptr(), N, vt_boxes.data_ptr() if vt_boxes is not None else None,
                                               float(sx), float(sy), self.roi_output_size, pos_mode, float(pos_hw[1]), float(pos_hw[0]),
                                               out.data_ptr(), out.stride(1), off, ctypes.byref(opts), ws.data_ptr(), ws.numel(),
@@ -205,11 +209,13 @@ class HFREModule:
 
     def __call__(self, aux_multi_level_features: List[torch.Tensor], aux_boxes: Union[torch.Tensor, List[torch.Tensor]],
                  vt_multi_level_features=None, vt_boxes: Union[torch.Tensor, List[torch.Tensor], None] = None,
-                 vt_scale=None, out: Optional[torch.Tensor] = None, batch: int = 1, box_image: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 vt_scale=None, out: Optional[torch.Tensor] = None, batch: int = 1, box_image: Optional[torch.Tensor] = None,
+                 out_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns fp32 [1, N, region_feature_dim] like the reference (:469).  `vt_boxes` may be omitted when `vt_scale=(sx, sy)` is
         given (vt = aux * scale in-kernel).  `out`: optional fp32 [N, C_region] row-contiguous destination.  batch > 1: every map
         tensor holds `batch` same-size images stacked ([1,C,H,W] views of image 0 whose storage continues image by image, H*W*ld
-        elements apart), `aux_boxes` holds all images' boxes and `box_image` (device int32 [N]) the image of each."""
+        elements apart), `aux_boxes` holds all images' boxes and `box_image` (device int32 [N]) the image of each.  `out_bf16`: optional
+        bf16 [N, C_region] destination written by the same finish kernel (the `.to(tower dtype)` of omchat_qwen2_5_vl.py:106)."""
         boxes = aux_boxes[0] if isinstance(aux_boxes, (list, tuple)) else aux_boxes
         dev = aux_multi_level_features[0].device if aux_multi_level_features else boxes.device
         if dev.type != "cuda":
@@ -272,6 +278,6 @@ class HFREModule:
         else:
             pos_hw = (H0 / self.aux_vision_tower_spatial_scale, W0 / self.aux_vision_tower_spatial_scale)
         return self.pool(srcs, boxes, vtb, vt_scale, pos_hw, out=out, batch=batch, box_image=box_image, img_strides=strides,
-                         ln_split=aux_channels)
+                         ln_split=aux_channels, out_bf16=out_bf16)
 
     forward = __call__

@@ -33,6 +33,7 @@ class HfreOpts(ctypes.Structure):
         ("ln_on", c_int32), ("ln_split", c_int32),
         ("ln_w0", c_void_p), ("ln_b0", c_void_p), ("ln_w1", c_void_p), ("ln_b1", c_void_p),
         ("ln_eps", c_float),
+        ("out_bf16", c_void_p), ("out_bf16_ld", c_int32),
     ]
 
 

@@ -204,9 +204,10 @@ class FO1Engine:
             vt_in = nchw(vt_feats[-1], (gh, gw))
         else:
             vt_in = [nchw(t, (gh, gw)) for t in vt_feats]
-        feat = self.hfre(aux_views, [boxes], vt_in, None, vt_scale=(sw, sh)).squeeze(0)   # fp32 [N, C_region]
+        feat16 = torch.empty(boxes.shape[0], self.cfg.mm_region_hidden_size, dtype=torch.bfloat16, device=self.dev)
+        self.hfre(aux_views, [boxes], vt_in, None, vt_scale=(sw, sh), out_bf16=feat16)     # fp32 [N, C_region] + its bf16 cast (:106), one kernel
         self._mark("hfre_region_pool")
-        out = self.mm_projector_aux(feat.to(torch.bfloat16))                               # :106-107
+        out = self.mm_projector_aux(feat16)                                                # :107
         self._mark("mm_projector_aux")
         return out
 
@@ -224,6 +225,7 @@ class FO1Engine:
             return None, [(0, 0)] * len(want)
         p = self.cfg.vit.patch_size
         feat = torch.empty(sum(boxes[i].shape[0] for i in idx), self.cfg.mm_region_hidden_size, dtype=torch.float32, device=self.dev)
+        feat16 = torch.empty(feat.shape, dtype=torch.bfloat16, device=self.dev)   # the `.to(tower dtype)` of :106, written by the HFRE finish kernel
         imgs = sorted({img_of[i] for i in idx})                 # unique images that feed the region branch
         all_imgs = len(imgs) == len(auxs)
         uniform = aux_stack is not None and all_imgs and len(set(grids)) == 1 and len(idx) == len(want)
@@ -257,7 +259,7 @@ class FO1Engine:
             else:
                 vt_in = vt_views
             r0, r1 = ranges[i]
-            self.hfre(aux_views, [boxes[i]], vt_in, None, vt_scale=scales(u), out=feat[r0:r1])
+            self.hfre(aux_views, [boxes[i]], vt_in, None, vt_scale=scales(u), out=feat[r0:r1], out_bf16=feat16[r0:r1])
 
         if uniform:
             G = len(auxs)
@@ -279,7 +281,7 @@ class FO1Engine:
                     vt_in = nchw(vt_last, (gh, gw))
                 else:
                     vt_in = [nchw(t, (gh, gw)) for t in vt_last]
-                self.hfre(aux_views, [boxes_cat], vt_in, None, vt_scale=scales(0), out=feat, batch=G, box_image=box_image)
+                self.hfre(aux_views, [boxes_cat], vt_in, None, vt_scale=scales(0), out=feat, batch=G, box_image=box_image, out_bf16=feat16)
             else:
                 for i in idx:
                     u = img_of[i]
@@ -333,7 +335,7 @@ class FO1Engine:
                     if img_of[i] == u:
                         hfre_request(i, aux_views, fv, vv)
             self._mark("hfre_region_pool")
-        out = self.mm_projector_aux(feat.to(torch.bfloat16))                               # :106-107
+        out = self.mm_projector_aux(feat16)                                                # :107
         self._mark("mm_projector_aux")
         return out, [ranges.get(i, (0, 0)) for i in range(len(want))]
 
