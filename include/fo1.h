@@ -90,13 +90,6 @@ typedef struct fo1_hfre_source {
     int32_t out_offset;  /* first output channel written by this source                    */
 } fo1_hfre_source_t;
 
-/* Tuning hook: footprint pixels one workgroup streams per row-slice (0 = auto: 256 up to 48 boxes, else 512). */
-int fo1_hfre_set_pixel_budget(int pixels);
-/* Tuning hook of fo1_hfre_region_pool_ex: unroll = 8 | 16 independent 16-byte loads per lane; chunk = channels per workgroup
- * (power of two, 64..512); budget = pixels per row slice (0 = keep); grid = workgroups walking the work list (0 = keep).
- * Process-global; results are bit-identical across unroll / grid (the fp32 sum order depends on budget and chunk only). */
-int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid);
-
 /* Bytes of scratch fo1_hfre_region_pool needs for these sources / n_boxes. */
 size_t fo1_hfre_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes);
 
@@ -180,20 +173,7 @@ int fo1_rmsnorm_quant_e4m3(const void* x, int ldx, const void* weight, int M, in
                            void* stream);
 int fo1_gemm_fp8(const void* Aq, int lda, const float* scale_a, const void* Wq, int ldw, const float* scale_w, const void* bias,
                  const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* stream);
-/* Tuning hooks: staging 0 auto / 1 register-staged / 2 LDS-DMA two-stage / 3, 4, 6 LDS-DMA ring of that depth
- * (counted vmcnt; 6 only for the 64x64 tile, else 4); tile 0 auto / 1 128x128 / 2 64x128 / 3 64x64 / 4 128x256
- * (8 waves); split-K 0 auto / n forced; per-shape kernel names in the profile. */
-int fo1_gemm_set_variant(int staging, int tile);
-int fo1_gemm_set_splitk(int splits);
-int fo1_gemm_set_big_schedule(int sched); /* 256x256 kernel, bit field: bit 0 = two fat phases per K tile with the DMA issued between MFMAs
-                                            * (0 = four phases); bit 1 = fragment-shaped epilogue stores (0 = LDS-staged coalesced);
-                                            * bit 2 = persistent tile loop (the next tile's first DMA under the epilogue, when there
-                                            * are more than 256 tiles; bit-identical, measured 2-5 % slower); bit 3 = non-temporal
-                                            * epilogue stores (no effect measured).  Default 1. */
-int fo1_gemm_set_debug(int bits); /* ablation for benches only (results invalid): 1 no global loads, 2 no MFMA, 4 no LDS reads + MFMA;
-                                   * 256x256 two-phase kernel: 8 epilogue computed but not stored, 16 one K tile per output tile
-                                   * (profiles/r02_gemm_t0_study.md) */
-int fo1_gemm_set_gemv(int on);   /* M <= 4 goes to the weight-streaming GEMV kernel (default on) */
+/* Instrumentation (with fo1_profile_enable): per-shape kernel names in the profile rows instead of one row per kernel. */
 int fo1_gemm_profile_shapes(int on);
 
 /* ------------------------------------------------------------------------
@@ -352,20 +332,6 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
                               const void* vtcache, long long vt_row_stride, void* out, const int32_t* dyn_kv_len,
                               int max_kv_len, int n_q_heads, int n_kv_heads, int head_dim, float scale,
                               void* workspace, size_t workspace_bytes, void* stream);
-
-/* A/B hook of fo1_gemv_batch_bf16: 0 (default) = a lane streams 1 / 2 / 4 weight rows per chunk position by M (x chunks read from
- * LDS are shared between them); 1 = always one row.  Results are bit-identical either way.  Process-global. */
-int fo1_gemv_batch_set_rows_per_lane(int rpl);
-
-/* A/B hooks of the decode step, process-global.
- * fo1_gemv_batch_set_impl: 1 (default) = MFMA skinny GEMM (csrc/decode_mfma.hip: the sequences ride as the 16 columns of
- *   v_mfma_f32_16x16x32_bf16, M <= 16, needs N % 4 == 0); 0 = the v_dot2 streaming kernel (M <= 8).  Both keep a
- *   sequence's numbers independent of the batch it decodes in; the two differ from each other in fp32 summation order.
- * fo1_attention_decode_set_impl: 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head,
- *   sequence), tiles round-robin over its waves, partials merged in LDS (one launch for slots <= 2048 rows; measured slower
- *   on MI355X: one CU cannot pull a head's K/V^T fast enough). */
-int fo1_gemv_batch_set_impl(int impl);
-int fo1_attention_decode_set_impl(int impl);
 
 /* ------------------------------------------------------------------------
  * Batched greedy decode: B <= 16 sequences advance one token per step through ONE stream of the weights, and

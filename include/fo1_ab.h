@@ -1,0 +1,58 @@
+/* fo1_ab.h — A/B, ablation and determinism-pin switches of libfo1hip_ab.so.  NOT part of the product ABI.
+ *
+ * Every function here writes PROCESS-GLOBAL state: not thread-safe, never to be called by a serving process.  They exist so that
+ *   - the parity tests can pin the GEMM tile / split-K / GEMV routing (a row's fp32 summation order then does not depend on how many
+ *     rows share the launch: "packed pass == one-image passes, bit for bit");
+ *   - the measured-slower kernel forms kept for A/B (four-phase and persistent 256 x 256 GEMM schedules, the v_dot2 decode GEMV, the
+ *     one-workgroup-per-head decode attention, the round-1 worst-case-grid HFRE gather) can still be selected and re-measured.
+ * They are compiled ONLY into the test / bench build (hipcc -DFO1_ENABLE_AB -> vlm_fo1_amd/libfo1hip_ab.so, loaded when FO1_AB=1; the
+ * GPU test session sets it in tests/conftest.py).  The product library vlm_fo1_amd/libfo1hip.so exports none of these symbols, carries
+ * none of that mutable state (the defaults are compile-time constants) and none of those kernels: tests/test_abi.py checks both
+ * export tables against the two headers. */
+#ifndef FO1_AB_H
+#define FO1_AB_H
+
+#include "fo1.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- HFRE gather ---- */
+/* footprint pixels one workgroup streams per row-slice (0 = auto: 256 up to 48 boxes, else 512). */
+int fo1_hfre_set_pixel_budget(int pixels);
+/* fo1_hfre_region_pool_ex: unroll = 8 | 16 independent 16-byte loads per lane (| 32 = scalar finish kernel); chunk = channels per workgroup
+ * (power of two, 64..512); budget = pixels per row slice (0 = keep); grid = workgroups walking the work list (0 = keep).
+ * Results are bit-identical across unroll / grid (the fp32 sum order depends on budget and chunk only). */
+int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid);
+
+/* ---- GEMM ---- */
+/* staging 0 auto / 1 register-staged / 2 LDS-DMA two-stage / 3, 4, 6 LDS-DMA ring of that depth (counted vmcnt; 6 only for the 64x64 tile,
+ * else 4); tile 0 auto / 1 128x128 / 2 64x128 / 3 64x64 / 4 128x256 (8 waves) / 5 256x256; split-K 0 auto / n forced.
+ * (2, 1) + splitk 1 + gemv 0 is the determinism pin of the parity tests. */
+int fo1_gemm_set_variant(int staging, int tile);
+int fo1_gemm_set_splitk(int splits);
+int fo1_gemm_set_gemv(int on);   /* M <= 4 goes to the weight-streaming GEMV kernel (default on) */
+/* 256x256 kernel, bit field: bit 0 = two fat phases per K tile with the DMA issued between MFMAs (0 = four phases); bit 1 = fragment-shaped
+ * epilogue stores (0 = LDS-staged coalesced); bit 2 = persistent tile loop (bit-identical, measured 2-5 % slower); bit 3 = non-temporal
+ * epilogue stores (no effect measured).  Default 1. */
+int fo1_gemm_set_big_schedule(int sched);
+/* ablation, RESULTS INVALID: 1 no global loads, 2 no MFMA, 4 no LDS reads + MFMA; 256x256 two-phase kernel: 8 epilogue computed but not
+ * stored, 16 one K tile per output tile (profiles/r02_gemm_t0_study.md) */
+int fo1_gemm_set_debug(int bits);
+
+/* ---- decode step ---- */
+/* fo1_gemv_batch_bf16, v_dot2 kernel: 0 (default) = a lane streams 1 / 2 / 4 weight rows per chunk position by M; 1 = always one row. */
+int fo1_gemv_batch_set_rows_per_lane(int rpl);
+/* 1 (default) = MFMA skinny GEMM (csrc/decode_mfma.hip: the sequences ride as the 16 columns of v_mfma_f32_16x16x32_bf16); 0 = the v_dot2
+ * streaming kernel (M <= 8); 3 = MFMA without any 8-row units; 5 = MFMA with the M <= 8 (HALF) units only (no R8 units for 9..16 sequences).
+ * All keep a sequence's numbers independent of the batch it decodes in; MFMA and v_dot2 differ from each other in fp32 summation order. */
+int fo1_gemv_batch_set_impl(int impl);
+/* 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence), partials merged in LDS (measured
+ * slower on MI355X: one CU cannot pull a head's K/V^T fast enough). */
+int fo1_attention_decode_set_impl(int impl);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FO1_AB_H */

@@ -4,6 +4,7 @@ split + combine), at several batch sizes, one model build.
 usage: decode_ab.py [out.json] [B ...]      (default B = 1 8 16)"""
 import json
 import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import sys
 import time
 

@@ -1,5 +1,7 @@
 """Per-kernel time of one batched decode step (GPU box only): eager launches with the library's per-launch event pairs.
 usage: decode_batch_profile.py [B] [kv_len]"""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))

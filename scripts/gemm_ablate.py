@@ -1,4 +1,6 @@
 """Ablation of the LDS-DMA GEMM main loop (GPU box): where does the time go?  Results are INVALID numerically."""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

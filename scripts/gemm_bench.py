@@ -3,6 +3,8 @@ usage: gemm_bench.py <out.json> [cold|warm] [filter]
 `cold` (default) rotates the weight operand through enough distinct copies (> 640 MB) that every launch streams its
 weights from HBM, as in the pipeline (8 GB of weights per step never stay in the 256 MB Infinity Cache); `warm` re-uses
 one copy (L2 / Infinity-Cache resident), which flatters the small latency-bound GEMMs by ~2x."""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,8 @@
 """Micro-benchmark of the large-M GEMM paths on the batched-prefill shapes (GPU box only): the 256x256 ping-pong kernel
 (tile 5) against the best of the round-1 tiles (auto), cold weights (every launch streams its weight panel from HBM).
 usage: gemm_bench_p8.py <out.json> [images]"""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,7 @@
 """Where the per-tile overhead of the 256x256 GEMM goes (GPU box only): normal / non-temporal epilogue stores / no epilogue stores /
 one K tile only (prologue + epilogue), cold weights.  usage: gemm_t0_study.py <out.json> [images]"""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,7 @@
 """HFRE three-kernel form, per-kernel times (library event pairs) at 1 / 8 / 12 images x 100 boxes: scalar finish (round-2 first form)
 vs the 16-byte finish; outputs compared bitwise.  usage: hfre_ab.py [out.json]"""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,4 +1,6 @@
 """Kernel-only times (dispatch timestamps) of the three HFRE kernels on the bench geometry.  usage: hfre_kernel_times.py [n_boxes ...]"""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

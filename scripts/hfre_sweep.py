@@ -2,6 +2,8 @@
 work-list kernels x unroll x chunk x slice budget x grid size.  Every timing is a hipGraph of 20 calls
 replayed 10 times; configurations of one budget are compared bitwise, and the default one is replayed 100 times under a noisy side
 stream (256 MB copies + GEMMs) and compared bitwise with the quiet result."""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,5 +1,7 @@
 """Does the best GEMM tile change when several images are in flight (occupancy gaps filled by other streams)?
 Forces one tile shape / split-K setting for ALL GEMMs and measures 3-in-flight throughput.  GPU box only."""
+import os
+os.environ.setdefault("FO1_AB", "1")   # A/B switches live in the test / bench build only (include/fo1_ab.h)
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# The test session runs on the test / bench build of the library (libfo1hip_ab.so): the parity tests pin the GEMM tile / split-K / GEMV
+# routing through include/fo1_ab.h's switches, which the product library (libfo1hip.so) does not have.  tests/test_product_lib_gpu.py
+# and __graft_entry__.smoke() / bench.py run the product library.
+os.environ.setdefault("FO1_AB", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

@@ -11,20 +11,43 @@ from vlm_fo1_amd import lib as L
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    txt = open(os.path.join(ROOT, "include", "fo1.h")).read()
+def declared_symbols(header="fo1.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(fo1_[a-z0-9_]+)\s*\(", txt)))
 
 
+def exported(so):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "vlm_fo1_amd", so)], capture_output=True, text=True, check=True).stdout
+    return sorted({l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("fo1_") and " T " in l})
+
+
 def test_library_exports_every_declared_symbol():
-    lib = L.load()
+    lib = L.load()              # the test session's library: the test / bench build (FO1_AB=1, tests/conftest.py)
     syms = declared_symbols()
     assert "fo1_hfre_region_pool" in syms
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/fo1.h but not exported"
     # and the Python binding table covers exactly the header
     assert sorted(L.SIGNATURES) == syms
+    assert sorted(L.SIGNATURES_AB) == declared_symbols("fo1_ab.h")
+
+
+def test_product_library_has_no_switches_and_the_ab_build_has_exactly_the_two_headers():
+    """the product library's export table IS include/fo1.h — none of the process-global A/B, ablation or
+    tuning switches (include/fo1_ab.h) exist in it; the test / bench build exports both headers and nothing else."""
+    prod, ab = declared_symbols(), declared_symbols("fo1_ab.h")
+    assert not set(prod) & set(ab)
+    assert exported("libfo1hip.so") == prod
+    assert exported("libfo1hip_ab.so") == sorted(prod + ab)
+    assert all("_set_" in s for s in ab) and not any("_set_" in s for s in prod)
+    # the product build also leaves the measured-slower kernel forms out
+    import subprocess
+    for so, want in (("libfo1hip.so", False), ("libfo1hip_ab.so", True)):
+        blob = open(os.path.join(ROOT, "vlm_fo1_amd", so), "rb").read()
+        for kernel in (b"gemm_bt_p8_kernel", b"gemm_bt_p4p_kernel", b"attn_decode_wg_kernel", b"gemv_batch_kernel", b"hfre_pool_kernel"):
+            assert (kernel in blob) == want, f"{kernel.decode()} {'missing from' if want else 'present in'} {so}"
 
 
 def test_abi_version():
@@ -55,6 +78,7 @@ def test_hfre_argument_errors():
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(L, "_lib", None)
     monkeypatch.setattr(L, "LIB_PATH", str(tmp_path / "nope.so"))
+    monkeypatch.setattr(L, "LIB_PATH_AB", str(tmp_path / "nope_ab.so"))
     with pytest.raises(L.Fo1Error):
         L.load()
 
@@ -70,7 +94,7 @@ def test_plain_c_host_builds_against_the_header_and_drives_the_library(tmp_path)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     inc = os.path.join(root, "include")
     hdr = tmp_path / "hdr.c"
-    hdr.write_text('#include "fo1.h"\nint main(void) { return 0; }\n')
+    hdr.write_text('#include "fo1.h"\n#include "fo1_ab.h"\nint main(void) { return 0; }\n')
     subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", inc, "-fsyntax-only", str(hdr)], check=True)
     exe = tmp_path / "abi_host"
     subprocess.run([gcc, "-std=c99", "-Wall", "-I", inc, os.path.join(root, "tests", "host_emul", "abi_host.c"), "-o", str(exe), "-ldl"], check=True)

@@ -16,6 +16,7 @@
 // V is consumed as V^T ([kv_head*HD + d][key]) so that a lane's 8 k-slots are two 8-byte LDS reads;
 // the transposed copy is written once per layer by fo1_transpose_bf16 (rope.hip).
 #include "common.h"
+#include "ab.h"
 
 namespace fo1 {
 
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __
 // 13.0 + 4.5 us (B = 16) for the 64-key split kernel + combine: all of a (KV head, sequence)'s K/V^T (333 KB) funnels through
 // ONE CU in fragment-shaped 64-byte / 8-byte pieces (20 GB/s), where the split kernel spreads 64-key chunks over 22+ CUs and
 // stages them coalesced through LDS.  Kept as an A/B option (fo1_attention_decode_set_impl), not the default.
+#ifdef FO1_ENABLE_AB      // one workgroup per (KV head, sequence): measured slower than split + combine, A/B only
 struct AttnDecParams {
     const uint16_t* Q; long long q_seq_stride;       // q rows [B][n_q_heads * 128]
     const uint16_t* K; long long k_tok, k_head;
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(NW * 64) void attn_decode_wg_kernel(const AttnDecPa
     }
 }
 
-int g_attn_decode_impl = 0;   // 0 = 64-key split-KV partials + combine; 1 = attn_decode_wg_kernel (measured slower: see the note below)
+static int g_attn_decode_impl = 0;   // 0 = 64-key split-KV partials + combine; 1 = attn_decode_wg_kernel (measured slower: see the note below)
 
 // One launch for slots up to 2048 rows (32 tiles over 8 waves); longer slots: 1024-key splits + the fixed-order combine.
 static int launch_attn_decode_wg(AttnDecParams& p, int max_kv_len, int batch, int n_q_heads, hipStream_t st) {
@@ -572,6 +574,8 @@ static int launch_attn_decode_wg(AttnDecParams& p, int max_kv_len, int batch, in
                    st, (const float*)p.part, p.dyn_kv_len, p.split_keys, p.n_kv_heads, p.group, p.O, p.seq_state, p.part_seq_stride, p.o_seq_stride);
     return FO1_OK;
 }
+
+#endif   // FO1_ENABLE_AB (attn_decode_wg_kernel)
 
 extern int g_gemv_profile_shapes;   // gemv.hip: per-shape profile rows (fo1_gemm_profile_shapes)
 
@@ -677,6 +681,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
         return set_err(FO1_ERR_WORKSPACE, "attention_decode: workspace too small");
     static const AttnItem* one_item = nullptr;
     const int group = n_q_heads / n_kv_heads;
+#ifdef FO1_ENABLE_AB
     if (g_attn_decode_impl == 1) {
         AttnDecParams d;
         d.Q = (const uint16_t*)q; d.q_seq_stride = 0;
@@ -687,6 +692,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
         d.n_kv_heads = n_kv_heads; d.group = group; d.scale = scale;
         return launch_attn_decode_wg(d, max_kv_len, 1, n_q_heads, (hipStream_t)stream);
     }
+#endif
     AttnParams p;
     p.Q = (const uint16_t*)q; p.q_tok = head_dim; p.q_head = (long long)group * head_dim;   // "queries" walk the heads of a group
     p.K = (const uint16_t*)kcache; p.k_tok = k_tok_stride; p.k_head = k_head_stride;
@@ -709,6 +715,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
     return FO1_OK;
 }
 
+#ifdef FO1_ENABLE_AB      // include/fo1_ab.h: test / bench build only
 // A/B hook: 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence) with the waves'
 // partials merged in LDS (one launch up to 2048 keys; measured slower, see attn_decode_wg_kernel).
 int fo1_attention_decode_set_impl(int impl) {
@@ -716,6 +723,7 @@ int fo1_attention_decode_set_impl(int impl) {
     fo1::g_attn_decode_impl = impl;
     return FO1_OK;
 }
+#endif   // FO1_ENABLE_AB
 
 // Batched decode attention: B sequences, one new token each (q rows [B, n_q_heads*head_dim]); sequence b attends the cache rows
 // [state[b][2], state[b][0]] (its slot start .. the row just written).  grid = (max chunks per slot, KV heads, B).
@@ -735,6 +743,7 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     if (workspace_bytes < fo1_attention_decode_batch_workspace_bytes(max_kv_len, n_kv_heads, head_dim, batch))
         return set_err(FO1_ERR_WORKSPACE, "attention_decode_batch: workspace too small");
     const int group = n_q_heads / n_kv_heads;
+#ifdef FO1_ENABLE_AB
     if (g_attn_decode_impl == 1) {
         AttnDecParams d;
         d.Q = (const uint16_t*)q; d.q_seq_stride = q_seq_stride;
@@ -745,6 +754,7 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
         d.n_kv_heads = n_kv_heads; d.group = group; d.scale = scale;
         return launch_attn_decode_wg(d, max_kv_len, batch, n_q_heads, (hipStream_t)stream);
     }
+#endif
     AttnParams p;
     p.Q = (const uint16_t*)q; p.q_tok = head_dim; p.q_head = (long long)group * head_dim;
     p.K = (const uint16_t*)kcache; p.k_tok = k_tok_stride; p.k_head = k_head_stride;

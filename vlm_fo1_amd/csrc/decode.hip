@@ -16,6 +16,7 @@
 //   argmax_accept          two-stage argmax per row, then ON-DEVICE bookkeeping: record the id, stop check, advance state,
 //                          write the next step's embedding-gather plan — the host never reads a token inside the loop
 #include "decode_common.h"
+#include "ab.h"
 
 namespace fo1 {
 
@@ -53,6 +54,7 @@ __device__ __forceinline__ float dot8b(const uint4& w, const uint4& x, float acc
 // from LDS between them.  At M = 8 one unit per lane reads 8 x-chunks per weight chunk — LDS traffic 8x the weight stream, 9 us
 // for the 90 MB gate/up matrix on its own; RPL = 4 brings it to 2x.  The per-(row, sequence) sum order does not depend on RPL
 // (or on M): a sequence decodes to the same numbers alone and in any batch.
+#ifdef FO1_ENABLE_AB      // the v_dot2 streaming kernel: equal at 1 sequence, 1.4x slower at 8 than the MFMA skinny GEMM; A/B only
 template <int MM, int MODE, bool KSPLIT, int RPL>
 __global__ __launch_bounds__(256) void gemv_batch_kernel(const GemvBParams p) {
     constexpr int NR = 8, U = 8 / RPL;   // 16-B weight loads per row per batch; two batches (register buffers) in flight per lane
@@ -392,18 +394,24 @@ static int dispatch_gemv_b(GemvBParams& p, int mode, hipStream_t st) {
     return ks ? launch_gemv_b<MM, GB_PLAIN, true, RB>(p, name, n_units, st) : launch_gemv_b<MM, GB_PLAIN, false, RA>(p, name, n_units, st);
 }
 
-static int g_gemv_impl = 1;  // 1 = MFMA skinny GEMM (decode_mfma.hip, M <= 16), 0 = the v_dot2 kernel above (M <= 8)
+#endif   // FO1_ENABLE_AB (gemv_batch_kernel)
+
+FO1_AB_VAR g_gemv_impl = 1;  // 1 = MFMA skinny GEMM (decode_mfma.hip, M <= 16), 0 = the v_dot2 kernel above (M <= 8)
 
 static int gemv_b_any(GemvBParams& p, int mode, hipStream_t st) {
     // the MFMA kernel moves epilogue operands four features at a time
     const bool quads = p.N % 4 == 0 && (!p.res || (p.ldr % 4 == 0 && ((uintptr_t)p.res & 7) == 0)) && ((uintptr_t)p.bias & 7) == 0 &&
                        ((uintptr_t)p.cos_t & 7) == 0 && ((uintptr_t)p.sin_t & 7) == 0 && ((uintptr_t)p.kcache & 7) == 0;
     if (g_gemv_impl == 1 && quads) return gemv_mfma_any(p, mode, st);
+#ifdef FO1_ENABLE_AB
     if (p.M > 8) return set_err(FO1_ERR_ARG, "gemv_batch: the v_dot2 kernel handles M <= 8 (M=%d)", p.M);
     if (p.M == 1) return dispatch_gemv_b<1>(p, mode, st);
     if (p.M == 2) return dispatch_gemv_b<2>(p, mode, st);
     if (p.M <= 4) return dispatch_gemv_b<4>(p, mode, st);
     return dispatch_gemv_b<8>(p, mode, st);
+#else
+    return set_err(FO1_ERR_ARG, "gemv_batch: operands must be 8-byte aligned with N %% 4 == 0 (N=%d)", p.N);
+#endif
 }
 
 // ---- argmax over B rows + on-device accept ------------------------------------------------------------------------------
@@ -529,6 +537,7 @@ extern "C" {
 
 
 
+#ifdef FO1_ENABLE_AB      // include/fo1_ab.h: test / bench build only
 // A/B hook: 1 = one unit (8 weight rows) per lane group whatever M is (the first form of this kernel); 0 = rows per lane by M.
 int fo1_gemv_batch_set_rows_per_lane(int rpl) {
     if (rpl != 0 && rpl != 1) return fo1::set_err(FO1_ERR_ARG, "gemv_batch_set_rows_per_lane: %d", rpl);
@@ -545,6 +554,7 @@ int fo1_gemv_batch_set_impl(int impl) {
     fo1::g_gemv_half = (impl & 2) ? 0 : ((impl & 4) ? 1 : 3);
     return FO1_OK;
 }
+#endif   // FO1_ENABLE_AB
 
 // Batched decode projection: C[M<=16, N] = epilogue(rmsnorm?(x) @ W^T), weights streamed once for all M rows.
 // mode 0: bias -> bf16 -> + residual;  mode 1: interleaved SwiGLU (C has N/2 columns);  mode 2: fused QKV:

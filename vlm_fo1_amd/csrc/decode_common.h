@@ -28,7 +28,11 @@ struct GemvBParams {
 enum { GB_PLAIN = 0, GB_SWIGLU = 1, GB_QKV = 2 };
 
 // decode_mfma.hip
-extern int g_gemv_half;   // decode_mfma.hip: 8-row units at M <= 8
+#ifdef FO1_ENABLE_AB
+extern int g_gemv_half;   // decode_mfma.hip: bit 0 = 8-row units at M <= 8 (HALF), bit 1 = at 9..16 sequences (R8)
+#else
+[[maybe_unused]] static constexpr int g_gemv_half = 3;
+#endif
 int gemv_mfma_any(GemvBParams& p, int mode, hipStream_t st);
 
 }  // namespace fo1

@@ -457,7 +457,9 @@ static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const
     return launch_gemv_mfma_mp<MM, MODE, NB, false, HALF, R8>(p, n_units, nsteps, name, st);
 }
 
+#ifdef FO1_ENABLE_AB
 int g_gemv_half = 3;     // bit 0: M <= 8 8-row units (HALF); bit 1: 9..16 sequences 8-row units (R8) — few-row projections (A/B: fo1_gemv_batch_set_impl)
+#endif
 
 template <int MM>
 static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {

@@ -20,10 +20,12 @@
 // Epilogue order mirrors the reference's op-by-op bf16 rounding:
 //   y = bf16(acc + bias); y = bf16(act(y)); y = bf16(y + residual)
 #include "common.h"
+#include "ab.h"
 
 #include <type_traits>
 
 namespace fo1 {
+
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -756,6 +758,7 @@ __device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16
     }
 }
 
+#ifdef FO1_ENABLE_AB      // four-phase schedule: superseded by gemm_bt_p4_kernel (+3..10 %), kept for A/B only
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bt_p8_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, BK = 64;
@@ -913,12 +916,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p8_kernel(const GemmParams p) 
     epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
 }
 
-static int g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds two-stage, 3/4/6 glds ring of that depth
-static int g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x256 (8 waves), 5 = 256x256 ping-pong
-static int g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
-static int g_gemm_profile_shapes = 0;
-static int g_gemm_debug = 0;
-static int g_gemm_gemv = 1;      // route M <= 4 to the weight-streaming GEMV (gemv.hip)
+#endif   // FO1_ENABLE_AB (gemm_bt_p8_kernel)
+
+FO1_AB_VAR g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds two-stage, 3/4/6 glds ring of that depth
+FO1_AB_VAR g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x256 (8 waves), 5 = 256x256 ping-pong
+FO1_AB_VAR g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
+static int g_gemm_profile_shapes = 0;   // profile-row naming (fo1_gemm_profile_shapes: instrumentation, part of the product API)
+FO1_AB_VAR g_gemm_debug = 0;
+FO1_AB_VAR g_gemm_gemv = 1;      // route M <= 4 to the weight-streaming GEMV (gemv.hip)
 
 extern int g_gemv_profile_shapes;
 int gemv_dispatch(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr, void* C, int ldc,
@@ -1201,6 +1206,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
 }
 
+#ifdef FO1_ENABLE_AB      // persistent tile loop: measured 2-5 % slower, kept for A/B only
 // Coalesced epilogue through a 4 KiB wave-private LDS strip (persistent kernel: the 128 KiB image is busy with the next tile):
 // the wave's 128 x 64 block in four passes of 32 rows.  Same arithmetic, rounding points and store shapes as epilogue32_coalesced.
 template <int EPI>
@@ -1477,10 +1483,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4p_kernel(const GemmParams p)
     }
 }
 
-static int g_gemm_persist = 0;     // 256x256 kernels: 1 = persistent tile loop with the next tile's first DMA under the epilogue (measured 2-5 % SLOWER than one tile per workgroup, see gemm_bt_p4p_kernel)
-static int g_gemm_coal = 1;        // 256x256 kernels: LDS-staged coalesced epilogue (0 = fragment-shaped stores, for A/B)
-static int g_gemm_nt_store = 0;    // 256x256 kernels: non-temporal stores in the coalesced epilogue (A/B)
-static int g_gemm_big_sched = 1;   // 256x256 kernel schedule: 0 = four phases per K tile (p8), 1 = two fat phases with DMA issued between MFMAs (p4, default: +3..10 % measured, profiles/r02_gemm_bench_p8_v2.log)
+#endif   // FO1_ENABLE_AB (gemm_bt_p4p_kernel)
+
+FO1_AB_VAR g_gemm_persist = 0;     // 256x256 kernels: 1 = persistent tile loop with the next tile's first DMA under the epilogue (measured 2-5 % SLOWER than one tile per workgroup, see gemm_bt_p4p_kernel)
+FO1_AB_VAR g_gemm_coal = 1;        // 256x256 kernels: LDS-staged coalesced epilogue (0 = fragment-shaped stores, for A/B)
+FO1_AB_VAR g_gemm_nt_store = 0;    // 256x256 kernels: non-temporal stores in the coalesced epilogue (A/B)
+FO1_AB_VAR g_gemm_big_sched = 1;   // 256x256 kernel schedule: 0 = four phases per K tile (p8), 1 = two fat phases with DMA issued between MFMAs (p4, default: +3..10 % measured, profiles/r02_gemm_bench_p8_v2.log)
 
 // 256 x 256 ping-pong kernel (gemm_bt_p8_kernel)
 static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
@@ -1499,8 +1507,10 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         const int nc = p.act == ACT_SWIGLU16 ? p.N / 2 : p.N;
         p.coal = g_gemm_coal && nc % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0 && p.sC % 8 == 0 &&
                  (p.res == nullptr || (p.ldr % 8 == 0 && ((uintptr_t)p.res & 15) == 0 && p.sR % 8 == 0));
-        if (p.coal && g_gemm_nt_store) p.coal = 2;
+        if (g_gemm_nt_store != 0 && p.coal) p.coal = 2;
     }
+    const int epi = p.splits > 1 ? 4 : p.act;
+#ifdef FO1_ENABLE_AB
     static bool attr_done = false;
     if (!attr_done) {
         FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -1510,7 +1520,6 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    const int epi = p.splits > 1 ? 4 : p.act;
     const int n_tiles = p.tiles_m * p.tiles_n, nk64 = p.K / 64;
     if (g_gemm_big_sched == 1 && g_gemm_persist && p.splits == 1 && batch == 1 && p.coal && n_tiles > 256 && nk64 >= 2 && nk64 % 2 == 0) {
         // persistent form: 256 workgroups (one per CU, a multiple of 8: every workgroup stays in its XCD's run of tiles)
@@ -1531,6 +1540,7 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         else FO1_LAUNCH(np, flops, gemm_bt_p4p_kernel<3>, gp, dim3(512), smem_p, st, p);
         return FO1_OK;
     }
+#endif
     if (g_gemm_big_sched == 1) {
         static bool attr4 = false;
         if (!attr4) {
@@ -1547,12 +1557,14 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         else if (epi == 2) FO1_LAUNCH(n4, flops, gemm_bt_p4_kernel<2>, grid, dim3(512), smem, st, p);
         else if (epi == 3) FO1_LAUNCH(n4, flops, gemm_bt_p4_kernel<3>, grid, dim3(512), smem, st, p);
         else FO1_LAUNCH(n4, flops, gemm_bt_p4_kernel<4>, grid, dim3(512), smem, st, p);
-    } else
-    if (epi == 0) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<0>, grid, dim3(512), smem, st, p);
+    }
+#ifdef FO1_ENABLE_AB
+    else if (epi == 0) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<0>, grid, dim3(512), smem, st, p);
     else if (epi == 1) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<1>, grid, dim3(512), smem, st, p);
     else if (epi == 2) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<2>, grid, dim3(512), smem, st, p);
     else if (epi == 3) FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<3>, grid, dim3(512), smem, st, p);
     else FO1_LAUNCH(name, flops, gemm_bt_p8_kernel<4>, grid, dim3(512), smem, st, p);
+#endif
     if (p.splits > 1) {
         const long long total = (long long)p.M * (p.N / 4);
         const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
@@ -1788,6 +1800,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
 
 extern "C" {
 
+#ifdef FO1_ENABLE_AB      // include/fo1_ab.h: test / bench build only
 int fo1_gemm_set_variant(int staging, int tile) {
     if (staging < 0 || staging > 6 || staging == 5 || tile < 0 || tile > 5) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
     fo1::g_gemm_variant = staging;
@@ -1821,6 +1834,7 @@ int fo1_gemm_set_gemv(int on) {
     fo1::g_gemm_gemv = on != 0;
     return FO1_OK;
 }
+#endif   // FO1_ENABLE_AB
 
 int fo1_gemm_profile_shapes(int on) {
     fo1::g_gemm_profile_shapes = on != 0;

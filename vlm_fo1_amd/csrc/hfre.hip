@@ -16,6 +16,7 @@
 // sine box embedding and writes the fp32 output.  No atomics: results are
 // run-to-run deterministic.
 #include "common.h"
+#include "ab.h"
 #include "hfre_math.h"
 
 namespace fo1 {
@@ -25,7 +26,7 @@ constexpr int kHfreWaves = kHfreThreads / 64;
 constexpr int kHfreWThreads = 64;    // hfre_weights_kernel: one wave per (box, source) — a latency chain (box load, atomic, two phases), so
                                      // what matters is how many are resident: 6 000 workgroups at 12 images x 100 boxes
 constexpr int kHfreMaxChunk = 512;   // channels per workgroup (64 lanes x 8 bf16)
-constexpr int kHfreUnroll = 8;
+[[maybe_unused]] constexpr int kHfreUnroll = 8;
 
 struct HfreSrcDev {
     const uint16_t* data;
@@ -161,6 +162,7 @@ __global__ __launch_bounds__(kHfreWThreads) void hfre_weights_kernel(const HfreP
         wx[c] = up_x ? upsample_axis_weight(f.c_lo + c, s_wAx, f.ax.lo, f.ax.hi, s.W, s.roi_W) : roi_axis_weight(f.ax, f.c_lo + c);
 }
 
+#ifdef FO1_ENABLE_AB      // round-1 worst-case-grid form (nine workgroups in ten only read a header and leave): A/B only
 __global__ __launch_bounds__(kHfreThreads) void hfre_pool_kernel(const HfreParams p) {
     __shared__ float s_wy[FO1_HFRE_MAX_EXTENT];
     __shared__ float s_wx[FO1_HFRE_MAX_EXTENT];
@@ -301,6 +303,8 @@ __global__ __launch_bounds__(256) void hfre_finish_kernel(const HfreParams p) {
     p.out[(size_t)n * p.out_ld + c] = v;
     if (p.out_bf16) p.out_bf16[(size_t)n * p.out_bf16_ld + c] = f32_to_bf16(v);
 }
+
+#endif   // FO1_ENABLE_AB (hfre_pool_kernel, hfre_finish_kernel)
 
 // ------------------------------------------------------------------------------------------
 // Work-list form (fo1_hfre_region_pool_ex): the grid of hfre_pool_kernel is sized for the worst case (every box as tall as the map:
@@ -559,14 +563,14 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_finish_vec_kernel(const Hfr
     }
 }
 
-static int g_hfre_pixel_budget = 0;  // 0 = auto
+FO1_AB_VAR g_hfre_pixel_budget = 0;  // 0 = auto
 // work-list path
-static int g_hfre_unroll = 8;        // independent 16-B loads per lane in flight (8 or 16)
-static int g_hfre_chunk = kHfreMaxChunk;   // channels per workgroup (<= kHfreMaxChunk)
-static int g_hfre_v2_budget = 256;   // pixels per slice: one value for every box count, so a box's result does not depend on what
+FO1_AB_VAR g_hfre_unroll = 8;        // independent 16-B loads per lane in flight (8 or 16)
+FO1_AB_VAR g_hfre_chunk = kHfreMaxChunk;   // channels per workgroup (<= kHfreMaxChunk)
+FO1_AB_VAR g_hfre_v2_budget = 256;   // pixels per slice: one value for every box count, so a box's result does not depend on what
                                      // else is in the call (batch invariance)
-static int g_hfre_finish_vec = 1;     // 16-byte finish (A/B: fo1_hfre_set_tuning unroll | 32 turns it off)
-static int g_hfre_grid = 4096;       // workgroups walking the work list (profiles/r02_hfre_sweep.json)
+FO1_AB_VAR g_hfre_finish_vec = 1;     // 16-byte finish (A/B: fo1_hfre_set_tuning unroll | 32 turns it off)
+FO1_AB_VAR g_hfre_grid = 4096;       // workgroups walking the work list (profiles/r02_hfre_sweep.json)
 
 // workspace = [partials: n_boxes * ws_box_stride floats][weights: n_boxes*n_sources*2*kHfreWStride floats][headers: n_boxes*n_sources*8 ints]
 static size_t hfre_ws_total(const HfreParams& p, int n_sources, int n_boxes) {
@@ -618,6 +622,7 @@ static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxe
 
 extern "C" {
 
+#ifdef FO1_ENABLE_AB      // include/fo1_ab.h: test / bench build only
 // test/tuning hook: pixels per workgroup slice (default 1024)
 int fo1_hfre_set_pixel_budget(int pixels) {
     if (pixels != 0 && (pixels < 16 || pixels > 65536)) return fo1::set_err(FO1_ERR_ARG, "hfre: pixel budget %d outside [16,65536] (0 = auto)", pixels);
@@ -638,7 +643,9 @@ int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid) {
     if (grid) fo1::g_hfre_grid = grid;
     return FO1_OK;
 }
+#endif   // FO1_ENABLE_AB
 
+#ifdef FO1_ENABLE_AB
 size_t fo1_hfre_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes) {
     fo1::HfreParams p;
     int wgs = 0;
@@ -699,6 +706,31 @@ int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const 
                dim3(cdiv(region_dim, 256), n_boxes), dim3(256), 0, st, p);
     return FO1_OK;
 }
+#else
+// Product build: the single-image entry points of round 1 (the name SURVEY 8b gives the HFRE seam) are the work-list path with default
+// options.  The work-list counters must be zero on a workspace's first use: this form, whose contract never asked the caller for a
+// zeroed workspace, clears them itself (one 64-thread launch).
+size_t fo1_hfre_ex_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes);
+int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, const float* boxes_aux, int n_boxes, const float* boxes_vt,
+                            float vt_scale_x, float vt_scale_y, int roi_size, int pos_mode, float pos_img_w, float pos_img_h, float* out, int out_ld,
+                            int region_dim, const fo1_hfre_opts_t* opts, void* workspace, size_t workspace_bytes, void* stream);
+size_t fo1_hfre_workspace_bytes(const fo1_hfre_source_t* sources, int n_sources, int n_boxes) {
+    return fo1_hfre_ex_workspace_bytes(sources, n_sources, n_boxes);
+}
+namespace fo1 {
+__global__ void hfre_zero_counters_kernel(int* ctr) { ctr[threadIdx.x * kHfreCtrStride] = 0; }
+}
+int fo1_hfre_region_pool(const fo1_hfre_source_t* sources, int n_sources, const float* boxes_aux, int n_boxes,
+                         const float* boxes_vt, float vt_scale_x, float vt_scale_y, int roi_size, int pos_mode, float pos_img_w,
+                         float pos_img_h, float* out, int out_ld, int region_dim, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+    using namespace fo1;
+    if (n_boxes > 0 && workspace != nullptr && workspace_bytes >= (size_t)kHfreBuckets * kHfreCtrStride * sizeof(int))
+        FO1_LAUNCH("hfre_zero_counters", 256.0, hfre_zero_counters_kernel, dim3(1), dim3(kHfreBuckets), 0, (hipStream_t)stream, (int*)workspace);
+    return fo1_hfre_region_pool_ex(sources, n_sources, boxes_aux, n_boxes, boxes_vt, vt_scale_x, vt_scale_y, roi_size, pos_mode, pos_img_w,
+                                   pos_img_h, out, out_ld, region_dim, nullptr, workspace, workspace_bytes, stream);
+}
+#endif   // FO1_ENABLE_AB
 
 
 // Work-list variant: same contract as fo1_hfre_region_pool, plus

@@ -31,7 +31,7 @@ def _apply_env():
         return
     _env_applied = True
     e = os.environ
-    if any(k in e for k in ("FO1_HFRE_UNROLL", "FO1_HFRE_CHUNK", "FO1_HFRE_BUDGET", "FO1_HFRE_GRID")):
+    if _lib.ab_build() and any(k in e for k in ("FO1_HFRE_UNROLL", "FO1_HFRE_CHUNK", "FO1_HFRE_BUDGET", "FO1_HFRE_GRID")):
         _lib.check(_lib.load().fo1_hfre_set_tuning(int(e.get("FO1_HFRE_UNROLL", 8)), int(e.get("FO1_HFRE_CHUNK", 512)),
                                                    int(e.get("FO1_HFRE_BUDGET", 0)), int(e.get("FO1_HFRE_GRID", 0))), "fo1_hfre_set_tuning")
 

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfo1hip.so")
+LIB_PATH = os.path.join(_HERE, "libfo1hip.so")          # product library (include/fo1.h)
+LIB_PATH_AB = os.path.join(_HERE, "libfo1hip_ab.so")    # test / bench build (+ include/fo1_ab.h), loaded when FO1_AB=1
 
 c_int, c_float, c_void_p, c_size_t, c_int32, c_longlong = (ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
                                                            ctypes.c_size_t, ctypes.c_int32, ctypes.c_longlong)
@@ -134,7 +135,6 @@ SIGNATURES = {
     "fo1_profile_enable": (c_int, [c_int]),
     "fo1_profile_read": (c_int, [ctypes.POINTER(ProfileRow), c_int, c_int]),
     "fo1_profile_stage": (c_int, [ctypes.c_char_p]),
-    "fo1_hfre_set_pixel_budget": (c_int, [c_int]),
     "fo1_vit_workspace_bytes": (c_size_t, [ctypes.POINTER(VitWeights), c_int]),
     "fo1_vit_forward": (c_int, [ctypes.POINTER(VitWeights), ctypes.POINTER(VitPlan), c_void_p, c_int, c_void_p, ctypes.POINTER(c_void_p), c_void_p,
                                 c_size_t, c_void_p]),
@@ -171,10 +171,6 @@ SIGNATURES = {
     "fo1_simplefpn_forward": (c_int, [ctypes.POINTER(FpnWeights), c_void_p, c_int, c_int, c_int, ctypes.POINTER(c_void_p), c_void_p, c_size_t, c_void_p]),
     "fo1_projector_workspace_bytes": (c_size_t, [ctypes.POINTER(ProjectorW), c_int]),
     "fo1_projector_forward": (c_int, [ctypes.POINTER(ProjectorW), c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
-    "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
-    "fo1_gemv_batch_set_impl": (c_int, [c_int]),
-    "fo1_attention_decode_set_impl": (c_int, [c_int]),
-    "fo1_hfre_set_tuning": (c_int, [c_int, c_int, c_int, c_int]),
     "fo1_hfre_workspace_bytes": (c_size_t, [ctypes.POINTER(HfreSource), c_int, c_int]),
     "fo1_hfre_region_pool": (c_int, [ctypes.POINTER(HfreSource), c_int, c_void_p, c_int, c_void_p, c_float, c_float,
                                      c_int, c_int, c_float, c_float, c_void_p, c_int, c_int, c_void_p, c_size_t,
@@ -191,11 +187,6 @@ SIGNATURES = {
     "fo1_rmsnorm_quant_e4m3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_longlong, c_void_p, c_void_p]),
     "fo1_gemm_fp8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                              c_int, c_int, c_int, c_int, c_void_p]),
-    "fo1_gemm_set_variant": (c_int, [c_int, c_int]),
-    "fo1_gemm_set_splitk": (c_int, [c_int]),
-    "fo1_gemm_set_big_schedule": (c_int, [c_int]),
-    "fo1_gemm_set_gemv": (c_int, [c_int]),
-    "fo1_gemm_set_debug": (c_int, [c_int]),
     "fo1_gemm_profile_shapes": (c_int, [c_int]),
     "fo1_rmsnorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "fo1_layernorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
@@ -256,6 +247,20 @@ SIGNATURES = {
                                      c_int, c_void_p]),
 }
 
+# include/fo1_ab.h: A/B / ablation / determinism-pin switches — exported by libfo1hip_ab.so ONLY (FO1_AB=1), never by the product library
+SIGNATURES_AB = {
+    "fo1_hfre_set_pixel_budget": (c_int, [c_int]),
+    "fo1_hfre_set_tuning": (c_int, [c_int, c_int, c_int, c_int]),
+    "fo1_gemm_set_variant": (c_int, [c_int, c_int]),
+    "fo1_gemm_set_splitk": (c_int, [c_int]),
+    "fo1_gemm_set_gemv": (c_int, [c_int]),
+    "fo1_gemm_set_big_schedule": (c_int, [c_int]),
+    "fo1_gemm_set_debug": (c_int, [c_int]),
+    "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
+    "fo1_gemv_batch_set_impl": (c_int, [c_int]),
+    "fo1_attention_decode_set_impl": (c_int, [c_int]),
+}
+
 _lib = None
 
 
@@ -263,19 +268,28 @@ class Fo1Error(RuntimeError):
     pass
 
 
+def ab_build() -> bool:
+    """True when this process uses the test / bench build (FO1_AB=1: libfo1hip_ab.so with include/fo1_ab.h's switches)."""
+    return os.environ.get("FO1_AB", "0") not in ("", "0")
+
+
 def load() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = LIB_PATH_AB if ab_build() else LIB_PATH
+        if not os.path.exists(path):
             raise Fo1Error(
-                f"{LIB_PATH} not found — build it with `python -m vlm_fo1_amd.build` "
+                f"{path} not found — build it with `python -m vlm_fo1_amd.build` "
                 "(hipcc --offload-arch=gfx950).  There is no fallback path.")
         # torch (the device-memory / stream plumbing) must load ITS HIP runtime first so that
         # libfo1hip.so binds to the same libamdhip64/libhsa instance; loading ours first puts a
         # second runtime in the process and launches fail with "no ROCm-capable device".
         import torch  # noqa: F401
-        lib = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
+        lib = ctypes.CDLL(path)
+        table = dict(SIGNATURES)
+        if ab_build():
+            table.update(SIGNATURES_AB)
+        for name, (res, args) in table.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
