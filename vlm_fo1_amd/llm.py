@@ -588,6 +588,13 @@ class BatchDecoder:
         self.steps += 1
         return ent[1]
 
+    def results(self) -> List[List[int]]:
+        """Generated ids per sequence so far (first token included)."""
+        B = self.B
+        n = self.state[:B, 4].cpu().tolist()
+        ids = self.ids[:B, :max(n)].cpu().tolist()
+        return [row[:k] for row, k in zip(ids, n)]
+
     def run(self, max_new_tokens: int, use_graph: bool = True, poll: int = 8) -> List[List[int]]:
         """Decode until every sequence has stopped (or max_new_tokens).  Returns the generated ids per sequence, the first
         token (from the prefill) included."""
@@ -600,3 +607,31 @@ class BatchDecoder:
         n = self.state[:B, 4].cpu().tolist()
         ids = self.ids[:B, :max(n)].cpu().tolist()
         return [row[:k] for row, k in zip(ids, n)]
+
+
+def run_decoders(decs: Sequence["BatchDecoder"], streams: Sequence, max_new_tokens: int, use_graph: bool = True, poll: int = 8) -> List[List[List[int]]]:
+    """Several started decode groups advanced TOGETHER, each on its own HIP stream: a step of one group is a chain of ~180 short
+    kernels (5 per layer) with launch gaps between them and ~2.5 TB/s of an 8 TB/s memory system in use — the chains of two groups
+    interleave on the GPU, so a pass of 25 sequences (13 + 12) finishes its 64 tokens in about the time one group of 16 takes alone
+    instead of the sum of two (bench.py `end_to_end`).  Per sequence nothing changes: same kernels, same sums, same ids.
+    -> [ids per sequence] per group."""
+    max_new = max(1, min(int(max_new_tokens), BatchDecoder.IDS_CAP))
+    live = list(range(len(decs)))
+    for i in range(max_new - 1):
+        if i % poll == 0:      # the only host reads: each group's `done` counter on the group's own stream, every `poll` steps
+            still = []
+            for k in live:
+                with torch.cuda.stream(streams[k]):
+                    if int(decs[k].done.item()) < decs[k].B:
+                        still.append(k)
+            live = still
+            if not live:
+                break
+        for k in live:
+            with torch.cuda.stream(streams[k]):
+                decs[k].step(use_graph)
+    out = []
+    for k, d in enumerate(decs):
+        with torch.cuda.stream(streams[k]):
+            out.append(d.results())
+    return out

@@ -128,6 +128,8 @@ class FO1Engine:
         r._graphs = collections.OrderedDict()
         r._seen = {}
         r._dec = None
+        r._dec_extra = []
+        r._dec_stream0 = None
         r.stage_hook = None
         return r
 
@@ -473,20 +475,50 @@ class FO1Engine:
         """Greedy generation for a batch of requests: one packed prefill, then the batched decode loop (vlm_fo1_amd.llm.BatchDecoder):
         weights streamed once per step for all sequences, stop rule and bookkeeping on the device.  Returns the new ids per request
         (stop token included, like HF generate)."""
+        from .llm import BatchDecoder, run_decoders
         out: List[List[int]] = []
-        dec = self._decoder()
         for i in range(0, len(requests), self.PREFILL_MAX):
             grp = requests[i:i + self.PREFILL_MAX]
             self.prefill_batch(grp, use_graph=use_graph)          # ONE packed pass for the whole group (its GEMMs see every image's rows)
             hp = self._last_batch
             first = self._last_next_tokens
-            # the decode loop takes MAX_BATCH sequences at a time (the MFMA's 16 columns); each group is relocated out of the
-            # prefill cache into the decoder's slots, so the later groups' prompt K / V stay where the prefill left them
-            for j in range(0, len(grp), dec.MAX_BATCH):
-                k = min(j + dec.MAX_BATCH, len(grp))
-                dec.start(hp["seqs"][j:k], hp["delta"][j:k], first[j:k], max_new_tokens, stop_ids)
+            n = len(grp)
+            if n <= BatchDecoder.MAX_BATCH:
+                dec = self._decoder()
+                dec.start(hp["seqs"], hp["delta"], first[:n], max_new_tokens, stop_ids)
                 out += dec.run(max_new_tokens, use_graph=use_graph)
+                continue
+            # more sequences than the decode kernels' 16 MFMA columns: balanced groups (25 -> 13 + 12), each relocated out of the
+            # prefill cache into its own decoder's slots and advanced on its own stream, all groups together (llm.run_decoders)
+            k = -(-n // BatchDecoder.MAX_BATCH)
+            cuts = [round(j * n / k) for j in range(k + 1)]
+            decs, streams = self._decoders(k)
+            cur = torch.cuda.current_stream()
+            for j in range(k):
+                a, b = cuts[j], cuts[j + 1]
+                streams[j].wait_stream(cur)                       # the prefill (and its first tokens) are on the caller's stream
+                with torch.cuda.stream(streams[j]):
+                    decs[j].start(hp["seqs"][a:b], hp["delta"][a:b], first[a:b], max_new_tokens, stop_ids)
+            for ids in run_decoders(decs[:k], streams[:k], max_new_tokens, use_graph=use_graph):
+                out += ids
+            for j in range(k):
+                cur.wait_stream(streams[j])                       # the next pass must not overwrite the prefill cache under a relocate
         return out
+
+    def _decoders(self, k: int):
+        """k decode groups' decoders (the first is the engine's own) and the side streams they run on."""
+        from .llm import BatchDecoder
+        extra = self.__dict__.setdefault("_dec_extra", [])
+        while len(extra) < k - 1:
+            extra.append((BatchDecoder(self.llm), torch.cuda.Stream(device=self.dev)))
+        if not hasattr(self, "_dec_stream0") or self._dec_stream0 is None:
+            self._dec_stream0 = torch.cuda.Stream(device=self.dev)
+        decs = [self._decoder()] + [d for d, _ in extra[:k - 1]]
+        streams = [self._dec_stream0] + [s for _, s in extra[:k - 1]]
+        for d in decs:
+            if d.llm is not self.llm:
+                raise RuntimeError("decoder bound to another engine")
+        return decs, streams
 
     def _decoder(self):
         from .llm import BatchDecoder
