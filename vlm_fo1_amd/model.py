@@ -359,6 +359,8 @@ class FO1Engine:
                         next_tokens=toks, region_ranges=ranges, row0=bp.row0)
 
     PREFILL_MAX = 32       # requests per packed prefill pass of generate_batch
+    DECODE_CONCURRENT = True   # decode groups of one pass advance together on their own streams (False: one after the other; A/B)
+    DECODE_GROUPS = 1      # minimum number of decode groups when a pass has more sequences than one group holds
     RAGGED_TOWERS = True   # images of different sizes share one DaViT / SimpleFPN pass (False: image by image, the round-2 path; A/B)
     GRAPH_CACHE = 8        # captured prefill graphs kept per engine (LRU); each holds its own activation pool
     CAPTURE_AFTER = 1      # sightings of a signature before it is captured: one-off shapes (a dataset of ragged images) run eagerly
@@ -490,8 +492,15 @@ class FO1Engine:
                 continue
             # more sequences than the decode kernels' 16 MFMA columns: balanced groups (25 -> 13 + 12), each relocated out of the
             # prefill cache into its own decoder's slots and advanced on its own stream, all groups together (llm.run_decoders)
-            k = -(-n // BatchDecoder.MAX_BATCH)
+            k = max(-(-n // BatchDecoder.MAX_BATCH), min(self.DECODE_GROUPS, n))
             cuts = [round(j * n / k) for j in range(k + 1)]
+            if not self.DECODE_CONCURRENT:      # A/B: the groups one after the other on the caller's stream
+                dec = self._decoder()
+                for j in range(k):
+                    a, b = cuts[j], cuts[j + 1]
+                    dec.start(hp["seqs"][a:b], hp["delta"][a:b], first[a:b], max_new_tokens, stop_ids)
+                    out += dec.run(max_new_tokens, use_graph=use_graph)
+                continue
             decs, streams = self._decoders(k)
             cur = torch.cuda.current_stream()
             for j in range(k):
