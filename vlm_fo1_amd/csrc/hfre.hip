@@ -15,8 +15,6 @@
 // hfre_finish_kernel sums the row-slices of each box in a fixed order, adds the
 // sine box embedding and writes the fp32 output.  No atomics: results are
 // run-to-run deterministic.
-#include <algorithm>
-
 #include "common.h"
 #include "ab.h"
 #include "hfre_math.h"
@@ -69,7 +67,6 @@ struct HfreParams {
     int ln_on, ln_split;                        // region LayerNorm (reference :365-372): blocks [0, ln_split) and [ln_split, region_dim)
     const float* ln_w0; const float* ln_b0; const float* ln_w1; const float* ln_b1;
     float ln_eps;
-    int xcd_order;                              // work list bucketed by XCD class (1, default) or interleaved (0: round-2 order, A/B)
     uint16_t* out_bf16; int out_bf16_ld;        // optional second destination: the same rows cast to bf16 (RNE) — what encode_regions does
                                                 // before mm_projector_aux (omchat_qwen2_5_vl.py:106): the cast rides in the finish kernel
     float* dimt;                                // work-list path: dim_t table of the sine embedding, region_dim / 8 entries (written by
@@ -141,12 +138,7 @@ __global__ __launch_bounds__(kHfreWThreads) void hfre_weights_kernel(const HfreP
         // results do not (every item owns its partial row, the finish sums in slice order)
         __shared__ int s_base;
         const int cnt = f.n_slices * s.nchunks;
-        // bucket = XCD class + 8 x spread: all items of one (image, source) map fall into buckets of ONE class, and the pool kernel's
-        // workgroups on XCD x (blockIdx % 8, observed placement: a speed matter only) walk the classes (img + source) % 8 == x — boxes
-        // that overlap on a map are then gathered through the same 4 MB L2 instead of up to eight (round 2: 1.89x the union bytes
-        // fetched).  The 8 spread buckets per class keep the returning atomics off one address.
-        const int img_b = p.box_image ? p.box_image[n] : 0;
-        const int bucket = p.xcd_order ? (((img_b + si) & 7) | ((n & 7) << 3)) : (int)(blockIdx.x % kHfreBuckets);
+        const int bucket = blockIdx.x % kHfreBuckets;
         if (tid == 0) s_base = atomicAdd(p.n_items + bucket * kHfreCtrStride, cnt);
         __syncthreads();
         int2* list = p.items + (size_t)bucket * p.items_cap;
@@ -422,38 +414,12 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_pool_items_kernel(const Hfr
     }
     __syncthreads();
     const int n_items = s_end[kHfreBuckets - 1];
-    // XCD-class walk: this workgroup (XCD class x = blockIdx % 8) takes the items of buckets x, x + 8, ..., x + 56 with stride = the
-    // number of workgroups of its class; the interleaved order (xcd_order 0) walks all buckets with the grid as stride
-    const int xc = p.xcd_order ? (int)(blockIdx.x & 7) : 0;
-    const int wl = p.xcd_order ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-    const int nwl = p.xcd_order ? (int)((gridDim.x + 7 - xc) >> 3) : (int)gridDim.x;
-    int cls_end[8];                                // inclusive prefix of this class's 8 bucket counts
-    int total = n_items;
-    if (p.xcd_order) {
-        int acc = 0;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        int b = 0;                                 // first bucket whose inclusive prefix exceeds `it` (uniform over the workgroup)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int b = xc + 8 * j;
-            acc += s_end[b] - (b ? s_end[b - 1] : 0);
-            cls_end[j] = acc;
-        }
-        total = acc;
-    }
-    for (int it = wl; it < total; it += nwl) {
-        int b = 0, off = it;                       // bucket and offset of item `it` (uniform over the workgroup)
-        if (p.xcd_order) {
-            int j = 0;
-#pragma unroll
-            for (int q = 0; q < 7; ++q) j += (cls_end[q] <= it) ? 1 : 0;
-            b = xc + 8 * j;
-            off = it - (j ? cls_end[j - 1] : 0);
-        } else {
-#pragma unroll
-            for (int o = kHfreBuckets / 2; o > 0; o >>= 1)
-                if (s_end[b + o - 1] <= it) b += o;
-            off = it - (b ? s_end[b - 1] : 0);
-        }
-        const int2 item = p.items[(size_t)b * p.items_cap + off];
+        for (int o = kHfreBuckets / 2; o > 0; o >>= 1)
+            if (s_end[b + o - 1] <= it) b += o;
+        const int2 item = p.items[(size_t)b * p.items_cap + (it - (b ? s_end[b - 1] : 0))];
         const int n = item.x, si = item.y >> 24, chunk_id = (item.y >> 12) & 0xFFF, k = item.y & 0xFFF;
         const HfreSrcDev& s = p.src[si];
         const int* h = p.hdr + ((size_t)n * p.n_sources + si) * 8;
@@ -604,7 +570,6 @@ FO1_AB_VAR g_hfre_chunk = kHfreMaxChunk;   // channels per workgroup (<= kHfreMa
 FO1_AB_VAR g_hfre_v2_budget = 256;   // pixels per slice: one value for every box count, so a box's result does not depend on what
                                      // else is in the call (batch invariance)
 FO1_AB_VAR g_hfre_finish_vec = 1;     // 16-byte finish (A/B: fo1_hfre_set_tuning unroll | 32 turns it off)
-FO1_AB_VAR g_hfre_xcd_order = 1;     // work list bucketed by XCD class (A/B: fo1_hfre_set_tuning unroll | 64 = round-2 interleaved order)
 FO1_AB_VAR g_hfre_grid = 4096;       // workgroups walking the work list (profiles/r02_hfre_sweep.json)
 
 // workspace = [partials: n_boxes * ws_box_stride floats][weights: n_boxes*n_sources*2*kHfreWStride floats][headers: n_boxes*n_sources*8 ints]
@@ -669,8 +634,7 @@ int fo1_hfre_set_pixel_budget(int pixels) {
 // of two); budget = pixels per slice (0 keeps the current value); grid = workgroups walking the work list (0 keeps)
 int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid) {
     fo1::g_hfre_finish_vec = (unroll & 32) ? 0 : 1;    // A/B: unroll | 32 = scalar finish
-    fo1::g_hfre_xcd_order = (unroll & 64) ? 0 : 1;     // A/B: unroll | 64 = interleaved work-list order (round 2)
-    unroll &= ~(32 | 64);
+    unroll &= ~32;
     if ((unroll != 8 && unroll != 16) || chunk < 64 || chunk > fo1::kHfreMaxChunk || (chunk & (chunk - 1)) ||
         (budget != 0 && (budget < 16 || budget > 65536)) || grid < 0 || grid > (1 << 20))
         return fo1::set_err(FO1_ERR_ARG, "hfre: set_tuning(unroll=%d, chunk=%d, budget=%d, grid=%d)", unroll, chunk, budget, grid);
@@ -786,11 +750,8 @@ static int hfre_bucket_cap(const fo1::HfreParams& p, int n_sources, int n_boxes)
         const int m = p.src[i].nchunks * p.src[i].max_slices;
         if (m > max_item) max_item = m;
     }
-    const long long nb = n_boxes > 0 ? n_boxes : 1, pairs = nb * n_sources;
-    // interleaved order: pair q -> bucket q % 64, exactly ceil(pairs / 64) pairs per bucket.  XCD-class order: bucket (class, n % 8) holds
-    // at most ONE (box, source) pair per box with that n % 8 (the <= 8 sources of a box fall into distinct classes): ceil(N / 8) pairs.
-    const long long per_bucket = std::max((pairs + fo1::kHfreBuckets - 1) / fo1::kHfreBuckets, (nb + 7) / 8);
-    return (int)per_bucket * max_item;
+    const long long pairs = (long long)(n_boxes > 0 ? n_boxes : 1) * n_sources;
+    return (int)((pairs + fo1::kHfreBuckets - 1) / fo1::kHfreBuckets) * max_item;
 }
 static size_t hfre_ex_layout(const fo1::HfreParams& p, int n_sources, int n_boxes, int total_wgs, size_t* off_w, size_t* off_h, size_t* off_i) {
     const size_t nb = (size_t)(n_boxes > 0 ? n_boxes : 1);
@@ -874,7 +835,6 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
     p.hdr = (int*)(wsb + off_h);
     p.items = (int2*)(wsb + off_i);
     p.items_cap = hfre_bucket_cap(p, n_sources, n_boxes);
-    p.xcd_order = g_hfre_xcd_order;
     hipStream_t st = (hipStream_t)stream;
     FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreWThreads), 0, st, p);
     double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
