@@ -164,7 +164,11 @@ class Prefetcher:
         from concurrent.futures import ThreadPoolExecutor
         import threading
         self._prepare, self._order, self._depth = prepare, list(order), max(1, int(depth))
-        self._pool = ThreadPoolExecutor(max_workers=max(1, int(threads)), thread_name_prefix="fo1-prefetch")
+        # helper threads start on device 0 whatever the creating thread uses: on rank r > 0 the device-side preprocessing would launch
+        # on a stream of the wrong GPU — every helper first selects the creator's device
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else None
+        self._pool = ThreadPoolExecutor(max_workers=max(1, int(threads)), thread_name_prefix="fo1-prefetch",
+                                        initializer=(lambda: torch.cuda.set_device(dev)) if dev is not None else None)
         self._fut, self._next, self._taken = {}, 0, 0
         self._lock = threading.Lock()
         self._fill()
