@@ -74,15 +74,98 @@ __device__ __forceinline__ void tile_coords(const GemmParams& p, int& tm, int& t
     tn = swz / p.tiles_m;
 }
 
+__device__ __forceinline__ void round2_bf16(float& a, float& b) {
+    const uint32_t pk = pack_bf16x2(a, b);
+    a = bf16_lo(pk);
+    b = bf16_hi(pk);
+}
+
+// Vector form of the 16x16-fragment epilogue (N % 4 == 0, 8-byte aligned bias / C / residual rows, bf16 output): every bias piece and every
+// residual piece of the wave's block is loaded FIRST, unconditionally, from clamped addresses (out-of-range rows / columns are never
+// stored) — the general form below loads each of them inside the bounds branch next to its use, which hipcc turns into load ->
+// s_waitcnt vmcnt(0) -> use: FM * FN * 5 serialised cache latencies per wave, most of a small-M product's time.  The activation is
+// a template parameter behind one wave-uniform switch.  Same arithmetic and rounding points (bias -> bf16 -> act -> bf16 -> +residual
+// -> bf16); values are rounded in pairs (v_cvt_pk_bf16_f32).
+template <int FM, int FN, int ACT>
+__device__ __forceinline__ void epilogue_vec(const GemmParams& p, f32x4 (&acc)[FN][FM], int m_base, int n_base, int lane, long long offC,
+                                             long long offR) {
+    const int mi = lane & 15, nq = (lane >> 4) * 4;
+    uint2 bv[FN], rv[FM][FN];
+    if (p.bias) {
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int n0 = n_base + fn * 16 + nq;
+            bv[fn] = *reinterpret_cast<const uint2*>(p.bias + (n0 < p.N ? n0 : 0));
+        }
+    }
+    if (p.res) {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int m = m_base + fm * 16 + mi;
+            const uint16_t* rrow = p.res + offR + (long long)(m < p.M ? m : p.M - 1) * p.ldr;
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+                const int n0 = n_base + fn * 16 + nq;
+                rv[fm][fn] = *reinterpret_cast<const uint2*>(rrow + (n0 < p.N ? n0 : 0));
+            }
+        }
+    }
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int m = m_base + fm * 16 + mi;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int n0 = n_base + fn * 16 + nq;
+            float v[4] = {acc[fn][fm][0], acc[fn][fm][1], acc[fn][fm][2], acc[fn][fm][3]};
+            if (p.bias) { v[0] += bf16_lo(bv[fn].x); v[1] += bf16_hi(bv[fn].x); v[2] += bf16_lo(bv[fn].y); v[3] += bf16_hi(bv[fn].y); }
+            if constexpr (ACT != ACT_NONE) {
+                round2_bf16(v[0], v[1]); round2_bf16(v[2], v[3]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = act_apply(v[r], ACT);
+            }
+            if (p.res) {
+                round2_bf16(v[0], v[1]); round2_bf16(v[2], v[3]);
+                v[0] += bf16_lo(rv[fm][fn].x); v[1] += bf16_hi(rv[fm][fn].x); v[2] += bf16_lo(rv[fm][fn].y); v[3] += bf16_hi(rv[fm][fn].y);
+            }
+            uint2 ov;
+            ov.x = pack_bf16x2(v[0], v[1]);
+            ov.y = pack_bf16x2(v[2], v[3]);
+            if (m < p.M && n0 < p.N) *reinterpret_cast<uint2*>(p.C + offC + (long long)m * p.ldc + n0) = ov;
+        }
+    }
+}
+
 template <int FM, int FN>
 __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FN][FM], int m_base, int n_base, int lane,
                                          long long offC, long long offR) {
     const int mi = lane & 15, nq = (lane >> 4) * 4;
     const bool vec_ok = (p.ldc % 4 == 0) && ((offC & 3) == 0) && (p.res == nullptr || ((p.ldr % 4 == 0) && ((offR & 3) == 0)));
+    if (vec_ok && p.act != ACT_SWIGLU16 && p.C32 == nullptr && p.N % 4 == 0 && ((uintptr_t)p.C & 7) == 0 &&
+        (p.bias == nullptr || ((uintptr_t)p.bias & 7) == 0) && (p.res == nullptr || ((uintptr_t)p.res & 7) == 0)) {
+        switch (p.act) {     // wave-uniform
+            case ACT_GELU: epilogue_vec<FM, FN, ACT_GELU>(p, acc, m_base, n_base, lane, offC, offR); break;
+            case ACT_SILU: epilogue_vec<FM, FN, ACT_SILU>(p, acc, m_base, n_base, lane, offC, offR); break;
+            case ACT_RELU: epilogue_vec<FM, FN, ACT_RELU>(p, acc, m_base, n_base, lane, offC, offR); break;
+            default: epilogue_vec<FM, FN, ACT_NONE>(p, acc, m_base, n_base, lane, offC, offR); break;
+        }
+        return;
+    }
     if (p.act == ACT_SWIGLU16) {
         // W rows are interleaved in 16-row groups [gate 16 | up 16 | gate 16 | ...]: fragment pair (fn, fn+1) holds
         // gate and up of the same 16 features.  out[m, f] = bf16( bf16(silu(bf16(g))) * bf16(u) ), C has N/2 columns.
         if constexpr (FN >= 2) {
+            // bias pieces of the lane's feature columns first (N % 32 == 0: a started [gate 16 | up 16] group is whole), not per element
+            // inside the bounds branches
+            const bool bvec = p.bias != nullptr && ((uintptr_t)p.bias & 7) == 0;
+            uint2 bg[FN / 2], bu[FN / 2];
+            if (bvec) {
+#pragma unroll
+                for (int j = 0; j < FN / 2; ++j) {
+                    const int n0 = n_base + j * 32 + nq, nc = n0 < p.N ? n0 : nq;
+                    bg[j] = *reinterpret_cast<const uint2*>(p.bias + nc);
+                    bu[j] = *reinterpret_cast<const uint2*>(p.bias + nc + 16);
+                }
+            }
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
                 const int m = m_base + fm * 16 + mi;
@@ -92,10 +175,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, f32x4 (&acc)[FN][F
                     const int n0 = n_base + fn * 16 + nq;       // gate column; up column = n0 + 16
                     if (n0 >= p.N) continue;
                     float o[4];
+                    const float gbv[4] = {bf16_lo(bg[fn / 2].x), bf16_hi(bg[fn / 2].x), bf16_lo(bg[fn / 2].y), bf16_hi(bg[fn / 2].y)};
+                    const float ubv[4] = {bf16_lo(bu[fn / 2].x), bf16_hi(bu[fn / 2].x), bf16_lo(bu[fn / 2].y), bf16_hi(bu[fn / 2].y)};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float g = acc[fn][fm][r], u = acc[fn + 1][fm][r];
-                        if (p.bias) { g += bf16_to_f32(p.bias[n0 + r]); u += bf16_to_f32(p.bias[n0 + 16 + r]); }
+                        if (bvec) { g += gbv[r]; u += ubv[r]; }
+                        else if (p.bias) { g += bf16_to_f32(p.bias[n0 + r]); u += bf16_to_f32(p.bias[n0 + 16 + r]); }
                         g = round_bf16(g);
                         u = round_bf16(u);
                         o[r] = round_bf16(fo1_silu(g)) * u;
@@ -663,99 +749,185 @@ __device__ __forceinline__ void epilogue32(const GemmParams& p, f32x16 (&acc)[MF
 // are XOR-swizzled with the row — and is read back row-wise, 16 B per lane, 8 lanes per row: every global store instruction
 // writes 8 whole 128-byte row segments (the fragment-shaped epilogue stores 8 B per lane to 32 different rows per instruction).
 // The residual is added in the row-wise phase from 16-B loads.  Same arithmetic and rounding points as epilogue32.
-template <int EPI>
-__device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16 (&acc)[4][2], char* region, int m_base, int n_base, int lane,
-                                                     long long offC, long long offR) {
+//
+// Round 3: NO LOAD SITS INSIDE A PER-ELEMENT BRANCH.  The first form loaded the bias under `if (p.bias && n0 < N)` next to its use
+// (32 times per lane, 64 two-byte loads in the SwiGLU form) and the residual row under `if (m < M && n < N)` in each of the 16
+// write-out iterations: hipcc cannot hoist a load out of a branch, so every one of them was load -> s_waitcnt vmcnt(0) -> use, a
+// chain of 16-64 cache / HBM latencies per tile (residual products: ~16 us of fixed cost per round of tiles against ~9 us without).
+// Now the residual rows (16 x 16 B per lane) and the lane's 8 bias pieces are loaded FIRST, unconditionally, from clamped addresses
+// (the values of out-of-range rows / columns are never stored), under one wave-uniform branch each; the conversions run underneath
+// their latency.  Values are rounded in pairs (one v_cvt_pk_bf16_f32 per two elements; with no activation the rounding IS the
+// pack).  Bit-identical output (tests/test_gemm_gpu.py pins the tiles against the fragment-shaped epilogue32).
+template <int EPI, bool HAS_BIAS, bool HAS_RES>
+__device__ __forceinline__ void epilogue32_coalesced_b(const GemmParams& p, f32x16 (&acc)[4][2], char* region, int m_base, int n_base, int lane,
+                                                       long long offC, long long offR) {
     const int mi = lane & 31, hi = lane >> 5, hi4 = hi * 4;
     if constexpr (EPI == ACT_SWIGLU16) {
         // 32 output columns per wave: 64-B rows, four 16-B slots swizzled with (row & 3)
+        // bias of the lane's features: gate rows nb + f0 .. + 3 and up rows nb + 16 + f0 .. + 3 for the four (nf, g) — the same for every mf
+        uint2 bg[4], bu[4];
+        if constexpr (HAS_BIAS) {
 #pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-            const int r = mf * 32 + mi;
+            for (int q = 0; q < 4; ++q) {
+                const int nb = n_base + (q >> 1) * 32, f0 = (q & 1) * 8 + hi4;
+                const int nc = nb < p.N ? nb + f0 : f0;     // N % 32 == 0 for the interleaved layout: a started 32-row group is whole
+                bg[q] = *reinterpret_cast<const uint2*>(p.bias + nc);
+                bu[q] = *reinterpret_cast<const uint2*>(p.bias + nc + 16);
+            }
+        }
 #pragma unroll
-            for (int nf = 0; nf < 2; ++nf) {
-                const int nb = n_base + nf * 32;
+        for (int q = 0; q < 4; ++q) {
+            const int nf = q >> 1, g = q & 1;
+            float gb[4] = {0.f, 0.f, 0.f, 0.f}, ub[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (HAS_BIAS) {
+                gb[0] = bf16_lo(bg[q].x); gb[1] = bf16_hi(bg[q].x); gb[2] = bf16_lo(bg[q].y); gb[3] = bf16_hi(bg[q].y);
+                ub[0] = bf16_lo(bu[q].x); ub[1] = bf16_hi(bu[q].x); ub[2] = bf16_lo(bu[q].y); ub[3] = bf16_hi(bu[q].y);
+            }
 #pragma unroll
-                for (int g = 0; g < 2; ++g) {
-                    const int f0 = g * 8 + hi4;
-                    float o[4];
+            for (int mf = 0; mf < 4; ++mf) {
+                const int r = mf * 32 + mi;
+                float gt[4], up[4];
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        float gt = acc[mf][nf][g * 4 + t], up = acc[mf][nf][8 + g * 4 + t];
-                        if (p.bias && nb < p.N) { gt += bf16_to_f32(p.bias[nb + f0 + t]); up += bf16_to_f32(p.bias[nb + 16 + f0 + t]); }
-                        gt = round_bf16(gt);
-                        up = round_bf16(up);
-                        o[t] = round_bf16(fo1_silu(gt)) * up;
-                    }
-                    uint2 ov;
-                    ov.x = pack_bf16x2(o[0], o[1]);
-                    ov.y = pack_bf16x2(o[2], o[3]);
-                    const int q = nf * 2 + g;
-                    *reinterpret_cast<uint2*>(region + r * 64 + ((q ^ (r & 3)) << 4) + hi * 8) = ov;
+                for (int t = 0; t < 4; ++t) { gt[t] = acc[mf][nf][g * 4 + t]; up[t] = acc[mf][nf][8 + g * 4 + t]; }
+                if constexpr (HAS_BIAS) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { gt[t] += gb[t]; up[t] += ub[t]; }
                 }
+                round2_bf16(gt[0], gt[1]); round2_bf16(gt[2], gt[3]);
+                round2_bf16(up[0], up[1]); round2_bf16(up[2], up[3]);
+                float sv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sv[t] = fo1_silu(gt[t]);
+                round2_bf16(sv[0], sv[1]); round2_bf16(sv[2], sv[3]);
+                uint2 ov;
+                ov.x = pack_bf16x2(sv[0] * up[0], sv[1] * up[1]);
+                ov.y = pack_bf16x2(sv[2] * up[2], sv[3] * up[3]);
+                *reinterpret_cast<uint2*>(region + r * 64 + ((q ^ (r & 3)) << 4) + hi * 8) = ov;
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const int n_out = (n_base >> 1) + (lane & 3) * 8, No = p.N >> 1;
+        uint4 lv[8];
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
-            const int r = it * 16 + (lane >> 2), m = m_base + r;
-            const uint4 v = *reinterpret_cast<const uint4*>(region + r * 64 + (((lane & 3) ^ (r & 3)) << 4));
-            if (m < p.M && n_out < No && !(p.debug & 8)) {
+            const int r = it * 16 + (lane >> 2);
+            lv[it] = *reinterpret_cast<const uint4*>(region + r * 64 + (((lane & 3) ^ (r & 3)) << 4));
+        }
+        const bool col_ok = n_out < No && !(p.debug & 8);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = m_base + it * 16 + (lane >> 2);
+            if (m < p.M && col_ok) {
                 uint4* dst = reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n_out);
-                if (p.coal == 2) __builtin_nontemporal_store(*reinterpret_cast<const v4u32*>(&v), reinterpret_cast<v4u32*>(dst));
-                else *dst = v;
+                if (p.coal == 2) __builtin_nontemporal_store(*reinterpret_cast<const v4u32*>(&lv[it]), reinterpret_cast<v4u32*>(dst));
+                else *dst = lv[it];
             }
         }
     } else {
-#pragma unroll
-        for (int mf = 0; mf < 4; ++mf) {
-            const int r = mf * 32 + mi;
-#pragma unroll
-            for (int nf = 0; nf < 2; ++nf)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n0 = n_base + nf * 32 + g * 8 + hi4;
-                    float v[4] = {acc[mf][nf][g * 4 + 0], acc[mf][nf][g * 4 + 1], acc[mf][nf][g * 4 + 2], acc[mf][nf][g * 4 + 3]};
-                    if (p.bias && n0 < p.N) {
-                        const uint2 bv = *reinterpret_cast<const uint2*>(p.bias + n0);
-                        v[0] += bf16_lo(bv.x); v[1] += bf16_hi(bv.x); v[2] += bf16_lo(bv.y); v[3] += bf16_hi(bv.y);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) v[t] = round_bf16(v[t]);
-                    if constexpr (EPI != ACT_NONE) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) v[t] = round_bf16(act_apply_t<EPI>(v[t]));
-                    }
-                    uint2 ov;
-                    ov.x = pack_bf16x2(v[0], v[1]);
-                    ov.y = pack_bf16x2(v[2], v[3]);
-                    const int q = nf * 4 + g;
-                    *reinterpret_cast<uint2*>(region + r * 128 + ((q ^ (r & 7)) << 4) + hi * 8) = ov;
-                }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the lane's 8 bias pieces (the same for every 32-row block) first; the residual rows of the write-out phase — all 16 in flight
+        // at once — are issued half way through the conversions, when 64 of the 128 accumulator registers are free for them (issued
+        // in front, hipcc spills ~100 registers, each reload a vmcnt(0)); their latency runs under the second half.
         const int n = n_base + (lane & 7) * 8;
+        uint2 bv[8];
+        if constexpr (HAS_BIAS) {
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int r = it * 8 + (lane >> 3), m = m_base + r;
-            uint4 v = *reinterpret_cast<const uint4*>(region + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
-            if (m < p.M && n < p.N) {
-                if (p.res) {
-                    const uint4 rv = *reinterpret_cast<const uint4*>(p.res + offR + (long long)m * p.ldr + n);
-                    v.x = pack_bf16x2(bf16_lo(v.x) + bf16_lo(rv.x), bf16_hi(v.x) + bf16_hi(rv.x));
-                    v.y = pack_bf16x2(bf16_lo(v.y) + bf16_lo(rv.y), bf16_hi(v.y) + bf16_hi(rv.y));
-                    v.z = pack_bf16x2(bf16_lo(v.z) + bf16_lo(rv.z), bf16_hi(v.z) + bf16_hi(rv.z));
-                    v.w = pack_bf16x2(bf16_lo(v.w) + bf16_lo(rv.w), bf16_hi(v.w) + bf16_hi(rv.w));
+            for (int q = 0; q < 8; ++q) {
+                const int n0 = n_base + (q >> 2) * 32 + (q & 3) * 8 + hi4;
+                bv[q] = *reinterpret_cast<const uint2*>(p.bias + (n0 < p.N ? n0 : 0));
+            }
+        }
+        uint4 rv[16];
+        auto load_res = [&]() {
+            if (HAS_RES && p.res) {
+                const uint16_t* rb = p.res + offR + (n < p.N ? n : 0);
+#pragma unroll
+                for (int it = 0; it < 16; ++it) {
+                    const int m = m_base + it * 8 + (lane >> 3);
+                    rv[it] = *reinterpret_cast<const uint4*>(rb + (long long)(m < p.M ? m : p.M - 1) * p.ldr);
                 }
-                if (!(p.debug & 8)) {
+            }
+        };
+        // (the sched_barriers pin the phases: left free, hipcc's scheduler spreads the 16 row loads and the write-out's address
+        // arithmetic through the conversions and spills ~100 registers — each reload a vmcnt(0))
+        // column group outermost (its 4 bias values unpacked once, live only here), the four 32-row blocks inside
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int nf = q >> 2, g = q & 3;
+            if (q == 4) {
+                __builtin_amdgcn_sched_barrier(0);
+                load_res();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            float b[4] = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (HAS_BIAS) { b[0] = bf16_lo(bv[q].x); b[1] = bf16_hi(bv[q].x); b[2] = bf16_lo(bv[q].y); b[3] = bf16_hi(bv[q].y); }
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const int r = mf * 32 + mi;
+                float v[4] = {acc[mf][nf][g * 4 + 0], acc[mf][nf][g * 4 + 1], acc[mf][nf][g * 4 + 2], acc[mf][nf][g * 4 + 3]};
+                if constexpr (HAS_BIAS) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] += b[t];
+                }
+                if constexpr (EPI != ACT_NONE) {
+                    round2_bf16(v[0], v[1]); round2_bf16(v[2], v[3]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] = act_apply_t<EPI>(v[t]);
+                }
+                uint2 ov;       // the pack rounds: bf16(bf16(x)) == bf16(x), so no separate rounding step without an activation
+                ov.x = pack_bf16x2(v[0], v[1]);
+                ov.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(region + r * 128 + ((q ^ (r & 7)) << 4) + hi * 8) = ov;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // write-out in two halves of 8 rows, each in three straight sweeps (8 LDS reads in flight, the residual adds under ONE uniform
+        // branch, the stores): interleaved per row they were 16 x (ds_read -> wait -> branch -> store)
+        const bool col_ok = n < p.N && !(p.debug & 8);
+        int lrow = lane >> 3;       // opaque copy: shared with the residual loads' row numbers, hipcc keeps all 16 live (and spills them)
+        asm volatile("" : "+v"(lrow));
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            __builtin_amdgcn_sched_barrier(0);
+            uint4 lv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = (hf * 8 + i) * 8 + lrow;
+                lv[i] = *reinterpret_cast<const uint4*>(region + r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+            }
+            if (HAS_RES && p.res) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint4 x = rv[hf * 8 + i];
+                    uint4& v = lv[i];
+                    v.x = pack_bf16x2(bf16_lo(v.x) + bf16_lo(x.x), bf16_hi(v.x) + bf16_hi(x.x));
+                    v.y = pack_bf16x2(bf16_lo(v.y) + bf16_lo(x.y), bf16_hi(v.y) + bf16_hi(x.y));
+                    v.z = pack_bf16x2(bf16_lo(v.z) + bf16_lo(x.z), bf16_hi(v.z) + bf16_hi(x.z));
+                    v.w = pack_bf16x2(bf16_lo(v.w) + bf16_lo(x.w), bf16_hi(v.w) + bf16_hi(x.w));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = m_base + (hf * 8 + i) * 8 + lrow;
+                if (m < p.M && col_ok) {
                     uint4* dst = reinterpret_cast<uint4*>(p.C + offC + (long long)m * p.ldc + n);
-                    if (p.coal == 2) __builtin_nontemporal_store(*reinterpret_cast<const v4u32*>(&v), reinterpret_cast<v4u32*>(dst));
-                    else *dst = v;
+                    if (p.coal == 2) __builtin_nontemporal_store(*reinterpret_cast<const v4u32*>(&lv[i]), reinterpret_cast<v4u32*>(dst));
+                    else *dst = lv[i];
                 }
             }
         }
     }
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16 (&acc)[4][2], char* region, int m_base, int n_base, int lane,
+                                                     long long offC, long long offR) {
+    // bias / residual presence as template parameters behind wave-uniform branches: a run-time `if (p.res)` around the residual loads
+    // would make the wait in front of the first bias use vmcnt(0) (the join of a path with 16 younger loads and one without)
+    constexpr bool RES = EPI != ACT_SWIGLU16;      // (the interleaved SwiGLU product has no residual operand)
+    if (p.bias) epilogue32_coalesced_b<EPI, true, RES>(p, acc, region, m_base, n_base, lane, offC, offR);
+    else epilogue32_coalesced_b<EPI, false, RES>(p, acc, region, m_base, n_base, lane, offC, offR);
 }
 
 #ifdef FO1_ENABLE_AB      // four-phase schedule: superseded by gemm_bt_p4_kernel (+3..10 %), kept for A/B only
