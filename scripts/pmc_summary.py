@@ -17,7 +17,8 @@ BENCH_NAMES = [
     (r"hfre_finish2_kernel", "hfre_finish2"),
     (r"hfre_pool_kernel", "hfre_pool"),
     (r"dwconv3x3_ln", "dwconv3x3_ln"),
-    (r"rownorm_kernel<0>", "rmsnorm"),
+    (r"rownorm_kernel<0,", "rmsnorm"),
+    (r"rownorm_kernel<1,", "layernorm"),
 ]
 
 

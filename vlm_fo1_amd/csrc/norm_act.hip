@@ -28,71 +28,109 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 
 constexpr int kMaxChunksPerLane = 8;  // D <= 64 lanes * 8 chunks * 8 elements = 4096
 
-// mode 0: RMSNorm (w only); mode 1: LayerNorm (w, b)
-template <int MODE>
+// mode 0: RMSNorm (w only); mode 1: LayerNorm (w, b).  NPER = 16-byte chunks per lane (a template parameter: straight-line code),
+// LPR = lanes per row: 64, or 32 with two rows per wave when a row is at most 32 chunks (D <= 256: DaViT stage 0, where one row per
+// wave left half the lanes idle).  Every load of the row, the weight and the bias is issued up front from a clamped address — the
+// first form loaded each chunk inside `if (c < nchunk)` next to its use, i.e. load -> s_waitcnt vmcnt(0) -> use per chunk: NPER
+// serialised HBM round trips per row.  Lanes past the row's end contribute exact zeros; the lane-local order (chunk, element) and the
+// butterfly are unchanged, so sums are bit-identical to the first form.
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+template <int MODE, int NPER, int LPR>
 __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ w,
                                                       const uint16_t* __restrict__ b, uint16_t* __restrict__ y, int ldy,
                                                       int M, int D, float eps) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const int lane = threadIdx.x & 63;
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63, sub = lane & (LPR - 1);
+    const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool row_ok = row < M;           // (no early return: the wave's other row may exist and the shuffles want every lane)
     const int nchunk = D >> 3;
-    const uint16_t* xr = x + (size_t)row * ldx;
-    uint4 v[kMaxChunksPerLane];
+    const uint16_t* xr = x + (size_t)(row_ok ? row : M - 1) * ldx;
+    uint4 v[NPER], wv[NPER], bv[NPER];
+    bool ok[NPER];
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
+        const int c = sub + i * LPR;
+        ok[i] = c < nchunk;
+        const int cc = ok[i] ? c : 0;
+        v[i] = *reinterpret_cast<const uint4*>(xr + cc * 8);
+        wv[i] = *reinterpret_cast<const uint4*>(w + cc * 8);
+        if (MODE == 1) bv[i] = *reinterpret_cast<const uint4*>(b + cc * 8);
+    }
     float s = 0.f, ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < kMaxChunksPerLane; ++i) {
-        const int c = lane + i * 64;
-        if (c < nchunk) {
-            v[i] = *reinterpret_cast<const uint4*>(xr + c * 8);
-            float f[8];
-            unpack8(v[i], f);
+    for (int i = 0; i < NPER; ++i) {
+        float f[8];
+        unpack8(v[i], f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { s += f[j]; ss += f[j] * f[j]; }
+        for (int j = 0; j < 8; ++j) {
+            const float t = ok[i] ? f[j] : 0.f;
+            s += t;
+            ss += t * t;
         }
     }
     float mean = 0.f, rstd;
     if (MODE == 0) {
-        ss = wave_sum(ss);
+        ss = row_sum<LPR>(ss);
         rstd = rsqrtf(ss / (float)D + eps);
     } else {
-        s = wave_sum(s);
+        s = row_sum<LPR>(s);
         mean = s / (float)D;
         // two-pass variance from registers (no catastrophic cancellation)
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < kMaxChunksPerLane; ++i) {
-            const int c = lane + i * 64;
-            if (c < nchunk) {
-                float f[8];
-                unpack8(v[i], f);
+        for (int i = 0; i < NPER; ++i) {
+            float f[8];
+            unpack8(v[i], f);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { const float d = f[j] - mean; q += d * d; }
+            for (int j = 0; j < 8; ++j) {
+                const float d = ok[i] ? f[j] - mean : 0.f;
+                q += d * d;
             }
         }
-        q = wave_sum(q);
+        q = row_sum<LPR>(q);
         rstd = rsqrtf(q / (float)D + eps);
     }
     uint16_t* yr = y + (size_t)row * ldy;
 #pragma unroll
-    for (int i = 0; i < kMaxChunksPerLane; ++i) {
-        const int c = lane + i * 64;
-        if (c < nchunk) {
-            float f[8], wf[8], o[8];
-            unpack8(v[i], f);
-            unpack8(*reinterpret_cast<const uint4*>(w + c * 8), wf);
-            if (MODE == 0) {
+    for (int i = 0; i < NPER; ++i) {
+        float f[8], wf[8], o[8];
+        unpack8(v[i], f);
+        unpack8(wv[i], wf);
+        if (MODE == 0) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = wf[j] * bf16_to_f32(f32_to_bf16(f[j] * rstd));
-            } else {
-                float bf[8];
-                unpack8(*reinterpret_cast<const uint4*>(b + c * 8), bf);
+            for (int j = 0; j < 8; ++j) o[j] = wf[j] * bf16_to_f32(f32_to_bf16(f[j] * rstd));
+        } else {
+            float bf[8];
+            unpack8(bv[i], bf);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (f[j] - mean) * rstd * wf[j] + bf[j];
-            }
-            *reinterpret_cast<uint4*>(yr + c * 8) = pack8(o);
+            for (int j = 0; j < 8; ++j) o[j] = (f[j] - mean) * rstd * wf[j] + bf[j];
         }
+        if (ok[i] && row_ok) *reinterpret_cast<uint4*>(yr + (sub + i * LPR) * 8) = pack8(o);
     }
+}
+
+template <int MODE>
+static int launch_rownorm(const char* name, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int M, int D, float eps,
+                          hipStream_t st) {
+    const int nchunk = D >> 3;
+    const double bytes = (double)M * D * 4.0;
+#define FO1_ROWNORM(NPER, LPR)                                                                                                          \
+    FO1_LAUNCH(name, bytes, (rownorm_kernel<MODE, NPER, LPR>), dim3(cdiv(M, 4 * (64 / LPR))), dim3(256), 0, st, (const uint16_t*)x, ldx, \
+               (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)y, ldy, M, D, eps)
+    if (nchunk <= 32) FO1_ROWNORM(1, 32);
+    else if (nchunk <= 64) FO1_ROWNORM(1, 64);
+    else if (nchunk <= 128) FO1_ROWNORM(2, 64);
+    else if (nchunk <= 192) FO1_ROWNORM(3, 64);
+    else if (nchunk <= 256) FO1_ROWNORM(4, 64);
+    else FO1_ROWNORM(kMaxChunksPerLane, 64);
+#undef FO1_ROWNORM
+    return FO1_OK;
 }
 
 // out[m, f] = bf16( bf16(silu(g[m,f])) * u[m,f] ),  gu = [g | u] with row stride ldgu
@@ -316,9 +354,7 @@ int fo1_rmsnorm_bf16(const void* x, int ldx, const void* weight, void* y, int ld
     int rc = rownorm_check(x, weight, y, M, D, ldx, ldy);
     if (rc) return rc;
     if (M == 0) return FO1_OK;
-    FO1_LAUNCH("rmsnorm", (double)M * D * 4.0, rownorm_kernel<0>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream,
-               (const uint16_t*)x, ldx, (const uint16_t*)weight, (const uint16_t*)nullptr, (uint16_t*)y, ldy, M, D, eps);
-    return FO1_OK;
+    return launch_rownorm<0>("rmsnorm", x, ldx, weight, weight, y, ldy, M, D, eps, (hipStream_t)stream);
 }
 
 // RMSNorm + row-wise e4m3 quantisation in one launch (the fp8 linears' producer; bit-identical to fo1_rmsnorm_bf16 followed by
@@ -342,9 +378,7 @@ int fo1_layernorm_bf16(const void* x, int ldx, const void* weight, const void* b
     if (rc) return rc;
     FO1_CHECK_ARG(bias != nullptr, "layernorm: NULL bias");
     if (M == 0) return FO1_OK;
-    FO1_LAUNCH("layernorm", (double)M * D * 4.0, rownorm_kernel<1>, dim3(cdiv(M, 4)), dim3(256), 0, (hipStream_t)stream,
-               (const uint16_t*)x, ldx, (const uint16_t*)weight, (const uint16_t*)bias, (uint16_t*)y, ldy, M, D, eps);
-    return FO1_OK;
+    return launch_rownorm<1>("layernorm", x, ldx, weight, bias, y, ldy, M, D, eps, (hipStream_t)stream);
 }
 
 int fo1_swiglu_bf16(const void* gate_up, int ldgu, void* out, int ldo, int M, int F, void* stream) {
