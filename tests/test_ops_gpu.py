@@ -567,3 +567,68 @@ def test_gemm_persistent_tile_loop_equals_one_tile_per_workgroup():
     finally:
         L.load().fo1_gemm_set_variant(0, 0)
         L.load().fo1_gemm_set_big_schedule(1)
+
+
+def test_gemm_coalesced_epilogue_equals_fragment_epilogue_bitwise():
+    """The LDS-staged epilogue of the 256x256 kernel (round 3: bias pieces and all 16 residual rows loaded up front from clamped addresses,
+    pairwise rounding, straight write-out sweeps) against the fragment-shaped epilogue32 (each load next to its use, element-wise
+    rounding): the same rounding points, so the outputs must be bit-identical — ragged M / N edges (clamped rows / columns), every
+    activation, with and without bias / residual, and the interleaved SwiGLU form."""
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(61)
+    shapes = [(700, 520, 64, True, True, 0), (1025, 1032, 192, True, True, 0), (300, 256, 128, False, True, 0), (1564, 3840, 1280, True, False, 0),
+              (777, 512, 320, True, True, 2), (2604, 2048, 1024, True, False, 1), (519, 776, 256, False, False, 1), (1300, 1288, 512, False, True, 2)]
+    try:
+        L.check(L.load().fo1_gemm_set_variant(0, 5), "variant")
+        for (M, N, K, hb, hr, act) in shapes:
+            a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+            w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+            bias = (torch.randn(N) * 0.1).to(BF).cuda() if hb else None
+            res = torch.randn(M, N).to(BF).cuda() if hr else None
+            L.check(L.load().fo1_gemm_set_big_schedule(1), "schedule")
+            coal = ops.gemm(a, w, bias, res, act)
+            L.check(L.load().fo1_gemm_set_big_schedule(3), "schedule")
+            frag = ops.gemm(a, w, bias, res, act)
+            assert torch.equal(coal, frag), f"{M}x{N}x{K} act={act}: coalesced != fragment epilogue, max diff {(coal.float() - frag.float()).abs().max().item():.4g}"
+        M, K, Fh = 1301, 512, 1312
+        a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+        w = ops.interleave_gate_up((torch.randn(Fh, K) * 0.05).to(BF), (torch.randn(Fh, K) * 0.05).to(BF)).cuda()
+        for b in (None, ops.interleave_gate_up((torch.randn(Fh) * 0.1).to(BF), (torch.randn(Fh) * 0.1).to(BF)).cuda()):
+            L.check(L.load().fo1_gemm_set_big_schedule(1), "schedule")
+            coal = ops.gemm(a, w, b, act=ops.ACT_SWIGLU16)
+            L.check(L.load().fo1_gemm_set_big_schedule(3), "schedule")
+            frag = ops.gemm(a, w, b, act=ops.ACT_SWIGLU16)
+            assert torch.equal(coal, frag), f"swiglu bias={b is not None}: coalesced != fragment epilogue"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_big_schedule(1)
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 4])
+def test_gemm_small_tile_vector_epilogue_equals_general_epilogue_bitwise(tile):
+    """epilogue_vec (16x16-fragment kernels: every bias / residual piece loaded up front, activation as a template parameter) is taken
+    when bias, residual and C are 8-byte aligned; a bias or residual view that starts 2 bytes off the alignment goes through the general
+    epilogue (loads next to their use).  Same operands, same rounding points: bit-identical outputs."""
+    from vlm_fo1_amd import lib as L, ops
+    torch.manual_seed(62 + tile)
+    shapes = [(77, 132, 128, True, True, 2), (300, 516, 256, True, True, 0), (651, 2048, 192, True, False, 1), (130, 1280, 320, False, True, 0),
+              (1564, 1284, 128, True, True, ops.ACT_RELU)]
+    try:
+        L.check(L.load().fo1_gemm_set_variant(2, tile), "variant")
+        for (M, N, K, hb, hr, act) in shapes:
+            a = (torch.randn(M, K) * 0.5).to(BF).cuda()
+            w = (torch.randn(N, K) * 0.05).to(BF).cuda()
+            bias_v = (torch.randn(N) * 0.1).to(BF).cuda()
+            res_v = torch.randn(M, N).to(BF).cuda()
+            bias_store, res_store = torch.empty(N + 8, dtype=BF, device="cuda"), torch.empty(M * N + 8, dtype=BF, device="cuda")
+            bias_store[1:N + 1].copy_(bias_v)
+            res_store[1:M * N + 1].copy_(res_v.reshape(-1))
+            outs = []
+            for mis in (False, True):       # views that start 2 bytes off the 8-byte alignment take the general epilogue
+                bias = (bias_store[1:N + 1] if mis else bias_v) if hb else None
+                res = (res_store[1:M * N + 1].view(M, N) if mis else res_v) if hr else None
+                outs.append(ops.gemm(a, w, bias, res, act))
+            if len(outs) == 2:
+                assert torch.equal(outs[0], outs[1]), f"tile {tile} {M}x{N}x{K} act={act}: vector != general epilogue, max diff {(outs[0].float() - outs[1].float()).abs().max().item():.4g}"
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)

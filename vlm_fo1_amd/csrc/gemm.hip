@@ -757,7 +757,9 @@ __device__ __forceinline__ void epilogue32(const GemmParams& p, f32x16 (&acc)[MF
 // Now the residual rows (16 x 16 B per lane) and the lane's 8 bias pieces are loaded FIRST, unconditionally, from clamped addresses
 // (the values of out-of-range rows / columns are never stored), under one wave-uniform branch each; the conversions run underneath
 // their latency.  Values are rounded in pairs (one v_cvt_pk_bf16_f32 per two elements; with no activation the rounding IS the
-// pack).  Bit-identical output (tests/test_gemm_gpu.py pins the tiles against the fragment-shaped epilogue32).
+// pack).  Bit-identical output (tests/test_ops_gpu.py: coalesced == fragment-shaped epilogue32, bit for bit).
+// Tried on top and dropped (profiles/r03_gemm_epilogue_row_pipelined_ab_no_gain.json): the write-out of each 32-row block issued between the
+// conversions of the following blocks (stores spread over the epilogue) — within +-1 % without a residual, 6 % slower with one.
 template <int EPI, bool HAS_BIAS, bool HAS_RES>
 __device__ __forceinline__ void epilogue32_coalesced_b(const GemmParams& p, f32x16 (&acc)[4][2], char* region, int m_base, int n_base, int lane,
                                                        long long offC, long long offR) {
@@ -923,8 +925,8 @@ __device__ __forceinline__ void epilogue32_coalesced_b(const GemmParams& p, f32x
 template <int EPI>
 __device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16 (&acc)[4][2], char* region, int m_base, int n_base, int lane,
                                                      long long offC, long long offR) {
-    // bias / residual presence as template parameters behind wave-uniform branches: a run-time `if (p.res)` around the residual loads
-    // would make the wait in front of the first bias use vmcnt(0) (the join of a path with 16 younger loads and one without)
+    // bias presence is a template parameter behind a wave-uniform branch; the residual stays a run-time uniform branch around its 16
+    // loads (as a template parameter the straight-line code gave hipcc's scheduler room to spill ~100 registers)
     constexpr bool RES = EPI != ACT_SWIGLU16;      // (the interleaved SwiGLU product has no residual operand)
     if (p.bias) epilogue32_coalesced_b<EPI, true, RES>(p, acc, region, m_base, n_base, lane, offC, offR);
     else epilogue32_coalesced_b<EPI, false, RES>(p, acc, region, m_base, n_base, lane, offC, offR);
