@@ -286,7 +286,8 @@ int fo1_im2col_bf16(const void* x, void* col, int H, int W, int C, int KH, int K
 int fo1_window_partition_bf16(const void* x, void* xw, int H, int W, int C, int ws, int batch, void* stream);
 int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, int H, int W, int C, int ws,
                                 int batch, void* stream);
-/* N = tokens of ONE image; qkv / out hold batch * N rows and every image gets its own per-group attention matrices */
+/* N = tokens of ONE image; qkv / out hold batch * N rows and every image gets its own per-group attention matrices.
+ * Rows are read / written 16 bytes at a time: ld % 8 == 0, ldo % 8 == 0, qkv and out 16-byte aligned. */
 size_t fo1_channel_attention_workspace_bytes(int N, int C, int batch);
 int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, int batch, void* workspace,
                                size_t workspace_bytes, void* stream);

@@ -33,7 +33,9 @@ constexpr int kMaxChunksPerLane = 8;  // D <= 64 lanes * 8 chunks * 8 elements =
 // wave left half the lanes idle).  Every load of the row, the weight and the bias is issued up front from a clamped address — the
 // first form loaded each chunk inside `if (c < nchunk)` next to its use, i.e. load -> s_waitcnt vmcnt(0) -> use per chunk: NPER
 // serialised HBM round trips per row.  Lanes past the row's end contribute exact zeros; the lane-local order (chunk, element) and the
-// butterfly are unchanged, so sums are bit-identical to the first form.
+// butterfly are unchanged.  Every multiply-add of the statistics and of the LayerNorm output is an explicit fmaf: under -ffp-contract
+// hipcc may fuse either product of (a a) + (b b), and did so differently here and in the fused depthwise-conv + LayerNorm kernel
+// (vision_ops.hip), which must agree with this one bit for bit (one element in 200 000 differed by an ulp of its rstd).
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
 #pragma unroll
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
         for (int j = 0; j < 8; ++j) {
             const float t = ok[i] ? f[j] : 0.f;
             s += t;
-            ss += t * t;
+            ss = fmaf(t, t, ss);      // explicit: left to -ffp-contract, hipcc is free to fuse EITHER product of (t0 t0) + (t1 t1)
         }
     }
     float mean = 0.f, rstd;
@@ -90,7 +92,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d = ok[i] ? f[j] - mean : 0.f;
-                q += d * d;
+                q = fmaf(d, d, q);
             }
         }
         q = row_sum<LPR>(q);
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
             float bf[8];
             unpack8(bv[i], bf);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (f[j] - mean) * rstd * wf[j] + bf[j];
+            for (int j = 0; j < 8; ++j) o[j] = fmaf((f[j] - mean) * rstd, wf[j], bf[j]);
         }
         if (ok[i] && row_ok) *reinterpret_cast<uint4*>(yr + (sub + i * LPR) * 8) = pack8(o);
     }
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void rmsnorm_quant_e4m3_kernel(const uint16_t*
             float f[8];
             unpack8(v[i], f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) ss += f[j] * f[j];
+            for (int j = 0; j < 8; ++j) ss = fmaf(f[j], f[j], ss);
         }
     }
     ss = wave_sum(ss);
