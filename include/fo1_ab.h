@@ -40,6 +40,10 @@ int fo1_gemm_set_big_schedule(int sched);
 /* ablation, RESULTS INVALID: 1 no global loads, 2 no MFMA, 4 no LDS reads + MFMA; 256x256 two-phase kernel: 8 epilogue computed but not
  * stored, 16 one K tile per output tile (profiles/r02_gemm_t0_study.md) */
 int fo1_gemm_set_debug(int bits);
+/* bit 5 (32) of fo1_gemm_set_debug, results VALID: waves 0 and 7 of every 256x256-kernel workgroup write s_memrealtime (100 MHz) at kernel entry,
+ * first MFMA, end of the K loop, end of the epilogue and their HW_ID / XCC_ID to this device buffer, [workgroups][2][6] uint64
+ * (scripts/gemm_timeline.py) */
+int fo1_gemm_set_stamp_buffer(void* device_buffer);
 
 /* ---- decode step ---- */
 /* fo1_gemv_batch_bf16, v_dot2 kernel: 0 (default) = a lane streams 1 / 2 / 4 weight rows per chunk position by M; 1 = always one row. */

@@ -1097,6 +1097,9 @@ FO1_AB_VAR g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4
 FO1_AB_VAR g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
 static int g_gemm_profile_shapes = 0;   // profile-row naming (fo1_gemm_profile_shapes: instrumentation, part of the product API)
 FO1_AB_VAR g_gemm_debug = 0;
+#ifdef FO1_ENABLE_AB
+static void* g_gemm_stamp_buf = nullptr;    // fo1_gemm_set_stamp_buffer (debug bit 5)
+#endif
 FO1_AB_VAR g_gemm_gemv = 1;      // route M <= 4 to the weight-streaming GEMV (gemv.hip)
 
 extern int g_gemv_profile_shapes;
@@ -1149,6 +1152,25 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
 // (E8M0 127) — twice the K per MFMA at twice the rate: 16 MFMAs of 64 cycles per K tile where bf16 issues 32 of 32 cycles, so the DMA
 // schedule and every wait count carry over.  A lane's 32 operand bytes are two 16-B slots of the same swizzled LDS image; A and B
 // fragments are read the same way, so the operands' common k order inside a lane does not matter.
+#ifdef FO1_ENABLE_AB
+// fo1_gemm_set_debug bit 5 (32): workgroup timeline.  Waves 0 and 7 (one of each staggered half) write the 100 MHz s_memrealtime at kernel
+// entry, first MFMA, end of the K loop and end of the epilogue, plus their HW_ID / XCC_ID, to the buffer of fo1_gemm_set_stamp_buffer:
+// [workgroup][2][6] u64.  scripts/gemm_timeline.py turns that into turnover / prologue / K loop / epilogue per workgroup and per CU.
+__device__ __forceinline__ void gemm_stamp(const GemmParams& p, int wave, int lane, int slot) {
+    if ((p.debug & 32) && lane == 0 && (wave == 0 || wave == 7)) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.part) + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 6;
+        o[slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 0) {
+            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+        }
+    }
+}
+#define FO1_GEMM_STAMP(slot) gemm_stamp(p, wave, lane, slot)
+#else
+#define FO1_GEMM_STAMP(slot)
+#endif
+
 template <int EPI, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, ES = FP8 ? 1 : 2, BK = 128 / ES;
@@ -1164,6 +1186,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const bool late = wave >= 4;
+    FO1_GEMM_STAMP(0);
     const long long bz = blockIdx.y;
     const char* A = reinterpret_cast<const char*>(p.A) + bz * p.sA * ES;
     const char* W = reinterpret_cast<const char*>(p.W) + bz * p.sW * ES;
@@ -1242,6 +1265,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     }
     FO1_P8_BARRIER();
     if (late) FO1_P8_BARRIER();
+    FO1_GEMM_STAMP(1);
 
     auto tile = [&](auto BUFC, int t) {
         constexpr int BUF = decltype(BUFC)::value;
@@ -1353,6 +1377,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         tile(std::integral_constant<int, 0>{}, t);
         if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
     }
+    FO1_GEMM_STAMP(2);
     if constexpr (FP8) {
         // dequantise: acc[mf][nf][r] = C[m][n] with m = m_base + mf*32 + (lane & 31), n = n_base + nf*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
         const int mb = m0 + wm * 128 + (lane & 31), nb = n0 + wn * 64 + hi * 4;
@@ -1374,6 +1399,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     if constexpr (EPI != 4) {
         if (p.coal) {   // every wave's LDS reads of the main loop are retired (the last load segment ended at a barrier this wave has passed)
             epilogue32_coalesced<EPI>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR);
+            FO1_GEMM_STAMP(3);
             return;
         }
     }
@@ -1685,6 +1711,10 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
     }
     const int epi = p.splits > 1 ? 4 : p.act;
 #ifdef FO1_ENABLE_AB
+    if (p.debug & 32) {       // workgroup timeline: the stamps go to the (otherwise unused) split-K partial pointer
+        if (p.splits == 1 && g_gemm_stamp_buf && p.coal) p.part = (float*)g_gemm_stamp_buf;
+        else p.debug &= ~32;
+    }
     static bool attr_done = false;
     if (!attr_done) {
         FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
@@ -2001,6 +2031,11 @@ int fo1_gemm_set_splitk(int splits) {
 
 int fo1_gemm_set_debug(int bits) {
     fo1::g_gemm_debug = bits;
+    return FO1_OK;
+}
+
+int fo1_gemm_set_stamp_buffer(void* device_buffer) {
+    fo1::g_gemm_stamp_buf = device_buffer;
     return FO1_OK;
 }
 

@@ -256,6 +256,7 @@ SIGNATURES_AB = {
     "fo1_gemm_set_gemv": (c_int, [c_int]),
     "fo1_gemm_set_big_schedule": (c_int, [c_int]),
     "fo1_gemm_set_debug": (c_int, [c_int]),
+    "fo1_gemm_set_stamp_buffer": (c_int, [c_void_p]),
     "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
     "fo1_gemv_batch_set_impl": (c_int, [c_int]),
     "fo1_attention_decode_set_impl": (c_int, [c_int]),
