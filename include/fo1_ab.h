@@ -41,7 +41,8 @@ int fo1_gemm_set_big_schedule(int sched);
  * stored, 16 one K tile per output tile (profiles/r02_gemm_t0_study.md) */
 int fo1_gemm_set_debug(int bits);
 /* bit 5 (32) of fo1_gemm_set_debug, results VALID: waves 0 and 7 of every 256x256-kernel workgroup write s_memrealtime (100 MHz) at kernel entry,
- * first MFMA, end of the K loop, end of the epilogue and their HW_ID / XCC_ID to this device buffer, [workgroups][2][6] uint64
+ * first MFMA, end of the K loop, end of the epilogue (slot 6: conversions staged in LDS) and their HW_ID / XCC_ID to this device buffer,
+ * [workgroups][2][8] uint64
  * (scripts/gemm_timeline.py) */
 int fo1_gemm_set_stamp_buffer(void* device_buffer);
 

@@ -25,7 +25,7 @@ for name, M, N, K, mode, has_bias in SHAPES:
     bias = torch.randn(N, device="cuda").bfloat16() if has_bias else None
     act = ops.ACT_SWIGLU16 if mode == 3 else ops.ACT_NONE
     tiles = -(-M // 256) * -(-N // 256)
-    stamps = torch.zeros(tiles * 2 * 6, dtype=torch.int64, device="cuda")
+    stamps = torch.zeros(tiles * 2 * 8, dtype=torch.int64, device="cuda")
     for _ in range(3):
         ops.gemm(a, w, bias, resid, act, out=c)
     L.check(lib.fo1_gemm_set_stamp_buffer(stamps.data_ptr()), "stamp buffer")
@@ -34,7 +34,7 @@ for name, M, N, K, mode, has_bias in SHAPES:
     torch.cuda.synchronize()
     L.check(lib.fo1_gemm_set_debug(0), "debug")
     L.check(lib.fo1_gemm_set_stamp_buffer(None), "stamp buffer")
-    st = stamps.cpu().numpy().reshape(tiles, 2, 6)
+    st = stamps.cpu().numpy().reshape(tiles, 2, 8)
     t = st[:, :, :4].astype(np.float64) / 100.0            # us
     t0 = t[:, :, 0].min()
     entry, first, kend, end = (t[:, :, i] for i in range(4))
@@ -50,6 +50,7 @@ for name, M, N, K, mode, has_bias in SHAPES:
                kernel_us=round(float(wg_end.max() - t0), 1),
                prologue_us=round(float(np.median(first - entry)), 2), k_loop_us=round(float(np.median(kend - first)), 2),
                epilogue_early_half_us=round(float(np.median((end - kend)[:, 0])), 2), epilogue_late_half_us=round(float(np.median((end - kend)[:, 1])), 2),
+               epilogue_convert_to_lds_us=(round(float(np.median((st[:, 0, 6].astype(np.float64) / 100.0) - kend[:, 0])), 2) if mode != 3 else None),
                late_half_lag_us=round(float(np.median(kend[:, 1] - kend[:, 0])), 2),
                turnover_gap_us=round(float(np.median(gaps)), 2) if gaps else None, turnover_gap_p90_us=round(float(np.percentile(gaps, 90)), 2) if gaps else None,
                k_tiles=K // 64, us_per_k_tile=round(float(np.median(kend - first)) / (K // 64), 3))

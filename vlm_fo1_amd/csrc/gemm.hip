@@ -744,6 +744,25 @@ __device__ __forceinline__ void epilogue32(const GemmParams& p, f32x16 (&acc)[MF
     }
 }
 
+#ifdef FO1_ENABLE_AB
+// fo1_gemm_set_debug bit 5 (32): workgroup timeline.  Waves 0 and 7 (one of each staggered half) write the 100 MHz s_memrealtime at kernel
+// entry, first MFMA, end of the K loop and end of the epilogue, plus their HW_ID / XCC_ID, to the buffer of fo1_gemm_set_stamp_buffer:
+// [workgroup][2][8] u64 (slots 6, 7: inside the coalesced epilogue — conversions staged in LDS, last store issued).  scripts/gemm_timeline.py turns that into turnover / prologue / K loop / epilogue per workgroup and per CU.
+__device__ __forceinline__ void gemm_stamp(const GemmParams& p, int wave, int lane, int slot) {
+    if ((p.debug & 32) && lane == 0 && (wave == 0 || wave == 7)) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.part) + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
+        o[slot] = __builtin_amdgcn_s_memrealtime();
+        if (slot == 0) {
+            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+        }
+    }
+}
+#define FO1_GEMM_STAMP(slot) gemm_stamp(p, wave, lane, slot)
+#else
+#define FO1_GEMM_STAMP(slot)
+#endif
+
 // Coalesced epilogue of the 256 x 256 kernels: the wave's 128 x 64 output block goes through its own 16 KiB of the (now idle)
 // LDS image — bias / activation applied in registers, rows written as 8-byte pieces into a 128-B-per-row image whose 16-B slots
 // are XOR-swizzled with the row — and is read back row-wise, 16 B per lane, 8 lanes per row: every global store instruction
@@ -883,6 +902,9 @@ __device__ __forceinline__ void epilogue32_coalesced_b(const GemmParams& p, f32x
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef FO1_ENABLE_AB
+        gemm_stamp(p, __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane, 6);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // write-out in two halves of 8 rows, each in three straight sweeps (8 LDS reads in flight, the residual adds under ONE uniform
         // branch, the stores): interleaved per row they were 16 x (ds_read -> wait -> branch -> store)
@@ -1152,25 +1174,6 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
 // (E8M0 127) — twice the K per MFMA at twice the rate: 16 MFMAs of 64 cycles per K tile where bf16 issues 32 of 32 cycles, so the DMA
 // schedule and every wait count carry over.  A lane's 32 operand bytes are two 16-B slots of the same swizzled LDS image; A and B
 // fragments are read the same way, so the operands' common k order inside a lane does not matter.
-#ifdef FO1_ENABLE_AB
-// fo1_gemm_set_debug bit 5 (32): workgroup timeline.  Waves 0 and 7 (one of each staggered half) write the 100 MHz s_memrealtime at kernel
-// entry, first MFMA, end of the K loop and end of the epilogue, plus their HW_ID / XCC_ID, to the buffer of fo1_gemm_set_stamp_buffer:
-// [workgroup][2][6] u64.  scripts/gemm_timeline.py turns that into turnover / prologue / K loop / epilogue per workgroup and per CU.
-__device__ __forceinline__ void gemm_stamp(const GemmParams& p, int wave, int lane, int slot) {
-    if ((p.debug & 32) && lane == 0 && (wave == 0 || wave == 7)) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.part) + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 6;
-        o[slot] = __builtin_amdgcn_s_memrealtime();
-        if (slot == 0) {
-            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
-            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
-        }
-    }
-}
-#define FO1_GEMM_STAMP(slot) gemm_stamp(p, wave, lane, slot)
-#else
-#define FO1_GEMM_STAMP(slot)
-#endif
-
 template <int EPI, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, ES = FP8 ? 1 : 2, BK = 128 / ES;
