@@ -335,7 +335,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
                               void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
- * Batched greedy decode: B <= 16 sequences advance one token per step through ONE stream of the weights, and
+ * Batched greedy decode: B <= 32 sequences advance one token per step through ONE stream of the weights, and
  * every position-dependent quantity lives in device memory, so a single captured hipGraph serves every step.
  * Reference: decode fast path omchat_qwen2_5_vl.py:143-155, positions modeling_qwen2_5_vl.py:1848-1860, stop rule
  * mm_utils.py:137-181 + HF greedy search (stop AFTER appending an EOS / keyword id, or at max_new_tokens).

@@ -1,5 +1,5 @@
-"""End-to-end anatomy of one pass of 25 images (prefill + 64-token decode), one pass at a time: decode groups sequential vs concurrent,
-2 vs 3 groups.   python scripts/e2e_ab.py"""
+"""End-to-end anatomy of one pass of 25 images (prefill + 64-token decode), one pass at a time: ONE decode group of 25 (round 3: two
+16-column MFMA groups per weight fragment) vs round 2's groups of <= 16, sequential vs concurrent.   python scripts/e2e_ab.py [--more]"""
 import os
 import sys
 import time
@@ -18,8 +18,8 @@ eng = pipe.eng
 K = 64
 
 
-def run(label, concurrent, groups, reps=4):
-    eng.DECODE_CONCURRENT, eng.DECODE_GROUPS = concurrent, groups
+def run(label, concurrent, groups, reps=4, gmax=16):
+    eng.DECODE_CONCURRENT, eng.DECODE_GROUPS, eng.DECODE_MAX_GROUP = concurrent, groups, gmax
     for _ in range(2):
         eng.generate_batch(pipe.requests, max_new_tokens=K, use_graph=True)
     torch.cuda.synchronize()
@@ -40,8 +40,10 @@ for _ in range(5):
     eng.prefill_batch(pipe.requests, use_graph=True)
 torch.cuda.synchronize()
 print(f"prefill only: {(time.perf_counter() - t0) / 5 * 1e3:.1f} ms", flush=True)
+run("ONE group of 25 (two MFMA column groups)", True, 1, gmax=32)
 run("2 groups (13 + 12) one after the other", False, 2)
 run("2 groups (13 + 12) together", True, 2)
-run("3 groups (9 + 8 + 8) together", True, 3)
-run("4 groups together", True, 4)
-run("5 groups together", True, 5)
+run("ONE group of 25 again", True, 1, gmax=32)
+if "--more" in sys.argv:
+    run("3 groups (9 + 8 + 8) together", True, 3)
+    run("4 groups together", True, 4)

@@ -112,13 +112,48 @@ def test_batched_decode_twelve_sequences_match_alone():
         L.load().fo1_gemm_set_gemv(1)
 
 
-def test_twenty_requests_one_prefill_pass_two_decode_groups():
-    """More requests than the decode loop's 16 MFMA columns: generate_batch runs ONE packed prefill pass over all 20, then decodes them
-    in groups of 16 + 4 out of the same prefill cache (the later group's prompt K / V must survive the first group's decode).  Per
-    request the ids equal the request decoded alone (prefill tile pinned, as above); the stop rule applies per sequence in both groups."""
+def test_twenty_five_requests_one_decode_group_of_two_mfma_column_groups():
+    """17..32 sequences ride as TWO 16-column groups per weight fragment (decode_mfma.hip, MM = 32: x fragments in registers for the
+    K = 2048 projections, 16-k-step pieces for `down`): 25 ragged requests — one packed prefill pass, ONE decode group — generate, per
+    request, exactly the ids the request generates alone (prefill tile pinned, as above), and the stop rule applies per sequence."""
     from test_batched_prefill_gpu import make_request
     from vlm_fo1_amd import lib as L
     cfg, weights, eng = build()
+    assert eng.DECODE_MAX_GROUP >= 25
+    reqs = [make_request(300 + i, 96 + 28 * (i % 4), 120 + 28 * (i % 3), 1 + (5 * i) % 9) for i in range(25)]
+    K = 6
+    try:
+        L.check(L.load().fo1_gemm_set_variant(2, 1), "variant")
+        L.check(L.load().fo1_gemm_set_splitk(1), "splitk")
+        L.check(L.load().fo1_gemm_set_gemv(0), "gemv")
+        got = eng.generate_batch(reqs, max_new_tokens=K, use_graph=True)
+        assert [len(g) for g in got] == [K] * 25
+        for i in (0, 15, 16, 17, 24):
+            assert eng.generate_batch([reqs[i]], max_new_tokens=K, use_graph=True)[0] == got[i], f"request {i} decodes differently in a batch of 25"
+        stop = got[21][2]
+        out = eng.generate_batch(reqs, max_new_tokens=K, stop_ids=[stop], use_graph=True)
+        for b, ids in enumerate(out):
+            cut = got[b].index(stop) + 1 if stop in got[b] else K
+            assert ids == got[b][:cut], f"sequence {b}: stop rule gave {ids}, expected {got[b][:cut]}"
+        # the same 25 in round 2's groups of at most 16 (13 + 12 on two streams): the same ids
+        eng.DECODE_MAX_GROUP = 16
+        assert eng.generate_batch(reqs, max_new_tokens=K, use_graph=True) == got
+    finally:
+        eng.DECODE_MAX_GROUP = type(eng).DECODE_MAX_GROUP
+        L.load().fo1_gemm_set_variant(0, 0)
+        L.load().fo1_gemm_set_splitk(0)
+        L.load().fo1_gemm_set_gemv(1)
+
+
+def test_twenty_requests_one_prefill_pass_two_decode_groups():
+    """More requests than a decode group carries (DECODE_MAX_GROUP = 16 here: round 2's one-column-group decode): generate_batch runs ONE
+    packed prefill pass over all 20, then decodes them in balanced groups out of the same prefill cache (the later group's prompt K / V
+    must survive the first group's decode).  Per request the ids equal the request decoded alone (prefill tile pinned, as above); the
+    stop rule applies per sequence in both groups."""
+    from test_batched_prefill_gpu import make_request
+    from vlm_fo1_amd import lib as L
+    cfg, weights, eng = build()
+    eng.DECODE_MAX_GROUP = 16
     reqs = [make_request(200 + i, 96 + 28 * (i % 4), 120 + 28 * (i % 3), 1 + (5 * i) % 9) for i in range(20)]
     K = 6
     try:
@@ -159,7 +194,7 @@ def _qkv_case(ops, M, seed=3):
     """Inputs of one fused-QKV decode projection (Qwen2.5-VL-3B head geometry) + fresh caches."""
     BF = torch.bfloat16
     g = torch.Generator().manual_seed(seed)
-    H, KV, HD, K, rows = 16, 2, 128, 2048, 256
+    H, KV, HD, K, rows = 16, 2, 128, 2048, 512
     x = (torch.randn(M, K, generator=g)).to(BF).cuda()
     w = (torch.randn((H + 2 * KV) * HD, K, generator=g) * 0.05).to(BF).cuda()
     b = (torch.randn((H + 2 * KV) * HD, generator=g) * 0.1).to(BF).cuda()
@@ -169,7 +204,7 @@ def _qkv_case(ops, M, seed=3):
     state = torch.zeros(M, 8, dtype=torch.int32)
     for m in range(M):
         state[m, 0] = 5 + 13 * m          # cache row
-        state[m, 1] = 200 - 7 * m         # rope-table row
+        state[m, 1] = 300 - 7 * m         # rope-table row (M <= 32: rows 83 .. 300; cache rows 5 .. 408)
     return dict(x=x, w=w, b=b, nw=nw, cos=cos, sin=sin, state=state.cuda(), H=H, KV=KV, HD=HD, rows=rows)
 
 
@@ -182,7 +217,7 @@ def _run_qkv(ops, c):
     return q.float().cpu(), kc.float().cpu(), vt.float().cpu()
 
 
-@pytest.mark.parametrize("M", [1, 5, 8, 16])
+@pytest.mark.parametrize("M", [1, 5, 8, 16, 25, 32])
 def test_gemv_mfma_qkv_matches_reference_and_dot2(M):
     """Fused QKV epilogue of the MFMA kernel (RMSNorm -> QKV + bias -> bf16 -> mRoPE -> q rows / K row / V^T column at state.pos)
     against a torch restatement of the reference's rounding points (modeling_qwen2_5_vl.py:126-140, 643-685), and — for M <= 8 —
@@ -282,6 +317,11 @@ def test_gemv_batch_rows_independent_of_batch():
         full16 = ops.gemv_batch(x16, w)                      # 16 sequences (MFMA kernel): 16 staged rows, same sums
         assert torch.equal(full16[:8], full), (N, K, "M=16 vs M=8")
         assert torch.equal(ops.gemv_batch(x16[11:12].contiguous(), w)[0], full16[11]), (N, K, "M=1 vs row 11 of 16")
+        x32 = torch.cat([x16, (torch.randn(16, K) * 0.5).to(BF).cuda()])
+        full32 = ops.gemv_batch(x32, w)                      # 32 sequences: two column groups per weight fragment, same sums
+        assert torch.equal(full32[:16], full16), (N, K, "M=32 vs M=16")
+        assert torch.equal(ops.gemv_batch(x32[27:28].contiguous(), w)[0], full32[27]), (N, K, "M=1 vs row 27 of 32")
+        assert torch.equal(ops.gemv_batch(x32[:21].contiguous(), w), full32[:21]), (N, K, "M=21 vs M=32")
         L.check(L.load().fo1_gemv_batch_set_rows_per_lane(1), "set_rows_per_lane")
         try:
             assert torch.equal(ops.gemv_batch(x, w), full)
@@ -295,7 +335,8 @@ def _gemv_batch_cases(gemm_ref, rb, ops, m16=False):
     shapes = [(1, 2048, 2048, False, True), (3, 2560, 2048, True, False), (8, 2048, 11008, False, True), (5, 1000, 264, True, True),
               (8, 151936 // 8, 2048, False, False)]
     if m16:
-        shapes += [(16, 2048, 11008, True, True), (13, 151936 // 8, 2048, False, False), (16, 1000, 264, True, True)]
+        shapes += [(16, 2048, 11008, True, True), (13, 151936 // 8, 2048, False, False), (16, 1000, 264, True, True),
+                   (32, 2048, 11008, True, True), (25, 151936 // 8, 2048, False, False), (17, 1000, 264, True, True), (32, 2560, 2048, True, True)]
     for (M, N, K, hb, hr) in shapes:
         x = (torch.randn(M, K) * 0.5).to(BF).cuda()
         w = (torch.randn(N, K) * 0.05).to(BF).cuda()
@@ -305,14 +346,15 @@ def _gemv_batch_cases(gemm_ref, rb, ops, m16=False):
         ref = gemm_ref(x, w, bias, res, 0)
         err = (got.float().cpu() - ref).abs().max().item()
         assert err <= 2e-2 * ref.abs().max().item() + 1e-3, f"gemv_batch {M}x{N}x{K}: max err {err:.4g}"
-    M, K, Fh = (16 if m16 else 8), 2048, 11008
-    x = (torch.randn(M, K)).to(BF).cuda()
-    nw = (1 + 0.1 * torch.randn(K)).to(BF).cuda()
-    wg, wu = (torch.randn(Fh, K) * 0.05).to(BF), (torch.randn(Fh, K) * 0.05).to(BF)
-    got = ops.gemv_batch(x, ops.interleave_gate_up(wg, wu).cuda(), mode=ops.GB_SWIGLU, norm_weight=nw, norm_eps=1e-6)
-    xf = x.float().cpu()
-    xn = rb(rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)) * nw.float().cpu())
-    g, u = rb(xn @ wg.float().t()), rb(xn @ wu.float().t())
-    ref = rb(rb(F.silu(g)) * u)
-    err = (got.float().cpu() - ref).abs().max().item()
-    assert got.shape == (M, Fh) and err <= 2e-2 * ref.abs().max().item() + 1e-3, f"gemv_batch swiglu+norm: max err {err:.4g}"
+    for M in ((16, 25, 32) if m16 else (8,)):
+        K, Fh = 2048, 11008
+        x = (torch.randn(M, K)).to(BF).cuda()
+        nw = (1 + 0.1 * torch.randn(K)).to(BF).cuda()
+        wg, wu = (torch.randn(Fh, K) * 0.05).to(BF), (torch.randn(Fh, K) * 0.05).to(BF)
+        got = ops.gemv_batch(x, ops.interleave_gate_up(wg, wu).cuda(), mode=ops.GB_SWIGLU, norm_weight=nw, norm_eps=1e-6)
+        xf = x.float().cpu()
+        xn = rb(rb(xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)) * nw.float().cpu())
+        g, u = rb(xn @ wg.float().t()), rb(xn @ wu.float().t())
+        ref = rb(rb(F.silu(g)) * u)
+        err = (got.float().cpu() - ref).abs().max().item()
+        assert got.shape == (M, Fh) and err <= 2e-2 * ref.abs().max().item() + 1e-3, f"gemv_batch swiglu+norm M={M}: max err {err:.4g}"

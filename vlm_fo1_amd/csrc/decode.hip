@@ -396,7 +396,7 @@ static int dispatch_gemv_b(GemvBParams& p, int mode, hipStream_t st) {
 
 #endif   // FO1_ENABLE_AB (gemv_batch_kernel)
 
-FO1_AB_VAR g_gemv_impl = 1;  // 1 = MFMA skinny GEMM (decode_mfma.hip, M <= 16), 0 = the v_dot2 kernel above (M <= 8)
+FO1_AB_VAR g_gemv_impl = 1;  // 1 = MFMA skinny GEMM (decode_mfma.hip, M <= 32), 0 = the v_dot2 kernel above (M <= 8)
 
 static int gemv_b_any(GemvBParams& p, int mode, hipStream_t st) {
     // the MFMA kernel moves epilogue operands four features at a time
@@ -566,7 +566,7 @@ int fo1_gemv_batch_bf16(const void* x, int ldx, const void* W, int ldw, const vo
                         void* vtcache, long long vt_row_stride, void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(x && W && (C || mode == 2), "gemv_batch: NULL operand");
-    FO1_CHECK_ARG(M >= 1 && M <= 16 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "gemv_batch: bad shape M=%d N=%d K=%d", M, N, K);
+    FO1_CHECK_ARG(M >= 1 && M <= 32 && N > 0 && K > 0 && K % 8 == 0 && ldx % 8 == 0 && ldw % 8 == 0, "gemv_batch: bad shape M=%d (1..32) N=%d K=%d", M, N, K);
     FO1_CHECK_ARG(mode >= 0 && mode <= 2, "gemv_batch: mode %d", mode);
     FO1_CHECK_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)norm_weight & 15) == 0, "gemv_batch: misaligned operand");
     if (mode == 1) FO1_CHECK_ARG(N % 32 == 0 && residual == nullptr, "gemv_batch: SwiGLU needs N %% 32 == 0 and no residual");

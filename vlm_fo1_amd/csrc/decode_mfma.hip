@@ -29,6 +29,13 @@
 //     are not what a weight stream waits for — and o / down / q,k,v run on 256 / 256 / 160 workgroups instead of 128 / 128 / 80
 //     (down at 16 sequences: 18.9 us = 2.4 TB/s before).  Chain A = first k-step of each pair, chain B = second: the same sets, the
 //     same order, the same bits as the other variants.
+//   * MM = 32 (round 3): 17..32 sequences as TWO column groups of the same MFMA per weight fragment — one stream of the weights for a whole
+//     25-image pass instead of one per group of 16.  32 staged x rows of K = 2048 (132 KB) do not fit next to the weight scratch and the
+//     reduction buffers, but a wave only ever multiplies by the k-steps s = wave + 8 d of x: for the single-piece projections (K <= 2048:
+//     q/k/v, o, gate/up, lm_head) its B fragments are constants of the launch.  x is staged (and RMS-normalised) in LDS once, each wave
+//     pulls its 4 k-steps x 2 halves x 2 groups = 16 fragments into 64 VGPRs, and the LDS region is then reused for scratch + reduction.
+//     Deep-K projections (down) stage x in pieces of 16 k-steps (66 KB).  Waves 0 and 1 run the epilogue of group 0 / 1.  Sums per
+//     (row, sequence) are built exactly as in the other variants.
 #include <type_traits>
 
 #include "decode_common.h"
@@ -70,8 +77,13 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     static_assert(MODE == GB_PLAIN || NB == 2, "paired modes use two row blocks");
     static_assert(!HALF || (MM == 8 && MODE != GB_SWIGLU), "HALF: M <= 8, plain or QKV");
     static_assert(!R8 || (MM == 16 && MODE != GB_SWIGLU && !HALF), "R8: 9..16 sequences, plain or QKV");
+    static_assert(MM == 8 || MM == 16 || MM == 32, "8, 16 or 32 sequence columns");
+    static_assert(MM != 32 || (!HALF && !R8), "32 sequences: 16-row blocks only");
+    constexpr int NG = MM == 32 ? 2 : 1;                                 // column groups of 16 sequences
+    constexpr int MR = MM == 32 ? 16 : MM;                               // sequences per group
+    constexpr bool XREG = MM == 32 && !MP;                               // x fragments live in registers (single-piece K)
     constexpr bool H8 = HALF || R8;                                      // 8-row blocks, a stage = the k-step pair (s, s + 8)
-    constexpr int PD = R8 ? 2 : ((HALF && !MP) ? 2 : 4);                 // register stages per wave = stages per staged piece
+    constexpr int PD = R8 ? 2 : ((HALF && !MP) ? 2 : ((MM == 32 && MP) ? 2 : 4));   // register stages per wave = stages per staged piece
     constexpr int SSTEP = H8 ? 16 : 8;                                   // k-step distance between a wave's consecutive stages
     constexpr int PSTEPS = SSTEP * PD;                                   // k-steps of x staged at a time: 32 (64: HALF && MP)
     constexpr int XPITCH = PSTEPS * 128 + 32;                            // bytes per staged x row (= 32 mod 256)
@@ -81,16 +93,17 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     constexpr int RB = H8 ? 8 : 16;                                      // weight rows per block
     extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
     unsigned char* const sx = gm_smem;                                   // [MM][XPITCH]
-    unsigned char* const sw = gm_smem + MM * XPITCH;                     // [GM_NW][NB][2048]  weight scratch (wave-private)
-    float* const sred = reinterpret_cast<float*>(sw + GM_NW * NB * 2048);   // [2][GM_NW][NB][64][4]
-    float* const srstd = sred + 2 * GM_NW * NB * 256;                    // [16]
+    unsigned char* const sw = XREG ? gm_smem : gm_smem + MM * XPITCH;    // [GM_NW][NB][2048]  weight scratch (wave-private); XREG: over the dead x image
+    float* const sred = reinterpret_cast<float*>(sw + GM_NW * NB * 2048);   // [2][NG][GM_NW][NB][64][4]
+    float* const srstd = XREG ? reinterpret_cast<float*>(gm_smem + MM * XPITCH) : sred + 2 * NG * GM_NW * NB * 256;   // [32]
+    static_assert(!XREG || GM_NW * NB * 2048 + 2 * NG * GM_NW * NB * 1024 <= MM * XPITCH, "scratch + reduction buffers fit in the x image");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int kch = p.K >> 3;                                            // 16-byte chunks per row
     const int n_pieces = (nsteps + PSTEPS - 1) / PSTEPS;
     const int lrow = lane >> 3, lch = lane & 7;                          // load shape: row of an 8-row group, chunk of the 128-byte k-step
     const int fi = lane & 15, fg = lane >> 4;                            // fragment shape: MFMA row / column, k group
     unsigned char* const swv = sw + wave * (NB * 2048);
-    const int xrow = MM == 16 ? fi : (fi & 7);
+    const int xrow = MR == 16 ? fi : (fi & 7);
     const int n_rope = MODE == GB_QKV ? (p.n_q + p.n_kv) * (64 / RB) : 0;
     const int xsel = (HALF && fi >= 8) ? 8 * 128 : 0;                    // HALF: columns 8-15 take the pair's second k-step
 
@@ -133,7 +146,8 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             for (int q = 0; q < 2; ++q) st[b][q] = gm_load_nt16(wp[b][q] + (long long)c[q] * 8);
     };
     // acc: the chain this stage adds to (R8: chain A = the pair's first k-step; accb = chain B = its second)
-    auto consume = [&](const uint4 (&st)[NB][2], int xs, gm_f32x4 (&acc)[NB], gm_f32x4 (&accb)[NB]) __attribute__((always_inline)) {
+    uint4 xf[XREG ? PD : 1][2][NG];                       // XREG: B fragments of this wave's k-steps (stage d, half h, column group g)
+    auto consume = [&](const uint4 (&st)[NB][2], int xs, int d, gm_f32x4 (&acc)[NG][NB], gm_f32x4 (&accb)[NG][NB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -144,11 +158,18 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         gm_lds_fence();
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            uint4 xv = *reinterpret_cast<const uint4*>(sx + xrow * XPITCH + xs * 128 + xsel + h * 64 + fg * 16);
+            uint4 xv[NG];
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if constexpr (XREG) xv[g] = xf[d][h][g];
+                else xv[g] = *reinterpret_cast<const uint4*>(sx + (g * 16 + xrow) * XPITCH + xs * 128 + xsel + h * 64 + fg * 16);
+            }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 uint4 wv = *reinterpret_cast<const uint4*>(swv + b * 2048 + fi * 128 + (((h * 4 + fg) ^ ((fi >> 1) & 7)) << 4));
-                acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xv), acc[b], 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < NG; ++g)      // one weight fragment, NG column groups of 16 sequences
+                    acc[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xv[g]), acc[g][b], 0, 0, 0);
             }
             if (R8) {     // the pair's second k-step: scratch rows 8-15 read as fragment rows 0-7 (fi ^ 8), x one k-step-pair half further
                 const int fj = fi ^ 8;
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     uint4 wv = *reinterpret_cast<const uint4*>(swv + b * 2048 + fj * 128 + (((h * 4 + fg) ^ ((fj >> 1) & 7)) << 4));
-                    accb[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xw), accb[b], 0, 0, 0);
+                    accb[0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xw), accb[0][b], 0, 0, 0);
                 }
             }
         }
@@ -232,8 +253,9 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     unit_ptrs(blockIdx.x, wcur);
 #pragma unroll
     for (int d = 0; d < PD; ++d) issue(wcur, wave + SSTEP * d, st[d]);
-    // decode state of this lane's sequence (QKV epilogue): cache row and rope-table row
-    const int n_seq = fi;
+    // decode state of this lane's sequence (QKV epilogue): cache row and rope-table row.  Wave g < NG runs the epilogue of column group g.
+    const int eg = wave < NG ? wave : 0;
+    const int n_seq = eg * 16 + fi;
     const bool seq_ok = n_seq < p.M && (!H8 || fg < 2);          // 8-row blocks: D rows 8-15 are chain B (HALF, folded into lanes fg < 2) or unused (R8)
     int pos = 0;
     long long trow = 0;
@@ -243,6 +265,18 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         trow = stt[1];
     }
     if (!MP) store_x(0, xr, nw);      // single piece: x staged (and normalised) once for every unit of this workgroup
+    if constexpr (XREG) {
+        // this wave's B fragments — k-steps wave + 8 d, both halves, both column groups — are the same for every unit: into registers,
+        // then the x image is dead and its LDS becomes the weight scratch and the reduction buffers
+#pragma unroll
+        for (int d = 0; d < PD; ++d)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+                    xf[d][h][g] = *reinterpret_cast<const uint4*>(sx + (g * 16 + fi) * XPITCH + (wave + SSTEP * d) * 128 + h * 64 + fg * 16);
+        __syncthreads();
+    }
     const uint16_t* const bias_src = p.bias ? p.bias : dummy;
     const uint16_t* const res_src = p.res ? p.res : dummy;
     const long long res_ld = p.res ? p.ldr : 0;
@@ -279,11 +313,13 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             }
         }
         // two chains per row: k-steps wave + 8d with d even / d odd (full: stages alternate; HALF: rows 0-7 / 8-15 of one stage)
-        gm_f32x4 accs[2][NB];
+        gm_f32x4 accs[2][NG][NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) accs[0][b] = accs[1][b] = gm_f32x4{0.f, 0.f, 0.f, 0.f};
-        gm_f32x4 (&acc)[NB] = accs[0];
-        gm_f32x4 (&acc2)[NB] = accs[1];
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) accs[0][g][b] = accs[1][g][b] = gm_f32x4{0.f, 0.f, 0.f, 0.f};
+        gm_f32x4 (&acc)[NG][NB] = accs[0];
+        gm_f32x4 (&acc2)[NG][NB] = accs[1];
 
         // every piece but the last: consume a k-step, refill its stage with the k-step one piece ahead in the same unit
         if (MP) {
@@ -294,7 +330,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
                 for (int d = 0; d < PD; ++d) {
                     const int xs = wave + SSTEP * d;              // k-step inside the staged piece
-                    consume(st[d], xs, accs[H8 ? 0 : (d & 1)], accs[1]);
+                    consume(st[d], xs, d, accs[H8 ? 0 : (d & 1)], accs[1]);
                     issue(wcur, (piece + 1) * PSTEPS + xs, st[d]);
                 }
             }
@@ -305,33 +341,38 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
         for (int d = 0; d < PD; ++d) {
             const int xs = wave + SSTEP * d;
-            consume(st[d], xs, accs[H8 ? 0 : (d & 1)], accs[1]);
+            consume(st[d], xs, d, accs[H8 ? 0 : (d & 1)], accs[1]);
             if (PF) issue(wnext, xs, st[d]);                  // the first piece of this workgroup's next unit
         }
         // chain A + chain B.  HALF: chain B of (row r, sequence n) sits in lane + 40 (fragment row r + 8, column n + 8)
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (HALF) {
+        for (int g = 0; g < NG; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc2[b][r] = __shfl(acc[b][r], (lane + 40) & 63, 64);
+            for (int b = 0; b < NB; ++b) {
+                if (HALF) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc2[g][b][r] = __shfl(acc[g][b][r], (lane + 40) & 63, 64);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[g][b][r] += acc2[g][b][r];
             }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[b][r] += acc2[b][r];
-        }
         // ---- the 8 waves' partial sums meet in LDS; double-buffered by unit parity: one barrier per unit ----
-        float* red = sred + (it & 1) * (GM_NW * NB * 256);
+        float* red = sred + (it & 1) * (NG * GM_NW * NB * 256);
 #pragma unroll
-        for (int b = 0; b < NB; ++b)
-            *reinterpret_cast<float4*>(red + ((wave * NB + b) * 64 + lane) * 4) = float4{acc[b][0], acc[b][1], acc[b][2], acc[b][3]};
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                *reinterpret_cast<float4*>(red + (((g * GM_NW + wave) * NB + b) * 64 + lane) * 4) =
+                    float4{acc[g][b][0], acc[g][b][1], acc[g][b][2], acc[g][b][3]};
         __syncthreads();
-        if (wave == 0) {
+        if (wave < NG) {        // wave g finishes column group g (sequences 16 g .. 16 g + 15)
             auto h4 = [](const uint2& q, int r) -> float { const uint32_t w = (r >> 1) ? q.y : q.x; return (r & 1) ? bf16_hi(w) : bf16_lo(w); };
             float v[NB][4];
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 float4 t[GM_NW];
 #pragma unroll
-                for (int w = 0; w < GM_NW; ++w) t[w] = *reinterpret_cast<const float4*>(red + ((w * NB + b) * 64 + lane) * 4);
+                for (int w = 0; w < GM_NW; ++w) t[w] = *reinterpret_cast<const float4*>(red + (((eg * GM_NW + w) * NB + b) * 64 + lane) * 4);
                 v[b][0] = ((t[0].x + t[1].x) + (t[2].x + t[3].x)) + ((t[4].x + t[5].x) + (t[6].x + t[7].x));
                 v[b][1] = ((t[0].y + t[1].y) + (t[2].y + t[3].y)) + ((t[4].y + t[5].y) + (t[6].y + t[7].y));
                 v[b][2] = ((t[0].z + t[1].z) + (t[2].z + t[3].z)) + ((t[4].z + t[5].z) + (t[6].z + t[7].z));
@@ -436,9 +477,12 @@ extern int g_gemv_profile_shapes;
 
 template <int MM, int MODE, int NB, bool MP, bool HALF, bool R8 = false>
 static int launch_gemv_mfma_mp(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
-    constexpr int pd = R8 ? 2 : ((HALF && !MP) ? 2 : 4);
+    constexpr int pd = R8 ? 2 : ((HALF && !MP) ? 2 : ((MM == 32 && MP) ? 2 : 4));
     constexpr int xpitch = ((HALF || R8) ? 16 : 8) * pd * 128 + 32;
-    const size_t smem = (size_t)MM * xpitch + (size_t)GM_NW * NB * 2048 + (size_t)2 * GM_NW * NB * 1024 + 64;
+    constexpr int ng = MM == 32 ? 2 : 1;
+    // MM == 32, single piece: the weight scratch and the reduction buffers reuse the x image once its fragments sit in registers
+    const size_t smem = (MM == 32 && !MP) ? (size_t)MM * xpitch + 128
+                                          : (size_t)MM * xpitch + (size_t)GM_NW * NB * 2048 + (size_t)2 * ng * GM_NW * NB * 1024 + 128;
     static bool attr = false;
     if (!attr) {
         FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB, MP, HALF, R8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -452,7 +496,7 @@ static int launch_gemv_mfma_mp(const GemvBParams& p, int n_units, int nsteps, co
 
 template <int MM, int MODE, int NB, bool HALF = false, bool R8 = false>
 static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
-    constexpr int piece = R8 ? 32 : GM_PIECE;        // k-steps of x staged at a time (R8 stages 2 pairs per wave)
+    constexpr int piece = R8 ? 32 : GM_PIECE;        // k-steps of x staged at a time (R8 stages 2 pairs per wave); 32 sequences: one piece up to K = 2048, pieces of 16 beyond
     if (nsteps > piece) return launch_gemv_mfma_mp<MM, MODE, NB, true, HALF, R8>(p, n_units, nsteps, name, st);
     return launch_gemv_mfma_mp<MM, MODE, NB, false, HALF, R8>(p, n_units, nsteps, name, st);
 }
@@ -491,7 +535,8 @@ static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
 
 int gemv_mfma_any(GemvBParams& p, int mode, hipStream_t st) {
     if (p.M <= 8) return dispatch_gemv_mfma<8>(p, mode, st);
-    return dispatch_gemv_mfma<16>(p, mode, st);
+    if (p.M <= 16) return dispatch_gemv_mfma<16>(p, mode, st);
+    return dispatch_gemv_mfma<32>(p, mode, st);
 }
 
 }  // namespace fo1

@@ -221,7 +221,7 @@ int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots,
                         int slot_rows, int max_kv_len, void* logits, void* workspace, size_t workspace_bytes, void* stream) {
     FO1_CHECK_ARG(w && slots && rope_cos && rope_sin && state && plan && ids_out && done && logits && w->layers && w->embed, "llm_decode_step: NULL argument");
     const int B = batch, d = w->hidden, H = w->n_heads, KV = w->n_kv_heads, HD = w->head_dim, I = w->intermediate;
-    FO1_CHECK_ARG(B >= 1 && B <= 16 && HD == 128, "llm_decode_step: batch %d (1..16), head_dim %d (128)", B, HD);
+    FO1_CHECK_ARG(B >= 1 && B <= 32 && HD == 128, "llm_decode_step: batch %d (1..32), head_dim %d (128)", B, HD);
     FO1_CHECK_ARG(max_kv_len >= 1 && max_kv_len <= slot_rows, "llm_decode_step: max_kv_len %d outside [1, slot_rows = %d]", max_kv_len, slot_rows);
     void *xa, *xb, *q, *att, *a, *aws, *asc;
     size_t abytes;

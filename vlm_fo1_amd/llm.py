@@ -443,13 +443,13 @@ class QwenLLM:
 
 
 class BatchDecoder:
-    """Greedy decode of up to 16 sequences at once: the weights are streamed ONCE per step for all sequences
+    """Greedy decode of up to 32 sequences at once: the weights are streamed ONCE per step for all sequences
     (fo1_gemv_batch_bf16), 5 launches per layer, and the whole step — embedding gather, 36 layers, lm_head, argmax, stop check,
     position bookkeeping — replays as one hipGraph with no host read inside the loop (the host polls a device-side `done` counter
     every few steps).  Reference semantics: HF greedy search over the 1-token fast path of omchat_qwen2_5_vl.py:143-155;
     positions = cache position + rope delta (modeling_qwen2_5_vl.py:1848-1860); a sequence stops AFTER its EOS / keyword id has
     been appended, or at max_new_tokens (mm_utils.py:137-181, 640-654)."""
-    MAX_BATCH = 16
+    MAX_BATCH = 32          # 17..32 sequences: two 16-column groups per weight fragment (decode_mfma.hip, MM = 32)
     IDS_CAP = 4096          # generated ids kept per sequence (every reference caller uses max_new_tokens <= 4096)
     MAX_STOP = 16           # stop ids the device-side rule compares against
 

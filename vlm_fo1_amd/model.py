@@ -361,6 +361,7 @@ class FO1Engine:
     PREFILL_MAX = 32       # requests per packed prefill pass of generate_batch
     DECODE_CONCURRENT = True   # decode groups of one pass advance together on their own streams (False: one after the other; A/B)
     DECODE_GROUPS = 1      # minimum number of decode groups when a pass has more sequences than one group holds
+    DECODE_MAX_GROUP = 32  # sequences per decode group (<= BatchDecoder.MAX_BATCH); 16 = round 2's one-MFMA-column-group decode (A/B)
     RAGGED_TOWERS = True   # images of different sizes share one DaViT / SimpleFPN pass (False: image by image, the round-2 path; A/B)
     GRAPH_CACHE = 8        # captured prefill graphs kept per engine (LRU); each holds its own activation pool
     CAPTURE_AFTER = 1      # sightings of a signature before it is captured: one-off shapes (a dataset of ragged images) run eagerly
@@ -485,14 +486,16 @@ class FO1Engine:
             hp = self._last_batch
             first = self._last_next_tokens
             n = len(grp)
-            if n <= BatchDecoder.MAX_BATCH:
+            gmax = min(BatchDecoder.MAX_BATCH, self.DECODE_MAX_GROUP)
+            if n <= gmax:
                 dec = self._decoder()
                 dec.start(hp["seqs"], hp["delta"], first[:n], max_new_tokens, stop_ids)
                 out += dec.run(max_new_tokens, use_graph=use_graph)
                 continue
-            # more sequences than the decode kernels' 16 MFMA columns: balanced groups (25 -> 13 + 12), each relocated out of the
+            # more sequences than one decode group carries (32 = two 16-column MFMA groups per weight fragment; DECODE_MAX_GROUP = 16
+            # restores round 2's groups for A/B): balanced groups (25 -> 13 + 12), each relocated out of the
             # prefill cache into its own decoder's slots and advanced on its own stream, all groups together (llm.run_decoders)
-            k = max(-(-n // BatchDecoder.MAX_BATCH), min(self.DECODE_GROUPS, n))
+            k = max(-(-n // gmax), min(self.DECODE_GROUPS, n))
             cuts = [round(j * n / k) for j in range(k + 1)]
             if not self.DECODE_CONCURRENT:      # A/B: the groups one after the other on the caller's stream
                 dec = self._decoder()

@@ -450,12 +450,12 @@ GB_PLAIN, GB_SWIGLU, GB_QKV = 0, 1, 2
 def gemv_batch(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
                mode: int = GB_PLAIN, norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 0.0,
                out: Optional[torch.Tensor] = None, qkv: Optional[dict] = None) -> torch.Tensor:
-    """Decode-step projection for M <= 16 sequences (fo1_gemv_batch_bf16).  qkv (mode GB_QKV): dict(n_q, n_kv, cos, sin, state,
+    """Decode-step projection for M <= 32 sequences (fo1_gemv_batch_bf16).  qkv (mode GB_QKV): dict(n_q, n_kv, cos, sin, state,
     kcache [n_kv, rows, 128], vtcache [n_kv*128, rows]) — `out` then receives only the rotated q rows [M, n_q*128]."""
     _chk(x, "x"); _chk(w, "w")
     px, ldx, M, K = _rows(x, "x")
     pw, ldw, N, K2 = _rows(w, "w")
-    assert K == K2 and M <= 16
+    assert K == K2 and M <= 32
     n_out = N // 2 if mode == GB_SWIGLU else (qkv["n_q"] * 128 if mode == GB_QKV else N)
     if out is None:
         out = torch.empty(M, n_out, dtype=torch.bfloat16, device=x.device)
