@@ -76,9 +76,9 @@ template <int MM, int MODE, int NB, bool MP, bool HALF, bool R8 = false>
 __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, const int n_units, const int nsteps) {
     static_assert(MODE == GB_PLAIN || NB == 2, "paired modes use two row blocks");
     static_assert(!HALF || (MM == 8 && MODE != GB_SWIGLU), "HALF: M <= 8, plain or QKV");
-    static_assert(!R8 || (MM == 16 && MODE != GB_SWIGLU && !HALF), "R8: 9..16 sequences, plain or QKV");
+    static_assert(!R8 || ((MM == 16 || MM == 32) && MODE != GB_SWIGLU && !HALF), "R8: 9..32 sequences, plain or QKV");
     static_assert(MM == 8 || MM == 16 || MM == 32, "8, 16 or 32 sequence columns");
-    static_assert(MM != 32 || (!HALF && !R8), "32 sequences: 16-row blocks only");
+    static_assert(MM != 32 || !HALF, "32 sequences: 16-row blocks, or 8-row blocks with the k-step pair as two MFMAs (R8, single-piece K only)");
     constexpr int NG = MM == 32 ? 2 : 1;                                 // column groups of 16 sequences
     constexpr int MR = MM == 32 ? 16 : MM;                               // sequences per group
     constexpr bool XREG = MM == 32 && !MP;                               // x fragments live in registers (single-piece K)
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             for (int q = 0; q < 2; ++q) st[b][q] = gm_load_nt16(wp[b][q] + (long long)c[q] * 8);
     };
     // acc: the chain this stage adds to (R8: chain A = the pair's first k-step; accb = chain B = its second)
-    uint4 xf[XREG ? PD : 1][2][NG];                       // XREG: B fragments of this wave's k-steps (stage d, half h, column group g)
+    uint4 xf[XREG ? PD : 1][H8 ? 2 : 1][2][NG];           // XREG: B fragments of this wave's k-steps (stage d, k-step of the pair, half h, column group g)
     auto consume = [&](const uint4 (&st)[NB][2], int xs, int d, gm_f32x4 (&acc)[NG][NB], gm_f32x4 (&accb)[NG][NB]) __attribute__((always_inline)) {
 #pragma unroll
         for (int b = 0; b < NB; ++b)
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             uint4 xv[NG];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if constexpr (XREG) xv[g] = xf[d][h][g];
+                if constexpr (XREG) xv[g] = xf[d][0][h][g];
                 else xv[g] = *reinterpret_cast<const uint4*>(sx + (g * 16 + xrow) * XPITCH + xs * 128 + xsel + h * 64 + fg * 16);
             }
 #pragma unroll
@@ -173,11 +173,18 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
             }
             if (R8) {     // the pair's second k-step: scratch rows 8-15 read as fragment rows 0-7 (fi ^ 8), x one k-step-pair half further
                 const int fj = fi ^ 8;
-                uint4 xw = *reinterpret_cast<const uint4*>(sx + xrow * XPITCH + (xs + 8) * 128 + h * 64 + fg * 16);
+                uint4 xw[NG];
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if constexpr (XREG) xw[g] = xf[d][H8 ? 1 : 0][h][g];
+                    else xw[g] = *reinterpret_cast<const uint4*>(sx + (g * 16 + xrow) * XPITCH + (xs + 8) * 128 + h * 64 + fg * 16);
+                }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
                     uint4 wv = *reinterpret_cast<const uint4*>(swv + b * 2048 + fj * 128 + (((h * 4 + fg) ^ ((fj >> 1) & 7)) << 4));
-                    accb[0][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xw), accb[0][b], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        accb[g][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<gm_bf16x8*>(&wv), *reinterpret_cast<gm_bf16x8*>(&xw[g]), accb[g][b], 0, 0, 0);
                 }
             }
         }
@@ -271,10 +278,12 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
         for (int d = 0; d < PD; ++d)
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int q = 0; q < (H8 ? 2 : 1); ++q)          // 8-row blocks: a stage is the k-step pair (s, s + 8)
 #pragma unroll
-                for (int g = 0; g < NG; ++g)
-                    xf[d][h][g] = *reinterpret_cast<const uint4*>(sx + (g * 16 + fi) * XPITCH + (wave + SSTEP * d) * 128 + h * 64 + fg * 16);
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int g = 0; g < NG; ++g)
+                        xf[d][q][h][g] = *reinterpret_cast<const uint4*>(sx + (g * 16 + fi) * XPITCH + (wave + SSTEP * d + 8 * q) * 128 + h * 64 + fg * 16);
         __syncthreads();
     }
     const uint16_t* const bias_src = p.bias ? p.bias : dummy;
@@ -526,6 +535,11 @@ static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
         // fill the chip like they do at M <= 8; bit 2 of fo1_gemv_batch_set_impl's half switch (g_gemv_half & 2 == 0) turns it off
         if ((g_gemv_half & 2) && mode == GB_QKV) return launch_gemv_mfma<16, GB_QKV, 2, false, true>(p, (p.n_q + p.n_kv) * 8 + p.n_kv * 8, nsteps, name, st);
         if ((g_gemv_half & 2) && mode == GB_PLAIN && p.N <= 4096) return launch_gemv_mfma<16, GB_PLAIN, 1, false, true>(p, cdiv(p.N, 8), nsteps, name, st);
+    }
+    if constexpr (MM == 32) {
+        // 17..32 sequences, single-piece K only (a deep-K piece of 32 x 4 KB rows does not fit next to the buffers): the same 8-row units
+        if ((g_gemv_half & 2) && nsteps <= 32 && mode == GB_QKV) return launch_gemv_mfma_mp<32, GB_QKV, 2, false, false, true>(p, (p.n_q + p.n_kv) * 8 + p.n_kv * 8, nsteps, name, st);
+        if ((g_gemv_half & 2) && nsteps <= 32 && mode == GB_PLAIN && p.N <= 4096) return launch_gemv_mfma_mp<32, GB_PLAIN, 1, false, false, true>(p, cdiv(p.N, 8), nsteps, name, st);
     }
     if (mode == GB_QKV) return launch_gemv_mfma<MM, GB_QKV, 2>(p, (p.n_q + p.n_kv) * 4 + p.n_kv * 4, nsteps, name, st);
     // plain: 16-row units for the few-row projections (every CU should stream), 32-row units for lm_head-sized matrices
