@@ -577,6 +577,11 @@ def main():
                                       prefill_pass_ms=round(t_pref * 1e3, 3),
                                       images_per_sec_with_64_token_answer=round(Bd / (t_pref + 64 * tb), 2),
                                       launches_per_layer=5, note="one pass at a time: packed prefill of the batch, then 64 batched decode steps")
+                # HBM roofline of the decode step: every weight byte streams once per step for all sequences of the group
+                wbytes = float(sum(t.numel() * t.element_size() for t in eng.llm.decode_weight_tensors())) if hasattr(eng.llm, "decode_weight_tensors") else 6.2e9
+                for blk, tt in ((dec, t1), (dec["batched"], tb)):
+                    blk["roofline"] = dict(bound="hbm", unit="GB/s", peak=8000.0, algorithmic_bytes_per_step=wbytes,
+                                           achieved=round(wbytes / tt / 1e9, 1), frac=round(wbytes / tt / 8e12, 4))
 
     # ---- end to end: upload + device preprocessing + packed prefill + 64-token batched decode + ids on the host, one timed loop ----
     e2e = None

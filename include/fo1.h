@@ -342,7 +342,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
  *   state: int32[B][8] = { pos, rope_row, kv_start, finished, n_gen, max_new, -, - }
  *     pos = cache row the fed token's K row / V^T column is written to; keys attended = [kv_start, pos];
  *     rope_row = row of the [positions, 128] mRoPE tables (cache position + rope delta).
- *   fo1_gemv_batch_bf16            C[M<=16,N] = epilogue(rmsnorm?(x) W^T): mode 0 bias/residual, 1 interleaved SwiGLU,
+ *   fo1_gemv_batch_bf16            C[M<=32,N] = epilogue(rmsnorm?(x) W^T): mode 0 bias/residual, 1 interleaved SwiGLU,
  *                                  2 fused QKV (bias -> bf16 -> mRoPE -> q rows out, K row + V^T column appended at state.pos)
  *   fo1_attention_decode_batch_bf16  split-KV attention of B one-token queries against their slots
  *   fo1_decode_argmax_accept       greedy pick per logits row + on-device accept: record id, stop check, advance state,

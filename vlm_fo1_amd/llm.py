@@ -219,6 +219,14 @@ class QwenLLM:
         pos, delta = rope_index_host(n_before, grid_hw_merged, n_after)
         return torch.tensor(plan, dtype=torch.int32).reshape(-1, 2), pos, delta
 
+    def decode_weight_tensors(self):
+        """The tensors one decode step streams once (projection weights + biases, norms, lm_head): the algorithmic bytes of the step's
+        HBM roofline (bench.py `decode.roofline`)."""
+        out = [self.lm_head, self.norm]
+        for w in self.layers:
+            out += [w["wqkv"], w["bqkv"], w["wo"], w["wgu"], w["wdown"], w["ln1"], w["ln2"]]
+        return out
+
     def embed_rows(self, plan_dev: torch.Tensor, image_tokens: torch.Tensor, region_tokens: Optional[torch.Tensor]):
         """DEVICE part of the splice: one row gather over (embed table | image tokens | region tokens)."""
         return ops.gather_rows(plan_dev, self.cfg.hidden_size, self.embed, image_tokens, region_tokens)
