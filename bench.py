@@ -539,7 +539,8 @@ def main():
                    note="one sequence at a time, host reads every token (the round-1 path)")
         # device decode loop: the sequences of one packed prefill advance together, weights streamed once per step, stop rule and
         # bookkeeping on the device (no host read per token); measured for one sequence and for the batch
-        Bd = min(B, 16)
+        from vlm_fo1_amd.llm import BatchDecoder
+        Bd = min(B, BatchDecoder.MAX_BATCH)      # one decode group: up to 32 sequences per weight stream
         if use_graph:
             eng = pipe.eng
 
