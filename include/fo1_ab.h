@@ -50,7 +50,7 @@ int fo1_gemm_set_stamp_buffer(void* device_buffer);
 /* fo1_gemv_batch_bf16, v_dot2 kernel: 0 (default) = a lane streams 1 / 2 / 4 weight rows per chunk position by M; 1 = always one row. */
 int fo1_gemv_batch_set_rows_per_lane(int rpl);
 /* 1 (default) = MFMA skinny GEMM (csrc/decode_mfma.hip: the sequences ride as the 16 columns of v_mfma_f32_16x16x32_bf16); 0 = the v_dot2
- * streaming kernel (M <= 8); 3 = MFMA without any 8-row units; 5 = MFMA with the M <= 8 (HALF) units only (no R8 units for 9..16 sequences).
+ * streaming kernel (M <= 8); 3 = MFMA without any 8-row units; 5 = MFMA with the M <= 8 (HALF) units only (no R8 units for 9..32 sequences).
  * All keep a sequence's numbers independent of the batch it decodes in; MFMA and v_dot2 differ from each other in fp32 summation order. */
 int fo1_gemv_batch_set_impl(int impl);
 /* 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence), partials merged in LDS (measured

@@ -29,7 +29,7 @@ enum { GB_PLAIN = 0, GB_SWIGLU = 1, GB_QKV = 2 };
 
 // decode_mfma.hip
 #ifdef FO1_ENABLE_AB
-extern int g_gemv_half;   // decode_mfma.hip: bit 0 = 8-row units at M <= 8 (HALF), bit 1 = at 9..16 sequences (R8)
+extern int g_gemv_half;   // decode_mfma.hip: bit 0 = 8-row units at M <= 8 (HALF), bit 1 = at 9..32 sequences (R8)
 #else
 [[maybe_unused]] static constexpr int g_gemv_half = 3;
 #endif

@@ -1,4 +1,4 @@
-// decode_mfma.hip — weight-streaming skinny GEMM for the decode step on gfx950: C[M <= 16, N] = epilogue(rmsnorm?(x) W^T) with
+// decode_mfma.hip — weight-streaming skinny GEMM for the decode step on gfx950: C[M <= 32, N] = epilogue(rmsnorm?(x) W^T) with
 // the B sequences of a decode batch riding as the 16 columns of v_mfma_f32_16x16x32_bf16 (reference: the 1-token
 // fast path of omchat_qwen2_5_vl.py:143-155 — q/k/v, o, gate/up, down, lm_head of modeling_qwen2_5_vl.py:731-734,633-635,1876).
 //
@@ -511,7 +511,7 @@ static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const
 }
 
 #ifdef FO1_ENABLE_AB
-int g_gemv_half = 3;     // bit 0: M <= 8 8-row units (HALF); bit 1: 9..16 sequences 8-row units (R8) — few-row projections (A/B: fo1_gemv_batch_set_impl)
+int g_gemv_half = 3;     // bit 0: M <= 8 8-row units (HALF); bit 1: 9..32 sequences 8-row units (R8; 17..32: single-piece K only) — few-row projections (A/B: fo1_gemv_batch_set_impl)
 #endif
 
 template <int MM>
