@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the VLM-FO1 hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: re-executes itself under torch.distributed.run)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One "step" = ONE packed pass of `--batch` (default 25) different images through every hot-path stage the engine implements
 (listed in config.stages: both towers, FPN, HFRE, connectors, splice, 36-layer LLM prefill, first greedy token), inputs already
@@ -20,7 +20,6 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import torch  # noqa: E402
 
@@ -32,7 +31,7 @@ def build_workload(device, n_boxes=100, img_hw=(480, 640), seed=1234, lift_cap=F
     """The configuration BASELINE.json's `metric` is quoted on: 1 image (640x480 synthetic, the COCO-typical size) x 100
     proposals (the reference's cap, mm_utils.py:600; boxes = the 100-box CountBench UPN fixture item rescaled to the image),
     Qwen2.5-VL-3B / DaViT-L true shapes.  n_boxes=32 gives configs[1].  Everything the timed region reads is resident in HBM."""
-    from hfre_cases import box_fixtures
+    from vlm_fo1_amd.fixtures import box_fixtures
     from vlm_fo1_amd.model import synthetic_prompt
     H, W = img_hw
     g = torch.Generator().manual_seed(seed)
@@ -409,6 +408,20 @@ def main():
     ap.add_argument("--dataset-items", type=int, default=150, help="items of the dataset to run (0 = all)")
     ap.add_argument("--dataset-aux", default="dynamic", choices=["dynamic", "squash"], help="aux image sizing (config aux_image_aspect_ratio)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher — one rank per GPU under torch.distributed.run on the
+        # loopback address (the container hostname may not resolve), same arguments.  rank 0's JSON line is the only stdout line.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        if os.environ.get("FO1_BENCH_SPAWN_DRYRUN") == "1":      # tests/test_bench_cli.py (no GPU): show the launch instead of doing it
+            print(json.dumps(cmd))
+            return
+        os.execv(sys.executable, cmd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

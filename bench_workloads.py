@@ -2,7 +2,7 @@
 
 No image or checkpoint exists offline, so pixel content is seeded noise — but the GEOMETRY is the datasets' own:
   * `countbench` / `pixmo`: every item of the reference's evaluation fixtures with its UPN box list verbatim
-    (tests/golden/dataset_boxes.npz: 487 items / 11 144 boxes and 529 items / 28 996 boxes, N in [2, 100]); the image is synthesised
+    (vlm_fo1_amd/fixtures/dataset_boxes.npz: 487 items / 11 144 boxes and 529 items / 28 996 boxes, N in [2, 100]); the image is synthesised
     at the extent of its boxes, max(x2) x max(y2) (SURVEY §8d cfg4) — 99 x 99 up to 5181 x 3444 pixels;
   * `coco-like`: image sizes cycled over a COCO-val2017-like list (640x480 dominant, portrait and 4:3 / 3:2 variants), 100 boxes per
     image drawn (seed 1234) from the empirical normalised (x1, y1, x2, y2) distribution of the Pixmo fixture.
@@ -28,7 +28,7 @@ COCO_SIZES = [((640, 480), 25), ((640, 427), 18), ((480, 640), 8), ((640, 426), 
 
 
 def _fixture():
-    return np.load(os.path.join(ROOT, "tests", "golden", "dataset_boxes.npz"))
+    return np.load(os.path.join(ROOT, "vlm_fo1_amd", "fixtures", "dataset_boxes.npz"))
 
 
 def dataset_items(name: str, limit: Optional[int] = None, seed: int = 1234) -> List[Dict]:

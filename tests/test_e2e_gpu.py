@@ -104,16 +104,18 @@ def test_graph_replay_is_bit_identical_to_eager():
 
 
 def test_bench_two_ranks_control_flow(tmp_path):
-    """bench.py under torch.distributed.run with 2 ranks (both on cuda:0 over gloo — a 1-GPU box cannot host two RCCL ranks):
-    the barrier / max-over-ranks / rank-0-prints-one-line contract and hipGraph capture with a live process group."""
+    """`python bench.py --gpus 2` WITHOUT a launcher (the form the driver uses): bench.py re-executes itself under
+    torch.distributed.run with 2 ranks (both on cuda:0 over gloo — a 1-GPU box cannot host two RCCL ranks): the barrier /
+    max-over-ranks / rank-0-prints-one-line contract and hipGraph capture with a live process group."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, FO1_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29517", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--main-only"]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]

@@ -518,6 +518,11 @@ template <int MM>
 static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
     const int nsteps = cdiv(p.K, 64);
     if (p.norm_w && nsteps > GM_PIECE) return set_err(FO1_ERR_ARG, "gemv_batch: fused RMSNorm needs K <= %d (K=%d)", GM_PIECE * 64, p.K);
+    // 17..32 sequences with a deep K (x staged in pieces) and a paired mode (two row blocks per unit: QKV, SwiGLU, 32-row plain units)
+    // would need 32 * 2080 + 8 * 2 * 2048 + 2 * 2 * 8 * 2 * 1024 + 128 = 164 992 B of LDS — more than the 156 KB the launch may ask
+    // for.  The shipped model (hidden 2048) never gets here; refuse instead of failing the launch.
+    if (MM == 32 && nsteps > 32 && (mode != GB_PLAIN || p.N >= 8192))
+        return set_err(FO1_ERR_ARG, "gemv_batch: M > 16 with K > 2048 is built for the plain few-row form only (M=%d N=%d K=%d mode=%d)", p.M, p.N, p.K, mode);
     char pname[56];
     const char* name = mode == GB_SWIGLU ? "gemv_mfma_swiglu" : (mode == GB_QKV ? "gemv_mfma_qkv" : "gemv_mfma");
     if (profile_enabled() && g_gemv_profile_shapes) {

@@ -94,7 +94,7 @@ class DaViT:
         # V^T scratch [C, n padded to 64] from the owner-scoped pool (zero-initialised; the pad columns are never written):
         # this module is shared by engine replicas, so the buffer must belong to the running request, not to the module
         n_pad = _round_up(n, 64)
-        vt = ops._workspace(f"davit_vt_{C}x{n_pad}", x.device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
+        vt = ops._workspace(f"davit_vt_{C}", x.device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
         ops.transpose_into(qkv[:, 2 * C:], vt, 0)
         hd = C // heads
         items = self._window_items(n // (ws * ws), ws * ws, heads)
@@ -134,7 +134,7 @@ class DaViT:
         qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
         n = hw.shape[0]
         n_pad = _round_up(n, 64)
-        vt = ops._workspace(f"davit_vt_{C}x{n_pad}", x.device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
+        vt = ops._workspace(f"davit_vt_{C}", x.device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
         ops.transpose_into(qkv[:, 2 * C:], vt, 0)
         hd = C // heads
         items = self._window_items(n // (ws * ws), ws * ws, heads)

@@ -1,4 +1,4 @@
-"""Extracts tests/golden/box_fixtures.json — a SMALL sample of the real UPN box lists
+"""Extracts vlm_fo1_amd/fixtures/box_fixtures.json — a SMALL sample of the real UPN box lists
 (data, not code) from the reference's evaluation fixtures
 (/root/reference/evaluation/processed_data/*.json) so that GPU-box tests and
 bench.py have real box geometry without reading /root/reference at run time."""
@@ -32,7 +32,7 @@ def main():
                           "bboxes": x["bboxes"], "extent": [xs, ys]})
         out[name] = items
         print(name, [(it["index"], len(it["bboxes"]), it["extent"]) for it in items])
-    json.dump(out, open("tests/golden/box_fixtures.json", "w"))
+    json.dump(out, open("vlm_fo1_amd/fixtures/box_fixtures.json", "w"))
 
 
 if __name__ == "__main__":

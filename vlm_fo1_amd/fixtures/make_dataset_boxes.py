@@ -1,10 +1,10 @@
-"""Extracts tests/golden/dataset_boxes.npz: the UPN box lists (data, not code) of EVERY item of the reference's two evaluation fixtures
+"""Extracts vlm_fo1_amd/fixtures/dataset_boxes.npz: the UPN box lists (data, not code) of EVERY item of the reference's two evaluation fixtures
 (/root/reference/evaluation/processed_data/{countbench,pixmoCount}_with_upn_score_0.3_0.8.json, SURVEY §8c/§8d cfg4: 487 items /
 11 144 boxes and 529 items / 28 996 boxes, integer pixels, N in [2, 100]) as int16 arrays, so that bench.py's dataset-shaped workloads
 and the GPU-box tests have the real variable-N box geometry without reading /root/reference at run time.  Images are not part of the
 fixtures (none exist offline): workloads synthesise each image at the extent of its boxes, max(x2) x max(y2).
 
-    python tests/golden/make_dataset_boxes.py
+    python vlm_fo1_amd/fixtures/make_dataset_boxes.py
 """
 import json
 import os

@@ -127,6 +127,7 @@ class QwenLLM:
         self.dplan = torch.zeros(1, 2, dtype=torch.int32, device=self.dev)     # gather plan of the one new token: (0, token id)
         self._dgraph = None
         self._dstate_keep = None
+        self.rope_epoch = 0         # bumped whenever the rope tables are re-allocated (grow_rope): step graphs key on it
         self._ws_owner = ops.new_owner(self)   # scratch-buffer key (ops.workspace_scope); FO1Engine overrides it with its own token
 
     def reserve(self, n_positions: int) -> bool:
@@ -164,7 +165,7 @@ class QwenLLM:
         cos_t, sin_t = mrope_tables(p, c.head_dim, c.rope_theta, c.mrope_section)
         self.rope_cos, self.rope_sin = cos_t.to(self.dev), sin_t.to(self.dev)
         self._dgraph = None
-        self.rope_epoch = getattr(self, "rope_epoch", 0) + 1
+        self.rope_epoch += 1
 
     def replica(self) -> "QwenLLM":
         """Same weights and rope tables (shared, read-only), private per-request state: KV cache, decode state, decode graph.
@@ -518,6 +519,10 @@ class BatchDecoder:
         while slot < need:
             slot *= 2
         self._ensure(max(B * slot, self.rows), slot)
+        rope_id = (llm.rope_epoch, llm.rope_cos.data_ptr())
+        if rope_id != getattr(self, "_rope_id", rope_id):
+            self._graphs = {}              # graphs of the previous table are unreachable by key: release them and their pools
+        self._rope_id = rope_id
         self.B, self.slot = B, slot
         self.len0, self.steps = max(L for _, L, *_ in seqs), 0      # host-side bound on any sequence's keys: len0 + steps + 1
         reloc = torch.tensor([[o, b * slot, L, 0] for b, (o, L, *_) in enumerate(seqs)], dtype=torch.int32)
@@ -573,7 +578,9 @@ class BatchDecoder:
             out = self._step_device()
             self.steps += 1
             return out
-        key = (self.B, self.slot, self.n_stop, self.kv_bucket())
+        # the rope tables' identity is part of the key: QwenLLM.reserve() on a larger later batch or a sibling decoder may re-allocate
+        # them (grow_rope) while this decoder's graphs survive — a replay would read the freed table
+        key = (self.B, self.slot, self.n_stop, self.kv_bucket(), self.llm.rope_epoch, self.llm.rope_cos.data_ptr())
         ent = self._graphs.get(key)
         if ent is None:
             with ops.graph_lock.capture(), torch.inference_mode(False):

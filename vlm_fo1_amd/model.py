@@ -309,6 +309,9 @@ class FO1Engine:
                         o += t.shape[0]
                 fpn_maps, fplan = self.fpn.forward_ragged(vt_sel, [grids[u] for u in imgs], r0s)
                 self._mark("simple_fpn")
+            # the plans own the device geometry tables (ops.ImgSegs) the launches above read: a captured graph of this pass holds
+            # their raw pointers, so the pass result keeps the plans alive past the towers' 64-entry plan caches
+            self._pass_keep += [aplan, fplan]
             slot = {u: j for j, u in enumerate(imgs)}
             for i in idx:
                 u = img_of[i]
@@ -343,8 +346,10 @@ class FO1Engine:
 
     def _device_batch(self, st, meta):
         with ops.workspace_scope(self._ws_owner):
+            self._pass_keep = keep = []      # host objects whose device tables this pass's launches (and a graph of them) point at
             grids = meta["grids"]
             tokens, feats, bp = self.vit.forward_batch(st["pix"], grids, capture=self.capture)
+            keep.append(bp)                  # (the ViT's batch plans are evicted from a 64-entry cache the same way)
             self._mark("qwen_vit+merger")
             image_tokens = self.mm_projector(tokens)
             self._mark("mm_projector")
@@ -356,7 +361,7 @@ class FO1Engine:
             last, logits, toks = self.llm.prefill_packed(emb, st["cos"], st["sin"], meta["seqs"], st["last"])
             self._mark("llm_prefill+lm_head+argmax")
             return dict(image_tokens=image_tokens, region_tokens=region_tokens, embeds=emb, last_hidden=last, logits=logits,
-                        next_tokens=toks, region_ranges=ranges, row0=bp.row0)
+                        next_tokens=toks, region_ranges=ranges, row0=bp.row0, _keep=keep)
 
     PREFILL_MAX = 32       # requests per packed prefill pass of generate_batch
     DECODE_CONCURRENT = True   # decode groups of one pass advance together on their own streams (False: one after the other; A/B)

@@ -184,7 +184,8 @@ class Prefetcher:
     def get(self, i: int):
         with self._lock:
             f = self._fut.pop(i, None)
-            self._taken += 1
+            if f is not None:              # only a scheduled item frees a slot of the window: a retry (its future was consumed by
+                self._taken += 1           # the failed group) must not widen it
         self._fill()
         if f is None:                      # not scheduled (a retry after a failed group, or out-of-order use): do it now
             return self._prepare(i)
