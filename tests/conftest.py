@@ -3,10 +3,11 @@ import sys
 
 import pytest
 
-# The test session runs on the test / bench build of the library (libfo1hip_ab.so): the parity tests pin the GEMM tile / split-K / GEMV
-# routing through include/fo1_ab.h's switches, which the product library (libfo1hip.so) does not have.  tests/test_product_lib_gpu.py
-# and __graft_entry__.smoke() / bench.py run the product library.
-os.environ.setdefault("FO1_AB", "1")
+# The test session runs on the PRODUCT library (vlm_fo1_amd/libfo1hip.so — the one bench.py times and a deployment loads): every
+# parity test that needs no determinism pin exercises exactly that binary.  Tests that pin the GEMM tile /
+# split-K / GEMV routing or compare A/B kernels ask for the `ab_library` fixture: inside it every call goes through the test / bench
+# build (libfo1hip_ab.so, include/fo1_ab.h), outside it through the product library again (vlm_fo1_amd.lib.use_ab).
+os.environ.pop("FO1_AB", None)
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
@@ -26,3 +27,41 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+def _use_ab():
+    from vlm_fo1_amd import lib as L
+    with L.use_ab() as lib:
+        assert lib._name.endswith("libfo1hip_ab.so")
+        yield lib
+    assert not L.ab_build(), "the session falls back to the product library after an A/B test"
+
+
+@pytest.fixture
+def ab_library():
+    """The test / bench build for the duration of ONE test (include/fo1_ab.h switches available through L.load())."""
+    yield from _use_ab()
+
+
+@pytest.fixture(scope="module")
+def ab_library_module():
+    yield from _use_ab()
+
+
+@pytest.fixture
+def product_library():
+    """Asserts — before and after the test — that the active library is the PRODUCT build and that it is really mapped into this
+    process (the same check the driver's native-code record makes)."""
+    from vlm_fo1_amd import lib as L
+
+    def check():
+        lib = L.load()
+        assert lib._name.endswith("libfo1hip.so") and not L.ab_build(), lib._name
+        for hook in L.SIGNATURES_AB:
+            assert not hasattr(lib, hook), hook + " exported by the product library"
+        with open("/proc/self/maps") as f:
+            assert any(line.rstrip().endswith("vlm_fo1_amd/libfo1hip.so") for line in f), "libfo1hip.so is not mapped"
+
+    check()
+    yield L.load()
+    check()

@@ -24,7 +24,8 @@ def exported(so):
 
 
 def test_library_exports_every_declared_symbol():
-    lib = L.load()              # the test session's library: the test / bench build (FO1_AB=1, tests/conftest.py)
+    lib = L.load()              # the test session's library: the PRODUCT build (tests/conftest.py)
+    assert lib._name.endswith("libfo1hip.so")
     syms = declared_symbols()
     assert "fo1_hfre_region_pool" in syms
     for s in syms:
@@ -32,6 +33,11 @@ def test_library_exports_every_declared_symbol():
     # and the Python binding table covers exactly the header
     assert sorted(L.SIGNATURES) == syms
     assert sorted(L.SIGNATURES_AB) == declared_symbols("fo1_ab.h")
+    with L.use_ab() as ab:      # the test / bench build exports both headers; the switch routes L.load() and restores it afterwards
+        assert L.load() is ab and L.ab_build() and ab._name.endswith("libfo1hip_ab.so")
+        for sname in syms + sorted(L.SIGNATURES_AB):
+            assert hasattr(ab, sname)
+    assert L.load() is lib and not L.ab_build()
 
 
 def test_product_library_has_no_switches_and_the_ab_build_has_exactly_the_two_headers():

@@ -88,7 +88,7 @@ def test_batched_decode_vs_alone_vs_oracle_and_stop_rule():
     assert [g[:3] for g in got[True]] == eng.generate_batch(reqs, max_new_tokens=3, use_graph=True)
 
 
-def test_batched_decode_twelve_sequences_match_alone():
+def test_batched_decode_twelve_sequences_match_alone(ab_library):
     """More than 8 sequences per weight stream (the MFMA kernel carries up to 16 as MFMA columns): 12 ragged requests generate, per
     request, exactly the ids the same path generates for the request alone.  The prefill GEMMs are pinned to one tile (as in
     test_ragged_batch_equals_sequential_bitwise_with_pinned_tile) so that the KV rows a request starts from are the same bits in
@@ -112,7 +112,7 @@ def test_batched_decode_twelve_sequences_match_alone():
         L.load().fo1_gemm_set_gemv(1)
 
 
-def test_twenty_five_requests_one_decode_group_of_two_mfma_column_groups():
+def test_twenty_five_requests_one_decode_group_of_two_mfma_column_groups(ab_library):
     """17..32 sequences ride as TWO 16-column groups per weight fragment (decode_mfma.hip, MM = 32: x fragments in registers for the
     K = 2048 projections, 16-k-step pieces for `down`): 25 ragged requests — one packed prefill pass, ONE decode group — generate, per
     request, exactly the ids the request generates alone (prefill tile pinned, as above), and the stop rule applies per sequence."""
@@ -145,7 +145,7 @@ def test_twenty_five_requests_one_decode_group_of_two_mfma_column_groups():
         L.load().fo1_gemm_set_gemv(1)
 
 
-def test_twenty_requests_one_prefill_pass_two_decode_groups():
+def test_twenty_requests_one_prefill_pass_two_decode_groups(ab_library):
     """More requests than a decode group carries (DECODE_MAX_GROUP = 16 here: round 2's one-column-group decode): generate_batch runs ONE
     packed prefill pass over all 20, then decodes them in balanced groups out of the same prefill cache (the later group's prompt K / V
     must survive the first group's decode).  Per request the ids equal the request decoded alone (prefill tile pinned, as above); the
@@ -176,7 +176,7 @@ def test_twenty_requests_one_prefill_pass_two_decode_groups():
 
 
 @pytest.mark.parametrize("impl,rows_per_lane", [(1, 0), (0, 0), (0, 1)])
-def test_gemv_batch_matches_reference(impl, rows_per_lane):
+def test_gemv_batch_matches_reference(impl, rows_per_lane, ab_library):
     """fo1_gemv_batch_bf16 (plain / SwiGLU epilogues, fused RMSNorm, K pieces for deep K) against torch fp32: the MFMA skinny GEMM
     (impl 1, default; also at M = 16) and the v_dot2 kernel (impl 0) with the rows-per-lane blocking by M (0) and one row per lane (1)."""
     from test_ops_gpu import gemm_ref, rb
@@ -218,7 +218,7 @@ def _run_qkv(ops, c):
 
 
 @pytest.mark.parametrize("M", [1, 5, 8, 16, 25, 32])
-def test_gemv_mfma_qkv_matches_reference_and_dot2(M):
+def test_gemv_mfma_qkv_matches_reference_and_dot2(M, ab_library):
     """Fused QKV epilogue of the MFMA kernel (RMSNorm -> QKV + bias -> bf16 -> mRoPE -> q rows / K row / V^T column at state.pos)
     against a torch restatement of the reference's rounding points (modeling_qwen2_5_vl.py:126-140, 643-685), and — for M <= 8 —
     against the v_dot2 kernel (same rounding points, different fp32 summation order)."""
@@ -257,7 +257,7 @@ def test_gemv_mfma_qkv_matches_reference_and_dot2(M):
             assert (a == b).float().mean().item() >= 0.97, f"{what}: MFMA and v_dot2 results should agree almost everywhere"
 
 
-def test_attention_decode_workgroup_kernel_matches_split_kernel_and_reference():
+def test_attention_decode_workgroup_kernel_matches_split_kernel_and_reference(ab_library):
     """Decode attention: the 64-key split-KV kernel + combine (impl 0, default) and the one-workgroup-per-(KV head, sequence) kernel
     (impl 1: tiles round-robin over 8 waves, merged in LDS; 1024-key splits + combine beyond 2048 rows) against fp32 softmax(q k^T / sqrt(d)) v,
     ragged batch, slot starts != 0."""
@@ -298,7 +298,7 @@ def test_attention_decode_workgroup_kernel_matches_split_kernel_and_reference():
         assert (out[1] - out[0]).abs().max().item() <= 2e-2
 
 
-def test_gemv_batch_rows_independent_of_batch():
+def test_gemv_batch_rows_independent_of_batch(ab_library):
     """Sequence m's outputs are the same numbers whether it runs alone or with 7 others, and whatever the rows-per-lane blocking:
     the per-(row, sequence) fp32 sum order is fixed by the shape alone (K segments, K split over waves, 8 lanes per row) — what
     lets a request decode identically alone and in a batch."""

@@ -39,7 +39,7 @@ def clone(o):
     return {k: (v.clone() if torch.is_tensor(v) else v) for k, v in o.items()}
 
 
-def test_ragged_batch_equals_sequential_bitwise_with_pinned_tile():
+def test_ragged_batch_equals_sequential_bitwise_with_pinned_tile(ab_library):
     from vlm_fo1_amd import lib as L
     eng = make_engine()
     reqs = [make_request(0, 500, 399, 7), make_request(1, 333, 711, 33), make_request(2, 64, 60, 1), make_request(3, 420, 420, 100)]
@@ -115,7 +115,7 @@ def test_graph_cache_is_bounded_and_one_off_shapes_run_eagerly():
     assert len(eng._graphs) == 2
 
 
-def test_prompts_sharing_one_image_run_the_towers_once_and_match_separate_requests():
+def test_prompts_sharing_one_image_run_the_towers_once_and_match_separate_requests(ab_library):
     """BASELINE configs[4]: 300 proposals = 3 prompts of 100 over ONE image (the reference caps region features at 100 per prompt,
     mm_utils.py:600, and would run the whole model three times).  Requests with the same `image_id` share the image: ViT / DaViT /
     SimpleFPN run once, every prompt's <image> block reads the same token rows, HFRE pools each prompt's boxes on the shared maps.

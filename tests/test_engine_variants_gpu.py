@@ -127,7 +127,7 @@ def run_variant(cfg, aux_mode, with_boxes, region_ln=None):
 
 @pytest.mark.parametrize("region,proj,with_boxes,aux_mode",
                          list(itertools.product(REGION, ("mlp2x_gelu", "linear"), (True, False), AUX)))
-def test_engine_variant(region, proj, with_boxes, aux_mode):
+def test_engine_variant(region, proj, with_boxes, aux_mode, product_library):
     cfg = make_cfg(mm_projector_type=proj, mm_projector_aux_type=proj, **REGION[region])
     eng, _ = run_variant(cfg, aux_mode, with_boxes)
     assert eng.capture == {"fpn": "last", "nofpn": "all", "auxonly": "none", "vtonly": "last"}[region]
@@ -139,7 +139,7 @@ def test_engine_variant(region, proj, with_boxes, aux_mode):
                                    dict(mm_apply_position_embedding=False)],
                          ids=lambda d: next(iter(d)) + "=" + str(next(iter(d.values()))))
 @pytest.mark.parametrize("region", ["fpn", "nofpn", "auxonly"])
-def test_engine_hfre_options(region, extra):
+def test_engine_hfre_options(region, extra, product_library):
     """Region LayerNorm (:365-372), feature-map / hybrid position embedding (:327-335), the aux-box embedding ('concat_aux_pos') and no
     embedding at all, through FO1Engine on the three region layouts."""
     if region == "auxonly" and "mm_region_feature_combination" in extra:
@@ -155,7 +155,7 @@ def test_engine_hfre_options(region, extra):
     run_variant(cfg, "dynamic", True, region_ln=ln)
 
 
-def test_batched_pass_of_a_variant_equals_one_image_passes():
+def test_batched_pass_of_a_variant_equals_one_image_passes(ab_library):
     """No-FPN and aux-only through `prefill_batch` with 3 same-geometry images (the stacked-maps HFRE launch of `_regions_batch`):
     every request's region / image tokens equal the one-image pass bit for bit."""
     from vlm_fo1_amd import lib as L

@@ -290,7 +290,7 @@ CASES = ["metric", "demo", "hires"]
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_index_bookkeeping_exact(world, name):
+def test_index_bookkeeping_exact(world, name, product_library):
     M = run_case(world, name)
     assert M["_meta"]["position_ids_equal"] and M["_meta"]["rope_delta_equal"]
     if name == "metric":
@@ -298,7 +298,7 @@ def test_index_bookkeeping_exact(world, name):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_towers_full_depth(world, name):
+def test_towers_full_depth(world, name, product_library):
     M = run_case(world, name)
     check(M, "vit_last_fullatt_map(block 31)", "vit_map")
     check(M, "vit_image_tokens(32 blocks+merger)", "vit_tokens")
@@ -310,7 +310,7 @@ def test_towers_full_depth(world, name):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_hfre_and_region_tokens(world, name):
+def test_hfre_and_region_tokens(world, name, product_library):
     M = run_case(world, name)
     # the north-star kernel: fp32 out on identical bf16 inputs -> the HFRE tolerance of tests/test_hfre_gpu.py
     m = M["hfre_features_isolated"]
@@ -323,7 +323,7 @@ def test_hfre_and_region_tokens(world, name):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_llm_36_layers(world, name):
+def test_llm_36_layers(world, name, product_library):
     M = run_case(world, name)
     check(M, "llm_hidden_layer36_isolated", "llm_hidden")
     check(M, "llm_last_row_final_norm_isolated", "llm_hidden")
@@ -331,7 +331,7 @@ def test_llm_36_layers(world, name):
 
 
 @pytest.mark.parametrize("name", CASES)
-def test_decoded_ids_vs_oracle(world, name):
+def test_decoded_ids_vs_oracle(world, name, product_library):
     """K teacher-forced greedy steps at 36 layers against the oracle's KV-cache decode (pinned to the reference's vendored model)."""
     M = run_case(world, name)
     D = M["decode_vs_oracle"]
@@ -347,7 +347,7 @@ def test_decoded_ids_vs_oracle(world, name):
 
 
 @pytest.mark.parametrize("name", ["metric", "demo"])
-def test_vs_reference_modules_at_full_depth(world, name):
+def test_vs_reference_modules_at_full_depth(world, name, product_library):
     """The REFERENCE's own modules (build-container golden): ids, region tokens, last hidden state; and, for `metric`, the engine
     against the reference's bf16 execution."""
     M = run_case(world, name)
@@ -374,7 +374,7 @@ def test_vs_reference_modules_at_full_depth(world, name):
         assert free[i] == R["fp32_ids"][i], f"{name}: free-running id {free[i]} != the reference's {R['fp32_ids'][i]} at step {i}"
 
 
-def test_logits_first_token(world):
+def test_logits_first_token(world, product_library):
     """Prefill logits: the first greedy token equals the oracle's whenever its margin qualifies (the whole-vocabulary maximum deviation
     is recorded in the metrics file; with 152k entries it is an extreme-value statistic that bounds nothing about the argmax)."""
     sig = noise()

@@ -60,7 +60,7 @@ def oracle_out(case):
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_hfre_vs_golden_and_oracle(name):
+def test_hfre_vs_golden_and_oracle(name, product_library):
     case = make_case(name)
     g = np.load(os.path.join(HERE, "golden", f"hfre_{name}.npz"))
     assert str(g["checksum"]) == checksum(case)
@@ -82,7 +82,7 @@ def test_hfre_in_kernel_vt_scaling_matches_explicit_vt_boxes():
 
 
 @pytest.mark.parametrize("budget", [16, 100, 4096])
-def test_hfre_slice_budget_invariance(budget):
+def test_hfre_slice_budget_invariance(budget, ab_library):
     """Row-slicing is a pure work partition: any pixel budget must give the same result
     (to fp32 re-association)."""
     from vlm_fo1_amd import lib as L
@@ -168,7 +168,7 @@ def test_hfre_linearity_at_max_size():
 
 
 @pytest.mark.parametrize("name", list(CASES))
-def test_hfre_worklist_equals_worst_case_grid(name):
+def test_hfre_worklist_equals_worst_case_grid(name, ab_library):
     """The work-list kernels do the same fp32 operations in the same order as the round-1 worst-case-grid kernels when both slice
     at the same pixel budget: bit-identical.  (The default budgets differ — the work-list form uses one budget for every box
     count — so the budget is pinned here.)"""
@@ -186,7 +186,7 @@ def test_hfre_worklist_equals_worst_case_grid(name):
 
 
 @pytest.mark.parametrize("unroll,chunk,grid", [(16, 512, 2048), (8, 512, 7), (8, 256, 64), (16, 128, 7)])
-def test_hfre_worklist_tuning_invariance(unroll, chunk, grid):
+def test_hfre_worklist_tuning_invariance(unroll, chunk, grid, ab_library):
     """unroll / grid size repartition the work only: bit-identical results (a grid of 7 makes every workgroup walk many items).
     The chunk width changes how many pixel slots a wave has, i.e. the order of the fp32 pixel sum: equal to re-association."""
     from vlm_fo1_amd import lib as L
@@ -224,7 +224,7 @@ def test_hfre_worklist_graph_replay_under_load():
         assert torch.equal(o, ref)
 
 
-def test_hfre_variants_vs_reference_golden_and_oracle():
+def test_hfre_variants_vs_reference_golden_and_oracle(product_library):
     """apply_region_layer_norm / concat_aux_pos / use_vt_region_feature_only against the reference HFREModule's outputs
     (tests/golden/hfre_variants.npz) and the oracle.  LayerNorm divides by the row's std (~0.05 here), which scales the pooling's
     fp32 re-association error by 1/std: rtol 1e-4, atol 2e-4 for that variant."""
@@ -252,7 +252,7 @@ def test_hfre_variants_vs_reference_golden_and_oracle():
     assert not torch.equal(torch.from_numpy(g["fm_pos"]), torch.from_numpy(g["hybrid"]))
 
 
-def test_hfre_vt_only_with_ln_or_fm_strategy_and_aux_only():
+def test_hfre_vt_only_with_ln_or_fm_strategy_and_aux_only(product_library):
     """ADVICE r2 + the aux-only route.  vt-only: the reference's branch (:293-317) ignores region LayerNorm and the embedding
     strategy — engine == the reference's own outputs for those configurations (== plain vt-only).  aux-only
     (use_vision_tower_region_feature=False): the reference raises UnboundLocalError (golden `aux_only_error`); the engine's extension
@@ -308,7 +308,7 @@ def test_hfre_bf16_second_destination_is_the_rne_cast_of_the_fp32_rows():
         assert torch.equal(o16, o32.to(torch.bfloat16))
 
 
-def test_hfre_batched_call_equals_per_image():
+def test_hfre_batched_call_equals_per_image(product_library):
     """batch > 1: the maps of B same-size images stacked, all boxes in one launch with box_image — every box's row is bit-identical
     to the one-image call (same slices, same order)."""
     from vlm_fo1_amd.hfre import HFREModule

@@ -60,7 +60,7 @@ GEMM_SHAPES = [
 
 @pytest.mark.parametrize("staging", [1, 2, 3, 4, 6])
 @pytest.mark.parametrize("tile", [1, 2, 3, 4])
-def test_gemm_variants(staging, tile):
+def test_gemm_variants(staging, tile, ab_library):
     from vlm_fo1_amd import lib as L, ops
     torch.manual_seed(staging * 10 + tile)
     try:
@@ -268,7 +268,7 @@ def test_attention_online_softmax_rescale_branch():
 
 
 @pytest.mark.parametrize("splits", [2, 3, 8])
-def test_gemm_splitk(splits):
+def test_gemm_splitk(splits, ab_library):
     """Split-K partials + fixed-order reduce must match the single-pass kernel to fp32 re-association."""
     from vlm_fo1_amd import lib as L, ops
     torch.manual_seed(11)
@@ -300,7 +300,7 @@ def test_gemm_splitk(splits):
         L.load().fo1_gemm_set_variant(0, 0)
 
 
-def test_gemm_fused_swiglu_epilogue():
+def test_gemm_fused_swiglu_epilogue(ab_library):
     """gate/up GEMM with SwiGLU in the epilogue == separate GEMM + swiglu kernel, bit for bit (same rounding points)."""
     from vlm_fo1_amd import lib as L, ops
     torch.manual_seed(12)
@@ -324,7 +324,7 @@ def test_gemm_fused_swiglu_epilogue():
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 4])
-def test_gemv_matches_tile_gemm(M):
+def test_gemv_matches_tile_gemm(M, ab_library):
     """The decode-step GEMV (M <= 4) must agree with the MFMA tile kernel on every epilogue form."""
     from vlm_fo1_amd import lib as L, ops
     torch.manual_seed(20 + M)
@@ -374,7 +374,7 @@ def test_attention_decode_split_kv():
     assert ops.argmax(big.cuda()).item() == 150000, "two-stage argmax: first index among ties"
 
 
-def test_gemv_fused_rmsnorm_and_ksplit():
+def test_gemv_fused_rmsnorm_and_ksplit(ab_library):
     """fo1_gemv_bf16 with the RMSNorm folded into its prologue == rmsnorm kernel + GEMV, bit for bit; deep-K shapes
     take the K-split-across-waves variant and must match the tile kernel."""
     from vlm_fo1_amd import lib as L, ops
@@ -465,7 +465,7 @@ P8_SHAPES = [
 
 
 @pytest.mark.parametrize("sched", [0, 1, 3])
-def test_gemm_p8_256x256(sched):
+def test_gemm_p8_256x256(sched, ab_library):
     """sched bit 0: 0 = four phases per K tile, 1 = two fat phases with the LDS-DMA issued between MFMAs (gemm_bt_p4_kernel);
     bit 1 set = fragment-shaped epilogue stores instead of the LDS-staged coalesced epilogue."""
     from vlm_fo1_amd import lib as L, ops
@@ -497,7 +497,7 @@ def test_gemm_p8_256x256(sched):
 
 
 @pytest.mark.parametrize("sched", [0, 1, 3])
-def test_gemm_p8_swiglu_and_one_hot(sched):
+def test_gemm_p8_swiglu_and_one_hot(sched, ab_library):
     """(a) the interleaved-SwiGLU epilogue on 32x32 fragments against the unfused reference; (b) an A = one-hot-rows GEMM whose exact
     answer is a row of W: catches any row/column or k-chunk mix-up exactly (no tolerance)."""
     from vlm_fo1_amd import lib as L, ops
@@ -531,7 +531,7 @@ def test_gemm_p8_swiglu_and_one_hot(sched):
         L.load().fo1_gemm_set_big_schedule(1)
 
 
-def test_gemm_persistent_tile_loop_equals_one_tile_per_workgroup():
+def test_gemm_persistent_tile_loop_equals_one_tile_per_workgroup(ab_library):
     """gemm_bt_p4p_kernel (256 persistent workgroups, the K loop running on across output tiles, epilogue through 4 KiB LDS strips)
     against gemm_bt_p4_kernel (one tile per workgroup): the per-tile arithmetic is the same instruction sequence, so the results
     must be BIT-IDENTICAL — for every epilogue, with ragged M / N edges, for more than 256 tiles (the persistent form's trigger) —
@@ -569,7 +569,7 @@ def test_gemm_persistent_tile_loop_equals_one_tile_per_workgroup():
         L.load().fo1_gemm_set_big_schedule(1)
 
 
-def test_gemm_coalesced_epilogue_equals_fragment_epilogue_bitwise():
+def test_gemm_coalesced_epilogue_equals_fragment_epilogue_bitwise(ab_library):
     """The LDS-staged epilogue of the 256x256 kernel (round 3: bias pieces and all 16 residual rows loaded up front from clamped addresses,
     pairwise rounding, straight write-out sweeps) against the fragment-shaped epilogue32 (each load next to its use, element-wise
     rounding): the same rounding points, so the outputs must be bit-identical — ragged M / N edges (clamped rows / columns), every
@@ -605,7 +605,7 @@ def test_gemm_coalesced_epilogue_equals_fragment_epilogue_bitwise():
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 4])
-def test_gemm_small_tile_vector_epilogue_equals_general_epilogue_bitwise(tile):
+def test_gemm_small_tile_vector_epilogue_equals_general_epilogue_bitwise(tile, ab_library):
     """epilogue_vec (16x16-fragment kernels: every bias / residual piece loaded up front, activation as a template parameter) is taken
     when bias, residual and C are 8-byte aligned; a bias or residual view that starts 2 bytes off the alignment goes through the general
     epilogue (loads next to their use).  Same operands, same rounding points: bit-identical outputs."""

@@ -1,5 +1,6 @@
-"""The PRODUCT library (vlm_fo1_amd/libfo1hip.so, include/fo1.h only) on the GPU: the test session itself runs on the test / bench
-build (FO1_AB=1, tests/conftest.py), so this file starts a fresh interpreter WITHOUT FO1_AB and runs the driver's own smoke check
+"""The PRODUCT library (vlm_fo1_amd/libfo1hip.so, include/fo1.h only) on the GPU in a process that never maps the test / bench build:
+the test session itself runs on the product library too (tests/conftest.py) but maps libfo1hip_ab.so beside it for the pinned
+tests, so this file starts a fresh interpreter WITHOUT FO1_AB and runs the driver's own smoke check
 (__graft_entry__.smoke(): HFRE against the oracle + one whole hot-path pass + greedy decode against the composed oracles) on the
 product library, and checks that none of include/fo1_ab.h's switches exist there."""
 import os

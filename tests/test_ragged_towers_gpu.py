@@ -6,7 +6,8 @@ tile pinned (the k-order of a row's dot products then does not depend on M) ever
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+# the whole module compares pinned-tile passes bit for bit: it runs on the test / bench build (conftest.ab_library_module)
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("ab_library_module")]
 
 SIZES = [(399, 500), (711, 333), (60, 64), (420, 420), (97, 233), (480, 640)]      # incl. sizes that pad the 12 x 12 windows and odd extents
 

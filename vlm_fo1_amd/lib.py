@@ -262,7 +262,8 @@ SIGNATURES_AB = {
     "fo1_attention_decode_set_impl": (c_int, [c_int]),
 }
 
-_lib = None
+_lib = None          # the ACTIVE library: every ops.* call goes through load()
+_handles = {}        # path -> CDLL (both builds may be mapped in one process: separate copies of the code and of its static state)
 
 
 class Fo1Error(RuntimeError):
@@ -270,14 +271,16 @@ class Fo1Error(RuntimeError):
 
 
 def ab_build() -> bool:
-    """True when this process uses the test / bench build (FO1_AB=1: libfo1hip_ab.so with include/fo1_ab.h's switches)."""
+    """True when the ACTIVE library is the test / bench build (libfo1hip_ab.so with include/fo1_ab.h's switches): a process started
+    with FO1_AB=1 (the profiling scripts), or code inside `use_ab()` (the tests that pin tiles / routing)."""
+    if _lib is not None:
+        return _lib is _handles.get(LIB_PATH_AB)
     return os.environ.get("FO1_AB", "0") not in ("", "0")
 
 
-def load() -> ctypes.CDLL:
-    global _lib
-    if _lib is None:
-        path = LIB_PATH_AB if ab_build() else LIB_PATH
+def _open(path: str, ab: bool) -> ctypes.CDLL:
+    lib = _handles.get(path)
+    if lib is None:
         if not os.path.exists(path):
             raise Fo1Error(
                 f"{path} not found — build it with `python -m vlm_fo1_amd.build` "
@@ -288,14 +291,45 @@ def load() -> ctypes.CDLL:
         import torch  # noqa: F401
         lib = ctypes.CDLL(path)
         table = dict(SIGNATURES)
-        if ab_build():
+        if ab:
             table.update(SIGNATURES_AB)
         for name, (res, args) in table.items():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = lib
+        _handles[path] = lib
+    return lib
+
+
+def load() -> ctypes.CDLL:
+    """The active library: the PRODUCT build unless the process was started with FO1_AB=1 or runs inside `use_ab()`."""
+    global _lib
+    if _lib is None:
+        ab = ab_build()
+        _lib = _open(LIB_PATH_AB if ab else LIB_PATH, ab)
     return _lib
+
+
+def active_path() -> str:
+    return load()._name
+
+
+class use_ab:
+    """Context manager: route every call through the test / bench build for the duration (tests that need include/fo1_ab.h's
+    determinism pins or A/B kernels).  Everything launched inside — including hipGraphs captured inside — runs the AB build's
+    kernels; everything outside runs the product library, which is what the parity tests therefore exercise by default.  Not
+    thread-safe by design: it is a test-session switch, not a per-request one."""
+
+    def __enter__(self):
+        global _lib
+        self._prev = load()
+        _lib = _open(LIB_PATH_AB, True)
+        return _lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
 
 
 def check(rc: int, what: str) -> None:
