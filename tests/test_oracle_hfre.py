@@ -231,3 +231,54 @@ def test_aux_only_reference_raises_and_extension_is_pinned_piecewise():
         b[:, [1, 3]] /= H0 / 0.25
         b[:, 2] -= b[:, 0]; b[:, 3] -= b[:, 1]; b[:, 0] += b[:, 2] / 2; b[:, 1] += b[:, 3] / 2
         torch.testing.assert_close((out - nopos), sine(b.unsqueeze(0), 3840 // 4)[0], rtol=1e-5, atol=1e-6)
+
+
+def test_roi_align_edge_vectors_hand_computed():
+    """torchvision 0.21.0 `roi_align(aligned=False, sampling_ratio=-1)` edge cases with HAND-derived answers (the
+    function is not vendored under /root/reference, so every HFRE golden runs through this restatement — an error here would be
+    invisible to golden and oracle comparisons alike).  Map f(y, x) = 10 y + x: bilinear interpolation reproduces it exactly between
+    pixel centres, so each expected value below is arithmetic on the published contract: roi = max(x2 - x1, 1); grid =
+    ceil(roi / P); sample = x1 + (p + (i + .5) / grid) * roi / P; a sample with y < -1 or y > H contributes 0; y is clamped to >= 0;
+    y_lo >= H - 1 collapses to the last row."""
+    def ramp(H, W):
+        yy, xx = torch.meshgrid(torch.arange(float(H)), torch.arange(float(W)), indexing="ij")
+        return (10 * yy + xx).reshape(1, 1, H, W)
+
+    f45 = ramp(4, 5)
+
+    def one(box, x=f45, P=1):
+        both = [O.roi_align_c(x, torch.tensor([box]), P, 1.0), O.roi_align_torch(x, torch.tensor([box]), P, 1.0)]
+        torch.testing.assert_close(both[0], both[1], rtol=0, atol=1e-5)     # the two restatements agree on the edge cases too
+        return both[0][0, 0]
+
+    # A. box exactly on the map's right / bottom border (x2 = W = 5, y2 = H = 4): roi 2 x 2, grid 2 x 2, samples y in {2.5, 3.5},
+    #    x in {3.5, 4.5}; y = 3.5 and x = 4.5 have lo >= size - 1 -> collapse to row 3 / column 4:
+    #    f(2.5, 3.5) = 28.5, f(2.5, 4) = 29, f(3, 3.5) = 33.5, f(3, 4) = 34 -> mean 31.25
+    assert abs(one([3., 2., 5., 4.]).item() - 31.25) < 1e-5
+    # B. samples with y in (-1, 0) are VALID and clamp to row 0: box y in [-0.8, 0.2] -> roi_h = 1, one sample at y = -0.3 -> row 0;
+    #    x samples 1.5, 2.5 -> mean 2.0.  y = -1.0 exactly is still valid (the test is y < -1); y = -2.1 is outside -> 0
+    assert abs(one([1., -0.8, 3., 0.2]).item() - 2.0) < 1e-5
+    assert abs(one([1., -1.5, 3., -0.5]).item() - 2.0) < 1e-5
+    assert one([1., -2.6, 3., -1.6]).item() == 0.0
+    # C. sub-pixel ROI (0.3 x 0.1 px): both extents are raised to 1 -> one sample at (y, x) = (1.3 + .5, 2.2 + .5) -> 18 + 2.7
+    assert abs(one([2.2, 1.3, 2.5, 1.4]).item() - 20.7) < 1e-5
+    # D. a sample exactly at y = H is valid (the test is y > H) and reads the last row; just beyond it contributes 0
+    assert abs(one([0., 3.5, 1., 4.5]).item() - 30.5) < 1e-5         # y = 4.0 -> row 3, x = 0.5
+    assert one([0., 3.6, 1., 4.6]).item() == 0.0                     # y = 4.1 > H
+    # E. grid = 1 with the real output size 7: a 7 x 7 px ROI has 1 px bins, ONE sample per bin at the bin centre
+    #    -> out[ph][pw] = 10 (ph + .5) + (pw + .5)
+    f88 = ramp(8, 8)
+    got = one([0., 0., 7., 7.], f88, P=7)
+    ph, pw = torch.meshgrid(torch.arange(7.), torch.arange(7.), indexing="ij")
+    torch.testing.assert_close(got, 10 * (ph + 0.5) + (pw + 0.5), rtol=0, atol=1e-5)
+    #    7.5 px -> grid = ceil(7.5 / 7) = 2: samples at bin quarter points; a linear map -> still the bin-centre value while every
+    #    sample stays below the last row / column (max sample = 7.5 * (6.75 / 7) = 7.232 > 7 = H - 1 collapses: excluded bins 6)
+    got = one([0., 0., 7.5, 7.5], f88, P=7)
+    bw = 7.5 / 7
+    torch.testing.assert_close(got[:6, :6], (10 * (ph + 0.5) * bw + (pw + 0.5) * bw)[:6, :6], rtol=0, atol=1e-4)
+    #    last bin: samples at 7.5 * 6.25 / 7 = 6.6964 (interpolates) and 7.2321 (lo = 7 >= H - 1 -> row 7 exactly)
+    last = (7.5 * 6.25 / 7 + 7.0) / 2
+    assert abs(got[6, 6].item() - (10 * last + last)) < 1e-4
+    # F. the fused mean of the bins (what HFRE consumes, hybrid_finegrained_region_encoder.py:255,270,361) = mean of the 49 values
+    m = O.roi_align_c(f88, torch.tensor([[0., 0., 7., 7.]]), 7, 1.0, mean=True)
+    assert abs(m.item() - (10 * 3.5 + 3.5)) < 1e-4
