@@ -149,14 +149,17 @@ def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode
     return out
 
 
-def end_to_end_run(pipe, cases, steps, K=64):
+def end_to_end_run(pipe, cases, steps, K=64, pool_slots=0):
     """END-TO-END images/s ("images completed / wall time", decode K reported) in ONE timed loop per pass of len(cases)
     images: resized uint8 images in pinned host memory -> upload -> device preprocessing of both towers (patchify / normalise,
     fo1_patchify_u8_bf16 / fo1_normalize_u8_bf16) -> ONE packed prefill pass -> K greedy tokens per image in the batched device decode
     loop (groups of BatchDecoder.MAX_BATCH sequences, stop rule on the device; random weights never emit a stop id, so every image
     decodes exactly K tokens) -> generated ids on the host.  One host thread per engine replica / HIP stream (generate_batch blocks
     on the ids), `len(pipe.engs)` passes in flight.  Outside: JPEG decode and the bicubic resize (PIL, host: the job of
-    sharded_eval.Prefetcher's threads) and tokenisation (cached prefix)."""
+    sharded_eval.Prefetcher's threads) and tokenisation (cached prefix).
+    pool_slots = 64 / 128: CONTINUOUS BATCHING (vlm_fo1_amd/serving.py) — the passes' sequences join ONE decode pool of that many
+    slots as soon as their prefill is done and the replica goes straight on with its next pass; sequences of up to pool_slots / 32
+    passes share every decode step (one weight stream per step for all of them).  0: every pass decodes its own group (round 3)."""
     import threading
     import numpy as np
     from vlm_fo1.model.image_processing import IMAGENET_MEAN, IMAGENET_STD, OPENAI_CLIP_MEAN, OPENAI_CLIP_STD, normalise_lut
@@ -174,13 +177,26 @@ def end_to_end_run(pipe, cases, steps, K=64):
     lut_a = normalise_lut(IMAGENET_MEAN, IMAGENET_STD).to(dev)
     n_tok = [0]
 
-    def one_pass(slot):
+    svc = None
+    if pool_slots:
+        svc = pipe.eng.enable_decode_pool(slots=pool_slots)
+        for e in pipe.engs:
+            e._pool_svc = svc
+
+    def requests_of_pass():
+        reqs = []
+        for c, (prim, aux) in zip(cases, hosts):
+            pu, au = prim.to(dev, non_blocking=True), aux.to(dev, non_blocking=True)
+            reqs.append(dict(ids=c["ids"], pix=ops.patchify_u8(pu, lut_p, 14, 2), grid=c["grid"], aux=ops.normalize_u8(au, lut_a), boxes=c["dev"]["boxes"]))
+        return reqs
+
+    def one_pass(slot, handles=None):
         eng = pipe.engs[slot]
         with torch.cuda.stream(pipe.streams[slot]):
-            reqs = []
-            for c, (prim, aux) in zip(cases, hosts):
-                pu, au = prim.to(dev, non_blocking=True), aux.to(dev, non_blocking=True)
-                reqs.append(dict(ids=c["ids"], pix=ops.patchify_u8(pu, lut_p, 14, 2), grid=c["grid"], aux=ops.normalize_u8(au, lut_a), boxes=c["dev"]["boxes"]))
+            reqs = requests_of_pass()
+            if handles is not None:          # pool: hand the sequences over, go on with the next pass; ids are collected at the end
+                handles.append(eng.submit_batch(reqs, max_new_tokens=K, use_graph=True))
+                return 0
             ids = eng.generate_batch(reqs, max_new_tokens=K, use_graph=True)
             assert all(len(t) == K for t in ids)
             return sum(len(t) for t in ids)
@@ -192,10 +208,19 @@ def end_to_end_run(pipe, cases, steps, K=64):
     torch.cuda.synchronize()
     per = max(1, steps // R)
 
+    lock = threading.Lock()
+
     def worker(slot):
         torch.cuda.set_device(dev)
+        hs = [] if svc is not None else None
+        n = 0
         for _ in range(per):
-            n = one_pass(slot)
+            n += one_pass(slot, hs)
+        for h in hs or ():
+            ids = h.result(timeout=600)
+            assert all(len(t) == K for t in ids)
+            n += sum(len(t) for t in ids)
+        with lock:
             n_tok[0] += n
 
     t0 = time.perf_counter()
@@ -208,9 +233,17 @@ def end_to_end_run(pipe, cases, steps, K=64):
     el = time.perf_counter() - t0
     n_img = per * R * len(cases)
     from vlm_fo1_amd.llm import BatchDecoder
+    extra = {}
+    if svc is not None:
+        st = dict(svc.stats)
+        extra = dict(decode="continuous batching: one decode pool per GPU, sequences of successive prefill passes share every step",
+                     pool_slots=pool_slots, pool_steps=st["steps"], pool_mean_live_sequences=round(st["occupancy_sum"] / max(1, st["steps"]), 1))
+        pipe.eng.disable_decode_pool()
+        for e in pipe.engs:
+            e._pool_svc = None
     return dict(images_per_sec=round(n_img / el, 2), new_tokens_per_image=K, generated_tokens_per_sec=round(n_tok[0] / el, 1),
                 ms_per_pass=round(el / (per * R) * 1e3 * R, 3), passes_timed=per * R, images_per_pass=len(cases), passes_in_flight=R,
-                decode_group=BatchDecoder.MAX_BATCH,
+                decode_group=pool_slots or BatchDecoder.MAX_BATCH, **extra,
                 includes=["uint8 upload (pinned)", "device preprocessing (both towers)", "packed prefill", f"{K}-token batched greedy decode", "ids to host"],
                 excludes=["JPEG decode + bicubic resize (host prefetch threads)", "tokenisation (cached prefix)"])
 
@@ -388,6 +421,8 @@ def main():
                     "128.3 / 1105 at 25; 8: 120.5)")
     ap.add_argument("--inflight", type=int, default=2, help="independent passes in flight per GPU (engine replicas on their own HIP "
                     "streams); 1 = strictly one pass at a time")
+    ap.add_argument("--pool-slots", type=int, default=128, choices=[0, 64, 128], help="end_to_end: slots of the decode pool the passes' sequences "
+                    "join (continuous batching, vlm_fo1_amd/serving.py); 0 = every pass decodes its own group of <= 32 (round 3's form)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true", help="skip the side measurements (one image / one pass at a time, decode loops, preprocessing): "
                     "only packed passes of the main workload run — what a rocprofv3 / PMC pass of this command should see, so that its "
@@ -609,7 +644,11 @@ def main():
         if auto_batch and B >= 16 and B < BatchDecoder.MAX_BATCH and not any("prompts" in c for c in cases):
             e2e_cases = cases + [build_workload(dev, n_boxes=args.boxes, img_hw=img_hw, seed=1234 + rank * 1000 + i, lift_cap=args.lift_cap)
                                  for i in range(B, BatchDecoder.MAX_BATCH)]
-        e2e = end_to_end_run(pipe, e2e_cases, steps=max(4, min(args.steps, 12)), K=64)
+        # continuous batching (round 4): one decode pool of 128 slots per GPU, fed by the replicas' prefill passes; more passes than the
+        # static form so that the pool's fill / drain phases at the two ends of the timed loop weigh little
+        e2e = end_to_end_run(pipe, e2e_cases, steps=max(8, min(args.steps, 24)), K=64, pool_slots=args.pool_slots)
+        if args.pool_slots:
+            e2e["static_groups"] = end_to_end_run(pipe, e2e_cases, steps=max(4, min(args.steps, 12)), K=64, pool_slots=0)
 
     # ---- dataset-shaped workload (ragged sizes / variable N): not part of `value` ----
     dset = None

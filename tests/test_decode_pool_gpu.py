@@ -1,0 +1,244 @@
+"""The decode pool (vlm_fo1_amd.llm.DecodePool over csrc/decode_pool.hip; scheduler vlm_fo1_amd.serving.PoolService): 64 / 128 sequence
+slots per weight stream, sequences of different prefill passes sharing every decode step (the loop it replaces is the
+reference's one-image-at-a-time `generate`, omchat_qwen2_5_vl.py:143-155 + HF greedy search, stop rule mm_utils.py:137-181).
+
+  * fo1_pool_gemm_bf16 (all epilogues, both pool sizes, split and unsplit shapes at the model's true widths) against torch fp32 with the
+    reference's rounding points;
+  * a sequence's ids do not depend on its slot or its neighbours, eager == graph replay, stream backend vs tile backend vs the
+    <= 32-sequence BatchDecoder agree wherever the oracle's margin qualifies, every id is checked against the CPU oracle's greedy decode;
+  * the stop rule and the budget, slots re-used by later joins while other sequences are mid-flight;
+  * the scheduler: passes submitted from several replica threads come back with exactly the ids a direct pool run gives.
+Runs on the PRODUCT library (no pins needed: pool kernels have no A/B switch)."""
+import threading
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+def rb(x):
+    return x.to(BF).float()
+
+
+def _close(got, ref, what, ulps=1.0, rare=2e-3):
+    """bf16 results of fp32 sums in a different order: within `ulps` bf16 ulps except a `rare` fraction at a rounding boundary (2 ulps)."""
+    got, ref = got.float().cpu(), ref.float().cpu()
+    scale = ref.abs().max().item()
+    tol = ulps * 2.0 ** -7 * ref.abs() + 2.0 ** -9 * scale * 0.02
+    bad = (got - ref).abs() > tol
+    assert bad.float().mean().item() <= rare, f"{what}: {int(bad.sum())}/{bad.numel()} beyond {ulps} bf16 ulps"
+    assert ((got - ref).abs() <= 2 * tol + 1e-6).all(), f"{what}: max |d| {float((got - ref).abs().max()):.4g} at scale {scale:.3g}"
+
+
+@pytest.mark.parametrize("P", [64, 128])
+def test_pool_gemm_matches_reference(P, product_library):
+    from vlm_fo1_amd import ops
+    g = torch.Generator().manual_seed(11 + P)
+
+    def rnd(*s, sc=1.0):
+        return (torch.randn(*s, generator=g) * sc).to(BF).cuda()
+
+    # ---- plain, K-split, residual + fused RMSNorm (o: 2048 x 2048; down: 2048 x 11008) and without the norm ----
+    for N, K in ((2048, 2048), (2048, 11008)):
+        x, w, res, nw = rnd(P, K), rnd(N, K, sc=0.03), rnd(P, N), (1 + 0.1 * torch.randn(N, generator=g)).to(BF).cuda()
+        y, h = ops.pool_gemm(x, w, residual=res, norm_weight=nw, norm_eps=1e-6)
+        y2 = ops.pool_gemm(x, w, residual=res)
+        torch.cuda.synchronize()
+        ref = rb(rb(x.float() @ w.float().t()) + res.float())
+        _close(y, ref, f"plain+res {N}x{K}")
+        assert torch.equal(y, y2), "the norm output must not change the hidden row"
+        yf = y.float()
+        href = rb(rb(yf * torch.rsqrt(yf.pow(2).mean(-1, keepdim=True) + 1e-6)) * nw.float())      # the norm of the row the kernel itself produced
+        _close(h, href, f"fused rmsnorm {N}x{K}")
+    # ---- plain, unsplit (lm_head-like: >= 128 row tiles), with and without bias ----
+    N, K = 128 * 131, 2048
+    x, w, b = rnd(P, K), rnd(N, K, sc=0.03), rnd(N, sc=0.2)
+    _close(ops.pool_gemm(x, w), rb(x.float() @ w.float().t()), "unsplit")
+    _close(ops.pool_gemm(x, w, b), rb(x.float() @ w.float().t() + b.float()), "unsplit + bias")
+    # ---- SwiGLU over 16-row interleaved gate / up rows at the true width ----
+    F_, K = 11008, 2048
+    gate, up, x = rnd(F_, K, sc=0.03), rnd(F_, K, sc=0.03), rnd(P, K)
+    wgu = ops.interleave_gate_up(gate, up).cuda()
+    got = ops.pool_gemm(x, wgu, mode=ops.PL_SWIGLU)
+    gt, u = rb(x.float() @ gate.float().t()), rb(x.float() @ up.float().t())
+    _close(got, rb(rb(torch.nn.functional.silu(gt)) * u), "swiglu", ulps=2.0, rare=5e-3)
+    # ---- fused QKV: bias -> bf16 -> mRoPE at the slot's table row -> q rows, K rows, V^T columns at the slot's cache row ----
+    H, KV, HD, K, rows = 16, 2, 128, 2048, 1024
+    x, w, b = rnd(P, K), rnd((H + 2 * KV) * HD, K, sc=0.05), rnd((H + 2 * KV) * HD, sc=0.1)
+    ang = torch.rand(rows, HD, generator=g) * 6.28
+    cos, sin = ang.cos().to(BF).cuda(), ang.sin().to(BF).cuda()
+    st = torch.zeros(P, 8, dtype=torch.int32)
+    st[:, 0] = torch.arange(P) * 7 + 3          # distinct cache rows
+    st[:, 1] = 900 - 5 * torch.arange(P)        # rope-table rows
+    kc = torch.zeros(KV, rows, HD, dtype=BF, device="cuda")
+    vt = torch.zeros(KV * HD, rows, dtype=BF, device="cuda")
+    q = ops.pool_gemm(x, w, b, mode=ops.PL_QKV, qkv=dict(n_q=H, n_kv=KV, cos=cos, sin=sin, state=st.cuda(), kcache=kc, vtcache=vt))
+    torch.cuda.synchronize()
+    qkv = rb(x.float() @ w.float().t() + b.float())
+    cf, sf = cos.float(), sin.float()
+    heads = qkv[:, :(H + KV) * HD].view(P, H + KV, HD)
+    tr = st[:, 1].long().cuda()
+    a, bb = heads[..., :64], heads[..., 64:]
+    c1, s1, c2, s2 = cf[tr, None, :64], sf[tr, None, :64], cf[tr, None, 64:], sf[tr, None, 64:]
+    rot = rb(torch.cat([rb(a * c1) + rb(-bb * s1), rb(bb * c2) + rb(a * s2)], -1))
+    scale = qkv.abs().max().item()
+    assert (q.float().view(P, H, HD) - rot[:, :H]).abs().max().item() <= 2e-2 * scale
+    pos = st[:, 0].long().cuda()
+    assert (kc.float()[:, pos].permute(1, 0, 2) - rot[:, H:]).abs().max().item() <= 2e-2 * scale
+    assert (vt.float()[:, pos].t().reshape(P, KV, HD) - qkv[:, (H + KV) * HD:].view(P, KV, HD)).abs().max().item() <= 2e-2 * scale
+    written = torch.zeros(rows, dtype=torch.bool, device="cuda")
+    written[pos] = True
+    assert kc[:, ~written].abs().max().item() == 0 and vt[:, ~written].abs().max().item() == 0, "cache rows of other positions touched"
+    # the stand-alone post-processing kernel (tile backend) gives the same rows from the same product
+    qkv16 = ops.gemm(x, w, b)
+    kc2, vt2 = torch.zeros_like(kc), torch.zeros_like(vt)
+    ops.pool_qkv_post(qkv16, H, KV, HD, cos, sin, st.cuda(), kc2, vt2)
+    torch.cuda.synchronize()
+    assert (qkv16[:, :H * HD].float() - q.float()).abs().max().item() <= 2e-2 * scale and (kc2.float() - kc.float()).abs().max().item() <= 2e-2 * scale
+
+
+def _engine(seed=31):
+    from vlm_fo1_amd.llm import LLMConfig
+    from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights
+    from vlm_fo1_amd.vit import ViTConfig
+    cfg = FO1Config(vit=ViTConfig(depth=2, fullatt_block_indexes=(1,)), llm=LLMConfig(num_layers=2, vocab_size=4096, max_seq=1024))
+    weights = random_weights(cfg, "cuda", seed=seed)
+    weights["llm"]["embed_tokens.weight"] = (weights["llm"]["embed_tokens.weight"].float() * 4).bfloat16()   # real top-1 margins
+    return cfg, weights, FO1Engine(cfg, weights, "cuda")
+
+
+def _requests(n):
+    from test_batched_prefill_gpu import make_request
+    return [make_request(300 + i, 96 + 28 * (i % 4), 120 + 28 * (i % 3), 1 + (5 * i) % 9) for i in range(n)]
+
+
+def _pool_run(pool, eng, hp, first, sel, K, stop=(), graph=True):
+    """Join the selected sequences of the last prefill, decode to the end -> ids in `sel` order."""
+    tags = [("t", b) for b in sel]
+    pool.join(eng.llm.kcache, eng.llm.vtcache, [hp["seqs"][b] for b in sel], [hp["delta"][b] for b in sel],
+              torch.stack([first[b] for b in sel]), K, stop, tags=tags)
+    got = {tag[1]: ids for _, tag, ids in pool.drain(use_graph=graph, poll=3)}
+    assert not pool.live and len(pool.free) == pool.P
+    return [got[b] for b in sel]
+
+
+@pytest.mark.parametrize("slots", [64, 128])
+def test_pool_ids_independent_of_slot_neighbours_backend_and_oracle(slots, product_library):
+    from test_batched_decode_gpu import oracle_logits
+    from vlm_fo1_amd.llm import DecodePool
+    cfg, weights, eng = _engine()
+    reqs = _requests(9)
+    K = 10
+    ref32 = eng.generate_batch(reqs, max_new_tokens=K, use_graph=True)          # the <= 32-sequence BatchDecoder
+    eng.prefill_batch(reqs, use_graph=False)
+    hp, first = eng._last_batch, eng._last_next_tokens.clone()
+    pool = DecodePool(eng.llm, slots=slots)
+    allg = _pool_run(pool, eng, hp, first, list(range(9)), K, graph=True)
+    assert [len(t) for t in allg] == [K] * 9
+    assert _pool_run(pool, eng, hp, first, list(range(9)), K, graph=False) == allg, "eager and graph-replayed pool steps differ"
+    # alone (slot 0) and in another slot order: the same ids, bit for bit
+    for b in (0, 4, 8):
+        assert _pool_run(pool, eng, hp, first, [b], K) == [allg[b]], f"sequence {b} decodes differently alone than among 8 others"
+    perm = [5, 2, 8, 0, 7, 1, 3, 6, 4]
+    assert _pool_run(pool, eng, hp, first, perm, K) == [allg[b] for b in perm], "ids depend on the slot"
+    # the tile backend (prefill GEMMs at M = P) and the BatchDecoder: other fp32 sum orders -> equal wherever the oracle's margin qualifies
+    tile = _pool_run(DecodePool(eng.llm, slots=slots, backend="tile"), eng, hp, first, list(range(9)), K)
+    tol = 0.05
+    n_q = 0
+    for b, r in enumerate(reqs[:4]):
+        ref_ids, ref_logits = oracle_logits(cfg, weights, r, allg[b])
+        for i, t in enumerate(allg[b]):
+            top2 = ref_logits[i].topk(2).values
+            assert float(ref_logits[i].max() - ref_logits[i][t]) <= 2 * tol, f"sequence {b} step {i}: pool token {t} is not (near-)optimal for the oracle"
+            if float(top2[0] - top2[1]) > 2 * tol:
+                n_q += 1
+                assert t == ref_ids[i], f"sequence {b} step {i}: pool id {t} != oracle greedy id {ref_ids[i]}"
+    assert n_q >= 4 * K // 2
+    for other, name in ((tile, "tile backend"), (ref32, "BatchDecoder")):
+        same = sum(int(a == b) for a, b in zip(other, allg))
+        assert same >= 7, f"{name}: only {same}/9 sequences decode to the pool's ids (near-ties may differ, not most sequences)"
+
+
+def test_pool_stop_rule_budget_and_slot_reuse_mid_flight(product_library):
+    from vlm_fo1_amd.llm import DecodePool
+    cfg, weights, eng = _engine()
+    reqs = _requests(6)
+    K = 12
+    eng.prefill_batch(reqs, use_graph=False)
+    hp, first = eng._last_batch, eng._last_next_tokens.clone()
+    pool = DecodePool(eng.llm, slots=64)
+    full = _pool_run(pool, eng, hp, first, list(range(6)), K)
+    stop = full[1][4]
+    out = _pool_run(pool, eng, hp, first, list(range(6)), K, stop=[stop])
+    for b, ids in enumerate(out):
+        cut = full[b].index(stop) + 1 if stop in full[b] else K
+        assert ids == full[b][:cut], f"sequence {b}: stop rule gave {ids}, expected {full[b][:cut]}"
+    assert len(out[1]) <= 5
+    assert _pool_run(pool, eng, hp, first, list(range(6)), 3) == [t[:3] for t in full], "budget"
+    # slots re-used while others are mid-flight: 0..2 join, 4 steps, 3..5 join, 2 steps, ...; every sequence still gets its own ids
+    pool.join(eng.llm.kcache, eng.llm.vtcache, hp["seqs"][:3], hp["delta"][:3], first[:3], 6, (), tags=[0, 1, 2])
+    for _ in range(4):
+        pool.step()
+    pool.join(eng.llm.kcache, eng.llm.vtcache, hp["seqs"][3:], hp["delta"][3:], first[3:], K, (), tags=[3, 4, 5])
+    got = {}
+    for _ in range(3):
+        pool.step()
+    for _, tag, ids in pool.harvest(pool.snapshot()):
+        got[tag] = ids
+    assert sorted(got) == [0, 1, 2] and sorted(pool.free)[:3] == [0, 1, 2], "the 6-token sequences have finished and freed slots 0-2"
+    pool.join(eng.llm.kcache, eng.llm.vtcache, hp["seqs"][:2], hp["delta"][:2], first[:2], K, (), tags=[10, 11])    # into the freed slots
+    for _, tag, ids in pool.drain(poll=2):
+        got[tag] = ids
+    assert [got[b] for b in range(3)] == [t[:6] for t in full[:3]]
+    assert [got[b] for b in (3, 4, 5)] == full[3:] and [got[10], got[11]] == full[:2]
+
+
+def test_pool_service_from_replica_threads_equals_direct_pool_runs(product_library):
+    """PoolService: three passes of three requests prefilled by two engine replicas on their own threads / streams, sequences of all
+    passes decoding together; every request's ids == a direct DecodePool run of its pass (same prefill bits, slot-independent decode)."""
+    from vlm_fo1_amd.llm import DecodePool
+    cfg, weights, eng = _engine()
+    reqs = _requests(9)
+    passes = [reqs[0:3], reqs[3:6], reqs[6:9]]
+    K = 9
+    want = []
+    direct = DecodePool(eng.llm, slots=64)
+    for grp in passes:
+        eng.prefill_batch(grp, use_graph=True)
+        eng.prefill_batch(grp, use_graph=True)      # second sighting: the captured graph (what the service run replays)
+        want.append(_pool_run(direct, eng, eng._last_batch, eng._last_next_tokens.clone(), [0, 1, 2], K))
+    svc = eng.enable_decode_pool(slots=64, steps_per_round=2)
+    try:
+        engines = [eng, eng.replica()]
+        assert engines[1]._pool_svc is svc
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        got, errs = {}, []
+
+        def worker(w):
+            try:
+                torch.cuda.set_device(0)
+                with torch.cuda.stream(streams[w]):
+                    hs = []
+                    for rep in range(3):             # every pass three times: slots are freed and re-used while other passes decode
+                        for p in range(w, 3, 2):
+                            hs.append((rep, p, engines[w].submit_batch(passes[p], K, (), use_graph=True)))
+                    for rep, p, h in hs:
+                        got[(rep, p)] = h.result(timeout=300)
+            except BaseException as e:
+                errs.append(e)
+
+        th = [threading.Thread(target=worker, args=(w,)) for w in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for (rep, p), ids in got.items():
+            assert ids == want[p], f"pass {p} (round {rep}) came back with other ids than the direct pool run"
+        assert len(got) == 9 and svc.stats["finished"] == 27 and svc.stats["joined"] == 27
+        # the blocking form: generate_batch routes through the pool too
+        assert eng.generate_batch(passes[1], max_new_tokens=K, use_graph=True) == want[1]
+    finally:
+        eng.disable_decode_pool()

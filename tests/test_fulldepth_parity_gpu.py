@@ -346,10 +346,11 @@ def test_decoded_ids_vs_oracle(world, name, product_library):
     assert D["engine_forced_ids"][:n_ok] == D["free_batch"][0][:n_ok], "teacher-forcing the engine on its own ids must reproduce them"
 
 
-@pytest.mark.parametrize("name", ["metric", "demo"])
+@pytest.mark.parametrize("name", ["metric", "demo", "hires"])
 def test_vs_reference_modules_at_full_depth(world, name, product_library):
-    """The REFERENCE's own modules (build-container golden): ids, region tokens, last hidden state; and, for `metric`, the engine
-    against the reference's bf16 execution."""
+    """The REFERENCE's own modules (build-container golden): ids, region tokens, last hidden state; and, for `metric` and `demo`, the
+    engine against the reference's bf16 execution.  `hires` (configs[4]'s geometry): prompt 0 of the three prompts over the one image,
+    fp32 reference (its towers run once for all three in the engine, once per prompt in the reference: same numbers)."""
     M = run_case(world, name)
     R = M.get("vs_reference_golden")
     assert R is not None, f"tests/golden/fulldepth_ref_{name}.npz is missing"

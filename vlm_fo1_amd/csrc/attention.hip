@@ -76,6 +76,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
         int kv0 = 0, kv_len;
         if (p.seq_state) {
             const int* st = p.seq_state + blockIdx.z * 8;
+            if (st[3]) return;          // finished (or empty pool slot): nobody reads this sequence's output
             kv0 = st[2];
             kv_len = st[0] + 1;
             Qb += (long long)blockIdx.z * p.q_seq_stride;
@@ -340,6 +341,7 @@ __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __
     int n_keys;
     if (seq_state) {   // sequence blockIdx.y of a decode batch
         const int* st = seq_state + blockIdx.y * 8;
+        if (st[3]) return;              // finished: the split kernel skipped it, the row keeps its previous (finite) contents
         n_keys = st[0] + 1 - st[2];
         part += (long long)blockIdx.y * part_seq_stride;
         out += (long long)blockIdx.y * out_seq_stride;

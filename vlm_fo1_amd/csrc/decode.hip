@@ -450,7 +450,9 @@ __global__ __launch_bounds__(256) void argmax_rows_partial_kernel(const uint16_t
 // step's embedding-gather plan entry.  A finished sequence keeps its state frozen: later steps recompute harmlessly in place.
 __device__ __forceinline__ void accept_token(int tok, int* st, int* plan, int* ids_out, int ids_ld, const int* stop_ids, int n_stop, int* done) {
     plan[0] = 0;
-    plan[1] = tok;
+    // a finished (or never-started) slot keeps stepping with whatever its rows hold: publish a valid embedding row for it — its
+    // logits may be stale or non-finite (the pool skips its attention), and an argmax over NaN rows leaves the index at INT_MAX
+    plan[1] = st[3] ? 0 : tok;
     if (st[3]) return;
     const int n = st[4];
     ids_out[n] = tok;
@@ -591,7 +593,7 @@ int fo1_decode_argmax_accept(const void* logits, long long ld_logits, int n_voca
                              int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids, int n_stop, int32_t* done, void* scratch,
                              void* stream) {
     using namespace fo1;
-    FO1_CHECK_ARG(state && plan && ids_out && done && B >= 1 && B <= 64 && ids_ld > 0 && n_stop >= 0 && (n_stop == 0 || stop_ids), "decode_accept: bad arguments");
+    FO1_CHECK_ARG(state && plan && ids_out && done && B >= 1 && B <= 256 && ids_ld > 0 && n_stop >= 0 && (n_stop == 0 || stop_ids), "decode_accept: bad arguments");
     FO1_CHECK_ARG((logits != nullptr) != (first_tokens != nullptr), "decode_accept: exactly one of logits / first_tokens");
     hipStream_t st = (hipStream_t)stream;
     float* pv = (float*)scratch;

@@ -179,12 +179,15 @@ __global__ __launch_bounds__(256) void qkv_post_vit_kernel(uint16_t* __restrict_
 
 // Decode step, one token: mRoPE on the q and k heads of the fused qkv row (in place), append the rotated K heads to
 // the K cache and the V heads (transposed) to the V^T cache, all at the device-side position.  One workgroup.
+// blockIdx.x = sequence of a decode pool (fo1_pool_qkv_post_bf16): row blockIdx.x of qkv [P, ld], state row blockIdx.x.
 template <int HD>
-__global__ __launch_bounds__(256) void decode_qkv_post_kernel(uint16_t* __restrict__ qkv, int n_q, int n_kv, const uint16_t* __restrict__ cosb,
+__global__ __launch_bounds__(256) void decode_qkv_post_kernel(uint16_t* __restrict__ qkv, long long ld, int n_q, int n_kv, const uint16_t* __restrict__ cosb,
                                                               const uint16_t* __restrict__ sinb, const int* __restrict__ st,
                                                               uint16_t* __restrict__ kcache, long long kc_head_stride,
                                                               uint16_t* __restrict__ vtcache, long long vt_row_stride) {
     constexpr int HC = HD / 16;
+    qkv += (long long)blockIdx.x * ld;
+    st += blockIdx.x * 8;
     const int pos = st[0], row = st[1];
     const int tid = threadIdx.x;
     const int n_rope = (n_q + n_kv) * HC;
@@ -311,7 +314,21 @@ int fo1_decode_qkv_post_bf16(void* qkv_row, int n_q_heads, int n_kv_heads, int h
     FO1_CHECK_ARG(qkv_row && cos_table && sin_table && state && kcache && vtcache, "decode_qkv_post: NULL operand");
     FO1_CHECK_ARG(head_dim == 128, "decode_qkv_post: head_dim %d not built (128)", head_dim);
     FO1_LAUNCH("decode_qkv_post", (double)(n_q_heads + 2 * n_kv_heads) * head_dim * 4.0, decode_qkv_post_kernel<128>, dim3(1), dim3(256), 0,
-               (hipStream_t)stream, (uint16_t*)qkv_row, n_q_heads, n_kv_heads, (const uint16_t*)cos_table, (const uint16_t*)sin_table,
+               (hipStream_t)stream, (uint16_t*)qkv_row, 0LL, n_q_heads, n_kv_heads, (const uint16_t*)cos_table, (const uint16_t*)sin_table,
+               (const int*)state, (uint16_t*)kcache, kcache_head_stride, (uint16_t*)vtcache, vt_row_stride);
+    return FO1_OK;
+}
+
+// The same for the P sequences of a decode pool (decode_pool.hip): row b of qkv [P, ld] is rotated with table row state[b][1], its
+// K heads / V heads land in the caches at row / column state[b][0] (the sequence's own slot).
+int fo1_pool_qkv_post_bf16(void* qkv, long long ld, int P, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
+                           const void* sin_table, const int32_t* state, void* kcache, long long kcache_head_stride, void* vtcache,
+                           long long vt_row_stride, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(qkv && cos_table && sin_table && state && kcache && vtcache && P >= 1, "pool_qkv_post: NULL operand");
+    FO1_CHECK_ARG(head_dim == 128 && ld % 8 == 0 && ((uintptr_t)qkv & 15) == 0, "pool_qkv_post: head_dim %d / ld %lld not built (128, ld %% 8)", head_dim, ld);
+    FO1_LAUNCH("pool_qkv_post", (double)P * (n_q_heads + 2 * n_kv_heads) * head_dim * 4.0, decode_qkv_post_kernel<128>, dim3(P), dim3(256), 0,
+               (hipStream_t)stream, (uint16_t*)qkv, ld, n_q_heads, n_kv_heads, (const uint16_t*)cos_table, (const uint16_t*)sin_table,
                (const int*)state, (uint16_t*)kcache, kcache_head_stride, (uint16_t*)vtcache, vt_row_stride);
     return FO1_OK;
 }

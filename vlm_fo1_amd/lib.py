@@ -201,6 +201,13 @@ SIGNATURES = {
     "fo1_decode_advance": (c_int, [c_void_p, c_void_p]),
     "fo1_decode_qkv_post_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p,
                                          c_longlong, c_void_p]),
+    "fo1_pool_qkv_post_bf16": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p,
+                                       c_longlong, c_void_p]),
+    "fo1_pool_gemm_splits": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
+    "fo1_pool_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fo1_pool_gemm_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int,
+                                   c_int, c_void_p, c_float, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong,
+                                   c_void_p, c_longlong, c_void_p, c_size_t, c_void_p]),
     "fo1_gemv_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_float, c_void_p]),
     "fo1_rope_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),

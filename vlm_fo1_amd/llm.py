@@ -650,3 +650,234 @@ def run_decoders(decs: Sequence["BatchDecoder"], streams: Sequence, max_new_toke
         with torch.cuda.stream(streams[k]):
             out.append(d.results())
     return out
+
+
+class DecodePool:
+    """Continuous batching for the greedy decode loop: a pool of 64 / 128 sequence SLOTS that advance together,
+    one token per step, through ONE stream of the weights (csrc/decode_pool.hip).  Sequences JOIN whenever a packed prefill pass has
+    finished (their K / V^T rows are relocated out of that pass's cache into free slots, first tokens accepted on the device) and LEAVE
+    individually when their stop rule fires (device-side, as in BatchDecoder); the step itself always computes all P rows — empty and
+    finished slots are rows nobody reads, their attention is skipped on the device.  Every position-dependent quantity lives in device
+    memory, so one captured hipGraph per (kv-length bucket) serves every step whatever the occupancy.
+
+    Reference semantics per sequence: HF greedy search over the 1-token fast path of omchat_qwen2_5_vl.py:143-155; positions = cache
+    position + rope delta (modeling_qwen2_5_vl.py:1848-1860); stop AFTER the EOS / keyword id has been appended, or at max_new_tokens
+    (mm_utils.py:137-181, 640-654).  A sequence's ids do not depend on its slot or on its neighbours (per-row fp32 sum order is a
+    function of the shape only; tests/test_decode_pool_gpu.py).
+
+    backend 'stream': fo1_pool_gemm_bf16 (weights straight from HBM into MFMA fragments, x through LDS, K-split few-row products with
+    the residual + RMSNorm in the reduce launch) — 9 launches per layer;  'tile': the prefill's tile GEMMs at M = P (A/B baseline)."""
+    IDS_CAP = 4096
+    MAX_STOP = 16
+    KV_BUCKET = 256          # the attention launch geometry follows the longest live context rounded up to this many keys
+
+    def __init__(self, llm: QwenLLM, slots: int = 128, slot_rows: int = 1024, backend: str = "stream"):
+        if slots not in (64, 128):
+            raise ValueError("a decode pool has 64 or 128 slots")
+        if backend not in ("stream", "tile"):
+            raise ValueError(f"unknown pool backend {backend!r}")
+        self.llm, self.P, self.backend = llm, slots, backend
+        dev = llm.dev
+        P = slots
+        with torch.inference_mode(False):
+            st = torch.zeros(P, 8, dtype=torch.int32)
+            st[:, 3] = 1                               # every slot starts empty = "finished": its attention is skipped, its ids ignored
+            self.state = st.to(dev)
+            self.plan = torch.zeros(P, 2, dtype=torch.int32, device=dev)
+            self.ids = torch.zeros(P, self.IDS_CAP, dtype=torch.int32, device=dev)
+            self.done = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.stop = torch.zeros(self.MAX_STOP, dtype=torch.int32, device=dev)
+            self.reloc = torch.zeros(P, 4, dtype=torch.int32, device=dev)
+        self.stop_ids: Optional[tuple] = None
+        self.n_stop = 0
+        self.slot_rows = 0
+        self.dk = self.dvt = None
+        self.free = list(range(P))                     # host view of the slots
+        self.bound = [0] * P                           # upper bound of the keys a live slot attends in the coming step
+        self.budget = [0] * P
+        self.live: Dict[int, object] = {}              # slot -> caller's tag
+        self.steps_run = 0
+        self._graphs: Dict[tuple, tuple] = {}
+        self._keep: list = []
+        self._ws_owner = ops.new_owner(self)
+        self._ensure(slot_rows)
+
+    # ---- memory ----------------------------------------------------------------------------------------------------------------
+    def _ensure(self, slot_rows: int):
+        """Slots of at least slot_rows cache rows each (power of two).  Re-allocation is only possible while the pool is empty."""
+        rows = 1024
+        while rows < slot_rows:
+            rows *= 2
+        if rows > self.slot_rows:
+            if self.live:
+                raise RuntimeError("DecodePool: slots can only grow while the pool is empty")
+            c = self.llm.cfg
+            bf = torch.bfloat16
+            with torch.inference_mode(False):
+                self.dk = self.dvt = None
+                self.dk = torch.zeros(c.num_layers, c.num_kv_heads, self.P * rows, c.head_dim, dtype=bf, device=self.llm.dev)
+                self.dvt = torch.zeros(c.num_layers, c.num_kv_heads * c.head_dim, self.P * rows, dtype=bf, device=self.llm.dev)
+            self.slot_rows = rows
+            self._graphs = {}
+        if self.llm.rope_cos.shape[0] < self.slot_rows:
+            self.llm.grow_rope(self.slot_rows)
+            self._graphs = {}
+
+    def fits(self, seqs, max_new_tokens: int) -> bool:
+        return max(L for _, L, *_ in seqs) + max(1, int(max_new_tokens)) + 1 <= self.slot_rows
+
+    # ---- join ------------------------------------------------------------------------------------------------------------------
+    def join(self, kcache: torch.Tensor, vtcache: torch.Tensor, seqs, deltas, first_tokens: torch.Tensor, max_new_tokens: int,
+             stop_ids: Sequence[int] = (), tags: Optional[Sequence] = None) -> List[int]:
+        """seqs [(cache row offset, L, ...)] of a packed prefill that ran on (kcache, vtcache); first_tokens device int32 [B].  Enqueues,
+        on the CURRENT stream (the pool's), the relocation of every sequence into a free slot and the on-device accept of its first
+        token.  Returns the slots.  Raises if there is no room (callers check `len(pool.free)` / `fits()` first)."""
+        B = len(seqs)
+        stop_ids = tuple(sorted(set(int(t) for t in stop_ids)))
+        if len(stop_ids) > self.MAX_STOP:
+            raise ValueError(f"DecodePool evaluates at most {self.MAX_STOP} stop ids on the device (got {len(stop_ids)})")
+        if self.stop_ids is None or (not self.live and stop_ids != self.stop_ids):
+            self.stop_ids, self.n_stop = stop_ids, len(stop_ids)
+            sv = torch.tensor(list(stop_ids) + [0] * (self.MAX_STOP - len(stop_ids)), dtype=torch.int32)
+            self.stop.copy_(sv, non_blocking=True)
+            self._keep.append(sv)
+        elif stop_ids != self.stop_ids:
+            raise ValueError("DecodePool: every sequence of a pool shares one stop-id set (drain the pool to change it)")
+        max_new = max(1, int(max_new_tokens))
+        if max_new > self.IDS_CAP:
+            raise ValueError(f"DecodePool keeps at most {self.IDS_CAP} generated ids per sequence (max_new_tokens={max_new})")
+        if B > len(self.free):
+            raise RuntimeError(f"DecodePool: {B} sequences, {len(self.free)} free slots")
+        if not self.fits(seqs, max_new):
+            self._ensure(max(L for _, L, *_ in seqs) + max_new + 1)      # raises unless the pool is empty
+        self.free.sort()
+        slots = [self.free.pop(0) for _ in range(B)]
+        R = self.slot_rows
+        reloc = torch.tensor([[o, s * R, L, 0] for s, (o, L, *_) in zip(slots, seqs)], dtype=torch.int32)
+        state = torch.tensor([[s * R + L, L + d, s * R, 0, 0, max_new, 0, 0] for s, (_, L, *_), d in zip(slots, seqs, deltas)], dtype=torch.int32)
+        first = first_tokens.to(torch.int32).contiguous()
+        self._keep += [reloc, state]
+        if len(self._keep) > 64:
+            del self._keep[:len(self._keep) - 64]
+        # contiguous runs of slots: one relocate + one accept launch per run
+        i = 0
+        with ops.workspace_scope(self._ws_owner):
+            while i < B:
+                j = i
+                while j + 1 < B and slots[j + 1] == slots[j] + 1:
+                    j += 1
+                a, n = slots[i], j - i + 1
+                self.reloc[a:a + n].copy_(reloc[i:j + 1], non_blocking=True)
+                self.state[a:a + n].copy_(state[i:j + 1], non_blocking=True)
+                ops.kv_relocate(kcache, self.dk, vtcache, self.dvt, self.reloc[a:a + n], max(L for _, L, *_ in seqs[i:j + 1]))
+                ops.decode_argmax_accept(None, first[i:j + 1], self.state[a:a + n], self.plan[a:a + n], self.ids[a:a + n],
+                                         self.stop[:self.n_stop], self.done)
+                i = j + 1
+        for k, s in enumerate(slots):
+            self.live[s] = tags[k] if tags is not None else None
+            self.bound[s] = seqs[k][1] + 1
+            self.budget[s] = max_new
+        return slots
+
+    # ---- step ------------------------------------------------------------------------------------------------------------------
+    def kv_bucket(self) -> int:
+        need = max((self.bound[s] for s in self.live), default=1)
+        return min(self.slot_rows, -(-need // self.KV_BUCKET) * self.KV_BUCKET)
+
+    def _step_device(self, bucket: int):
+        llm, P = self.llm, self.P
+        c = llm.cfg
+        H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
+        scale = 1.0 / math.sqrt(HD)
+        st = self.state
+        n = len(llm.layers)
+        with ops.workspace_scope(self._ws_owner):
+            x = ops.gather_rows(self.plan, c.hidden_size, llm.embed)
+            if self.backend == "stream":
+                h = ops.rmsnorm(x, llm.layers[0]["ln1"], c.rms_norm_eps)
+                for li, w in enumerate(llm.layers):
+                    q = ops.pool_gemm(h, w["wqkv"], w["bqkv"], mode=ops.PL_QKV,
+                                      qkv=dict(n_q=H, n_kv=KV, cos=llm.rope_cos, sin=llm.rope_sin, state=st, kcache=self.dk[li], vtcache=self.dvt[li]))
+                    att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
+                    x, h = ops.pool_gemm(att, w["wo"], residual=x, norm_weight=w["ln2"], norm_eps=c.rms_norm_eps)
+                    a = ops.pool_gemm(h, w["wgu"], mode=ops.PL_SWIGLU)
+                    nw = llm.layers[li + 1]["ln1"] if li + 1 < n else llm.norm
+                    x, h = ops.pool_gemm(a, w["wdown"], residual=x, norm_weight=nw, norm_eps=c.rms_norm_eps)
+                logits = ops.pool_gemm(h, llm.lm_head)
+            else:
+                for li, w in enumerate(llm.layers):
+                    qkv = ops.gemm(ops.rmsnorm(x, w["ln1"], c.rms_norm_eps), w["wqkv"], w["bqkv"])
+                    ops.pool_qkv_post(qkv, H, KV, HD, llm.rope_cos, llm.rope_sin, st, self.dk[li], self.dvt[li])
+                    att = ops.attention_decode_batch(qkv[:, :H * HD], self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
+                    x = ops.gemm(att, w["wo"], residual=x)
+                    a = ops.gemm(ops.rmsnorm(x, w["ln2"], c.rms_norm_eps), w["wgu"], act=ops.ACT_SWIGLU16)
+                    x = ops.gemm(a, w["wdown"], residual=x)
+                logits = ops.gemm(ops.rmsnorm(x, llm.norm, c.rms_norm_eps), llm.lm_head)
+            ops.decode_argmax_accept(logits, None, st, self.plan, self.ids, self.stop[:self.n_stop], self.done)
+            return logits
+
+    def step(self, use_graph: bool = True):
+        """One token for every live sequence (all P rows are computed)."""
+        bucket = self.kv_bucket()
+        if not use_graph:
+            out = self._step_device(bucket)
+        else:
+            key = (self.slot_rows, self.n_stop, bucket, self.backend, self.llm.rope_epoch, self.llm.rope_cos.data_ptr())
+            ent = self._graphs.get(key)
+            if ent is None:
+                with ops.graph_lock.capture(), torch.inference_mode(False):
+                    snap = (self.state.clone(), self.plan.clone(), self.ids.clone(), self.done.clone())
+                    s = torch.cuda.Stream()
+                    s.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s):
+                        self._step_device(bucket)      # warm-up (allocates scratch); rolled back below.  The K / V^T it appends land on
+                    torch.cuda.current_stream().wait_stream(s)   # the rows the captured step rewrites with the same values
+                    torch.cuda.synchronize()
+                    for dst, src in zip((self.state, self.plan, self.ids, self.done), snap):
+                        dst.copy_(src)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        logits = self._step_device(bucket)
+                    ent = (g, logits)
+                    self._graphs[key] = ent
+            with ops.graph_lock.replay():
+                ent[0].replay()
+            out = ent[1]
+        self.steps_run += 1
+        for s in self.live:
+            self.bound[s] += 1
+        return out
+
+    # ---- leave -----------------------------------------------------------------------------------------------------------------
+    def snapshot(self, pinned: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+        """Asynchronous copy of (state, generated ids) to pinned host memory on the current stream -> (state, ids, event)."""
+        cols = min(self.IDS_CAP, max((self.budget[s] for s in self.live), default=1))
+        if pinned is None or pinned[1].shape[1] < cols:
+            pinned = (torch.empty(self.P, 8, dtype=torch.int32).pin_memory(), torch.empty(self.P, max(cols, 64), dtype=torch.int32).pin_memory())
+        pinned[0].copy_(self.state, non_blocking=True)
+        pinned[1][:, :cols].copy_(self.ids[:, :cols], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return pinned[0], pinned[1], ev, dict(self.live)
+
+    def harvest(self, snap) -> List[Tuple[int, object, List[int]]]:
+        """Sequences that had finished when `snap` was taken (and have not been collected yet): [(slot, tag, ids)]; their slots are free again."""
+        st, ids, ev, live_then = snap
+        ev.synchronize()
+        out = []
+        for s, tag in live_then.items():
+            if s in self.live and self.live[s] is tag and int(st[s, 3]) == 1:
+                n = int(st[s, 4])
+                out.append((s, tag, ids[s, :n].tolist()))
+                del self.live[s]
+                self.free.append(s)
+        return out
+
+    def drain(self, use_graph: bool = True, poll: int = 8) -> List[Tuple[int, object, List[int]]]:
+        """Step until every live sequence has stopped (synchronous convenience for tests / one-shot callers)."""
+        out = []
+        while self.live:
+            for _ in range(poll):
+                self.step(use_graph)
+            out += self.harvest(self.snapshot())
+        return out

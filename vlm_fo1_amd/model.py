@@ -129,6 +129,7 @@ class FO1Engine:
         r._seen = {}
         r._dec = None
         r._dec_extra = []
+        r._pool_svc = getattr(self, "_pool_svc", None)      # ONE decode pool per GPU: replicas feed the same service
         r._dec_stream0 = None
         r.stage_hook = None
         return r
@@ -485,6 +486,13 @@ class FO1Engine:
         (stop token included, like HF generate)."""
         from .llm import BatchDecoder, run_decoders
         out: List[List[int]] = []
+        if getattr(self, "_pool_svc", None) is not None:
+            # decode pool: every pass's sequences join the shared pool; this call's later passes prefill while its earlier ones decode
+            handles = [self.submit_batch(requests[i:i + self.PREFILL_MAX], max_new_tokens, stop_ids, use_graph)
+                       for i in range(0, len(requests), self.PREFILL_MAX)]
+            for h in handles:
+                out += h.result()
+            return out
         for i in range(0, len(requests), self.PREFILL_MAX):
             grp = requests[i:i + self.PREFILL_MAX]
             self.prefill_batch(grp, use_graph=use_graph)          # ONE packed pass for the whole group (its GEMMs see every image's rows)
@@ -521,6 +529,37 @@ class FO1Engine:
             for j in range(k):
                 cur.wait_stream(streams[j])                       # the next pass must not overwrite the prefill cache under a relocate
         return out
+
+    # ---- continuous batching: one decode pool per GPU, shared by every replica (vlm_fo1_amd/serving.py) -------------------------------
+    def enable_decode_pool(self, slots: int = 128, slot_rows: int = 1024, backend: str = "stream", steps_per_round: int = 4):
+        """From now on generate_batch() / submit_batch() of this engine AND of the replicas made from it afterwards hand their sequences
+        to ONE DecodePool (llm.DecodePool): the sequences of successive prefill passes — of any replica — share every decode step
+        (64 / 128 per weight stream instead of <= 32 per pass).  Returns the service."""
+        from .serving import PoolService
+        if getattr(self, "_pool_svc", None) is None:
+            self._pool_svc = PoolService(self.llm, slots=slots, slot_rows=slot_rows, backend=backend, steps_per_round=steps_per_round)
+        return self._pool_svc
+
+    def disable_decode_pool(self) -> None:
+        svc = getattr(self, "_pool_svc", None)
+        if svc is not None:
+            svc.close()
+        self._pool_svc = None
+
+    def submit_batch(self, requests: Sequence[dict], max_new_tokens: int = 512, stop_ids: Sequence[int] = (), use_graph: bool = True):
+        """One packed prefill pass (<= PREFILL_MAX requests), then its sequences join the decode pool.  Returns a serving.PoolHandle as
+        soon as the pool has taken the K / V^T rows over: the caller may start its next pass while these sequences decode;
+        handle.result() -> the new ids per request (stop token included, like HF generate)."""
+        svc = getattr(self, "_pool_svc", None)
+        if svc is None:
+            raise RuntimeError("submit_batch needs enable_decode_pool()")
+        if len(requests) > self.PREFILL_MAX:
+            raise ValueError(f"submit_batch takes one prefill pass (<= {self.PREFILL_MAX} requests)")
+        self.prefill_batch(requests, use_graph=use_graph)
+        hp = self._last_batch
+        h = svc.submit(self.llm, hp["seqs"], hp["delta"], self._last_next_tokens[:len(requests)], max_new_tokens, stop_ids)
+        h.wait_relocated()
+        return h
 
     def _decoders(self, k: int):
         """k decode groups' decoders (the first is the engine's own) and the side streams they run on."""
