@@ -719,6 +719,13 @@ class DecodePool:
                 self.dvt = torch.zeros(c.num_layers, c.num_kv_heads * c.head_dim, self.P * rows, dtype=bf, device=self.llm.dev)
             self.slot_rows = rows
             self._graphs = {}
+            # an empty / finished slot still runs every step: its (ignored) K / V^T rows must land inside ITS OWN slot — row 0 of the
+            # cache is slot 0's first prompt token
+            st = torch.zeros(self.P, 8, dtype=torch.int32)
+            st[:, 0] = st[:, 2] = torch.arange(self.P, dtype=torch.int32) * rows
+            st[:, 3] = 1
+            with torch.inference_mode(False):
+                self.state.copy_(st)
         if self.llm.rope_cos.shape[0] < self.slot_rows:
             self.llm.grow_rope(self.slot_rows)
             self._graphs = {}
@@ -850,19 +857,20 @@ class DecodePool:
 
     # ---- leave -----------------------------------------------------------------------------------------------------------------
     def snapshot(self, pinned: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
-        """Asynchronous copy of (state, generated ids) to pinned host memory on the current stream -> (state, ids, event)."""
+        """Asynchronous copy of (state, generated ids) to pinned host memory on the current stream -> (state, ids, event, live slots)."""
         cols = min(self.IDS_CAP, max((self.budget[s] for s in self.live), default=1))
-        if pinned is None or pinned[1].shape[1] < cols:
-            pinned = (torch.empty(self.P, 8, dtype=torch.int32).pin_memory(), torch.empty(self.P, max(cols, 64), dtype=torch.int32).pin_memory())
+        if pinned is None or pinned[1].numel() < self.P * cols:
+            pinned = (torch.empty(self.P, 8, dtype=torch.int32).pin_memory(), torch.empty(self.P * max(cols, 64), dtype=torch.int32).pin_memory())
         pinned[0].copy_(self.state, non_blocking=True)
-        pinned[1][:, :cols].copy_(self.ids[:, :cols], non_blocking=True)
+        host_ids = pinned[1][:self.P * cols].view(self.P, cols)            # contiguous on both sides: a plain asynchronous memcpy
+        host_ids.copy_(self.ids[:, :cols].contiguous(), non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return pinned[0], pinned[1], ev, dict(self.live)
+        return pinned[0], host_ids, ev, dict(self.live), pinned
 
     def harvest(self, snap) -> List[Tuple[int, object, List[int]]]:
         """Sequences that had finished when `snap` was taken (and have not been collected yet): [(slot, tag, ids)]; their slots are free again."""
-        st, ids, ev, live_then = snap
+        st, ids, ev, live_then = snap[:4]
         ev.synchronize()
         out = []
         for s, tag in live_then.items():

@@ -168,7 +168,7 @@ class PoolService:
                         self.stats["steps"] += self.steps_per_round
                         self.stats["occupancy_sum"] += self.steps_per_round * len(pool.live)
                         snap = pool.snapshot(pinned[rnd & 1])
-                        pinned[rnd & 1] = (snap[0], snap[1])
+                        pinned[rnd & 1] = snap[4]
                         rnd += 1
                     if prev is not None:
                         for _, (h, k), ids in pool.harvest(prev):
