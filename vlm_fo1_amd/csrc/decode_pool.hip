@@ -26,6 +26,7 @@
 // the same ids in any slot and next to any other sequences.  Against the <= 32-sequence kernels the fp32 order differs (ids may differ
 // at near-ties, like any two bf16 executions).
 #include "decode_common.h"
+#include "ab.h"
 
 namespace fo1 {
 
@@ -55,7 +56,7 @@ __device__ __forceinline__ uint4 pl_load_nt16(const uint16_t* p) {
 }
 __device__ __forceinline__ float pl_round(float v) { return bf16_to_f32(f32_to_bf16(v)); }
 
-template <int NSG, int MODE>
+template <int NSG, int MODE, bool NT>
 __global__ __launch_bounds__(256, 2) void pool_gemm_kernel(const PoolGemmParams p) {
     constexpr int P = NSG * 32;
     constexpr int XBUF = P * PL_XP;
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void pool_gemm_kernel(const PoolGemmParams 
         const int k = kt < kt1 ? kt : kt1 - 1;                          // clamped: never a load under a branch
         const uint16_t* s = wrow + (long long)k * 128;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) w[j] = pl_load_nt16(s + j * 8);
+        for (int j = 0; j < 8; ++j) w[j] = NT ? pl_load_nt16(s + j * 8) : *reinterpret_cast<const uint4*>(s + j * 8);
     };
     auto loadX = [&](int kt, pl_u32x4 (&x)[XL]) __attribute__((always_inline)) {
         const int k = kt < kt1 ? kt : kt1 - 1;
@@ -350,21 +351,39 @@ __global__ __launch_bounds__(256) void pool_reduce_res_norm_kernel(const PoolRes
     }
 }
 
-template <int NSG, int MODE>
-static int launch_pool_gemm(const PoolGemmParams& p, const char* name, hipStream_t st) {
+FO1_AB_VAR g_pool_variant = 0;      // bit 0: W loads non-temporal (bypass L1) instead of L1-allocating (A/B: fo1_pool_gemm_set_variant)
+
+template <int NSG, int MODE, bool NT>
+static int launch_pool_gemm_nt(const PoolGemmParams& p, const char* name, hipStream_t st) {
     constexpr int smem = 2 * NSG * 32 * PL_XP;
     static bool attr = false;
     if (!attr) {
-        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)pool_gemm_kernel<NSG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)pool_gemm_kernel<NSG, MODE, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr = true;
     }
-    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (pool_gemm_kernel<NSG, MODE>), dim3(p.n_tiles * p.splits), dim3(256), smem, st, p);
+    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (pool_gemm_kernel<NSG, MODE, NT>), dim3(p.n_tiles * p.splits), dim3(256), smem, st, p);
     return FO1_OK;
+}
+
+template <int NSG, int MODE>
+static int launch_pool_gemm(const PoolGemmParams& p, const char* name, hipStream_t st) {
+#ifdef FO1_ENABLE_AB
+    if (g_pool_variant & 1) return launch_pool_gemm_nt<NSG, MODE, true>(p, name, st);
+#endif
+    return launch_pool_gemm_nt<NSG, MODE, false>(p, name, st);
 }
 
 }  // namespace fo1
 
 extern "C" {
+
+#ifdef FO1_ENABLE_AB      // include/fo1_ab.h: test / bench build only
+int fo1_pool_gemm_set_variant(int bits) {
+    if (bits < 0 || bits > 1) return fo1::set_err(FO1_ERR_ARG, "pool_gemm_set_variant: %d", bits);
+    fo1::g_pool_variant = bits;
+    return FO1_OK;
+}
+#endif
 
 // Split policy of the pool GEMM (shape only): N / 128 row tiles; few-row projections are split over K until about one workgroup
 // per CU streams, at least two 128-element K tiles per workgroup.  Returns the number of splits; *kper = K tiles per split.

@@ -267,6 +267,7 @@ SIGNATURES_AB = {
     "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
     "fo1_gemv_batch_set_impl": (c_int, [c_int]),
     "fo1_attention_decode_set_impl": (c_int, [c_int]),
+    "fo1_pool_gemm_set_variant": (c_int, [c_int]),
 }
 
 _lib = None          # the ACTIVE library: every ops.* call goes through load()
