@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FO1_ABI_VERSION 4   /* 4: decode pool (fo1_pool_*): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 4   /* 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -365,22 +365,6 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
                                     long long out_seq_stride, const int32_t* state, int batch, int max_kv_len,
                                     int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace,
                                     size_t workspace_bytes, void* stream);
-/* ---- decode pool: the step of 64 / 128 sequence slots (continuous batching; vlm_fo1_amd/csrc/decode_pool.hip) ----
- * Past 32 sequences the step's projections are skinny GEMMs C[P, N] = x[P, K] W[N, K]^T with the weights still streamed from HBM once
- * per step.  P = 64 or 128 rows are always computed (empty / finished slots are rows nobody reads); per (slot, feature) the fp32 sum
- * order depends on the shape only, so a sequence decodes to the same ids in any slot and next to any neighbours.
- *   mode 0: bias -> bf16 -> + residual -> bf16; with norm_weight the same launch pair also writes Qwen2RMSNorm(C) * norm_weight to norm_out
- *           (modeling_qwen2_5_vl.py:126-140: the next projection's input);  mode 1: interleaved SwiGLU (C has N / 2 columns);
- *   mode 2: fused QKV: bias -> bf16 -> mRoPE (table row state[b][1]) -> q rows to C [P, n_q * 128], K rows / V^T columns appended to the
- *           caches at row / column state[b][0].
- * Few-row shapes are split over K (fo1_pool_gemm_splits: shape only) through fp32 partials in the caller's workspace, summed in fixed order. */
-int fo1_pool_gemm_splits(int N, int K, int* k_tiles_per_split);
-size_t fo1_pool_gemm_workspace_bytes(int P, int N, int K);
-int fo1_pool_gemm_bf16(const void* x, long long ldx, const void* W, long long ldw, const void* bias, const void* residual, long long ldr,
-                       void* C, long long ldc, int P, int N, int K, int mode, const void* norm_weight, float norm_eps, void* norm_out,
-                       long long ld_norm, int n_q_heads, int n_kv_heads, const void* cos_table, const void* sin_table,
-                       const int32_t* state, void* kcache, long long kcache_head_stride, void* vtcache, long long vt_row_stride,
-                       void* workspace, size_t workspace_bytes, void* stream);
 int fo1_decode_argmax_accept(const void* logits, long long ld_logits, int n_vocab, int B, const int32_t* first_tokens,
                              int32_t* state, int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids,
                              int n_stop, int32_t* done, void* scratch, void* stream);

@@ -56,9 +56,8 @@ int fo1_gemv_batch_set_impl(int impl);
 /* 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence), partials merged in LDS (measured
  * slower on MI355X: one CU cannot pull a head's K/V^T fast enough). */
 int fo1_attention_decode_set_impl(int impl);
-/* Decode-pool GEMM (fo1_pool_gemm_bf16): bit 0 = weight loads non-temporal (they bypass the CU's L1: every 16-byte fragment piece is its
- * own L2 request — measured 8x the L2 traffic, 81 us for the 90 MB gate/up matrix); 0 (default) = L1-allocating loads. */
-int fo1_pool_gemm_set_variant(int bits);
+/* Keys per split of the batched decode attention for more than 32 sequences (decode pool): 64 / 128 / 256 (default) / 512. */
+int fo1_attention_decode_set_pool_chunk(int keys);
 
 #ifdef __cplusplus
 }

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
-"""Decode-pool step timing on the GPU: ms per step and per-kernel times of llm.DecodePool at 64 / 128 slots, stream backend
-(csrc/decode_pool.hip) against the tile backend (prefill GEMMs at M = P) and the <= 32-sequence BatchDecoder, at the metric configuration's
-context (651-token prompts).  Prints one JSON object; `python scripts/pool_bench.py [--layers N] [--slots 64 128] [--backends stream tile]`."""
+"""Decode-pool step timing on the GPU: ms per step and per-kernel times of llm.DecodePool at 64 / 128 slots, against the <= 32-sequence BatchDecoder, at the metric configuration's
+context (651-token prompts).  Prints one JSON object; `python scripts/pool_bench.py [--slots 64 128] [--chunks 64 128 256]`."""
 import argparse
 import json
 import os
@@ -17,7 +16,7 @@ import torch  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--slots", type=int, nargs="+", default=[64, 128])
-    ap.add_argument("--backends", nargs="+", default=["stream", "tile"])
+    ap.add_argument("--chunks", type=int, nargs="+", default=[0], help="keys per split of the pool's decode attention to A/B (needs FO1_AB=1; 0 = default)")
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--fill", type=float, default=1.0, help="fraction of the slots that hold live sequences")
     args = ap.parse_args()
@@ -54,8 +53,10 @@ def main():
     out["batch_decoder_32"] = dict(ms_per_step=round(t32 * 1e3, 3), tokens_per_sec=round(32 / t32, 1), hbm_frac=round(wbytes / t32 / 8e12, 4))
 
     for P in args.slots:
-        for be in args.backends:
-            pool = DecodePool(eng.llm, slots=P, backend=be)
+        for be in args.chunks:
+            if be:
+                L.check(L.load().fo1_attention_decode_set_pool_chunk(be), "chunk")
+            pool = DecodePool(eng.llm, slots=P)
             n_live = max(1, int(round(P * args.fill)))
             left = n_live
             while left > 0:
@@ -87,7 +88,7 @@ def main():
                 a[1] += r["total_ms"]
             row["kernels_ms_per_step"] = {k: [v[0], round(v[1], 4)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
             row["sum_kernel_ms"] = round(sum(v[1] for v in agg.values()), 3)
-            out[f"pool_{P}_{be}"] = row
+            out[f"pool_{P}" + (f"_chunk{be}" if be else "")] = row
             del pool
             torch.cuda.empty_cache()
     print(json.dumps(out))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Decode-pool projections at P = 64 / 128 rows, cold weights (GPU box only): fo1_pool_gemm_bf16 (both weight-load policies) against
-every tile / staging / split-K form of fo1_gemm_bf16 at M = P.  usage: pool_gemm_bench.py <out.json>"""
+"""Decode-pool projections at P = 64 / 128 rows, cold weights (GPU box only): every tile / staging / split-K form of fo1_gemm_bf16 at M = P
+(round 4's first run also timed a dedicated weights-to-VGPR kernel: profiles/r04_pool_gemm_stream_kernel_vs_tile_kernels.json).  usage: pool_gemm_bench.py <out.json>"""
 import os
 os.environ.setdefault("FO1_AB", "1")
 import json
@@ -38,22 +38,6 @@ for P in (128, 64):
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / iters * 1e3
-
-        def pool(w):
-            if kind == "qkv":
-                return ops.pool_gemm(x, w, None, mode=ops.PL_QKV, qkv=dict(n_q=16, n_kv=2, cos=cos, sin=cos, state=st, kcache=kc, vtcache=vt))
-            if kind == "swiglu":
-                return ops.pool_gemm(x, w, mode=ops.PL_SWIGLU)
-            if kind == "res":
-                return ops.pool_gemm(x, w, residual=r, norm_weight=nw, norm_eps=1e-6)
-            return ops.pool_gemm(x, w)
-
-        for nt in (0, 1):
-            lib.fo1_pool_gemm_set_variant(nt)
-            us = timeit(pool)
-            res.append(dict(P=P, shape=name, impl=f"pool nt={nt}", us=round(us, 2), tbps=round(wb / us / 1e6, 3)))
-            print(res[-1], flush=True)
-        lib.fo1_pool_gemm_set_variant(0)
 
         def tile(w):
             if kind == "swiglu":

@@ -729,8 +729,23 @@ int fo1_attention_decode_set_impl(int impl) {
 
 // Batched decode attention: B sequences, one new token each (q rows [B, n_q_heads*head_dim]); sequence b attends the cache rows
 // [state[b][2], state[b][0]] (its slot start .. the row just written).  grid = (max chunks per slot, KV heads, B).
+// Keys per split of the batched decode attention — a function of the batch size only (a sequence's partial sums must not depend on
+// who shares the launch): up to 32 sequences (BatchDecoder) 64 keys per workgroup, so that even one sequence spreads over 2 x 11
+// CUs; a decode pool (64 / 128 slots) has sequences to spare and gives every workgroup 4 tiles of 64 keys — the tile loop's register
+// prefetch then overlaps the next tile's loads with the MFMAs of the current one (one-tile workgroups are a load -> compute chain).
+namespace fo1 {
+FO1_AB_VAR g_attn_pool_chunk = 256;      // A/B: fo1_attention_decode_set_pool_chunk
+static inline int decode_batch_chunk(int batch) { return batch > 32 ? g_attn_pool_chunk : 64; }
+}  // namespace fo1
+#ifdef FO1_ENABLE_AB
+int fo1_attention_decode_set_pool_chunk(int keys) {
+    if (keys != 64 && keys != 128 && keys != 256 && keys != 512) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_pool_chunk: %d", keys);
+    fo1::g_attn_pool_chunk = keys;
+    return FO1_OK;
+}
+#endif
 size_t fo1_attention_decode_batch_workspace_bytes(int max_kv_len, int n_kv_heads, int head_dim, int batch) {
-    return (size_t)batch * fo1_attention_decode_workspace_bytes(max_kv_len, n_kv_heads, head_dim);
+    return (size_t)batch * fo1::cdiv(max_kv_len, fo1::decode_batch_chunk(batch)) * n_kv_heads * 16 * (head_dim + 2) * sizeof(float);
 }
 
 int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const void* kcache, long long k_tok_stride, long long k_head_stride,
@@ -763,9 +778,10 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     p.VT = (const uint16_t*)vtcache; p.vt_row = vt_row_stride;
     p.O = nullptr; p.o_tok = 0; p.o_head = 0;
     p.items = nullptr;
-    p.n_items = cdiv(max_kv_len, 64); p.Hq = n_kv_heads; p.group = 1;
+    const int chunk = decode_batch_chunk(batch);
+    p.n_items = cdiv(max_kv_len, chunk); p.Hq = n_kv_heads; p.group = 1;
     p.scale = scale; p.causal = 0; p.q_row_base = nullptr;
-    p.part = (float*)workspace; p.dyn_kv_len = nullptr; p.kv_chunk = 64;
+    p.part = (float*)workspace; p.dyn_kv_len = nullptr; p.kv_chunk = chunk;
     p.q_range_end = group;
     p.seq_state = (const int*)state; p.q_seq_stride = q_seq_stride;
     p.part_seq_stride = (long long)p.n_items * n_kv_heads * 16 * (head_dim + 2);
@@ -774,7 +790,7 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     FO1_LAUNCH("attn_decode_split", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
                dim3(p.n_items, n_kv_heads, batch), dim3(256), 0, st, p);
     FO1_LAUNCH("attn_decode_combine", (double)batch * n_q_heads * head_dim * 8.0, attn_decode_combine_kernel<128>, dim3(n_q_heads, batch), dim3(128), 0,
-               st, (const float*)workspace, (const int*)nullptr, 64, n_kv_heads, group, (uint16_t*)out, (const int*)state, p.part_seq_stride,
+               st, (const float*)workspace, (const int*)nullptr, chunk, n_kv_heads, group, (uint16_t*)out, (const int*)state, p.part_seq_stride,
                out_seq_stride);
     return FO1_OK;
 }

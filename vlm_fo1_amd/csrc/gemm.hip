@@ -1961,6 +1961,10 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         // best small tile; merger 260 tiles = 51 % of two rounds loses, 659 vs 894)
         // K >= 256 (nk >= 4): with the two-phase schedule and the coalesced epilogue even four K tiles per output tile beat the 64 x 128
         // tile (DaViT stage 0 at 25 images: ~400 vs 211 TFLOP/s); the first threshold (nk >= 8) dated from the four-phase kernel
+        // 64 < M <= 128 with >= 128 row tiles (the decode pool's gate/up and lm_head products, llm.DecodePool): a weight stream whose
+        // activations come back from L2 once per tile column — 128 x 128 tiles halve that re-read against 64 x 64 (cold weights,
+        // profiles/r04_pool_gemm_stream_kernel_vs_tile_kernels.json: gate/up 34.4 -> 30.5 us, lm_head 163 -> 152 us at M = 128)
+        if (glds && p.M > 64 && p.M <= 128 && t128 >= 128 && nk >= 16) tile = 1;
         const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256) * batch;
         if (glds && nk >= 4 && p.M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) tile = 5;
     }
@@ -1994,7 +1998,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
     }
     if (tile == 5) tile = 1;
     if (g_gemm_variant >= 3) p.stages = g_gemm_variant;
-    else if (g_gemm_variant == 0 && glds && ((tile == 3 && t64 <= 768) || (tile == 2 && tiles * p.splits < 512))) p.stages = 3;
+    else if (g_gemm_variant == 0 && glds && ((tile == 3 && t64 <= 768) || (tile == 2 && tiles * p.splits < 512) || (tile == 1 && auto_tile && p.M <= 128))) p.stages = 3;
     else p.stages = 2;
     if (tile == 4 && glds && p.stages == 2) return launch_gemm_wide<128, 256>(p, batch, st);
     if (tile == 4) tile = 1;

@@ -203,11 +203,6 @@ SIGNATURES = {
                                          c_longlong, c_void_p]),
     "fo1_pool_qkv_post_bf16": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p,
                                        c_longlong, c_void_p]),
-    "fo1_pool_gemm_splits": (c_int, [c_int, c_int, ctypes.POINTER(c_int)]),
-    "fo1_pool_gemm_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "fo1_pool_gemm_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_void_p, c_void_p, c_longlong, c_void_p, c_longlong, c_int, c_int, c_int,
-                                   c_int, c_void_p, c_float, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong,
-                                   c_void_p, c_longlong, c_void_p, c_size_t, c_void_p]),
     "fo1_gemv_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                               c_void_p, c_float, c_void_p]),
     "fo1_rope_vit_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
@@ -267,7 +262,7 @@ SIGNATURES_AB = {
     "fo1_gemv_batch_set_rows_per_lane": (c_int, [c_int]),
     "fo1_gemv_batch_set_impl": (c_int, [c_int]),
     "fo1_attention_decode_set_impl": (c_int, [c_int]),
-    "fo1_pool_gemm_set_variant": (c_int, [c_int]),
+    "fo1_attention_decode_set_pool_chunk": (c_int, [c_int]),
 }
 
 _lib = None          # the ACTIVE library: every ops.* call goes through load()

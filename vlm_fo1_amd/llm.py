@@ -654,29 +654,31 @@ def run_decoders(decs: Sequence["BatchDecoder"], streams: Sequence, max_new_toke
 
 class DecodePool:
     """Continuous batching for the greedy decode loop: a pool of 64 / 128 sequence SLOTS that advance together,
-    one token per step, through ONE stream of the weights (csrc/decode_pool.hip).  Sequences JOIN whenever a packed prefill pass has
-    finished (their K / V^T rows are relocated out of that pass's cache into free slots, first tokens accepted on the device) and LEAVE
-    individually when their stop rule fires (device-side, as in BatchDecoder); the step itself always computes all P rows — empty and
-    finished slots are rows nobody reads, their attention is skipped on the device.  Every position-dependent quantity lives in device
-    memory, so one captured hipGraph per (kv-length bucket) serves every step whatever the occupancy.
+    one token per step, through ONE stream of the weights.  Sequences JOIN whenever a packed prefill pass has finished (their K / V^T
+    rows are relocated out of that pass's cache into free slots, first tokens accepted on the device) and LEAVE individually when their
+    stop rule fires (device-side, as in BatchDecoder); the step itself always computes all P rows — empty and finished slots are rows
+    nobody reads, their attention is skipped on the device.  Every position-dependent quantity lives in device memory, so one captured
+    hipGraph per (kv-length bucket) serves every step whatever the occupancy.
+
+    Past 32 sequences the step's projections are skinny GEMMs C[P, N] = x[P, K] W[N, K]^T: the prefill's LDS-DMA tile kernels at M = P
+    (fo1_gemm_bf16: 64 x 64 / 64 x 128 rings for the few-row shapes, 128 x 128 for gate/up and lm_head), RMSNorm and the q/k/v
+    post-processing (mRoPE at each slot's position + cache append, fo1_pool_qkv_post_bf16) as their own launches, the split-KV decode
+    attention with 256 keys per workgroup.  A dedicated weights-to-VGPR streaming kernel was built and measured first
+    (profiles/r04_pool_gemm_stream_kernel_vs_tile_kernels.json: 1.3-1.6x SLOWER than the tile kernels on every shape — two K tiles of
+    register prefetch cannot cover the HBM latency that a 3-4 stage LDS ring does) and is not in the tree.
 
     Reference semantics per sequence: HF greedy search over the 1-token fast path of omchat_qwen2_5_vl.py:143-155; positions = cache
     position + rope delta (modeling_qwen2_5_vl.py:1848-1860); stop AFTER the EOS / keyword id has been appended, or at max_new_tokens
-    (mm_utils.py:137-181, 640-654).  A sequence's ids do not depend on its slot or on its neighbours (per-row fp32 sum order is a
-    function of the shape only; tests/test_decode_pool_gpu.py).
-
-    backend 'stream': fo1_pool_gemm_bf16 (weights straight from HBM into MFMA fragments, x through LDS, K-split few-row products with
-    the residual + RMSNorm in the reduce launch) — 9 launches per layer;  'tile': the prefill's tile GEMMs at M = P (A/B baseline)."""
+    (mm_utils.py:137-181, 640-654).  A sequence's ids do not depend on its slot or on its neighbours (every kernel's per-row fp32 sum
+    order is a function of the launch shape only, and the shape is always P rows; tests/test_decode_pool_gpu.py)."""
     IDS_CAP = 4096
     MAX_STOP = 16
     KV_BUCKET = 256          # the attention launch geometry follows the longest live context rounded up to this many keys
 
-    def __init__(self, llm: QwenLLM, slots: int = 128, slot_rows: int = 1024, backend: str = "stream"):
+    def __init__(self, llm: QwenLLM, slots: int = 128, slot_rows: int = 1024):
         if slots not in (64, 128):
             raise ValueError("a decode pool has 64 or 128 slots")
-        if backend not in ("stream", "tile"):
-            raise ValueError(f"unknown pool backend {backend!r}")
-        self.llm, self.P, self.backend = llm, slots, backend
+        self.llm, self.P = llm, slots
         dev = llm.dev
         P = slots
         with torch.inference_mode(False):
@@ -797,29 +799,16 @@ class DecodePool:
         H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
         scale = 1.0 / math.sqrt(HD)
         st = self.state
-        n = len(llm.layers)
         with ops.workspace_scope(self._ws_owner):
             x = ops.gather_rows(self.plan, c.hidden_size, llm.embed)
-            if self.backend == "stream":
-                h = ops.rmsnorm(x, llm.layers[0]["ln1"], c.rms_norm_eps)
-                for li, w in enumerate(llm.layers):
-                    q = ops.pool_gemm(h, w["wqkv"], w["bqkv"], mode=ops.PL_QKV,
-                                      qkv=dict(n_q=H, n_kv=KV, cos=llm.rope_cos, sin=llm.rope_sin, state=st, kcache=self.dk[li], vtcache=self.dvt[li]))
-                    att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
-                    x, h = ops.pool_gemm(att, w["wo"], residual=x, norm_weight=w["ln2"], norm_eps=c.rms_norm_eps)
-                    a = ops.pool_gemm(h, w["wgu"], mode=ops.PL_SWIGLU)
-                    nw = llm.layers[li + 1]["ln1"] if li + 1 < n else llm.norm
-                    x, h = ops.pool_gemm(a, w["wdown"], residual=x, norm_weight=nw, norm_eps=c.rms_norm_eps)
-                logits = ops.pool_gemm(h, llm.lm_head)
-            else:
-                for li, w in enumerate(llm.layers):
-                    qkv = ops.gemm(ops.rmsnorm(x, w["ln1"], c.rms_norm_eps), w["wqkv"], w["bqkv"])
-                    ops.pool_qkv_post(qkv, H, KV, HD, llm.rope_cos, llm.rope_sin, st, self.dk[li], self.dvt[li])
-                    att = ops.attention_decode_batch(qkv[:, :H * HD], self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
-                    x = ops.gemm(att, w["wo"], residual=x)
-                    a = ops.gemm(ops.rmsnorm(x, w["ln2"], c.rms_norm_eps), w["wgu"], act=ops.ACT_SWIGLU16)
-                    x = ops.gemm(a, w["wdown"], residual=x)
-                logits = ops.gemm(ops.rmsnorm(x, llm.norm, c.rms_norm_eps), llm.lm_head)
+            for li, w in enumerate(llm.layers):
+                qkv = ops.gemm(ops.rmsnorm(x, w["ln1"], c.rms_norm_eps), w["wqkv"], w["bqkv"])
+                ops.pool_qkv_post(qkv, H, KV, HD, llm.rope_cos, llm.rope_sin, st, self.dk[li], self.dvt[li])
+                att = ops.attention_decode_batch(qkv[:, :H * HD], self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
+                x = ops.gemm(att, w["wo"], residual=x)
+                a = ops.gemm(ops.rmsnorm(x, w["ln2"], c.rms_norm_eps), w["wgu"], act=ops.ACT_SWIGLU16)
+                x = ops.gemm(a, w["wdown"], residual=x)
+            logits = ops.gemm(ops.rmsnorm(x, llm.norm, c.rms_norm_eps), llm.lm_head)
             ops.decode_argmax_accept(logits, None, st, self.plan, self.ids, self.stop[:self.n_stop], self.done)
             return logits
 
@@ -829,7 +818,7 @@ class DecodePool:
         if not use_graph:
             out = self._step_device(bucket)
         else:
-            key = (self.slot_rows, self.n_stop, bucket, self.backend, self.llm.rope_epoch, self.llm.rope_cos.data_ptr())
+            key = (self.slot_rows, self.n_stop, bucket, self.llm.rope_epoch, self.llm.rope_cos.data_ptr())
             ent = self._graphs.get(key)
             if ent is None:
                 with ops.graph_lock.capture(), torch.inference_mode(False):

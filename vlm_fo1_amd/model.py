@@ -531,13 +531,13 @@ class FO1Engine:
         return out
 
     # ---- continuous batching: one decode pool per GPU, shared by every replica (vlm_fo1_amd/serving.py) -------------------------------
-    def enable_decode_pool(self, slots: int = 128, slot_rows: int = 1024, backend: str = "stream", steps_per_round: int = 4):
+    def enable_decode_pool(self, slots: int = 128, slot_rows: int = 1024, steps_per_round: int = 4):
         """From now on generate_batch() / submit_batch() of this engine AND of the replicas made from it afterwards hand their sequences
         to ONE DecodePool (llm.DecodePool): the sequences of successive prefill passes — of any replica — share every decode step
         (64 / 128 per weight stream instead of <= 32 per pass).  Returns the service."""
         from .serving import PoolService
         if getattr(self, "_pool_svc", None) is None:
-            self._pool_svc = PoolService(self.llm, slots=slots, slot_rows=slot_rows, backend=backend, steps_per_round=steps_per_round)
+            self._pool_svc = PoolService(self.llm, slots=slots, slot_rows=slot_rows, steps_per_round=steps_per_round)
         return self._pool_svc
 
     def disable_decode_pool(self) -> None:

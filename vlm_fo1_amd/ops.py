@@ -497,49 +497,6 @@ def attention_decode_batch(q: torch.Tensor, kcache: torch.Tensor, vtcache: torch
 
 
 # ---- decode pool: 64 / 128 sequence slots per weight stream (decode_pool.hip) ---------------------------------------------------------
-PL_PLAIN, PL_SWIGLU, PL_QKV = 0, 1, 2
-
-
-def pool_gemm(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, mode: int = PL_PLAIN,
-              norm_weight: Optional[torch.Tensor] = None, norm_eps: float = 0.0, qkv: Optional[dict] = None):
-    """out[P, N] = epilogue(x[P, K] @ w[N, K]^T) for the P = 64 / 128 slots of a decode pool (fo1_pool_gemm_bf16).  With norm_weight
-    returns (out, rmsnorm(out) * norm_weight).  qkv (mode PL_QKV): dict(n_q, n_kv, cos, sin, state, kcache [n_kv, rows, 128], vtcache
-    [n_kv*128, rows]) — `out` is the rotated q rows [P, n_q*128]."""
-    _chk(x, "x"); _chk(w, "w")
-    px, ldx, P, K = _rows(x, "x")
-    pw, ldw, N, K2 = _rows(w, "w")
-    assert K == K2
-    n_out = N // 2 if mode == PL_SWIGLU else (qkv["n_q"] * 128 if mode == PL_QKV else N)
-    out = torch.empty(P, n_out, dtype=torch.bfloat16, device=x.device)
-    po, ldc, _, _ = _rows(out, "out")
-    pr, ldr = (None, 0)
-    if residual is not None:
-        _chk(residual, "residual")
-        pr, ldr, _, _ = _rows(residual, "residual")
-    h, ph, ldh = None, None, 0
-    if norm_weight is not None:
-        _chk(norm_weight, "norm_weight")
-        h = torch.empty(P, N, dtype=torch.bfloat16, device=x.device)
-        ph, ldh, _, _ = _rows(h, "h")
-    need = _L.load().fo1_pool_gemm_workspace_bytes(P, N, K)
-    if mode == PL_QKV or norm_weight is not None:
-        need = max(need, P * N * 4)
-    ws = _workspace("pool_gemm", x.device, need) if need else None
-    if mode == PL_QKV:
-        kc, vt = qkv["kcache"], qkv["vtcache"]
-        _chk(kc, "kcache"); _chk(vt, "vtcache")
-        assert kc.dim() == 3 and kc.stride(2) == 1 and kc.stride(1) == 128 and qkv["state"].dtype == torch.int32
-        pv, ldv, _, _ = _rows(vt, "vtcache")
-        extra = (qkv["n_q"], qkv["n_kv"], qkv["cos"].data_ptr(), qkv["sin"].data_ptr(), qkv["state"].data_ptr(), kc.data_ptr(), kc.stride(0), pv, ldv)
-    else:
-        extra = (0, 0, None, None, None, None, 0, None, 0)
-    rc = _L.load().fo1_pool_gemm_bf16(px, ldx, pw, ldw, bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc, P, N, K, mode,
-                                      norm_weight.data_ptr() if norm_weight is not None else None, float(norm_eps), ph, ldh, *extra,
-                                      ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream())
-    _L.check(rc, "fo1_pool_gemm_bf16")
-    return (out, h) if norm_weight is not None else out
-
-
 def pool_qkv_post(qkv: torch.Tensor, n_q: int, n_kv: int, head_dim: int, cos_table: torch.Tensor, sin_table: torch.Tensor, state: torch.Tensor,
                   kcache: torch.Tensor, vtcache: torch.Tensor) -> None:
     """mRoPE + cache append for the P rows of a pool step's fused q/k/v product (in place; fo1_pool_qkv_post_bf16)."""

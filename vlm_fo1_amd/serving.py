@@ -69,12 +69,12 @@ class PoolService:
     (sequences that had stopped: ids to their handles, slots free again).  The host runs at most two rounds ahead of the GPU and never
     reads a token inside a round."""
 
-    def __init__(self, llm: QwenLLM, slots: int = 128, slot_rows: int = 1024, backend: str = "stream", steps_per_round: int = 4,
-                 use_graph: bool = True):
-        self.dev = llm.dev
+    def __init__(self, llm: QwenLLM, slots: int = 128, slot_rows: int = 1024, steps_per_round: int = 4, use_graph: bool = True):
+        dev = torch.device(llm.dev)
+        self.dev = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
         self.steps_per_round = max(1, int(steps_per_round))
         self.use_graph = use_graph
-        self._args = (llm, slots, slot_rows, backend)
+        self._args = (llm, slots, slot_rows)
         self.pool: Optional[DecodePool] = None
         self._q: "queue.Queue" = queue.Queue()
         self._stop = False
