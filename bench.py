@@ -248,6 +248,80 @@ def end_to_end_run(pipe, cases, steps, K=64, pool_slots=0):
                 excludes=["JPEG decode + bicubic resize (host prefetch threads)", "tokenisation (cached prefix)"])
 
 
+def driver_level_run(pipe, n_items=384, n_warm=128, K=64, batch=32, inflight=4, pool_slots=128, prefetch_threads=4):
+    """DRIVER-LEVEL images/s: the reference's own evaluation loop as a user runs it — `evaluation/eval_coco.py`'s
+    eval_coco() (reference evaluation/eval_coco.py:36-66: file -> PIL -> prepare_inputs -> generate -> decode -> regex -> COCO records
+    -> json dump), unmodified, on `n_items` synthetic 640 x 480 JPEG files x 100 UPN boxes, a deterministic stand-in tokenizer and the
+    engine whose passes this bench has just timed (no checkpoint / tokenizer / dataset exists offline; `load_pretrained_model` is the
+    one thing replaced).  Everything a user waits for is inside the timed call: jsonl parsing, image-header cost model, JPEG decode +
+    bicubic resize + tokenisation + uploads on the prefetch threads, packed prefill passes on `inflight` worker threads, the decode
+    pool, tokenizer.decode, the regex extraction and the dump.  max_new_tokens is fixed at K ($FO1_MAX_NEW_TOKENS; the reference's
+    4096 relies on an EOS random weights never emit).  One untimed call first (graph captures, replicas, pool)."""
+    import shutil
+    import tempfile
+    from vlm_fo1.model.fo1_model import FO1ForCausalLM, FO1HFConfig
+    from vlm_fo1.model.image_processing import CLIPStyleAuxProcessor, Qwen2VLPatchProcessor
+    from vlm_fo1_amd.fixtures.synthetic import ToyTokenizer, full_config_dict, write_coco_like_dataset
+    sys.path.insert(0, os.path.join(ROOT, "evaluation"))
+    import eval_coco as E
+    dev = pipe.eng.dev
+    root = tempfile.mkdtemp(prefix="fo1_driver_level_")
+    try:
+        warm = write_coco_like_dataset(os.path.join(root, "warm"), n_warm, seed=1)
+        data = write_coco_like_dataset(os.path.join(root, "data"), n_items, seed=2)
+        model = FO1ForCausalLM.from_engine(FO1HFConfig(full_config_dict()), pipe.eng)
+        primary, aux = Qwen2VLPatchProcessor(min_pixels=56 * 56, max_pixels=2048 * 2048), CLIPStyleAuxProcessor(size=768, resize_mode="dynamic")
+        primary.device = aux.device = model.device
+        tok = ToyTokenizer()
+        E.load_pretrained_model = lambda model_id, device="cuda": (tok, model, (primary, aux))
+        env = dict(FO1_BATCH=str(batch), FO1_INFLIGHT=str(inflight), FO1_DECODE_POOL=str(pool_slots), FO1_MAX_NEW_TOKENS=str(K),
+                   FO1_PREFETCH_THREADS=str(prefetch_threads))
+        saved = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        name = "synthetic/VLM-FO1_Qwen2.5-VL-3B-synthetic"
+        try:
+            E.eval_coco(name, warm[0], warm[1], warm[2], os.path.join(root, "out_warm"), device=str(dev))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            E.eval_coco(name, data[0], data[1], data[2], os.path.join(root, "out"), device=str(dev))
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            # host side of one item, single thread (what the prefetch threads do): sizes the threads an 8-GPU node needs
+            from vlm_fo1.mm_utils import prepare_inputs
+            import json as _json
+            items = [_json.loads(l) for l in open(data[0])][:24]
+            th = time.perf_counter()
+            for d in items:
+                messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(data[2], d["image"])}},
+                                                         {"type": "text", "text": d["conversations"][0]["value"]}], "bbox_list": d["bbox_list"]}]
+                prepare_inputs(name, model, (primary, aux), tok, messages, device=str(dev), max_tokens=K, top_p=0.05, temperature=0.0, do_sample=False)
+            torch.cuda.synchronize()
+            host_ms = (time.perf_counter() - th) / len(items) * 1e3
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            pipe.eng.disable_decode_pool()
+            for r, _ in model.__dict__.get("_worker_replicas", []):
+                r.engine._pool_svc = None
+        out_file = os.path.join(root, "out", name.split("/")[-1], "eval_predictions.json")
+        ips = n_items / el
+        return dict(images_per_sec=round(ips, 2), items=n_items, seconds=round(el, 3), new_tokens_per_image=K, images_per_pass=batch,
+                    prefill_workers=inflight, decode_pool_slots=pool_slots, prefetch_threads=prefetch_threads,
+                    host_threads_per_gpu=inflight + prefetch_threads + 1 + (1 if pool_slots else 0),
+                    host_prepare_ms_per_item_one_thread=round(host_ms, 2),
+                    host_prepare_threads_needed_at_this_rate=round(ips * host_ms / 1e3, 2),
+                    host_prepare_threads_needed_for_8_gpus=round(8 * ips * host_ms / 1e3, 1),
+                    predictions_file_written=os.path.exists(out_file),
+                    loop="evaluation/eval_coco.py eval_coco(): jsonl -> cost model -> [prefetch threads: PIL decode + resize + tokenise + upload + device "
+                         "preprocess] -> packed prefill passes -> decode pool -> tokenizer.decode -> regex -> COCO records -> json dump",
+                    data="synthetic 640x480 JPEG files x 100 UPN boxes; ToyTokenizer; random weights at the true shapes")
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
+
+
 def cpu_baseline(case, pipe, reps=3, decode_tokens=64):
     """The oracle (a port of the reference's operators: oracle/*.py, torch fp32) of the same stages on this box's host cores, at
     FULL depth (32 ViT blocks, 36 LLM layers): warm-up 1 pass, then the median of `reps` passes, plus `decode_tokens` greedy
@@ -423,6 +497,8 @@ def main():
                     "streams); 1 = strictly one pass at a time")
     ap.add_argument("--pool-slots", type=int, default=128, choices=[0, 64, 128], help="end_to_end: slots of the decode pool the passes' sequences "
                     "join (continuous batching, vlm_fo1_amd/serving.py); 0 = every pass decodes its own group of <= 32 (round 3's form)")
+    ap.add_argument("--driver-items", type=int, default=384, help="driver_level: images of the synthetic COCO-shaped dataset run through "
+                    "evaluation/eval_coco.py's own loop (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true", help="skip the side measurements (one image / one pass at a time, decode loops, preprocessing): "
                     "only packed passes of the main workload run — what a rocprofv3 / PMC pass of this command should see, so that its "
@@ -650,6 +726,13 @@ def main():
         if args.pool_slots:
             e2e["static_groups"] = end_to_end_run(pipe, e2e_cases, steps=max(4, min(args.steps, 12)), K=64, pool_slots=0)
 
+    # ---- driver level: evaluation/eval_coco.py's own loop on files: not part of `value` ----
+    drv = None
+    if rank == 0 and not args.main_only and use_graph and args.driver_items > 0 and args.boxes <= 100 and img_hw == (480, 640):
+        drv = driver_level_run(pipe, n_items=args.driver_items, K=64, pool_slots=args.pool_slots)
+        if e2e is not None:
+            drv["vs_end_to_end"] = round(drv["images_per_sec"] / e2e["images_per_sec"], 3)
+
     # ---- dataset-shaped workload (ragged sizes / variable N): not part of `value` ----
     dset = None
     if rank == 0 and not args.main_only and args.dataset != "none":
@@ -784,7 +867,7 @@ def main():
                                       (f"; {R} passes in flight on {R} HIP streams (engine replicas share weights)" if R > 1 else "; one pass at a time"),
                                images_per_step=B, passes_in_flight=R, global_batch=B * world,
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
-                   end_to_end=e2e, one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
+                   end_to_end=e2e, driver_level=drv, one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
         if args.fp8:
             out["fp8_note"] = ("W8A8 e4m3 linears are an MI355X-side lever BASELINE configs[4] names; the reference has no fp8 path, so this mode's parity is "
                                "UNPINNED (deviation table against the bf16 engine: DESIGN.md section 10, tests/test_fp8_engine_gpu.py)")

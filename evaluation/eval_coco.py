@@ -41,7 +41,7 @@ def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=
         data_list = [json.loads(line) for line in f]
     cat_ids = {c["name"]: c["id"] for c in json.load(open(original_data_path))["categories"]}
 
-    batch = max(1, int(os.environ.get("FO1_BATCH", "8")))     # images per packed pass (prefill + batched decode); 1 = the reference's loop
+    batch = max(1, int(os.environ.get("FO1_BATCH", "32")))     # images per packed pass (prefill + batched decode); 1 = the reference's loop
 
     def inputs_of(i):
         """Host side of one item (a1): PIL decode / resize, tokenisation, uploads.  Runs on the prefetch threads, ahead of the GPU."""
@@ -49,7 +49,7 @@ def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=
         messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(img_folder, d["image"])}},
                                                  {"type": "text", "text": d["conversations"][0]["value"]}],
                      "bbox_list": d["bbox_list"]}]
-        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
+        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=int(os.environ.get("FO1_MAX_NEW_TOKENS", "4096")), top_p=0.05,
                             temperature=0.0, do_sample=False)
         kw["streamer"] = None
         if torch.cuda.is_available():
@@ -68,10 +68,11 @@ def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=
                 return [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(outs, kws)]
         return generate_group if batch > 1 else generate
 
-    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 2)
+    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 4), one decode pool ($FO1_DECODE_POOL)
     # cost = f(pixels, N): the image header gives the size without decoding; a missing file falls back to the box count
     costs = [SE.item_cost(*SE.image_size(os.path.join(img_folder, d["image"])), len(d["bbox_list"])) for d in data_list]
-    merged = SE.run_sharded(len(data_list), costs, generate, device=device if world > 1 else "cpu", batch=batch, prepare=inputs_of)
+    merged = SE.run_sharded(len(data_list), costs, generate, device=device if world > 1 else "cpu", batch=batch, prepare=inputs_of,
+                            prefetch_depth=max(16, 3 * batch), prefetch_threads=int(os.environ.get("FO1_PREFETCH_THREADS", "4")))
     if rank != 0:
         return
     res = []

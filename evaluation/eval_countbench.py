@@ -30,14 +30,14 @@ def eval_countbench(data_path, image_path, model_id, device):
     with open(data_path) as f:
         data = json.load(f)
 
-    batch = max(1, int(os.environ.get("FO1_BATCH", "8")))     # images per packed pass (prefill + batched decode); 1 = the reference's loop
+    batch = max(1, int(os.environ.get("FO1_BATCH", "32")))     # images per packed pass (prefill + batched decode); 1 = the reference's loop
 
     def inputs_of(i):
         """Host side of one item (a1): PIL decode / resize, tokenisation, uploads.  Runs on the prefetch threads, ahead of the GPU."""
         item = data[i]
         messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(image_path, item["image"])}},
                                                  {"type": "text", "text": item["question"]}], "bbox_list": item["bboxes"]}]
-        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=4096, top_p=0.05,
+        kw = prepare_inputs(model_id, model, image_processors, tokenizer, messages, device=device, max_tokens=int(os.environ.get("FO1_MAX_NEW_TOKENS", "4096")), top_p=0.05,
                             temperature=0.0, do_sample=False)
         kw["streamer"] = None
         if torch.cuda.is_available():
@@ -56,10 +56,11 @@ def eval_countbench(data_path, image_path, model_id, device):
                 return [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(outs, kws)]
         return generate_group if batch > 1 else generate
 
-    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 2)
+    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 4), one decode pool ($FO1_DECODE_POOL)
     # cost = f(pixels, N): the image header gives the size without decoding; a missing file falls back to the box extent
     costs = [SE.item_cost(*SE.image_size(os.path.join(image_path, item["image"]), item["bboxes"]), len(item["bboxes"])) for item in data]
-    merged = SE.run_sharded(len(data), costs, generate, device=device if world > 1 else "cpu", batch=batch, prepare=inputs_of)
+    merged = SE.run_sharded(len(data), costs, generate, device=device if world > 1 else "cpu", batch=batch, prepare=inputs_of,
+                            prefetch_depth=max(16, 3 * batch), prefetch_threads=int(os.environ.get("FO1_PREFETCH_THREADS", "4")))
     if rank != 0:
         return None
     correct = total = 0

@@ -56,7 +56,7 @@ int fo1_gemv_batch_set_impl(int impl);
 /* 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence), partials merged in LDS (measured
  * slower on MI355X: one CU cannot pull a head's K/V^T fast enough). */
 int fo1_attention_decode_set_impl(int impl);
-/* Keys per split of the batched decode attention for more than 32 sequences (decode pool): 64 / 128 / 256 (default) / 512. */
+/* Keys per split of the batched decode attention for more than 32 sequences (decode pool): 64 / 128 / 256 / 512 (default). */
 int fo1_attention_decode_set_pool_chunk(int keys);
 
 #ifdef __cplusplus

@@ -19,25 +19,7 @@ REF = "/root/reference/vlm_fo1"
 HAVE_REF = os.path.isdir(REF)
 
 
-class ToyTokenizer:
-    """Deterministic stand-in (no checkpoint offline): words -> hashed ids, optional BOS."""
-    pad_token_id = 0
-
-    def __init__(self, bos=None):
-        self.bos_token_id = bos
-
-    def _enc(self, text):
-        ids = [(sum(ord(c) * (i + 7) for i, c in enumerate(w)) % 5000) + 10 for w in text.replace("\n", " \n ").split(" ") if w != ""]
-        return ([self.bos_token_id] if self.bos_token_id is not None else []) + ids
-
-    def __call__(self, text):
-        return types.SimpleNamespace(input_ids=self._enc(text))
-
-    def encode(self, text, allowed_special=None):
-        return self._enc(text)
-
-    def batch_decode(self, ids, skip_special_tokens=True):
-        return [" ".join(str(int(i)) for i in row) for row in ids]
+from vlm_fo1_amd.fixtures.synthetic import ToyTokenizer  # noqa: E402,F401  (shared with bench.py's driver_level block)
 
 
 def load_ref(name):

@@ -106,12 +106,24 @@ class FO1ForCausalLM:
         self._vt_aux = _TowerHandle(types.SimpleNamespace(**DAVIT_LARGE))
         self.use_graph = True   # replay a captured hipGraph per input-shape signature
 
+    @classmethod
+    def from_engine(cls, config: FO1HFConfig, engine: FO1Engine) -> "FO1ForCausalLM":
+        """The drop-in model object around an engine that already exists (bench.py's `driver_level` block measures the eval drivers'
+        own loop on the engine whose passes it has just timed, instead of loading a second copy of the weights)."""
+        m = cls.__new__(cls)
+        m.config, m.device, m.dtype, m.engine = config, torch.device(engine.dev), torch.bfloat16, engine
+        m._vt = _TowerHandle(getattr(config, "vision_config", None))
+        m._vt_aux = _TowerHandle(types.SimpleNamespace(**DAVIT_LARGE))
+        m.use_graph = True
+        return m
+
     def replica(self) -> "FO1ForCausalLM":
         """Same weights, private per-request state (KV cache, graphs, scratch): one per worker thread / HIP stream, so several
         requests can be in flight on one GPU (vlm_fo1_amd.sharded_eval.run_sharded with a list of workers)."""
         import copy
         r = copy.copy(self)
         r.engine = self.engine.replica()
+        r.__dict__.pop("_worker_replicas", None)       # (sharded_eval.request_workers keeps the model's replicas on the model)
         return r
 
     # ---- nn.Module-ish surface the reference drivers call ----

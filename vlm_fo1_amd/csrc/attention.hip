@@ -731,10 +731,11 @@ int fo1_attention_decode_set_impl(int impl) {
 // [state[b][2], state[b][0]] (its slot start .. the row just written).  grid = (max chunks per slot, KV heads, B).
 // Keys per split of the batched decode attention — a function of the batch size only (a sequence's partial sums must not depend on
 // who shares the launch): up to 32 sequences (BatchDecoder) 64 keys per workgroup, so that even one sequence spreads over 2 x 11
-// CUs; a decode pool (64 / 128 slots) has sequences to spare and gives every workgroup 4 tiles of 64 keys — the tile loop's register
+// CUs; a decode pool (64 / 128 slots) has sequences to spare and gives every workgroup up to 8 tiles of 64 keys (measured at 128 slots x
+// 651-715 keys, profiles/r04_pool_step_attention_chunk_ab.json: split kernel 1.11 / 0.91 / 0.90 / 0.84 ms per step at 64 / 128 / 256 / 512) — the tile loop's register
 // prefetch then overlaps the next tile's loads with the MFMAs of the current one (one-tile workgroups are a load -> compute chain).
 namespace fo1 {
-FO1_AB_VAR g_attn_pool_chunk = 256;      // A/B: fo1_attention_decode_set_pool_chunk
+FO1_AB_VAR g_attn_pool_chunk = 512;      // A/B: fo1_attention_decode_set_pool_chunk
 static inline int decode_batch_chunk(int batch) { return batch > 32 ? g_attn_pool_chunk : 64; }
 }  // namespace fo1
 #ifdef FO1_ENABLE_AB

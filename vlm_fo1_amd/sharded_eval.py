@@ -103,18 +103,35 @@ def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu",
 
 
 def request_workers(model, make_generate: Callable, n: Optional[int] = None) -> list:
-    """[make_generate(model_i, stream_i)] for `n` requests in flight on one GPU (default: $FO1_INFLIGHT or 2): worker 0 uses the
+    """[make_generate(model_i, stream_i)] for `n` requests in flight on one GPU (default: $FO1_INFLIGHT or 4): worker 0 uses the
     loaded model on the current stream, the others a `model.replica()` (shared weights, private KV cache / graphs / scratch)
     on a fresh HIP stream.  `make_generate(model, stream)` must return `generate(i) -> token ids` that runs its device work
-    under `torch.cuda.stream(stream)`.  Falls back to one worker when the model cannot be replicated or there is no GPU."""
+    under `torch.cuda.stream(stream)`.  Falls back to one worker when the model cannot be replicated or there is no GPU.
+
+    $FO1_DECODE_POOL (default 128; 0 = off): every worker hands the sequences of its prefill passes to ONE decode pool of that many
+    slots (vlm_fo1_amd/serving.py: continuous batching) instead of decoding its own group — measured on the COCO-shaped loop
+    (bench.py `driver_level`).  Replicas and their streams are kept on the model, so a second evaluation in the same process re-uses
+    the captured graphs."""
     if n is None:
-        n = int(os.environ.get("FO1_INFLIGHT", "2"))
-    if n <= 1 or not torch.cuda.is_available() or not hasattr(model, "replica"):
+        n = int(os.environ.get("FO1_INFLIGHT", "4"))
+    if not torch.cuda.is_available() or not hasattr(model, "replica"):
         return [make_generate(model, torch.cuda.current_stream() if torch.cuda.is_available() else None)]
-    workers = [make_generate(model, torch.cuda.current_stream())]
-    for _ in range(n - 1):
-        workers.append(make_generate(model.replica(), torch.cuda.Stream()))
-    return workers
+    pool = int(os.environ.get("FO1_DECODE_POOL", "128"))
+    eng = getattr(model, "engine", None)
+    if eng is not None and hasattr(eng, "enable_decode_pool"):
+        if pool in (64, 128):
+            eng.enable_decode_pool(slots=pool)
+        elif getattr(eng, "_pool_svc", None) is not None:
+            eng.disable_decode_pool()
+    if n <= 1:
+        return [make_generate(model, torch.cuda.current_stream())]
+    kept = model.__dict__.setdefault("_worker_replicas", [])
+    while len(kept) < n - 1:
+        kept.append((model.replica(), torch.cuda.Stream()))
+    for r, _ in kept:                       # replicas made before the pool was switched follow the model
+        if getattr(r, "engine", None) is not None and eng is not None:
+            r.engine._pool_svc = getattr(eng, "_pool_svc", None)
+    return [make_generate(model, torch.cuda.current_stream())] + [make_generate(r, st) for r, st in kept[:n - 1]]
 
 
 def item_cost(width: int, height: int, n_boxes: int, aux: str = "dynamic", new_tokens: int = 64) -> float:
