@@ -279,22 +279,26 @@ def driver_level_run(pipe, n_items=384, n_warm=128, K=64, batch=32, inflight=4, 
         saved = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         name = "synthetic/VLM-FO1_Qwen2.5-VL-3B-synthetic"
+        import contextlib
         try:
-            E.eval_coco(name, warm[0], warm[1], warm[2], os.path.join(root, "out_warm"), device=str(dev))
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            E.eval_coco(name, data[0], data[1], data[2], os.path.join(root, "out"), device=str(dev))
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
+            # the drivers (like the reference's) print every prompt: this process's stdout carries ONE JSON line, so theirs goes to a file
+            with open(os.path.join(root, "driver_stdout.log"), "w") as log, contextlib.redirect_stdout(log):
+                E.eval_coco(name, warm[0], warm[1], warm[2], os.path.join(root, "out_warm"), device=str(dev))
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                E.eval_coco(name, data[0], data[1], data[2], os.path.join(root, "out"), device=str(dev))
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
             # host side of one item, single thread (what the prefetch threads do): sizes the threads an 8-GPU node needs
             from vlm_fo1.mm_utils import prepare_inputs
             import json as _json
             items = [_json.loads(l) for l in open(data[0])][:24]
             th = time.perf_counter()
-            for d in items:
-                messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(data[2], d["image"])}},
-                                                         {"type": "text", "text": d["conversations"][0]["value"]}], "bbox_list": d["bbox_list"]}]
-                prepare_inputs(name, model, (primary, aux), tok, messages, device=str(dev), max_tokens=K, top_p=0.05, temperature=0.0, do_sample=False)
+            with open(os.devnull, "w") as null, contextlib.redirect_stdout(null):
+                for d in items:
+                    messages = [{"role": "user", "content": [{"type": "image_url", "image_url": {"url": os.path.join(data[2], d["image"])}},
+                                                             {"type": "text", "text": d["conversations"][0]["value"]}], "bbox_list": d["bbox_list"]}]
+                    prepare_inputs(name, model, (primary, aux), tok, messages, device=str(dev), max_tokens=K, top_p=0.05, temperature=0.0, do_sample=False)
             torch.cuda.synchronize()
             host_ms = (time.perf_counter() - th) / len(items) * 1e3
         finally:
