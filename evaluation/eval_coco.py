@@ -32,6 +32,7 @@ def records_from_answer(ans, data, cat_ids):
 
 
 def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=None, device="cuda:0"):
+    sys.setswitchinterval(float(os.environ.get("FO1_SWITCH_INTERVAL", "0.0005")))   # a dozen short-burst host threads: 5 ms GIL hand-overs starve the launch threads
     rank, world, local = SE.init_distributed()
     if world > 1:
         device = f"cuda:{local}"
@@ -64,8 +65,11 @@ def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=
 
         def generate_group(idxs, kws):
             with torch.cuda.stream(stream):
+                if hasattr(m, "generate_many_async"):       # prefill now, decode in the shared pool; the worker goes on with its next group
+                    pend = m.generate_many_async(kws)
+                    return SE.Deferred(lambda: [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(pend.result(), kws)])
                 outs = m.generate_many(kws)
-                return [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(outs, kws)]
+                return [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(outs, kws)]     # (the reference's slice, inference.py:47-48)
         return generate_group if batch > 1 else generate
 
     generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 4), one decode pool ($FO1_DECODE_POOL)

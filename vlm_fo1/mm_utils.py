@@ -346,6 +346,7 @@ def prepare_inputs(model_name, model, image_processors, tokenizer, messages, dev
 
     if "qwen" in lowered:
         input_ids = torch.tensor([ids]).to(device)
+        input_ids._fo1_ids = list(ids)      # host copy for the engine's splice planner (FO1ForCausalLM._request): no device -> host read per request
         keywords = ["<|im_end|>"]
     stopping = KeywordsStoppingCriteria(keywords, tokenizer, input_ids)
     try:

@@ -158,8 +158,11 @@ class FO1ForCausalLM:
         boxes = None
         if bbox_list is not None and len(bbox_list) > 0 and bbox_list[0] is not None:
             boxes = bbox_list[0].to(device=dev, dtype=torch.float32)
-        self._check_model_max_length(inputs[0].tolist(), (grid[1] // 2) * (grid[2] // 2))
-        return dict(ids=inputs[0].tolist(), pix=images[0].to(device=dev, dtype=torch.bfloat16), grid=(grid[1], grid[2]),
+        ids = getattr(inputs, "_fo1_ids", None)      # prepare_inputs keeps the host list next to the device tensor
+        if ids is None or len(ids) != inputs.shape[1]:
+            ids = inputs[0].tolist()
+        self._check_model_max_length(ids, (grid[1] // 2) * (grid[2] // 2))
+        return dict(ids=ids, pix=images[0].to(device=dev, dtype=torch.bfloat16), grid=(grid[1], grid[2]),
                     aux=images_aux[0].to(device=dev, dtype=torch.bfloat16), boxes=boxes)
 
     def _check_model_max_length(self, ids, n_image_tokens: int) -> None:
@@ -199,6 +202,34 @@ class FO1ForCausalLM:
         from vlm_fo1_amd.llm import BatchDecoder
         return int(max_new_tokens) <= BatchDecoder.IDS_CAP
 
+    def _batch_plan(self, requests_kwargs: List[dict]):
+        """Validation shared by generate_many / generate_many_async -> (engine requests, max_new_tokens, device stop ids), or None when
+        the batch must take the one-by-one host loop (a stop criterion the device rule cannot express, a budget beyond its id buffer)."""
+        k0 = requests_kwargs[0]
+        if k0.get("do_sample") or (k0.get("temperature") not in (0, 0.0, None)):
+            raise NotImplementedError("sampling is not built; every reference caller decodes greedily (temperature=0)")
+        stop = self._device_stop_ids(k0.get("stopping_criteria"))
+        if stop is None or not self._fits_device_loop(k0.get("max_new_tokens", 512)):
+            return None
+        for kw in requests_kwargs[1:]:       # one budget and one stop rule per packed batch: refuse a mixed batch rather than apply the first's
+            if int(kw.get("max_new_tokens", 512)) != int(k0.get("max_new_tokens", 512)) or \
+                    self._device_stop_ids(kw.get("stopping_criteria")) != stop or kw.get("do_sample") or \
+                    (kw.get("temperature") not in (0, 0.0, None)):
+                raise ValueError("generate_many: every request of a batch must share max_new_tokens, stopping criteria and greedy decoding")
+        reqs = [self._request(kw.get("inputs"), kw.get("images"), kw.get("images_aux"), kw.get("image_grid_thws"), kw.get("bbox_list"))
+                for kw in requests_kwargs]
+        return reqs, int(k0.get("max_new_tokens", 512)), stop
+
+    @staticmethod
+    def _assemble(requests_kwargs, reqs, new) -> List[torch.LongTensor]:
+        out = []
+        for kw, req, ids in zip(requests_kwargs, reqs, new):
+            inp = kw["inputs"]
+            # [1, L_in + new] on the inputs' device, like HF generate — assembled on the host from the id lists both sides already hold
+            # (one upload per request instead of an upload, a device concat and a read back)
+            out.append(torch.tensor([list(req["ids"]) + list(ids)], dtype=inp.dtype).to(inp.device))
+        return out
+
     @torch.no_grad()
     def generate_many(self, requests_kwargs: List[dict]) -> List[torch.LongTensor]:
         """Greedy generation for several prepare_inputs(...) kwargs sets at once: the images go through ONE packed prefill pass and
@@ -207,25 +238,42 @@ class FO1ForCausalLM:
         the same for every item)."""
         if not requests_kwargs:
             return []
-        k0 = requests_kwargs[0]
-        if k0.get("do_sample") or (k0.get("temperature") not in (0, 0.0, None)):
-            raise NotImplementedError("sampling is not built; every reference caller decodes greedily (temperature=0)")
-        stop = self._device_stop_ids(k0.get("stopping_criteria"))
-        if stop is None or not self._fits_device_loop(k0.get("max_new_tokens", 512)):
+        plan = self._batch_plan(requests_kwargs)
+        if plan is None:
             return [self.generate(**kw) for kw in requests_kwargs]
-        for kw in requests_kwargs[1:]:       # one budget and one stop rule per packed batch: refuse a mixed batch rather than apply the first's
-            if int(kw.get("max_new_tokens", 512)) != int(k0.get("max_new_tokens", 512)) or \
-                    self._device_stop_ids(kw.get("stopping_criteria")) != stop or kw.get("do_sample") or \
-                    (kw.get("temperature") not in (0, 0.0, None)):
-                raise ValueError("generate_many: every request of a batch must share max_new_tokens, stopping criteria and greedy decoding")
-        reqs = [self._request(kw.get("inputs"), kw.get("images"), kw.get("images_aux"), kw.get("image_grid_thws"), kw.get("bbox_list"))
-                for kw in requests_kwargs]
-        new = self.engine.generate_batch(reqs, max_new_tokens=int(k0.get("max_new_tokens", 512)), stop_ids=stop, use_graph=self.use_graph)
-        out = []
-        for kw, ids in zip(requests_kwargs, new):
-            inp = kw["inputs"]
-            out.append(torch.cat([inp.to(self.device), torch.tensor([ids], dtype=inp.dtype, device=self.device)], dim=1).to(inp.device))
-        return out
+        reqs, max_new, stop = plan
+        new = self.engine.generate_batch(reqs, max_new_tokens=max_new, stop_ids=stop, use_graph=self.use_graph)
+        return self._assemble(requests_kwargs, reqs, new)
+
+    @torch.no_grad()
+    def generate_many_async(self, requests_kwargs: List[dict]):
+        """generate_many in two halves for callers that keep several groups in flight (sharded_eval.run_sharded): the packed prefill
+        runs now and its sequences join the engine's decode pool (FO1Engine.enable_decode_pool); the returned object's `result()` blocks
+        until they have stopped and returns what generate_many returns.  Without a pool (or for a batch the device rule cannot take)
+        the work is simply done now."""
+        class _Ready:
+            def __init__(self, value):
+                self._value = value
+
+            def result(self):
+                return self._value
+
+        if not requests_kwargs:
+            return _Ready([])
+        eng = self.engine
+        plan = self._batch_plan(requests_kwargs) if getattr(eng, "_pool_svc", None) is not None else None
+        if plan is None:
+            return _Ready(self.generate_many(requests_kwargs))
+        reqs, max_new, stop = plan
+        handles = [eng.submit_batch(reqs[i:i + eng.PREFILL_MAX], max_new, stop, self.use_graph) for i in range(0, len(reqs), eng.PREFILL_MAX)]
+        model = self
+
+        class _Pending:
+            def result(self):
+                new = [ids for h in handles for ids in h.result()]
+                return model._assemble(requests_kwargs, reqs, new)
+
+        return _Pending()
 
     @torch.no_grad()
     def generate(self, inputs=None, images=None, images_aux=None, image_grid_thws=None, bbox_list=None, do_sample=False,

@@ -37,9 +37,22 @@ class LLMConfig:
     max_seq: int = 8192
 
 
+_ROPE_INDEX_CACHE: Dict[tuple, tuple] = {}
+
+
 def rope_index_host(n_before: int, grid_hw_merged: Tuple[int, int], n_after: int):
     """[3, L] int64 position ids for <text><image gh x gw><text> and the rope delta
-    (reference get_rope_index :1630-1697, single image, t = 1)."""
+    (reference get_rope_index :1630-1697, single image, t = 1).  Memoised: a pure function of the prompt structure."""
+    key = (int(n_before), int(grid_hw_merged[0]), int(grid_hw_merged[1]), int(n_after))
+    hit = _ROPE_INDEX_CACHE.get(key)
+    if hit is None:
+        if len(_ROPE_INDEX_CACHE) >= 1024:
+            _ROPE_INDEX_CACHE.pop(next(iter(_ROPE_INDEX_CACHE)))
+        hit = _ROPE_INDEX_CACHE[key] = _rope_index_host(n_before, grid_hw_merged, n_after)
+    return hit
+
+
+def _rope_index_host(n_before: int, grid_hw_merged: Tuple[int, int], n_after: int):
     gh, gw = grid_hw_merged
     pre = torch.arange(n_before).view(1, -1).expand(3, -1)
     t_idx = torch.zeros(gh * gw, dtype=torch.long)
@@ -190,35 +203,39 @@ class QwenLLM:
     # ---- splice ------------------------------------------------------------------------------
     def plan_inputs(self, input_ids: Sequence[int], n_img: int, n_regions: int, grid_hw_merged: Tuple[int, int]):
         """HOST part of the splice: sentinel ids -> (gather plan int32 [L',2] (cpu), pos [3,L'] (cpu), rope delta).
-        One image per prompt (what prepare_inputs produces)."""
-        plan: List[Tuple[int, int]] = []
-        ri = 0
-        n_before = None
-        for t in input_ids:
-            if t == IMAGE_TOKEN_INDEX:
-                if n_before is not None:
-                    raise ValueError("more than one <image> sentinel in the prompt")
-                n_before = len(plan)
-                plan.extend((1, j) for j in range(n_img))
-            elif t == DEFAULT_REGION_INDEX:
-                if ri >= n_regions:
-                    # same failure the reference raises at omchat_qwen2_5_vl.py:361
-                    raise IndexError("prompt has more <regionfeat> placeholders than region features")
-                plan.append((2, ri))
-                ri += 1
-            else:
-                t = int(t)
-                if t < 0 or t >= self.cfg.vocab_size:   # torch's embedding lookup raises the same way in the reference
-                    raise IndexError(f"token id {t} is outside the embedding table (vocab_size {self.cfg.vocab_size})")
-                plan.append((0, t))
-        if n_before is None:
+        One image per prompt (what prepare_inputs produces).  Vectorised: at > 100 images/s per GPU a Python loop over the ~650 rows of
+        every prompt (3-4 ms each) is most of a worker thread's time under the GIL (profiles/r04_driver_level_host_profile_first.log)."""
+        import numpy as np
+        ids = np.asarray(input_ids, dtype=np.int64).reshape(-1)
+        img_at = np.flatnonzero(ids == IMAGE_TOKEN_INDEX)
+        if img_at.size > 1:
+            raise ValueError("more than one <image> sentinel in the prompt")
+        if img_at.size == 0:
             raise ValueError("prompt has no <image> sentinel")
+        is_reg = ids == DEFAULT_REGION_INDEX
+        if int(is_reg.sum()) > n_regions:
+            # same failure the reference raises at omchat_qwen2_5_vl.py:361
+            raise IndexError("prompt has more <regionfeat> placeholders than region features")
+        text = ~is_reg
+        text[img_at[0]] = False
+        bad = ids[text]
+        if bad.size and (int(bad.min()) < 0 or int(bad.max()) >= self.cfg.vocab_size):   # torch's embedding lookup raises the same way in the reference
+            t = int(bad[(bad < 0) | (bad >= self.cfg.vocab_size)][0])
+            raise IndexError(f"token id {t} is outside the embedding table (vocab_size {self.cfg.vocab_size})")
         if grid_hw_merged[0] * grid_hw_merged[1] != n_img:
             # reference modeling_qwen2_5_vl.py:1797-1800
             raise ValueError(f"Image features and image tokens do not match: tokens: {grid_hw_merged[0] * grid_hw_merged[1]}, features {n_img}")
-        n_after = len(plan) - n_before - n_img
+        n_before = int(img_at[0])
+        kind = np.where(is_reg, 2, 0).astype(np.int32)
+        val = np.where(is_reg, np.cumsum(is_reg) - 1, ids).astype(np.int32)
+        plan = np.empty((ids.size - 1 + n_img, 2), dtype=np.int32)
+        plan[:n_before, 0], plan[:n_before, 1] = kind[:n_before], val[:n_before]
+        plan[n_before:n_before + n_img, 0] = 1
+        plan[n_before:n_before + n_img, 1] = np.arange(n_img, dtype=np.int32)
+        plan[n_before + n_img:, 0], plan[n_before + n_img:, 1] = kind[n_before + 1:], val[n_before + 1:]
+        n_after = plan.shape[0] - n_before - n_img
         pos, delta = rope_index_host(n_before, grid_hw_merged, n_after)
-        return torch.tensor(plan, dtype=torch.int32).reshape(-1, 2), pos, delta
+        return torch.from_numpy(plan), pos, delta
 
     def decode_weight_tensors(self):
         """The tensors one decode step streams once (projection weights + biases, norms, lm_head): the algorithmic bytes of the step's

@@ -170,6 +170,18 @@ def image_size(path: str, boxes=None):
         return 640, 480
 
 
+class Deferred:
+    """What a batched `generate(idxs, prepared)` may return instead of the ids: the group's prefill has run and its sequences are
+    decoding in the shared pool; `result()` blocks until they have stopped and returns [ids per item].  run_sharded keeps a few of them
+    outstanding per worker, so two workers keep the GPU as busy as the closed-loop bench (bench.py `end_to_end`)."""
+
+    def __init__(self, resolve: Callable):
+        self._resolve = resolve
+
+    def result(self):
+        return self._resolve()
+
+
 class Prefetcher:
     """Runs `prepare(i)` (PIL decode / resize, tokenisation, uploads: host work of a1) on helper threads up to `depth` items ahead of
     the consumer, in the order the items will be consumed — the per-rank prefetch thread of SURVEY §8e: at > 100 images/s per GPU the
@@ -258,36 +270,75 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
             return fn(grp[0]) if single else fn(list(grp))
         return fn(grp[0], pf.get(grp[0])) if single else fn(list(grp), [pf.get(i) for i in grp])
 
-    def run_group(fn, grp):
+    def retry_one_by_one(fn, grp):
+        recs = []
+        for i in grp:
+            try:
+                o = call(fn, [i], False)
+                o = o.result() if isinstance(o, Deferred) else o
+                recs.append((i, [int(t) for t in o[0]]))
+            except Exception as e1:
+                if _fatal(e1):
+                    raise
+                print(f"[rank {rank}] item {i} failed: {type(e1).__name__}: {e1}")
+                recs.append((i, None))
+        return recs
+
+    def failed(fn, grp, e):
+        """per-item error record instead of the reference's silent `continue` (eval_coco.py:60-65)"""
+        if _fatal(e):
+            raise e
+        if batch > 1 and len(grp) > 1:
+            return retry_one_by_one(fn, grp)
+        print(f"[rank {rank}] item {grp[0]} failed: {type(e).__name__}: {e}")
+        return [(grp[0], None)]
+
+    def start_group(fn, grp):
+        """-> records, or (grp, Deferred) when the worker handed the group's sequences to the decode pool and can go on with its next
+        group while they decode (`generate` returned a Deferred)."""
         try:
             if batch > 1:
                 outs = call(fn, grp, False)
+                if isinstance(outs, Deferred):
+                    return grp, outs
                 return [(i, [int(t) for t in o]) for i, o in zip(grp, outs)]
             return [(grp[0], [int(t) for t in call(fn, grp, True)])]
-        except Exception as e:  # per-item error record instead of the reference's silent `continue` (eval_coco.py:60-65)
-            if _fatal(e):
-                raise
-            if batch > 1 and len(grp) > 1:
-                recs = []
-                for i in grp:
-                    try:
-                        recs.append((i, [int(t) for t in call(fn, [i], False)[0]]))
-                    except Exception as e1:
-                        if _fatal(e1):
-                            raise
-                        print(f"[rank {rank}] item {i} failed: {type(e1).__name__}: {e1}")
-                        recs.append((i, None))
-                return recs
-            print(f"[rank {rank}] item {grp[0]} failed: {type(e).__name__}: {e}")
-            return [(grp[0], None)]
+        except Exception as e:
+            return failed(fn, grp, e)
 
+    def settle(fn, pending):
+        grp, d = pending
+        try:
+            return [(i, [int(t) for t in o]) for i, o in zip(grp, d.result())]
+        except Exception as e:
+            return failed(fn, grp, e)
+
+    def run_worker(fn, next_group, emit):
+        """One worker's loop: up to OUTSTANDING deferred groups in flight (their prefill done, their sequences decoding in the pool)."""
+        import collections
+        pending = collections.deque()
+        while True:
+            g = next_group()
+            if g is None:
+                break
+            r = start_group(fn, g)
+            if isinstance(r, tuple):
+                pending.append(r)
+                if len(pending) > OUTSTANDING:
+                    emit(settle(fn, pending.popleft()))
+            else:
+                emit(r)
+        while pending:
+            emit(settle(fn, pending.popleft()))
+
+    OUTSTANDING = 2
     fatal: Optional[BaseException] = None
     local: list = []
     if len(workers) == 1:
         try:
-            for g in it:
-                local.extend(run_group(workers[0], g))
-        except Exception as e:      # only fatal ones get here (run_group turns the rest into error records)
+            gi = iter(it)
+            run_worker(workers[0], lambda: next(gi, None), local.extend)
+        except Exception as e:      # only fatal ones get here (the rest became error records)
             fatal = e
     else:
         import queue
@@ -297,19 +348,21 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
             q.put(g)
         lock, errors = threading.Lock(), []
 
+        def next_group():
+            try:
+                return q.get_nowait()
+            except queue.Empty:
+                return None
+
+        def emit(recs):
+            with lock:
+                local.extend(recs)
+
         def loop(fn):
-            while True:
-                try:
-                    g = q.get_nowait()
-                except queue.Empty:
-                    return
-                try:
-                    recs = run_group(fn, g)
-                except BaseException as e:   # fatal: stop this worker, re-raised on the main thread
-                    errors.append(e)
-                    return
-                with lock:
-                    local.extend(recs)
+            try:
+                run_worker(fn, next_group, emit)
+            except BaseException as e:   # fatal: stop this worker, re-raised on the main thread
+                errors.append(e)
 
         threads = [threading.Thread(target=loop, args=(fn,), daemon=True) for fn in workers]
         for t in threads:
