@@ -248,7 +248,7 @@ def end_to_end_run(pipe, cases, steps, K=64, pool_slots=0):
                 excludes=["JPEG decode + bicubic resize (host prefetch threads)", "tokenisation (cached prefix)"])
 
 
-def driver_level_run(pipe, n_items=384, n_warm=128, K=64, batch=32, inflight=4, pool_slots=128, prefetch_threads=4):
+def driver_level_run(pipe, n_items=384, n_warm=128, K=64, batch=32, inflight=2, pool_slots=128, prefetch_threads=4):
     """DRIVER-LEVEL images/s: the reference's own evaluation loop as a user runs it — `evaluation/eval_coco.py`'s
     eval_coco() (reference evaluation/eval_coco.py:36-66: file -> PIL -> prepare_inputs -> generate -> decode -> regex -> COCO records
     -> json dump), unmodified, on `n_items` synthetic 640 x 480 JPEG files x 100 UPN boxes, a deterministic stand-in tokenizer and the
@@ -537,6 +537,11 @@ def main():
             print(json.dumps(cmd))
             return
         os.execv(sys.executable, cmd)
+
+    # Host tensors on the GPU path (index plans, rope tables) are a few hundred KB: one intra-op thread.  torch's default — one per core,
+    # 256 on the GPU box — turns every small torch.cat / clone of the submitting threads into an OpenMP region on an oversubscribed pool
+    # (driver_level: host planning 10x slower, profiles/r04_driver_level_host_profile_*.log).  cpu_baseline sets its own count.
+    torch.set_num_threads(1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

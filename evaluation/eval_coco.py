@@ -32,6 +32,10 @@ def records_from_answer(ans, data, cat_ids):
 
 
 def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=None, device="cuda:0"):
+    # host tensors on this path are a few hundred KB at most: one intra-op thread.  With torch's default (one per core, 256 here) every
+    # small torch.cat / clone of the prefetch and worker threads opens an OpenMP region on the same oversubscribed pool — measured 10x
+    # slower host planning and 50 ms per prepare_inputs (profiles/r04_driver_level_host_profile_*.log)
+    torch.set_num_threads(int(os.environ.get("FO1_HOST_TORCH_THREADS", "1")))
     sys.setswitchinterval(float(os.environ.get("FO1_SWITCH_INTERVAL", "0.0005")))   # a dozen short-burst host threads: 5 ms GIL hand-overs starve the launch threads
     rank, world, local = SE.init_distributed()
     if world > 1:
@@ -72,7 +76,7 @@ def eval_coco(model_id, eval_data_path, original_data_path, img_folder, out_dir=
                 return [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(outs, kws)]     # (the reference's slice, inference.py:47-48)
         return generate_group if batch > 1 else generate
 
-    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 4), one decode pool ($FO1_DECODE_POOL)
+    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 2: each keeps up to three groups in the pool), one decode pool ($FO1_DECODE_POOL)
     # cost = f(pixels, N): the image header gives the size without decoding; a missing file falls back to the box count
     costs = [SE.item_cost(*SE.image_size(os.path.join(img_folder, d["image"])), len(d["bbox_list"])) for d in data_list]
     merged = SE.run_sharded(len(data_list), costs, generate, device=device if world > 1 else "cpu", batch=batch, prepare=inputs_of,

@@ -23,6 +23,10 @@ def count_from_answer(outputs: str) -> int:
 
 
 def eval_countbench(data_path, image_path, model_id, device):
+    # host tensors on this path are a few hundred KB at most: one intra-op thread.  With torch's default (one per core, 256 here) every
+    # small torch.cat / clone of the prefetch and worker threads opens an OpenMP region on the same oversubscribed pool — measured 10x
+    # slower host planning and 50 ms per prepare_inputs (profiles/r04_driver_level_host_profile_*.log)
+    torch.set_num_threads(int(os.environ.get("FO1_HOST_TORCH_THREADS", "1")))
     sys.setswitchinterval(float(os.environ.get("FO1_SWITCH_INTERVAL", "0.0005")))   # a dozen short-burst host threads: 5 ms GIL hand-overs starve the launch threads
     rank, world, local = SE.init_distributed()
     if world > 1:
@@ -60,7 +64,7 @@ def eval_countbench(data_path, image_path, model_id, device):
                 return [o[0, kw["inputs"].shape[1]:].tolist() for o, kw in zip(outs, kws)]     # (the reference's slice, inference.py:47-48)
         return generate_group if batch > 1 else generate
 
-    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 4), one decode pool ($FO1_DECODE_POOL)
+    generate = SE.request_workers(model, make_generate)       # $FO1_INFLIGHT passes in flight per GPU (default 2: each keeps up to three groups in the pool), one decode pool ($FO1_DECODE_POOL)
     # cost = f(pixels, N): the image header gives the size without decoding; a missing file falls back to the box extent
     costs = [SE.item_cost(*SE.image_size(os.path.join(image_path, item["image"]), item["bboxes"]), len(item["bboxes"])) for item in data]
     merged = SE.run_sharded(len(data), costs, generate, device=device if world > 1 else "cpu", batch=batch, prepare=inputs_of,

@@ -11,11 +11,12 @@ import bench as B
 
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
+torch.set_num_threads(1)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 768
 cases = [B.build_workload(dev, n_boxes=100, seed=1234 + i) for i in range(2)]
 pipe = B.Pipeline(cases[0], dev, inflight=1, batch=2, cases=cases)
 res = []
-for inflight, threads, batch, pool in ((2, 4, 32, 128), (3, 4, 32, 128), (2, 8, 32, 128), (4, 4, 32, 128), (3, 2, 32, 128), (2, 4, 32, 0)):
+for inflight, threads, batch, pool in ((2, 4, 32, 128), (3, 4, 32, 128), (4, 4, 32, 128), (2, 2, 32, 128), (2, 4, 32, 128)):
     r = B.driver_level_run(pipe, n_items=n, n_warm=max(128, inflight * batch), K=64, batch=batch, inflight=inflight, pool_slots=pool, prefetch_threads=threads)
     pipe.eng.__dict__.pop("_unused", None)
     res.append(r)

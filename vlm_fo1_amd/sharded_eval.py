@@ -103,7 +103,7 @@ def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu",
 
 
 def request_workers(model, make_generate: Callable, n: Optional[int] = None) -> list:
-    """[make_generate(model_i, stream_i)] for `n` requests in flight on one GPU (default: $FO1_INFLIGHT or 4): worker 0 uses the
+    """[make_generate(model_i, stream_i)] for `n` requests in flight on one GPU (default: $FO1_INFLIGHT or 2): worker 0 uses the
     loaded model on the current stream, the others a `model.replica()` (shared weights, private KV cache / graphs / scratch)
     on a fresh HIP stream.  `make_generate(model, stream)` must return `generate(i) -> token ids` that runs its device work
     under `torch.cuda.stream(stream)`.  Falls back to one worker when the model cannot be replicated or there is no GPU.
@@ -113,7 +113,7 @@ def request_workers(model, make_generate: Callable, n: Optional[int] = None) -> 
     (bench.py `driver_level`).  Replicas and their streams are kept on the model, so a second evaluation in the same process re-uses
     the captured graphs."""
     if n is None:
-        n = int(os.environ.get("FO1_INFLIGHT", "4"))
+        n = int(os.environ.get("FO1_INFLIGHT", "2"))
     if not torch.cuda.is_available() or not hasattr(model, "replica"):
         return [make_generate(model, torch.cuda.current_stream() if torch.cuda.is_available() else None)]
     pool = int(os.environ.get("FO1_DECODE_POOL", "128"))
