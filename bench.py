@@ -248,7 +248,7 @@ def end_to_end_run(pipe, cases, steps, K=64, pool_slots=0):
                 excludes=["JPEG decode + bicubic resize (host prefetch threads)", "tokenisation (cached prefix)"])
 
 
-def driver_level_run(pipe, n_items=384, n_warm=128, K=64, batch=32, inflight=2, pool_slots=128, prefetch_threads=4):
+def driver_level_run(pipe, n_items=768, n_warm=128, K=64, batch=32, inflight=2, pool_slots=128, prefetch_threads=4):
     """DRIVER-LEVEL images/s: the reference's own evaluation loop as a user runs it — `evaluation/eval_coco.py`'s
     eval_coco() (reference evaluation/eval_coco.py:36-66: file -> PIL -> prepare_inputs -> generate -> decode -> regex -> COCO records
     -> json dump), unmodified, on `n_items` synthetic 640 x 480 JPEG files x 100 UPN boxes, a deterministic stand-in tokenizer and the
@@ -285,6 +285,9 @@ def driver_level_run(pipe, n_items=384, n_warm=128, K=64, batch=32, inflight=2, 
             with open(os.path.join(root, "driver_stdout.log"), "w") as log, contextlib.redirect_stdout(log):
                 E.eval_coco(name, warm[0], warm[1], warm[2], os.path.join(root, "out_warm"), device=str(dev))
                 torch.cuda.synchronize()
+                import gc
+                gc.collect()
+                gc.freeze()      # what load_pretrained_model does for a served engine (vlm_fo1/model/builder.py): no gen-2 sweeps over its object graph
                 t0 = time.perf_counter()
                 E.eval_coco(name, data[0], data[1], data[2], os.path.join(root, "out"), device=str(dev))
                 torch.cuda.synchronize()
@@ -324,6 +327,88 @@ def driver_level_run(pipe, n_items=384, n_warm=128, K=64, batch=32, inflight=2, 
                     data="synthetic 640x480 JPEG files x 100 UPN boxes; ToyTokenizer; random weights at the true shapes")
     finally:
         shutil.rmtree(root, ignore_errors=True)
+
+
+def hires_run(pipe, steps=6, images=4):
+    """BASELINE configs[4]'s geometry in the default run: 1344 x 1344 image (S = 9216 patches) x 300 proposals, run as 3
+    prompts of <= 100 over ONE image (the reference caps region features at 100 per prompt, mm_utils.py:600: its callers would run the
+    whole model three times; here the towers run once per image, `image_id`), `images` images per packed pass, two passes in flight.
+    bf16, then the same passes with the e4m3 linears (`fp8`: parity UNPINNED — the reference has no fp8 path; deviation table in
+    DESIGN.md section 10)."""
+    dev = pipe.eng.dev
+    cases = [build_workload(dev, n_boxes=300, img_hw=(1344, 1344), seed=4321 + i) for i in range(images)]
+    reqs = []
+    for ci, c in enumerate(cases):
+        for ids, bx in c["prompts"]:
+            reqs.append(dict(ids=ids, pix=c["dev"]["pix"], grid=c["grid"], aux=c["dev"]["aux"], boxes=bx.to(dev), image_id=ci))
+    R = len(pipe.engs)
+
+    def timed():
+        for slot in range(R):
+            for _ in range(2):
+                with torch.cuda.stream(pipe.streams[slot]):
+                    pipe.engs[slot].prefill_batch(reqs, use_graph=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            with torch.cuda.stream(pipe.streams[k % R]):
+                pipe.engs[k % R].prefill_batch(reqs, use_graph=True)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    t_bf16 = timed()
+    out = dict(workload="BASELINE configs[4] geometry: 1344x1344 (S=9216 patches) x 300 proposals as 3 prompts of 100 over one image, prefill to the "
+                        "first greedy token of every prompt", images_per_pass=images, prompts_per_pass=len(reqs), passes_in_flight=R,
+               llm_rows_per_pass=sum(len(r["ids"]) - 1 + (r["grid"][0] // 2) * (r["grid"][1] // 2) for r in reqs),
+               bf16=dict(images_per_sec=round(images / t_bf16, 2), ms_per_pass=round(t_bf16 * 1e3, 2), dtype="bf16"))
+    n = pipe.eng.enable_fp8("all")
+    for e in pipe.engs[1:]:
+        e._graphs.clear(); e._seen.clear()
+    try:
+        t_fp8 = timed()
+        out["fp8"] = dict(images_per_sec=round(images / t_fp8, 2), ms_per_pass=round(t_fp8 * 1e3, 2),
+                          dtype=f"fp8-e4m3 linears, preset all ({n} weights; bf16 elsewhere)",
+                          parity="UNPINNED: the reference has no fp8 path (deviation table against the bf16 engine: DESIGN.md section 10, tests/test_fp8_engine_gpu.py)")
+    finally:
+        pipe.eng.disable_fp8()
+        for e in pipe.engs:
+            e._graphs.clear(); e._seen.clear()
+    return out
+
+
+def pool_decode_run(pipe, slots=128, steps=48):
+    """The decode pool's step with every slot live (llm.DecodePool, 651-token prompts): ms per step, tokens/s and the HBM roofline of
+    the step = (weights streamed once + every live sequence's K / V^T read once) / step time."""
+    from vlm_fo1_amd.llm import DecodePool
+    eng = pipe.eng
+    reqs = pipe.requests[:32] if len(pipe.requests) >= 32 else pipe.requests
+    eng.prefill_batch(reqs, use_graph=False)
+    torch.cuda.synchronize()
+    hp, first = eng._last_batch, eng._last_next_tokens.clone()
+    pool = DecodePool(eng.llm, slots=slots)
+    left = slots
+    while left > 0:
+        n = min(len(reqs), left)
+        pool.join(eng.llm.kcache, eng.llm.vtcache, hp["seqs"][:n], hp["delta"][:n], first[:n], 300, ())
+        left -= n
+    for _ in range(4):
+        pool.step(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pool.step(True)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    c = eng.llm.cfg
+    wbytes = float(sum(x.numel() * x.element_size() for x in eng.llm.decode_weight_tensors()))
+    L_ctx = hp["seqs"][0][1] + 4 + steps // 2
+    kv = 2.0 * slots * c.num_layers * c.num_kv_heads * c.head_dim * 2 * L_ctx
+    del pool
+    torch.cuda.empty_cache()
+    return dict(sequences=slots, ms_per_step=round(t * 1e3, 3), tokens_per_sec=round(slots / t, 1), launches_per_layer=10,
+                note="every slot live, one hipGraph replay per step; decode_pool = continuous batching (vlm_fo1_amd/serving.py)",
+                roofline=dict(bound="hbm", unit="GB/s", peak=8000.0, algorithmic_bytes_per_step=wbytes + kv, weight_bytes=wbytes, kv_bytes=kv,
+                              achieved=round((wbytes + kv) / t / 1e9, 1), frac=round((wbytes + kv) / t / 8e12, 4)))
 
 
 def cpu_baseline(case, pipe, reps=3, decode_tokens=64):
@@ -501,8 +586,9 @@ def main():
                     "streams); 1 = strictly one pass at a time")
     ap.add_argument("--pool-slots", type=int, default=128, choices=[0, 64, 128], help="end_to_end: slots of the decode pool the passes' sequences "
                     "join (continuous batching, vlm_fo1_amd/serving.py); 0 = every pass decodes its own group of <= 32 (round 3's form)")
-    ap.add_argument("--driver-items", type=int, default=384, help="driver_level: images of the synthetic COCO-shaped dataset run through "
+    ap.add_argument("--driver-items", type=int, default=768, help="driver_level: images of the synthetic COCO-shaped dataset run through "
                     "evaluation/eval_coco.py's own loop (0 = skip)")
+    ap.add_argument("--no-hires", action="store_true", help="skip the `hires` block (BASELINE configs[4]'s geometry: 1344x1344 x 300 proposals, bf16 and fp8 linears)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true", help="skip the side measurements (one image / one pass at a time, decode loops, preprocessing): "
                     "only packed passes of the main workload run — what a rocprofv3 / PMC pass of this command should see, so that its "
@@ -718,6 +804,8 @@ def main():
                 for blk, tt in ((dec, t1), (dec["batched"], tb)):
                     blk["roofline"] = dict(bound="hbm", unit="GB/s", peak=8000.0, algorithmic_bytes_per_step=wbytes,
                                            achieved=round(wbytes / tt / 1e9, 1), frac=round(wbytes / tt / 8e12, 4))
+            if args.pool_slots and B >= 16:
+                dec["pool"] = pool_decode_run(pipe, slots=args.pool_slots)
 
     # ---- end to end: upload + device preprocessing + packed prefill + 64-token batched decode + ids on the host, one timed loop ----
     e2e = None
@@ -741,6 +829,11 @@ def main():
         drv = driver_level_run(pipe, n_items=args.driver_items, K=64, pool_slots=args.pool_slots)
         if e2e is not None:
             drv["vs_end_to_end"] = round(drv["images_per_sec"] / e2e["images_per_sec"], 3)
+
+    # ---- BASELINE configs[4]'s geometry (bf16 and fp8 linears): not part of `value` ----
+    hires = None
+    if rank == 0 and not args.main_only and use_graph and not args.no_hires and args.boxes <= 100 and img_hw == (480, 640) and not args.fp8:
+        hires = hires_run(pipe)
 
     # ---- dataset-shaped workload (ragged sizes / variable N): not part of `value` ----
     dset = None
@@ -876,7 +969,7 @@ def main():
                                       (f"; {R} passes in flight on {R} HIP streams (engine replicas share weights)" if R > 1 else "; one pass at a time"),
                                images_per_step=B, passes_in_flight=R, global_batch=B * world,
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
-                   end_to_end=e2e, driver_level=drv, one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
+                   end_to_end=e2e, driver_level=drv, hires=hires, one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
         if args.fp8:
             out["fp8_note"] = ("W8A8 e4m3 linears are an MI355X-side lever BASELINE configs[4] names; the reference has no fp8 path, so this mode's parity is "
                                "UNPINNED (deviation table against the bf16 engine: DESIGN.md section 10, tests/test_fp8_engine_gpu.py)")
