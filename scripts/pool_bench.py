@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--slots", type=int, nargs="+", default=[64, 128])
     ap.add_argument("--chunks", type=int, nargs="+", default=[0], help="keys per split of the pool's decode attention to A/B (needs FO1_AB=1; 0 = default)")
     ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--attn-impl", type=int, nargs="+", default=[0], help="A/B (FO1_AB=1): 0 = split-KV + combine, 1 = one workgroup per (KV head, sequence)")
     ap.add_argument("--fill", type=float, default=1.0, help="fraction of the slots that hold live sequences")
     args = ap.parse_args()
     import bench as B
@@ -53,7 +54,10 @@ def main():
     out["batch_decoder_32"] = dict(ms_per_step=round(t32 * 1e3, 3), tokens_per_sec=round(32 / t32, 1), hbm_frac=round(wbytes / t32 / 8e12, 4))
 
     for P in args.slots:
-        for be in args.chunks:
+        for be0 in [(c, i) for c in args.chunks for i in args.attn_impl]:
+            be, impl = be0
+            if impl or len(args.attn_impl) > 1:
+                L.check(L.load().fo1_attention_decode_set_impl(impl), "impl")
             if be:
                 L.check(L.load().fo1_attention_decode_set_pool_chunk(be), "chunk")
             pool = DecodePool(eng.llm, slots=P)
@@ -88,7 +92,7 @@ def main():
                 a[1] += r["total_ms"]
             row["kernels_ms_per_step"] = {k: [v[0], round(v[1], 4)] for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
             row["sum_kernel_ms"] = round(sum(v[1] for v in agg.values()), 3)
-            out[f"pool_{P}" + (f"_chunk{be}" if be else "")] = row
+            out[f"pool_{P}" + (f"_chunk{be}" if be else "") + (f"_impl{impl}" if len(args.attn_impl) > 1 or impl else "")] = row
             del pool
             torch.cuda.empty_cache()
     print(json.dumps(out))
