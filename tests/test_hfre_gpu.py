@@ -175,12 +175,14 @@ def test_hfre_worklist_equals_worst_case_grid(name, ab_library):
     from vlm_fo1_amd import lib as L
     d = to_dev(make_case(name))
     try:
+        L.check(L.load().fo1_hfre_set_tuning(8, 512, -1, 0), "work-list form")       # (the default since round 4 is the band form)
         L.check(L.load().fo1_hfre_set_pixel_budget(512), "set budget")
         a = engine_out(d, worklist=True)
         b = engine_out(d, worklist=False)
         again = engine_out(d, worklist=True)
     finally:
         L.load().fo1_hfre_set_pixel_budget(0)
+        L.load().fo1_hfre_set_tuning(8, 512, -2, 32)
     assert torch.equal(a, b)
     assert torch.equal(a, again), "the item counter is reset per call; list order does not reach the results"
 
@@ -191,18 +193,77 @@ def test_hfre_worklist_tuning_invariance(unroll, chunk, grid, ab_library):
     The chunk width changes how many pixel slots a wave has, i.e. the order of the fp32 pixel sum: equal to re-association."""
     from vlm_fo1_amd import lib as L
     d = to_dev(make_case("countbench30_fpn"))
-    ref = engine_out(d, worklist=True)
     try:
+        L.check(L.load().fo1_hfre_set_tuning(8, 512, -1, 0), "work-list form")
+        ref = engine_out(d, worklist=True)
         L.check(L.load().fo1_hfre_set_tuning(unroll, chunk, 0, grid), "set tuning")
         got = engine_out(d, worklist=True)
         again = engine_out(d, worklist=True)
     finally:
         L.load().fo1_hfre_set_tuning(8, 512, 0, 4096)
+        L.load().fo1_hfre_set_tuning(8, 512, -2, 32)
     assert torch.equal(got, again)
     if chunk == 512:
         assert torch.equal(got, ref)
     else:
         torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("name", list(CASES) + ["full_size", "batched"])
+def test_hfre_band_form_equals_work_list_form_and_is_invariant_to_the_row_range(name, ab_library):
+    """Round 4's band kernel (a workgroup streams a strip of the map once and feeds every box that touches it) against rounds 2 / 3's
+    work-list kernel (box-major gather): the same separable weights and fp32 fmaf per (pixel, channel), another summation order ->
+    equal to fp32 re-association; rows per work item (8 / 32 / one range per map) only change how a box's rows are split into
+    partial slices; and run-to-run the band form is bit-identical (a box's accumulator row is owned by one wave)."""
+    from vlm_fo1_amd import lib as L
+    from vlm_fo1_amd.hfre import HFREModule
+    lib = L.load()
+
+    def run():
+        if name == "batched":
+            cases = [_full_size_case(480, 640, n, 200 + i) for i, n in enumerate((100, 37, 1))]
+            stack = lambda key: [torch.cat([c[key][l].permute(0, 2, 3, 1).contiguous() for c in cases], 0).cuda() for l in range(4)]
+            aux, fpn = stack("aux_maps"), stack("fpn_maps")
+            gh, gw = cases[0]["grid_hw"]
+            m = HFREModule(roi_output_size=7, region_feature_dim=cases[0]["region_dim"], apply_position_embedding=True,
+                           use_vision_tower_region_feature=True, vision_tower_region_feature_dim=2048, use_simpleFPN_for_vt=True,
+                           simple_fpn=lambda x: [t[:1].permute(0, 3, 1, 2) for t in fpn])
+            boxes = torch.cat([c["boxes"] for c in cases]).cuda()
+            vtb = torch.cat([c["vt_boxes"] for c in cases]).cuda()
+            bi = torch.cat([torch.full((c["boxes"].shape[0],), i, dtype=torch.int32) for i, c in enumerate(cases)]).cuda()
+            return m([t[:1].permute(0, 3, 1, 2) for t in aux], [boxes], torch.zeros(1, 1280, gh, gw, dtype=torch.bfloat16, device="cuda"), [vtb],
+                     batch=3, box_image=bi).squeeze(0).clone()
+        d = to_dev(_full_size_case(480, 640, 100, 77) if name == "full_size" else make_case(name))
+        return engine_out(d, worklist=True).clone()
+
+    try:
+        L.check(lib.fo1_hfre_set_tuning(8, 512, -1, 0), "work-list form")
+        ref = run()
+        outs = {}
+        for rr in (32, 8, 1024):
+            L.check(lib.fo1_hfre_set_tuning(8, 512, -2, rr), "band form")
+            outs[rr] = run()
+            assert torch.equal(outs[rr], run()), "band form is not run-to-run deterministic"
+    finally:
+        lib.fo1_hfre_set_tuning(8, 512, -2, 32)
+    for rr, got in outs.items():
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6, msg=lambda m: f"band form (rows per item {rr}) vs work-list form: {m}")
+
+
+def test_hfre_band_form_more_boxes_than_one_pass_holds(product_library):
+    """More than 128 boxes on one image: the band kernel accumulates 128 boxes per pass over the strip (box order), the rest in further
+    passes — every box's row must still equal what it gets in a call of its own."""
+    case = _full_size_case(480, 640, 100, 31)
+    d = to_dev(case)
+    rep = 3                                             # 300 boxes on one image: three passes
+    big = dict(d)
+    big["boxes"] = d["boxes"].repeat(rep, 1) + torch.arange(rep, device="cuda").repeat_interleave(100).view(-1, 1) * 0.5
+    big["vt_boxes"] = d["vt_boxes"].repeat(rep, 1) + torch.arange(rep, device="cuda").repeat_interleave(100).view(-1, 1) * 0.5 * d["vt_scale"][0]
+    all_rows = engine_out(big)
+    for k in range(rep):
+        part = dict(d)
+        part["boxes"], part["vt_boxes"] = big["boxes"][100 * k:100 * (k + 1)], big["vt_boxes"][100 * k:100 * (k + 1)]
+        assert torch.equal(engine_out(part), all_rows[100 * k:100 * (k + 1)]), f"boxes {100 * k}..: a box's row depends on what else is in the call"
 
 
 def test_hfre_worklist_graph_replay_under_load():

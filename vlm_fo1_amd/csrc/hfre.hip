@@ -36,6 +36,13 @@ struct HfreSrcDev {
     int chunk, nchunks, max_slices;
     int wg_base;  // first workgroup id of this source
     int ws_off;   // float offset of this source inside one box's workspace block
+    // ---- band path (hfre_pool_bands_kernel) ----
+    int lpp;          // lanes per pixel: a workgroup streams lpp * 8 channels of the map (16 B per lane)
+    int rb;           // rows staged in LDS at a time (one band)
+    int rr;           // rows per work item (a row range = one partial-sum slice of every box that touches it)
+    int n_ranges;     // ceil(H / rr)
+    int bchunks;      // C / (lpp * 8)
+    int item_base;    // first work item of this source; items of one image = bchunks * n_ranges
 };
 
 struct HfreParams {
@@ -69,6 +76,8 @@ struct HfreParams {
     float ln_eps;
     uint16_t* out_bf16; int out_bf16_ld;        // optional second destination: the same rows cast to bf16 (RNE) — what encode_regions does
                                                 // before mm_projector_aux (omchat_qwen2_5_vl.py:106): the cast rides in the finish kernel
+    int band_mode;                              // 1: hfre_pool_bands_kernel (slices = row ranges of rr rows), 0: work list (slices by pixel budget)
+    int n_images, band_items;                   // band path: images in the call, total work items
     float* dimt;                                // work-list path: dim_t table of the sine embedding, region_dim / 8 entries (written by
                                                 // hfre_weights_kernel, read by hfre_finish_vec_kernel); nullptr = powf per element
 };
@@ -105,6 +114,9 @@ __device__ __forceinline__ Footprint hfre_footprint(const HfreParams& p, const H
     if (fh <= 0 || fw <= 0) {
         f.rows_per_slice = 1;
         f.n_slices = 0;
+    } else if (p.band_mode) {
+        f.rows_per_slice = s.rr;                              // slice k = the box's rows inside row range (r_lo / rr + k)
+        f.n_slices = f.r_hi / s.rr - f.r_lo / s.rr + 1;
     } else {
         f.rows_per_slice = slice_rows(fw, p.pixel_budget);
         f.n_slices = (fh + f.rows_per_slice - 1) / f.rows_per_slice;
@@ -499,6 +511,193 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_pool_items_kernel(const Hfr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Band form (round 4): every map row is read from HBM ONCE.
+// The work-list form above gathers box by box: two proposals that overlap read the same pixels twice, and because a (box, source)'s
+// items are spread over all 8 XCDs those re-reads miss the XCD L2 — PMC: 2.25 GB fetched for a 1.19 GB footprint union at 25 images x
+// 100 proposals (profiles/r03_pmc_traffic.json), where the union itself is 87 % of the maps.  Here the roles are swapped: a workgroup
+// owns (image, source, channel chunk of lpp * 8 channels, range of rr rows), streams that strip of the map through a double-buffered
+// LDS band (rb rows at a time, the loads of the next band in flight under the arithmetic of the current one) and accumulates, for
+// EVERY box of the image whose footprint touches the band, wy[r] * wx[c] * F[r, c, :] into that box's accumulator row in LDS.  At
+// the end of the range each box's partial row goes to the workspace as slice k = range - first range of the box; the finish kernels
+// (unchanged) sum the slices in order.  Same separable weights, same fp32 fmaf per (pixel, channel); per box the pixels are summed
+// band by band, column block by column block (a re-association of the work-list form's order: results agree to fp32 rounding, and
+// are run-to-run deterministic — a box's accumulator is owned by one wave).
+// ------------------------------------------------------------------------------------------
+constexpr int kHfreBandThreads = 512;
+constexpr int kHfreBandWaves = kHfreBandThreads / 64;
+constexpr int kHfreBandBuf = 40960;                // bytes per LDS band buffer
+constexpr int kHfreBandMaxBoxes = 128;             // boxes accumulated per pass (more boxes on one image: further passes over the strip)
+constexpr int kHfreBandLoads = kHfreBandBuf / 16 / kHfreBandThreads;   // 16-byte loads per thread and band (5)
+constexpr int kHfreBandSmem = 2 * kHfreBandBuf + kHfreBandMaxBoxes * 64 * 4;
+
+typedef __attribute__((ext_vector_type(4))) unsigned int hf_u32x4;
+
+__global__ __launch_bounds__(kHfreBandThreads) void hfre_pool_bands_kernel(const HfreParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hb_smem[];
+    unsigned char* const s_band = hb_smem;                                              // [2][kHfreBandBuf]
+    float* const s_acc = reinterpret_cast<float*>(hb_smem + 2 * kHfreBandBuf);          // [kHfreBandMaxBoxes][ch]
+    __shared__ int s_box[kHfreBandMaxBoxes], s_rlo[kHfreBandMaxBoxes], s_rhi[kHfreBandMaxBoxes], s_clo[kHfreBandMaxBoxes], s_chi[kHfreBandMaxBoxes];
+    __shared__ int s_wcnt[kHfreBandWaves];
+    __shared__ int s_total, s_next;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- which strip ----
+    int si = 0;
+    for (int i = 1; i < p.n_sources; ++i) {      // (item ranges are laid out largest strip first, not in source order)
+        const int b0 = p.src[i].item_base;
+        if ((int)blockIdx.x >= b0 && (int)blockIdx.x < b0 + p.n_images * p.src[i].bchunks * p.src[i].n_ranges) si = i;
+    }
+    const HfreSrcDev& s = p.src[si];
+    int local = blockIdx.x - s.item_base;
+    const int per_img = s.bchunks * s.n_ranges;
+    const int img = local / per_img;
+    local -= img * per_img;
+    const int chunk_id = local / s.n_ranges, g = local - chunk_id * s.n_ranges;
+    const int R0 = g * s.rr, R1 = min(s.H - 1, R0 + s.rr - 1);
+    const int lpp = s.lpp, ch = lpp * 8, spw = 64 / lpp;       // lanes per pixel, channels of the strip, pixel slots per wave
+    const int slot = lane / lpp, cl = lane - slot * lpp;
+    const int W = s.W, rb = s.rb;
+    const int n_bands = (R1 - R0 + rb) / rb;
+    const uint16_t* const gbase = s.data + (long long)img * p.img_stride[si] + (size_t)chunk_id * ch;
+    const int band_elems = rb * W * lpp;                        // 16-byte elements of a band (<= kHfreBandBuf / 16)
+
+    for (int scan_from = 0; scan_from < p.n_boxes;) {
+        // ---- the boxes of this image that touch the row range, in box order (ordered compaction), at most kHfreBandMaxBoxes ----
+        if (tid == 0) { s_total = 0; s_next = p.n_boxes; }
+        __syncthreads();
+        for (int base = scan_from; base < p.n_boxes; base += kHfreBandThreads) {
+            const int n = base + tid;
+            bool m = false;
+            int r_lo = 0, r_hi = -1, c_lo = 0, c_hi = -1;
+            if (n < p.n_boxes && (p.box_image ? p.box_image[n] : 0) == img) {
+                const int* h = p.hdr + ((size_t)n * p.n_sources + si) * 8;
+                r_lo = h[0]; r_hi = h[1]; c_lo = h[2]; c_hi = h[3];
+                m = h[5] > 0 && r_lo <= R1 && r_hi >= R0;
+            }
+            const unsigned long long mask = __ballot(m);
+            if (lane == 0) s_wcnt[wave] = __popcll(mask);
+            __syncthreads();
+            int off = s_total;
+            for (int w = 0; w < wave; ++w) off += s_wcnt[w];
+            if (m) {
+                const int pos = off + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < kHfreBandMaxBoxes) { s_box[pos] = n; s_rlo[pos] = r_lo; s_rhi[pos] = r_hi; s_clo[pos] = c_lo; s_chi[pos] = c_hi; }
+                else atomicMin(&s_next, n);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int t = s_total;
+                for (int w = 0; w < kHfreBandWaves; ++w) t += s_wcnt[w];
+                s_total = t;
+            }
+            __syncthreads();
+            if (s_total >= kHfreBandMaxBoxes) {               // uniform: the list is full — whatever was not scanned waits for another pass
+                if (tid == 0 && base + kHfreBandThreads < s_next) s_next = base + kHfreBandThreads;
+                __syncthreads();
+                break;
+            }
+        }
+        const int n_list = min(s_total, kHfreBandMaxBoxes);
+        scan_from = s_next;                                    // first box left for another pass (n_boxes: none)
+        if (n_list == 0) break;
+        for (int i = tid; i < n_list * ch; i += kHfreBandThreads) s_acc[i] = 0.f;
+
+        // ---- stream the strip: band b+1 is loaded while band b is multiplied ----
+        hf_u32x4 stage[kHfreBandLoads];
+        auto load_band = [&](int b) __attribute__((always_inline)) {
+            const int row0 = R0 + b * rb;
+#pragma unroll
+            for (int i = 0; i < kHfreBandLoads; ++i) {
+                int e = tid + i * kHfreBandThreads;
+                e = e < band_elems ? e : band_elems - 1;                   // clamped: no load under a branch
+                const int pix = e / lpp, q = e - pix * lpp;
+                int r = row0 + pix / W;
+                r = r <= R1 ? r : R1;
+                const int c = pix % W;
+                stage[i] = *reinterpret_cast<const hf_u32x4*>(gbase + ((size_t)r * W + c) * s.ld + q * 8);
+            }
+        };
+        auto store_band = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < kHfreBandLoads; ++i) {
+                const int e = tid + i * kHfreBandThreads;
+                if (e < band_elems) *reinterpret_cast<hf_u32x4*>(s_band + buf * kHfreBandBuf + e * 16) = stage[i];
+            }
+        };
+        load_band(0);
+        store_band(0);
+        __syncthreads();
+        for (int b = 0; b < n_bands; ++b) {
+            const int br0 = R0 + b * rb, br1 = min(R1, br0 + rb - 1);
+            load_band(b + 1 < n_bands ? b + 1 : b);                        // (the last iteration reloads its own band: harmless, never stored)
+            const unsigned char* tile = s_band + (b & 1) * kHfreBandBuf;
+            for (int li = wave; li < n_list; li += kHfreBandWaves) {
+                const int r_lo = s_rlo[li], r_hi = s_rhi[li];
+                if (r_hi < br0 || r_lo > br1) continue;                    // wave-uniform
+                const int c_lo = s_clo[li], c_hi = s_chi[li], n = s_box[li];
+                const int ra = max(r_lo, br0), rz = min(r_hi, br1);
+                const float* gwy = p.wbuf + ((size_t)n * p.n_sources + si) * 2 * kHfreWStride;
+                const float* gwx = gwy + kHfreWStride;
+                float acc[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+                for (int cb = c_lo; cb <= c_hi; cb += 8 * spw) {            // column block: 8 columns per pixel slot
+                    float wx[8];
+                    int cc[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int c = cb + slot + u * spw;
+                        const bool ok = c <= c_hi;
+                        cc[u] = ok ? c : c_hi;
+                        wx[u] = gwx[cc[u] - c_lo];
+                        wx[u] = ok ? wx[u] : 0.f;
+                    }
+                    for (int r = ra; r <= rz; ++r) {
+                        const float wy = gwy[r - r_lo];
+                        const unsigned char* row = tile + ((size_t)(r - br0) * W) * (lpp * 16) + cl * 16;
+                        uint4 v[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const uint4*>(row + (size_t)cc[u] * (lpp * 16));
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            const float w = wy * wx[u];
+                            acc[0] = fmaf(w, bf16_lo(v[u].x), acc[0]);
+                            acc[1] = fmaf(w, bf16_hi(v[u].x), acc[1]);
+                            acc[2] = fmaf(w, bf16_lo(v[u].y), acc[2]);
+                            acc[3] = fmaf(w, bf16_hi(v[u].y), acc[3]);
+                            acc[4] = fmaf(w, bf16_lo(v[u].z), acc[4]);
+                            acc[5] = fmaf(w, bf16_hi(v[u].z), acc[5]);
+                            acc[6] = fmaf(w, bf16_lo(v[u].w), acc[6]);
+                            acc[7] = fmaf(w, bf16_hi(v[u].w), acc[7]);
+                        }
+                    }
+                }
+                for (int off = 32; off >= lpp; off >>= 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], off, 64);
+                }
+                if (lane < lpp) {                                           // slot 0 holds the band's sum: this wave owns the box's row
+                    float* a = s_acc + li * ch + cl * 8;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] += acc[j];
+                }
+            }
+            store_band((b + 1) & 1);       // last read one band ago: every wave has passed the barrier since
+            __syncthreads();
+        }
+        // ---- the range's partial rows: slice k of box n = range g - first range of the box ----
+        const int q4 = ch / 4;
+        for (int i = tid; i < n_list * q4; i += kHfreBandThreads) {
+            const int li = i / q4, j = i - li * q4;
+            const int n = s_box[li], k = g - s_rlo[li] / s.rr;
+            float* dst = p.ws + (size_t)n * p.ws_box_stride + s.ws_off + (size_t)k * s.C + (size_t)chunk_id * ch + j * 4;
+            *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(s_acc + li * ch + j * 4);
+        }
+        __syncthreads();                   // s_acc / lists are rewritten by the next pass
+    }
+}
+
 // grid (n_boxes, nseg): nseg channel segments per row without LayerNorm, 1 with (the statistics need the whole block)
 __global__ __launch_bounds__(kHfreThreads) void hfre_finish2_kernel(const HfreParams p) {
     __shared__ int s_misc[FO1_HFRE_MAX_SOURCES + 4];
@@ -578,6 +777,8 @@ FO1_AB_VAR g_hfre_v2_budget = 256;   // pixels per slice: one value for every bo
                                      // else is in the call (batch invariance)
 FO1_AB_VAR g_hfre_finish_vec = 1;     // 16-byte finish (A/B: fo1_hfre_set_tuning unroll | 32 turns it off)
 FO1_AB_VAR g_hfre_grid = 4096;       // workgroups walking the work list (profiles/r02_hfre_sweep.json)
+FO1_AB_VAR g_hfre_bands = 1;         // 1 = band kernel (every map row read once), 0 = work list (round 2 / 3); A/B: fo1_hfre_set_tuning(budget = -1 / -2)
+FO1_AB_VAR g_hfre_rr = 32;           // band path: rows per work item
 
 // workspace = [partials: n_boxes * ws_box_stride floats][weights: n_boxes*n_sources*2*kHfreWStride floats][headers: n_boxes*n_sources*8 ints]
 static size_t hfre_ws_total(const HfreParams& p, int n_sources, int n_boxes) {
@@ -585,12 +786,14 @@ static size_t hfre_ws_total(const HfreParams& p, int n_sources, int n_boxes) {
     return ((size_t)p.ws_box_stride * nb + nb * n_sources * 2 * kHfreWStride) * sizeof(float) + nb * n_sources * 8 * sizeof(int);
 }
 
-static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxes, HfreParams& p, int& total_wgs, bool v2 = false) {
+static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxes, HfreParams& p, int& total_wgs, bool v2 = false, int n_images = 1) {
     FO1_CHECK_ARG(sources != nullptr, "hfre: sources is NULL");
     FO1_CHECK_ARG(n_sources >= 1 && n_sources <= FO1_HFRE_MAX_SOURCES, "hfre: n_sources=%d out of [1,%d]", n_sources,
                   FO1_HFRE_MAX_SOURCES);
     FO1_CHECK_ARG(n_boxes >= 0, "hfre: n_boxes=%d < 0", n_boxes);
     p.n_sources = n_sources;
+    p.band_mode = (v2 && g_hfre_bands) ? 1 : 0;
+    p.n_images = n_images > 0 ? n_images : 1;
     // measured on MI355X (profiles/r01_hfre.md): per-workgroup streaming is latency-bound (~16 KB in flight), so
     // small slices win until the empty-workgroup count takes over: 256 px up to ~48 boxes, 512 px beyond
     p.pixel_budget = g_hfre_pixel_budget > 0 ? g_hfre_pixel_budget : (v2 ? g_hfre_v2_budget : (n_boxes <= 48 ? 256 : 512));
@@ -615,6 +818,18 @@ static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxe
         d.chunk = chunk;
         d.nchunks = s.C / chunk;
         d.max_slices = cdiv(s.H, slice_rows(s.W, p.pixel_budget));
+        // band path: the widest channel strip whose single row fits an LDS band buffer, as many rows per band as fit, rr rows per item
+        int lpp = 8;
+        while (lpp > 1 && (long long)s.W * lpp * 16 > kHfreBandBuf) lpp >>= 1;
+        d.lpp = lpp;
+        d.rb = (int)(kHfreBandBuf / ((long long)s.W * lpp * 16));
+        if (d.rb < 1) d.rb = 1;                      // (W <= FO1_HFRE_MAX_EXTENT = 1024 always fits at lpp = 2)
+        if (d.rb > 16) d.rb = 16;
+        d.rr = g_hfre_rr > d.rb ? g_hfre_rr : d.rb;
+        d.n_ranges = cdiv(s.H, d.rr);
+        d.bchunks = s.C / (lpp * 8);
+        d.item_base = 0;
+        if (p.band_mode) d.max_slices = d.n_ranges;
         d.wg_base = wg;
         d.ws_off = ws;
         wg += n_boxes * d.nchunks * d.max_slices;
@@ -622,6 +837,20 @@ static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxe
     }
     p.ws_box_stride = ws;
     total_wgs = wg;
+    // band items: the largest strips first (one workgroup per item, dispatched in order: the long ones must not start last)
+    p.band_items = 0;
+    bool placed[FO1_HFRE_MAX_SOURCES] = {false};
+    for (int k = 0; k < n_sources; ++k) {
+        int best = -1;
+        long long best_sz = -1;
+        for (int i = 0; i < n_sources; ++i) {
+            const long long sz = (long long)(p.src[i].rr < p.src[i].H ? p.src[i].rr : p.src[i].H) * p.src[i].W * p.src[i].lpp;
+            if (!placed[i] && sz > best_sz) { best = i; best_sz = sz; }
+        }
+        placed[best] = true;
+        p.src[best].item_base = p.band_items;
+        p.band_items += p.n_images * p.src[best].bchunks * p.src[best].n_ranges;
+    }
     return FO1_OK;
 }
 
@@ -640,6 +869,11 @@ int fo1_hfre_set_pixel_budget(int pixels) {
 // tuning hooks of fo1_hfre_region_pool_ex: unroll 8 | 16 independent loads per lane; chunk = channels per workgroup (64..512, power
 // of two); budget = pixels per slice (0 keeps the current value); grid = workgroups walking the work list (0 keeps)
 int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid) {
+    if (budget == -1 || budget == -2) {                // A/B: -1 = work-list form (rounds 2 / 3), -2 = band form (default); the rest is ignored
+        fo1::g_hfre_bands = budget == -2 ? 1 : 0;
+        if (grid > 0) fo1::g_hfre_rr = grid;           // with -2: rows per work item
+        return FO1_OK;
+    }
     fo1::g_hfre_finish_vec = (unroll & 32) ? 0 : 1;    // A/B: unroll | 32 = scalar finish
     unroll &= ~32;
     if ((unroll != 8 && unroll != 16) || chunk < 64 || chunk > fo1::kHfreMaxChunk || (chunk & (chunk - 1)) ||
@@ -787,7 +1021,7 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
     using namespace fo1;
     HfreParams p;
     int wgs = 0;
-    int rc = hfre_plan(sources, n_sources, n_boxes, p, wgs, true);
+    int rc = hfre_plan(sources, n_sources, n_boxes, p, wgs, true, opts ? opts->batch : 1);
     if (rc != FO1_OK) return rc;
     if (n_boxes == 0) return FO1_OK;
     FO1_CHECK_ARG(boxes_aux != nullptr && out != nullptr, "hfre: NULL boxes/out");
@@ -840,15 +1074,24 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
     p.dimt = (float*)(wsb + kHfreExCtr);
     p.wbuf = (float*)(wsb + off_w);
     p.hdr = (int*)(wsb + off_h);
-    p.items = (int2*)(wsb + off_i);
+    p.items = p.band_mode ? nullptr : (int2*)(wsb + off_i);      // band form: no work list (hfre_weights_kernel skips it)
     p.items_cap = hfre_bucket_cap(p, n_sources, n_boxes);
     hipStream_t st = (hipStream_t)stream;
     FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreWThreads), 0, st, p);
     double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
     for (int i = 0; i < n_sources; ++i) bytes += (double)sources[i].H * sources[i].W * sources[i].C * 2.0 * (opts ? opts->batch : 1);
-    const int grid = wgs < g_hfre_grid ? wgs : g_hfre_grid;
-    if (g_hfre_unroll == 16) { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<16>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
-    else                     { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<8>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
+    if (p.band_mode) {
+        static bool attr = false;
+        if (!attr) {
+            FO1_CHECK_HIP(hipFuncSetAttribute((const void*)hfre_pool_bands_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kHfreBandSmem));
+            attr = true;
+        }
+        FO1_LAUNCH("hfre_pool_bands", bytes, hfre_pool_bands_kernel, dim3(p.band_items), dim3(kHfreBandThreads), kHfreBandSmem, st, p);
+    } else {
+        const int grid = wgs < g_hfre_grid ? wgs : g_hfre_grid;
+        if (g_hfre_unroll == 16) { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<16>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
+        else                     { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<8>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
+    }
     bool vec = !p.ln_on && region_dim % 16 == 0 && region_dim <= 32768 && out_ld % 4 == 0 && ((uintptr_t)out & 15) == 0 && g_hfre_finish_vec;
     for (int i = 0; i < n_sources; ++i) vec = vec && sources[i].out_offset % 4 == 0;
     if (vec) {
