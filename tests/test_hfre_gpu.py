@@ -175,14 +175,13 @@ def test_hfre_worklist_equals_worst_case_grid(name, ab_library):
     from vlm_fo1_amd import lib as L
     d = to_dev(make_case(name))
     try:
-        L.check(L.load().fo1_hfre_set_tuning(8, 512, -1, 0), "work-list form")       # (the default since round 4 is the band form)
+        L.check(L.load().fo1_hfre_set_tuning(8, 512, -1, 0), "work-list form")
         L.check(L.load().fo1_hfre_set_pixel_budget(512), "set budget")
         a = engine_out(d, worklist=True)
         b = engine_out(d, worklist=False)
         again = engine_out(d, worklist=True)
     finally:
         L.load().fo1_hfre_set_pixel_budget(0)
-        L.load().fo1_hfre_set_tuning(8, 512, -2, 32)
     assert torch.equal(a, b)
     assert torch.equal(a, again), "the item counter is reset per call; list order does not reach the results"
 
@@ -201,7 +200,6 @@ def test_hfre_worklist_tuning_invariance(unroll, chunk, grid, ab_library):
         again = engine_out(d, worklist=True)
     finally:
         L.load().fo1_hfre_set_tuning(8, 512, 0, 4096)
-        L.load().fo1_hfre_set_tuning(8, 512, -2, 32)
     assert torch.equal(got, again)
     if chunk == 512:
         assert torch.equal(got, ref)
@@ -211,8 +209,9 @@ def test_hfre_worklist_tuning_invariance(unroll, chunk, grid, ab_library):
 
 @pytest.mark.parametrize("name", list(CASES) + ["full_size", "batched"])
 def test_hfre_band_form_equals_work_list_form_and_is_invariant_to_the_row_range(name, ab_library):
-    """Round 4's band kernel (a workgroup streams a strip of the map once and feeds every box that touches it) against rounds 2 / 3's
-    work-list kernel (box-major gather): the same separable weights and fp32 fmaf per (pixel, channel), another summation order ->
+    """Round 4's band kernel (a workgroup streams a strip of the map once and feeds every box that touches it; A/B build only: measured
+    4x slower than the work-list kernel, profiles/r04_hfre_band_form_in_pipeline_4x_slower.json) against the work-list kernel
+    (box-major gather): the same separable weights and fp32 fmaf per (pixel, channel), another summation order ->
     equal to fp32 re-association; rows per work item (8 / 32 / one range per map) only change how a box's rows are split into
     partial slices; and run-to-run the band form is bit-identical (a box's accumulator row is owned by one wave)."""
     from vlm_fo1_amd import lib as L
@@ -245,14 +244,23 @@ def test_hfre_band_form_equals_work_list_form_and_is_invariant_to_the_row_range(
             outs[rr] = run()
             assert torch.equal(outs[rr], run()), "band form is not run-to-run deterministic"
     finally:
-        lib.fo1_hfre_set_tuning(8, 512, -2, 32)
+        lib.fo1_hfre_set_tuning(8, 512, -1, 32)
     for rr, got in outs.items():
         torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6, msg=lambda m: f"band form (rows per item {rr}) vs work-list form: {m}")
 
 
-def test_hfre_band_form_more_boxes_than_one_pass_holds(product_library):
+def test_hfre_band_form_more_boxes_than_one_pass_holds(ab_library):
     """More than 128 boxes on one image: the band kernel accumulates 128 boxes per pass over the strip (box order), the rest in further
     passes — every box's row must still equal what it gets in a call of its own."""
+    from vlm_fo1_amd import lib as L
+    L.check(L.load().fo1_hfre_set_tuning(8, 512, -2, 32), "band form")
+    try:
+        _band_many_boxes()
+    finally:
+        L.load().fo1_hfre_set_tuning(8, 512, -1, 32)
+
+
+def _band_many_boxes():
     case = _full_size_case(480, 640, 100, 31)
     d = to_dev(case)
     rep = 3                                             # 300 boxes on one image: three passes

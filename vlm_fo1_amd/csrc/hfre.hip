@@ -511,8 +511,9 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_pool_items_kernel(const Hfr
     }
 }
 
+#ifdef FO1_ENABLE_AB
 // ------------------------------------------------------------------------------------------
-// Band form (round 4): every map row is read from HBM ONCE.
+// Band form (round 4, A/B only — MEASURED 4x SLOWER than the work-list form, see below): every map row is read from HBM ONCE.
 // The work-list form above gathers box by box: two proposals that overlap read the same pixels twice, and because a (box, source)'s
 // items are spread over all 8 XCDs those re-reads miss the XCD L2 — PMC: 2.25 GB fetched for a 1.19 GB footprint union at 25 images x
 // 100 proposals (profiles/r03_pmc_traffic.json), where the union itself is 87 % of the maps.  Here the roles are swapped: a workgroup
@@ -523,6 +524,12 @@ __global__ __launch_bounds__(kHfreThreads) void hfre_pool_items_kernel(const Hfr
 // (unchanged) sum the slices in order.  Same separable weights, same fp32 fmaf per (pixel, channel); per box the pixels are summed
 // band by band, column block by column block (a re-association of the work-list form's order: results agree to fp32 rounding, and
 // are run-to-run deterministic — a box's accumulator is owned by one wave).
+// MEASURED (25 images x 100 proposals inside the packed pass, profiles/r04_hfre_band_form_in_pipeline_4x_slower.json): 1609 us against
+// 417 us for the work-list kernel.  The strip arithmetic is cut into (box, band) units of one or two map rows (a band is what 40 KB of
+// LDS holds: 184 px x 128 B = one row of the widest FPN level), ~3 x more units than the work-list form's 256-pixel slices, and every
+// unit pays a dependent chain — its tap weights from L2, a 24-shuffle slot reduction, an LDS read-modify-write — with three boxes per
+// wave per band in sequence: ~6 us per band where the band's bytes stream in ~1.2 us.  The work-list kernel already moves its
+// (redundant) bytes at 5.4 TB/s; trading its re-reads for this bookkeeping loses.  Kept in the test / bench build for the A/B.
 // ------------------------------------------------------------------------------------------
 constexpr int kHfreBandThreads = 512;
 constexpr int kHfreBandWaves = kHfreBandThreads / 64;
@@ -698,6 +705,8 @@ __global__ __launch_bounds__(kHfreBandThreads) void hfre_pool_bands_kernel(const
     }
 }
 
+#endif   // FO1_ENABLE_AB (band form)
+
 // grid (n_boxes, nseg): nseg channel segments per row without LayerNorm, 1 with (the statistics need the whole block)
 __global__ __launch_bounds__(kHfreThreads) void hfre_finish2_kernel(const HfreParams p) {
     __shared__ int s_misc[FO1_HFRE_MAX_SOURCES + 4];
@@ -777,7 +786,7 @@ FO1_AB_VAR g_hfre_v2_budget = 256;   // pixels per slice: one value for every bo
                                      // else is in the call (batch invariance)
 FO1_AB_VAR g_hfre_finish_vec = 1;     // 16-byte finish (A/B: fo1_hfre_set_tuning unroll | 32 turns it off)
 FO1_AB_VAR g_hfre_grid = 4096;       // workgroups walking the work list (profiles/r02_hfre_sweep.json)
-FO1_AB_VAR g_hfre_bands = 1;         // 1 = band kernel (every map row read once), 0 = work list (round 2 / 3); A/B: fo1_hfre_set_tuning(budget = -1 / -2)
+FO1_AB_VAR g_hfre_bands = 0;         // 0 = work list (default), 1 = band kernel (every map row read once: measured 4x slower, A/B only); fo1_hfre_set_tuning(budget = -1 / -2)
 FO1_AB_VAR g_hfre_rr = 32;           // band path: rows per work item
 
 // workspace = [partials: n_boxes * ws_box_stride floats][weights: n_boxes*n_sources*2*kHfreWStride floats][headers: n_boxes*n_sources*8 ints]
@@ -820,9 +829,9 @@ static int hfre_plan(const fo1_hfre_source_t* sources, int n_sources, int n_boxe
         d.max_slices = cdiv(s.H, slice_rows(s.W, p.pixel_budget));
         // band path: the widest channel strip whose single row fits an LDS band buffer, as many rows per band as fit, rr rows per item
         int lpp = 8;
-        while (lpp > 1 && (long long)s.W * lpp * 16 > kHfreBandBuf) lpp >>= 1;
+        while (lpp > 1 && (long long)s.W * lpp * 16 > 40960) lpp >>= 1;
         d.lpp = lpp;
-        d.rb = (int)(kHfreBandBuf / ((long long)s.W * lpp * 16));
+        d.rb = (int)(40960 / ((long long)s.W * lpp * 16));
         if (d.rb < 1) d.rb = 1;                      // (W <= FO1_HFRE_MAX_EXTENT = 1024 always fits at lpp = 2)
         if (d.rb > 16) d.rb = 16;
         d.rr = g_hfre_rr > d.rb ? g_hfre_rr : d.rb;
@@ -869,7 +878,7 @@ int fo1_hfre_set_pixel_budget(int pixels) {
 // tuning hooks of fo1_hfre_region_pool_ex: unroll 8 | 16 independent loads per lane; chunk = channels per workgroup (64..512, power
 // of two); budget = pixels per slice (0 keeps the current value); grid = workgroups walking the work list (0 keeps)
 int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid) {
-    if (budget == -1 || budget == -2) {                // A/B: -1 = work-list form (rounds 2 / 3), -2 = band form (default); the rest is ignored
+    if (budget == -1 || budget == -2) {                // A/B: -1 = work-list form (default), -2 = band form; the rest is ignored
         fo1::g_hfre_bands = budget == -2 ? 1 : 0;
         if (grid > 0) fo1::g_hfre_rr = grid;           // with -2: rows per work item
         return FO1_OK;
@@ -1080,6 +1089,7 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
     FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreWThreads), 0, st, p);
     double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
     for (int i = 0; i < n_sources; ++i) bytes += (double)sources[i].H * sources[i].W * sources[i].C * 2.0 * (opts ? opts->batch : 1);
+#ifdef FO1_ENABLE_AB
     if (p.band_mode) {
         static bool attr = false;
         if (!attr) {
@@ -1087,7 +1097,9 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
             attr = true;
         }
         FO1_LAUNCH("hfre_pool_bands", bytes, hfre_pool_bands_kernel, dim3(p.band_items), dim3(kHfreBandThreads), kHfreBandSmem, st, p);
-    } else {
+    } else
+#endif
+    {
         const int grid = wgs < g_hfre_grid ? wgs : g_hfre_grid;
         if (g_hfre_unroll == 16) { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<16>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
         else                     { FO1_LAUNCH("hfre_pool_items", bytes, (hfre_pool_items_kernel<8>), dim3(grid), dim3(kHfreThreads), 0, st, p); }
