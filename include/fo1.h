@@ -258,6 +258,17 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
                        const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads,
                        int head_dim, float scale, int causal, const int32_t* q_row_base, double flops_hint,
                        void* stream);
+/* fo1_attention_bf16 with a second key range per item: prefix_ranges int32 [n_items][2] = [start, end) (empty when start >= end), attended
+ * in full by every query of the item before its own (causal) range.  Several prompts over ONE image share the rows of their common
+ * prefix (system text + image tokens): the prefix runs through a layer once, each prompt's remaining rows attend [prefix | own rows].
+ * The prefix rows precede the item's rows in the index space.  (Reference: one whole-model run per prompt of <= 100 regions,
+ * mm_utils.py:600; BASELINE configs[4]'s 300 proposals are three prompts over one image.) */
+int fo1_attention_prefix_bf16(const void* Q, long long q_tok_stride, long long q_head_stride,
+                              const void* K, long long k_tok_stride, long long k_head_stride,
+                              const void* VT, long long vt_row_stride,
+                              void* O, long long o_tok_stride, long long o_head_stride,
+                              const int32_t* items, const int32_t* prefix_ranges, int n_items, int q_block, int n_q_heads,
+                              int n_kv_heads, int head_dim, float scale, int causal, double flops_hint, void* stream);
 
 /* ------------------------------------------------------------------------
  * DaViT / SimpleFPN / splice data-movement kernels on token-major bf16 maps [H*W, C] (C % 8 == 0).

@@ -39,3 +39,47 @@ def test_plan_batch_layout():
         img0 += ni
         reg0 += nr
     assert hp["rows"] == off and hp["cos"].shape == (off, 128) and hp["plan"].shape == (off, 2)
+
+
+def test_plan_batch_share_prefix_reassembles_every_prompt():
+    """llm.plan_batch(share_prefix=True): prompts over one image with a common leading part keep ONE copy of those rows (a multiple of
+    4, at least SHARE_MIN_ROWS); prefix rows + own rows of every prompt are exactly the rows (gather plan, rope tables) of the
+    unshared layout, the last-row plan points at the prompt's last real row, other prompts are untouched."""
+    import torch
+    from vlm_fo1_amd.llm import LLMConfig, QwenLLM
+    from vlm_fo1_amd.model import synthetic_prompt
+    llm = QwenLLM.__new__(QwenLLM)
+    llm.cfg = LLMConfig()
+    base = synthetic_prompt(100, n_text=60, seed=7)
+
+    def variant(k, cut=0):
+        ids = list(base)
+        ids[-5] = 3000 + k
+        return ids[:len(ids) - cut]
+
+    prompts = [variant(0), variant(1, 3), variant(2), variant(0), variant(1), synthetic_prompt(5, seed=3), variant(9)]
+    n_img, grids = [2304] * 5 + [391, 2304], [(48, 48)] * 5 + [(17, 23), (48, 48)]
+    img_base = [0, 0, 0, 2304, 2304, 4608, 4608 + 391]
+    n_reg = [100] * 5 + [5, 100]
+    plain = llm.plan_batch(prompts, n_img, n_reg, grids, img_base=img_base)
+    hp = llm.plan_batch(prompts, n_img, n_reg, grids, img_base=img_base, share_prefix=True)
+    assert [len(s) for s in hp["seqs"]] == [5, 5, 5, 5, 5, 3, 3], "two groups share; the small image and the single prompt of the last image do not"
+    assert hp["rows"] < plain["rows"] - 3 * 2300 and hp["seqs"][0][3] == hp["seqs"][1][3] == hp["seqs"][2][3] != hp["seqs"][3][3]
+    for b, (s0, s1) in enumerate(zip(plain["seqs"], hp["seqs"])):
+        o0, L, _ = s0
+        if len(s1) == 5:
+            o, L1, Lp, po, P = s1
+            assert P % 4 == 0 and P >= llm.SHARE_MIN_ROWS and Lp % 4 == 0 and po + P <= o
+            rows = torch.cat([hp["plan"][po:po + P], hp["plan"][o:o + L - P]])
+            cs = torch.cat([hp["cos"][po:po + P], hp["cos"][o:o + L - P]])
+            sn = torch.cat([hp["sin"][po:po + P], hp["sin"][o:o + L - P]])
+            last = o + L - P - 1
+        else:
+            o, L1, Lp = s1
+            rows, cs, sn, last = hp["plan"][o:o + L], hp["cos"][o:o + L], hp["sin"][o:o + L], o + L - 1
+        assert L1 == L and torch.equal(rows, plain["plan"][o0:o0 + L]) and torch.equal(cs, plain["cos"][o0:o0 + L]) and torch.equal(sn, plain["sin"][o0:o0 + L])
+        assert hp["last"][b].tolist() == [0, last] and hp["delta"][b] == plain["delta"][b] and torch.equal(hp["pos"][b], plain["pos"][b])
+    from vlm_fo1_amd.llm import reloc_rows
+    rr = reloc_rows(hp["seqs"][:2] + hp["seqs"][5:6], [0, 4096, 8192])
+    (o, L, _, po, P), (o1, L1, *_), (o5, L5, _) = hp["seqs"][0], hp["seqs"][1], hp["seqs"][5]
+    assert rr == [[po, 0, P, 0], [o, P, L - P, 0], [po, 4096, P, 0], [o1, 4096 + P, L1 - P, 0], [o5, 8192, L5, 0]]

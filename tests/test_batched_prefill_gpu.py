@@ -157,3 +157,56 @@ def test_prompts_sharing_one_image_run_the_towers_once_and_match_separate_reques
         L.load().fo1_gemm_set_variant(0, 0)
         L.load().fo1_gemm_set_splitk(0)
         L.load().fo1_gemm_set_gemv(1)
+
+
+def test_shared_prefix_rows_run_through_the_llm_once(product_library):
+    """Prompts over ONE image whose first rows are identical (system text + the image tokens, up to the first region) share those rows
+    (llm.plan_batch(share_prefix=True), fo1_attention_prefix_bf16): the prefix runs through every layer once, each prompt's remaining
+    rows attend [prefix | own rows].  In a causal model that is the same function as running every prompt's full rows (what the
+    reference does, once per prompt: mm_utils.py:600 caps a prompt at 100 regions): compared here against the full-row pass of the
+    same engine — equal up to the fp32 order of the online softmax (the key tiles of a prompt's own rows start at another offset) —
+    through prefill, graph replay, the <= 32-sequence decoder and the decode pool."""
+    import torch.nn.functional as F
+    from vlm_fo1_amd.model import synthetic_prompt
+    eng = make_engine(seed=13)
+    img_a, img_b, other = make_request(72, 640, 480, 30), make_request(74, 500, 399, 20), make_request(73, 420, 300, 9)
+    lead = synthetic_prompt(10, vocab=4096, seed=80)
+
+    def prompt(k, n):      # the same leading text for every prompt of an image, another question at the end
+        ids = synthetic_prompt(n, vocab=4096, seed=80)
+        assert ids[:19] == lead[:19]
+        return ids[:-3] + [1500 + k, 1600 + k, 1700 + k]
+
+    reqs = [dict(ids=prompt(k, 10), pix=img_a["pix"], grid=img_a["grid"], aux=img_a["aux"], boxes=img_a["boxes"][k * 10:(k + 1) * 10], image_id="a") for k in range(3)]
+    reqs += [other]
+    reqs += [dict(ids=prompt(5 + k, 10), pix=img_b["pix"], grid=img_b["grid"], aux=img_b["aux"], boxes=img_b["boxes"][k * 10:(k + 1) * 10], image_id="b") for k in range(2)]
+    eng.SHARE_PREFIX = False
+    full = [clone(o) for o in eng.prefill_batch(reqs)]
+    rows_full = eng._last_batch["rows"]
+    ids_full = eng.generate_batch(reqs, max_new_tokens=6, use_graph=True)
+    eng.SHARE_PREFIX = True
+    got = [clone(o) for o in eng.prefill_batch(reqs)]
+    hp = eng._last_batch
+    assert [len(s) for s in hp["seqs"]] == [5, 5, 5, 3, 5, 5] and hp["seqs"][0][3] == hp["seqs"][2][3] and hp["seqs"][4][3] == hp["seqs"][5][3]
+    P_a, P_b = hp["seqs"][0][4], hp["seqs"][4][4]
+    assert P_a % 4 == 0 and P_a >= 391 and rows_full - hp["rows"] >= 2 * P_a + P_b - 16, (rows_full, hp["rows"], P_a, P_b)
+    for i, (a, b) in enumerate(zip(full, got)):
+        assert torch.equal(a["embeds"], b["embeds"]) and torch.equal(a["region_tokens"], b["region_tokens"]), f"prompt {i}: spliced rows differ"
+        cos = F.cosine_similarity(a["last_hidden"].float(), b["last_hidden"].float(), dim=-1).item()
+        d = (a["logits"].float() - b["logits"].float()).abs().max().item()
+        assert cos >= 0.9995 and d <= 2.0 ** -6 * a["logits"].float().abs().max().item() + 1e-3, f"prompt {i}: cos {cos:.6f}, logits max |d| {d:.4g}"
+    # graph replay == eager, bit for bit
+    for _ in range(3):
+        rep = eng.prefill_batch(reqs, use_graph=True)
+    for a, b in zip(got, rep):
+        for k in ("last_hidden", "logits", "next_token"):
+            assert torch.equal(a[k], b[k])
+    # decode from the shared layout (two-piece relocation): the <= 32-sequence decoder and the pool give the full-row pass's ids except at near-ties
+    ids_shared = eng.generate_batch(reqs, max_new_tokens=6, use_graph=True)
+    assert sum(int(a == b) for a, b in zip(ids_full, ids_shared)) >= 5, (ids_full, ids_shared)
+    eng.enable_decode_pool(slots=64)
+    try:
+        ids_pool = eng.generate_batch(reqs, max_new_tokens=6, use_graph=True)
+    finally:
+        eng.disable_decode_pool()
+    assert sum(int(a == b) for a, b in zip(ids_shared, ids_pool)) >= 5, (ids_shared, ids_pool)

@@ -34,6 +34,9 @@ struct AttnParams {
     const uint16_t* VT; long long vt_row;            // V^T row stride (elements); row = kv_head*HD + d
     uint16_t* O; long long o_tok, o_head;
     const AttnItem* items;
+    const int2* items2;                              // optional, per item: a SECOND key range [x, y) every query of the item sees in full, walked
+                                                     // before the item's own range — the shared prompt prefix of several prompts over one
+                                                     // image (its rows precede the item's in the index space, so `key <= query` holds)
     int n_items, Hq, group;                          // group = Hq / Hkv
     float scale;
     int causal;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     constexpr int NVR = (HD * (KB / 4) + NT - 1) / NT; // V^T 8-byte pieces per thread
     uint4 rk[NKR];
     uint2 rv[NVR];
-    auto gload = [&](int k0) {
+    auto gload = [&](int k0, int kv_hi) {
 #pragma unroll
         for (int i = 0; i < NKR; ++i) {
             const int q = tid + i * NT;
@@ -180,12 +183,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
             if (q < HD * (KB / 4)) *reinterpret_cast<uint2*>(&sVT[d * LDVT + c * 4]) = rv[i];
         }
     };
-    if (it.kv_start < kv_hi) gload(it.kv_start);
-    for (int k0 = it.kv_start; k0 < kv_hi; k0 += KB) {
+    // tile walk: the optional second range first (the shared prefix), then the item's own range
+    const int own_hi = kv_hi;
+    int2 r2 = int2{0, 0};
+    if (!PARTIAL && p.items2) r2 = p.items2[blockIdx.x];
+    const bool has2 = r2.y > r2.x;
+    int k0 = has2 ? r2.x : it.kv_start;
+    kv_hi = has2 ? r2.y : own_hi;
+    bool in2 = has2;
+    if (k0 < kv_hi) gload(k0, kv_hi);
+    else if (in2) { in2 = false; k0 = it.kv_start; kv_hi = own_hi; if (k0 < kv_hi) gload(k0, kv_hi); }
+    for (; k0 < kv_hi;) {
         __syncthreads();  // previous tile fully consumed
         swrite();
         __syncthreads();
-        if (k0 + KB < kv_hi) gload(k0 + KB);
+        // the tile after this one (possibly the first tile of the item's own range)
+        int nk0 = k0 + KB, nhi = kv_hi;
+        bool nin2 = in2;
+        if (nk0 >= kv_hi && in2) { nk0 = it.kv_start; nhi = own_hi; nin2 = false; }
+        if (nk0 < nhi) gload(nk0, nhi);
 
         // ---- S^T = K Q^T : 4 key sub-tiles of 16 ----
         // Every fragment read of the tile is issued before the first MFMA (and the V^T fragments before the softmax): left to itself
@@ -305,6 +321,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
                 o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vk[db]), pf[half], o[db], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        k0 = nk0;
+        kv_hi = nhi;
+        in2 = nin2;
     }
 
     if (PARTIAL) {
@@ -608,7 +627,7 @@ static int attention_entry(const void* Q, long long q_tok_stride, long long q_he
                        void* O, long long o_tok_stride, long long o_head_stride,
                        const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads, int head_dim,
                        float scale, int causal, const int32_t* q_row_base, double flops_hint, void* stream,
-                       const float* bias, int wlen, int sw_ws, int sw_shift, int sw_nwy, int sw_nwx) {
+                       const float* bias, int wlen, int sw_ws, int sw_shift, int sw_nwy, int sw_nwx, const int32_t* prefix_ranges = nullptr) {
     using namespace fo1;
     if (n_items == 0) return FO1_OK;
     FO1_CHECK_ARG(Q && K && VT && O && items, "attention: NULL operand");
@@ -627,6 +646,7 @@ static int attention_entry(const void* Q, long long q_tok_stride, long long q_he
     p.VT = (const uint16_t*)VT; p.vt_row = vt_row_stride;
     p.O = (uint16_t*)O; p.o_tok = o_tok_stride; p.o_head = o_head_stride;
     p.items = (const AttnItem*)items;
+    p.items2 = (const int2*)prefix_ranges;
     p.n_items = n_items; p.Hq = n_q_heads; p.group = n_q_heads / n_kv_heads;
     p.scale = scale; p.causal = causal; p.q_row_base = (const int*)q_row_base;
     p.part = nullptr; p.dyn_kv_len = nullptr; p.kv_chunk = 0; p.q_range_end = 0;
@@ -646,6 +666,22 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
                        float scale, int causal, const int32_t* q_row_base, double flops_hint, void* stream) {
     return attention_entry(Q, q_tok_stride, q_head_stride, K, k_tok_stride, k_head_stride, VT, vt_row_stride, O, o_tok_stride, o_head_stride, items, n_items,
                            q_block, n_q_heads, n_kv_heads, head_dim, scale, causal, q_row_base, flops_hint, stream, nullptr, 0, 0, 0, 0, 0);
+}
+
+// fo1_attention_bf16 with a second key range per item (prefix_ranges: int32 [n_items][2] = [start, end), empty when start >= end) that
+// every query of the item attends in full, before its own (causal) range: several prompts over ONE image share the rows of their common
+// prefix (system text + the image tokens) — the prefix rows run through the layer once, every prompt's remaining rows attend
+// [prefix | own rows].  The prefix rows must precede the item's rows in the index space.  (The reference runs the whole model once per
+// prompt, mm_utils.py:600 caps a prompt at 100 region features: BASELINE configs[4]'s 300 proposals are three such prompts.)
+int fo1_attention_prefix_bf16(const void* Q, long long q_tok_stride, long long q_head_stride,
+                              const void* K, long long k_tok_stride, long long k_head_stride,
+                              const void* VT, long long vt_row_stride,
+                              void* O, long long o_tok_stride, long long o_head_stride,
+                              const int32_t* items, const int32_t* prefix_ranges, int n_items, int q_block, int n_q_heads, int n_kv_heads,
+                              int head_dim, float scale, int causal, double flops_hint, void* stream) {
+    FO1_CHECK_ARG(prefix_ranges != nullptr && ((uintptr_t)prefix_ranges & 7) == 0, "attention_prefix: prefix_ranges NULL or misaligned");
+    return attention_entry(Q, q_tok_stride, q_head_stride, K, k_tok_stride, k_head_stride, VT, vt_row_stride, O, o_tok_stride, o_head_stride, items, n_items,
+                           q_block, n_q_heads, n_kv_heads, head_dim, scale, causal, nullptr, flops_hint, stream, nullptr, 0, 0, 0, 0, 0, prefix_ranges);
 }
 
 // Window attention with an additive bias (Swin W-MSA / SW-MSA, backbone/swin.py:136-175): softmax(q k^T scale + bias[head][i][j]
@@ -705,7 +741,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
     p.scale = scale; p.causal = 0; p.q_row_base = nullptr;
     p.part = (float*)workspace; p.dyn_kv_len = (const int*)dyn_kv_len; p.kv_chunk = 64;
     (void)one_item;
-    p.items = nullptr;
+    p.items = nullptr; p.items2 = nullptr;
     p.q_range_end = group;
     p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
     p.bias = nullptr; p.wlen = 0; p.sw_ws = p.sw_shift = p.sw_nwy = p.sw_nwx = 0;
@@ -778,7 +814,7 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     p.K = (const uint16_t*)kcache; p.k_tok = k_tok_stride; p.k_head = k_head_stride;
     p.VT = (const uint16_t*)vtcache; p.vt_row = vt_row_stride;
     p.O = nullptr; p.o_tok = 0; p.o_head = 0;
-    p.items = nullptr;
+    p.items = nullptr; p.items2 = nullptr;
     const int chunk = decode_batch_chunk(batch);
     p.n_items = cdiv(max_kv_len, chunk); p.Hq = n_kv_heads; p.group = 1;
     p.scale = scale; p.causal = 0; p.q_row_base = nullptr;

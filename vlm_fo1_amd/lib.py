@@ -215,6 +215,9 @@ SIGNATURES = {
     "fo1_attention_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,
                                    c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_float, c_int, c_void_p, ctypes.c_double, c_void_p]),
+    "fo1_attention_prefix_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,
+                                          c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                          c_float, c_int, ctypes.c_double, c_void_p]),
     "fo1_dwconv3x3_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_dwconv3x3_ln_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int,
                                       c_int, c_void_p]),

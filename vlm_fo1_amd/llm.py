@@ -258,7 +258,7 @@ class QwenLLM:
 
     # ---- transformer -------------------------------------------------------------------------
     def _forward(self, x: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, pos0: int, collect: Optional[list] = None,
-                 items: Optional[torch.Tensor] = None, flops: Optional[float] = None):
+                 items: Optional[torch.Tensor] = None, flops: Optional[float] = None, prefix_ranges: Optional[torch.Tensor] = None):
         c = self.cfg
         L = x.shape[0]
         H, KV, HD = c.num_heads, c.num_kv_heads, c.head_dim
@@ -274,7 +274,7 @@ class QwenLLM:
             qkv = ops.norm_linear(x, w["ln1"], c.rms_norm_eps, w["wqkv"], w["bqkv"])
             ops.qkv_post_llm(qkv, H, KV, HD, cos, sin, self.kcache[li], self.vtcache[li], pos0)   # mRoPE + K append + V^T, one launch
             att = ops.attention_strided(qkv[:, :H * HD], q_row0=pos0, k=self.kcache[li], vt=self.vtcache[li], items=items,
-                                        n_q_heads=H, n_kv_heads=KV, head_dim=HD, scale=scale, causal=True, flops=flops)
+                                        n_q_heads=H, n_kv_heads=KV, head_dim=HD, scale=scale, causal=True, flops=flops, prefix_ranges=prefix_ranges)
             x = ops.gemm(att, w["wo"], residual=x)
             a = ops.norm_linear(x, w["ln2"], c.rms_norm_eps, w["wgu"], act=ops.ACT_SWIGLU16)   # gate/up GEMM, SwiGLU in its epilogue
             x = ops.gemm(a, w["wdown"], residual=x)
@@ -313,47 +313,112 @@ class QwenLLM:
     # ---- several prompts packed into one pass (the reference's batch-aware splice, omchat_qwen2_5_vl.py:380-416) ----
     PACK_ALIGN = 4   # the attention kernel reads V^T in 8-byte (4-key) pieces: every sequence starts at a multiple of 4
 
+    SHARE_MIN_ROWS = 256     # a common prefix shorter than this is not worth a second key range per attention item
+
     def plan_batch(self, prompts: Sequence[Sequence[int]], n_img: Sequence[int], n_regions: Sequence[int],
-                   grids_merged: Sequence[Tuple[int, int]], img_base: Optional[Sequence[int]] = None):
-        """HOST: B prompts -> one packed plan.  Sequence b owns rows [off_b, off_b + Lp_b), Lp_b = L_b rounded up to PACK_ALIGN
+                   grids_merged: Sequence[Tuple[int, int]], img_base: Optional[Sequence[int]] = None, share_prefix: bool = False):
+        """HOST: B prompts -> one packed plan.  Sequence b owns rows [off_b, off_b + Lp_b), Lp_b = its row count rounded up to PACK_ALIGN
         with dummy rows (token 0) appended AFTER its real rows: causal attention keeps them invisible to every real row.  Image /
         region indices address the batch-concatenated token tables.  Returns dict(plan int32 [R,2], cos, sin bf16 [R, hd] (host),
-        seqs [(off, L, Lp)], pos [per-sequence [3, L]], delta [per sequence], last int32 [B,2] gather plan of the last real rows)."""
+        seqs, pos [per-sequence [3, L]], delta [per sequence], last int32 [B,2] gather plan of the last real rows).
+
+        seqs[b] = (off, L, Lp) — or, with share_prefix, (off, L, Lp, poff, P) for prompts over ONE image (same img_base) whose first P
+        rows are identical (system text + the image block, up to the first region): those P rows (a multiple of PACK_ALIGN, at
+        [poff, poff + P)) run through every layer ONCE, `off` / `Lp` describe the prompt's remaining L - P rows, which attend
+        [prefix | own rows] (fo1_attention_prefix_bf16).  In a causal model the prefix rows' states do not depend on what follows, so
+        every prompt's rows are what its own full pass computes (the reference would run the whole model once per prompt)."""
         c = self.cfg
-        plans, coss, sins, seqs, poss, deltas = [], [], [], [], [], []
-        off = img0 = reg0 = 0
+        A = self.PACK_ALIGN
+        B = len(prompts)
+        per = []
+        img0 = reg0 = 0
         for b, (ids, ni, nr, gm) in enumerate(zip(prompts, n_img, n_regions, grids_merged)):
             if img_base is not None:      # several prompts over ONE image: they all address that image's rows of the token table
                 img0 = int(img_base[b])
             pl, pos, delta = self.plan_inputs(ids, ni, nr, gm)
-            L = pl.shape[0]
-            Lp = (L + self.PACK_ALIGN - 1) // self.PACK_ALIGN * self.PACK_ALIGN
             pl = pl.clone()
             pl[:, 1] += (pl[:, 0] == 1).to(torch.int32) * img0 + (pl[:, 0] == 2).to(torch.int32) * reg0
-            if Lp > L:
-                pl = torch.cat([pl, torch.zeros(Lp - L, 2, dtype=torch.int32)], 0)
-                tail = int(pos.max()) + 1 + torch.arange(Lp - L).view(1, -1).expand(3, -1)
+            per.append((pl, pos, delta))
+            img0 += ni; reg0 += nr
+        # prompts that share a prefix: same image rows AND the same plan rows up to the first difference
+        shared = {}                       # first member -> (P, members)
+        member_of = [None] * B
+        if share_prefix and img_base is not None:
+            by_img = {}
+            for b in range(B):
+                by_img.setdefault(int(img_base[b]), []).append(b)
+            for members in by_img.values():
+                if len(members) < 2:
+                    continue
+                p0 = per[members[0]][0]
+                P = p0.shape[0]
+                for m in members[1:]:
+                    pm = per[m][0]
+                    n = min(P, pm.shape[0])
+                    diff = (p0[:n] != pm[:n]).any(dim=1).nonzero()
+                    P = int(diff[0]) if diff.numel() else n
+                P = min(P, min(per[m][0].shape[0] for m in members) - 1) // A * A      # every prompt keeps >= 1 own row (its last row feeds the head)
+                if P >= self.SHARE_MIN_ROWS:
+                    shared[members[0]] = (P, members)
+                    for m in members:
+                        member_of[m] = members[0]
+        plans, coss, sins, seqs, poss, deltas, last_rows = [], [], [], [None] * B, [], [], []
+        prefix_at = {}
+        off = 0
+        for b in range(B):
+            pl, pos, delta = per[b]
+            L = pl.shape[0]
+            P = shared[member_of[b]][0] if member_of[b] is not None else 0
+            own = L - P
+            Lp = (own + A - 1) // A * A
+            if Lp > own:
+                pl = torch.cat([pl, torch.zeros(Lp - own, 2, dtype=torch.int32)], 0)
+                tail = int(pos.max()) + 1 + torch.arange(Lp - own).view(1, -1).expand(3, -1)
                 pos_p = torch.cat([pos, tail], 1)
             else:
                 pos_p = pos
             cs, sn = mrope_tables(pos_p, c.head_dim, c.rope_theta, c.mrope_section)
-            plans.append(pl); coss.append(cs); sins.append(sn)
-            seqs.append((off, L, Lp)); poss.append(pos); deltas.append(delta)
-            off += Lp; img0 += ni; reg0 += nr
-        last = torch.tensor([[0, o + L - 1] for o, L, _ in seqs], dtype=torch.int32).reshape(-1, 2)
+            if P and member_of[b] == b:   # the group's first prompt: its prefix rows are the group's
+                plans.append(pl[:P]); coss.append(cs[:P]); sins.append(sn[:P])
+                prefix_at[b] = off
+                off += P
+            plans.append(pl[P:]); coss.append(cs[P:]); sins.append(sn[P:])
+            seqs[b] = (off, L, Lp) if not P else (off, L, Lp, prefix_at[member_of[b]], P)
+            last_rows.append(off + own - 1)
+            poss.append(pos); deltas.append(delta)
+            off += Lp
+        last = torch.tensor([[0, r] for r in last_rows], dtype=torch.int32).reshape(-1, 2)
         return dict(plan=torch.cat(plans, 0).contiguous(), cos=torch.cat(coss, 0).contiguous(), sin=torch.cat(sins, 0).contiguous(),
                     seqs=seqs, pos=poss, delta=deltas, last=last, rows=off)
 
-    def packed_items(self, seqs) -> Tuple[torch.Tensor, float]:
+    def packed_items(self, seqs):
+        """-> (attention work items int32 [n, 4] on the device, flop count, prefix ranges int32 [n, 2] or None)."""
         key = ("packed", tuple(seqs))
         hit = self._item_cache.get(key)
         if hit is None:
-            blk = ops.pick_q_block([(o, o + Lp) for o, _, Lp in seqs], self.cfg.num_heads)
-            rows = [[q0, min(q0 + blk, o + Lp), o, o + Lp] for o, _, Lp in seqs for q0 in range(o, o + Lp, blk)]
+            segs = []                                  # (q0, q1, second range) — one per sequence, one per distinct shared prefix
+            done = set()
+            fl = 0.0
+            for sq in seqs:
+                o, _, Lp, *pre = sq
+                if pre:
+                    po, P = pre
+                    if (po, P) not in done:
+                        done.add((po, P))
+                        segs.append((po, po + P, (0, 0)))
+                        fl += P * (P + 1) / 2.0
+                    segs.append((o, o + Lp, (po, po + P)))
+                    fl += Lp * (Lp + 1) / 2.0 + float(Lp) * P
+                else:
+                    segs.append((o, o + Lp, (0, 0)))
+                    fl += Lp * (Lp + 1) / 2.0
+            blk = ops.pick_q_block([(a, b) for a, b, _ in segs], self.cfg.num_heads)
+            rows = [[q0, min(q0 + blk, b), a, b] for a, b, _ in segs for q0 in range(a, b, blk)]
+            rng = [list(r2) for a, b, r2 in segs for _ in range(a, b, blk)]
             it = torch.tensor(rows, dtype=torch.int32).to(self.dev)
             it.q_block = blk
-            fl = 4.0 * self.cfg.num_heads * self.cfg.head_dim * sum(Lp * (Lp + 1) / 2.0 for _, _, Lp in seqs)
-            hit = (it, fl)
+            r2 = torch.tensor(rng, dtype=torch.int32).to(self.dev) if any(x[1] > x[0] for x in rng) else None
+            hit = (it, 4.0 * self.cfg.num_heads * self.cfg.head_dim * fl, r2)
             self._item_cache[key] = hit
         return hit
 
@@ -363,15 +428,15 @@ class QwenLLM:
         K / V^T land at cache positions = packed row indices.  Returns (final-norm last hidden [B, d], logits [B, V], next ids
         int32 [B])."""
         c = self.cfg
-        items, flops = self.packed_items(seqs)
+        items, flops, prefix_ranges = self.packed_items(seqs)
         from . import stage_abi
-        if stage_abi.enabled() and collect is None:      # the same launches, sequenced by fo1_llm_prefill (csrc/stages.hip)
+        if stage_abi.enabled() and collect is None and prefix_ranges is None:      # the same launches, sequenced by fo1_llm_prefill (csrc/stages.hip)
             if embeds.shape[0] > self.capacity:
                 raise ValueError(f"sequence {embeds.shape[0]} exceeds the KV cache ({self.capacity}); call reserve() first")
             with ops.workspace_scope(self._ws_owner):
                 return stage_abi.llm_stage(self).prefill_packed(embeds, cos, sin, seqs, last_plan)
         with ops.workspace_scope(self._ws_owner):
-            x = self._forward(embeds, cos, sin, 0, collect, items=items, flops=flops)
+            x = self._forward(embeds, cos, sin, 0, collect, items=items, flops=flops, prefix_ranges=prefix_ranges)
             last = ops.rmsnorm(ops.gather_rows(last_plan, c.hidden_size, x), self.norm, c.rms_norm_eps)
             logits = ops.gemm(last, self.lm_head)
             toks = torch.empty(last.shape[0], dtype=torch.int32, device=self.dev)
@@ -468,6 +533,20 @@ class QwenLLM:
         return None, logits, self.dplan.view(-1)[1:2].clone()
 
 
+def reloc_rows(seqs, dst0s):
+    """kv_relocate entries [src0, dst0, len, 0] that move every sequence of a packed prefill to cache row dst0: one entry, or two for a
+    sequence whose first P rows are a prefix shared with other prompts (plan_batch(share_prefix=True): (off, L, Lp, poff, P))."""
+    rows = []
+    for sq, d in zip(seqs, dst0s):
+        o, L, _, *pre = sq
+        if pre:
+            po, P = pre
+            rows += [[po, d, P, 0], [o, d + P, L - P, 0]]
+        else:
+            rows.append([o, d, L, 0])
+    return rows
+
+
 class BatchDecoder:
     """Greedy decode of up to 32 sequences at once: the weights are streamed ONCE per step for all sequences
     (fo1_gemv_batch_bf16), 5 launches per layer, and the whole step — embedding gather, 36 layers, lm_head, argmax, stop check,
@@ -491,7 +570,7 @@ class BatchDecoder:
             self.ids = torch.zeros(B, self.IDS_CAP, dtype=torch.int32, device=dev)
             self.done = torch.zeros(1, dtype=torch.int32, device=dev)
             self.stop = torch.zeros(self.MAX_STOP, dtype=torch.int32, device=dev)
-            self.reloc = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+            self.reloc = torch.zeros(2 * B, 4, dtype=torch.int32, device=dev)      # (a shared-prefix sequence moves in two pieces)
         self.n_stop = 0
         self.dk = self.dvt = None
         self.rows = 0
@@ -542,18 +621,19 @@ class BatchDecoder:
         self._rope_id = rope_id
         self.B, self.slot = B, slot
         self.len0, self.steps = max(L for _, L, *_ in seqs), 0      # host-side bound on any sequence's keys: len0 + steps + 1
-        reloc = torch.tensor([[o, b * slot, L, 0] for b, (o, L, *_) in enumerate(seqs)], dtype=torch.int32)
+        reloc = torch.tensor(reloc_rows(seqs, [b * slot for b in range(B)]), dtype=torch.int32)
+        nr = reloc.shape[0]
         state = torch.tensor([[b * slot + L, L + d, b * slot, 0, 0, max_new, 0, 0] for b, ((o, L, *_), d) in enumerate(zip(seqs, deltas))],
                              dtype=torch.int32)
         stop = torch.tensor(stop_ids + [0] * (self.MAX_STOP - len(stop_ids)), dtype=torch.int32)
         self.n_stop = len(stop_ids)
-        self.reloc[:B].copy_(reloc, non_blocking=True)
+        self.reloc[:nr].copy_(reloc, non_blocking=True)
         self.state[:B].copy_(state, non_blocking=True)
         self.stop.copy_(stop, non_blocking=True)
         self._keep = [reloc, state, stop]                 # sources of the async uploads stay alive
         self.done.zero_()
         with ops.workspace_scope(self._ws_owner):
-            ops.kv_relocate(llm.kcache, self.dk, llm.vtcache, self.dvt, self.reloc[:B], max(L for _, L, *_ in seqs))
+            ops.kv_relocate(llm.kcache, self.dk, llm.vtcache, self.dvt, self.reloc[:nr], max(L for _, L, *_ in seqs))
             ops.decode_argmax_accept(None, first_tokens.to(torch.int32).contiguous(), self.state[:B], self.plan[:B], self.ids[:B],
                                      self.stop[:self.n_stop], self.done)
 
@@ -706,7 +786,7 @@ class DecodePool:
             self.ids = torch.zeros(P, self.IDS_CAP, dtype=torch.int32, device=dev)
             self.done = torch.zeros(1, dtype=torch.int32, device=dev)
             self.stop = torch.zeros(self.MAX_STOP, dtype=torch.int32, device=dev)
-            self.reloc = torch.zeros(P, 4, dtype=torch.int32, device=dev)
+            self.reloc = torch.zeros(2 * P, 4, dtype=torch.int32, device=dev)     # (a shared-prefix sequence moves in two pieces)
         self.stop_ids: Optional[tuple] = None
         self.n_stop = 0
         self.slot_rows = 0
@@ -779,10 +859,9 @@ class DecodePool:
         self.free.sort()
         slots = [self.free.pop(0) for _ in range(B)]
         R = self.slot_rows
-        reloc = torch.tensor([[o, s * R, L, 0] for s, (o, L, *_) in zip(slots, seqs)], dtype=torch.int32)
         state = torch.tensor([[s * R + L, L + d, s * R, 0, 0, max_new, 0, 0] for s, (_, L, *_), d in zip(slots, seqs, deltas)], dtype=torch.int32)
         first = first_tokens.to(torch.int32).contiguous()
-        self._keep += [reloc, state]
+        self._keep += [state]
         if len(self._keep) > 64:
             del self._keep[:len(self._keep) - 64]
         # contiguous runs of slots: one relocate + one accept launch per run
@@ -793,9 +872,12 @@ class DecodePool:
                 while j + 1 < B and slots[j + 1] == slots[j] + 1:
                     j += 1
                 a, n = slots[i], j - i + 1
-                self.reloc[a:a + n].copy_(reloc[i:j + 1], non_blocking=True)
+                reloc = torch.tensor(reloc_rows(seqs[i:j + 1], [s * R for s in slots[i:j + 1]]), dtype=torch.int32)
+                nr = reloc.shape[0]                      # <= 2 n: the run's entries live at rows [2 a, 2 a + nr) of the device table
+                self._keep.append(reloc)
+                self.reloc[2 * a:2 * a + nr].copy_(reloc, non_blocking=True)
                 self.state[a:a + n].copy_(state[i:j + 1], non_blocking=True)
-                ops.kv_relocate(kcache, self.dk, vtcache, self.dvt, self.reloc[a:a + n], max(L for _, L, *_ in seqs[i:j + 1]))
+                ops.kv_relocate(kcache, self.dk, vtcache, self.dvt, self.reloc[2 * a:2 * a + nr], max(L for _, L, *_ in seqs[i:j + 1]))
                 ops.decode_argmax_accept(None, first[i:j + 1], self.state[a:a + n], self.plan[a:a + n], self.ids[a:a + n],
                                          self.stop[:self.n_stop], self.done)
                 i = j + 1

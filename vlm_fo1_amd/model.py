@@ -369,6 +369,8 @@ class FO1Engine:
     DECODE_GROUPS = 1      # minimum number of decode groups when a pass has more sequences than one group holds
     DECODE_MAX_GROUP = 32  # sequences per decode group (<= BatchDecoder.MAX_BATCH); 16 = round 2's one-MFMA-column-group decode (A/B)
     RAGGED_TOWERS = True   # images of different sizes share one DaViT / SimpleFPN pass (False: image by image, the round-2 path; A/B)
+    SHARE_PREFIX = True    # prompts over ONE image (`image_id`) run their common prefix rows (system text + image tokens) through the LLM once
+                           # (llm.plan_batch(share_prefix=True), fo1_attention_prefix_bf16); False: every prompt's full rows (round 3; A/B)
     GRAPH_CACHE = 8        # captured prefill graphs kept per engine (LRU); each holds its own activation pool
     CAPTURE_AFTER = 1      # sightings of a signature before it is captured: one-off shapes (a dataset of ragged images) run eagerly
 
@@ -412,7 +414,8 @@ class FO1Engine:
         for i in first_of:
             tok_base.append(o)
             o += n_img[i]
-        hp = self.llm.plan_batch(prompts, n_img, n_reg, [(g[0] // m, g[1] // m) for g in grids], img_base=[tok_base[u] for u in img_of])
+        hp = self.llm.plan_batch(prompts, n_img, n_reg, [(g[0] // m, g[1] // m) for g in grids], img_base=[tok_base[u] for u in img_of],
+                                 share_prefix=self.SHARE_PREFIX and U < B)
         if self.llm.reserve(hp["rows"]):
             # the caches moved (cache_epoch bumped): every captured pass holds dead pointers and is unreachable by key — release the
             # graphs and their private activation pools now instead of waiting for 8 new captures to evict them
@@ -465,12 +468,18 @@ class FO1Engine:
             with ops.graph_lock.replay():
                 g.replay()
         outs = []
-        for i, (o, L, Lp) in enumerate(hp["seqs"]):
+        for i, (o, L, Lp, *pre) in enumerate(hp["seqs"]):
             r0, r1 = res["region_ranges"][i]
             i0 = res["row0"][img_of[i]] // (m * m)
+            if not pre:
+                emb = res["embeds"][o:o + L]
+            elif ent is None:     # a prompt whose prefix rows are shared: its embedding rows are two pieces (assembled for introspection only,
+                emb = torch.cat([res["embeds"][pre[0]:pre[0] + pre[1]], res["embeds"][o:o + L - pre[1]]], 0)     # never under graph replay)
+            else:
+                emb = None
             outs.append(dict(image_tokens=res["image_tokens"][i0:i0 + n_img[i]],
                              region_tokens=res["region_tokens"][r0:r1] if res["region_tokens"] is not None and want[i] else None,
-                             embeds=res["embeds"][o:o + L], last_hidden=res["last_hidden"][i:i + 1], logits=res["logits"][i:i + 1],
+                             embeds=emb, last_hidden=res["last_hidden"][i:i + 1], logits=res["logits"][i:i + 1],
                              next_token=res["next_tokens"][i:i + 1], position_ids=hp["pos"][i], rope_delta=hp["delta"][i],
                              cache_rows=(o, L)))
         self._last_batch = hp

@@ -818,7 +818,8 @@ def gather_rows_into(plan: torch.Tensor, D: int, table: torch.Tensor, out: torch
 
 def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_q_heads: int,
                       n_kv_heads: int, head_dim: int, scale: float, causal: bool, flops: float = 0.0,
-                      out: Optional[torch.Tensor] = None, q_row_base: Optional[torch.Tensor] = None, n_items: Optional[int] = None) -> torch.Tensor:
+                      out: Optional[torch.Tensor] = None, q_row_base: Optional[torch.Tensor] = None, n_items: Optional[int] = None,
+                      prefix_ranges: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Attention against a KV cache.  q [Lq, n_q_heads*head_dim] holds absolute positions q_row0 .. q_row0+Lq (the
     items index absolute positions) — or, with `q_row_base` (device int32 scalar), positions *q_row_base + row so a
     captured graph can serve every decode step.  k is the cache [n_kv, Lmax, head_dim], vt the transposed V cache
@@ -833,6 +834,14 @@ def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.T
     po, ldo, _, _ = _rows(out, "out")
     if q_row_base is not None:
         q_row0 = 0
+    if prefix_ranges is not None:      # items with a second (shared-prefix) key range: fo1_attention_prefix_bf16
+        assert prefix_ranges.dtype == torch.int32 and prefix_ranges.is_contiguous() and prefix_ranges.shape == (items.shape[0], 2) and q_row_base is None
+        rc = _L.load().fo1_attention_prefix_bf16(pq - q_row0 * ldq * 2, ldq, head_dim, k.data_ptr(), k.stride(1), k.stride(0), pv, ldv,
+                                                 po - q_row0 * ldo * 2, ldo, head_dim, items.data_ptr(), prefix_ranges.data_ptr(), items.shape[0],
+                                                 getattr(items, "q_block", 64), n_q_heads, n_kv_heads, head_dim, float(scale), 1 if causal else 0,
+                                                 float(flops), _stream())
+        _L.check(rc, "fo1_attention_prefix_bf16")
+        return out
     rc = _L.load().fo1_attention_bf16(pq - q_row0 * ldq * 2, ldq, head_dim, k.data_ptr(), k.stride(1), k.stride(0), pv, ldv,
                                       po - q_row0 * ldo * 2, ldo, head_dim, items.data_ptr(),
                                       n_items if n_items is not None else items.shape[0], getattr(items, "q_block", 64),

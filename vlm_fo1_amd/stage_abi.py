@@ -142,7 +142,8 @@ class LlmStage:
         L = _lib.load()
         llm, c = self.llm, self.llm.cfg
         dev = embeds.device
-        items, flops = llm.packed_items(seqs)
+        items, flops, prefix_ranges = llm.packed_items(seqs)
+        assert prefix_ranges is None, "fo1_llm_prefill takes plain work items (QwenLLM.prefill_packed keeps shared-prefix passes on the primitive path)"
         R, B = embeds.shape[0], last_plan.shape[0]
         last = torch.empty(B, c.hidden_size, dtype=torch.bfloat16, device=dev)
         logits = torch.empty(B, self.W.vocab, dtype=torch.bfloat16, device=dev)
