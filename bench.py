@@ -58,7 +58,7 @@ def build_workload(device, n_boxes=100, img_hw=(480, 640), seed=1234, lift_cap=F
     if device is not None:
         case["dev"] = dict(pix=pix.to(device), aux=aux.to(device), boxes=b.to(device))
     if n_boxes > 100 and not lift_cap:
-        case["prompts"] = [(synthetic_prompt(min(100, n_boxes - k), n_text=60, seed=seed + k), b[k:k + 100]) for k in range(0, n_boxes, 100)]
+        case["prompts"] = [(synthetic_prompt(min(100, n_boxes - k), n_text=60, seed=seed + k, lead_seed=seed), b[k:k + 100]) for k in range(0, n_boxes, 100)]     # one preamble per image, another question per prompt
     return case
 
 

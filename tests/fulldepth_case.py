@@ -78,5 +78,6 @@ def build_case(name: str):
     groups = []
     for k in range(0, boxes.shape[0], 100):
         b = boxes[k:k + 100]
-        groups.append((synthetic_prompt(b.shape[0], n_text=60, seed=c["seed"] + k), b))
+        groups.append((synthetic_prompt(b.shape[0], n_text=60, seed=c["seed"] + k, lead_seed=c["seed"]), b))     # the prompts of an image share its preamble
+                                                                                                         # (prompt 0, the golden's, is unchanged)
     return dict(name=name, pix=pix, aux=aux, grid=(gh, gw), img_hw=(H, W), boxes=boxes, groups=groups)

@@ -744,13 +744,17 @@ def random_weights(cfg: FO1Config, device="cuda", seed: int = 0) -> Dict[str, Di
     return dict(vit=vit, davit=dav, fpn=fpn, llm=llm, proj=proj)
 
 
-def synthetic_prompt(n_boxes: int, n_text: int = 60, vocab: int = 151936, seed: int = 0) -> List[int]:
+def synthetic_prompt(n_boxes: int, n_text: int = 60, vocab: int = 151936, seed: int = 0, lead_seed: Optional[int] = None) -> List[int]:
     """Sentinel id sequence of the reference's prompt layout (mm_utils.py:504-521): system/user preamble,
     <image>, then per region one index token + one <regionfeat>, then the question.  No tokenizer is
-    available offline, so text ids are seeded randoms (SURVEY §8d 'Prompt')."""
+    available offline, so text ids are seeded randoms (SURVEY §8d 'Prompt').  `lead_seed`: the seed of the 18 preamble ids — several
+    prompts over one image carry the SAME preamble (system text, `<|im_start|>user`, `<|vision_start|>`: mm_utils.py:559-575) and
+    differ in the regions and the question that follow."""
     g = torch.Generator().manual_seed(seed)
     ids = torch.randint(1000, vocab - 1000, (n_text,), generator=g).tolist()
     pre, post = ids[:18], ids[18:]
+    if lead_seed is not None and lead_seed != seed:
+        pre = torch.randint(1000, vocab - 1000, (n_text,), generator=torch.Generator().manual_seed(lead_seed)).tolist()[:18]
     seq = pre + [IMAGE_TOKEN_INDEX] + [post[0]]
     for i in range(n_boxes):
         seq += [2000 + i, DEFAULT_REGION_INDEX]
