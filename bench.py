@@ -357,9 +357,12 @@ def hires_run(pipe, steps=6, images=4):
         return (time.perf_counter() - t0) / steps
 
     t_bf16 = timed()
+    full_rows = sum(len(r["ids"]) - 1 + (r["grid"][0] // 2) * (r["grid"][1] // 2) for r in reqs)
     out = dict(workload="BASELINE configs[4] geometry: 1344x1344 (S=9216 patches) x 300 proposals as 3 prompts of 100 over one image, prefill to the "
                         "first greedy token of every prompt", images_per_pass=images, prompts_per_pass=len(reqs), passes_in_flight=R,
-               llm_rows_per_pass=sum(len(r["ids"]) - 1 + (r["grid"][0] // 2) * (r["grid"][1] // 2) for r in reqs),
+               llm_rows_per_pass=int(pipe.eng._last_batch["rows"]), llm_rows_per_pass_without_prefix_sharing=full_rows,
+               prefix_sharing="the prompts of an image run their common rows (preamble + image tokens) through the LLM once (FO1Engine.SHARE_PREFIX, "
+                              "fo1_attention_prefix_bf16); the reference runs the whole model once per prompt",
                bf16=dict(images_per_sec=round(images / t_bf16, 2), ms_per_pass=round(t_bf16 * 1e3, 2), dtype="bf16"))
     n = pipe.eng.enable_fp8("all")
     for e in pipe.engs[1:]:

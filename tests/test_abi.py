@@ -52,7 +52,7 @@ def test_product_library_has_no_switches_and_the_ab_build_has_exactly_the_two_he
     import subprocess
     for so, want in (("libfo1hip.so", False), ("libfo1hip_ab.so", True)):
         blob = open(os.path.join(ROOT, "vlm_fo1_amd", so), "rb").read()
-        for kernel in (b"gemm_bt_p8_kernel", b"gemm_bt_p4p_kernel", b"attn_decode_wg_kernel", b"gemv_batch_kernel", b"hfre_pool_kernel"):
+        for kernel in (b"gemm_bt_p8_kernel", b"gemm_bt_p4p_kernel", b"attn_decode_wg_kernel", b"gemv_batch_kernel", b"hfre_pool_kernel", b"hfre_pool_bands_kernel"):
             assert (kernel in blob) == want, f"{kernel.decode()} {'missing from' if want else 'present in'} {so}"
 
 
