@@ -960,11 +960,11 @@ class DecodePool:
         """Sequences that had finished when `snap` was taken (and have not been collected yet): [(slot, tag, ids)]; their slots are free again."""
         st, ids, ev, live_then = snap[:4]
         ev.synchronize()
+        fin, ngen = st[:, 3].tolist(), st[:, 4].tolist()          # one host read of the pinned snapshot, not two per live slot
         out = []
         for s, tag in live_then.items():
-            if s in self.live and self.live[s] is tag and int(st[s, 3]) == 1:
-                n = int(st[s, 4])
-                out.append((s, tag, ids[s, :n].tolist()))
+            if s in self.live and self.live[s] is tag and fin[s] == 1:
+                out.append((s, tag, ids[s, :ngen[s]].tolist()))
                 del self.live[s]
                 self.free.append(s)
         return out
