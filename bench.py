@@ -555,10 +555,10 @@ def hfre_algorithmic_bytes(case, region_dim=5888, P=7):
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r03_pmc_traffic.json, written by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs with the
+    (profiles/r04_pmc_traffic.json, written by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs with the
     gfx950 x2 FETCH correction of MI355X_MICROARCH.md applied).  PMC counters cannot be read from inside the process, so the
     bench line carries the committed figure and names its source; null when no PMC pass exists for the kernel."""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):     # newest pass that has the kernel
+    for name in ("r04_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):     # newest pass that has the kernel
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as f:
