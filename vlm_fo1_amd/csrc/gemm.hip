@@ -1174,12 +1174,19 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
 // (E8M0 127) — twice the K per MFMA at twice the rate: 16 MFMAs of 64 cycles per K tile where bf16 issues 32 of 32 cycles, so the DMA
 // schedule and every wait count carry over.  A lane's 32 operand bytes are two 16-B slots of the same swizzled LDS image; A and B
 // fragments are read the same way, so the operands' common k order inside a lane does not matter.
-template <int EPI, bool FP8 = false>
+// ABL (A/B build only, scripts/gemm_loop_ablation.py): main-loop ablations for timing — 1 = no LDS-DMA issue inside the loop, 2 = no fragment
+// reads inside the loop, 4 = no barriers inside the loop, 8 = no vmcnt waits inside the loop, 16 = every DMA piece from K tile 0 (L2-hot), 32 = half of a wave's DMA pieces issued in its load-Y segment
+// (results valid).  The results of an ablated launch are garbage by construction.
+template <int EPI, bool FP8 = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, ES = FP8 ? 1 : 2, BK = 128 / ES;
     using frag_t = std::conditional_t<FP8, v8i32, bf16x8>;
     constexpr int NKS = FP8 ? 2 : 4;                    // MFMA k-steps per K tile
     constexpr int GROUP = 16384, BUFSZ = 4 * GROUP;       // A0 | A1 | B0 | B1
+    // LY (A/B only, ABL & 32): four of a wave's eight DMA pieces per K tile ride in load-Y (8 fragment reads, half a segment of slack) and two
+    // in each MFMA segment instead of four.  Measured equal to the product placement on every pass shape (profiles/r04_gemm_loop_ablation_*.json):
+    // what the DMA costs the K loop (22-28 %) does not depend on which wave issues a piece or when.
+    constexpr bool LY = !FP8 && (ABL & 32) != 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUFSZ]
 
     int tm, tn;
@@ -1194,10 +1201,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     const char* A = reinterpret_cast<const char*>(p.A) + bz * p.sA * ES;
     const char* W = reinterpret_cast<const char*>(p.W) + bz * p.sW * ES;
 
-    // per-lane source of each DMA piece.  FP8: 32-bit byte offsets from the (uniform) matrix bases — the 8 x 8-byte pointers are what
-    // pushes that variant (8-register operand tuples) over 256 VGPRs; fo1_gemm_fp8 bounds the matrices to 4 GB
-    using src_t = std::conditional_t<FP8, uint32_t, const char*>;
-    src_t src[4][2];
+    // per-lane source of each DMA piece: a 32-bit byte offset from a wave-uniform base.  bf16: the base is this workgroup's first A / W row
+    // (+ the K tile), so the offset spans at most 255 rows; the piece is issued in the saddr form (SGPR base pair + one offset VGPR) from
+    // inline asm — hipcc selects the 64-bit-VGPR form for __builtin_amdgcn_global_load_lds, whose address pair it rebuilds with a
+    // v_lshl_add_u64 per piece IN an operand register the MFMAs before it still read (measured, profiles/r04_gemm_loop_ablation*.json:
+    // the DMA issue, not its data, cost 22-28 % of the K loop).  FP8: offsets from the matrix bases (fo1_gemm_fp8 bounds them to 4 GB).
+    uint32_t src[4][2];
+    const char* At = A + (FP8 ? 0ll : (long long)m0 * p.lda * ES);
+    const char* Wt = W + (FP8 ? 0ll : (long long)n0 * p.ldw * ES);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -1207,33 +1218,44 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
             if (g < 2) {
                 int gm = m0 + (lr >> 6) * 128 + g * 64 + (lr & 63);
                 gm = gm < p.M ? gm : p.M - 1;
-                if constexpr (FP8) src[g][i] = (uint32_t)gm * (uint32_t)p.lda + cs; else src[g][i] = A + (long long)gm * p.lda * ES + cs;
+                src[g][i] = (uint32_t)(FP8 ? gm : gm - m0) * (uint32_t)(p.lda * ES) + cs;
             } else {
                 int gn = n0 + (lr >> 5) * 64 + (g - 2) * 32 + (lr & 31);
                 gn = gn < p.N ? gn : p.N - 1;
-                if constexpr (FP8) src[g][i] = (uint32_t)gn * (uint32_t)p.ldw + cs; else src[g][i] = W + (long long)gn * p.ldw * ES + cs;
+                src[g][i] = (uint32_t)(FP8 ? gn : gn - n0) * (uint32_t)(p.ldw * ES) + cs;
             }
         }
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) char*)smem;
     const int nk_all = p.K / BK;
     const int kt0 = blockIdx.z * p.kper;
     const int nk = (p.debug & 16) ? 1 : min(nk_all - kt0, p.kper);      // (ablation: one K tile = prologue + epilogue only)
-    auto stage = [&](int g, int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            char* dst = smem + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;
-            const src_t so = g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i];
-            const char* s;
+    auto piece = [&](int g, int i, int kt, int buf) __attribute__((always_inline)) {
+        {
+            const uint32_t so = g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i];
+            const char* ub = (g < 2 ? At : Wt) + (long long)((ABL & 16) ? 0 : kt0 + kt) * 128;
             if constexpr (FP8) {
-                // uniform base (+ K-tile offset) in SGPRs, the lane's 32-bit offset in one VGPR: the saddr form of global_load_lds.
+                // uniform base (+ K-tile offset) in SGPRs, the lane's 32-bit offset in one VGPR.
                 // The empty asm keeps hipcc from re-associating this into eight hoisted 64-bit per-lane pointers.
-                const char* ub = (g < 2 ? A : W) + (long long)(kt0 + kt) * 128;
+                char* dst = smem + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;
                 asm volatile("" : "+s"(ub));
-                s = ub + so;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + so),
+                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
             } else {
-                s = so + (long long)(kt0 + kt) * 128;
+                const uint32_t dst = lds0 + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;     // M0 = the piece's LDS base
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(so), "s"(ub), "s"(dst) : "memory");
             }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    auto stage = [&](int g, int kt, int buf) __attribute__((always_inline)) {
+        piece(g, 0, kt, buf);
+        piece(g, 1, kt, buf);
+    };
+    // one piece pinned between two MFMA pairs of a segment (the compiler otherwise bunches the segment's four pieces behind its first MFMA)
+    auto pinned = [&](bool on, int g, int i, int kt, int buf) __attribute__((always_inline)) {
+        if (on) {
+            __builtin_amdgcn_sched_barrier(0);
+            piece(g, i, kt, buf);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -1262,18 +1284,34 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     stage(0, 0, 0); stage(2, 0, 0); stage(3, 0, 0); stage(1, 0, 0);
     if (nk > 1) {
         stage(0, 1, 1); stage(2, 1, 1);
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if constexpr (LY) {     // LY: B1 of tile 1 too (only A1 is issued in MFMA-X(0))
+            stage(3, 1, 1);
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     FO1_P8_BARRIER();
     if (late) FO1_P8_BARRIER();
     FO1_GEMM_STAMP(1);
+    if constexpr ((ABL & 2) != 0 && !FP8) {     // ablation: the fragments are read once, from tile 0
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+            for (int fm = 0; fm < 2; ++fm) areg[fm][ks] = *reinterpret_cast<const bf16x8*>(smem + a_off[fm] + (((ks * 2 + hi) ^ a_sw[fm]) << 4));
+#pragma unroll
+            for (int h = 0; h < 2; ++h) breg[h][ks] = *reinterpret_cast<const bf16x8*>(smem + (2 + h) * GROUP + b_off + (((ks * 2 + hi) ^ b_sw) << 4));
+        }
+    }
 
-    auto tile = [&](auto BUFC, int t) {
+    // STEADY: both later tiles exist — no branch around any DMA piece, wait or barrier (the K loop proper); the last two tiles run the general form
+    auto tile = [&](auto BUFC, auto STEADYC, int t) {
         constexpr int BUF = decltype(BUFC)::value;
+        constexpr bool STEADY = decltype(STEADYC)::value;
         const char* base = smem + BUF * BUFSZ;
-        const bool more1 = t + 1 < nk, more2 = t + 2 < nk;
+        const bool more1 = STEADY || t + 1 < nk, more2 = STEADY || t + 2 < nk;
         // FP8: every fragment address derives from ONE register per operand (row * 128 + ((hi * 2) ^ swizzle) * 16): the k-step flips
         // bit 6, the second 16-B slot bit 4, groups / buffers / the second 32-row block are constants.  The empty asm makes the
         // base opaque per use — otherwise hipcc keeps all ~40 derived addresses live in registers and spills (a reload waits
@@ -1287,6 +1325,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
             return v8i32{(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)up.x, (int)up.y, (int)up.z, (int)up.w};
         };
         auto loadA = [&](int h) {
+            if constexpr ((ABL & 2) != 0) return;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -1296,6 +1335,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
                 }
         };
         auto loadB = [&](int h) {
+            if constexpr ((ABL & 2) != 0) return;
 #pragma unroll
             for (int ks = 0; ks < NKS; ++ks) {
                 if constexpr (FP8) breg[h][ks] = frag8(b_base8, BUF * BUFSZ + (2 + h) * GROUP, ks);
@@ -1306,15 +1346,31 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
             if constexpr (FP8) c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b, a, c, 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
             else c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, c, 0, 0, 0);
         };
+        // 16 MFMAs (4 K steps x 2 x 2 fragments) of A half AH with pinned DMA pieces: group gA after the 2nd MFMA of K steps 0 and 1 (LY: of
+        // K steps 0 and 2), group gB (if >= 0) after that of K steps 2 and 3
+        auto segment = [&](auto AHC, bool on, int gA, int gB, int kt, int buf) __attribute__((always_inline)) {
+            constexpr int AH = decltype(AHC)::value;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mm(breg[i >> 1][ks], areg[i & 1][ks], acc[AH * 2 + (i & 1)][i >> 1]);
+                    if (i == 1) {
+                        if (gB >= 0) pinned(on, ks < 2 ? gA : gB, ks & 1, kt, buf);
+                        else if (!(ks & 1)) pinned(on, gA, ks >> 1, kt, buf);
+                    }
+                }
+            }
+        };
         auto end_load = [&]() {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            FO1_P8_BARRIER();
+            if constexpr (!(ABL & 4)) FO1_P8_BARRIER();
             __builtin_amdgcn_sched_barrier(0);
         };
         auto end_mfma = [&](bool last) {
             __builtin_amdgcn_sched_barrier(0);
-            if (!(last && late)) FO1_P8_BARRIER();
+            if (!(ABL & 4) && !(last && late)) FO1_P8_BARRIER();
             __builtin_amdgcn_sched_barrier(0);
         };
 #define FO1_P4_MFMA2A(AH, KS)                                     \
@@ -1329,46 +1385,51 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         loadB(1);
         loadA(0);
         // A1 of this tile (issued in MFMA-X(t-1)) must have landed before load-Y; only MFMA-Y(t-1)'s A0, B0 of tile t+1 are newer
-        if (more1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // (LY: behind A1(t) sit A0, B0 [load-Y(t-1)] and B1 [MFMA-Y(t-1)] of tile t+1)
+        if constexpr (!(ABL & 8)) {
+            if (more1) { if constexpr (LY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         end_load();
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8) {
             FO1_P4_MFMA2A(0, 0)
-            if (more1) stage(3, t + 1, BUF ^ 1);
+            if (!(ABL & 1) && more1) stage(3, t + 1, BUF ^ 1);
             FO1_P4_MFMA2B(0, 0)
             FO1_P4_MFMA2A(0, 1)
-            if (more1) stage(1, t + 1, BUF ^ 1);
+            if (!(ABL & 1) && more1) stage(1, t + 1, BUF ^ 1);
             FO1_P4_MFMA2B(0, 1)
         } else {
-            FO1_P4_MFMA4(0, 0)
-            if (more1) stage(3, t + 1, BUF ^ 1);
-            FO1_P4_MFMA4(0, 1)
-            FO1_P4_MFMA4(0, NKS - 2)
-            if (more1) stage(1, t + 1, BUF ^ 1);
-            FO1_P4_MFMA4(0, NKS - 1)
+            if constexpr (LY) segment(std::integral_constant<int, 0>{}, !(ABL & 1) && more1, 1, -1, t + 1, BUF ^ 1);     // A1(t+1)
+            else segment(std::integral_constant<int, 0>{}, !(ABL & 1) && more1, 3, 1, t + 1, BUF ^ 1);
         }
         __builtin_amdgcn_s_setprio(0);
         end_mfma(false);
         // ---- phase Y ----
         loadA(1);
-        if (more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        if constexpr (LY) {
+            // A0, B0 of tile t+2 into THIS buffer: both wave halves read those groups in load-X(t), at least one barrier ago.  A0, B0, B1 of
+            // tile t+1 must have landed for load-X(t+1): behind them sit A1(t+1) [MFMA-X(t)] and these four pieces
+            if (!(ABL & 1) && more2) { stage(0, t + 2, BUF); stage(2, t + 2, BUF); }
+            if constexpr (!(ABL & 8)) {
+                if (more2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else if (more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            }
+        } else {
+            if (!(ABL & 8) && more1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        }
         end_load();
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8) {
             FO1_P4_MFMA2A(1, 0)
-            if (more2) stage(0, t + 2, BUF);
+            if (!(ABL & 1) && more2) stage(0, t + 2, BUF);
             FO1_P4_MFMA2B(1, 0)
             FO1_P4_MFMA2A(1, 1)
-            if (more2) stage(2, t + 2, BUF);
+            if (!(ABL & 1) && more2) stage(2, t + 2, BUF);
             FO1_P4_MFMA2B(1, 1)
         } else {
-            FO1_P4_MFMA4(1, 0)
-            if (more2) stage(0, t + 2, BUF);
-            FO1_P4_MFMA4(1, 1)
-            FO1_P4_MFMA4(1, NKS - 2)
-            if (more2) stage(2, t + 2, BUF);
-            FO1_P4_MFMA4(1, NKS - 1)
+            if constexpr (LY) segment(std::integral_constant<int, 1>{}, !(ABL & 1) && more2, 3, -1, t + 2, BUF);         // B1(t+2)
+            else segment(std::integral_constant<int, 1>{}, !(ABL & 1) && more2, 0, 2, t + 2, BUF);
         }
         __builtin_amdgcn_s_setprio(0);
         end_mfma(!more1);
@@ -1376,9 +1437,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
 #undef FO1_P4_MFMA2A
 #undef FO1_P4_MFMA2B
     };
-    for (int t = 0; t < nk; t += 2) {
-        tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, t + 1);
+    int t = 0;
+    for (; t + 3 < nk; t += 2) {
+        tile(std::integral_constant<int, 0>{}, std::true_type{}, t);
+        tile(std::integral_constant<int, 1>{}, std::true_type{}, t + 1);
+    }
+    for (; t < nk; t += 2) {
+        tile(std::integral_constant<int, 0>{}, std::false_type{}, t);
+        if (t + 1 < nk) tile(std::integral_constant<int, 1>{}, std::false_type{}, t + 1);
     }
     FO1_GEMM_STAMP(2);
     if constexpr (FP8) {
@@ -1745,6 +1811,22 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
         else if (epi == 1) FO1_LAUNCH(np, flops, gemm_bt_p4p_kernel<1>, gp, dim3(512), smem_p, st, p);
         else if (epi == 2) FO1_LAUNCH(np, flops, gemm_bt_p4p_kernel<2>, gp, dim3(512), smem_p, st, p);
         else FO1_LAUNCH(np, flops, gemm_bt_p4p_kernel<3>, gp, dim3(512), smem_p, st, p);
+        return FO1_OK;
+    }
+#endif
+#ifdef FO1_ENABLE_AB
+    if (g_gemm_big_sched == 1 && epi == 0 && (p.debug >> 6) & 63) {      // main-loop ablations (debug bits 6-8 = ABL), timing only
+        const int abl = (p.debug >> 6) & 63;
+#define FO1_ABL_CASE(V)                                                                                                                   \
+    case V: {                                                                                                                             \
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<0, false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
+        FO1_LAUNCH("gemm_bt_p4_ablated", flops, (gemm_bt_p4_kernel<0, false, V>), grid, dim3(512), smem, st, p);                          \
+    } break;
+        switch (abl) {
+            FO1_ABL_CASE(1) FO1_ABL_CASE(2) FO1_ABL_CASE(4) FO1_ABL_CASE(8) FO1_ABL_CASE(16) FO1_ABL_CASE(24) FO1_ABL_CASE(32)
+            default: return set_err(FO1_ERR_ARG, "gemm: no such ablation %d", abl);
+        }
+#undef FO1_ABL_CASE
         return FO1_OK;
     }
 #endif
