@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FO1_ABI_VERSION 4   /* 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 5   /* 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16); 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -236,6 +236,23 @@ int fo1_decode_qkv_post_bf16(void* qkv_row, int n_q_heads, int n_kv_heads, int h
 int fo1_pool_qkv_post_bf16(void* qkv, long long ld, int P, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
                            const void* sin_table, const int32_t* state, void* kcache, long long kcache_head_stride,
                            void* vtcache, long long vt_row_stride, void* stream);
+/* The same fed by the split-K planes of the q/k/v projection (fo1_gemm_bf16_partials below): row b = bf16(sum_z part[z][b] + bias), the
+ * GEMM epilogue's rounding; the rotated q heads go to q_out [P, ld] (the decode attention's query rows), K / V^T straight to the caches. */
+int fo1_pool_qkv_post_partials_bf16(const float* part, int splits, const void* bias, void* q_out, long long ld, int P, int n_q_heads,
+                                    int n_kv_heads, int head_dim, const void* cos_table, const void* sin_table, const int32_t* state,
+                                    void* kcache, long long kcache_head_stride, void* vtcache, long long vt_row_stride, void* stream);
+/* Decode-pool projections as split-K planes (Qwen2_5_VLDecoderLayer's q/k/v, o and down nn.Linear at 33..128 rows, modeling_qwen2_5_vl.py
+ * :636, :700-742): part[z][m][n] (fp32, row stride N) = A[m, K run z] . W[n, K run z], z < *splits_out (the effective count for the requested
+ * `splits`: K tiles of 64 in equal runs).  No epilogue, no reduce launch — a few-row product has too few output tiles to fill 256 CUs, and
+ * its consumer reads the planes anyway:
+ *   fo1_splitk_residual_rmsnorm_bf16   x_out = bf16(bf16(sum_z part[z] (+ bias)) + residual);  xn_out = Qwen2RMSNorm(x_out) * norm_weight
+ *                                      (the residual add of :736 / :742 and the NEXT layernorm, :728 / :739, in the launch that reduces)
+ *   fo1_pool_qkv_post_partials_bf16    above.
+ * K % 64 == 0, N % 4 == 0 (% 8 for the consumers), operands 16-byte aligned, part holds splits * M * N floats. */
+int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* part, int* splits_out,
+                           void* stream);
+int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N, const void* bias, const void* residual, int ldr, void* x_out,
+                                     int ldx, const void* norm_weight, float eps, void* xn_out, int ldn, void* stream);
 /* Weight-streaming GEMV (M <= 4) with the fo1_gemm_bf16 epilogues and an optional fused Qwen2RMSNorm on the input rows
  * (norm_weight [K] or NULL): folds input_layernorm / post_attention_layernorm into the projections of the decode step. */
 int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, int ldr,

@@ -88,6 +88,84 @@ def test_pool_projections_and_qkv_post_match_reference(P, product_library):
     assert kc[:, ~written].abs().max().item() == 0 and vt[:, ~written].abs().max().item() == 0, "cache rows of other positions touched"
 
 
+@pytest.mark.parametrize("P", [64, 128])
+def test_pool_splitk_planes_and_fused_consumers(P, product_library):
+    """fo1_gemm_bf16_partials (fp32 split-K planes, no epilogue) and the two kernels that consume them in the pool step:
+    fo1_splitk_residual_rmsnorm_bf16 — x = bf16(bf16(sum_z plane_z) + residual) EXACTLY (the same fp32 adds in the same order), the fused
+    RMSNorm within one bf16 ulp of torch fp32 — and fo1_pool_qkv_post_partials_bf16 == fo1_pool_qkv_post_bf16 on bf16(sum_z plane_z + bias), bit for bit."""
+    from vlm_fo1_amd import ops
+    g = torch.Generator().manual_seed(23 + P)
+
+    def rnd(*s, sc=1.0):
+        return (torch.randn(*s, generator=g) * sc).to(BF).cuda()
+
+    def planes_of(x, w, splits):
+        N = w.shape[0]
+        part = torch.full((splits * P * N + 64,), float("nan"), dtype=torch.float32, device="cuda")
+        s = ops.gemm_partials(x, w, splits, part)
+        torch.cuda.synchronize()
+        assert 2 <= s <= splits and torch.isnan(part[s * P * N:]).all(), "planes beyond the effective split count written"
+        pl = part[:s * P * N].view(s, P, N)
+        tot = pl[0].clone()
+        for z in range(1, s):
+            tot += pl[z]
+        ref = x.float() @ w.float().t()
+        assert (tot - ref).abs().max().item() <= 2e-5 * K ** 0.5 * ref.abs().max().item(), "sum of the planes != the product"
+        return part, s, tot
+
+    for N, K, splits in ((2048, 2048, 4), (2048, 11008, 8)):          # o / down
+        x, w, res, nw = rnd(P, K), rnd(N, K, sc=0.03), rnd(P, N), (1 + 0.1 * torch.randn(N, generator=g)).to(BF).cuda()
+        part, s, tot = planes_of(x, w, splits)
+        xo, xn = torch.empty(P, N, dtype=BF, device="cuda"), torch.empty(P, N, dtype=BF, device="cuda")
+        ops.splitk_residual_rmsnorm(part, s, res, nw, 1e-6, xo, xn)
+        torch.cuda.synchronize()
+        x_ref = rb(rb(tot) + res.float())
+        assert torch.equal(xo.float(), x_ref), f"x_out {N}x{K}"
+        rstd = torch.rsqrt((x_ref.double() ** 2).mean(-1, keepdim=True) + 1e-6).float()
+        _close(xn, rb(nw.float() * rb(x_ref * rstd)), f"fused RMSNorm {N}x{K}")
+        # in place on the residual buffer, as the pool step calls it
+        res2 = res.clone()
+        ops.splitk_residual_rmsnorm(part, s, res2, nw, 1e-6, res2, xn)
+        torch.cuda.synchronize()
+        assert torch.equal(res2, xo), "in-place x_out"
+    H, KV, HD, K, rows = 16, 2, 128, 2048, 1024
+    x, w, b = rnd(P, K), rnd((H + 2 * KV) * HD, K, sc=0.05), rnd((H + 2 * KV) * HD, sc=0.1)
+    ang = torch.rand(rows, HD, generator=g) * 6.28
+    cos, sin = ang.cos().to(BF).cuda(), ang.sin().to(BF).cuda()
+    st = torch.zeros(P, 8, dtype=torch.int32)
+    st[:, 0] = torch.arange(P) * 7 + 3
+    st[:, 1] = 900 - 5 * torch.arange(P)
+    st = st.cuda()
+    part, s, tot = planes_of(x, w, 4)
+    q = torch.zeros(P, H * HD, dtype=BF, device="cuda")
+    kc, vt = torch.zeros(KV, rows, HD, dtype=BF, device="cuda"), torch.zeros(KV * HD, rows, dtype=BF, device="cuda")
+    ops.pool_qkv_post_partials(part, s, b, q, H, KV, HD, cos, sin, st, kc, vt)
+    qkv_ref = (tot + b.float()).to(BF)
+    kc2, vt2 = torch.zeros_like(kc), torch.zeros_like(vt)
+    ops.pool_qkv_post(qkv_ref, H, KV, HD, cos, sin, st, kc2, vt2)
+    torch.cuda.synchronize()
+    assert torch.equal(q, qkv_ref[:, :H * HD]) and torch.equal(kc, kc2) and torch.equal(vt, vt2), "q rows / K rows / V^T columns"
+
+
+def test_pool_fused_splitk_step_against_unfused(product_library):
+    """The pool step with split-K planes + fused consumers (9 launches per layer) against the same step on plain GEMM epilogues + separate
+    RMSNorm launches (11): other fp32 sum orders in q/k/v and o, so ids may differ at near-ties only."""
+    from vlm_fo1_amd.llm import DecodePool
+    cfg, weights, eng = _engine()
+    reqs = _requests(9)
+    eng.prefill_batch(reqs, use_graph=False)
+    hp, first = eng._last_batch, eng._last_next_tokens.clone()
+    K = 12
+    pool = DecodePool(eng.llm, slots=64, slot_rows=512)
+    assert pool.FUSED_SPLITK
+    fused = _pool_run(pool, eng, hp, first, list(range(9)), K)
+    pool2 = DecodePool(eng.llm, slots=64, slot_rows=512)
+    pool2.FUSED_SPLITK = False
+    plain = _pool_run(pool2, eng, hp, first, list(range(9)), K)
+    same = sum(a == b for a, b in zip(fused, plain))
+    assert same >= 7, f"only {same}/9 sequences decode to the same ids with and without the fused split-K consumers"
+
+
 def _engine(seed=31):
     from vlm_fo1_amd.llm import LLMConfig
     from vlm_fo1_amd.model import FO1Config, FO1Engine, random_weights

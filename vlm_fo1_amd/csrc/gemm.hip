@@ -1960,7 +1960,7 @@ static int launch_ring(GemmParams& p, const char* name, double flops, dim3 grid,
 }
 
 template <int BM, int BN>
-static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
+static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st, bool reduce = true) {
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
     const dim3 grid(p.tiles_m * p.tiles_n, batch, glds ? p.splits : 1);
@@ -1985,7 +1985,7 @@ static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
         else if constexpr (BM + BN <= 128) rc = launch_ring<BM, BN, 6>(p, name, flops, grid, st);
         else rc = launch_ring<BM, BN, 4>(p, name, flops, grid, st);
         if (rc != FO1_OK) return rc;
-        if (p.splits > 1) {
+        if (p.splits > 1 && reduce) {
             const long long total = (long long)p.M * (p.N / 4);
             const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
             FO1_LAUNCH("gemm_splitk_reduce", (double)p.M * p.N * 4.0 * p.splits, gemm_splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
@@ -2001,7 +2001,7 @@ static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st) {
             attr_done = true;
         }
         FO1_LAUNCH(name, flops, (gemm_bt_glds_kernel<BM, BN>), grid, dim3(256), smem, st, p);
-        if (p.splits > 1) {
+        if (p.splits > 1 && reduce) {
             const long long total = (long long)p.M * (p.N / 4);
             const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
             FO1_LAUNCH("gemm_splitk_reduce", (double)p.M * p.N * 4.0 * p.splits, gemm_splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
@@ -2181,6 +2181,37 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
     if (g_gemm_gemv && M <= 4 && !out_f32 && (size_t)(M > 2 ? 4 : M) * K * 2 <= 150 * 1024 && (act != 3 || N % 32 == 0))
         return gemv_dispatch(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, (hipStream_t)stream, nullptr, 0.f);
     return gemm_dispatch(p, 1, (hipStream_t)stream, (float*)workspace, workspace_bytes);
+}
+
+// Split-K partial sums only (the decode pool's q/k/v, o and down projections, llm.DecodePool): part[z][m][n] (fp32, row stride N) = the
+// product over the z-th run of K tiles, z < *splits_out = the effective split count for the request (K tiles of 64 dealt in equal runs,
+// the last may be shorter).  No epilogue and no reduce launch: the consumer sums the planes in z order — fo1_splitk_residual_rmsnorm_bf16
+// (+ residual, + the next RMSNorm) or fo1_pool_qkv_post_partials_bf16 (+ bias, RoPE, cache append).  LDS-DMA ring kernel, 64 x 64 tiles
+// (64 x 128 when those alone give a workgroup per CU).
+int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* part, int* splits_out,
+                           void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(A && W && part && splits_out, "gemm_partials: NULL operand");
+    FO1_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 64 == 0 && N % 4 == 0, "gemm_partials: bad shape M=%d N=%d K=%d (K %% 64, N %% 4)", M, N, K);
+    FO1_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K, "gemm_partials: lda / ldw");
+    FO1_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)part & 15) == 0, "gemm_partials: operands must be 16-byte aligned");
+    const int nk = K / 64;
+    FO1_CHECK_ARG(splits >= 2 && splits <= nk && splits <= 64, "gemm_partials: splits=%d (2 .. min(64, K / 64 = %d))", splits, nk);
+    GemmParams p;
+    p.A = (const uint16_t*)A; p.W = (const uint16_t*)W; p.bias = nullptr; p.res = nullptr; p.C = nullptr; p.C32 = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = N; p.ldr = 0; p.act = ACT_NONE;
+    p.sA = p.sW = p.sC = p.sR = 0;
+    p.coal = 0; p.debug = 0; p.stages = 3;
+    p.scale_m = p.scale_n = nullptr;
+    p.kper = cdiv(nk, splits);
+    p.splits = cdiv(nk, p.kper);
+    p.part = part;
+    *splits_out = p.splits;
+    if (p.splits < 2) return set_err(FO1_ERR_ARG, "gemm_partials: K too shallow for %d splits", splits);
+    // (128 x 128 tiles for the 65..128-row down projection — the weights fetched once instead of once per 64-row tile — measured no faster:
+    // 17.4 vs 16.3 us at 12-16 planes, profiles/r04_pool_step_splitk_sweep.json)
+    if ((long long)cdiv(M, 64) * cdiv(N, 128) * p.splits >= 256) return launch_gemm<64, 128>(p, 1, true, (hipStream_t)stream, false);
+    return launch_gemm<64, 64>(p, 1, true, (hipStream_t)stream, false);
 }
 
 // fp8 linear (BASELINE configs[4], "fp8 MFMA"): C[M,N] = epilogue((Aq Wq^T) * scale_a[m] * scale_w[n]) with OCP e4m3 operands, fp32

@@ -117,6 +117,68 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
     }
 }
 
+// Split-K consumer of the decode pool (fo1_gemm_bf16_partials): per row m
+//     x_out[m] = bf16( bf16( sum_z part[z][m] (+ bias) ) + residual[m] )        (the rounding points of the GEMM's own epilogue)
+//     xn_out[m] = RMSNorm(x_out[m]) * w                                         (Qwen2RMSNorm: bf16(x * rstd) * w, as rownorm_kernel<0>)
+// in ONE launch instead of gemm_splitk_reduce + rmsnorm.  One 256-thread workgroup per row, NPER 8-column chunks per thread; the planes
+// are summed in z order and the squares in a fixed tree, so a row's result depends on nothing but that row.  x_out may be the residual
+// buffer itself (every element is read and then written by the same thread).
+template <int NPER>
+__global__ __launch_bounds__(256) void splitk_residual_rmsnorm_kernel(const float* __restrict__ part, int splits, long long plane, int N,
+                                                                      const uint16_t* __restrict__ bias, const uint16_t* res, int ldr,
+                                                                      uint16_t* x_out, int ldx, const uint16_t* __restrict__ w, float eps,
+                                                                      uint16_t* __restrict__ xn_out, int ldn) {
+    __shared__ float wsum[4];
+    const int m = blockIdx.x, tid = threadIdx.x, nchunk = N >> 3;
+    float xv[NPER][8];
+    uint4 wv[NPER];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
+        const int c = tid + i * 256;
+        const bool ok = c < nchunk;
+        const int cc = ok ? c : 0;
+        const float* pr = part + (long long)m * N + cc * 8;
+        float4 a0 = *reinterpret_cast<const float4*>(pr), a1 = *reinterpret_cast<const float4*>(pr + 4);
+        for (int z = 1; z < splits; ++z) {
+            const float4 b0 = *reinterpret_cast<const float4*>(pr + z * plane), b1 = *reinterpret_cast<const float4*>(pr + z * plane + 4);
+            a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+            a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+        }
+        float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        float r[8];
+        unpack8(*reinterpret_cast<const uint4*>(res + (size_t)m * ldr + cc * 8), r);
+        wv[i] = *reinterpret_cast<const uint4*>(w + cc * 8);
+        if (bias) {
+            float bf[8];
+            unpack8(*reinterpret_cast<const uint4*>(bias + cc * 8), bf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += bf[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(v[j])) + r[j]));
+            xv[i][j] = ok ? t : 0.f;
+            ss = fmaf(xv[i][j], xv[i][j], ss);
+        }
+        if (ok) *reinterpret_cast<uint4*>(x_out + (size_t)m * ldx + c * 8) = pack8(xv[i]);
+    }
+    ss = row_sum<64>(ss);
+    if ((tid & 63) == 0) wsum[tid >> 6] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf(((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / (float)N + eps);
+#pragma unroll
+    for (int i = 0; i < NPER; ++i) {
+        const int c = tid + i * 256;
+        if (c >= nchunk) continue;
+        float wf[8], o[8];
+        unpack8(wv[i], wf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = wf[j] * bf16_to_f32(f32_to_bf16(xv[i][j] * rstd));
+        *reinterpret_cast<uint4*>(xn_out + (size_t)m * ldn + c * 8) = pack8(o);
+    }
+}
+
 template <int MODE>
 static int launch_rownorm(const char* name, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int M, int D, float eps,
                           hipStream_t st) {
@@ -444,6 +506,27 @@ int fo1_zero_bytes(void* p, size_t bytes, void* stream) {
     const size_t n16 = bytes / 16;
     const int grid = (int)(n16 / 256 + 1 < 4096 ? n16 / 256 + 1 : 4096);
     FO1_LAUNCH("zero_bytes", (double)bytes, zero16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, (uint4*)p, n16);
+    return FO1_OK;
+}
+
+int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N, const void* bias, const void* residual, int ldr, void* x_out,
+                                     int ldx, const void* norm_weight, float eps, void* xn_out, int ldn, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(part && residual && x_out && norm_weight && xn_out, "splitk_residual_rmsnorm: NULL operand");
+    FO1_CHECK_ARG(M >= 1 && splits >= 1 && N % 8 == 0 && N >= 8 && N <= 8 * 256 * 4, "splitk_residual_rmsnorm: M=%d splits=%d N=%d (N %% 8, <= 8192)", M, splits, N);
+    FO1_CHECK_ARG(ldr % 8 == 0 && ldx % 8 == 0 && ldn % 8 == 0 && ldr >= N && ldx >= N && ldn >= N, "splitk_residual_rmsnorm: row strides");
+    FO1_CHECK_ARG(((uintptr_t)part & 15) == 0 && ((uintptr_t)residual & 15) == 0 && ((uintptr_t)x_out & 15) == 0 && ((uintptr_t)xn_out & 15) == 0 &&
+                      ((uintptr_t)norm_weight & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0), "splitk_residual_rmsnorm: 16-byte alignment");
+    const long long plane = (long long)M * N;
+    const int nper = cdiv(N >> 3, 256);
+#define FO1_SKRN(NP)                                                                                                                        \
+    FO1_LAUNCH("splitk_residual_rmsnorm", (double)M * N * (4.0 * splits + 6.0), splitk_residual_rmsnorm_kernel<NP>, dim3(M), dim3(256), 0,  \
+               (hipStream_t)stream, part, splits, plane, N, (const uint16_t*)bias, (const uint16_t*)residual, ldr, (uint16_t*)x_out, ldx,   \
+               (const uint16_t*)norm_weight, eps, (uint16_t*)xn_out, ldn)
+    if (nper == 1) FO1_SKRN(1);
+    else if (nper == 2) FO1_SKRN(2);
+    else FO1_SKRN(4);
+#undef FO1_SKRN
     return FO1_OK;
 }
 

@@ -180,24 +180,51 @@ __global__ __launch_bounds__(256) void qkv_post_vit_kernel(uint16_t* __restrict_
 // Decode step, one token: mRoPE on the q and k heads of the fused qkv row (in place), append the rotated K heads to
 // the K cache and the V heads (transposed) to the V^T cache, all at the device-side position.  One workgroup.
 // blockIdx.x = sequence of a decode pool (fo1_pool_qkv_post_bf16): row blockIdx.x of qkv [P, ld], state row blockIdx.x.
-template <int HD>
+// PART (fo1_pool_qkv_post_partials_bf16): the row is first built from the split-K planes of fo1_gemm_bf16_partials — bf16(sum_z part[z] + bias),
+// the GEMM epilogue's own rounding — in LDS (at most 4096 columns); only the rotated q heads go back to qkv.
+template <int HD, bool PART = false>
 __global__ __launch_bounds__(256) void decode_qkv_post_kernel(uint16_t* __restrict__ qkv, long long ld, int n_q, int n_kv, const uint16_t* __restrict__ cosb,
                                                               const uint16_t* __restrict__ sinb, const int* __restrict__ st,
                                                               uint16_t* __restrict__ kcache, long long kc_head_stride,
-                                                              uint16_t* __restrict__ vtcache, long long vt_row_stride) {
+                                                              uint16_t* __restrict__ vtcache, long long vt_row_stride,
+                                                              const float* __restrict__ part, int splits, long long plane,
+                                                              const uint16_t* __restrict__ bias) {
     constexpr int HC = HD / 16;
+    __shared__ __attribute__((aligned(16))) uint16_t lrow[PART ? 4096 : 8];
+    const int tid = threadIdx.x;
+    if constexpr (PART) {
+        const int N = (n_q + 2 * n_kv) * HD;
+        const float* pr = part + (long long)blockIdx.x * N;
+        for (int c = tid; c < (N >> 3); c += 256) {
+            float4 a0 = *reinterpret_cast<const float4*>(pr + c * 8), a1 = *reinterpret_cast<const float4*>(pr + c * 8 + 4);
+            for (int z = 1; z < splits; ++z) {
+                const float4 b0 = *reinterpret_cast<const float4*>(pr + z * plane + c * 8), b1 = *reinterpret_cast<const float4*>(pr + z * plane + c * 8 + 4);
+                a0.x += b0.x; a0.y += b0.y; a0.z += b0.z; a0.w += b0.w;
+                a1.x += b1.x; a1.y += b1.y; a1.z += b1.z; a1.w += b1.w;
+            }
+            float v[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            if (bias) {
+                float bf[8];
+                unpack8r(*reinterpret_cast<const uint4*>(bias + c * 8), bf);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += bf[j];
+            }
+            *reinterpret_cast<uint4*>(lrow + c * 8) = pack8r(v);
+        }
+        __syncthreads();
+    }
     qkv += (long long)blockIdx.x * ld;
     st += blockIdx.x * 8;
     const int pos = st[0], row = st[1];
-    const int tid = threadIdx.x;
     const int n_rope = (n_q + n_kv) * HC;
     for (int i = tid; i < n_rope; i += 256) {
         const int c = i % HC, hd = i / HC;
         uint16_t* p = qkv + hd * HD;
+        const uint16_t* ps = PART ? lrow + hd * HD : p;
         const int d0 = c * 8;
         float a[8], b[8], ca[8], sa[8], cb[8], sb[8], oa[8], ob[8];
-        unpack8r(*reinterpret_cast<const uint4*>(p + d0), a);
-        unpack8r(*reinterpret_cast<const uint4*>(p + d0 + HD / 2), b);
+        unpack8r(*reinterpret_cast<const uint4*>(ps + d0), a);
+        unpack8r(*reinterpret_cast<const uint4*>(ps + d0 + HD / 2), b);
         unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)row * HD + d0), ca);
         unpack8r(*reinterpret_cast<const uint4*>(sinb + (long long)row * HD + d0), sa);
         unpack8r(*reinterpret_cast<const uint4*>(cosb + (long long)row * HD + d0 + HD / 2), cb);
@@ -208,15 +235,17 @@ __global__ __launch_bounds__(256) void decode_qkv_post_kernel(uint16_t* __restri
             ob[j] = rb(b[j] * cb[j]) + rb(a[j] * sb[j]);
         }
         const uint4 ua = pack8r(oa), ub = pack8r(ob);
-        *reinterpret_cast<uint4*>(p + d0) = ua;
-        *reinterpret_cast<uint4*>(p + d0 + HD / 2) = ub;
+        if (!PART || hd < n_q) {
+            *reinterpret_cast<uint4*>(p + d0) = ua;
+            *reinterpret_cast<uint4*>(p + d0 + HD / 2) = ub;
+        }
         if (hd >= n_q) {
             uint16_t* kc = kcache + (long long)(hd - n_q) * kc_head_stride + (long long)pos * HD;
             *reinterpret_cast<uint4*>(kc + d0) = ua;
             *reinterpret_cast<uint4*>(kc + d0 + HD / 2) = ub;
         }
     }
-    const uint16_t* v = qkv + (n_q + n_kv) * HD;
+    const uint16_t* v = (PART ? lrow : qkv) + (n_q + n_kv) * HD;
     for (int i = tid; i < n_kv * HD; i += 256) vtcache[(long long)i * vt_row_stride + pos] = v[i];
 }
 
@@ -315,7 +344,8 @@ int fo1_decode_qkv_post_bf16(void* qkv_row, int n_q_heads, int n_kv_heads, int h
     FO1_CHECK_ARG(head_dim == 128, "decode_qkv_post: head_dim %d not built (128)", head_dim);
     FO1_LAUNCH("decode_qkv_post", (double)(n_q_heads + 2 * n_kv_heads) * head_dim * 4.0, decode_qkv_post_kernel<128>, dim3(1), dim3(256), 0,
                (hipStream_t)stream, (uint16_t*)qkv_row, 0LL, n_q_heads, n_kv_heads, (const uint16_t*)cos_table, (const uint16_t*)sin_table,
-               (const int*)state, (uint16_t*)kcache, kcache_head_stride, (uint16_t*)vtcache, vt_row_stride);
+               (const int*)state, (uint16_t*)kcache, kcache_head_stride, (uint16_t*)vtcache, vt_row_stride, (const float*)nullptr, 0, 0LL,
+               (const uint16_t*)nullptr);
     return FO1_OK;
 }
 
@@ -329,7 +359,26 @@ int fo1_pool_qkv_post_bf16(void* qkv, long long ld, int P, int n_q_heads, int n_
     FO1_CHECK_ARG(head_dim == 128 && ld % 8 == 0 && ((uintptr_t)qkv & 15) == 0, "pool_qkv_post: head_dim %d / ld %lld not built (128, ld %% 8)", head_dim, ld);
     FO1_LAUNCH("pool_qkv_post", (double)P * (n_q_heads + 2 * n_kv_heads) * head_dim * 4.0, decode_qkv_post_kernel<128>, dim3(P), dim3(256), 0,
                (hipStream_t)stream, (uint16_t*)qkv, ld, n_q_heads, n_kv_heads, (const uint16_t*)cos_table, (const uint16_t*)sin_table,
-               (const int*)state, (uint16_t*)kcache, kcache_head_stride, (uint16_t*)vtcache, vt_row_stride);
+               (const int*)state, (uint16_t*)kcache, kcache_head_stride, (uint16_t*)vtcache, vt_row_stride, (const float*)nullptr, 0, 0LL,
+               (const uint16_t*)nullptr);
+    return FO1_OK;
+}
+
+// The same fed by the split-K planes of the q/k/v projection (fo1_gemm_bf16_partials): row b = bf16(sum_z part[z][b] + bias); the rotated q
+// heads are written to q_out [P, ld] (the decode attention's query rows), K / V^T go straight to the caches.
+int fo1_pool_qkv_post_partials_bf16(const float* part, int splits, const void* bias, void* q_out, long long ld, int P, int n_q_heads,
+                                    int n_kv_heads, int head_dim, const void* cos_table, const void* sin_table, const int32_t* state, void* kcache,
+                                    long long kcache_head_stride, void* vtcache, long long vt_row_stride, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(part && q_out && cos_table && sin_table && state && kcache && vtcache && P >= 1 && splits >= 1, "pool_qkv_post_partials: NULL operand");
+    FO1_CHECK_ARG(head_dim == 128 && ld % 8 == 0 && ((uintptr_t)q_out & 15) == 0 && ((uintptr_t)part & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 15) == 0),
+                  "pool_qkv_post_partials: head_dim %d / ld %lld not built (128, ld %% 8, 16-byte aligned operands)", head_dim, ld);
+    const int N = (n_q_heads + 2 * n_kv_heads) * head_dim;
+    FO1_CHECK_ARG(N <= 4096 && ld >= n_q_heads * head_dim, "pool_qkv_post_partials: %d fused columns (<= 4096)", N);
+    FO1_LAUNCH("pool_qkv_post_partials", (double)P * N * (4.0 * splits + 2.0), (decode_qkv_post_kernel<128, true>), dim3(P), dim3(256), 0,
+               (hipStream_t)stream, (uint16_t*)q_out, ld, n_q_heads, n_kv_heads, (const uint16_t*)cos_table, (const uint16_t*)sin_table,
+               (const int*)state, (uint16_t*)kcache, kcache_head_stride, (uint16_t*)vtcache, vt_row_stride, part, splits, (long long)P * N,
+               (const uint16_t*)bias);
     return FO1_OK;
 }
 

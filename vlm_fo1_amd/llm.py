@@ -892,6 +892,12 @@ class DecodePool:
         need = max((self.bound[s] for s in self.live), default=1)
         return min(self.slot_rows, -(-need // self.KV_BUCKET) * self.KV_BUCKET)
 
+    # Split-K planes + fused consumers for the few-tile projections (q/k/v: 80 output tiles, o: 64, down: 32 on 256 CUs): the GEMM writes
+    # fp32 planes from >= 256 workgroups and the kernel that needs the result anyway sums them — q/k/v in the RoPE / cache-append kernel, o and
+    # down in ONE kernel with the residual add and the NEXT RMSNorm (9 launches per layer instead of 11, none of them on a quarter of the chip).
+    FUSED_SPLITK = True
+    SPLITS = dict(qkv=4, o=4, down=8)
+
     def _step_device(self, bucket: int):
         llm, P = self.llm, self.P
         c = llm.cfg
@@ -900,14 +906,30 @@ class DecodePool:
         st = self.state
         with ops.workspace_scope(self._ws_owner):
             x = ops.gather_rows(self.plan, c.hidden_size, llm.embed)
-            for li, w in enumerate(llm.layers):
-                qkv = ops.gemm(ops.rmsnorm(x, w["ln1"], c.rms_norm_eps), w["wqkv"], w["bqkv"])
-                ops.pool_qkv_post(qkv, H, KV, HD, llm.rope_cos, llm.rope_sin, st, self.dk[li], self.dvt[li])
-                att = ops.attention_decode_batch(qkv[:, :H * HD], self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
-                x = ops.gemm(att, w["wo"], residual=x)
-                a = ops.gemm(ops.rmsnorm(x, w["ln2"], c.rms_norm_eps), w["wgu"], act=ops.ACT_SWIGLU16)
-                x = ops.gemm(a, w["wdown"], residual=x)
-            logits = ops.gemm(ops.rmsnorm(x, llm.norm, c.rms_norm_eps), llm.lm_head)
+            if self.FUSED_SPLITK:
+                eps, D = c.rms_norm_eps, c.hidden_size
+                part = torch.empty(max(self.SPLITS["qkv"] * (H + 2 * KV) * HD, max(self.SPLITS["o"], self.SPLITS["down"]) * D) * P, dtype=torch.float32, device=x.device)
+                xn = ops.rmsnorm(x, llm.layers[0]["ln1"], eps)
+                q = torch.empty(P, H * HD, dtype=torch.bfloat16, device=x.device)
+                for li, w in enumerate(llm.layers):
+                    s = ops.gemm_partials(xn, w["wqkv"], self.SPLITS["qkv"], part)
+                    ops.pool_qkv_post_partials(part, s, w["bqkv"], q, H, KV, HD, llm.rope_cos, llm.rope_sin, st, self.dk[li], self.dvt[li])
+                    att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
+                    s = ops.gemm_partials(att, w["wo"], self.SPLITS["o"], part)
+                    ops.splitk_residual_rmsnorm(part, s, x, w["ln2"], eps, x, xn)
+                    a = ops.gemm(xn, w["wgu"], act=ops.ACT_SWIGLU16)
+                    s = ops.gemm_partials(a, w["wdown"], self.SPLITS["down"], part)
+                    ops.splitk_residual_rmsnorm(part, s, x, llm.layers[li + 1]["ln1"] if li + 1 < len(llm.layers) else llm.norm, eps, x, xn)
+                logits = ops.gemm(xn, llm.lm_head)
+            else:
+                for li, w in enumerate(llm.layers):
+                    qkv = ops.gemm(ops.rmsnorm(x, w["ln1"], c.rms_norm_eps), w["wqkv"], w["bqkv"])
+                    ops.pool_qkv_post(qkv, H, KV, HD, llm.rope_cos, llm.rope_sin, st, self.dk[li], self.dvt[li])
+                    att = ops.attention_decode_batch(qkv[:, :H * HD], self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
+                    x = ops.gemm(att, w["wo"], residual=x)
+                    a = ops.gemm(ops.rmsnorm(x, w["ln2"], c.rms_norm_eps), w["wgu"], act=ops.ACT_SWIGLU16)
+                    x = ops.gemm(a, w["wdown"], residual=x)
+                logits = ops.gemm(ops.rmsnorm(x, llm.norm, c.rms_norm_eps), llm.lm_head)
             ops.decode_argmax_accept(logits, None, st, self.plan, self.ids, self.stop[:self.n_stop], self.done)
             return logits
 

@@ -9,6 +9,8 @@ import math
 import threading
 from typing import Optional, Sequence
 
+import ctypes
+
 import torch
 
 from . import lib as _L
@@ -507,6 +509,47 @@ def pool_qkv_post(qkv: torch.Tensor, n_q: int, n_kv: int, head_dim: int, cos_tab
     rc = _L.load().fo1_pool_qkv_post_bf16(p, ld, P, n_q, n_kv, head_dim, cos_table.data_ptr(), sin_table.data_ptr(), state.data_ptr(), kcache.data_ptr(),
                                           kcache.stride(0), pv, ldv, _stream())
     _L.check(rc, "fo1_pool_qkv_post_bf16")
+
+
+def gemm_partials(a: torch.Tensor, w: torch.Tensor, splits: int, part: torch.Tensor) -> int:
+    """Split-K planes of a @ w.T into part (fp32, >= splits * M * N elements): -> the effective number of planes [z, M, N] written
+    (fo1_gemm_bf16_partials; no epilogue, no reduce — consumers: splitk_residual_rmsnorm, pool_qkv_post_partials)."""
+    _chk(a, "a"); _chk(w, "w")
+    pa, lda, M, K = _rows(a, "a")
+    pw, ldw, N, Kw = _rows(w, "w")
+    assert K == Kw and part.dtype == torch.float32 and part.is_contiguous() and part.numel() >= splits * M * N
+    eff = ctypes.c_int(0)
+    rc = _L.load().fo1_gemm_bf16_partials(pa, lda, pw, ldw, M, N, K, int(splits), part.data_ptr(), ctypes.byref(eff), _stream())
+    _L.check(rc, "fo1_gemm_bf16_partials")
+    return eff.value
+
+
+def splitk_residual_rmsnorm(part: torch.Tensor, splits: int, residual: torch.Tensor, norm_weight: torch.Tensor, eps: float, x_out: torch.Tensor,
+                            xn_out: torch.Tensor, bias: Optional[torch.Tensor] = None) -> None:
+    """x_out = bf16(bf16(sum_z part[z] (+ bias)) + residual); xn_out = RMSNorm(x_out) * norm_weight — one launch (fo1_splitk_residual_rmsnorm_bf16).
+    x_out may alias residual (each element is read and written by the same thread)."""
+    _chk(residual, "residual"); _chk(x_out, "x_out"); _chk(xn_out, "xn_out")
+    pr, ldr, M, N = _rows(residual, "residual")
+    px, ldx, _, _ = _rows(x_out, "x_out")
+    pn, ldn, _, _ = _rows(xn_out, "xn_out")
+    assert part.dtype == torch.float32 and part.numel() >= splits * M * N and norm_weight.numel() == N
+    rc = _L.load().fo1_splitk_residual_rmsnorm_bf16(part.data_ptr(), int(splits), M, N, bias.data_ptr() if bias is not None else None, pr, ldr, px, ldx,
+                                                    norm_weight.data_ptr(), float(eps), pn, ldn, _stream())
+    _L.check(rc, "fo1_splitk_residual_rmsnorm_bf16")
+
+
+def pool_qkv_post_partials(part: torch.Tensor, splits: int, bias: Optional[torch.Tensor], q_out: torch.Tensor, n_q: int, n_kv: int, head_dim: int,
+                           cos_table: torch.Tensor, sin_table: torch.Tensor, state: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tensor) -> None:
+    """pool_qkv_post fed by the split-K planes of the q/k/v projection: rotated q rows -> q_out [P, >= n_q * head_dim], K / V^T -> caches."""
+    _chk(q_out, "q_out"); _chk(kcache, "kcache"); _chk(vtcache, "vtcache")
+    p, ld, P, _ = _rows(q_out, "q_out")
+    assert kcache.dim() == 3 and state.dtype == torch.int32 and state.is_contiguous() and state.shape[0] >= P
+    assert part.dtype == torch.float32 and part.numel() >= splits * P * (n_q + 2 * n_kv) * head_dim
+    pv, ldv, _, _ = _rows(vtcache, "vtcache")
+    rc = _L.load().fo1_pool_qkv_post_partials_bf16(part.data_ptr(), int(splits), bias.data_ptr() if bias is not None else None, p, ld, P, n_q, n_kv, head_dim,
+                                                   cos_table.data_ptr(), sin_table.data_ptr(), state.data_ptr(), kcache.data_ptr(), kcache.stride(0), pv, ldv,
+                                                   _stream())
+    _L.check(rc, "fo1_pool_qkv_post_partials_bf16")
 
 
 def decode_argmax_accept(logits: Optional[torch.Tensor], first_tokens: Optional[torch.Tensor], state: torch.Tensor, plan: torch.Tensor,
