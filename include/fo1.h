@@ -248,11 +248,14 @@ int fo1_pool_qkv_post_partials_bf16(const float* part, int splits, const void* b
  *   fo1_splitk_residual_rmsnorm_bf16   x_out = bf16(bf16(sum_z part[z] (+ bias)) + residual);  xn_out = Qwen2RMSNorm(x_out) * norm_weight
  *                                      (the residual add of :736 / :742 and the NEXT layernorm, :728 / :739, in the launch that reduces)
  *   fo1_pool_qkv_post_partials_bf16    above.
+ *   fo1_splitk_swiglu_bf16             the gate/up projection against the 16-row interleaved weight: out[m, f] = bf16(bf16(silu(bf16(g))) * bf16(u)),
+ *                                      g / u = sum_z of plane columns 32 (f / 16) + f % 16 and + 16 — fo1_gemm_bf16's act 3 epilogue (:636) on planes
  * K % 64 == 0, N % 4 == 0 (% 8 for the consumers), operands 16-byte aligned, part holds splits * M * N floats. */
 int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* part, int* splits_out,
                            void* stream);
 int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N, const void* bias, const void* residual, int ldr, void* x_out,
                                      int ldx, const void* norm_weight, float eps, void* xn_out, int ldn, void* stream);
+int fo1_splitk_swiglu_bf16(const float* part, int splits, int M, int N, void* out, int ldo, void* stream);
 /* Weight-streaming GEMV (M <= 4) with the fo1_gemm_bf16 epilogues and an optional fused Qwen2RMSNorm on the input rows
  * (norm_weight [K] or NULL): folds input_layernorm / post_attention_layernorm into the projections of the decode step. */
 int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, int ldr,

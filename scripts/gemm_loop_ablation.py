@@ -13,7 +13,7 @@ from vlm_fo1_amd import lib as L, ops
 
 lib = L.load()
 SHAPES = [("vit_qkv", 39100, 3840, 1280), ("vit_fc", 39100, 6912, 1280), ("llm_o", 16275, 2048, 2048), ("llm_gateup_plain", 16275, 22016, 2048), ("llm_down", 16275, 2048, 11008), ("square", 8192, 8192, 8192)]
-ABLS = (0, 32, 1, 8, 16, 32, 0)     # 1 no DMA, 2 no fragment reads, 4 no barriers, 8 no vmcnt waits, 16 DMA from K tile 0 only, 24 = 8 + 16, 32 = half of each wave's DMA pieces issued in its load-Y segment instead of its MFMA segments (valid results); 0 and 32 are timed first AND last
+ABLS = (0, 64, 1, 8, 16, 64, 0)     # 1 no DMA, 2 no fragment reads, 4 no barriers, 8 no vmcnt waits, 16 DMA from K tile 0 only, 24 = 8 + 16, 32 = half of each wave's DMA pieces issued in its load-Y segment instead of its MFMA segments (valid results); 64 = only the A half of the DMA pieces issued; 0 and 64 are timed first AND last
 res = []
 for name, M, N, K in SHAPES:
     x = (torch.randn(M, K, device="cuda") * 0.5).bfloat16()

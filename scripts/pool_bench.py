@@ -19,7 +19,7 @@ def main():
     ap.add_argument("--chunks", type=int, nargs="+", default=[0], help="keys per split of the pool's decode attention to A/B (needs FO1_AB=1; 0 = default)")
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--attn-impl", type=int, nargs="+", default=[0], help="A/B (FO1_AB=1): 0 = split-KV + combine, 1 = one workgroup per (KV head, sequence)")
-    ap.add_argument("--splits", type=int, nargs=3, default=None, metavar=("QKV", "O", "DOWN"), help="split-K planes of the pool's q/k/v, o and down projections (default: DecodePool.SPLITS)")
+    ap.add_argument("--splits", type=int, nargs=4, default=None, metavar=("QKV", "O", "DOWN", "GATEUP"), help="split-K planes of the pool's q/k/v, o, down and gate/up projections (default: DecodePool.SPLITS; GATEUP 0 = SwiGLU epilogue)")
     ap.add_argument("--unfused", action="store_true", help="the step on plain GEMM epilogues + separate RMSNorm launches (DecodePool.FUSED_SPLITK = False)")
     ap.add_argument("--fill", type=float, default=1.0, help="fraction of the slots that hold live sequences")
     args = ap.parse_args()
@@ -27,7 +27,7 @@ def main():
     from vlm_fo1_amd import lib as L
     from vlm_fo1_amd.llm import BatchDecoder, DecodePool
     if args.splits:
-        DecodePool.SPLITS = dict(qkv=args.splits[0], o=args.splits[1], down=args.splits[2])
+        DecodePool.SPLITS = dict(qkv=args.splits[0], o=args.splits[1], down=args.splits[2], gateup=args.splits[3])
     if args.unfused:
         DecodePool.FUSED_SPLITK = False
     dev = torch.device("cuda", 0)

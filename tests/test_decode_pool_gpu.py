@@ -128,6 +128,17 @@ def test_pool_splitk_planes_and_fused_consumers(P, product_library):
         ops.splitk_residual_rmsnorm(part, s, res2, nw, 1e-6, res2, xn)
         torch.cuda.synchronize()
         assert torch.equal(res2, xo), "in-place x_out"
+    # gate/up against the 16-row interleaved weight at the true width (the 128 x 256 tile, 3 planes) -> fo1_splitk_swiglu_bf16: EXACTLY the
+    # SwiGLU of the bf16-rounded plane sums
+    F_, K = 11008, 2048
+    gate, up, x = rnd(F_, K, sc=0.03), rnd(F_, K, sc=0.03), rnd(P, K)
+    part, s, tot = planes_of(x, ops.interleave_gate_up(gate, up).cuda(), 3)
+    got = ops.splitk_swiglu(part, s, P, 2 * F_)
+    t4 = tot.view(P, F_ // 16, 2, 16)
+    gt, u = rb(t4[:, :, 0].reshape(P, F_)), rb(t4[:, :, 1].reshape(P, F_))
+    ref = rb(rb(gt * torch.sigmoid(gt)) * u)
+    _close(got, ref, "splitk swiglu", ulps=1.0, rare=2e-3)          # (silu: the kernel's exp / rcp against torch's sigmoid)
+    _close(got, rb(rb(torch.nn.functional.silu(rb(x.float() @ gate.float().t()))) * rb(x.float() @ up.float().t())), "splitk swiglu vs fp32 product", ulps=2.0, rare=5e-3)
     H, KV, HD, K, rows = 16, 2, 128, 2048, 1024
     x, w, b = rnd(P, K), rnd((H + 2 * KV) * HD, K, sc=0.05), rnd((H + 2 * KV) * HD, sc=0.1)
     ang = torch.rand(rows, HD, generator=g) * 6.28

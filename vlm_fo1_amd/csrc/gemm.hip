@@ -1130,7 +1130,7 @@ int gemv_dispatch(const void* A, int lda, const void* W, int ldw, const void* bi
 
 // 128 x 256 tile, 8 waves (2 x 4): halves the L2->LDS traffic of the 64 x 128 tile for wide-N GEMMs
 template <int BM, int BN>
-static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
+static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st, bool reduce = true) {
     p.tiles_m = cdiv(p.M, BM);
     p.tiles_n = cdiv(p.N, BN);
     const dim3 grid(p.tiles_m * p.tiles_n, batch, p.splits);
@@ -1148,7 +1148,7 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
         attr_done = true;
     }
     FO1_LAUNCH(name, flops, (gemm_bt_glds_kernel<BM, BN, 2, 4>), grid, dim3(512), smem, st, p);
-    if (p.splits > 1) {
+    if (p.splits > 1 && reduce) {
         const long long total = (long long)p.M * (p.N / 4);
         const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
         FO1_LAUNCH("gemm_splitk_reduce", (double)p.M * p.N * 4.0 * p.splits, gemm_splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
@@ -1176,7 +1176,7 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st) {
 // fragments are read the same way, so the operands' common k order inside a lane does not matter.
 // ABL (A/B build only, scripts/gemm_loop_ablation.py): main-loop ablations for timing — 1 = no LDS-DMA issue inside the loop, 2 = no fragment
 // reads inside the loop, 4 = no barriers inside the loop, 8 = no vmcnt waits inside the loop, 16 = every DMA piece from K tile 0 (L2-hot), 32 = half of a wave's DMA pieces issued in its load-Y segment
-// (results valid).  The results of an ablated launch are garbage by construction.
+// (results valid), 64 = only the A half of the DMA pieces is issued (what a kernel that fetched W another way would leave on the LDS-DMA path).  The results of an ablated launch are garbage by construction.
 template <int EPI, bool FP8 = false, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, ES = FP8 ? 1 : 2, BK = 128 / ES;
@@ -1252,6 +1252,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     };
     // one piece pinned between two MFMA pairs of a segment (the compiler otherwise bunches the segment's four pieces behind its first MFMA)
     auto pinned = [&](bool on, int g, int i, int kt, int buf) __attribute__((always_inline)) {
+        if ((ABL & 64) && g >= 2) return;       // ablation: the W half of the DMA traffic is not issued
         if (on) {
             __builtin_amdgcn_sched_barrier(0);
             piece(g, i, kt, buf);
@@ -1815,15 +1816,15 @@ static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
     }
 #endif
 #ifdef FO1_ENABLE_AB
-    if (g_gemm_big_sched == 1 && epi == 0 && (p.debug >> 6) & 63) {      // main-loop ablations (debug bits 6-8 = ABL), timing only
-        const int abl = (p.debug >> 6) & 63;
+    if (g_gemm_big_sched == 1 && epi == 0 && (p.debug >> 6) & 127) {      // main-loop ablations (debug bits 6-8 = ABL), timing only
+        const int abl = (p.debug >> 6) & 127;
 #define FO1_ABL_CASE(V)                                                                                                                   \
     case V: {                                                                                                                             \
         FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<0, false, V>, hipFuncAttributeMaxDynamicSharedMemorySize, smem)); \
         FO1_LAUNCH("gemm_bt_p4_ablated", flops, (gemm_bt_p4_kernel<0, false, V>), grid, dim3(512), smem, st, p);                          \
     } break;
         switch (abl) {
-            FO1_ABL_CASE(1) FO1_ABL_CASE(2) FO1_ABL_CASE(4) FO1_ABL_CASE(8) FO1_ABL_CASE(16) FO1_ABL_CASE(24) FO1_ABL_CASE(32)
+            FO1_ABL_CASE(1) FO1_ABL_CASE(2) FO1_ABL_CASE(4) FO1_ABL_CASE(8) FO1_ABL_CASE(16) FO1_ABL_CASE(24) FO1_ABL_CASE(32) FO1_ABL_CASE(64)
             default: return set_err(FO1_ERR_ARG, "gemm: no such ablation %d", abl);
         }
 #undef FO1_ABL_CASE
@@ -2208,6 +2209,9 @@ int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M
     p.part = part;
     *splits_out = p.splits;
     if (p.splits < 2) return set_err(FO1_ERR_ARG, "gemm_partials: K too shallow for %d splits", splits);
+    // wide outputs (gate/up: 22016 columns) at 65..128 rows: 128 x 256 tiles — the activations come back from L2 once per tile COLUMN, and
+    // 86 column tiles x 3 planes fill the chip where 172 tiles of 128 x 128 with the SwiGLU epilogue leave a third of it idle
+    if (M > 64 && M <= 128 && N >= 8192 && nk >= 16) return launch_gemm_wide<128, 256>(p, 1, (hipStream_t)stream, false);
     // (128 x 128 tiles for the 65..128-row down projection — the weights fetched once instead of once per 64-row tile — measured no faster:
     // 17.4 vs 16.3 us at 12-16 planes, profiles/r04_pool_step_splitk_sweep.json)
     if ((long long)cdiv(M, 64) * cdiv(N, 128) * p.splits >= 256) return launch_gemm<64, 128>(p, 1, true, (hipStream_t)stream, false);

@@ -179,6 +179,37 @@ __global__ __launch_bounds__(256) void splitk_residual_rmsnorm_kernel(const floa
     }
 }
 
+// Split-K consumer for the gate/up projection of the decode pool: the planes hold the product against the 16-row interleaved weight
+// [gate 16 | up 16 | ...] (ops.interleave_gate_up); out[m, f] = bf16( bf16(silu(bf16(g))) * bf16(u) ) with g, u = sum_z of the planes'
+// columns 32 (f / 16) + f % 16 and + 16 — the rounding points of fo1_gemm_bf16's ACT_SWIGLU16 epilogue.  8 features per thread.
+__global__ __launch_bounds__(256) void splitk_swiglu_kernel(const float* __restrict__ part, int splits, long long plane, int M, int N,
+                                                            uint16_t* __restrict__ out, int ldo) {
+    const int F = N >> 1, chunks = F >> 3;
+    const long long total = (long long)M * chunks;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks), c = (int)(i - (long long)m * chunks);
+        const int f0 = c * 8, col = (f0 >> 4) * 32 + (f0 & 15);
+        const float* pr = part + (long long)m * N + col;
+        float4 g0 = *reinterpret_cast<const float4*>(pr), g1 = *reinterpret_cast<const float4*>(pr + 4);
+        float4 u0 = *reinterpret_cast<const float4*>(pr + 16), u1 = *reinterpret_cast<const float4*>(pr + 20);
+        for (int z = 1; z < splits; ++z) {
+            const float* pz = pr + z * plane;
+            const float4 a0 = *reinterpret_cast<const float4*>(pz), a1 = *reinterpret_cast<const float4*>(pz + 4);
+            const float4 b0 = *reinterpret_cast<const float4*>(pz + 16), b1 = *reinterpret_cast<const float4*>(pz + 20);
+            g0.x += a0.x; g0.y += a0.y; g0.z += a0.z; g0.w += a0.w; g1.x += a1.x; g1.y += a1.y; g1.z += a1.z; g1.w += a1.w;
+            u0.x += b0.x; u0.y += b0.y; u0.z += b0.z; u0.w += b0.w; u1.x += b1.x; u1.y += b1.y; u1.z += b1.z; u1.w += b1.w;
+        }
+        const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, u[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float sg = bf16_to_f32(f32_to_bf16(fo1_silu(bf16_to_f32(f32_to_bf16(g[j])))));
+            o[j] = sg * bf16_to_f32(f32_to_bf16(u[j]));
+        }
+        *reinterpret_cast<uint4*>(out + (size_t)m * ldo + f0) = pack8(o);
+    }
+}
+
 template <int MODE>
 static int launch_rownorm(const char* name, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int M, int D, float eps,
                           hipStream_t st) {
@@ -527,6 +558,18 @@ int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N
     else if (nper == 2) FO1_SKRN(2);
     else FO1_SKRN(4);
 #undef FO1_SKRN
+    return FO1_OK;
+}
+
+int fo1_splitk_swiglu_bf16(const float* part, int splits, int M, int N, void* out, int ldo, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(part && out && M >= 1 && splits >= 1, "splitk_swiglu: NULL operand");
+    FO1_CHECK_ARG(N % 32 == 0 && ldo % 8 == 0 && ldo >= N / 2 && ((uintptr_t)part & 15) == 0 && ((uintptr_t)out & 15) == 0,
+                  "splitk_swiglu: N=%d (%% 32), ldo=%d (%% 8, >= N / 2), 16-byte aligned operands", N, ldo);
+    const long long total = (long long)M * (N / 16);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    FO1_LAUNCH("splitk_swiglu", (double)M * N * (4.0 * splits + 1.0), splitk_swiglu_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, part, splits,
+               (long long)M * N, M, N, (uint16_t*)out, ldo);
     return FO1_OK;
 }
 

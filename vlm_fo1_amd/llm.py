@@ -896,7 +896,9 @@ class DecodePool:
     # fp32 planes from >= 256 workgroups and the kernel that needs the result anyway sums them — q/k/v in the RoPE / cache-append kernel, o and
     # down in ONE kernel with the residual add and the NEXT RMSNorm (9 launches per layer instead of 11, none of them on a quarter of the chip).
     FUSED_SPLITK = True
-    SPLITS = dict(qkv=4, o=4, down=8)
+    # gateup 0 = one GEMM with the SwiGLU epilogue (172 tiles of 128 x 128: 34 us); as 2 / 3 / 4 planes of 128 x 256 tiles + fo1_splitk_swiglu_bf16 it
+    # measured 36 / 49 / 46 us (profiles/r04_pool_step_splitk_sweep.json) — the planes path stays available, parity-tested, unused
+    SPLITS = dict(qkv=4, o=4, down=8, gateup=0)
 
     def _step_device(self, bucket: int):
         llm, P = self.llm, self.P
@@ -908,7 +910,9 @@ class DecodePool:
             x = ops.gather_rows(self.plan, c.hidden_size, llm.embed)
             if self.FUSED_SPLITK:
                 eps, D = c.rms_norm_eps, c.hidden_size
-                part = torch.empty(max(self.SPLITS["qkv"] * (H + 2 * KV) * HD, max(self.SPLITS["o"], self.SPLITS["down"]) * D) * P, dtype=torch.float32, device=x.device)
+                NGU = llm.layers[0]["wgu"].shape[0]
+                part = torch.empty(max(self.SPLITS["qkv"] * (H + 2 * KV) * HD, max(self.SPLITS["o"], self.SPLITS["down"]) * D, self.SPLITS["gateup"] * NGU) * P, dtype=torch.float32,
+                                   device=x.device)
                 xn = ops.rmsnorm(x, llm.layers[0]["ln1"], eps)
                 q = torch.empty(P, H * HD, dtype=torch.bfloat16, device=x.device)
                 for li, w in enumerate(llm.layers):
@@ -917,7 +921,11 @@ class DecodePool:
                     att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, bucket, H, KV, HD, scale)
                     s = ops.gemm_partials(att, w["wo"], self.SPLITS["o"], part)
                     ops.splitk_residual_rmsnorm(part, s, x, w["ln2"], eps, x, xn)
-                    a = ops.gemm(xn, w["wgu"], act=ops.ACT_SWIGLU16)
+                    if self.SPLITS["gateup"] >= 2:
+                        s = ops.gemm_partials(xn, w["wgu"], self.SPLITS["gateup"], part)
+                        a = ops.splitk_swiglu(part, s, P, NGU)
+                    else:
+                        a = ops.gemm(xn, w["wgu"], act=ops.ACT_SWIGLU16)
                     s = ops.gemm_partials(a, w["wdown"], self.SPLITS["down"], part)
                     ops.splitk_residual_rmsnorm(part, s, x, llm.layers[li + 1]["ln1"] if li + 1 < len(llm.layers) else llm.norm, eps, x, xn)
                 logits = ops.gemm(xn, llm.lm_head)

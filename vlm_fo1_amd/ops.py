@@ -538,6 +538,16 @@ def splitk_residual_rmsnorm(part: torch.Tensor, splits: int, residual: torch.Ten
     _L.check(rc, "fo1_splitk_residual_rmsnorm_bf16")
 
 
+def splitk_swiglu(part: torch.Tensor, splits: int, M: int, N: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out [M, N / 2] = SwiGLU over the split-K planes of a product against a 16-row interleaved gate/up weight (fo1_splitk_swiglu_bf16)."""
+    assert part.dtype == torch.float32 and part.numel() >= splits * M * N and part.is_cuda
+    if out is None:
+        out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=part.device)
+    po, ldo, _, _ = _rows(out, "out")
+    _L.check(_L.load().fo1_splitk_swiglu_bf16(part.data_ptr(), int(splits), M, N, po, ldo, _stream()), "fo1_splitk_swiglu_bf16")
+    return out
+
+
 def pool_qkv_post_partials(part: torch.Tensor, splits: int, bias: Optional[torch.Tensor], q_out: torch.Tensor, n_q: int, n_kv: int, head_dim: int,
                            cos_table: torch.Tensor, sin_table: torch.Tensor, state: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tensor) -> None:
     """pool_qkv_post fed by the split-K planes of the q/k/v projection: rotated q rows -> q_out [P, >= n_q * head_dim], K / V^T -> caches."""
