@@ -25,6 +25,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16
+MFMA_FP8_PEAK_TF = 5000.0   # dense fp8 (the secondary --fp8 measurement's dominant kernel)
 
 
 def build_workload(device, n_boxes=100, img_hw=(480, 640), seed=1234, lift_cap=False):
@@ -913,7 +914,7 @@ def main():
         work = dom["total_work"] / dom["calls"]
         mfma = dom["name"].startswith("gemm") or dom["name"].startswith("attn")
         ach = work / (avg_ms * 1e-3) / (1e12 if mfma else 1e9)
-        peak = MFMA_BF16_PEAK_TF if mfma else HBM_PEAK_GBS
+        peak = (MFMA_FP8_PEAK_TF if dom["name"].startswith("gemm_fp8") else MFMA_BF16_PEAK_TF) if mfma else HBM_PEAK_GBS
         traffic, traffic_src = pmc_traffic(dom["name"])
         # all MFMA GEMM templates together (the three tile shapes are one kernel source)
         g_rows = [r for r in rows if r["name"].startswith("gemm_bt_")]

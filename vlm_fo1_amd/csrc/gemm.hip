@@ -1233,17 +1233,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         {
             const uint32_t so = g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i];
             const char* ub = (g < 2 ? At : Wt) + (long long)((ABL & 16) ? 0 : kt0 + kt) * 128;
-            if constexpr (FP8) {
-                // uniform base (+ K-tile offset) in SGPRs, the lane's 32-bit offset in one VGPR.
-                // The empty asm keeps hipcc from re-associating this into eight hoisted 64-bit per-lane pointers.
-                char* dst = smem + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;
-                asm volatile("" : "+s"(ub));
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ub + so),
-                                                 (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-            } else {
-                const uint32_t dst = lds0 + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;     // M0 = the piece's LDS base
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(so), "s"(ub), "s"(dst) : "memory");
-            }
+            const uint32_t dst = lds0 + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;     // M0 = the piece's LDS base
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(so), "s"(ub), "s"(dst) : "memory");
         }
     };
     auto stage = [&](int g, int kt, int buf) __attribute__((always_inline)) {
@@ -1356,7 +1347,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     mm(breg[i >> 1][ks], areg[i & 1][ks], acc[AH * 2 + (i & 1)][i >> 1]);
-                    if (i == 1) {
+                    if (NKS == 2) {          // FP8: 8 MFMAs of twice the length — a piece after every second one, group gA first (the waits
+                        if (i == 1) pinned(on, ks == 0 ? gA : gB, 0, kt, buf);       // count on gB's pair being the newest)
+                        if (i == 3) pinned(on, ks == 0 ? gA : gB, 1, kt, buf);
+                    } else if (i == 1) {
                         if (gB >= 0) pinned(on, ks < 2 ? gA : gB, ks & 1, kt, buf);
                         else if (!(ks & 1)) pinned(on, gA, ks >> 1, kt, buf);
                     }
@@ -1374,13 +1368,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
             if (!(ABL & 4) && !(last && late)) FO1_P8_BARRIER();
             __builtin_amdgcn_sched_barrier(0);
         };
-#define FO1_P4_MFMA2A(AH, KS)                                     \
-    mm(breg[0][KS], areg[0][KS], acc[(AH) * 2 + 0][0]);           \
-    mm(breg[0][KS], areg[1][KS], acc[(AH) * 2 + 1][0]);
-#define FO1_P4_MFMA2B(AH, KS)                                     \
-    mm(breg[1][KS], areg[0][KS], acc[(AH) * 2 + 0][1]);           \
-    mm(breg[1][KS], areg[1][KS], acc[(AH) * 2 + 1][1]);
-#define FO1_P4_MFMA4(AH, KS) FO1_P4_MFMA2A(AH, KS) FO1_P4_MFMA2B(AH, KS)
         // ---- phase X ----
         loadB(0);
         loadB(1);
@@ -1394,12 +1381,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         end_load();
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8) {
-            FO1_P4_MFMA2A(0, 0)
-            if (!(ABL & 1) && more1) stage(3, t + 1, BUF ^ 1);
-            FO1_P4_MFMA2B(0, 0)
-            FO1_P4_MFMA2A(0, 1)
-            if (!(ABL & 1) && more1) stage(1, t + 1, BUF ^ 1);
-            FO1_P4_MFMA2B(0, 1)
+            segment(std::integral_constant<int, 0>{}, !(ABL & 1) && more1, 3, 1, t + 1, BUF ^ 1);
         } else {
             if constexpr (LY) segment(std::integral_constant<int, 0>{}, !(ABL & 1) && more1, 1, -1, t + 1, BUF ^ 1);     // A1(t+1)
             else segment(std::integral_constant<int, 0>{}, !(ABL & 1) && more1, 3, 1, t + 1, BUF ^ 1);
@@ -1422,21 +1404,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
         end_load();
         __builtin_amdgcn_s_setprio(1);
         if constexpr (FP8) {
-            FO1_P4_MFMA2A(1, 0)
-            if (!(ABL & 1) && more2) stage(0, t + 2, BUF);
-            FO1_P4_MFMA2B(1, 0)
-            FO1_P4_MFMA2A(1, 1)
-            if (!(ABL & 1) && more2) stage(2, t + 2, BUF);
-            FO1_P4_MFMA2B(1, 1)
+            segment(std::integral_constant<int, 1>{}, !(ABL & 1) && more2, 0, 2, t + 2, BUF);
         } else {
             if constexpr (LY) segment(std::integral_constant<int, 1>{}, !(ABL & 1) && more2, 3, -1, t + 2, BUF);         // B1(t+2)
             else segment(std::integral_constant<int, 1>{}, !(ABL & 1) && more2, 0, 2, t + 2, BUF);
         }
         __builtin_amdgcn_s_setprio(0);
         end_mfma(!more1);
-#undef FO1_P4_MFMA4
-#undef FO1_P4_MFMA2A
-#undef FO1_P4_MFMA2B
     };
     int t = 0;
     for (; t + 3 < nk; t += 2) {
