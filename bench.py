@@ -929,6 +929,17 @@ def main():
                     algorithmic_work_per_launch=work,
                     per_step_ms={r["name"]: round(r["total_ms"] / nprof, 4) for r in rows},
                     launches={r["name"]: r["calls"] // nprof for r in rows})
+        if mfma:
+            # what the matrix pipes sustain on THIS box (fo1_mfma_clock_probe: a register-resident dense bf16 MFMA loop on every CU, no memory
+            # traffic): `peak` above is 256 CUs x 4 SIMDs x 1024 flop/cycle at 2.4 GHz, under load the chip clocks to its power budget
+            try:
+                from vlm_fo1_amd import ops as _ops
+                rnd, zero = _ops.mfma_clock_probe(1), _ops.mfma_clock_probe(0)
+                roof["sustained_mfma"] = dict(random_operands=rnd, zero_operands=zero, frac_of_random_operand_rate=round(ach / rnd["tflops"], 4),
+                                              note="register-resident v_mfma_f32_32x32x16_bf16 loop, 8 waves per CU, no loads: the ceiling of any bf16 MFMA kernel at "
+                                                   "this box's power budget (DVFS); frac_of_random_operand_rate = roofline.achieved / that rate")
+            except Exception as e:       # instrumentation only
+                roof["sustained_mfma"] = dict(error=str(e)[:200])
         # the HFRE gather is the HBM-bound kernel north_star names: report it next to the dominant (MFMA) kernel
         by = {r["name"]: r for r in rows}
         hf = [k for k in by if k.startswith("hfre")]

@@ -173,6 +173,11 @@ int fo1_rmsnorm_quant_e4m3(const void* x, int ldx, const void* weight, int M, in
                            void* stream);
 int fo1_gemm_fp8(const void* Aq, int lda, const float* scale_a, const void* Wq, int ldw, const float* scale_w, const void* bias,
                  const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* stream);
+/* Instrumentation: the clock the matrix pipes sustain on this box (csrc/probe.hip).  A register-resident loop of v_mfma_f32_32x32x16_bf16 on
+ * every CU (8 waves per workgroup, `iters` x 32 MFMAs per wave, no memory traffic); out = uint64 [workgroups][2] {shader cycles (s_memtime),
+ * 100 MHz ticks (s_memrealtime)}.  operands 0 = zeros, 1 = pseudo-random bf16.  cycles / ticks = the DVFS clock; the dense bf16 peak of the
+ * roofline (2.5 PFLOP/s) assumes 2.4 GHz. */
+int fo1_mfma_clock_probe(int operands, int iters, int workgroups, void* out, void* sink, void* stream);
 /* Instrumentation (with fo1_profile_enable): per-shape kernel names in the profile rows instead of one row per kernel. */
 int fo1_gemm_profile_shapes(int on);
 

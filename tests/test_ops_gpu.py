@@ -632,3 +632,16 @@ def test_gemm_small_tile_vector_epilogue_equals_general_epilogue_bitwise(tile, a
                 assert torch.equal(outs[0], outs[1]), f"tile {tile} {M}x{N}x{K} act={act}: vector != general epilogue, max diff {(outs[0].float() - outs[1].float()).abs().max().item():.4g}"
     finally:
         L.load().fo1_gemm_set_variant(0, 0)
+
+
+def test_mfma_clock_probe_reports_a_plausible_clock(product_library):
+    """fo1_mfma_clock_probe (csrc/probe.hip, instrumentation): cycles / wall ticks of a register-resident MFMA loop = a clock inside the part's
+    DVFS range, 32 cycles per 32x32x16 bf16 MFMA per SIMD (two waves share one), and zero operands never clock lower than random ones."""
+    from vlm_fo1_amd import ops
+    rnd = ops.mfma_clock_probe(1, iters=400)
+    zero = ops.mfma_clock_probe(0, iters=400)
+    for r in (rnd, zero):
+        assert 0.8 <= r["clock_ghz"] <= 2.6, r
+        cycles_per_mfma = r["clock_ghz"] * 1e3 * r["us"] / (400 * 32 * 2)
+        assert 31.0 <= cycles_per_mfma <= 36.0, (r, cycles_per_mfma)
+    assert zero["tflops"] >= 0.97 * rnd["tflops"]

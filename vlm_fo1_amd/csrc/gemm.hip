@@ -746,16 +746,20 @@ __device__ __forceinline__ void epilogue32(const GemmParams& p, f32x16 (&acc)[MF
 
 #ifdef FO1_ENABLE_AB
 // fo1_gemm_set_debug bit 5 (32): workgroup timeline.  Waves 0 and 7 (one of each staggered half) write the 100 MHz s_memrealtime at kernel
-// entry, first MFMA, end of the K loop and end of the epilogue, plus their HW_ID / XCC_ID, to the buffer of fo1_gemm_set_stamp_buffer:
+// entry, first MFMA, end of the K loop and end of the epilogue, plus their HW_ID / XCC_ID (and s_memtime at both ends of the K loop), to the buffer of fo1_gemm_set_stamp_buffer:
 // [workgroup][2][8] u64 (slots 6, 7: inside the coalesced epilogue — conversions staged in LDS, last store issued).  scripts/gemm_timeline.py turns that into turnover / prologue / K loop / epilogue per workgroup and per CU.
 __device__ __forceinline__ void gemm_stamp(const GemmParams& p, int wave, int lane, int slot) {
     if ((p.debug & 32) && lane == 0 && (wave == 0 || wave == 7)) {
         unsigned long long* o = reinterpret_cast<unsigned long long*>(p.part) + ((size_t)blockIdx.x * 2 + (wave ? 1 : 0)) * 8;
         o[slot] = __builtin_amdgcn_s_memrealtime();
         if (slot == 0) {
-            o[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
-            o[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
+            o[4] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_ID
+            o[5] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);     // XCC_ID
         }
+        // the shader-clock counter at both ends of the K loop, low 32 bits in the upper halves of the two id words: cycles / time = the
+        // clock the loop actually ran at (DVFS)
+        if (slot == 1) o[4] |= (unsigned long long)(unsigned)__builtin_amdgcn_s_memtime() << 32;
+        if (slot == 2) o[5] |= (unsigned long long)(unsigned)__builtin_amdgcn_s_memtime() << 32;
     }
 }
 #define FO1_GEMM_STAMP(slot) gemm_stamp(p, wave, lane, slot)

@@ -188,6 +188,7 @@ SIGNATURES = {
     "fo1_gemm_fp8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                              c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_gemm_profile_shapes": (c_int, [c_int]),
+    "fo1_mfma_clock_probe": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fo1_rmsnorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "fo1_layernorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "fo1_swiglu_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

@@ -511,6 +511,20 @@ def pool_qkv_post(qkv: torch.Tensor, n_q: int, n_kv: int, head_dim: int, cos_tab
     _L.check(rc, "fo1_pool_qkv_post_bf16")
 
 
+def mfma_clock_probe(operands: int = 1, iters: int = 2000, workgroups: int = 256) -> dict:
+    """Sustained clock / rate of a register-resident dense bf16 MFMA loop on this box (fo1_mfma_clock_probe, csrc/probe.hip):
+    {clock_ghz (median over workgroups), tflops, us}.  operands 1 = pseudo-random bf16, 0 = zeros."""
+    out = torch.zeros(workgroups, 2, dtype=torch.int64, device="cuda")
+    sink = torch.zeros(1, dtype=torch.float32, device="cuda")
+    for _ in range(2):          # the second launch is the measurement (the first ramps the clocks)
+        _L.check(_L.load().fo1_mfma_clock_probe(int(operands), int(iters), int(workgroups), out.data_ptr(), sink.data_ptr(), _stream()), "fo1_mfma_clock_probe")
+    torch.cuda.current_stream().synchronize()
+    o = out.cpu().double()
+    ghz = (o[:, 0] / (o[:, 1] * 10.0)).median().item()
+    us = (o[:, 1] / 100.0).median().item()
+    return dict(clock_ghz=round(ghz, 3), us=round(us, 1), tflops=round(workgroups * 8.0 * iters * 32.0 * 32768.0 / (us * 1e-6) / 1e12, 1))
+
+
 def gemm_partials(a: torch.Tensor, w: torch.Tensor, splits: int, part: torch.Tensor) -> int:
     """Split-K planes of a @ w.T into part (fp32, >= splits * M * N elements): -> the effective number of planes [z, M, N] written
     (fo1_gemm_bf16_partials; no epilogue, no reduce — consumers: splitk_residual_rmsnorm, pool_qkv_post_partials)."""
