@@ -409,7 +409,7 @@ def pool_decode_run(pipe, slots=128, steps=48):
     kv = 2.0 * slots * c.num_layers * c.num_kv_heads * c.head_dim * 2 * L_ctx
     del pool
     torch.cuda.empty_cache()
-    return dict(sequences=slots, ms_per_step=round(t * 1e3, 3), tokens_per_sec=round(slots / t, 1), launches_per_layer=9,
+    return dict(sequences=slots, ms_per_step=round(t * 1e3, 3), tokens_per_sec=round(slots / t, 1), launches_per_layer=8,
                 note="every slot live, one hipGraph replay per step; decode_pool = continuous batching (vlm_fo1_amd/serving.py)",
                 roofline=dict(bound="hbm", unit="GB/s", peak=8000.0, algorithmic_bytes_per_step=wbytes + kv, weight_bytes=wbytes, kv_bytes=kv,
                               achieved=round((wbytes + kv) / t / 1e9, 1), frac=round((wbytes + kv) / t / 8e12, 4)))

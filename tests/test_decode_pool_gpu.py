@@ -9,6 +9,7 @@ reference's one-image-at-a-time `generate`, omchat_qwen2_5_vl.py:143-155 + HF gr
   * the stop rule and the budget, slots re-used by later joins while other sequences are mid-flight;
   * the scheduler: passes submitted from several replica threads come back with exactly the ids a direct pool run gives.
 Runs on the PRODUCT library (no pins needed)."""
+import math
 import threading
 
 import pytest
@@ -318,3 +319,46 @@ def test_pool_service_from_replica_threads_equals_direct_pool_runs(product_libra
         assert eng.generate_batch(passes[1], max_new_tokens=K, use_graph=True) == want[1]
     finally:
         eng.disable_decode_pool()
+
+
+def test_pool_attention_one_chunk_writes_rows_without_combine(ab_library):
+    """More than 32 sequences whose contexts fit ONE 1024-key chunk (the pool's default): the split kernel writes the normalised rows itself
+    (no combine launch).  Against torch fp32 (P rounded to bf16 like the kernel), and against the 512-key split + combine form of the same
+    kernel (other merge order: equal within a bf16 ulp); finished slots keep their previous rows."""
+    from vlm_fo1_amd import lib as L, ops
+    lib = L.load()
+    B, H, KV, HD, slot = 40, 16, 2, 128, 1024
+    scale = 1.0 / math.sqrt(HD)
+    g = torch.Generator().manual_seed(5)
+    kc = (torch.randn(KV, B * slot, HD, generator=g) * 0.5).bfloat16().cuda()
+    vt = (torch.randn(KV * HD, B * slot, generator=g) * 0.5).bfloat16().cuda()
+    q = (torch.randn(B, H * HD, generator=g) * 0.5).bfloat16().cuda()
+    lens = [1 + (37 * b) % 700 for b in range(B)]
+    lens[3], lens[7] = 1023, 512
+    state = torch.zeros(B, 8, dtype=torch.int32)
+    for b in range(B):
+        state[b, 0] = b * slot + lens[b] - 1
+        state[b, 2] = b * slot
+    state[5, 3] = 1                                   # finished: skipped
+    state = state.cuda()
+    out = {}
+    for chunk in (1024, 512):
+        L.check(lib.fo1_attention_decode_set_pool_chunk(chunk), "chunk")
+        o = ops.attention_decode_batch(q, kc, vt, state, 1024, H, KV, HD, scale)
+        torch.cuda.synchronize()
+        out[chunk] = o.float().cpu()
+    L.check(lib.fo1_attention_decode_set_pool_chunk(1024), "chunk")
+    grp = H // KV
+    for b in range(B):
+        if b == 5:
+            continue
+        k = kc[:, b * slot:b * slot + lens[b]].float().cpu()            # [KV, L, HD]
+        v = vt[:, b * slot:b * slot + lens[b]].float().cpu().view(KV, HD, -1)
+        qq = q[b].float().cpu().view(KV, grp, HD)
+        s = torch.einsum("kgd,kld->kgl", qq, k) * scale
+        p = torch.softmax(s, -1)
+        ref = torch.einsum("kgl,kdl->kgd", p, v).reshape(H * HD)
+        for c in (1024, 512):
+            err = (out[c][b] - ref).abs().max().item()
+            assert err <= 2.0 ** -7 * ref.abs().max().item() + 2e-3, (b, c, err)
+        assert (out[1024][b] - out[512][b]).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item() + 1e-3, b

@@ -327,6 +327,22 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     }
 
     if (PARTIAL) {
+        if (p.O != nullptr) {
+            // batched decode whose chunk covers the whole context (ONE item per sequence and KV head): the normalised rows go straight to
+            // the output — the value attn_decode_combine_kernel computes from a single partial (w = exp(0) = 1: num / den = o / l) —
+            // and the combine launch is not made.  o_tok = the output's sequence stride, o_head = HD.
+            if (wave == 0 && q_ok) {
+                uint16_t* op = p.O + (long long)blockIdx.z * p.o_tok + ((long long)h * p.q_range_end + ql) * p.o_head;
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    uint2 w;
+                    w.x = pack_bf16x2(l_run > 0.f ? o[db][0] / l_run : 0.f, l_run > 0.f ? o[db][1] / l_run : 0.f);
+                    w.y = pack_bf16x2(l_run > 0.f ? o[db][2] / l_run : 0.f, l_run > 0.f ? o[db][3] / l_run : 0.f);
+                    *reinterpret_cast<uint2*>(op + db * 16 + g * 4) = w;
+                }
+            }
+            return;
+        }
         if (wave == 0 && q_ok) {
             float* pr = partb + (((long long)blockIdx.x * p.Hq + h) * 16 + ql) * (HD + 2);
 #pragma unroll
@@ -771,12 +787,13 @@ int fo1_attention_decode_set_impl(int impl) {
 // 651-715 keys, profiles/r04_pool_step_attention_chunk_ab.json: split kernel 1.11 / 0.91 / 0.90 / 0.84 ms per step at 64 / 128 / 256 / 512) — the tile loop's register
 // prefetch then overlaps the next tile's loads with the MFMAs of the current one (one-tile workgroups are a load -> compute chain).
 namespace fo1 {
-FO1_AB_VAR g_attn_pool_chunk = 512;      // A/B: fo1_attention_decode_set_pool_chunk
+FO1_AB_VAR g_attn_pool_chunk = 1024;     // A/B: fo1_attention_decode_set_pool_chunk.  1024 keys: a pool slot's whole context (slot_rows <= 1024) is ONE chunk —
+                                         // the split kernel writes the rows itself, no combine launch (512: 23.7 + 4.3 us per layer, 1024: 22.2 + 0; profiles/r04_pool_step_attention_one_chunk.json)
 static inline int decode_batch_chunk(int batch) { return batch > 32 ? g_attn_pool_chunk : 64; }
 }  // namespace fo1
 #ifdef FO1_ENABLE_AB
 int fo1_attention_decode_set_pool_chunk(int keys) {
-    if (keys != 64 && keys != 128 && keys != 256 && keys != 512) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_pool_chunk: %d", keys);
+    if (keys < 64 || keys > 4096 || keys % 64) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_pool_chunk: %d", keys);
     fo1::g_attn_pool_chunk = keys;
     return FO1_OK;
 }
@@ -824,6 +841,12 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     p.part_seq_stride = (long long)p.n_items * n_kv_heads * 16 * (head_dim + 2);
     p.bias = nullptr; p.wlen = 0; p.sw_ws = p.sw_shift = p.sw_nwy = p.sw_nwx = 0;
     hipStream_t st = (hipStream_t)stream;
+    if (p.n_items == 1 && batch > 32) {       // the pool: one chunk per (sequence, KV head) -> rows written by the split kernel itself, no combine launch
+        p.O = (uint16_t*)out; p.o_tok = out_seq_stride; p.o_head = head_dim;
+        FO1_LAUNCH("attn_decode_one_chunk", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
+                   dim3(1, n_kv_heads, batch), dim3(256), 0, st, p);
+        return FO1_OK;
+    }
     FO1_LAUNCH("attn_decode_split", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
                dim3(p.n_items, n_kv_heads, batch), dim3(256), 0, st, p);
     FO1_LAUNCH("attn_decode_combine", (double)batch * n_q_heads * head_dim * 8.0, attn_decode_combine_kernel<128>, dim3(n_q_heads, batch), dim3(128), 0,
