@@ -947,7 +947,8 @@ class DecodePool:
         if not use_graph:
             out = self._step_device(bucket)
         else:
-            key = (self.slot_rows, self.n_stop, bucket, self.llm.rope_epoch, self.llm.rope_cos.data_ptr())
+            # (the step's form is part of the key: FUSED_SPLITK / SPLITS may be set per pool, scripts/pool_bench.py and the A/B test do)
+            key = (self.slot_rows, self.n_stop, bucket, self.llm.rope_epoch, self.llm.rope_cos.data_ptr(), bool(self.FUSED_SPLITK), tuple(sorted(self.SPLITS.items())))
             ent = self._graphs.get(key)
             if ent is None:
                 with ops.graph_lock.capture(), torch.inference_mode(False):
