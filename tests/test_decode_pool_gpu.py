@@ -1,4 +1,4 @@
-"""The decode pool (vlm_fo1_amd.llm.DecodePool over csrc/decode_pool.hip; scheduler vlm_fo1_amd.serving.PoolService): 64 / 128 sequence
+"""The decode pool (vlm_fo1_amd.llm.DecodePool; scheduler vlm_fo1_amd.serving.PoolService): 64 / 128 sequence
 slots per weight stream, sequences of different prefill passes sharing every decode step (the loop it replaces is the
 reference's one-image-at-a-time `generate`, omchat_qwen2_5_vl.py:143-155 + HF greedy search, stop rule mm_utils.py:137-181).
 
@@ -160,7 +160,7 @@ def test_pool_splitk_planes_and_fused_consumers(P, product_library):
 
 
 def test_pool_fused_splitk_step_against_unfused(product_library):
-    """The pool step with split-K planes + fused consumers (9 launches per layer) against the same step on plain GEMM epilogues + separate
+    """The pool step with split-K planes + fused consumers (8 launches per layer) against the same step on plain GEMM epilogues + separate
     RMSNorm launches (11): other fp32 sum orders in q/k/v and o, so ids may differ at near-ties only."""
     from vlm_fo1_amd.llm import DecodePool
     cfg, weights, eng = _engine()

@@ -349,7 +349,7 @@ int fo1_decode_qkv_post_bf16(void* qkv_row, int n_q_heads, int n_kv_heads, int h
     return FO1_OK;
 }
 
-// The same for the P sequences of a decode pool (decode_pool.hip): row b of qkv [P, ld] is rotated with table row state[b][1], its
+// The same for the P sequences of a decode pool (llm.DecodePool): row b of qkv [P, ld] is rotated with table row state[b][1], its
 // K heads / V heads land in the caches at row / column state[b][0] (the sequence's own slot).
 int fo1_pool_qkv_post_bf16(void* qkv, long long ld, int P, int n_q_heads, int n_kv_heads, int head_dim, const void* cos_table,
                            const void* sin_table, const int32_t* state, void* kcache, long long kcache_head_stride, void* vtcache,

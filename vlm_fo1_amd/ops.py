@@ -498,7 +498,7 @@ def attention_decode_batch(q: torch.Tensor, kcache: torch.Tensor, vtcache: torch
     return out
 
 
-# ---- decode pool: 64 / 128 sequence slots per weight stream (decode_pool.hip) ---------------------------------------------------------
+# ---- decode pool: 64 / 128 sequence slots per weight stream (llm.DecodePool) ---------------------------------------------------------
 def pool_qkv_post(qkv: torch.Tensor, n_q: int, n_kv: int, head_dim: int, cos_table: torch.Tensor, sin_table: torch.Tensor, state: torch.Tensor,
                   kcache: torch.Tensor, vtcache: torch.Tensor) -> None:
     """mRoPE + cache append for the P rows of a pool step's fused q/k/v product (in place; fo1_pool_qkv_post_bf16)."""
