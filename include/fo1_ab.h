@@ -38,10 +38,15 @@ int fo1_gemm_set_gemv(int on);   /* M <= 4 goes to the weight-streaming GEMV ker
  * epilogue stores (no effect measured).  Default 1. */
 int fo1_gemm_set_big_schedule(int sched);
 /* ablation, RESULTS INVALID: 1 no global loads, 2 no MFMA, 4 no LDS reads + MFMA; 256x256 two-phase kernel: 8 epilogue computed but not
- * stored, 16 one K tile per output tile (profiles/r02_gemm_t0_study.md) */
+ * stored, 16 one K tile per output tile (profiles/r02_gemm_t0_study.md).
+ * Bits 6..12 (round 4, scripts/gemm_loop_ablation.py; plain / residual bf16 products of the 256x256 two-phase kernel only): ABL = bits >> 6 —
+ * 1 no LDS-DMA issue inside the K loop, 2 no fragment reads inside it, 4 no barriers, 8 no vmcnt waits, 16 every DMA piece from K tile 0,
+ * 64 only the A half of the pieces issued (all RESULTS INVALID), 32 half of a wave's pieces issued in its load-Y segment (results valid);
+ * instantiated: 1, 2, 4, 8, 16, 24, 32, 64. */
 int fo1_gemm_set_debug(int bits);
 /* bit 5 (32) of fo1_gemm_set_debug, results VALID: waves 0 and 7 of every 256x256-kernel workgroup write s_memrealtime (100 MHz) at kernel entry,
- * first MFMA, end of the K loop, end of the epilogue (slot 6: conversions staged in LDS) and their HW_ID / XCC_ID to this device buffer,
+ * first MFMA, end of the K loop, end of the epilogue (slot 6: conversions staged in LDS) and their HW_ID / XCC_ID (upper halves of those two
+ * words: s_memtime, low 32 bits, at the first MFMA and at the end of the K loop — the shader cycles and so the clock of the loop) to this device buffer,
  * [workgroups][2][8] uint64
  * (scripts/gemm_timeline.py) */
 int fo1_gemm_set_stamp_buffer(void* device_buffer);
@@ -56,7 +61,8 @@ int fo1_gemv_batch_set_impl(int impl);
 /* 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence), partials merged in LDS (measured
  * slower on MI355X: one CU cannot pull a head's K/V^T fast enough). */
 int fo1_attention_decode_set_impl(int impl);
-/* Keys per split of the batched decode attention for more than 32 sequences (decode pool): 64 / 128 / 256 / 512 (default). */
+/* Keys per chunk of the batched decode attention for more than 32 sequences (decode pool): a multiple of 64 up to 4096, default 1024 = a pool
+ * slot's whole context, for which the split kernel writes the output rows itself and no combine launch is made. */
 int fo1_attention_decode_set_pool_chunk(int keys);
 
 #ifdef __cplusplus
