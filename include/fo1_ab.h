@@ -59,7 +59,9 @@ int fo1_gemv_batch_set_rows_per_lane(int rpl);
  * All keep a sequence's numbers independent of the batch it decodes in; MFMA and v_dot2 differ from each other in fp32 summation order. */
 int fo1_gemv_batch_set_impl(int impl);
 /* 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence), partials merged in LDS (measured
- * slower on MI355X: one CU cannot pull a head's K/V^T fast enough). */
+ * slower on MI355X: one CU cannot pull a head's K/V^T fast enough); 2 (round 4, batched decode only) = one workgroup per (KV head, sequence) whose four
+ * waves each walk their own 64-key tiles through wave-private LDS images, merged once in LDS (21.8 vs 23.4 us per layer at 128 sequences: the launch is
+ * within a third of HBM bandwidth either way). */
 int fo1_attention_decode_set_impl(int impl);
 /* Keys per chunk of the batched decode attention for more than 32 sequences (decode pool): a multiple of 64 up to 4096, default 1024 = a pool
  * slot's whole context, for which the split kernel writes the output rows itself and no combine launch is made. */

@@ -348,6 +348,12 @@ def test_pool_attention_one_chunk_writes_rows_without_combine(ab_library):
         torch.cuda.synchronize()
         out[chunk] = o.float().cpu()
     L.check(lib.fo1_attention_decode_set_pool_chunk(1024), "chunk")
+    L.check(lib.fo1_attention_decode_set_impl(2), "impl")          # A/B: four waves of a workgroup each walking their own tiles
+    try:
+        out["ws"] = ops.attention_decode_batch(q, kc, vt, state, 1024, H, KV, HD, scale).float().cpu()
+        torch.cuda.synchronize()
+    finally:
+        lib.fo1_attention_decode_set_impl(0)
     grp = H // KV
     for b in range(B):
         if b == 5:
@@ -358,7 +364,7 @@ def test_pool_attention_one_chunk_writes_rows_without_combine(ab_library):
         s = torch.einsum("kgd,kld->kgl", qq, k) * scale
         p = torch.softmax(s, -1)
         ref = torch.einsum("kgl,kdl->kgd", p, v).reshape(H * HD)
-        for c in (1024, 512):
+        for c in (1024, 512, "ws"):
             err = (out[c][b] - ref).abs().max().item()
             assert err <= 2.0 ** -7 * ref.abs().max().item() + 2e-3, (b, c, err)
         assert (out[1024][b] - out[512][b]).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item() + 1e-3, b

@@ -612,6 +612,208 @@ static int launch_attn_decode_wg(AttnDecParams& p, int max_kv_len, int batch, in
     return FO1_OK;
 }
 
+// impl 2 (round 4, A/B): one workgroup per (KV head, sequence) whose FOUR WAVES EACH WALK THEIR OWN 64-key tiles (wave w: tiles w, w + 4, ...)
+// through a wave-private LDS image — the per-tile arithmetic, layouts and the coalesced 16-B / 8-B loads prefetched one tile ahead in registers are
+// attn_fwd_kernel's, but nothing in the loop waits for another wave: the dependent chain of a 700-key context is 3 tiles instead of 11.  The four
+// (m, l, O) meet in LDS once, merged in wave order.  Batched decode only (seq_state); any context length.
+__global__ __launch_bounds__(256) void attn_decode_ws_kernel(const AttnDecParams p) {
+    constexpr int HD = 128, NC = 4, NDB = 8, KB = 64, LDKR = HD + 8, LDVT = KB + 4, PITCH = HD + 2;
+    constexpr int WAVE_LDS = (KB * LDKR + HD * LDVT) * 2;          // bytes per wave: K tile + V^T tile
+    extern __shared__ __attribute__((aligned(16))) char smem_ws[];
+    const int kvh = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 15, g = lane >> 4;
+    const int* st = p.seq_state + b * 8;
+    if (st[3]) return;                               // finished / empty slot (workgroup-uniform)
+    const int kv0 = st[2], kv_len = st[0] + 1;
+    uint16_t* sK = reinterpret_cast<uint16_t*>(smem_ws + wave * WAVE_LDS);
+    uint16_t* sVT = sK + KB * LDKR;
+
+    bf16x8 qf[NC];
+    {
+        const uint16_t* qp = p.Q + (long long)b * p.q_seq_stride + ((long long)kvh * p.group + (ql < p.group ? ql : 0)) * HD;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            uint4 v = uint4{0, 0, 0, 0};
+            if (ql < p.group) v = *reinterpret_cast<const uint4*>(qp + c * 32 + g * 8);
+            qf[c] = *reinterpret_cast<bf16x8*>(&v);
+        }
+    }
+    f32x4 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c1 = p.scale * 1.44269504088896f;
+    const uint16_t* Kb = p.K + (long long)kvh * p.k_head;
+    const uint16_t* VTb = p.VT + (long long)kvh * HD * p.vt_row;
+
+    constexpr int NKR = KB * (HD / 8) / 64;          // 16-B K chunks per lane per tile (16)
+    constexpr int NVR = HD * (KB / 4) / 64;          // 8-B V^T pieces per lane per tile (32)
+    uint4 rk[NKR];
+    uint2 rv[NVR];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NKR; ++i) {
+            const int q = lane + i * 64, r = q >> 4, c = q & 15;
+            rk[i] = uint4{0, 0, 0, 0};
+            if (k0 + r < kv_len) rk[i] = *reinterpret_cast<const uint4*>(Kb + (long long)(k0 + r) * p.k_tok + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NVR; ++i) {
+            const int q = lane + i * 64, d = q >> 4, c = q & 15;
+            rv[i] = uint2{0, 0};
+            if (k0 + c * 4 < kv_len) rv[i] = *reinterpret_cast<const uint2*>(VTb + (long long)d * p.vt_row + k0 + c * 4);
+        }
+    };
+    auto swrite = [&]() {
+#pragma unroll
+        for (int i = 0; i < NKR; ++i) {
+            const int q = lane + i * 64, r = q >> 4, c = q & 15;
+            *reinterpret_cast<uint4*>(&sK[r * LDKR + c * 8]) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVR; ++i) {
+            const int q = lane + i * 64, d = q >> 4, c = q & 15;
+            *reinterpret_cast<uint2*>(&sVT[d * LDVT + c * 4]) = rv[i];
+        }
+    };
+    int k0 = kv0 + wave * KB;
+    if (k0 < kv_len) gload(k0);
+    for (; k0 < kv_len; k0 += 4 * KB) {
+        // wave-private image: this wave's LDS instructions execute in order, so the tile's writes follow the previous tile's reads and
+        // precede this tile's; the fences only keep hipcc from moving them
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        swrite();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int nk0 = k0 + 4 * KB;
+        if (nk0 < kv_len) gload(nk0);
+
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            bf16x8 kf[2][NC];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) kf[kt][c] = *reinterpret_cast<const bf16x8*>(&sK[((kh * 2 + kt) * 16 + ql) * LDKR + c * 32 + g * 8]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    s[kh * 2 + kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[c], s[kh * 2 + kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint2 vlo[NDB], vhi[NDB];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const uint16_t* vr = &sVT[(db * 16 + ql) * LDVT + g * 4];
+            vlo[db] = *reinterpret_cast<const uint2*>(vr);
+            vhi[db] = *reinterpret_cast<const uint2*>(vr + 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + KB > kv_len) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (k0 + kt * 16 + g * 4 + r >= kv_len) s[kt][r] = -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])), fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * c1);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t w[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = half * 2 + t;
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c1, -m_use));
+                    psum += e[r];
+                }
+                w[t * 2 + 0] = pack_bf16x2(e[0], e[1]);
+                w[t * 2 + 1] = pack_bf16x2(e[2], e[3]);
+            }
+            uint4 pk = uint4{w[0], w[1], w[2], w[3]};
+            pf[half] = *reinterpret_cast<bf16x8*>(&pk);
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) { o[db][0] *= alpha; o[db][1] *= alpha; o[db][2] *= alpha; o[db][3] *= alpha; }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 vk[NDB];
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) vk[db] = uint4{vlo[db].x, vlo[db].y, vhi[db].x, vhi[db].y};
+            if (half == 0) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const uint16_t* vr = &sVT[(db * 16 + ql) * LDVT + 32 + g * 4];
+                    vlo[db] = *reinterpret_cast<const uint2*>(vr);
+                    vhi[db] = *reinterpret_cast<const uint2*>(vr + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vk[db]), pf[half], o[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the waves' partials meet in LDS (each wave re-uses its own image): [16 queries][HD + 2] fp32 = O row, m (base 2), l
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    float* sp = reinterpret_cast<float*>(smem_ws + wave * WAVE_LDS);
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+        *reinterpret_cast<float4*>(sp + ql * PITCH + db * 16 + g * 4) = float4{o[db][0], o[db][1], o[db][2], o[db][3]};
+    if (g == 0) { sp[ql * PITCH + HD] = m_run; sp[ql * PITCH + HD + 1] = l_run; }
+    __syncthreads();
+    const int d = tid & (HD - 1);
+    for (int qq = tid >> 7; qq < p.group; qq += 2) {
+        float mw[4], M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            mw[w] = reinterpret_cast<const float*>(smem_ws + w * WAVE_LDS)[qq * PITCH + HD];
+            M = fmaxf(M, mw[w]);
+        }
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float* pw = reinterpret_cast<const float*>(smem_ws + w * WAVE_LDS) + qq * PITCH;
+            const float f = (mw[w] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(mw[w] - M);
+            num += f * pw[d];
+            den += f * pw[HD + 1];
+        }
+        p.O[(long long)b * p.o_seq_stride + ((long long)kvh * p.group + qq) * HD + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
+    }
+}
+
+static int launch_attn_decode_ws(AttnDecParams& p, int max_kv_len, int batch, hipStream_t st) {
+    constexpr int smem = 4 * (64 * (128 + 8) + 128 * (64 + 4)) * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)attn_decode_ws_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    FO1_LAUNCH("attn_decode_ws", (double)batch * max_kv_len * p.n_kv_heads * 128 * 4.0, attn_decode_ws_kernel, dim3(1, p.n_kv_heads, batch), dim3(256), smem, st, p);
+    return FO1_OK;
+}
+
 #endif   // FO1_ENABLE_AB (attn_decode_wg_kernel)
 
 extern int g_gemv_profile_shapes;   // gemv.hip: per-shape profile rows (fo1_gemm_profile_shapes)
@@ -773,7 +975,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
 // A/B hook: 0 (default) = 64-key split-KV partials + combine kernel; 1 = one workgroup per (KV head, sequence) with the waves'
 // partials merged in LDS (one launch up to 2048 keys; measured slower, see attn_decode_wg_kernel).
 int fo1_attention_decode_set_impl(int impl) {
-    if (impl != 0 && impl != 1) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_impl: %d", impl);
+    if (impl < 0 || impl > 2) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_impl: %d", impl);
     fo1::g_attn_decode_impl = impl;
     return FO1_OK;
 }
@@ -824,6 +1026,16 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
         d.part = (float*)workspace; d.seq_state = (const int*)state; d.dyn_kv_len = nullptr;
         d.n_kv_heads = n_kv_heads; d.group = group; d.scale = scale;
         return launch_attn_decode_wg(d, max_kv_len, batch, n_q_heads, (hipStream_t)stream);
+    }
+    if (g_attn_decode_impl == 2) {
+        AttnDecParams d;
+        d.Q = (const uint16_t*)q; d.q_seq_stride = q_seq_stride;
+        d.K = (const uint16_t*)kcache; d.k_tok = k_tok_stride; d.k_head = k_head_stride;
+        d.VT = (const uint16_t*)vtcache; d.vt_row = vt_row_stride;
+        d.O = (uint16_t*)out; d.o_seq_stride = out_seq_stride;
+        d.part = nullptr; d.part_seq_stride = 0; d.seq_state = (const int*)state; d.dyn_kv_len = nullptr;
+        d.n_kv_heads = n_kv_heads; d.group = group; d.scale = scale; d.split_keys = 0; d.n_splits = 1;
+        return launch_attn_decode_ws(d, max_kv_len, batch, (hipStream_t)stream);
     }
 #endif
     AttnParams p;
