@@ -261,6 +261,11 @@ int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M
 int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N, const void* bias, const void* residual, int ldr, void* x_out,
                                      int ldx, const void* norm_weight, float eps, void* xn_out, int ldn, void* stream);
 int fo1_splitk_swiglu_bf16(const float* part, int splits, int M, int N, void* out, int ldo, void* stream);
+/* fo1_gemm_bf16 for a weight that few rows (<= 128) stream once per call — the decode pool's gate/up and lm_head: W_tiled is a copy of W [N, K] laid
+ * out [N / 128][K / 64][128][64] (made once at load), so a K tile of a column tile is one contiguous 16 KB block.  Same kernel, arithmetic and
+ * epilogues as fo1_gemm_bf16 (bit-identical on the same tile shape).  N % 128 == 0, K % 64 == 0. */
+int fo1_gemm_bf16_wtiled(const void* A, int lda, const void* W_tiled, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
+                         int K, int act, void* stream);
 /* Weight-streaming GEMV (M <= 4) with the fo1_gemm_bf16 epilogues and an optional fused Qwen2RMSNorm on the input rows
  * (norm_weight [K] or NULL): folds input_layernorm / post_attention_layernorm into the projections of the decode step. */
 int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, int ldr,

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--attn-impl", type=int, nargs="+", default=[0], help="A/B (FO1_AB=1): 0 = split-KV + combine, 1 = one workgroup per (KV head, sequence)")
     ap.add_argument("--splits", type=int, nargs=4, default=None, metavar=("QKV", "O", "DOWN", "GATEUP"), help="split-K planes of the pool's q/k/v, o, down and gate/up projections (default: DecodePool.SPLITS; GATEUP 0 = SwiGLU epilogue)")
+    ap.add_argument("--tiled", action="store_true", help="gate/up and lm_head from the pre-tiled weight copies (DecodePool.TILED_WEIGHTS = True; default off)")
+    ap.add_argument("--no-tiled", action="store_true", help="(default) gate/up and lm_head from the row-major weights")
     ap.add_argument("--unfused", action="store_true", help="the step on plain GEMM epilogues + separate RMSNorm launches (DecodePool.FUSED_SPLITK = False)")
     ap.add_argument("--fill", type=float, default=1.0, help="fraction of the slots that hold live sequences")
     args = ap.parse_args()
@@ -30,12 +32,16 @@ def main():
         DecodePool.SPLITS = dict(qkv=args.splits[0], o=args.splits[1], down=args.splits[2], gateup=args.splits[3])
     if args.unfused:
         DecodePool.FUSED_SPLITK = False
+    if args.no_tiled:
+        DecodePool.TILED_WEIGHTS = False
+    if args.tiled:
+        DecodePool.TILED_WEIGHTS = True
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     cases = [B.build_workload(dev, n_boxes=100, seed=1234 + i) for i in range(32)]
     pipe = B.Pipeline(cases[0], dev, inflight=1, batch=32, cases=cases)
     eng = pipe.eng
-    out = dict(fused_splitk=DecodePool.FUSED_SPLITK, splits=dict(DecodePool.SPLITS), prompt_tokens=len(cases[0]["ids"]) - 1 + cases[0]["grid"][0] * cases[0]["grid"][1] // 4)
+    out = dict(tiled_weights=DecodePool.TILED_WEIGHTS, fused_splitk=DecodePool.FUSED_SPLITK, splits=dict(DecodePool.SPLITS), prompt_tokens=len(cases[0]["ids"]) - 1 + cases[0]["grid"][0] * cases[0]["grid"][1] // 4)
     wbytes = float(sum(t.numel() * t.element_size() for t in eng.llm.decode_weight_tensors()))
     out["weight_bytes_per_step"] = wbytes
     eng.prefill_batch(pipe.requests, use_graph=False)

@@ -59,6 +59,17 @@ def test_pool_projections_and_qkv_post_match_reference(P, product_library):
     got = ops.gemm(x, ops.interleave_gate_up(gate, up).cuda(), act=ops.ACT_SWIGLU16)
     gt, u = rb(x.float() @ gate.float().t()), rb(x.float() @ up.float().t())
     _close(got, rb(rb(torch.nn.functional.silu(gt)) * u), "swiglu", ulps=2.0, rare=5e-3)
+    # the pre-tiled weight copy the pool streams gate/up and lm_head from (fo1_gemm_bf16_wtiled): the same kernel on another address pattern -> same bits
+    wgu = ops.interleave_gate_up(gate, up).cuda()
+    got_t = ops.gemm_wtiled(x, ops.tile_weight(wgu), act=ops.ACT_SWIGLU16)
+    if P > 64:
+        assert torch.equal(got_t, got), "tiled gate/up (same 128 x 128 ring tile as the row-major call)"
+    else:
+        _close(got_t, got, "tiled gate/up (64 x 128 tile against the row-major call's 64 x 64)", ulps=1.0)
+    wl, xb, rl = rnd(128 * 9, K, sc=0.03), rnd(P, K), rnd(P, 128 * 9)
+    bl = rnd(128 * 9, sc=0.1)
+    ref_t = ops.gemm_wtiled(xb, ops.tile_weight(wl), bl, rl)
+    _close(ref_t, rb(rb(xb.float() @ wl.float().t() + bl.float()) + rl.float()), "tiled plain + bias + residual", mag=(xb.float() @ wl.float().t()).abs().cpu() + 4)
     # ---- q/k/v: bias -> bf16 (GEMM), then mRoPE at the slot's table row -> q rows in place, K rows, V^T columns at the slot's cache row ----
     H, KV, HD, K, rows = 16, 2, 128, 2048, 1024
     x, w, b = rnd(P, K), rnd((H + 2 * KV) * HD, K, sc=0.05), rnd((H + 2 * KV) * HD, sc=0.1)

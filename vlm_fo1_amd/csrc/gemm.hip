@@ -52,6 +52,9 @@ struct GemmParams {
     // fp8 (fo1_gemm_fp8): A and W are OCP e4m3 bytes, C = (A W^T) * scale_m[m] * scale_n[n] before the epilogue
     const float* scale_m;
     const float* scale_n;
+    // ring kernels with BN = 128 (fo1_gemm_bf16_wtiled): W is a copy pre-tiled as [N / 128][K / 64][128 rows][64] — a K tile of a column tile is ONE
+    // contiguous 16 KB block (the decode pool's weight streams: profiles/r04_hbm_stream_patterns.jsonl)
+    int w_tiled = 0;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3, ACT_RELU = 5 };   // (4 = the split-K partial epilogue of the 256x256 kernels)
@@ -530,15 +533,21 @@ __global__ __launch_bounds__(256) void gemm_bt_ring_kernel(const GemmParams p) {
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int lr = lane >> 3, lc = lane & 7;
+    const int nk_all = p.K / BK;
     const uint16_t* src[IPW];
+    int kstep[IPW];                        // elements from one K tile to the next: 64, or a whole 128 x 64 block of a pre-tiled W
 #pragma unroll
     for (int i = 0; i < IPW; ++i) {
         const int R = (wave * IPW + i) * 8 + lr;
         const int cs = (lc ^ ((R >> 1) & 7)) * 8;
+        kstep[i] = BK;
         if (R < BM) {
             int gm = m0 + R;
             gm = gm < p.M ? gm : p.M - 1;
             src[i] = A + (long long)gm * p.lda + cs;
+        } else if (BN == 128 && p.w_tiled) {
+            src[i] = W + ((long long)tn * nk_all * BN + (R - BM)) * BK + cs;
+            kstep[i] = BN * BK;
         } else {
             int gn = n0 + (R - BM);
             gn = gn < p.N ? gn : p.N - 1;
@@ -549,12 +558,11 @@ __global__ __launch_bounds__(256) void gemm_bt_ring_kernel(const GemmParams p) {
 #pragma unroll
         for (int i = 0; i < IPW; ++i) {
             char* dst = smem + buf * (ROWS * 128) + (wave * IPW + i) * 1024;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + kt * BK),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[i] + (long long)kt * kstep[i]),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
 
-    const int nk_all = p.K / BK;
     const int kt0 = blockIdx.z * p.kper;
     const int nk = min(nk_all - kt0, p.kper);
 #pragma unroll
@@ -2194,6 +2202,32 @@ int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M
     // 17.4 vs 16.3 us at 12-16 planes, profiles/r04_pool_step_splitk_sweep.json)
     if ((long long)cdiv(M, 64) * cdiv(N, 128) * p.splits >= 256) return launch_gemm<64, 128>(p, 1, true, (hipStream_t)stream, false);
     return launch_gemm<64, 64>(p, 1, true, (hipStream_t)stream, false);
+}
+
+// fo1_gemm_bf16 for a weight streamed ONCE per call by few rows (the decode pool's gate/up and lm_head at 65..128 rows, 33..64 rows on the
+// 64 x 128 tile): W_tiled is the copy of W [N, K] laid out [N / 128][K / 64][128][64] (ops.tile_weight), so that every K tile of a column tile is
+// one contiguous 16 KB block instead of 128 pieces of 128 B at a 2 K-byte stride.  Same kernel (LDS-DMA ring, BN = 128), same arithmetic and
+// epilogues — results bit-identical to fo1_gemm_bf16 on the row-major W when that call takes the same tile.  N % 128 == 0, K % 64 == 0, M <= 128.
+int fo1_gemm_bf16_wtiled(const void* A, int lda, const void* W_tiled, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
+                         int K, int act, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(A && W_tiled && C, "gemm_wtiled: NULL operand");
+    FO1_CHECK_ARG(M >= 1 && M <= 128 && N >= 128 && N % 128 == 0 && K >= 64 && K % 64 == 0, "gemm_wtiled: M=%d (<= 128) N=%d (%% 128) K=%d (%% 64)", M, N, K);
+    FO1_CHECK_ARG(lda % 8 == 0 && lda >= K && ((uintptr_t)A & 15) == 0 && ((uintptr_t)W_tiled & 15) == 0, "gemm_wtiled: A / W alignment");
+    FO1_CHECK_ARG((act >= 0 && act <= 3) || act == 5, "gemm_wtiled: act=%d", act);
+    if (act == 3) FO1_CHECK_ARG(residual == nullptr && ldc % 4 == 0 && ((uintptr_t)C & 7) == 0 && ldc >= N / 2, "gemm_wtiled: swiglu epilogue layout");
+    else FO1_CHECK_ARG(ldc >= N, "gemm_wtiled: ldc too small");
+    FO1_CHECK_ARG(residual == nullptr || ldr >= N, "gemm_wtiled: ldr too small");
+    GemmParams p;
+    p.A = (const uint16_t*)A; p.W = (const uint16_t*)W_tiled; p.bias = (const uint16_t*)bias; p.res = (const uint16_t*)residual;
+    p.C = (uint16_t*)C; p.C32 = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = K; p.ldc = ldc; p.ldr = ldr; p.act = act;
+    p.sA = p.sW = p.sC = p.sR = 0;
+    p.splits = 1; p.kper = K / 64 + 1; p.part = nullptr; p.stages = 3; p.debug = 0; p.coal = 0;
+    p.scale_m = p.scale_n = nullptr;
+    p.w_tiled = 1;
+    if (M > 64) return launch_gemm<128, 128>(p, 1, true, (hipStream_t)stream);
+    return launch_gemm<64, 128>(p, 1, true, (hipStream_t)stream);
 }
 
 // fp8 linear (BASELINE configs[4], "fp8 MFMA"): C[M,N] = epilogue((Aq Wq^T) * scale_a[m] * scale_w[n]) with OCP e4m3 operands, fp32

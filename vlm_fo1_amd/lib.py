@@ -207,6 +207,7 @@ SIGNATURES = {
     "fo1_pool_qkv_post_partials_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_longlong, c_void_p, c_longlong, c_void_p]),
     "fo1_gemm_bf16_partials": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fo1_gemm_bf16_wtiled": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_splitk_swiglu_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "fo1_splitk_residual_rmsnorm_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p,
                                                  c_int, c_void_p]),

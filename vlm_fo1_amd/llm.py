@@ -800,6 +800,7 @@ class DecodePool:
         self._keep: list = []
         self._ws_owner = ops.new_owner(self)
         self._ensure(slot_rows)
+        self._tiled()
 
     # ---- memory ----------------------------------------------------------------------------------------------------------------
     def _ensure(self, slot_rows: int):
@@ -899,6 +900,23 @@ class DecodePool:
     # gateup 0 = one GEMM with the SwiGLU epilogue (172 tiles of 128 x 128: 34 us); as 2 / 3 / 4 planes of 128 x 256 tiles + fo1_splitk_swiglu_bf16 it
     # measured 36 / 49 / 46 us (profiles/r04_pool_step_splitk_sweep.json) — the planes path stays available, parity-tested, unused
     SPLITS = dict(qkv=4, o=4, down=8, gateup=0)
+    # TILED_WEIGHTS: gate/up and lm_head read a copy pre-tiled as [N / 128][K / 64][128][64] (ops.tile_weight, fo1_gemm_bf16_wtiled: a K tile is one
+    # contiguous 16 KB block; 3.8 GB at the 3B shapes).  Bit-identical, and the weight stream ALONE gains 15 % that way (profiles/r04_hbm_stream_patterns.jsonl),
+    # but the step does not: 3.872 vs 3.888 ms (profiles/r04_pool_step_tiled_weights_ab.json) — the activations on the same DMA path are what the tile waits for.  Off.
+    TILED_WEIGHTS = False
+
+    def _tiled(self):
+        """(per-layer tiled gate/up copies, tiled lm_head) or None; built once per LLM, in DecodePool.__init__ (never inside a graph capture)."""
+        if not self.TILED_WEIGHTS:
+            return None
+        t = self.llm.__dict__.get("_pool_tiled_w")          # on the LLM: every pool over these weights shares the copies
+        if t is None:
+            def tile(w):
+                return ops.tile_weight(w) if (w.shape[0] % 128 == 0 and w.shape[1] % 64 == 0) else None
+            with torch.inference_mode(False):
+                t = ([tile(w["wgu"]) for w in self.llm.layers], tile(self.llm.lm_head))
+            self.llm._pool_tiled_w = t
+        return t
 
     def _step_device(self, bucket: int):
         llm, P = self.llm, self.P
@@ -924,11 +942,13 @@ class DecodePool:
                     if self.SPLITS["gateup"] >= 2:
                         s = ops.gemm_partials(xn, w["wgu"], self.SPLITS["gateup"], part)
                         a = ops.splitk_swiglu(part, s, P, NGU)
+                    elif self._tiled() is not None and self._tiled()[0][li] is not None:
+                        a = ops.gemm_wtiled(xn, self._tiled()[0][li], act=ops.ACT_SWIGLU16)
                     else:
                         a = ops.gemm(xn, w["wgu"], act=ops.ACT_SWIGLU16)
                     s = ops.gemm_partials(a, w["wdown"], self.SPLITS["down"], part)
                     ops.splitk_residual_rmsnorm(part, s, x, llm.layers[li + 1]["ln1"] if li + 1 < len(llm.layers) else llm.norm, eps, x, xn)
-                logits = ops.gemm(xn, llm.lm_head)
+                logits = ops.gemm_wtiled(xn, self._tiled()[1]) if (self._tiled() is not None and self._tiled()[1] is not None) else ops.gemm(xn, llm.lm_head)
             else:
                 for li, w in enumerate(llm.layers):
                     qkv = ops.gemm(ops.rmsnorm(x, w["ln1"], c.rms_norm_eps), w["wqkv"], w["bqkv"])
@@ -948,7 +968,7 @@ class DecodePool:
             out = self._step_device(bucket)
         else:
             # (the step's form is part of the key: FUSED_SPLITK / SPLITS may be set per pool, scripts/pool_bench.py and the A/B test do)
-            key = (self.slot_rows, self.n_stop, bucket, self.llm.rope_epoch, self.llm.rope_cos.data_ptr(), bool(self.FUSED_SPLITK), tuple(sorted(self.SPLITS.items())))
+            key = (self.slot_rows, self.n_stop, bucket, self.llm.rope_epoch, self.llm.rope_cos.data_ptr(), bool(self.FUSED_SPLITK), tuple(sorted(self.SPLITS.items())), bool(self.TILED_WEIGHTS))
             ent = self._graphs.get(key)
             if ent is None:
                 with ops.graph_lock.capture(), torch.inference_mode(False):

@@ -552,6 +552,30 @@ def splitk_residual_rmsnorm(part: torch.Tensor, splits: int, residual: torch.Ten
     _L.check(rc, "fo1_splitk_residual_rmsnorm_bf16")
 
 
+def tile_weight(w: torch.Tensor) -> torch.Tensor:
+    """The [N / 128][K / 64][128][64] copy of a row-major weight [N, K] that fo1_gemm_bf16_wtiled streams (N % 128 == 0, K % 64 == 0)."""
+    N, K = w.shape
+    assert N % 128 == 0 and K % 64 == 0 and w.dtype == torch.bfloat16
+    return w.view(N // 128, 128, K // 64, 64).permute(0, 2, 1, 3).contiguous()
+
+
+def gemm_wtiled(a: torch.Tensor, w_tiled: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+    """a @ W.T (+ epilogue) with W given as ops.tile_weight(W): the weight-streaming form for <= 128 rows (fo1_gemm_bf16_wtiled)."""
+    _chk(a, "a"); _chk(w_tiled, "w_tiled")
+    pa, lda, M, K = _rows(a, "a")
+    assert w_tiled.dim() == 4 and w_tiled.shape[2:] == (128, 64) and w_tiled.is_contiguous() and w_tiled.shape[1] * 64 == K
+    N = w_tiled.shape[0] * 128
+    out = torch.empty(M, N // 2 if act == ACT_SWIGLU16 else N, dtype=torch.bfloat16, device=a.device)
+    po, ldc, _, _ = _rows(out, "out")
+    pr, ldr = (None, 0)
+    if residual is not None:
+        _chk(residual, "residual")
+        pr, ldr, _, _ = _rows(residual, "residual")
+    rc = _L.load().fo1_gemm_bf16_wtiled(pa, lda, w_tiled.data_ptr(), bias.data_ptr() if bias is not None else None, pr, ldr, po, ldc, M, N, K, int(act), _stream())
+    _L.check(rc, "fo1_gemm_bf16_wtiled")
+    return out
+
+
 def splitk_swiglu(part: torch.Tensor, splits: int, M: int, N: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out [M, N / 2] = SwiGLU over the split-K planes of a product against a 16-row interleaved gate/up weight (fo1_splitk_swiglu_bf16)."""
     assert part.dtype == torch.float32 and part.numel() >= splits * M * N and part.is_cuda
