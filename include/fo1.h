@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FO1_ABI_VERSION 5   /* 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16); 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 5   /* 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
