@@ -276,8 +276,12 @@ int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bi
  * _flash_attention_forward / SDPA at modeling_qwen2_5_vl.py:205,319,895,990; DaViT window
  * attention modeling_davit.py:262-270).  head_dim in {32, 80, 128}; GQA via n_q_heads/n_kv_heads.
  * `items` = device int32[n_items][4] {q_start, q_end, kv_start, kv_end}: each item is <= q_block
- * (16, 32 or 64: one wave per 16 queries; smaller blocks = more workgroups for short sequences)
  * queries attending keys [kv_start, kv_end) (and key <= query when causal); kv_start % 4 == 0.
+ * q_block 16, 32 or 64: 16x16-MFMA kernel, one wave per 16 queries (smaller blocks = more workgroups
+ * for short sequences).  q_block 128 or 256 (head_dim 80 / 128, no q_row_base): 32x32-MFMA kernel,
+ * 8 waves x 32 queries per workgroup — 256 queries of one head, or 128 queries x the TWO query heads
+ * of one KV head (n_q_heads / n_kv_heads even: both heads share the staged K / V^T tiles); O rows are
+ * stored in 16-byte pieces (O 16-byte aligned, strides % 8 == 0), K / V^T row strides < 2^22.
  * V is passed transposed: VT[(kv_head*head_dim + d)*vt_row_stride + key] (fo1_transpose_bf16),
  * finite beyond kv_end up to the next multiple of 4.  Strides in elements.
  * ---------------------------------------------------------------------- */

@@ -267,6 +267,102 @@ def test_attention_online_softmax_rescale_branch():
     assert err.max() < 3e-2, f"max err {err.max():.4g} at row {int(err.max(1).values.argmax())}"
 
 
+def _attn_case(segs, H, KV, D, seed):
+    from vlm_fo1_amd import ops
+    torch.manual_seed(seed)
+    L = max(e for _, e in segs)
+    qkv = (torch.randn(L, (H + 2 * KV) * D) * 1.5).to(BF).cuda()
+    q, k, v = qkv[:, :H * D], qkv[:, H * D:(H + KV) * D], qkv[:, (H + KV) * D:]
+    vt = torch.zeros(KV * D, (L + 63) // 64 * 64, dtype=BF, device="cuda")
+    ops.transpose_into(v, vt, 0)
+    return qkv, q, k, v, vt, L
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(name="llm_packed_gqa", H=16, KV=2, D=128, segs=[(0, 652), (652, 1304), (1304, 1364), (1364, 1500)], causal=True, blk=128),
+    dict(name="llm_one_sequence", H=16, KV=2, D=128, segs=[(0, 391)], causal=True, blk=128),
+    dict(name="vit_full_two_images", H=16, KV=16, D=80, segs=[(0, 1564), (1564, 1864)], causal=False, blk=256),
+    dict(name="hd128_mha_causal", H=4, KV=4, D=128, segs=[(0, 700)], causal=True, blk=256),
+    dict(name="hd80_gqa_pairs", H=4, KV=2, D=80, segs=[(0, 300), (300, 556)], causal=False, blk=128),
+])
+def test_attention_32x32_form(cfg):
+    """attn_fwd32_kernel (q_block 128 / 256: 32x32 MFMA, 8 waves x 32 queries, two query heads of one KV head per workgroup when
+    grouped) against the fp32 reference at the 16x16 kernel's tolerance, and against the 16x16 kernel itself: the same products
+    in another summation order (fp32 accumulate -> one bf16 rounding): equal to <= 2 bf16 ulps + 2e-3."""
+    from vlm_fo1_amd import ops
+    H, KV, D, segs = cfg["H"], cfg["KV"], cfg["D"], cfg["segs"]
+    qkv, q, k, v, vt, L = _attn_case(segs, H, KV, D, 17)
+    scale = 1.0 / math.sqrt(D)
+    ref = attn_ref(q.float().cpu().reshape(L, H, D), k.float().cpu().reshape(L, KV, D), v.float().cpu().reshape(L, KV, D),
+                   segs, cfg["causal"], scale).reshape(L, H * D)
+    old = ops.attention(q, k, vt, ops.make_items(segs, "cuda", block=64), H, KV, D, scale, cfg["causal"])
+    got = ops.attention(q, k, vt, ops.make_items(segs, "cuda", block=cfg["blk"]), H, KV, D, scale, cfg["causal"])
+    err = (got.float().cpu() - ref).abs()
+    assert err.max() < 3e-2, f"{cfg['name']}: max err {err.max():.4g}; worst row {int(err.max(1).values.argmax())}"
+    rel = (got.float().cpu() - ref).norm() / ref.norm()
+    assert rel < 6e-3, f"{cfg['name']}: rel fro err {rel:.4g}"
+    d = (got.float() - old.float()).abs().cpu()
+    assert (d <= 2 * 2.0 ** -7 * old.float().abs().cpu() + 2e-3).all(), f"{cfg['name']}: vs the 16x16 kernel max {d.max():.4g}"
+    # run to run and partition to partition: a query's arithmetic depends on its segment and its place in the 32-query wave only
+    again = ops.attention(q, k, vt, ops.make_items(segs, "cuda", block=cfg["blk"]), H, KV, D, scale, cfg["causal"])
+    assert torch.equal(got, again)
+
+
+def test_attention_32x32_form_prefix_ranges():
+    """Second key range per item (shared prompt prefix, fo1_attention_prefix_bf16) on the 32x32 kernel: rows [0, 408) are the prefix,
+    two prompts own [408, 660) and [660, 1000); every own row attends [prefix | own rows up to itself] = the causal attention of the
+    sequence [prefix | own rows] restricted to its own rows."""
+    from vlm_fo1_amd import ops
+    H, KV, D = 16, 2, 128
+    P, A, B = 408, 252, 340
+    segs_all = [(0, P + A + B)]
+    qkv, q, k, v, vt, L = _attn_case(segs_all, H, KV, D, 23)
+    kc = k.reshape(L, KV, D).permute(1, 0, 2).contiguous()          # cache layout [kv head][pos][D]
+    scale = 1.0 / math.sqrt(D)
+    qf, kf, vf = q.float().cpu().reshape(L, H, D), k.float().cpu().reshape(L, KV, D), v.float().cpu().reshape(L, KV, D)
+    ref = torch.zeros(L, H * D)
+    ref[:P] = attn_ref(qf[:P], kf[:P], vf[:P], [(0, P)], True, scale).reshape(P, H * D)
+    for (a, b) in ((P, P + A), (P + A, L)):
+        idx = list(range(P)) + list(range(a, b))
+        r = attn_ref(qf[idx], kf[idx], vf[idx], [(0, len(idx))], True, scale).reshape(len(idx), H * D)
+        ref[a:b] = r[P:]
+    for blk in (64, 128):
+        rows, rng = [], []
+        for (a, b, r2) in ((0, P, (0, 0)), (P, P + A, (0, P)), (P + A, L, (0, P))):
+            for q0 in range(a, b, blk):
+                rows.append([q0, min(q0 + blk, b), a, b]); rng.append(list(r2))
+        items = torch.tensor(rows, dtype=torch.int32).cuda(); items.q_block = blk
+        got = ops.attention_strided(q, 0, kc, vt, items, H, KV, D, scale, True, prefix_ranges=torch.tensor(rng, dtype=torch.int32).cuda())
+        err = (got.float().cpu() - ref).abs()
+        assert err.max() < 3e-2, f"q_block {blk}: max err {err.max():.4g}; worst row {int(err.max(1).values.argmax())}"
+        assert (got.float().cpu() - ref).norm() / ref.norm() < 6e-3
+
+
+def test_attention_32x32_form_rescale_branch():
+    """The spiked-key case of test_attention_online_softmax_rescale_branch on the 32x32 kernel (the O rescale is a wave-uniform
+    branch that random data takes only in the first tiles)."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(8)
+    L, H, D = 512, 2, 128
+    q = torch.randn(L, H * D)
+    k = torch.randn(L, H * D) * 0.3
+    v = torch.randn(L, H * D)
+    k[200] = q[10] * 2.0
+    k[70] = q[33] * 3.0
+    k[450, :D] = q[300, :D] * 2.5
+    qkv = torch.cat([q, k, v], 1).to(BF).cuda()
+    vt = torch.zeros(H * D, 512, dtype=BF, device="cuda")
+    ops.transpose_into(qkv[:, 2 * H * D:], vt, 0)
+    sc = 1 / math.sqrt(D)
+    qf = qkv.float().cpu()
+    ref = attn_ref(qf[:, :H * D].reshape(L, H, D), qf[:, H * D:2 * H * D].reshape(L, H, D),
+                   qf[:, 2 * H * D:].reshape(L, H, D), [(0, L)], False, sc).reshape(L, H * D)
+    for blk in (128, 256):
+        got = ops.attention(qkv[:, :H * D], qkv[:, H * D:2 * H * D], vt, ops.make_items([(0, L)], "cuda", block=blk), H, H, D, sc, False)
+        err = (got.float().cpu() - ref).abs()
+        assert err.max() < 3e-2, f"q_block {blk}: max err {err.max():.4g} at row {int(err.max(1).values.argmax())}"
+
+
 @pytest.mark.parametrize("splits", [2, 3, 8])
 def test_gemm_splitk(splits, ab_library):
     """Split-K partials + fixed-order reduce must match the single-pass kernel to fp32 re-association."""

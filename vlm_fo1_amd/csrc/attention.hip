@@ -366,6 +366,309 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     }
 }
 
+// ---- prefill attention on 32x32 MFMA tiles: 8 waves x 32 queries per workgroup -------------------------------------------------
+// The same fragment algebra as attn_fwd_kernel on v_mfma_f32_32x32x16_bf16: S^T = K Q^T (a = K rows, b = Q), so a lane owns ONE
+// query column (lane & 31) and 16 of the 32 keys of a sub-tile (the other 16 live in lane ^ 32): row maximum = in-lane chain + one
+// cross-half exchange, row sum = in-lane partials merged once after the last tile.  The exponentiated scores, rounded to bf16 in
+// pairs, ARE the B operand of O^T = V^T P^T — k-slot j of PV step t of sub-tile s is key 32 s + 16 t + 8 (j >> 2) + 4 hi + (j & 3), and
+// the V^T A operand reads exactly those keys as two 8-byte pieces of its row (which is why V is cached transposed).
+// Against the 16x16 form: half the LDS fragment bytes per flop, one cross-lane exchange per 64-key tile instead of four, K / V^T tiles
+// staged once per 256 query-rows (QB queries x HPW heads of one KV head: with GQA the two query heads of a workgroup share the tile),
+// a double-buffered LDS image with ONE barrier per tile, register prefetch two tiles ahead (issue-early / write-late), and output rows
+// staged through LDS and stored as whole rows.
+//   HPW = 1: 256 queries of one head per workgroup (ViT full attention, head dim 80 = 5 k-steps of 16, O^T padded to 96 rows);
+//   HPW = 2: 128 queries x 2 query heads that share a KV head (LLM prefill, 16 q / 2 kv heads).
+// Items: as attn_fwd_kernel (<= QB queries of one segment, a key range, optionally a second key range walked first).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int HD, int HPW>
+__global__ __launch_bounds__(512, 2) void attn_fwd32_kernel(const AttnParams p) {
+    constexpr int WPH = 8 / HPW;              // waves per head
+    constexpr int KB = 64;                    // keys per tile
+    constexpr int NKC = HD / 16;              // k-steps of QK^T
+    constexpr int NDB = (HD + 31) / 32;       // 32-row d blocks of O^T
+    constexpr int HDV = NDB * 32;             // V^T rows in the LDS image (rows >= HD stay zero)
+    constexpr int LDK = HD + 8;               // K row pitch (elements): 16-lane b128 groups hit 16 distinct 16-B bank groups
+    constexpr int LDV = KB + 8;               // V^T row pitch: 144 B = 9 x 16 B (odd): the b128 lane groups hit 16 distinct 16-B bank groups
+    constexpr int SK = KB * LDK, SV = HDV * LDV;
+    constexpr int KCH = HD / 8;               // 16-B chunks per K row
+    constexpr int NKR = (KB * KCH + 511) / 512;
+    constexpr int NVR = (HD * (KB / 4) + 511) / 512;
+    static_assert(HD % 16 == 0 && 8 % HPW == 0, "attn_fwd32: head dim / heads per workgroup");
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem32[];
+    uint16_t* sK = smem32;                    // [2][SK]
+    uint16_t* sVT = smem32 + 2 * SK;          // [2][SV]
+
+    const AttnItem it = p.items[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qc = lane & 31, hi = lane >> 5;
+    const int hsel = wave / WPH, wq = wave - hsel * WPH;
+    const int h = blockIdx.y * HPW + hsel;
+    const int kvh = (blockIdx.y * HPW) / p.group;          // both heads of the workgroup share it (group % HPW == 0)
+    const int wq0 = it.q_start + wq * 32;                  // this wave's first query
+    const int q_idx = wq0 + qc;
+    const bool q_ok = q_idx < it.q_end;
+    const bool wave_on = wq0 < it.q_end;
+
+    if constexpr (HDV > HD) {      // O^T pad rows of both buffers: zeroed once, never rewritten
+        constexpr int PADW = (HDV - HD) * LDV / 2;     // dwords per buffer
+        for (int q = tid; q < 2 * PADW; q += 512) {
+            const int b = q >= PADW ? 1 : 0;
+            reinterpret_cast<uint32_t*>(sVT + b * SV + HD * LDV)[q - b * PADW] = 0u;
+        }
+    }
+
+    // Q fragments (B operand): lane (query qc, k-half hi) holds d = kc*16 + hi*8 .. +8
+    bf16x8 qf[NKC];
+    {
+        const int q_ld = q_ok ? q_idx : it.q_end - 1;
+        const uint16_t* qp = p.Q + (long long)q_ld * p.q_tok + (long long)h * p.q_head + hi * 8;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) {
+            const uint4 v = *reinterpret_cast<const uint4*>(qp + kc * 16);
+            qf[kc] = *reinterpret_cast<const bf16x8*>(&v);
+        }
+        // the fragments are complete HERE: left pending, hipcc's waitcnt pass puts `s_waitcnt vmcnt(7) .. vmcnt(0)` in front of the QK^T MFMAs
+        // inside the tile loop (the first trip needs them), and every trip then drains the tile prefetch it has just issued
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc) asm volatile("" : "+v"(qf[kc]));
+    }
+    f32x16 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;       // m_run: running maximum of c1 * score (base 2); l_run: THIS lane's share of the row sum
+    const float c1 = p.scale * 1.44269504088896f;
+
+    int own_hi = it.kv_end;
+    if (p.causal && it.q_end < own_hi) own_hi = it.q_end;  // keys beyond the last query are never attended
+    const uint16_t* Kb = p.K + (long long)kvh * p.k_head;
+    const uint16_t* VTb = p.VT + (long long)kvh * HD * p.vt_row;
+
+    // ---- staging: global -> registers two tiles ahead, registers -> LDS one tile ahead.  Raw buffer loads: a wave-uniform descriptor +
+    // scalar tile offset + ONE loop-invariant 32-bit lane offset per piece (no address arithmetic in the loop, no load inside a branch).
+    // The K descriptor ends at the range's last row, so the rows past it read as zero; V^T columns past the range are zeroed on the way
+    // to LDS (last tile only: 0 x NaN would poison the PV product). ----
+    typedef __attribute__((ext_vector_type(4))) unsigned int v4u;
+    typedef __attribute__((ext_vector_type(2))) unsigned int v2u;
+    const int k_tok = (int)p.k_tok, vt_row = (int)p.vt_row;
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)VTb, 0, HD * vt_row * 2, 0x00020000);
+    uint32_t koff[NKR], voff[NVR];
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) {
+        int q = tid + i * 512;
+        if (NKR * 512 != KB * KCH && q >= KB * KCH) q = KB * KCH - 1;
+        const int r = q / KCH, c = q - r * KCH;
+        koff[i] = (uint32_t)(r * k_tok + c * 8) * 2u;
+    }
+#pragma unroll
+    for (int i = 0; i < NVR; ++i) {
+        int q = tid + i * 512;
+        if (NVR * 512 != HD * (KB / 4) && q >= HD * (KB / 4)) q = HD * (KB / 4) - 1;
+        voff[i] = (uint32_t)((q >> 4) * vt_row + (q & 15) * 4) * 2u;
+    }
+    v4u rk[NKR];
+    v2u rv[NVR];
+    auto gload = [&](int k0, int hi_) {
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, hi_ * k_tok * 2, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NKR; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[i], k0 * k_tok * 2, 0);
+#pragma unroll
+        for (int i = 0; i < NVR; ++i) rv[i] = __builtin_amdgcn_raw_buffer_load_b64(rsV, voff[i], k0 * 2, 0);
+    };
+    auto swrite = [&](int buf, int k0, int hi_) {
+        const bool last = k0 + KB > hi_;       // wave-uniform: only a range's last tile has columns to zero
+#pragma unroll
+        for (int i = 0; i < NKR; ++i) {
+            const int q = tid + i * 512;
+            const int r = q / KCH, c = q - r * KCH;
+            if (NKR * 512 == KB * KCH || q < KB * KCH) *reinterpret_cast<v4u*>(&sK[buf * SK + r * LDK + c * 8]) = rk[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NVR; ++i) {
+            const int q = tid + i * 512;
+            const int d = q >> 4, c = q & 15;
+            v2u v = rv[i];
+            if (last) {
+                const int nb = min(max(hi_ - (k0 + c * 4), 0), 4) * 16;      // valid bits of this 4-key piece
+                const unsigned long long m = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+                v.x &= (uint32_t)m;
+                v.y &= (uint32_t)(m >> 32);
+            }
+            // 4-key pieces land with the low two bits of their index swapped: the 8 k-slots of a PV step (keys 16 t + 4 hi + {0..3, 8..11})
+            // are then 16 contiguous bytes of the row — one ds_read_b128 per fragment
+            const int cp = (c & ~3) | ((c & 1) << 1) | ((c >> 1) & 1);
+            if (NVR * 512 == HD * (KB / 4) || q < HD * (KB / 4)) *reinterpret_cast<v2u*>(&sVT[buf * SV + d * LDV + cp * 4]) = v;
+        }
+    };
+
+    // one 64-key tile for this wave's 32 queries
+    auto compute = [&](int buf, int k0, int hi_) {
+        const uint16_t* bK = sK + buf * SK + qc * LDK + hi * 8;
+        const uint16_t* bV = sVT + buf * SV + qc * LDV + hi * 8;
+        // ---- S^T = K Q^T: every fragment read in front of the MFMAs (the two sub-tiles' accumulators alternate) ----
+        bf16x8 kf[2][NKC];
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) kf[sub][kc] = *reinterpret_cast<const bf16x8*>(bK + sub * 32 * LDK + kc * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[sub][kc], qf[kc], s[sub], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // V^T fragments of the first 32 keys: in flight while the softmax runs
+        bf16x8 va[2][NDB];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) va[t][db] = *reinterpret_cast<const bf16x8*>(bV + db * 32 * LDV + t * 16);
+        __builtin_amdgcn_sched_barrier(0);
+        // s[sub][r] = raw score(key = k0 + sub*32 + (r&3) + 8*(r>>2) + 4*hi, query = q_idx); the mask only where a tile needs one (wave-uniform)
+        const bool need_mask = (k0 + KB > hi_) || (p.causal && k0 + KB - 1 > wq0);
+        if (need_mask) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const bool ok = key < hi_ && (!p.causal || key <= q_idx);
+                    s[sub][r] = ok ? s[sub][r] : -INFINITY;
+                }
+        }
+        float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx * c1);
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;       // no valid key yet: everything stays zero
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+        m_run = m_new;
+        // probabilities of one 32-key sub-tile -> the two B operands of its PV steps (k-slot j of step t = score register 8 t + j) + the lane's row-sum share
+        auto probs = [&](const f32x16& sc, bf16x8 (&pf)[2]) -> float {
+            float ps = 0.f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint32_t w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t * 8 + 2 * j], c1, -m_use));       // masked: exp2(-inf) = 0
+                    const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[t * 8 + 2 * j + 1], c1, -m_use));
+                    ps += e0 + e1;
+                    w[j] = pack_bf16x2(e0, e1);
+                }
+                const uint4 pk = uint4{w[0], w[1], w[2], w[3]};
+                pf[t] = *reinterpret_cast<const bf16x8*>(&pk);
+            }
+            return ps;
+        };
+        bf16x8 pf0[2], pf1[2];
+        const float ps0 = probs(s[0], pf0);
+        if (__any(alpha != 1.0f)) {               // wave-uniform: later tiles rarely move the maximum
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+        }
+        // ---- O^T = alpha O^T + V^T P^T.  The second 32 keys' fragments are requested first; the first 32 keys' MFMAs then run with the
+        // second sub-tile's exponentials in their shadow (one MFMA : ~7 VALU issues), the second 32 keys' MFMAs close the tile. ----
+        bf16x8 vb[2][NDB];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) vb[t][db] = *reinterpret_cast<const bf16x8*>(bV + db * 32 * LDV + 32 + t * 16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[t][db], pf0[t], o[db], 0, 0, 0);
+        const float ps1 = probs(s[1], pf1);
+#pragma unroll
+        for (int i = 0; i < 2 * NDB; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2, (56 + 2 * NDB - 1) / (2 * NDB), 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        l_run = l_run * alpha + (ps0 + ps1);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[t][db], pf1[t], o[db], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // ---- tile walk: the optional second range first (the shared prefix), then the item's own range ----
+    int2 r2 = int2{0, 0};
+    if (p.items2) r2 = p.items2[blockIdx.x];
+    const bool has2 = r2.y > r2.x;
+    int k0 = has2 ? r2.x : it.kv_start, khi = has2 ? r2.y : own_hi;
+    bool in2 = has2;
+    // (k1, khi1, in21) = the tile after (k0, khi, in2); (k2, ...) the one after that
+    auto advance = [&](int& k, int& hi_, bool& in) {
+        k += KB;
+        if (k >= hi_ && in) { k = it.kv_start; hi_ = own_hi; in = false; }
+    };
+    int k1 = k0, khi1 = khi; bool in21 = in2;
+    if (k0 < khi) {
+        gload(k0, khi);
+        advance(k1, khi1, in21);
+        swrite(0, k0, khi);
+        if (k1 < khi1) gload(k1, khi1);
+    }
+    int buf = 0;
+    while (k0 < khi) {
+        __syncthreads();                        // tile (k0) is visible in sbuf[buf]; everyone is done with sbuf[buf ^ 1]
+        int k2 = k1, khi2 = khi1; bool in22 = in21;
+        if (k1 < khi1) {
+            swrite(buf ^ 1, k1, khi1);
+            advance(k2, khi2, in22);
+            if (k2 < khi2) gload(k2, khi2);
+        }
+        // causal: a tile whose first key lies beyond this wave's last query is skipped by the wave (own range only)
+        if (wave_on && !(p.causal && !in2 && k0 > wq0 + 31)) compute(buf, k0, khi);
+        k0 = k1; khi = khi1; in2 = in21;
+        k1 = k2; khi1 = khi2; in21 = in22;
+        buf ^= 1;
+    }
+
+    // ---- output: normalise, stage the wave's 32 x HD block in its own slice of the (now free) LDS image, store whole rows ----
+    constexpr int LDO = HD + 8;
+    static_assert(8 * 32 * LDO <= 2 * (SK + SV), "attn_fwd32: output staging does not fit the LDS image");
+    __syncthreads();
+    l_run += __shfl_xor(l_run, 32, 64);
+    const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+    uint16_t* sO = smem32 + wave * 32 * LDO;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int d = db * 32 + g4 * 8 + hi * 4;
+            if (HDV == HD || d < HD) {
+                uint2 w;
+                w.x = pack_bf16x2(o[db][g4 * 4 + 0] * inv, o[db][g4 * 4 + 1] * inv);
+                w.y = pack_bf16x2(o[db][g4 * 4 + 2] * inv, o[db][g4 * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(sO + qc * LDO + d) = w;
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // wave-private slice: program order, the fence pins hipcc
+#pragma unroll
+    for (int i = 0; i < (32 * KCH + 63) / 64; ++i) {
+        const int q = lane + i * 64;
+        const int r = q / KCH, c = q - r * KCH;
+        if (q < 32 * KCH && wq0 + r < it.q_end) {
+            const uint4 v = *reinterpret_cast<const uint4*>(sO + r * LDO + c * 8);
+            *reinterpret_cast<uint4*>(p.O + (long long)(wq0 + r) * p.o_tok + (long long)h * p.o_head + c * 8) = v;
+        }
+    }
+}
+
 // out[head, d] = sum_s exp(m_s - M) O_s[d] / sum_s exp(m_s - M) l_s over the valid KV chunks (fixed order)
 template <int HD>
 __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __restrict__ part, const int* __restrict__ dyn_kv_len,
@@ -818,6 +1121,25 @@ static int launch_attn_decode_ws(AttnDecParams& p, int max_kv_len, int batch, hi
 
 extern int g_gemv_profile_shapes;   // gemv.hip: per-shape profile rows (fo1_gemm_profile_shapes)
 
+template <int HD, int HPW>
+static int launch_attn32(const AttnParams& p, hipStream_t st, double flops) {
+    constexpr int LDK = HD + 8, LDV = 64 + 8, HDV = (HD + 31) / 32 * 32;
+    constexpr int smem = 2 * (64 * LDK + HDV * LDV) * 2;
+    static bool attr_done = false;      // > 64 KB of dynamic LDS needs the attribute (first call of an instantiation; never inside a capture: passes run eagerly first)
+    if (!attr_done) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd32_kernel<HD, HPW>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr_done = true;
+    }
+    char pname[48];
+    const char* name = "attn_fwd32";
+    if (profile_enabled() && g_gemv_profile_shapes) {
+        snprintf(pname, sizeof pname, "attn_fwd32 hd%d q%d items%d heads%d%s", HD, 256 / HPW, p.n_items, p.Hq, p.causal ? " causal" : "");
+        name = pname;
+    }
+    FO1_LAUNCH(name, flops, (attn_fwd32_kernel<HD, HPW>), dim3(p.n_items, p.Hq / HPW), dim3(512), smem, st, p);
+    return FO1_OK;
+}
+
 template <int HD>
 static int launch_attn(const AttnParams& p, int q_block, hipStream_t st, double flops) {
     char pname[48];
@@ -851,7 +1173,8 @@ static int attention_entry(const void* Q, long long q_tok_stride, long long q_he
     FO1_CHECK_ARG(Q && K && VT && O && items, "attention: NULL operand");
     FO1_CHECK_ARG(n_items > 0 && n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, "attention: bad head counts");
     FO1_CHECK_ARG(head_dim == 32 || head_dim == 80 || head_dim == 128, "attention: head_dim %d not built (32, 80, 128)", head_dim);
-    FO1_CHECK_ARG(q_block == 16 || q_block == 32 || q_block == 64, "attention: q_block %d must be 16, 32 or 64", q_block);
+    FO1_CHECK_ARG(q_block == 16 || q_block == 32 || q_block == 64 || q_block == 128 || q_block == 256,
+                  "attention: q_block %d must be 16, 32, 64 (16x16 MFMA form) or 128, 256 (32x32 form)", q_block);
     FO1_CHECK_ARG(q_tok_stride % 8 == 0 && q_head_stride % 8 == 0 && k_tok_stride % 8 == 0 && k_head_stride % 8 == 0,
                   "attention: Q/K strides must be multiples of 8 elements");
     FO1_CHECK_ARG(vt_row_stride % 4 == 0 && o_tok_stride % 4 == 0 && o_head_stride % 4 == 0,
@@ -871,6 +1194,18 @@ static int attention_entry(const void* Q, long long q_tok_stride, long long q_he
     p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
     p.bias = bias; p.wlen = wlen; p.sw_ws = sw_ws; p.sw_shift = sw_shift; p.sw_nwy = sw_nwy; p.sw_nwx = sw_nwx;
     hipStream_t st = (hipStream_t)stream;
+    if (q_block >= 128) {
+        // 32x32-MFMA form (attn_fwd32_kernel): 256 queries of one head, or 128 queries x the 2 query heads of one KV head, per workgroup
+        const int hpw = 256 / q_block;
+        FO1_CHECK_ARG(head_dim == 80 || head_dim == 128, "attention: q_block %d is built for head_dim 80 and 128 (got %d)", q_block, head_dim);
+        FO1_CHECK_ARG(!bias && !q_row_base, "attention: q_block %d takes no bias operand and no q_row_base", q_block);
+        FO1_CHECK_ARG(n_q_heads % hpw == 0 && (n_q_heads / n_kv_heads) % hpw == 0,
+                      "attention: q_block 128 needs an even number of query heads per KV head (%d / %d)", n_q_heads, n_kv_heads);
+        FO1_CHECK_ARG(o_tok_stride % 8 == 0 && o_head_stride % 8 == 0 && ((uintptr_t)O & 15) == 0, "attention: q_block %d stores 16-byte pieces: O misaligned", q_block);
+        FO1_CHECK_ARG(k_tok_stride < (1 << 22) && vt_row_stride < (1 << 22), "attention: q_block %d addresses a tile with 32-bit offsets: K / V^T row stride too large", q_block);
+        if (head_dim == 80) return hpw == 2 ? launch_attn32<80, 2>(p, st, flops_hint) : launch_attn32<80, 1>(p, st, flops_hint);
+        return hpw == 2 ? launch_attn32<128, 2>(p, st, flops_hint) : launch_attn32<128, 1>(p, st, flops_hint);
+    }
     if (head_dim == 32) return launch_attn<32>(p, q_block, st, flops_hint);
     if (head_dim == 80) return launch_attn<80>(p, q_block, st, flops_hint);
     return launch_attn<128>(p, q_block, st, flops_hint);

@@ -287,7 +287,7 @@ class QwenLLM:
         it = self._item_cache.get(key)
         if it is None:
             # never evict: a captured prefill graph may hold this tensor's pointer (entries are a few hundred bytes each)
-            blk = ops.pick_q_block([(pos0, kv_end)], self.cfg.num_heads)
+            blk = ops.pick_q_block([(pos0, kv_end)], self.cfg.num_heads, self.cfg.head_dim, self.cfg.num_kv_heads)
             it = torch.tensor([[q0, min(q0 + blk, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, blk)], dtype=torch.int32).to(self.dev)
             it.q_block = blk
             self._item_cache[key] = it
@@ -412,7 +412,7 @@ class QwenLLM:
                 else:
                     segs.append((o, o + Lp, (0, 0)))
                     fl += Lp * (Lp + 1) / 2.0
-            blk = ops.pick_q_block([(a, b) for a, b, _ in segs], self.cfg.num_heads)
+            blk = ops.pick_q_block([(a, b) for a, b, _ in segs], self.cfg.num_heads, self.cfg.head_dim, self.cfg.num_kv_heads)
             rows = [[q0, min(q0 + blk, b), a, b] for a, b, _ in segs for q0 in range(a, b, blk)]
             rng = [list(r2) for a, b, r2 in segs for _ in range(a, b, blk)]
             it = torch.tensor(rows, dtype=torch.int32).to(self.dev)

@@ -6,6 +6,7 @@ PyTorch fallback; a missing library or a CPU tensor raises."""
 from __future__ import annotations
 
 import math
+import os
 import threading
 from typing import Optional, Sequence
 
@@ -645,10 +646,21 @@ def decode_advance(state: torch.Tensor) -> None:
     _L.check(_L.load().fo1_decode_advance(state.data_ptr(), _stream()), "fo1_decode_advance")
 
 
-def pick_q_block(segments: Sequence[Sequence[int]], n_heads: int, target_wgs: int = 512) -> int:
-    """Query block (64/32/16 = 4/2/1 waves per workgroup).  Measured on MI355X (profiles/r01 notes): smaller
-    blocks re-stage every K/V tile once per block and LOSE (LLM prefill L=515: 64 -> 1.9 ms, auto 16/32 -> 4.7 ms
-    per image), so 64 stays the default; the knob is kept for very short sequences."""
+def pick_q_block(segments: Sequence[Sequence[int]], n_heads: int, head_dim: int = 0, n_kv_heads: Optional[int] = None) -> int:
+    """Query block of an attention work list.
+    64 (/ 32 / 16) = the 16x16-MFMA kernel, 4 / 2 / 1 waves x 16 queries per workgroup — smaller blocks re-stage every K/V tile once
+    per block and LOSE (LLM prefill L=515: 64 -> 1.9 ms, auto 16/32 -> 4.7 ms per image), so 64 is the floor.
+    128 / 256 = the 32x32-MFMA kernel (attn_fwd32_kernel, head dim 80 / 128, round 5): 8 waves x 32 queries per workgroup —
+    128 queries x the TWO query heads of one KV head when the model is grouped-query (LLM prefill: both heads share the staged
+    K / V^T tile), 256 queries of one head otherwise (ViT full attention).  Short segments (ViT windows of 64 tokens, DaViT's 144-token
+    windows at head dim 32, one-token extends) stay on the 64-query kernel.  FO1_ATTN32=0 turns the new form off (A/B)."""
+    if head_dim in (80, 128) and os.environ.get("FO1_ATTN32", "1") != "0" and len(segments):
+        longest = max(int(e) - int(s) for s, e, *_ in segments)
+        group = n_heads // (n_kv_heads or n_heads)
+        if head_dim == 128 and group % 2 == 0 and longest > 64:
+            return 128
+        if longest >= 192:
+            return 256
     return 64
 
 

@@ -86,7 +86,7 @@ class GridPlan:
         self.sin = fr.sin().contiguous().to(device)
         wins = [(a, b) for a, b in zip(cu[:-1], cu[1:])]
         self.items_win = ops.make_items(wins, device, block=ops.pick_q_block(wins, cfg.num_heads))
-        self.items_full = ops.make_items([(0, S)], device, block=ops.pick_q_block([(0, S)], cfg.num_heads))
+        self.items_full = ops.make_items([(0, S)], device, block=ops.pick_q_block([(0, S)], cfg.num_heads, cfg.hidden_size // cfg.num_heads))
         self.cu_window = cu
         self.Sp = _round_up(S, 64)
 
@@ -126,7 +126,7 @@ class BatchPlan:
         self.cu_window = None
         self.win_segments, self.full_segments = wins, fulls
         self.items_win = ops.make_items(wins, device, block=ops.pick_q_block(wins, cfg.num_heads))
-        self.items_full = ops.make_items(fulls, device, block=ops.pick_q_block(fulls, cfg.num_heads))
+        self.items_full = ops.make_items(fulls, device, block=ops.pick_q_block(fulls, cfg.num_heads, cfg.hidden_size // cfg.num_heads))
         self.gh = self.gw = None
 
 
