@@ -871,7 +871,10 @@ def main():
     # ---- roofline of the dominant kernel: separate profiled pass (hipEvents per launch) ----
     roof = None
     if rank == 0:
-        L.load().fo1_gemm_profile_shapes(1 if args.profile_shapes else 0)
+        if args.profile_shapes:      # per-shape profile rows: an instrument of include/fo1_ab.h (FO1_AB=1 runs only)
+            if not L.ab_build():
+                raise SystemExit("--profile-shapes needs the test / bench build: run with FO1_AB=1")
+            L.load().fo1_gemm_profile_shapes(1)
         nprof = min(args.steps, 50)
         TAGS = {"qwen_vit+merger": "vit", "mm_projector": "proj", "davit_large": "davit", "simple_fpn": "fpn",
                 "hfre_region_pool": "hfre", "mm_projector_aux": "proj_aux", "splice": "splice", "llm_prefill+lm_head+argmax": "llm"}
@@ -934,7 +937,8 @@ def main():
             # traffic): `peak` above is 256 CUs x 4 SIMDs x 1024 flop/cycle at 2.4 GHz, under load the chip clocks to its power budget
             try:
                 from vlm_fo1_amd import ops as _ops
-                rnd, zero = _ops.mfma_clock_probe(1), _ops.mfma_clock_probe(0)
+                with L.use_ab():         # the probe is an instrument of include/fo1_ab.h: the test / bench build is mapped HERE, after the timed region
+                    rnd, zero = _ops.mfma_clock_probe(1), _ops.mfma_clock_probe(0)
                 roof["sustained_mfma"] = dict(random_operands=rnd, zero_operands=zero, frac_of_random_operand_rate=round(ach / rnd["tflops"], 4),
                                               note="register-resident v_mfma_f32_32x32x16_bf16 loop, 8 waves per CU, no loads: the ceiling of any bf16 MFMA kernel at "
                                                    "this box's power budget (DVFS); frac_of_random_operand_rate = roofline.achieved / that rate")

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FO1_ABI_VERSION 5   /* 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 6   /* 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -173,13 +173,6 @@ int fo1_rmsnorm_quant_e4m3(const void* x, int ldx, const void* weight, int M, in
                            void* stream);
 int fo1_gemm_fp8(const void* Aq, int lda, const float* scale_a, const void* Wq, int ldw, const float* scale_w, const void* bias,
                  const void* residual, int ldr, void* C, int ldc, int M, int N, int K, int act, void* stream);
-/* Instrumentation: the clock the matrix pipes sustain on this box (csrc/probe.hip).  A register-resident loop of v_mfma_f32_32x32x16_bf16 on
- * every CU (8 waves per workgroup, `iters` x 32 MFMAs per wave, no memory traffic); out = uint64 [workgroups][2] {shader cycles (s_memtime),
- * 100 MHz ticks (s_memrealtime)}.  operands 0 = zeros, 1 = pseudo-random bf16.  cycles / ticks = the DVFS clock; the dense bf16 peak of the
- * roofline (2.5 PFLOP/s) assumes 2.4 GHz. */
-int fo1_mfma_clock_probe(int operands, int iters, int workgroups, void* out, void* sink, void* stream);
-/* Instrumentation (with fo1_profile_enable): per-shape kernel names in the profile rows instead of one row per kernel. */
-int fo1_gemm_profile_shapes(int on);
 
 /* ------------------------------------------------------------------------
  * Row norms / small elementwise ops (HBM-bound).  All tensors bf16 row-major with explicit row
@@ -253,19 +246,11 @@ int fo1_pool_qkv_post_partials_bf16(const float* part, int splits, const void* b
  *   fo1_splitk_residual_rmsnorm_bf16   x_out = bf16(bf16(sum_z part[z] (+ bias)) + residual);  xn_out = Qwen2RMSNorm(x_out) * norm_weight
  *                                      (the residual add of :736 / :742 and the NEXT layernorm, :728 / :739, in the launch that reduces)
  *   fo1_pool_qkv_post_partials_bf16    above.
- *   fo1_splitk_swiglu_bf16             the gate/up projection against the 16-row interleaved weight: out[m, f] = bf16(bf16(silu(bf16(g))) * bf16(u)),
- *                                      g / u = sum_z of plane columns 32 (f / 16) + f % 16 and + 16 — fo1_gemm_bf16's act 3 epilogue (:636) on planes
  * K % 64 == 0, N % 4 == 0 (% 8 for the consumers), operands 16-byte aligned, part holds splits * M * N floats. */
 int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int splits, float* part, int* splits_out,
                            void* stream);
 int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N, const void* bias, const void* residual, int ldr, void* x_out,
                                      int ldx, const void* norm_weight, float eps, void* xn_out, int ldn, void* stream);
-int fo1_splitk_swiglu_bf16(const float* part, int splits, int M, int N, void* out, int ldo, void* stream);
-/* fo1_gemm_bf16 for a weight that few rows (<= 128) stream once per call — the decode pool's gate/up and lm_head: W_tiled is a copy of W [N, K] laid
- * out [N / 128][K / 64][128][64] (made once at load), so a K tile of a column tile is one contiguous 16 KB block.  Same kernel, arithmetic and
- * epilogues as fo1_gemm_bf16 (bit-identical on the same tile shape).  N % 128 == 0, K % 64 == 0. */
-int fo1_gemm_bf16_wtiled(const void* A, int lda, const void* W_tiled, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
-                         int K, int act, void* stream);
 /* Weight-streaming GEMV (M <= 4) with the fo1_gemm_bf16 epilogues and an optional fused Qwen2RMSNorm on the input rows
  * (norm_weight [K] or NULL): folds input_layernorm / post_attention_layernorm into the projections of the decode step. */
 int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, int ldr,

@@ -67,6 +67,24 @@ int fo1_attention_decode_set_impl(int impl);
  * slot's whole context, for which the split kernel writes the output rows itself and no combine launch is made. */
 int fo1_attention_decode_set_pool_chunk(int keys);
 
+/* ---- measured no-gain kernel forms and instruments (round 5: moved out of the product ABI) ---- */
+/* SwiGLU over the split-K planes of fo1_gemm_bf16_partials for the gate/up projection against the 16-row interleaved weight:
+ * out[m, f] = bf16(bf16(silu(bf16(g))) * bf16(u)), g / u = sum_z of plane columns 32 (f / 16) + f % 16 and + 16 — fo1_gemm_bf16's act 3 epilogue on
+ * planes.  Measured slower than the one-GEMM form in the decode pool (36-49 vs 34 us per layer); llm.DecodePool.SPLITS["gateup"] selects it. */
+int fo1_splitk_swiglu_bf16(const float* part, int splits, int M, int N, void* out, int ldo, void* stream);
+/* fo1_gemm_bf16 for a weight that few rows (<= 128) stream once per call — the decode pool's gate/up and lm_head: W_tiled is a copy of W [N, K] laid
+ * out [N / 128][K / 64][128][64] (made once at load), so a K tile of a column tile is one contiguous 16 KB block.  Same kernel, arithmetic and
+ * epilogues as fo1_gemm_bf16 (bit-identical on the same tile shape).  N % 128 == 0, K % 64 == 0. */
+int fo1_gemm_bf16_wtiled(const void* A, int lda, const void* W_tiled, const void* bias, const void* residual, int ldr, void* C, int ldc, int M, int N,
+                         int K, int act, void* stream);
+/* Instrumentation: the clock the matrix pipes sustain on this box (csrc/probe.hip).  A register-resident loop of v_mfma_f32_32x32x16_bf16 on
+ * every CU (8 waves per workgroup, `iters` x 32 MFMAs per wave, no memory traffic); out = uint64 [workgroups][2] {shader cycles (s_memtime),
+ * 100 MHz ticks (s_memrealtime)}.  operands 0 = zeros, 1 = pseudo-random bf16.  cycles / ticks = the DVFS clock; the dense bf16 peak of the
+ * roofline (2.5 PFLOP/s) assumes 2.4 GHz. */
+int fo1_mfma_clock_probe(int operands, int iters, int workgroups, void* out, void* sink, void* stream);
+/* Instrumentation (with fo1_profile_enable): per-shape kernel names in the profile rows instead of one row per kernel. */
+int fo1_gemm_profile_shapes(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,5 +1,6 @@
 """Per-kernel time of one eager decode step (hipEvent profile), bench workload."""
 import sys, os
+os.environ.setdefault("FO1_AB", "1")   # fo1_gemm_profile_shapes is an instrument of the test / bench build (include/fo1_ab.h)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import torch

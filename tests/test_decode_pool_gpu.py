@@ -60,15 +60,19 @@ def test_pool_projections_and_qkv_post_match_reference(P, product_library):
     gt, u = rb(x.float() @ gate.float().t()), rb(x.float() @ up.float().t())
     _close(got, rb(rb(torch.nn.functional.silu(gt)) * u), "swiglu", ulps=2.0, rare=5e-3)
     # the pre-tiled weight copy the pool streams gate/up and lm_head from (fo1_gemm_bf16_wtiled): the same kernel on another address pattern -> same bits
+    # (round 5: a measured no-gain form, include/fo1_ab.h — the test / bench build only)
+    from vlm_fo1_amd import lib as L
     wgu = ops.interleave_gate_up(gate, up).cuda()
-    got_t = ops.gemm_wtiled(x, ops.tile_weight(wgu), act=ops.ACT_SWIGLU16)
+    wl, xb, rl = rnd(128 * 9, K, sc=0.03), rnd(P, K), rnd(P, 128 * 9)
+    bl = rnd(128 * 9, sc=0.1)
+    with L.use_ab():
+        got_t = ops.gemm_wtiled(x, ops.tile_weight(wgu), act=ops.ACT_SWIGLU16)
+        ref_t = ops.gemm_wtiled(xb, ops.tile_weight(wl), bl, rl)
+        torch.cuda.synchronize()
     if P > 64:
         assert torch.equal(got_t, got), "tiled gate/up (same 128 x 128 ring tile as the row-major call)"
     else:
         _close(got_t, got, "tiled gate/up (64 x 128 tile against the row-major call's 64 x 64)", ulps=1.0)
-    wl, xb, rl = rnd(128 * 9, K, sc=0.03), rnd(P, K), rnd(P, 128 * 9)
-    bl = rnd(128 * 9, sc=0.1)
-    ref_t = ops.gemm_wtiled(xb, ops.tile_weight(wl), bl, rl)
     _close(ref_t, rb(rb(xb.float() @ wl.float().t() + bl.float()) + rl.float()), "tiled plain + bias + residual", mag=(xb.float() @ wl.float().t()).abs().cpu() + 4)
     # ---- q/k/v: bias -> bf16 (GEMM), then mRoPE at the slot's table row -> q rows in place, K rows, V^T columns at the slot's cache row ----
     H, KV, HD, K, rows = 16, 2, 128, 2048, 1024
@@ -145,7 +149,10 @@ def test_pool_splitk_planes_and_fused_consumers(P, product_library):
     F_, K = 11008, 2048
     gate, up, x = rnd(F_, K, sc=0.03), rnd(F_, K, sc=0.03), rnd(P, K)
     part, s, tot = planes_of(x, ops.interleave_gate_up(gate, up).cuda(), 3)
-    got = ops.splitk_swiglu(part, s, P, 2 * F_)
+    from vlm_fo1_amd import lib as L
+    with L.use_ab():          # (round 5: a measured no-gain form, include/fo1_ab.h — the test / bench build only)
+        got = ops.splitk_swiglu(part, s, P, 2 * F_)
+        torch.cuda.synchronize()
     t4 = tot.view(P, F_ // 16, 2, 16)
     gt, u = rb(t4[:, :, 0].reshape(P, F_)), rb(t4[:, :, 1].reshape(P, F_))
     ref = rb(rb(gt * torch.sigmoid(gt)) * u)

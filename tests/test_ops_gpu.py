@@ -283,7 +283,7 @@ def _attn_case(segs, H, KV, D, seed):
     dict(name="llm_one_sequence", H=16, KV=2, D=128, segs=[(0, 391)], causal=True, blk=128),
     dict(name="vit_full_two_images", H=16, KV=16, D=80, segs=[(0, 1564), (1564, 1864)], causal=False, blk=256),
     dict(name="hd128_mha_causal", H=4, KV=4, D=128, segs=[(0, 700)], causal=True, blk=256),
-    dict(name="hd80_gqa_pairs", H=4, KV=2, D=80, segs=[(0, 300), (300, 556)], causal=False, blk=128),
+    dict(name="hd80_gqa_pairs", H=8, KV=4, D=80, segs=[(0, 300), (300, 556)], causal=False, blk=128),
 ])
 def test_attention_32x32_form(cfg):
     """attn_fwd32_kernel (q_block 128 / 256: 32x32 MFMA, 8 waves x 32 queries, two query heads of one KV head per workgroup when
@@ -730,8 +730,8 @@ def test_gemm_small_tile_vector_epilogue_equals_general_epilogue_bitwise(tile, a
         L.load().fo1_gemm_set_variant(0, 0)
 
 
-def test_mfma_clock_probe_reports_a_plausible_clock(product_library):
-    """fo1_mfma_clock_probe (csrc/probe.hip, instrumentation): cycles / wall ticks of a register-resident MFMA loop = a clock inside the part's
+def test_mfma_clock_probe_reports_a_plausible_clock(ab_library):
+    """fo1_mfma_clock_probe (csrc/probe.hip; an instrument of include/fo1_ab.h since round 5 — bench.py loads the test / bench build for it after the timed region): cycles / wall ticks of a register-resident MFMA loop = a clock inside the part's
     DVFS range, 32 cycles per 32x32x16 bf16 MFMA per SIMD (two waves share one), and zero operands never clock lower than random ones."""
     from vlm_fo1_amd import ops
     rnd = ops.mfma_clock_probe(1, iters=400)

@@ -79,7 +79,21 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
         int kv0 = 0, kv_len;
         if (p.seq_state) {
             const int* st = p.seq_state + blockIdx.z * 8;
-            if (st[3]) return;          // finished (or empty pool slot): nobody reads this sequence's output
+            if (st[3]) {
+                // finished (or empty pool slot): nobody reads this sequence's tokens, but its attention row still flows through the
+                // o-projection into the slot's frozen K / V^T row of every later layer — it must be FINITE (0 x NaN would poison a later
+                // occupant whose keys come within the 4-key V^T piece of that row).  One-chunk form: the row is written
+                // here, as zeros; split form: attn_decode_combine_kernel writes it.
+                if (p.O != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
+                    const int ql = threadIdx.x & 15, g = threadIdx.x >> 4;
+                    if (ql < p.q_range_end) {
+                        uint16_t* op = p.O + (long long)blockIdx.z * p.o_tok + ((long long)blockIdx.y * p.q_range_end + ql) * p.o_head;
+#pragma unroll
+                        for (int db = 0; db < HD / 16; ++db) *reinterpret_cast<uint2*>(op + db * 16 + g * 4) = uint2{0u, 0u};
+                    }
+                }
+                return;
+            }
             kv0 = st[2];
             kv_len = st[0] + 1;
             Qb += (long long)blockIdx.z * p.q_seq_stride;
@@ -399,12 +413,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd32_kernel(const AttnParams p) 
     uint16_t* sK = smem32;                    // [2][SK]
     uint16_t* sVT = smem32 + 2 * SK;          // [2][SV]
 
-    const AttnItem it = p.items[blockIdx.x];
+    // grid = (head groups, items): the dispatch order walks the ITEMS slowest, so a work list sorted by descending cost (ops.make_items: the
+    // causal blocks with the most key tiles first) is longest-processing-time-first over the whole launch, and the workgroups that share an
+    // item's K / V^T tiles start together
+    const int item = blockIdx.y, hg = blockIdx.x;
+    const AttnItem it = p.items[item];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int qc = lane & 31, hi = lane >> 5;
     const int hsel = wave / WPH, wq = wave - hsel * WPH;
-    const int h = blockIdx.y * HPW + hsel;
-    const int kvh = (blockIdx.y * HPW) / p.group;          // both heads of the workgroup share it (group % HPW == 0)
+    const int h = hg * HPW + hsel;
+    const int kvh = (hg * HPW) / p.group;                  // both heads of the workgroup share it (group % HPW == 0)
     const int wq0 = it.q_start + wq * 32;                  // this wave's first query
     const int q_idx = wq0 + qc;
     const bool q_ok = q_idx < it.q_end;
@@ -606,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd32_kernel(const AttnParams p) 
 
     // ---- tile walk: the optional second range first (the shared prefix), then the item's own range ----
     int2 r2 = int2{0, 0};
-    if (p.items2) r2 = p.items2[blockIdx.x];
+    if (p.items2) r2 = p.items2[item];
     const bool has2 = r2.y > r2.x;
     int k0 = has2 ? r2.x : it.kv_start, khi = has2 ? r2.y : own_hi;
     bool in2 = has2;
@@ -679,10 +697,13 @@ __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __
     int n_keys;
     if (seq_state) {   // sequence blockIdx.y of a decode batch
         const int* st = seq_state + blockIdx.y * 8;
-        if (st[3]) return;              // finished: the split kernel skipped it, the row keeps its previous (finite) contents
+        out += (long long)blockIdx.y * out_seq_stride;
+        if (st[3]) {                    // finished: the split kernel skipped it; the row is zeroed (it must be finite, see attn_fwd_kernel)
+            out[(long long)head * HD + d] = 0;
+            return;
+        }
         n_keys = st[0] + 1 - st[2];
         part += (long long)blockIdx.y * part_seq_stride;
-        out += (long long)blockIdx.y * out_seq_stride;
     } else {
         n_keys = *dyn_kv_len;
     }
@@ -1136,7 +1157,7 @@ static int launch_attn32(const AttnParams& p, hipStream_t st, double flops) {
         snprintf(pname, sizeof pname, "attn_fwd32 hd%d q%d items%d heads%d%s", HD, 256 / HPW, p.n_items, p.Hq, p.causal ? " causal" : "");
         name = pname;
     }
-    FO1_LAUNCH(name, flops, (attn_fwd32_kernel<HD, HPW>), dim3(p.n_items, p.Hq / HPW), dim3(512), smem, st, p);
+    FO1_LAUNCH(name, flops, (attn_fwd32_kernel<HD, HPW>), dim3(p.Hq / HPW, p.n_items), dim3(512), smem, st, p);
     return FO1_OK;
 }
 
@@ -1199,6 +1220,7 @@ static int attention_entry(const void* Q, long long q_tok_stride, long long q_he
         const int hpw = 256 / q_block;
         FO1_CHECK_ARG(head_dim == 80 || head_dim == 128, "attention: q_block %d is built for head_dim 80 and 128 (got %d)", q_block, head_dim);
         FO1_CHECK_ARG(!bias && !q_row_base, "attention: q_block %d takes no bias operand and no q_row_base", q_block);
+        FO1_CHECK_ARG(n_items <= 65535, "attention: q_block %d walks the items on grid.y: at most 65535 (got %d)", q_block, n_items);
         FO1_CHECK_ARG(n_q_heads % hpw == 0 && (n_q_heads / n_kv_heads) % hpw == 0,
                       "attention: q_block 128 needs an even number of query heads per KV head (%d / %d)", n_q_heads, n_kv_heads);
         FO1_CHECK_ARG(o_tok_stride % 8 == 0 && o_head_stride % 8 == 0 && ((uintptr_t)O & 15) == 0, "attention: q_block %d stores 16-byte pieces: O misaligned", q_block);

@@ -1129,7 +1129,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p8_kernel(const GemmParams p) 
 FO1_AB_VAR g_gemm_variant = 0;  // 0 auto, 1 reg, 2 glds two-stage, 3/4/6 glds ring of that depth
 FO1_AB_VAR g_gemm_tile = 0;     // 0 auto, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 128x256 (8 waves), 5 = 256x256 ping-pong
 FO1_AB_VAR g_gemm_splitk = 0;   // 0 auto, n >= 1 forced
-static int g_gemm_profile_shapes = 0;   // profile-row naming (fo1_gemm_profile_shapes: instrumentation, part of the product API)
+static int g_gemm_profile_shapes = 0;   // profile-row naming (fo1_gemm_profile_shapes, include/fo1_ab.h)
 FO1_AB_VAR g_gemm_debug = 0;
 #ifdef FO1_ENABLE_AB
 static void* g_gemm_stamp_buf = nullptr;    // fo1_gemm_set_stamp_buffer (debug bit 5)
@@ -2121,11 +2121,13 @@ int fo1_gemm_set_gemv(int on) {
 }
 #endif   // FO1_ENABLE_AB
 
+#ifdef FO1_ENABLE_AB      // instrument (include/fo1_ab.h)
 int fo1_gemm_profile_shapes(int on) {
     fo1::g_gemm_profile_shapes = on != 0;
     fo1::g_gemv_profile_shapes = on != 0;
     return FO1_OK;
 }
+#endif
 
 int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr,
                      void* C, int ldc, int M, int N, int K, int act, int out_f32, void* workspace, size_t workspace_bytes,
@@ -2204,6 +2206,7 @@ int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M
     return launch_gemm<64, 64>(p, 1, true, (hipStream_t)stream, false);
 }
 
+#ifdef FO1_ENABLE_AB      // include/fo1_ab.h: a measured no-gain form, test / bench build only
 // fo1_gemm_bf16 for a weight streamed ONCE per call by few rows (the decode pool's gate/up and lm_head at 65..128 rows, 33..64 rows on the
 // 64 x 128 tile): W_tiled is the copy of W [N, K] laid out [N / 128][K / 64][128][64] (ops.tile_weight), so that every K tile of a column tile is
 // one contiguous 16 KB block instead of 128 pieces of 128 B at a 2 K-byte stride.  Same kernel (LDS-DMA ring, BN = 128), same arithmetic and
@@ -2229,6 +2232,7 @@ int fo1_gemm_bf16_wtiled(const void* A, int lda, const void* W_tiled, const void
     if (M > 64) return launch_gemm<128, 128>(p, 1, true, (hipStream_t)stream);
     return launch_gemm<64, 128>(p, 1, true, (hipStream_t)stream);
 }
+#endif   // FO1_ENABLE_AB
 
 // fp8 linear (BASELINE configs[4], "fp8 MFMA"): C[M,N] = epilogue((Aq Wq^T) * scale_a[m] * scale_w[n]) with OCP e4m3 operands, fp32
 // accumulation on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales), bf16 output; epilogues as fo1_gemm_bf16 (act 0..3).

@@ -561,6 +561,7 @@ int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N
     return FO1_OK;
 }
 
+#ifdef FO1_ENABLE_AB      // include/fo1_ab.h: a measured no-gain form, test / bench build only
 int fo1_splitk_swiglu_bf16(const float* part, int splits, int M, int N, void* out, int ldo, void* stream) {
     using namespace fo1;
     FO1_CHECK_ARG(part && out && M >= 1 && splits >= 1, "splitk_swiglu: NULL operand");
@@ -572,5 +573,6 @@ int fo1_splitk_swiglu_bf16(const float* part, int splits, int M, int N, void* ou
                (long long)M * N, M, N, (uint16_t*)out, ldo);
     return FO1_OK;
 }
+#endif   // FO1_ENABLE_AB
 
 }  // extern "C"

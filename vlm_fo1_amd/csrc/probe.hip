@@ -1,10 +1,12 @@
-// Instrumentation (part of the product API, like fo1_profile_*): what clock the matrix pipes sustain on THIS box.  The dense bf16 peak a
+// Instrumentation (include/fo1_ab.h: test / bench build only — bench.py's `roofline.sustained_mfma` leg loads it after the timed region): what clock the matrix pipes sustain on THIS box.  The dense bf16 peak a
 // roofline is priced against (2.5 PFLOP/s) is 256 CUs x 4 SIMDs x 1024 flop/cycle at 2.4 GHz; under load the chip clocks to its power
 // budget (DVFS), so the attainable rate is peak x (sustained clock / 2.4 GHz) even for a loop that issues an MFMA every cycle it can.
 // fo1_mfma_clock_probe runs such a loop — register-resident operands, no memory traffic, 8 waves on every CU — and returns per workgroup
 // the shader cycles (s_memtime) and the 100 MHz wall ticks (s_memrealtime) it took.  bench.py reports it next to the roofline
 // (`roofline.sustained_mfma`): the ceiling of ANY bf16 MFMA kernel on this box and data, measured in the same process.
 #include "common.h"
+
+#ifdef FO1_ENABLE_AB
 
 namespace fo1 {
 
@@ -61,3 +63,5 @@ int fo1_mfma_clock_probe(int operands, int iters, int workgroups, void* out, voi
 }
 
 }  // extern "C"
+
+#endif   // FO1_ENABLE_AB

@@ -187,8 +187,6 @@ SIGNATURES = {
     "fo1_rmsnorm_quant_e4m3": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p, c_longlong, c_void_p, c_void_p]),
     "fo1_gemm_fp8": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                              c_int, c_int, c_int, c_int, c_void_p]),
-    "fo1_gemm_profile_shapes": (c_int, [c_int]),
-    "fo1_mfma_clock_probe": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "fo1_rmsnorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "fo1_layernorm_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
     "fo1_swiglu_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
@@ -207,8 +205,6 @@ SIGNATURES = {
     "fo1_pool_qkv_post_partials_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                                 c_void_p, c_longlong, c_void_p, c_longlong, c_void_p]),
     "fo1_gemm_bf16_partials": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "fo1_gemm_bf16_wtiled": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "fo1_splitk_swiglu_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "fo1_splitk_residual_rmsnorm_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_float, c_void_p,
                                                  c_int, c_void_p]),
     "fo1_gemv_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -274,6 +270,11 @@ SIGNATURES_AB = {
     "fo1_gemv_batch_set_impl": (c_int, [c_int]),
     "fo1_attention_decode_set_impl": (c_int, [c_int]),
     "fo1_attention_decode_set_pool_chunk": (c_int, [c_int]),
+    # measured no-gain kernel forms and instruments (round 5: out of the product ABI)
+    "fo1_gemm_profile_shapes": (c_int, [c_int]),
+    "fo1_mfma_clock_probe": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fo1_gemm_bf16_wtiled": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_splitk_swiglu_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }
 
 _lib = None          # the ACTIVE library: every ops.* call goes through load()

@@ -141,6 +141,7 @@ class QwenLLM:
         self._dgraph = None
         self._dstate_keep = None
         self.rope_epoch = 0         # bumped whenever the rope tables are re-allocated (grow_rope): step graphs key on it
+        self._rope_retired = []     # replaced tables, never freed (shared by the replicas: see grow_rope)
         self._ws_owner = ops.new_owner(self)   # scratch-buffer key (ops.workspace_scope); FO1Engine overrides it with its own token
 
     def reserve(self, n_positions: int) -> bool:
@@ -160,8 +161,9 @@ class QwenLLM:
         k[:, :, :self.capacity] = self.kcache
         v[:, :, :self.capacity] = self.vtcache
         self.kcache, self.vtcache, self.capacity = k, v, cap
-        if self.rope_cos.shape[0] < cap:
-            self.grow_rope(cap)
+        # (the text-position rope table is NOT grown here: the prefill does not read it — packed passes bring their own tables — and a
+        # worker thread's reserve() must not re-allocate a table that the decode pool's graphs, replaying on another stream, still read
+        # (ADVICE r4).  The decode paths grow it when THEY need the rows: _check_room, BatchDecoder._ensure, DecodePool.)
         self._dgraph = None
         self._item_cache = {}
         self.cache_epoch += 1
@@ -176,6 +178,10 @@ class QwenLLM:
             return
         p = torch.arange(rows).view(1, -1).expand(3, -1)
         cos_t, sin_t = mrope_tables(p, c.head_dim, c.rope_theta, c.mrope_section)
+        # the old tables stay allocated for the life of the process (0.5 KB per row, geometric growth: at most twice the final size):
+        # a step graph captured on another engine replica / the decode pool may still be replaying with their pointers on its own
+        # stream, and nothing here can wait for it (the epoch / data_ptr graph keys only protect the NEXT capture)
+        self._rope_retired.append((self.rope_cos, self.rope_sin))
         self.rope_cos, self.rope_sin = cos_t.to(self.dev), sin_t.to(self.dev)
         self._dgraph = None
         self.rope_epoch += 1
@@ -288,7 +294,9 @@ class QwenLLM:
         if it is None:
             # never evict: a captured prefill graph may hold this tensor's pointer (entries are a few hundred bytes each)
             blk = ops.pick_q_block([(pos0, kv_end)], self.cfg.num_heads, self.cfg.head_dim, self.cfg.num_kv_heads)
-            it = torch.tensor([[q0, min(q0 + blk, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, blk)], dtype=torch.int32).to(self.dev)
+            rows = [[q0, min(q0 + blk, kv_end), 0, kv_end] for q0 in range(pos0, kv_end, blk)]
+            rows = [rows[i] for i in ops.order_items(rows, blk, True)]      # 32x32 form: the blocks with the most key tiles first
+            it = torch.tensor(rows, dtype=torch.int32).to(self.dev)
             it.q_block = blk
             self._item_cache[key] = it
         return it
@@ -415,6 +423,8 @@ class QwenLLM:
             blk = ops.pick_q_block([(a, b) for a, b, _ in segs], self.cfg.num_heads, self.cfg.head_dim, self.cfg.num_kv_heads)
             rows = [[q0, min(q0 + blk, b), a, b] for a, b, _ in segs for q0 in range(a, b, blk)]
             rng = [list(r2) for a, b, r2 in segs for _ in range(a, b, blk)]
+            order = ops.order_items(rows, blk, True, prefix=rng)           # 32x32 form: longest-processing-time-first over the launch
+            rows, rng = [rows[i] for i in order], [rng[i] for i in order]
             it = torch.tensor(rows, dtype=torch.int32).to(self.dev)
             it.q_block = blk
             r2 = torch.tensor(rng, dtype=torch.int32).to(self.dev) if any(x[1] > x[0] for x in rng) else None
@@ -449,6 +459,8 @@ class QwenLLM:
         if self.kv_len + 1 > self.capacity:
             self.reserve(self.kv_len + 1)
             self.sync_decode_state()
+        if self.rope_cos.shape[0] < self.capacity:      # the step reads table row (position + rope delta) < capacity
+            self.grow_rope(self.capacity)
 
     def sync_decode_state(self):
         """Publish (kv_len, rope row, first decode work item) to the device-side decode state."""
@@ -859,6 +871,32 @@ class DecodePool:
             self._ensure(max(L for _, L, *_ in seqs) + max_new + 1)      # raises unless the pool is empty
         self.free.sort()
         slots = [self.free.pop(0) for _ in range(B)]
+        try:
+            self._join_slots(slots, kcache, vtcache, seqs, deltas, first_tokens, max_new)
+        except BaseException:
+            # nothing of this submission is live: its slots go back (their device state may be half written — the next occupant's
+            # join rewrites state, plan and K / V^T rows; until then the slot is marked finished so that no step reads it)
+            done = torch.zeros(len(slots), 8, dtype=torch.int32)
+            done[:, 0] = done[:, 2] = torch.tensor(slots, dtype=torch.int32) * self.slot_rows
+            done[:, 3] = 1
+            self._keep.append(done)
+            try:
+                for k, sl in enumerate(slots):
+                    self.state[sl:sl + 1].copy_(done[k:k + 1], non_blocking=True)
+            except BaseException:
+                pass
+            self.free += slots
+            raise
+        for k, s in enumerate(slots):
+            # a tag identifies ONE occupancy of a slot: harvest() compares it by identity against an older snapshot, so the default must
+            # be unique per join (with None, `None is None` handed a re-joined slot's new occupant the old occupant's ids — ADVICE r4)
+            self.live[s] = tags[k] if tags is not None else object()
+            self.bound[s] = seqs[k][1] + 1
+            self.budget[s] = max_new
+        return slots
+
+    def _join_slots(self, slots, kcache, vtcache, seqs, deltas, first_tokens, max_new):
+        B = len(slots)
         R = self.slot_rows
         state = torch.tensor([[s * R + L, L + d, s * R, 0, 0, max_new, 0, 0] for s, (_, L, *_), d in zip(slots, seqs, deltas)], dtype=torch.int32)
         first = first_tokens.to(torch.int32).contiguous()
@@ -882,11 +920,6 @@ class DecodePool:
                 ops.decode_argmax_accept(None, first[i:j + 1], self.state[a:a + n], self.plan[a:a + n], self.ids[a:a + n],
                                          self.stop[:self.n_stop], self.done)
                 i = j + 1
-        for k, s in enumerate(slots):
-            self.live[s] = tags[k] if tags is not None else None
-            self.bound[s] = seqs[k][1] + 1
-            self.budget[s] = max_new
-        return slots
 
     # ---- step ------------------------------------------------------------------------------------------------------------------
     def kv_bucket(self) -> int:

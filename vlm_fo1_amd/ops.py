@@ -512,9 +512,16 @@ def pool_qkv_post(qkv: torch.Tensor, n_q: int, n_kv: int, head_dim: int, cos_tab
     _L.check(rc, "fo1_pool_qkv_post_bf16")
 
 
+def _need_ab(what: str) -> None:
+    """Entry points of include/fo1_ab.h (measured no-gain kernel forms, instruments) exist in the test / bench build only."""
+    if not _L.ab_build():
+        raise _L.Fo1Error(f"{what} is part of include/fo1_ab.h: call it inside `with vlm_fo1_amd.lib.use_ab():` (or start the process with FO1_AB=1)")
+
+
 def mfma_clock_probe(operands: int = 1, iters: int = 2000, workgroups: int = 256) -> dict:
     """Sustained clock / rate of a register-resident dense bf16 MFMA loop on this box (fo1_mfma_clock_probe, csrc/probe.hip):
     {clock_ghz (median over workgroups), tflops, us}.  operands 1 = pseudo-random bf16, 0 = zeros."""
+    _need_ab("fo1_mfma_clock_probe")
     out = torch.zeros(workgroups, 2, dtype=torch.int64, device="cuda")
     sink = torch.zeros(1, dtype=torch.float32, device="cuda")
     for _ in range(2):          # the second launch is the measurement (the first ramps the clocks)
@@ -562,6 +569,7 @@ def tile_weight(w: torch.Tensor) -> torch.Tensor:
 
 def gemm_wtiled(a: torch.Tensor, w_tiled: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
     """a @ W.T (+ epilogue) with W given as ops.tile_weight(W): the weight-streaming form for <= 128 rows (fo1_gemm_bf16_wtiled)."""
+    _need_ab("fo1_gemm_bf16_wtiled")
     _chk(a, "a"); _chk(w_tiled, "w_tiled")
     pa, lda, M, K = _rows(a, "a")
     assert w_tiled.dim() == 4 and w_tiled.shape[2:] == (128, 64) and w_tiled.is_contiguous() and w_tiled.shape[1] * 64 == K
@@ -579,6 +587,7 @@ def gemm_wtiled(a: torch.Tensor, w_tiled: torch.Tensor, bias: Optional[torch.Ten
 
 def splitk_swiglu(part: torch.Tensor, splits: int, M: int, N: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out [M, N / 2] = SwiGLU over the split-K planes of a product against a 16-row interleaved gate/up weight (fo1_splitk_swiglu_bf16)."""
+    _need_ab("fo1_splitk_swiglu_bf16")
     assert part.dtype == torch.float32 and part.numel() >= splits * M * N and part.is_cuda
     if out is None:
         out = torch.empty(M, N // 2, dtype=torch.bfloat16, device=part.device)
@@ -664,6 +673,21 @@ def pick_q_block(segments: Sequence[Sequence[int]], n_heads: int, head_dim: int 
     return 64
 
 
+def order_items(rows, block: int, causal: bool, prefix=None):
+    """Work-list order of the 32x32 attention form (q_block >= 128): descending cost = key tiles the item walks (its own range — up to its
+    last query when causal — plus its second range).  The kernel's grid walks the items slowest, so this is longest-processing-time-first
+    over the launch: the few-tile blocks fill the tail instead of a 48-tile block starting last (hires LLM: items of 2..48 tiles).
+    A pure permutation of the work: every query's arithmetic is unchanged.  -> index permutation."""
+    if block < 128:
+        return list(range(len(rows)))
+    def cost(i):
+        q0, q1, k0, k1 = rows[i]
+        own = (min(k1, q1) if causal else k1) - k0
+        pre = 0 if prefix is None else max(0, prefix[i][1] - prefix[i][0])
+        return -((own + 63) // 64 + (pre + 63) // 64)
+    return sorted(range(len(rows)), key=cost)
+
+
 def make_items(segments: Sequence[Sequence[int]], device, causal: bool = False, block: int = 64) -> torch.Tensor:
     """Host-side work list for fo1_attention_bf16: split every segment [start, end) into query blocks
     of <= block.  Index bookkeeping belongs on the host.  The block size rides along as
@@ -672,6 +696,7 @@ def make_items(segments: Sequence[Sequence[int]], device, causal: bool = False, 
     for s, e in segments:
         for q0 in range(s, e, block):
             rows.append((q0, min(q0 + block, e), s, e))
+    rows = [rows[i] for i in order_items(rows, block, causal)]
     t = torch.tensor(rows, dtype=torch.int32).reshape(-1, 4).to(device)
     t.q_block = block
     return t

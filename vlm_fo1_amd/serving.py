@@ -78,6 +78,7 @@ class PoolService:
         self.pool: Optional[DecodePool] = None
         self._q: "queue.Queue" = queue.Queue()
         self._stop = False
+        self._closed = False
         self._fatal: Optional[BaseException] = None
         self.stats = dict(steps=0, joined=0, finished=0, occupancy_sum=0)
         self._ready = threading.Event()
@@ -93,6 +94,8 @@ class PoolService:
         The prefill must have been enqueued on the CURRENT stream: an event recorded here orders the pool's relocation after it."""
         if self._fatal is not None:
             raise self._fatal
+        if self._closed or self._stop or not self._thread.is_alive():
+            raise RuntimeError("decode pool: the service is closed (its scheduler thread has stopped); create a new PoolService")
         n = len(seqs)
         if n > self.pool.P:
             raise ValueError(f"decode pool: {n} sequences in one submission, {self.pool.P} slots")
@@ -100,12 +103,27 @@ class PoolService:
         ev = torch.cuda.Event()
         ev.record()
         self._q.put((h, src_llm.kcache, src_llm.vtcache, list(seqs), list(deltas), first_tokens, int(max_new_tokens), tuple(stop_ids), ev))
+        if self._closed or not self._thread.is_alive():      # raced close() / the scheduler's fatal path: nobody will ever serve the queue
+            self._fail_queued(self._fatal or RuntimeError("decode pool: closed while the submission was being queued"))
         return h
 
     def close(self):
+        """Stops the scheduler after the sequences in flight have finished; whatever is still queued afterwards fails (a
+        handle of a closed service must not block forever)."""
         self._stop = True
         self._q.put(None)
         self._thread.join(timeout=60)
+        self._closed = True
+        self._fail_queued(self._fatal or RuntimeError("decode pool: the service was closed before the submission was admitted"))
+
+    def _fail_queued(self, e: BaseException):
+        while True:
+            try:
+                it = self._q.get_nowait()
+            except queue.Empty:
+                return
+            if it is not None:
+                it[0]._fail(e)
 
     # ---- scheduler thread -----------------------------------------------------------------------------------------------------
     def _admit(self, pool: DecodePool, waiting: list) -> None:
