@@ -330,6 +330,112 @@ def driver_level_run(pipe, n_items=768, n_warm=128, K=64, batch=32, inflight=2, 
         shutil.rmtree(root, ignore_errors=True)
 
 
+def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, K=64, batch=32, inflight=2, pool_slots=128, prefetch_threads=4, sample=64):
+    """`scale` block of a multi-rank run: the path north_star describes, timed ACROSS the ranks — evaluation/eval_coco.py's
+    own loop (reference evaluation/eval_coco.py:36-88) through sharded_eval.run_sharded: LPT shard by (pixels, N) -> per-rank prefetch
+    threads -> packed prefill passes -> decode pool -> ONE all_gather of fixed-width records at the eval reducer -> rank 0 parses / dumps.
+    Weak scaling: items_per_gpu x world synthetic 640 x 480 JPEG files x 100 boxes on the node's shared filesystem.  Every rank calls this
+    (collectives inside); rank 0 returns the block: whole-job images/s, per-rank shard seconds, the gather's milliseconds / bytes / backend,
+    the host-thread budget, and whether the merged token ids of the first `sample` items equal what ONE rank computes for them alone
+    (full passes of `batch` same-shape images: a row's arithmetic does not depend on which images share its pass)."""
+    import contextlib
+    import shutil
+    import tempfile
+    import torch.distributed as dist
+    from vlm_fo1.model.fo1_model import FO1ForCausalLM, FO1HFConfig
+    from vlm_fo1.model.image_processing import CLIPStyleAuxProcessor, Qwen2VLPatchProcessor
+    from vlm_fo1_amd import sharded_eval as SE
+    from vlm_fo1_amd.fixtures.synthetic import ToyTokenizer, full_config_dict, write_coco_like_dataset
+    sys.path.insert(0, os.path.join(ROOT, "evaluation"))
+    import eval_coco as E
+    dev = pipe.eng.dev
+    n_items, n_warm = items_per_gpu * world, n_warm_per_gpu * world
+    box = [None]
+    if rank == 0:
+        root = tempfile.mkdtemp(prefix="fo1_scale_")
+        warm = write_coco_like_dataset(os.path.join(root, "warm"), n_warm, seed=1)
+        data = write_coco_like_dataset(os.path.join(root, "data"), n_items, seed=2)
+        sub = os.path.join(root, "data", "sample.jsonl")          # the first `sample` items as their own dataset (same files)
+        with open(data[0]) as f, open(sub, "w") as g:
+            g.writelines(f.readlines()[:sample])
+        box[0] = dict(root=root, warm=warm, data=data, sub=sub)
+    if world > 1:
+        dist.broadcast_object_list(box, src=0)
+    root, warm, data, sub = box[0]["root"], box[0]["warm"], box[0]["data"], box[0]["sub"]
+    try:
+        model = FO1ForCausalLM.from_engine(FO1HFConfig(full_config_dict()), pipe.eng)
+        primary, aux = Qwen2VLPatchProcessor(min_pixels=56 * 56, max_pixels=2048 * 2048), CLIPStyleAuxProcessor(size=768, resize_mode="dynamic")
+        primary.device = aux.device = model.device
+        tok = ToyTokenizer()
+        E.load_pretrained_model = lambda model_id, device="cuda": (tok, model, (primary, aux))
+        env = dict(FO1_BATCH=str(batch), FO1_INFLIGHT=str(inflight), FO1_DECODE_POOL=str(pool_slots), FO1_MAX_NEW_TOKENS=str(K),
+                   FO1_PREFETCH_THREADS=str(prefetch_threads))
+        saved = {k: os.environ.get(k) for k in list(env) + ["RANK", "WORLD_SIZE"]}
+        os.environ.update(env)
+        name = "synthetic/VLM-FO1_Qwen2.5-VL-3B-synthetic"
+        out_dir = os.path.join(root, f"out_rank{rank}")
+        try:
+            with open(os.path.join(root, f"driver_stdout_rank{rank}.log"), "w") as log, contextlib.redirect_stdout(log):
+                E.eval_coco(name, warm[0], warm[1], warm[2], out_dir + "_warm", device=str(dev))
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                t0 = time.perf_counter()
+                E.eval_coco(name, data[0], data[1], data[2], out_dir, device=str(dev))
+                torch.cuda.synchronize()
+                if world > 1:
+                    dist.barrier()
+                el = time.perf_counter() - t0
+                mine = {k: v for k, v in SE.LAST.items() if k != "merged"}
+                merged = SE.LAST.get("merged")
+                stats = [None] * world
+                if world > 1:
+                    dist.all_gather_object(stats, mine)
+                else:
+                    stats = [mine]
+                same = None
+                if rank == 0:
+                    # ONE rank alone on the first `sample` items: run_sharded / gather_records take the world from the environment
+                    os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
+                    E.eval_coco(name, sub, data[1], data[2], out_dir + "_sample", device=str(dev))
+                    torch.cuda.synchronize()
+                    alone = dict(SE.LAST.get("merged") or [])
+                    together = dict(merged or [])
+                    same = len(alone) == sample and all(together.get(i) == alone[i] for i in alone)
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+            pipe.eng.disable_decode_pool()
+            for r, _ in model.__dict__.get("_worker_replicas", []):
+                r.engine._pool_svc = None
+        if world > 1:
+            dist.barrier()
+        if rank != 0:
+            return None
+        threads = inflight + prefetch_threads + 1 + (1 if pool_slots else 0)
+        return dict(images_per_sec=round(n_items / el, 2), items=n_items, items_per_gpu=items_per_gpu, seconds=round(el, 3), world_size=world,
+                    dist_world_size=(dist.get_world_size() if world > 1 else 1), backend=(dist.get_backend() if world > 1 else "none"),
+                    one_device_gloo_test_mode=bool(one_dev), new_tokens_per_image=K, images_per_pass=batch,
+                    per_rank_shard_seconds=[round(st["shard_seconds"], 3) for st in stats],
+                    per_rank_items=[st["shard_items"] for st in stats],
+                    gather_ms=[round(st["gather_ms"], 2) for st in stats],
+                    gather_record_bytes_per_rank=stats[0].get("gather_record_bytes_per_rank"),
+                    sample_items=sample, sample_ids_equal_to_one_rank_alone=same,
+                    predictions_file_written=os.path.exists(os.path.join(out_dir, name.split("/")[-1], "eval_predictions.json")),
+                    host_threads_per_gpu=threads, host_threads_for_this_run=threads * world,
+                    loop="evaluation/eval_coco.py eval_coco() on every rank: jsonl -> cost model -> sharded_eval.assign (LPT) -> [prefetch threads] -> packed "
+                         "prefill passes -> decode pool -> sharded_eval.gather_records (one all_gather) -> rank 0: tokenizer.decode -> regex -> COCO records -> json dump",
+                    data="synthetic 640x480 JPEG files x 100 UPN boxes; ToyTokenizer; random weights at the true shapes; weak scaling (items_per_gpu per rank)")
+    finally:
+        if world > 1:
+            dist.barrier()
+        if rank == 0:
+            shutil.rmtree(root, ignore_errors=True)
+
+
 def hires_run(pipe, steps=6, images=4):
     """BASELINE configs[4]'s geometry in the default run: 1344 x 1344 image (S = 9216 patches) x 300 proposals, run as 3
     prompts of <= 100 over ONE image (the reference caps region features at 100 per prompt, mm_utils.py:600: its callers would run the
@@ -592,6 +698,8 @@ def main():
                     "join (continuous batching, vlm_fo1_amd/serving.py); 0 = every pass decodes its own group of <= 32 (round 3's form)")
     ap.add_argument("--driver-items", type=int, default=768, help="driver_level: images of the synthetic COCO-shaped dataset run through "
                     "evaluation/eval_coco.py's own loop (0 = skip)")
+    ap.add_argument("--scale-items", type=int, default=256, help="multi-rank runs: images PER GPU of the `scale` block (evaluation/eval_coco.py's loop through "
+                    "sharded_eval.run_sharded across the ranks, one all_gather at the reducer); a multiple of 32; 0 = skip")
     ap.add_argument("--no-hires", action="store_true", help="skip the `hires` block (BASELINE configs[4]'s geometry: 1344x1344 x 300 proposals, bf16 and fp8 linears)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true", help="skip the side measurements (one image / one pass at a time, decode loops, preprocessing): "
@@ -706,6 +814,12 @@ def main():
         t = torch.tensor([el], device="cpu" if one_dev else dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         el = float(t.item())
+
+    # ---- multi-rank runs: the sharded evaluation loop across the ranks (LPT shard -> prefetch -> pool -> one all_gather); every rank takes
+    # part, right after the timed region (the other ranks then leave; rank 0 goes on with its side measurements).  Never `value`. ----
+    scale = None
+    if world > 1 and use_graph and args.scale_items > 0 and args.boxes <= 100 and img_hw == (480, 640):
+        scale = scale_run(pipe, world, rank, one_dev, items_per_gpu=args.scale_items, pool_slots=args.pool_slots or 128)
 
     # ---- side measurements on rank 0 (never `value`): one packed pass at a time, and strictly one image at a time ----
     single = one_pass = None
@@ -988,7 +1102,7 @@ def main():
                                       (f"; {R} passes in flight on {R} HIP streams (engine replicas share weights)" if R > 1 else "; one pass at a time"),
                                images_per_step=B, passes_in_flight=R, global_batch=B * world,
                                parallelism=f"dp{world} (images sharded, no data-path collective)" + (" [test: all ranks on one device]" if one_dev else "")),
-                   end_to_end=e2e, driver_level=drv, hires=hires, one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
+                   end_to_end=e2e, driver_level=drv, scale=scale, hires=hires, one_image_at_a_time=single, one_pass_at_a_time=one_pass, dataset=dset, decode=dec, preprocess=prep, roofline=roof)
         if args.fp8:
             out["fp8_note"] = ("W8A8 e4m3 linears are an MI355X-side lever BASELINE configs[4] names; the reference has no fp8 path, so this mode's parity is "
                                "UNPINNED (deviation table against the bf16 engine: DESIGN.md section 10, tests/test_fp8_engine_gpu.py)")

@@ -115,7 +115,7 @@ def test_bench_two_ranks_control_flow(tmp_path):
     env = dict(os.environ, FO1_BENCH_ONE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--main-only"]
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--main-only", "--scale-items", "64"]
     p = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
@@ -123,6 +123,13 @@ def test_bench_two_ranks_control_flow(tmp_path):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["scaling"] == "weak" and out["value"] > 0
     assert "cpu_baseline" not in out and out["roofline"]["bound"] in ("mfma", "hbm")
+    # the `scale` block (round 5): evaluation/eval_coco.py's loop through sharded_eval.run_sharded ACROSS the two ranks — LPT shard, per-rank
+    # prefetch + decode pool, ONE all_gather at the reducer — and the merged ids of a sample equal to what one rank computes alone
+    sc = out["scale"]
+    assert sc["world_size"] == 2 and sc["dist_world_size"] == 2 and sc["backend"] == "gloo" and sc["one_device_gloo_test_mode"] is True
+    assert sc["items"] == 128 and sc["per_rank_items"] == [64, 64] and len(sc["per_rank_shard_seconds"]) == 2 and len(sc["gather_ms"]) == 2
+    assert sc["images_per_sec"] > 0 and sc["predictions_file_written"] and sc["host_threads_for_this_run"] == 2 * sc["host_threads_per_gpu"]
+    assert sc["sample_ids_equal_to_one_rank_alone"] is True, sc
 
 
 def test_replicas_in_flight_match_sequential():

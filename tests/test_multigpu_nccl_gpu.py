@@ -49,6 +49,12 @@ def test_bench_two_gpus_over_rccl():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["global_batch"] == 2 * out["config"]["images_per_step"]
+    # the nccl twin of tests/test_e2e_gpu.py::test_bench_two_ranks_control_flow's `scale` checks: the sharded evaluation loop across two
+    # real devices, the one all_gather over RCCL, merged ids of the sample == one rank alone
+    sc = out["scale"]
+    assert sc["world_size"] == 2 and sc["dist_world_size"] == 2 and sc["backend"] == "nccl" and sc["one_device_gloo_test_mode"] is False
+    assert sc["per_rank_items"] == [sc["items_per_gpu"]] * 2 and len(sc["gather_ms"]) == 2 and sc["images_per_sec"] > 0
+    assert sc["sample_ids_equal_to_one_rank_alone"] is True, sc
 
 
 @need2

@@ -55,6 +55,8 @@ struct GemmParams {
     // ring kernels with BN = 128 (fo1_gemm_bf16_wtiled): W is a copy pre-tiled as [N / 128][K / 64][128 rows][64] — a K tile of a column tile is ONE
     // contiguous 16 KB block (the decode pool's weight streams: profiles/r04_hbm_stream_patterns.jsonl)
     int w_tiled = 0;
+    // 256 x 256 kernels: tile rows per group of the XCD-grouped tile order (tile_coords_grouped_id); 8 = the measured default
+    int gm = 8;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3, ACT_RELU = 5 };   // (4 = the split-K partial epilogue of the 256x256 kernels)
@@ -646,7 +648,7 @@ __device__ __forceinline__ void tile_coords_grouped_id(const GemmParams& p, int 
     const int nwg = p.tiles_m * p.tiles_n;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     const int swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    constexpr int GM = 8;
+    const int GM = p.gm;
     const int per_group = GM * p.tiles_n;
     const int gid = swz / per_group, in = swz - gid * per_group;
     const int first = gid * GM;
@@ -1135,6 +1137,7 @@ FO1_AB_VAR g_gemm_debug = 0;
 static void* g_gemm_stamp_buf = nullptr;    // fo1_gemm_set_stamp_buffer (debug bit 5)
 #endif
 FO1_AB_VAR g_gemm_gemv = 1;      // route M <= 4 to the weight-streaming GEMV (gemv.hip)
+FO1_AB_VAR g_gemm_group_m = 0;   // A/B (fo1_gemm_set_group_m): tile rows per group of the 256 x 256 kernels' tile order; 0 = the product rule
 
 extern int g_gemv_profile_shapes;
 int gemv_dispatch(const void* A, int lda, const void* W, int ldw, const void* bias, const void* residual, int ldr, void* C, int ldc,
@@ -1750,6 +1753,7 @@ FO1_AB_VAR g_gemm_big_sched = 1;   // 256x256 kernel schedule: 0 = four phases p
 static int launch_gemm_p8(GemmParams& p, int batch, hipStream_t st) {
     p.tiles_m = cdiv(p.M, 256);
     p.tiles_n = cdiv(p.N, 256);
+    if (g_gemm_group_m > 0) p.gm = g_gemm_group_m;
     const dim3 grid(p.tiles_m * p.tiles_n, batch, p.splits);
     const double flops = 2.0 * p.M * (double)p.N * p.K * batch;
     char pname[48];
@@ -2112,6 +2116,12 @@ int fo1_gemm_set_debug(int bits) {
 
 int fo1_gemm_set_stamp_buffer(void* device_buffer) {
     fo1::g_gemm_stamp_buf = device_buffer;
+    return FO1_OK;
+}
+
+int fo1_gemm_set_group_m(int rows) {
+    if (rows < 0 || rows > 1024) return fo1::set_err(FO1_ERR_ARG, "gemm_set_group_m: %d", rows);
+    fo1::g_gemm_group_m = rows;
     return FO1_OK;
 }
 

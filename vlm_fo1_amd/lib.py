@@ -263,6 +263,7 @@ SIGNATURES_AB = {
     "fo1_gemm_set_variant": (c_int, [c_int, c_int]),
     "fo1_gemm_set_splitk": (c_int, [c_int]),
     "fo1_gemm_set_gemv": (c_int, [c_int]),
+    "fo1_gemm_set_group_m": (c_int, [c_int]),
     "fo1_gemm_set_big_schedule": (c_int, [c_int]),
     "fo1_gemm_set_debug": (c_int, [c_int]),
     "fo1_gemm_set_stamp_buffer": (c_int, [c_void_p]),

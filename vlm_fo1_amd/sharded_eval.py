@@ -17,6 +17,10 @@ import torch.distributed as dist
 
 ERR = -1  # status of an item whose generation raised (the reference silently drops it: eval_coco.py:60-65)
 
+# What the last run_sharded() of this process did (bench.py's `scale` block reads it): items and seconds of this rank's shard, the
+# gather's milliseconds, bytes and backend, the world size — and, on rank 0, the merged records themselves.
+LAST: dict = {}
+
 
 def world_info() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
@@ -79,17 +83,24 @@ def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu",
         if fatal is not None:
             raise fatal
         raise RemoteRankFailed(f"[rank {rank}] another rank stopped on a fatal error; no records were gathered")
-    rec = torch.full((nmax, 2 + kmax), -2, dtype=torch.int32, device=dev)   # -2 = padding row
+    # the record block is built on the HOST and crosses to the device in one copy (row-by-row device writes were three tiny H2D copies
+    # per record, ~2 000 per rank on COCO-5k: VERDICT r4 weak #14)
+    import numpy as np
+    host = np.full((nmax, 2 + kmax), -2, dtype=np.int32)                     # -2 = padding row
     for j, (idx, toks) in enumerate(local):
-        rec[j, 0] = idx
+        host[j, 0] = idx
         if toks is None:
-            rec[j, 1] = ERR
+            host[j, 1] = ERR
         else:
-            rec[j, 1] = len(toks)
+            host[j, 1] = len(toks)
             if toks:
-                rec[j, 2:2 + len(toks)] = torch.tensor(toks, dtype=torch.int32)
+                host[j, 2:2 + len(toks)] = np.asarray(toks, dtype=np.int32)
+    rec = torch.from_numpy(host).to(dev)
     out = [torch.empty_like(rec) for _ in range(world)]
     dist.all_gather(out, rec)
+    if dev.type == "cuda":
+        torch.cuda.current_stream().synchronize()
+    LAST.update(gather_record_bytes_per_rank=int(host.nbytes), gather_backend=dist.get_backend(), gather_world=dist.get_world_size())
     if rank != 0:
         return None
     merged = []
@@ -254,6 +265,8 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
     `prepare(i)`: optional host-side preparation of item i (image decode / resize / tokenisation / upload).  When given it runs on
     a Prefetcher ahead of the GPU work and `generate` receives the prepared object(s) as a second argument: `generate(i, prepared)`
     or `generate([i0, ...], [prepared0, ...])`."""
+    import time
+    t_start = time.perf_counter()
     rank, world, _ = world_info()
     mine = assign(costs, world)[rank]
     workers = list(generate) if isinstance(generate, (list, tuple)) else [generate]
@@ -374,4 +387,10 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
     if pf is not None:
         pf.close()
     local.sort(key=lambda r: r[0])
-    return gather_records(local, device, fatal=fatal)
+    import time
+    t_shard = time.perf_counter()
+    LAST.clear()
+    LAST.update(rank=rank, world=world, shard_items=len(mine), shard_seconds=t_shard - t_start)
+    merged = gather_records(local, device, fatal=fatal)
+    LAST.update(gather_ms=(time.perf_counter() - t_shard) * 1e3, merged=merged)
+    return merged
