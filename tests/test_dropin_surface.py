@@ -165,7 +165,7 @@ def test_primary_processor_matches_hf_pil_processor(w, h, max_pixels):
 
 
 @pytest.mark.skipif(not HAVE_REF, reason="/root/reference not present")
-@pytest.mark.parametrize("mode", ["dynamic", "squash"])
+@pytest.mark.parametrize("mode", ["dynamic", "squash", "dynamic_square"])
 def test_aux_processor_matches_reference_clip_processor(mode):
     spec = importlib.util.spec_from_file_location("ref_clip_ip", os.path.join(REF, "model/multimodal_encoder/davit/image_processing_clip.py"))
     m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
@@ -174,11 +174,14 @@ def test_aux_processor_matches_reference_clip_processor(mode):
                resize_mode=mode)
     ref_ip = m.CLIPImageProcessor(**cfg)
     from vlm_fo1.model.image_processing import CLIPStyleAuxProcessor
-    img = _noise_image(500, 399, 3)
-    ref = ref_ip.preprocess(img, return_tensors="pt")["pixel_values"][0]
-    got = CLIPStyleAuxProcessor(resize_mode=mode).preprocess(img, return_tensors="pt")["pixel_values"][0]
-    assert got.shape == ref.shape
-    torch.testing.assert_close(got, ref, rtol=0, atol=2e-6)
+    # (dynamic_square, image_processing_clip.py:190-204: the candidate square closest in AREA — 500 x 399 -> 448, 700 x 530 -> 640, and
+    # 448 x 577 = 258 496 sits between 512^2 and 448^2 ... every size goes through the reference's own selection loop)
+    for w, h, seed in ((500, 399, 3), (700, 530, 4), (448, 577, 5)) if mode == "dynamic_square" else ((500, 399, 3),):
+        img = _noise_image(w, h, seed)
+        ref = ref_ip.preprocess(img, return_tensors="pt")["pixel_values"][0]
+        got = CLIPStyleAuxProcessor(resize_mode=mode).preprocess(img, return_tensors="pt")["pixel_values"][0]
+        assert got.shape == ref.shape, (mode, w, h, got.shape, ref.shape)
+        torch.testing.assert_close(got, ref, rtol=0, atol=2e-6)
 
 
 def test_model_max_length_overflow_fails_like_the_reference_splice():

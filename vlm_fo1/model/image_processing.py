@@ -13,7 +13,7 @@ Equivalence with the installed HF PIL processor / the reference CLIP processor: 
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional
+from typing import Dict, Optional, Sequence
 
 import numpy as np
 import torch
@@ -113,15 +113,29 @@ class Qwen2VLPatchProcessor:
 
 
 class CLIPStyleAuxProcessor:
-    def __init__(self, size: int = 768, resize_mode: str = "squash", image_mean=IMAGENET_MEAN, image_std=IMAGENET_STD):
+    # image_processing_clip.py:98: the reference's default candidate sizes of the `dynamic_square` mode
+    CANDIDATE_SIZES = (384, 448, 512, 576, 640, 704, 768, 832, 896, 960, 1024, 1280, 1536, 1792, 2048)
+
+    def __init__(self, size: int = 768, resize_mode: str = "squash", image_mean=IMAGENET_MEAN, image_std=IMAGENET_STD,
+                 candidate_sizes: Optional[Sequence[int]] = None):
         self.size = size
         self.resize_mode = resize_mode
         self.do_resize = resize_mode != "dynamic"      # davit_aux_encoder.py:47-49
+        self.candidate_sizes = tuple(candidate_sizes) if candidate_sizes else self.CANDIDATE_SIZES
         self.image_mean, self.image_std = image_mean, image_std
         self.device = None       # see Qwen2VLPatchProcessor.device
         self._lut = None
-        if resize_mode not in ("squash", "dynamic"):
-            raise NotImplementedError(f"aux resize mode {resize_mode!r} is not built (squash / dynamic)")
+        if resize_mode not in ("squash", "dynamic", "dynamic_square"):
+            raise NotImplementedError(f"aux resize mode {resize_mode!r} is not built (squash / dynamic / dynamic_square)")
+
+    def target_hw(self, w: int, h: int):
+        """Resized (width, height) of a w x h image.  squash: size x size.  dynamic_square (image_processing_clip.py:190-204): the square
+        whose AREA is closest to the image's, among the candidate sizes (first one wins a tie: the reference compares with `<`)."""
+        if self.resize_mode == "dynamic_square":
+            area = w * h
+            best = min(self.candidate_sizes, key=lambda c: abs(c * c - area))      # min() keeps the first of equal keys
+            return best, best
+        return self.size, self.size
 
     def preprocess(self, images, return_tensors: Optional[str] = "pt") -> Dict[str, object]:
         if not isinstance(images, (list, tuple)):
@@ -130,7 +144,7 @@ class CLIPStyleAuxProcessor:
         for img in images:
             img = img.convert("RGB")
             if self.do_resize:
-                img = img.resize((self.size, self.size), Image.Resampling.BICUBIC)
+                img = img.resize(self.target_hw(*img.size), Image.Resampling.BICUBIC)
             if self.device is not None:
                 from vlm_fo1_amd import ops
                 if self._lut is None:
