@@ -489,7 +489,7 @@ def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, 
                     dist.all_gather_object(stats, mine)
                 else:
                     stats = [mine]
-                same = None
+                same = same_detail = None
                 if rank == 0:
                     # ONE rank alone on the first `sample` items: run_sharded / gather_records take the world from the environment
                     os.environ["RANK"], os.environ["WORLD_SIZE"] = "0", "1"
@@ -498,6 +498,19 @@ def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, 
                     alone = dict(SE.LAST.get("merged") or [])
                     together = dict(merged or [])
                     same = len(alone) == sample and all(together.get(i) == alone[i] for i in alone)
+                    if not same:      # say how they differ: items, and the position of the first differing token of each
+                        diff = [i for i in alone if together.get(i) != alone[i]]
+                        first = []
+                        for i in diff:
+                            a, b = alone[i] or [], together.get(i) or []
+                            k = next((j for j in range(min(len(a), len(b))) if a[j] != b[j]), min(len(a), len(b)))
+                            first.append(k)
+                        E.eval_coco(name, sub, data[1], data[2], out_dir + "_sample2", device=str(dev))      # and whether ONE rank repeats itself
+                        again = dict(SE.LAST.get("merged") or [])
+                        same_detail = dict(items_differing=len(diff), first_differing_token_positions=sorted(first)[:16],
+                                           one_rank_repeats_itself=all(again.get(i) == alone[i] for i in alone))
+                    else:
+                        same_detail = None
         finally:
             for k, v in saved.items():
                 if v is None:
@@ -519,7 +532,7 @@ def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, 
                     per_rank_items=[st["shard_items"] for st in stats],
                     gather_ms=[round(st["gather_ms"], 2) for st in stats],
                     gather_record_bytes_per_rank=stats[0].get("gather_record_bytes_per_rank"),
-                    sample_items=sample, sample_ids_equal_to_one_rank_alone=same,
+                    sample_items=sample, sample_ids_equal_to_one_rank_alone=same, sample_difference=same_detail,
                     predictions_file_written=os.path.exists(os.path.join(out_dir, name.split("/")[-1], "eval_predictions.json")),
                     host_threads_per_gpu=threads, host_threads_for_this_run=threads * world,
                     loop="evaluation/eval_coco.py eval_coco() on every rank: jsonl -> cost model -> sharded_eval.assign (LPT) -> [prefetch threads] -> packed "
@@ -861,6 +874,8 @@ def main():
 
     from vlm_fo1_amd import lib as L
     L.load()
+    if os.environ.get("FO1_GEMM_GROUP_M") and L.ab_build():      # A/B of the 256 x 256 GEMM's tile order (include/fo1_ab.h, FO1_AB=1 runs only)
+        L.load().fo1_gemm_set_group_m(int(os.environ["FO1_GEMM_GROUP_M"]))
     img_hw = tuple(int(v) for v in args.image.lower().split("x"))
     S_img = (round(img_hw[0] / 28) * 2) * (round(img_hw[1] / 28) * 2)
     auto_batch = args.batch <= 0

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FO1_ABI_VERSION 6   /* 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 6   /* 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -251,6 +251,22 @@ int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M
                            void* stream);
 int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N, const void* bias, const void* residual, int ldr, void* x_out,
                                      int ldx, const void* norm_weight, float eps, void* xn_out, int ldn, void* stream);
+/* q/k/v projection + bias + rotary embedding + K-cache append + V^T write in ONE launch (round 5): exactly what fo1_gemm_bf16 followed by
+ * fo1_qkv_post_llm_bf16 / fo1_qkv_post_vit_bf16 computes, bit for bit, without the second pass over the [M, N] activation — the rotation, the cache
+ * append and the transposed V store run in the 256 x 256 GEMM kernel's epilogue while the tile is still in LDS.
+ *   mode 0, LLM (modeling_qwen2_5_vl.py:643-685,731-734): W rows [q heads | k heads | v heads] of head_dim 128; cos / sin bf16 [M][128] (the packed rows'
+ *     mRoPE tables); rotated q -> C[:, :n_q_heads * 128] (the k / v columns of C are not written); rotated k -> kcache[kv head][pos0 + m][128];
+ *     v -> vt[(kv head * 128 + d) * vt_ld + pos0 + m].
+ *   mode 1, ViT (:162-169,219-230): W rows HEAD-MAJOR — per head [q 80 | k 80 | v 80 | 16 zero rows], N = 256 * n_q_heads (a head's rotate-half
+ *     pairs then never straddle two output tiles); cos / sin fp32 [M][40]; rotated q, k -> C in that layout (attention: head stride 256, k at
+ *     column 80 of a head); v -> vt[(head * 80 + d) * vt_ld + pos0 + m].  kcache unused.
+ * K % 64 == 0, N % 256 == 0, pos0 % 8 == 0, vt_ld % 8 == 0, 16-byte aligned operands; any M (built for M >= 1024: one 256 x 256 tile per workgroup). */
+/* 1 when fo1_gemm_bf16 runs an [M, K] x [N, K]^T bf16 product (K % 64 == 0, aligned operands) on the 256 x 256 kernel: where a caller may swap
+ * fo1_gemm_bf16 + fo1_qkv_post_* for fo1_qkv_proj_rope_bf16 without changing a bit. */
+int fo1_gemm_takes_big_tile(int M, int N, int K);
+int fo1_qkv_proj_rope_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K, int mode,
+                           int n_q_heads, int n_kv_heads, const void* cos_table, const void* sin_table, void* kcache, long long kcache_head_stride,
+                           int pos0, void* vt, long long vt_ld, void* stream);
 /* Weight-streaming GEMV (M <= 4) with the fo1_gemm_bf16 epilogues and an optional fused Qwen2RMSNorm on the input rows
  * (norm_weight [K] or NULL): folds input_layernorm / post_attention_layernorm into the projections of the decode step. */
 int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bias, const void* residual, int ldr,

@@ -736,6 +736,75 @@ def test_gemm_small_tile_vector_epilogue_equals_general_epilogue_bitwise(tile, a
         L.load().fo1_gemm_set_variant(0, 0)
 
 
+@pytest.mark.parametrize("M,pos0", [(700, 16), (1290, 0)])
+def test_qkv_proj_rope_llm_equals_gemm_plus_qkv_post(ab_library, M, pos0):
+    """fo1_qkv_proj_rope_bf16 mode 0 (q/k/v projection with mRoPE + K-cache append + V^T write in the 256 x 256 GEMM's epilogue) against the two
+    launches it replaces on the SAME GEMM kernel (tile pinned to 256 x 256): rotated q rows, the K cache and the V^T cache bit for bit — M not a
+    multiple of 8 (row tails of the transposed 16-byte stores), a non-zero cache position."""
+    from vlm_fo1_amd import lib as L, ops
+    H, KV, D, K, cap = 16, 2, 128, 256, 2048
+    g = torch.Generator().manual_seed(31 + M)
+    x = (torch.randn(M, K, generator=g)).to(BF).cuda()
+    w = (torch.randn((H + 2 * KV) * D, K, generator=g) * 0.08).to(BF).cuda()
+    b = (torch.randn((H + 2 * KV) * D, generator=g) * 0.3).to(BF).cuda()
+    ang = torch.rand(M, D, generator=g) * 6.28
+    cos, sin = ang.cos().to(BF).cuda(), ang.sin().to(BF).cuda()
+    L.load().fo1_gemm_set_variant(0, 5)
+    try:
+        assert L.load().fo1_gemm_takes_big_tile(M, (H + 2 * KV) * D, K) == 1
+        qkv = ops.gemm(x, w, b)
+        kc_ref = torch.zeros(KV, cap, D, dtype=BF, device="cuda"); vt_ref = torch.zeros(KV * D, cap, dtype=BF, device="cuda")
+        ops.qkv_post_llm(qkv, H, KV, D, cos, sin, kc_ref, vt_ref, pos0)
+        kc = torch.zeros_like(kc_ref); vt = torch.zeros_like(vt_ref)
+        out = ops.qkv_proj_rope(x, w, b, 0, H, KV, cos, sin, kc, pos0, vt)
+        torch.cuda.synchronize()
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+    assert torch.equal(out[:, :H * D], qkv[:, :H * D]), f"rotated q: max diff {(out[:, :H * D].float() - qkv[:, :H * D].float()).abs().max().item():.4g}"
+    assert torch.equal(kc, kc_ref), f"K cache: max diff {(kc.float() - kc_ref.float()).abs().max().item():.4g}"
+    assert torch.equal(vt, vt_ref), f"V^T cache: max diff {(vt.float() - vt_ref.float()).abs().max().item():.4g}"
+    assert kc_ref[:, pos0:pos0 + M].abs().sum() > 0 and vt_ref[:, pos0:pos0 + M].abs().sum() > 0
+
+
+@pytest.mark.parametrize("M", [1001, 1536])
+def test_qkv_proj_rope_vit_equals_gemm_plus_qkv_post(ab_library, M):
+    """mode 1: the ViT's q/k/v projection on HEAD-MAJOR weight rows (per head [q 80 | k 80 | v 80 | 16 zero rows] = one 256-column tile, so that
+    a head's rotate-half pairs never straddle two workgroups) with the fp32 2-D RoPE and the V -> V^T copy in the epilogue, against fo1_gemm_bf16 +
+    fo1_qkv_post_vit_bf16 on the reference layout [q heads | k heads | v heads]: the same numbers, bit for bit, at their new addresses."""
+    from vlm_fo1_amd import lib as L, ops
+    H, D, K = 16, 80, 256
+    d = H * D
+    g = torch.Generator().manual_seed(41 + M)
+    x = (torch.randn(M, K, generator=g)).to(BF).cuda()
+    w = (torch.randn(3 * d, K, generator=g) * 0.08).to(BF)
+    b = (torch.randn(3 * d, generator=g) * 0.3).to(BF)
+    ang = torch.rand(M, D // 2, generator=g) * 6.28
+    cos, sin = ang.cos().cuda(), ang.sin().cuda()
+    Sp = (M + 63) // 64 * 64
+    L.load().fo1_gemm_set_variant(0, 5)
+    try:
+        qkv = ops.gemm(x, w.cuda(), b.cuda())
+        vt_ref = torch.zeros(d, Sp, dtype=BF, device="cuda")
+        ops.qkv_post_vit(qkv, H, D, cos, sin, vt_ref)
+        vt = torch.zeros_like(vt_ref)
+        out = ops.qkv_proj_rope(x, ops.head_major_qkv(w, H, D).cuda(), ops.head_major_qkv(b, H, D).cuda(), 1, H, H, cos, sin, None, 0, vt)
+        torch.cuda.synchronize()
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+    o = out.view(M, H, 256)
+    assert torch.equal(o[:, :, :D].reshape(M, d), qkv[:, :d]), "rotated q"
+    assert torch.equal(o[:, :, D:2 * D].reshape(M, d), qkv[:, d:2 * d]), "rotated k"
+    assert torch.equal(vt, vt_ref), f"V^T: max diff {(vt.float() - vt_ref.float()).abs().max().item():.4g}"
+    # and the attention reads the head-major layout through its head stride: same output as on the reference layout
+    items = ops.make_items([(0, M)], "cuda", block=64)
+    a_ref = ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt_ref, items, H, H, D, D ** -0.5, False)
+    a_hm = ops.attention(out, out[:, D:], vt, items, H, H, D, D ** -0.5, False, qk_head_stride=256)
+    assert torch.equal(a_ref, a_hm)
+    items = ops.make_items([(0, M)], "cuda", block=256)
+    assert torch.equal(ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt_ref, items, H, H, D, D ** -0.5, False),
+                       ops.attention(out, out[:, D:], vt, items, H, H, D, D ** -0.5, False, qk_head_stride=256))
+
+
 def test_mfma_clock_probe_reports_a_plausible_clock(ab_library):
     """fo1_mfma_clock_probe (csrc/probe.hip; an instrument of include/fo1_ab.h since round 5 — bench.py loads the test / bench build for it after the timed region): cycles / wall ticks of a register-resident MFMA loop = a clock inside the part's
     DVFS range, 32 cycles per 32x32x16 bf16 MFMA per SIMD (two waves share one), and zero operands never clock lower than random ones."""

@@ -57,6 +57,15 @@ struct GemmParams {
     int w_tiled = 0;
     // 256 x 256 kernels: tile rows per group of the XCD-grouped tile order (tile_coords_grouped_id); 8 = the measured default
     int gm = 8;
+    // fused q/k/v epilogue (fo1_qkv_proj_rope_bf16, EPI 6 / 7): rotary tables (LLM: bf16 cos / sin [M][128]; ViT: fp32 [M][40]), the K cache
+    // (LLM), the V^T destination, head counts
+    const void* rope_cos = nullptr;
+    const void* rope_sin = nullptr;
+    uint16_t* kcache = nullptr;
+    long long kc_head_stride = 0;
+    uint16_t* vt = nullptr;
+    long long vt_ld = 0;
+    int pos0 = 0, n_q = 0, n_kv = 0;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3, ACT_RELU = 5 };   // (4 = the split-K partial epilogue of the 256x256 kernels)
@@ -958,6 +967,180 @@ __device__ __forceinline__ void epilogue32_coalesced_b(const GemmParams& p, f32x
     }
 }
 
+// ---- fused q/k/v epilogue of the 256 x 256 kernel (round 5, VERDICT r4 #1a): bias -> bf16 (the projection's own rounding), then what
+// fo1_qkv_post_llm_bf16 / fo1_qkv_post_vit_bf16 did in a second launch over the whole [M, 3 d] activation — rotary embedding of the q / k heads,
+// K rows appended to the cache, V written transposed — while the tile still sits in LDS.  Same arithmetic and rounding points as those kernels
+// (rope.hip): bit-identical results (tests/test_ops_gpu.py::test_qkv_proj_rope_*).
+//   MODE 0, LLM (modeling_qwen2_5_vl.py:643-685,162-169): columns [q heads | k heads | v heads], head dim 128 = two waves of a tile row:
+//     rotate-half partner = the same row / slot of the NEIGHBOUR wave's staged block (wave ^ 1); cos / sin bf16 [M][128] per packed row;
+//     three roundings bf16(bf16(x cos) + bf16(+-y sin)); q -> C, k -> kcache[kv head][pos0 + m][128], v -> vt[(kv head * 128 + d)][pos0 + m].
+//   MODE 1, ViT (:219-230): HEAD-MAJOR columns — one 256-wide tile per head = [q 80 | k 80 | v 80 | 16 pad] (the weight rows are laid out
+//     so at load: a head's rotate-half pairs d, d + 40 never straddle two workgroups); fp32 cos / sin [M][40], fp32 math, ONE rounding;
+//     q, k -> C (the attention reads them with head stride 256), v -> vt[(head * 80 + d)][pos0 + m].
+// The waves of a tile meet at ONE extra workgroup barrier between staging and write-out (a partner slot belongs to another wave).
+template <int MODE>
+__device__ __forceinline__ void epilogue32_qkv(const GemmParams& p, f32x16 (&acc)[4][2], char* smem, int wave, int m_base, int n_base, int lane) {
+    char* region = smem + wave * 16384;
+    const int mi = lane & 31, hi = lane >> 5, hi4 = hi * 4;
+    {
+        uint2 bv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bv[q] = uint2{0u, 0u};
+        if (p.bias) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bv[q] = *reinterpret_cast<const uint2*>(p.bias + n_base + (q >> 2) * 32 + (q & 3) * 8 + hi4);      // N % 256 == 0: in range
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int nf = q >> 2, g = q & 3;
+            const float b[4] = {bf16_lo(bv[q].x), bf16_hi(bv[q].x), bf16_lo(bv[q].y), bf16_hi(bv[q].y)};
+#pragma unroll
+            for (int mf = 0; mf < 4; ++mf) {
+                const int r = mf * 32 + mi;
+                uint2 ov;
+                ov.x = pack_bf16x2(acc[mf][nf][g * 4 + 0] + b[0], acc[mf][nf][g * 4 + 1] + b[1]);
+                ov.y = pack_bf16x2(acc[mf][nf][g * 4 + 2] + b[2], acc[mf][nf][g * 4 + 3] + b[3]);
+                *reinterpret_cast<uint2*>(region + r * 128 + ((q ^ (r & 7)) << 4) + hi * 8) = ov;
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    const int lrow = lane >> 3, c = lane & 7;
+    auto unpack8 = [](const uint4& u, float (&f)[8]) {
+        f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
+        f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
+    };
+    // V columns of this wave, transposed: lane = column, 8 rows per 16-byte store along the V^T row
+    auto store_vt = [&](bool is_v, uint16_t* vrow) {
+        const int ch = lane >> 3, e2 = (lane & 7) * 2;
+#pragma unroll 4
+        for (int g = 0; g < 16; ++g) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j2 = 0; j2 < 4; ++j2) {
+                const uint32_t lo = *reinterpret_cast<const uint16_t*>(region + (g * 8 + 2 * j2) * 128 + ((ch ^ (2 * j2)) << 4) + e2);
+                const uint32_t up = *reinterpret_cast<const uint16_t*>(region + (g * 8 + 2 * j2 + 1) * 128 + ((ch ^ (2 * j2 + 1)) << 4) + e2);
+                w[j2] = lo | (up << 16);
+            }
+            const int mg = m_base + g * 8;
+            if (is_v) {
+                if (mg + 8 <= p.M) {
+                    *reinterpret_cast<uint4*>(vrow + g * 8) = uint4{w[0], w[1], w[2], w[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        if (mg + j < p.M) vrow[g * 8 + j] = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
+                }
+            }
+        }
+    };
+    if constexpr (MODE == 0) {
+        const int Nq = p.n_q * 128, Nk = p.n_kv * 128;
+        if (n_base >= Nq + Nk) {        // wave-uniform: a V block
+            const int kvh = (n_base - Nq - Nk) >> 7;
+            store_vt(true, p.vt + (long long)(kvh * 128 + (n_base & 64) + lane) * p.vt_ld + p.pos0 + m_base);
+            return;
+        }
+        const bool is_k = n_base >= Nq, first = (n_base & 64) == 0;
+        const char* preg = smem + (wave ^ 1) * 16384;                  // the head's other half: same rows, same slots
+        const int d0 = (n_base & 64) + c * 8;
+        const uint16_t* cosb = reinterpret_cast<const uint16_t*>(p.rope_cos) + d0;
+        const uint16_t* sinb = reinterpret_cast<const uint16_t*>(p.rope_sin) + d0;
+        uint16_t* dst = is_k ? p.kcache + (long long)((n_base - Nq) >> 7) * p.kc_head_stride + (long long)p.pos0 * 128 + d0
+                             : p.C + n_base + c * 8;
+        const long long dld = is_k ? 128 : p.ldc;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            uint4 cv[8], sv[8], xv[8], yv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {       // table rows first: their latency runs under the LDS reads
+                const int m = m_base + (hf * 8 + i) * 8 + lrow;
+                const long long mr = (long long)(m < p.M ? m : p.M - 1) * 128;
+                cv[i] = *reinterpret_cast<const uint4*>(cosb + mr);
+                sv[i] = *reinterpret_cast<const uint4*>(sinb + mr);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int r = (hf * 8 + i) * 8 + lrow, sw = (c ^ (r & 7)) << 4;
+                xv[i] = *reinterpret_cast<const uint4*>(region + r * 128 + sw);
+                yv[i] = *reinterpret_cast<const uint4*>(preg + r * 128 + sw);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float x[8], y[8], cs[8], sn[8];
+                unpack8(xv[i], x); unpack8(yv[i], y); unpack8(cv[i], cs); unpack8(sv[i], sn);
+                uint32_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a0 = x[2 * j] * cs[2 * j], a1 = x[2 * j + 1] * cs[2 * j + 1];
+                    float b0 = (first ? -y[2 * j] : y[2 * j]) * sn[2 * j], b1 = (first ? -y[2 * j + 1] : y[2 * j + 1]) * sn[2 * j + 1];
+                    round2_bf16(a0, a1);
+                    round2_bf16(b0, b1);
+                    o[j] = pack_bf16x2(a0 + b0, a1 + b1);
+                }
+                const int m = m_base + (hf * 8 + i) * 8 + lrow;
+                if (m < p.M) *reinterpret_cast<uint4*>(dst + (long long)m * dld) = uint4{o[0], o[1], o[2], o[3]};
+            }
+        }
+    } else {
+        const int wn = wave & 3, head = n_base >> 8;
+        const int tc = wn * 64 + c * 8;                                 // this lane's first column inside the head's tile
+        const bool is_qk = tc < 160, is_vl = tc >= 160 && tc < 240;
+        const int dd = tc < 80 ? tc : (tc < 160 ? tc - 80 : 0);         // column inside the q / k head (0 for the lanes that do not rotate)
+        const bool first = dd < 40;
+        const int ptc = is_qk ? (first ? tc + 40 : tc - 40) : tc;       // the rotate-half partner's tile column
+        const char* preg = smem + ((wave & 4) | (ptc >> 6)) * 16384;
+        const int pc = (ptc & 63) >> 3;
+        const int dm = first ? dd : dd - 40;
+        const float* cosf_ = reinterpret_cast<const float*>(p.rope_cos) + dm;
+        const float* sinf_ = reinterpret_cast<const float*>(p.rope_sin) + dm;
+        uint16_t* dst = p.C + n_base - wn * 64 + tc;
+#pragma unroll
+        for (int qt = 0; qt < 4; ++qt) {
+            float4 ca[4], cb[4], sa[4], sb[4];
+            uint4 xv[4], yv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m_base + (qt * 4 + i) * 8 + lrow;
+                const long long mr = (long long)(m < p.M ? m : p.M - 1) * 40;
+                ca[i] = *reinterpret_cast<const float4*>(cosf_ + mr); cb[i] = *reinterpret_cast<const float4*>(cosf_ + mr + 4);
+                sa[i] = *reinterpret_cast<const float4*>(sinf_ + mr); sb[i] = *reinterpret_cast<const float4*>(sinf_ + mr + 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = (qt * 4 + i) * 8 + lrow;
+                xv[i] = *reinterpret_cast<const uint4*>(region + r * 128 + ((c ^ (r & 7)) << 4));
+                yv[i] = *reinterpret_cast<const uint4*>(preg + r * 128 + ((pc ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float x[8], y[8], o[8];
+                unpack8(xv[i], x); unpack8(yv[i], y);
+                const float cs[8] = {ca[i].x, ca[i].y, ca[i].z, ca[i].w, cb[i].x, cb[i].y, cb[i].z, cb[i].w};
+                const float sn[8] = {sa[i].x, sa[i].y, sa[i].z, sa[i].w, sb[i].x, sb[i].y, sb[i].z, sb[i].w};
+                if (first) {        // (the explicit contraction of rope.hip's rope_vit_body)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(x[j], cs[j], -(y[j] * sn[j]));
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(x[j], cs[j], y[j] * sn[j]);
+                }
+                const int m = m_base + (qt * 4 + i) * 8 + lrow;
+                if (m < p.M && is_qk)
+                    *reinterpret_cast<uint4*>(dst + (long long)m * p.ldc) =
+                        uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+            }
+        }
+        if (wn >= 2) {      // the head's V columns: tile columns 160..239 = lanes 32..63 of wave 2, lanes 0..47 of wave 3
+            const int tcl = wn * 64 + lane;
+            store_vt(tcl >= 160 && tcl < 240, p.vt + (long long)(head * 80 + (tcl - 160)) * p.vt_ld + p.pos0 + m_base);
+        }
+        (void)is_vl;
+    }
+}
+
 template <int EPI>
 __device__ __forceinline__ void epilogue32_coalesced(const GemmParams& p, f32x16 (&acc)[4][2], char* region, int m_base, int n_base, int lane,
                                                      long long offC, long long offR) {
@@ -1455,14 +1638,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
                 }
         }
     }
-    if constexpr (EPI != 4) {
-        if (p.coal) {   // every wave's LDS reads of the main loop are retired (the last load segment ended at a barrier this wave has passed)
-            epilogue32_coalesced<EPI>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR);
-            FO1_GEMM_STAMP(3);
-            return;
+    if constexpr (EPI == 6 || EPI == 7) {       // fused q/k/v epilogue (fo1_qkv_proj_rope_bf16): always through the LDS image
+        epilogue32_qkv<EPI - 6>(p, acc, smem, wave, m0 + wm * 128, n0 + wn * 64, lane);
+        return;
+    } else {
+        if constexpr (EPI != 4) {
+            if (p.coal) {   // every wave's LDS reads of the main loop are retired (the last load segment ended at a barrier this wave has passed)
+                epilogue32_coalesced<EPI>(p, acc, smem + wave * 16384, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR);
+                FO1_GEMM_STAMP(3);
+                return;
+            }
         }
+        epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
     }
-    epilogue32<EPI, 4, 2>(p, acc, m0 + wm * 128, n0 + wn * 64, lane, bz * p.sC, bz * p.sR, blockIdx.z);
 }
 
 #ifdef FO1_ENABLE_AB      // persistent tile loop: measured 2-5 % slower, kept for A/B only
@@ -2003,6 +2191,37 @@ static int launch_gemm(GemmParams& p, int batch, bool glds, hipStream_t st, bool
     return FO1_OK;
 }
 
+// q/k/v projection with the fused epilogue (EPI 6 LLM / 7 ViT): always the 256 x 256 two-phase kernel (the epilogue pairs waves of one tile row)
+static int launch_qkv_p4(GemmParams& p, int mode, hipStream_t st) {
+    p.tiles_m = cdiv(p.M, 256);
+    p.tiles_n = cdiv(p.N, 256);
+    if (g_gemm_group_m > 0) p.gm = g_gemm_group_m;
+    p.splits = 1;
+    p.kper = p.K / 64 + 1;
+    p.part = nullptr;
+    p.debug = 0;
+    p.coal = 1;
+    p.stages = 2;
+    const dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
+    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    constexpr int smem = 2 * 4 * 16384;
+    static bool attr = false;
+    if (!attr) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
+    }
+    char pname[56];
+    const char* name = "gemm_bt_p4<256,256>";
+    if (profile_enabled() && g_gemm_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemm %dx%dx%d t256x256 qkv%d", p.M, p.N, p.K, mode);
+        name = pname;
+    }
+    if (mode == 0) FO1_LAUNCH(name, flops, gemm_bt_p4_kernel<6>, grid, dim3(512), smem, st, p);
+    else FO1_LAUNCH(name, flops, gemm_bt_p4_kernel<7>, grid, dim3(512), smem, st, p);
+    return FO1_OK;
+}
+
 int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws_bytes) {
     bool glds = (p.K % 64 == 0);
     if (g_gemm_variant == 1) glds = false;
@@ -2039,7 +2258,7 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         // profiles/r04_pool_gemm_stream_kernel_vs_tile_kernels.json: gate/up 34.4 -> 30.5 us, lm_head 163 -> 152 us at M = 128)
         if (glds && p.M > 64 && p.M <= 128 && t128 >= 128 && nk >= 16) tile = 1;
         const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256) * batch;
-        if (glds && nk >= 4 && p.M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) tile = 5;
+        if (glds && nk >= 4 && p.M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) tile = 5;      // (fo1_gemm_takes_big_tile states this rule for callers)
     }
     p.splits = 1;
     p.kper = nk + 1;
@@ -2180,6 +2399,56 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
     if (g_gemm_gemv && M <= 4 && !out_f32 && (size_t)(M > 2 ? 4 : M) * K * 2 <= 150 * 1024 && (act != 3 || N % 32 == 0))
         return gemv_dispatch(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, (hipStream_t)stream, nullptr, 0.f);
     return gemm_dispatch(p, 1, (hipStream_t)stream, (float*)workspace, workspace_bytes);
+}
+
+// 1 when fo1_gemm_bf16 runs an [M, K] x [N, K]^T product (bf16 out, K % 64 == 0, aligned operands) on the 256 x 256 two-phase kernel — the
+// rule of gemm_dispatch (and, in the test / bench build, its tile pin).  fo1_qkv_proj_rope_bf16 always runs on that kernel: a caller that
+// wants the fused and the two-launch form to agree BIT FOR BIT takes the fused one exactly where this says 1.
+int fo1_gemm_takes_big_tile(int M, int N, int K) {
+    using namespace fo1;
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64) return 0;
+    if (g_gemm_tile != 0) return g_gemm_tile == 5 ? 1 : 0;
+    const int nk = K / 64;
+    const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 256);
+    return (nk >= 4 && M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) ? 1 : 0;
+}
+
+// q/k/v projection + bias + rotary embedding + K-cache append + V^T write in ONE launch (the 256 x 256 kernel with the fused epilogue
+// epilogue32_qkv): what fo1_gemm_bf16 followed by fo1_qkv_post_llm_bf16 / fo1_qkv_post_vit_bf16 computes, bit for bit, without the second pass
+// over the [M, N] activation.  mode 0 (LLM, modeling_qwen2_5_vl.py:643-685): W rows [q heads | k heads | v heads], head_dim 128; cos / sin bf16
+// [M][128]; q (rotated) -> C[:, :n_q * 128]; k (rotated) -> kcache[kv head][pos0 + m][128]; v -> vt[kv head * 128 + d][pos0 + m]; the k / v columns of
+// C are NOT written.  mode 1 (ViT, :219-230, :162-169): W rows HEAD-MAJOR, per head [q 80 | k 80 | v 80 | 16 zero rows] (N = 256 * n_q_heads); cos /
+// sin fp32 [M][40]; q, k (rotated) -> C in that layout (attention: head stride 256, k at column 80); v -> vt[head * 80 + d][pos0 + m].
+// K % 64 == 0, N % 256 == 0, pos0 % 8 == 0, vt_ld % 8 == 0, 16-byte aligned operands.
+int fo1_qkv_proj_rope_bf16(const void* A, int lda, const void* W, int ldw, const void* bias, void* C, int ldc, int M, int N, int K, int mode,
+                           int n_q_heads, int n_kv_heads, const void* cos_table, const void* sin_table, void* kcache, long long kcache_head_stride,
+                           int pos0, void* vt, long long vt_ld, void* stream) {
+    using namespace fo1;
+    if (M == 0) return FO1_OK;
+    FO1_CHECK_ARG(A && W && C && cos_table && sin_table && vt, "qkv_proj_rope: NULL operand");
+    FO1_CHECK_ARG(mode == 0 || mode == 1, "qkv_proj_rope: mode %d (0 LLM, 1 ViT head-major)", mode);
+    FO1_CHECK_ARG(M > 0 && K >= 128 && K % 64 == 0 && N % 256 == 0, "qkv_proj_rope: M=%d N=%d (%% 256) K=%d (%% 64, >= 128)", M, N, K);
+    FO1_CHECK_ARG(lda % 8 == 0 && ldw % 8 == 0 && lda >= K && ldw >= K && ldc % 8 == 0 && ldc >= (mode == 0 ? n_q_heads * 128 : N), "qkv_proj_rope: leading dimensions");
+    FO1_CHECK_ARG(((uintptr_t)A & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && ((uintptr_t)vt & 15) == 0 &&
+                  ((uintptr_t)cos_table & 15) == 0 && ((uintptr_t)sin_table & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 7) == 0),
+                  "qkv_proj_rope: operands must be 16-byte aligned");
+    FO1_CHECK_ARG(pos0 >= 0 && pos0 % 8 == 0 && vt_ld % 8 == 0 && vt_ld >= pos0 + M, "qkv_proj_rope: pos0=%d (%% 8), vt_ld=%lld (%% 8, >= pos0 + M)", pos0, vt_ld);
+    if (mode == 0) {
+        FO1_CHECK_ARG(n_q_heads > 0 && n_kv_heads > 0 && N == (n_q_heads + 2 * n_kv_heads) * 128, "qkv_proj_rope: N=%d is not (%d + 2 x %d) heads of 128", N, n_q_heads, n_kv_heads);
+        FO1_CHECK_ARG(kcache && ((uintptr_t)kcache & 15) == 0 && kcache_head_stride % 8 == 0, "qkv_proj_rope: kcache");
+    } else {
+        FO1_CHECK_ARG(n_q_heads > 0 && N == n_q_heads * 256, "qkv_proj_rope: N=%d is not %d head tiles of 256", N, n_q_heads);
+    }
+    GemmParams p;
+    p.A = (const uint16_t*)A; p.W = (const uint16_t*)W; p.bias = (const uint16_t*)bias; p.res = nullptr;
+    p.C = (uint16_t*)C; p.C32 = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.act = 0;
+    p.sA = p.sW = p.sC = p.sR = 0;
+    p.scale_m = p.scale_n = nullptr;
+    p.rope_cos = cos_table; p.rope_sin = sin_table;
+    p.kcache = (uint16_t*)kcache; p.kc_head_stride = kcache_head_stride;
+    p.vt = (uint16_t*)vt; p.vt_ld = vt_ld; p.pos0 = pos0; p.n_q = n_q_heads; p.n_kv = n_kv_heads;
+    return launch_qkv_p4(p, mode, (hipStream_t)stream);
 }
 
 // Split-K partial sums only (the decode pool's q/k/v, o and down projections, llm.DecodePool): part[z][m][n] (fp32, row stride N) = the

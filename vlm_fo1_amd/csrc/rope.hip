@@ -92,8 +92,10 @@ __device__ __forceinline__ void rope_vit_body(uint16_t* __restrict__ x, int ld, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float cs = cp[j], sn = sp[j];
-            oa[j] = a[j] * cs - b[j] * sn;
-            ob[j] = b[j] * cs + a[j] * sn;
+            // explicit contraction (one product rounded to fp32, the other fused): the q/k/v GEMM's fused epilogue (gemm.hip, epilogue32_qkv)
+            // writes the same two expressions and must give the same bits, whatever -ffp-contract would pick for `a * cs - b * sn`
+            oa[j] = __builtin_fmaf(a[j], cs, -(b[j] * sn));
+            ob[j] = __builtin_fmaf(b[j], cs, a[j] * sn);
         }
         *reinterpret_cast<uint4*>(p + d0) = pack8r(oa);
         *reinterpret_cast<uint4*>(p + d0 + HH) = pack8r(ob);

@@ -276,9 +276,16 @@ class QwenLLM:
         scale = 1.0 / math.sqrt(HD)
         if flops is None:
             flops = 4.0 * H * HD * (L * (pos0 + (L + 1) / 2.0))
+        fused = (HD == 128 and pos0 % 8 == 0 and self.capacity % 8 == 0 and ops.qkv_fused_for(L, (H + 2 * KV) * HD, c.hidden_size)
+                 and not ops.fp8_routed(self.layers[0]["wqkv"], L))
         for li, w in enumerate(self.layers):
-            qkv = ops.norm_linear(x, w["ln1"], c.rms_norm_eps, w["wqkv"], w["bqkv"])
-            ops.qkv_post_llm(qkv, H, KV, HD, cos, sin, self.kcache[li], self.vtcache[li], pos0)   # mRoPE + K append + V^T, one launch
+            if fused:
+                # q/k/v projection with mRoPE + K append + V^T in the GEMM's epilogue (ops.qkv_proj_rope mode 0): same bits, one launch less and no
+                # second pass over the [L, 2560] activation
+                qkv = ops.qkv_proj_rope(ops.rmsnorm(x, w["ln1"], c.rms_norm_eps), w["wqkv"], w["bqkv"], 0, H, KV, cos, sin, self.kcache[li], pos0, self.vtcache[li])
+            else:
+                qkv = ops.norm_linear(x, w["ln1"], c.rms_norm_eps, w["wqkv"], w["bqkv"])
+                ops.qkv_post_llm(qkv, H, KV, HD, cos, sin, self.kcache[li], self.vtcache[li], pos0)   # mRoPE + K append + V^T, one launch
             att = ops.attention_strided(qkv[:, :H * HD], q_row0=pos0, k=self.kcache[li], vt=self.vtcache[li], items=items,
                                         n_q_heads=H, n_kv_heads=KV, head_dim=HD, scale=scale, causal=True, flops=flops, prefix_ranges=prefix_ranges)
             x = ops.gemm(att, w["wo"], residual=x)

@@ -259,6 +259,14 @@ def norm_linear(x: torch.Tensor, norm_w: torch.Tensor, eps: float, w: torch.Tens
     return gemm(rmsnorm(x, norm_w, eps), w, bias, act=act)
 
 
+def fp8_routed(w: torch.Tensor, rows: int) -> bool:
+    """True when norm_linear / gemm would send a product of `rows` rows with this weight through the fp8 kernel."""
+    if not _fp8_weights or rows < FP8_MIN_ROWS:
+        return False
+    pw, ldw, N, K = _rows(w, "w")
+    return (pw, N, K) in _fp8_weights
+
+
 def register_fp8_weight(w: torch.Tensor):
     """Quantise a bf16 [N, K] weight and let gemm() route large-M products with it through the fp8 kernel.  The bf16 tensor stays
     (decode and small-M products keep using it).  Returns the routing key (truthy), or None when the shape does not qualify
@@ -412,6 +420,58 @@ def qkv_post_vit(qkv: torch.Tensor, n_heads: int, head_dim: int, cos: torch.Tens
     assert Cv == n_heads * head_dim
     _L.check(_L.load().fo1_qkv_post_vit_bf16(p, ld, n_heads, head_dim, cos.data_ptr(), sin.data_ptr(), S, pv, ldv, _stream()),
              "fo1_qkv_post_vit_bf16")
+
+
+def qkv_fused_enabled() -> bool:
+    """FO1_QKV_FUSED=0 turns the fused q/k/v epilogue off (A/B; both forms give the same bits)."""
+    return os.environ.get("FO1_QKV_FUSED", "1") != "0"
+
+
+def qkv_fused_for(M: int, N: int, K: int) -> bool:
+    """Take the fused q/k/v form (qkv_proj_rope: always the 256 x 256 GEMM kernel) for a product that gemm() itself would run on that kernel
+    — and only there: a row's fp32 sum order is the kernel's, so the fused and the two-launch form then agree bit for bit (also under the
+    test build's tile pins, which fo1_gemm_takes_big_tile honours)."""
+    return qkv_fused_enabled() and bool(_L.load().fo1_gemm_takes_big_tile(int(M), int(N), int(K)))
+
+
+def qkv_proj_rope(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], mode: int, n_q: int, n_kv: int, cos: torch.Tensor, sin: torch.Tensor,
+                  kcache: Optional[torch.Tensor], pos0: int, vt: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q/k/v projection + bias + RoPE + K-cache append + V^T write in one launch (fo1_qkv_proj_rope_bf16: the 256 x 256 GEMM with the fused
+    epilogue).  mode 0 (LLM): w [(n_q + 2 n_kv) * 128, K], cos / sin bf16 [M, 128], kcache [n_kv, max_seq, 128]; returns [M, N] whose first
+    n_q * 128 columns hold the rotated q heads (the k / v columns are not written).  mode 1 (ViT): w head-major [n_q * 256, K] (head_major_qkv),
+    cos / sin fp32 [M, 40]; returns [M, n_q * 256] = per head [q 80 | k 80 | - | -] rotated.  vt: the V^T destination [heads * head_dim, ld]."""
+    _chk(x, "x"); _chk(w, "w"); _chk(vt, "vt")
+    px, ldx, M, K = _rows(x, "x")
+    pw, ldw, N, Kw = _rows(w, "w")
+    assert K == Kw
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    po, ldo, _, _ = _rows(out, "out")
+    pv, ldv, _, _ = _rows(vt, "vt")
+    if mode == 0:
+        _chk(cos, "cos"); _chk(sin, "sin"); _chk(kcache, "kcache")
+        assert cos.shape == (M, 128) and cos.is_contiguous() and sin.shape == (M, 128) and sin.is_contiguous()
+        assert kcache.dim() == 3 and kcache.shape[2] == 128 and kcache.stride(2) == 1 and kcache.stride(1) == 128
+        pk, ks = kcache.data_ptr(), kcache.stride(0)
+    else:
+        _chk(cos, "cos", torch.float32); _chk(sin, "sin", torch.float32)
+        assert cos.shape == (M, 40) and cos.is_contiguous() and sin.shape == (M, 40) and sin.is_contiguous()
+        pk, ks = None, 0
+    rc = _L.load().fo1_qkv_proj_rope_bf16(px, ldx, pw, ldw, bias.data_ptr() if bias is not None else None, po, ldo, M, N, K, int(mode), int(n_q), int(n_kv),
+                                          cos.data_ptr(), sin.data_ptr(), pk, ks, int(pos0), pv, ldv, _stream())
+    _L.check(rc, "fo1_qkv_proj_rope_bf16")
+    return out
+
+
+def head_major_qkv(w: torch.Tensor, n_heads: int, head_dim: int = 80, tile: int = 256) -> torch.Tensor:
+    """[3 * n_heads * head_dim, ...] rows ordered [q heads | k heads | v heads] -> [n_heads * tile, ...] rows ordered per head
+    [q | k | v | zero pad] (qkv_proj_rope mode 1: one 256-column output tile per head).  Works for the weight [3 d, K] and the bias [3 d]."""
+    d = n_heads * head_dim
+    assert w.shape[0] == 3 * d and 3 * head_dim <= tile
+    parts = w.reshape(3, n_heads, head_dim, *w.shape[1:]).transpose(0, 1)                     # [head, 3, head_dim, ...]
+    out = torch.zeros(n_heads, tile, *w.shape[1:], dtype=w.dtype, device=w.device)
+    out[:, :3 * head_dim] = parts.reshape(n_heads, 3 * head_dim, *w.shape[1:])
+    return out.reshape(n_heads * tile, *w.shape[1:]).contiguous()
 
 
 def transpose_into(src: torch.Tensor, dst: torch.Tensor, col0: int = 0, dyn_col0: Optional[torch.Tensor] = None) -> None:
@@ -704,9 +764,10 @@ def make_items(segments: Sequence[Sequence[int]], device, causal: bool = False, 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_q_heads: int, n_kv_heads: int,
               head_dim: int, scale: float, causal: bool, out: Optional[torch.Tensor] = None,
-              flops: float = 0.0) -> torch.Tensor:
+              flops: float = 0.0, qk_head_stride: Optional[int] = None) -> torch.Tensor:
     """q: [L, >= n_q_heads*head_dim] view (heads contiguous), k: [Lk, ...] view, vt: [n_kv_heads*head_dim, ld] (V^T).
-    Returns out [L, n_q_heads*head_dim]."""
+    qk_head_stride: elements between consecutive heads of q and of k when they are not packed (the head-major q/k/v layout of
+    qkv_proj_rope mode 1: 256).  Returns out [L, n_q_heads*head_dim]."""
     _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt")
     assert items.dtype == torch.int32 and items.is_contiguous() and items.device == q.device
     pq, ldq, L, _ = _rows(q, "q")
@@ -715,7 +776,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.T
     if out is None:
         out = torch.empty(L, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
     po, ldo, _, _ = _rows(out, "out")
-    rc = _L.load().fo1_attention_bf16(pq, ldq, head_dim, pk, ldk, head_dim, pv, ldv, po, ldo, head_dim,
+    hs = head_dim if qk_head_stride is None else int(qk_head_stride)
+    rc = _L.load().fo1_attention_bf16(pq, ldq, hs, pk, ldk, hs, pv, ldv, po, ldo, head_dim,
                                       items.data_ptr(), items.shape[0], getattr(items, "q_block", 64), n_q_heads, n_kv_heads,
                                       head_dim, float(scale), 1 if causal else 0, None, float(flops), _stream())
     _L.check(rc, "fo1_attention_bf16")

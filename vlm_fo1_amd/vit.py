@@ -137,6 +137,9 @@ class QwenViT:
         bf = torch.bfloat16
         d, ff = cfg.hidden_size, cfg.intermediate_size
         self.ffp = _round_up(ff, 64)  # 3420 -> 3456: zero rows/cols are exact and make K % 64 == 0
+        # fused q/k/v epilogue (round 5): RoPE + V^T in the q/k/v GEMM's epilogue for passes large enough for the 256 x 256 GEMM kernel (ops.qkv_fused_for) — needs head dim 80
+        # (three heads' worth of columns + pad = one 256-wide tile) and a second, head-major copy of the qkv weights (315 MB at depth 32)
+        self._fused_qkv = ops.qkv_fused_enabled() and d // cfg.num_heads == 80 and d % 64 == 0
 
         def dv(t):
             return t.to(device=self.dev, dtype=bf).contiguous()
@@ -160,6 +163,9 @@ class QwenViT:
             self.blocks.append(dict(
                 n1=dv(state[p + "norm1.weight"]), n2=dv(state[p + "norm2.weight"]),
                 wqkv=dv(state[p + "attn.qkv.weight"]), bqkv=dv(state[p + "attn.qkv.bias"]),
+                # head-major copy for the fused q/k/v epilogue (ops.qkv_proj_rope mode 1): per head [q | k | v | 16 zero rows] = one 256-column tile
+                wqkv_hm=(dv(ops.head_major_qkv(state[p + "attn.qkv.weight"], cfg.num_heads, d // cfg.num_heads)) if self._fused_qkv else None),
+                bqkv_hm=(dv(ops.head_major_qkv(state[p + "attn.qkv.bias"], cfg.num_heads, d // cfg.num_heads)) if self._fused_qkv else None),
                 wo=dv(state[p + "attn.proj.weight"]), bo=dv(state[p + "attn.proj.bias"]),
                 wgu=dv(ops.interleave_gate_up(padrows(state[p + "mlp.gate_proj.weight"], self.ffp), padrows(state[p + "mlp.up_proj.weight"], self.ffp))),
                 bgu=dv(ops.interleave_gate_up(padrows(state[p + "mlp.gate_proj.bias"], self.ffp), padrows(state[p + "mlp.up_proj.bias"], self.ffp))),
@@ -226,12 +232,19 @@ class QwenViT:
         fl_win = 4.0 * d * sum((b - a) ** 2 for a, b in win_seg)
         fl_full = 4.0 * d * sum((b - a) ** 2 for a, b in full_seg)
         feats: List[torch.Tensor] = []
+        fused_qkv = self._fused_qkv and ops.qkv_fused_for(S, 3 * d, d) and not ops.fp8_routed(self.blocks[0]["wqkv"], S)
         for i, w in enumerate(self.blocks):
             full = i in c.fullatt_block_indexes
-            qkv = ops.norm_linear(x, w["n1"], 1e-6, w["wqkv"], w["bqkv"])
-            ops.qkv_post_vit(qkv, H, hd, g.cos, g.sin, vt)   # 2-D RoPE on q/k + V -> V^T, one launch
-            att = ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
-                                flops=fl_full if full else fl_win)
+            if fused_qkv:
+                # q/k/v projection with 2-D RoPE + V -> V^T in the GEMM's epilogue (one launch, no second pass over [S, 3 d]); head-major columns
+                qkv = ops.qkv_proj_rope(ops.rmsnorm(x, w["n1"], 1e-6), w["wqkv_hm"], w["bqkv_hm"], 1, H, H, g.cos, g.sin, None, 0, vt)
+                att = ops.attention(qkv, qkv[:, hd:], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
+                                    flops=fl_full if full else fl_win, qk_head_stride=256)
+            else:
+                qkv = ops.norm_linear(x, w["n1"], 1e-6, w["wqkv"], w["bqkv"])
+                ops.qkv_post_vit(qkv, H, hd, g.cos, g.sin, vt)   # 2-D RoPE on q/k + V -> V^T, one launch
+                att = ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
+                                    flops=fl_full if full else fl_win)
             x = ops.gemm(att, w["wo"], w["bo"], residual=x)
             a = ops.norm_linear(x, w["n2"], 1e-6, w["wgu"], w["bgu"], act=ops.ACT_SWIGLU16)
             x = ops.gemm(a, w["wd"], w["bd"], residual=x)
