@@ -66,6 +66,12 @@ struct GemmParams {
     uint16_t* vt = nullptr;
     long long vt_ld = 0;
     int pos0 = 0, n_q = 0, n_kv = 0;
+    // implicit 3x3 convolution (fo1_conv3x3_gemm_bf16, CONV instantiations of the 256 x 256 kernel): A is a zero-PADDED token-major map
+    // [.., Wp, Cin]; a_rows[m] = byte offset of output pixel m's tap (0, 0) in it; K tile kt reads tap (ky, kx) = (kt >> conv_lgc) / 3, % 3
+    // at channel block kt & ((1 << conv_lgc) - 1): source = a_rows[m] + ky * conv_row_bytes + kx * conv_cin_bytes + block * 128
+    const uint32_t* a_rows = nullptr;
+    uint32_t conv_row_bytes = 0, conv_cin_bytes = 0;
+    int conv_lgc = 0;
 };
 
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_SILU = 2, ACT_SWIGLU16 = 3, ACT_RELU = 5 };   // (4 = the split-K partial epilogue of the 256x256 kernels)
@@ -982,6 +988,10 @@ template <int MODE>
 __device__ __forceinline__ void epilogue32_qkv(const GemmParams& p, f32x16 (&acc)[4][2], char* smem, int wave, int m_base, int n_base, int lane) {
     char* region = smem + wave * 16384;
     const int mi = lane & 31, hi = lane >> 5, hi4 = hi * 4;
+    // staged block: 128 rows x 128 B, the 16-B slot of column chunk q of row r is q ^ (r & 7) ^ ((r >> 3) & 7): conflict-free for the 16-B row
+    // reads of the rotation (8 consecutive rows x 8 chunks per instruction) AND for the 2-byte column reads of the V transpose (8 rows that are
+    // 8 apart per instruction)
+    auto slot = [](int q, int r) { return (q ^ (r & 7) ^ ((r >> 3) & 7)) << 4; };
     {
         uint2 bv[8];
 #pragma unroll
@@ -1000,77 +1010,87 @@ __device__ __forceinline__ void epilogue32_qkv(const GemmParams& p, f32x16 (&acc
                 uint2 ov;
                 ov.x = pack_bf16x2(acc[mf][nf][g * 4 + 0] + b[0], acc[mf][nf][g * 4 + 1] + b[1]);
                 ov.y = pack_bf16x2(acc[mf][nf][g * 4 + 2] + b[2], acc[mf][nf][g * 4 + 3] + b[3]);
-                *reinterpret_cast<uint2*>(region + r * 128 + ((q ^ (r & 7)) << 4) + hi * 8) = ov;
+                *reinterpret_cast<uint2*>(region + r * 128 + slot(q, r) + hi * 8) = ov;
             }
         }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __syncthreads();
-    __builtin_amdgcn_sched_barrier(0);
     const int lrow = lane >> 3, c = lane & 7;
     auto unpack8 = [](const uint4& u, float (&f)[8]) {
         f[0] = bf16_lo(u.x); f[1] = bf16_hi(u.x); f[2] = bf16_lo(u.y); f[3] = bf16_hi(u.y);
         f[4] = bf16_lo(u.z); f[5] = bf16_hi(u.z); f[6] = bf16_lo(u.w); f[7] = bf16_hi(u.w);
     };
-    // V columns of this wave, transposed: lane = column, 8 rows per 16-byte store along the V^T row
-    auto store_vt = [&](bool is_v, uint16_t* vrow) {
-        const int ch = lane >> 3, e2 = (lane & 7) * 2;
-#pragma unroll 4
-        for (int g = 0; g < 16; ++g) {
-            uint32_t w[4];
+    // V columns [cg0, cg1) x 8 of this wave's block, transposed: an instruction covers 8 columns x 64 rows — lane = (column, 8-row group), the 8
+    // lanes of a column write 128 contiguous bytes of its V^T row.  vcol0 = the V^T row of the block's column 0 (may lie before the buffer when
+    // cg0 > 0: only columns >= cg0 * 8 are touched).
+    auto store_vt = [&](int cg0, int cg1, uint16_t* vcol0) {
+        const int dl = lane >> 3, rg = lane & 7;
+        for (int cg = cg0; cg < cg1; ++cg) {
+            uint16_t* vrow = vcol0 + (long long)(cg * 8 + dl) * p.vt_ld;
 #pragma unroll
-            for (int j2 = 0; j2 < 4; ++j2) {
-                const uint32_t lo = *reinterpret_cast<const uint16_t*>(region + (g * 8 + 2 * j2) * 128 + ((ch ^ (2 * j2)) << 4) + e2);
-                const uint32_t up = *reinterpret_cast<const uint16_t*>(region + (g * 8 + 2 * j2 + 1) * 128 + ((ch ^ (2 * j2 + 1)) << 4) + e2);
-                w[j2] = lo | (up << 16);
-            }
-            const int mg = m_base + g * 8;
-            if (is_v) {
+            for (int rh = 0; rh < 2; ++rh) {
+                uint32_t w[4];
+#pragma unroll
+                for (int j2 = 0; j2 < 4; ++j2) {
+                    const int r0 = rh * 64 + rg * 8 + 2 * j2;
+                    const uint32_t lo = *reinterpret_cast<const uint16_t*>(region + r0 * 128 + ((cg ^ (2 * j2) ^ rg) << 4) + dl * 2);
+                    const uint32_t up = *reinterpret_cast<const uint16_t*>(region + (r0 + 1) * 128 + ((cg ^ (2 * j2 + 1) ^ rg) << 4) + dl * 2);
+                    w[j2] = lo | (up << 16);
+                }
+                const int rr = rh * 64 + rg * 8, mg = m_base + rr;
                 if (mg + 8 <= p.M) {
-                    *reinterpret_cast<uint4*>(vrow + g * 8) = uint4{w[0], w[1], w[2], w[3]};
+                    *reinterpret_cast<uint4*>(vrow + rr) = uint4{w[0], w[1], w[2], w[3]};
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j)
-                        if (mg + j < p.M) vrow[g * 8 + j] = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
+                        if (mg + j < p.M) vrow[rr + j] = (uint16_t)(w[j >> 1] >> ((j & 1) * 16));
                 }
             }
         }
     };
     if constexpr (MODE == 0) {
         const int Nq = p.n_q * 128, Nk = p.n_kv * 128;
-        if (n_base >= Nq + Nk) {        // wave-uniform: a V block
+        const bool is_v = n_base >= Nq + Nk;                           // wave-uniform
+        const bool is_k = !is_v && n_base >= Nq, first = (n_base & 64) == 0;
+        const int d0 = (n_base & 64) + c * 8;
+        // every table piece of the wave's 16 row groups is requested BEFORE the workgroup barrier (the accumulators are dead: 128 registers):
+        // their latency runs under the wait for the tile's other waves
+        uint4 cv[16], sv[16];
+        if (!is_v) {
+            const uint16_t* cosb = reinterpret_cast<const uint16_t*>(p.rope_cos) + d0;
+            const uint16_t* sinb = reinterpret_cast<const uint16_t*>(p.rope_sin) + d0;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int m = m_base + i * 8 + lrow;
+                const long long mr = (long long)(m < p.M ? m : p.M - 1) * 128;
+                cv[i] = *reinterpret_cast<const uint4*>(cosb + mr);
+                sv[i] = *reinterpret_cast<const uint4*>(sinb + mr);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (is_v) {
             const int kvh = (n_base - Nq - Nk) >> 7;
-            store_vt(true, p.vt + (long long)(kvh * 128 + (n_base & 64) + lane) * p.vt_ld + p.pos0 + m_base);
+            store_vt(0, 8, p.vt + (long long)(kvh * 128 + (n_base & 64)) * p.vt_ld + p.pos0 + m_base);
             return;
         }
-        const bool is_k = n_base >= Nq, first = (n_base & 64) == 0;
         const char* preg = smem + (wave ^ 1) * 16384;                  // the head's other half: same rows, same slots
-        const int d0 = (n_base & 64) + c * 8;
-        const uint16_t* cosb = reinterpret_cast<const uint16_t*>(p.rope_cos) + d0;
-        const uint16_t* sinb = reinterpret_cast<const uint16_t*>(p.rope_sin) + d0;
         uint16_t* dst = is_k ? p.kcache + (long long)((n_base - Nq) >> 7) * p.kc_head_stride + (long long)p.pos0 * 128 + d0
                              : p.C + n_base + c * 8;
         const long long dld = is_k ? 128 : p.ldc;
 #pragma unroll
         for (int hf = 0; hf < 2; ++hf) {
-            uint4 cv[8], sv[8], xv[8], yv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {       // table rows first: their latency runs under the LDS reads
-                const int m = m_base + (hf * 8 + i) * 8 + lrow;
-                const long long mr = (long long)(m < p.M ? m : p.M - 1) * 128;
-                cv[i] = *reinterpret_cast<const uint4*>(cosb + mr);
-                sv[i] = *reinterpret_cast<const uint4*>(sinb + mr);
-            }
+            uint4 xv[8], yv[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
-                const int r = (hf * 8 + i) * 8 + lrow, sw = (c ^ (r & 7)) << 4;
-                xv[i] = *reinterpret_cast<const uint4*>(region + r * 128 + sw);
-                yv[i] = *reinterpret_cast<const uint4*>(preg + r * 128 + sw);
+                const int r = (hf * 8 + i) * 8 + lrow;
+                xv[i] = *reinterpret_cast<const uint4*>(region + r * 128 + slot(c, r));
+                yv[i] = *reinterpret_cast<const uint4*>(preg + r * 128 + slot(c, r));
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float x[8], y[8], cs[8], sn[8];
-                unpack8(xv[i], x); unpack8(yv[i], y); unpack8(cv[i], cs); unpack8(sv[i], sn);
+                unpack8(xv[i], x); unpack8(yv[i], y); unpack8(cv[hf * 8 + i], cs); unpack8(sv[hf * 8 + i], sn);
                 uint32_t o[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -1087,7 +1107,7 @@ __device__ __forceinline__ void epilogue32_qkv(const GemmParams& p, f32x16 (&acc
     } else {
         const int wn = wave & 3, head = n_base >> 8;
         const int tc = wn * 64 + c * 8;                                 // this lane's first column inside the head's tile
-        const bool is_qk = tc < 160, is_vl = tc >= 160 && tc < 240;
+        const bool is_qk = tc < 160;
         const int dd = tc < 80 ? tc : (tc < 160 ? tc - 80 : 0);         // column inside the q / k head (0 for the lanes that do not rotate)
         const bool first = dd < 40;
         const int ptc = is_qk ? (first ? tc + 40 : tc - 40) : tc;       // the rotate-half partner's tile column
@@ -1097,47 +1117,63 @@ __device__ __forceinline__ void epilogue32_qkv(const GemmParams& p, f32x16 (&acc
         const float* cosf_ = reinterpret_cast<const float*>(p.rope_cos) + dm;
         const float* sinf_ = reinterpret_cast<const float*>(p.rope_sin) + dm;
         uint16_t* dst = p.C + n_base - wn * 64 + tc;
-#pragma unroll
-        for (int qt = 0; qt < 4; ++qt) {
-            float4 ca[4], cb[4], sa[4], sb[4];
-            uint4 xv[4], yv[4];
+        // fp32 tables: 64 B per lane and row — a rolling window of two 4-row quarters (128 registers), the first two requested before the barrier
+        float4 tb[2][4][4];
+        auto tload = [&](int qt, float4 (&t)[4][4]) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m_base + (qt * 4 + i) * 8 + lrow;
                 const long long mr = (long long)(m < p.M ? m : p.M - 1) * 40;
-                ca[i] = *reinterpret_cast<const float4*>(cosf_ + mr); cb[i] = *reinterpret_cast<const float4*>(cosf_ + mr + 4);
-                sa[i] = *reinterpret_cast<const float4*>(sinf_ + mr); sb[i] = *reinterpret_cast<const float4*>(sinf_ + mr + 4);
+                t[i][0] = *reinterpret_cast<const float4*>(cosf_ + mr); t[i][1] = *reinterpret_cast<const float4*>(cosf_ + mr + 4);
+                t[i][2] = *reinterpret_cast<const float4*>(sinf_ + mr); t[i][3] = *reinterpret_cast<const float4*>(sinf_ + mr + 4);
             }
+        };
+        const bool rot_wave = wn < 3;                                  // wave 3 holds V and pad columns only
+        if (rot_wave) { tload(0, tb[0]); tload(1, tb[1]); }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        if (rot_wave) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = (qt * 4 + i) * 8 + lrow;
-                xv[i] = *reinterpret_cast<const uint4*>(region + r * 128 + ((c ^ (r & 7)) << 4));
-                yv[i] = *reinterpret_cast<const uint4*>(preg + r * 128 + ((pc ^ (r & 7)) << 4));
-            }
+            for (int qt = 0; qt < 4; ++qt) {
+                float4 (&t)[4][4] = tb[qt & 1];
+                uint4 xv[4], yv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float x[8], y[8], o[8];
-                unpack8(xv[i], x); unpack8(yv[i], y);
-                const float cs[8] = {ca[i].x, ca[i].y, ca[i].z, ca[i].w, cb[i].x, cb[i].y, cb[i].z, cb[i].w};
-                const float sn[8] = {sa[i].x, sa[i].y, sa[i].z, sa[i].w, sb[i].x, sb[i].y, sb[i].z, sb[i].w};
-                if (first) {        // (the explicit contraction of rope.hip's rope_vit_body)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(x[j], cs[j], -(y[j] * sn[j]));
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(x[j], cs[j], y[j] * sn[j]);
+                for (int i = 0; i < 4; ++i) {
+                    const int r = (qt * 4 + i) * 8 + lrow;
+                    xv[i] = *reinterpret_cast<const uint4*>(region + r * 128 + slot(c, r));
+                    yv[i] = *reinterpret_cast<const uint4*>(preg + r * 128 + slot(pc, r));
                 }
-                const int m = m_base + (qt * 4 + i) * 8 + lrow;
-                if (m < p.M && is_qk)
-                    *reinterpret_cast<uint4*>(dst + (long long)m * p.ldc) =
-                        uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                uint4 ov[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float x[8], y[8], o[8];
+                    unpack8(xv[i], x); unpack8(yv[i], y);
+                    const float cs[8] = {t[i][0].x, t[i][0].y, t[i][0].z, t[i][0].w, t[i][1].x, t[i][1].y, t[i][1].z, t[i][1].w};
+                    const float sn[8] = {t[i][2].x, t[i][2].y, t[i][2].z, t[i][2].w, t[i][3].x, t[i][3].y, t[i][3].z, t[i][3].w};
+                    if (first) {        // (the explicit contraction of rope.hip's rope_vit_body)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(x[j], cs[j], -(y[j] * sn[j]));
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(x[j], cs[j], y[j] * sn[j]);
+                    }
+                    ov[i] = uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (qt + 2 < 4) tload(qt + 2, tb[qt & 1]);             // the window moves on: its registers are free again
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = m_base + (qt * 4 + i) * 8 + lrow;
+                    if (m < p.M && is_qk) *reinterpret_cast<uint4*>(dst + (long long)m * p.ldc) = ov[i];
+                }
             }
         }
-        if (wn >= 2) {      // the head's V columns: tile columns 160..239 = lanes 32..63 of wave 2, lanes 0..47 of wave 3
-            const int tcl = wn * 64 + lane;
-            store_vt(tcl >= 160 && tcl < 240, p.vt + (long long)(head * 80 + (tcl - 160)) * p.vt_ld + p.pos0 + m_base);
+        if (wn >= 2) {      // the head's V columns: tile columns 160..239 = block columns 32..63 of wave 2, 0..47 of wave 3
+            uint16_t* vcol0 = p.vt + (long long)(head * 80 + wn * 64 - 160) * p.vt_ld + p.pos0 + m_base;
+            if (wn == 2) store_vt(4, 8, vcol0);
+            else store_vt(0, 6, vcol0);
         }
-        (void)is_vl;
     }
 }
 
@@ -1375,7 +1411,7 @@ static int launch_gemm_wide(GemmParams& p, int batch, hipStream_t st, bool reduc
 // ABL (A/B build only, scripts/gemm_loop_ablation.py): main-loop ablations for timing — 1 = no LDS-DMA issue inside the loop, 2 = no fragment
 // reads inside the loop, 4 = no barriers inside the loop, 8 = no vmcnt waits inside the loop, 16 = every DMA piece from K tile 0 (L2-hot), 32 = half of a wave's DMA pieces issued in its load-Y segment
 // (results valid), 64 = only the A half of the DMA pieces is issued (what a kernel that fetched W another way would leave on the LDS-DMA path).  The results of an ablated launch are garbage by construction.
-template <int EPI, bool FP8 = false, int ABL = 0>
+template <int EPI, bool FP8 = false, int ABL = 0, bool CONV = false>
 __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) {
     constexpr int BM = 256, BN = 256, ES = FP8 ? 1 : 2, BK = 128 / ES;
     using frag_t = std::conditional_t<FP8, v8i32, bf16x8>;
@@ -1405,7 +1441,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     // v_lshl_add_u64 per piece IN an operand register the MFMAs before it still read (measured, profiles/r04_gemm_loop_ablation*.json:
     // the DMA issue, not its data, cost 22-28 % of the K loop).  FP8: offsets from the matrix bases (fo1_gemm_fp8 bounds them to 4 GB).
     uint32_t src[4][2];
-    const char* At = A + (FP8 ? 0ll : (long long)m0 * p.lda * ES);
+    const char* At = A + ((FP8 || CONV) ? 0ll : (long long)m0 * p.lda * ES);
     const char* Wt = W + (FP8 ? 0ll : (long long)n0 * p.ldw * ES);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -1416,7 +1452,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
             if (g < 2) {
                 int gm = m0 + (lr >> 6) * 128 + g * 64 + (lr & 63);
                 gm = gm < p.M ? gm : p.M - 1;
-                src[g][i] = (uint32_t)(FP8 ? gm : gm - m0) * (uint32_t)(p.lda * ES) + cs;
+                if constexpr (CONV) src[g][i] = p.a_rows[gm] + cs;       // implicit convolution: the row's tap-(0, 0) address in the padded map
+                else src[g][i] = (uint32_t)(FP8 ? gm : gm - m0) * (uint32_t)(p.lda * ES) + cs;
             } else {
                 int gn = n0 + (lr >> 5) * 64 + (g - 2) * 32 + (lr & 31);
                 gn = gn < p.N ? gn : p.N - 1;
@@ -1430,7 +1467,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     auto piece = [&](int g, int i, int kt, int buf) __attribute__((always_inline)) {
         {
             const uint32_t so = g == 0 ? src[0][i] : g == 1 ? src[1][i] : g == 2 ? src[2][i] : src[3][i];
-            const char* ub = (g < 2 ? At : Wt) + (long long)((ABL & 16) ? 0 : kt0 + kt) * 128;
+            const char* ub;
+            if (CONV && g < 2) {        // K tile -> (tap row, tap column, channel block): scalar arithmetic, the lane offsets stay loop-invariant
+                const int kk = kt0 + kt, tap = kk >> p.conv_lgc, ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+                ub = At + (long long)ky * p.conv_row_bytes + (long long)kx * p.conv_cin_bytes + (long long)(kk & ((1 << p.conv_lgc) - 1)) * 128;
+            } else {
+                ub = (g < 2 ? At : Wt) + (long long)((ABL & 16) ? 0 : kt0 + kt) * 128;
+            }
             const uint32_t dst = lds0 + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;     // M0 = the piece's LDS base
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(so), "s"(ub), "s"(dst) : "memory");
         }
@@ -2399,6 +2442,57 @@ int fo1_gemm_bf16_ws(const void* A, int lda, const void* W, int ldw, const void*
     if (g_gemm_gemv && M <= 4 && !out_f32 && (size_t)(M > 2 ? 4 : M) * K * 2 <= 150 * 1024 && (act != 3 || N % 32 == 0))
         return gemv_dispatch(A, lda, W, ldw, bias, residual, ldr, C, ldc, M, N, K, act, (hipStream_t)stream, nullptr, 0.f);
     return gemm_dispatch(p, 1, (hipStream_t)stream, (float*)workspace, workspace_bytes);
+}
+
+// 3x3 convolution as an IMPLICIT GEMM on the 256 x 256 kernel (round 5, VERDICT r4 #1b; DaViT ConvEmbed modeling_davit.py:102-148, SimpleFPN
+// simple_fpn.py:141-176): C[m, :] = sum over (ky, kx, c) of Xpad[row(m) + (ky, kx)][c] * W[:, ky, kx, c] + bias — what fo1_im2col_bf16 +
+// fo1_gemm_bf16 compute (same kernel, same K order: bit-identical) without the [M, 9 Cin] column matrix (2.2 GB per launch at the FPN's
+// finest level).  Xpad: token-major map zero-padded by one pixel per side, row pitch Wp pixels (written there by fo1_layernorm_rows_bf16);
+// a_rows [M] uint32: byte offset in Xpad of output pixel m's top-left tap (host-built: any stride, any batch of images sharing Wp);
+// W [N][3][3][Cin] bf16, Cin = 64 * 2^j.  act 0 / 1 (GELU).
+int fo1_conv3x3_gemm_bf16(const void* Xpad, const uint32_t* a_rows, int Wp, int Cin, const void* W, int ldw, const void* bias, void* C, int ldc, int M,
+                          int N, int act, void* stream) {
+    using namespace fo1;
+    if (M == 0) return FO1_OK;
+    FO1_CHECK_ARG(Xpad && a_rows && W && C, "conv3x3_gemm: NULL operand");
+    FO1_CHECK_ARG(Cin >= 64 && (Cin & (Cin - 1)) == 0 && Wp >= 3, "conv3x3_gemm: Cin=%d must be a power of two >= 64 (Wp=%d)", Cin, Wp);
+    FO1_CHECK_ARG(M > 0 && N > 0 && N % 8 == 0 && ldw % 8 == 0 && ldw >= 9 * Cin && ldc % 8 == 0 && ldc >= N, "conv3x3_gemm: M=%d N=%d ldw=%d ldc=%d", M, N, ldw, ldc);
+    FO1_CHECK_ARG(((uintptr_t)Xpad & 15) == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)C & 15) == 0 && (bias == nullptr || ((uintptr_t)bias & 7) == 0),
+                  "conv3x3_gemm: operands must be 16-byte aligned");
+    FO1_CHECK_ARG(act == 0 || act == 1, "conv3x3_gemm: act=%d (0 none, 1 GELU)", act);
+    GemmParams p;
+    p.A = (const uint16_t*)Xpad; p.W = (const uint16_t*)W; p.bias = (const uint16_t*)bias; p.res = nullptr;
+    p.C = (uint16_t*)C; p.C32 = nullptr;
+    p.M = M; p.N = N; p.K = 9 * Cin; p.lda = Cin; p.ldw = ldw; p.ldc = ldc; p.ldr = 0; p.act = act;
+    p.sA = p.sW = p.sC = p.sR = 0;
+    p.scale_m = p.scale_n = nullptr;
+    p.a_rows = a_rows; p.conv_row_bytes = (uint32_t)Wp * Cin * 2u; p.conv_cin_bytes = (uint32_t)Cin * 2u;
+    int lg = 0;
+    while ((64 << lg) < Cin) ++lg;
+    p.conv_lgc = lg;
+    p.tiles_m = cdiv(M, 256);
+    p.tiles_n = cdiv(N, 256);
+    if (g_gemm_group_m > 0) p.gm = g_gemm_group_m;
+    p.splits = 1; p.kper = p.K / 64 + 1; p.part = nullptr; p.debug = 0; p.coal = 1; p.stages = 2;
+    const dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
+    constexpr int smem = 2 * 4 * 16384;
+    static bool attr = false;
+    if (!attr) {
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<0, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_p4_kernel<1, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        attr = true;
+    }
+    const double flops = 2.0 * M * (double)N * p.K;
+    char pname[56];
+    const char* name = "gemm_bt_p4<256,256>";
+    if (profile_enabled() && g_gemm_profile_shapes) {
+        snprintf(pname, sizeof pname, "gemm %dx%dx%d t256x256 conv", M, N, p.K);
+        name = pname;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (act == 0) FO1_LAUNCH(name, flops, (gemm_bt_p4_kernel<0, false, 0, true>), grid, dim3(512), smem, st, p);
+    else FO1_LAUNCH(name, flops, (gemm_bt_p4_kernel<1, false, 0, true>), grid, dim3(512), smem, st, p);
+    return FO1_OK;
 }
 
 // 1 when fo1_gemm_bf16 runs an [M, K] x [N, K]^T product (bf16 out, K % 64 == 0, aligned operands) on the 256 x 256 two-phase kernel — the

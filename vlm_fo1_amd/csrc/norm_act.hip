@@ -46,7 +46,7 @@ __device__ __forceinline__ float row_sum(float v) {
 template <int MODE, int NPER, int LPR>
 __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict__ x, int ldx, const uint16_t* __restrict__ w,
                                                       const uint16_t* __restrict__ b, uint16_t* __restrict__ y, int ldy,
-                                                      int M, int D, float eps) {
+                                                      int M, int D, float eps, const int* __restrict__ y_rows) {
     constexpr int RPW = 64 / LPR;
     const int lane = threadIdx.x & 63, sub = lane & (LPR - 1);
     const int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
@@ -98,7 +98,8 @@ __global__ __launch_bounds__(256) void rownorm_kernel(const uint16_t* __restrict
         q = row_sum<LPR>(q);
         rstd = rsqrtf(q / (float)D + eps);
     }
-    uint16_t* yr = y + (size_t)row * ldy;
+    // y_rows (fo1_layernorm_rows_bf16): row m lands at row y_rows[m] of y — the zero-padded map an implicit-GEMM convolution reads
+    uint16_t* yr = y + (size_t)(y_rows ? y_rows[row_ok ? row : M - 1] : row) * ldy;
 #pragma unroll
     for (int i = 0; i < NPER; ++i) {
         float f[8], wf[8], o[8];
@@ -212,12 +213,12 @@ __global__ __launch_bounds__(256) void splitk_swiglu_kernel(const float* __restr
 
 template <int MODE>
 static int launch_rownorm(const char* name, const void* x, int ldx, const void* w, const void* b, void* y, int ldy, int M, int D, float eps,
-                          hipStream_t st) {
+                          hipStream_t st, const int* y_rows = nullptr) {
     const int nchunk = D >> 3;
     const double bytes = (double)M * D * 4.0;
 #define FO1_ROWNORM(NPER, LPR)                                                                                                          \
     FO1_LAUNCH(name, bytes, (rownorm_kernel<MODE, NPER, LPR>), dim3(cdiv(M, 4 * (64 / LPR))), dim3(256), 0, st, (const uint16_t*)x, ldx, \
-               (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)y, ldy, M, D, eps)
+               (const uint16_t*)w, (const uint16_t*)b, (uint16_t*)y, ldy, M, D, eps, y_rows)
     if (nchunk <= 32) FO1_ROWNORM(1, 32);
     else if (nchunk <= 64) FO1_ROWNORM(1, 64);
     else if (nchunk <= 128) FO1_ROWNORM(2, 64);
@@ -474,6 +475,19 @@ int fo1_layernorm_bf16(const void* x, int ldx, const void* weight, const void* b
     FO1_CHECK_ARG(bias != nullptr, "layernorm: NULL bias");
     if (M == 0) return FO1_OK;
     return launch_rownorm<1>("layernorm", x, ldx, weight, bias, y, ldy, M, D, eps, (hipStream_t)stream);
+}
+
+// LayerNorm whose output row m is written to row y_rows[m] of y (int32 [M]): the producer side of fo1_conv3x3_gemm_bf16 — the normalised map
+// goes straight into the zero-padded layout the implicit-GEMM convolution reads (borders: the caller zeroes y once).  Same arithmetic as
+// fo1_layernorm_bf16, bit for bit.
+int fo1_layernorm_rows_bf16(const void* x, int ldx, const void* weight, const void* bias, void* y, int ldy, const int32_t* y_rows, int M, int D,
+                            float eps, void* stream) {
+    using namespace fo1;
+    int rc = rownorm_check(x, weight, y, M, D, ldx, ldy);
+    if (rc) return rc;
+    FO1_CHECK_ARG(bias != nullptr && y_rows != nullptr, "layernorm_rows: NULL bias / row map");
+    if (M == 0) return FO1_OK;
+    return launch_rownorm<1>("layernorm", x, ldx, weight, bias, y, ldy, M, D, eps, (hipStream_t)stream, (const int*)y_rows);
 }
 
 int fo1_swiglu_bf16(const void* gate_up, int ldgu, void* out, int ldo, int M, int F, void* stream) {
