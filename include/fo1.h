@@ -189,6 +189,9 @@ int fo1_rmsnorm_bf16(const void* x, int ldx, const void* weight, void* y, int ld
                      float eps, void* stream);
 int fo1_layernorm_bf16(const void* x, int ldx, const void* weight, const void* bias, void* y, int ldy,
                        int M, int D, float eps, void* stream);
+/* fo1_layernorm_bf16 with output row m written to row y_rows[m] of y (int32 [M]): the producer side of fo1_conv3x3_gemm_bf16's padded map. */
+int fo1_layernorm_rows_bf16(const void* x, int ldx, const void* weight, const void* bias, void* y, int ldy, const int32_t* y_rows, int M, int D,
+                            float eps, void* stream);
 int fo1_swiglu_bf16(const void* gate_up, int ldgu, void* out, int ldo, int M, int F, void* stream);
 int fo1_bias_act_bf16(const void* x, int ldx, const void* bias, void* y, int ldy, int M, int D, int act,
                       void* stream);
@@ -261,6 +264,14 @@ int fo1_splitk_residual_rmsnorm_bf16(const float* part, int splits, int M, int N
  *     pairs then never straddle two output tiles); cos / sin fp32 [M][40]; rotated q, k -> C in that layout (attention: head stride 256, k at
  *     column 80 of a head); v -> vt[(head * 80 + d) * vt_ld + pos0 + m].  kcache unused.
  * K % 64 == 0, N % 256 == 0, pos0 % 8 == 0, vt_ld % 8 == 0, 16-byte aligned operands; any M (built for M >= 1024: one 256 x 256 tile per workgroup). */
+/* 3x3 convolution as an IMPLICIT GEMM (round 5; DaViT ConvEmbed modeling_davit.py:102-148, SimpleFPN simple_fpn.py:141-176): what fo1_im2col_bf16 +
+ * fo1_gemm_bf16 compute — same 256 x 256 kernel, same K order (ky, kx, channel): bit-identical — without the [M, 9 Cin] column matrix.
+ *   Xpad    token-major bf16 map(s), zero-padded by one pixel per side, row pitch Wp pixels of Cin channels (fo1_layernorm_rows_bf16 writes the
+ *           normalised map straight into this layout; the caller zeroes the buffer once)
+ *   a_rows  uint32 [M]: byte offset in Xpad of output pixel m's top-left tap — built by the host for any stride / batch of images sharing Wp
+ *   W       [N][3][3][Cin] bf16 (row stride ldw >= 9 Cin), Cin = 64 * 2^j;  act 0 / 1 (GELU);  C [M, N] bf16. */
+int fo1_conv3x3_gemm_bf16(const void* Xpad, const uint32_t* a_rows, int Wp, int Cin, const void* W, int ldw, const void* bias, void* C, int ldc, int M,
+                          int N, int act, void* stream);
 /* 1 when fo1_gemm_bf16 runs an [M, K] x [N, K]^T bf16 product (K % 64 == 0, aligned operands) on the 256 x 256 kernel: where a caller may swap
  * fo1_gemm_bf16 + fo1_qkv_post_* for fo1_qkv_proj_rope_bf16 without changing a bit. */
 int fo1_gemm_takes_big_tile(int M, int N, int K);

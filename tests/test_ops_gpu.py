@@ -805,6 +805,38 @@ def test_qkv_proj_rope_vit_equals_gemm_plus_qkv_post(ab_library, M):
                        ops.attention(out, out[:, D:], vt, items, H, H, D, D ** -0.5, False, qk_head_stride=256))
 
 
+@pytest.mark.parametrize("cfg", [
+    dict(name="fpn_s1", B=2, H=40, W=52, Cin=512, Cout=512, stride=1, act=0, bias=False),
+    dict(name="davit_s2", B=3, H=61, W=83, Cin=256, Cout=512, stride=2, act=0, bias=True),
+    dict(name="gelu_1024", B=1, H=48, W=48, Cin=1024, Cout=256, stride=2, act=1, bias=True),
+])
+def test_conv3x3_implicit_gemm_equals_im2col_gemm(ab_library, cfg):
+    """fo1_layernorm_rows_bf16 + fo1_conv3x3_gemm_bf16 (LayerNorm written straight into the zero-padded map, 3x3 convolution as an implicit GEMM
+    on the 256 x 256 kernel: the nine taps are nine K-tile address offsets, no column matrix) against layernorm + fo1_im2col_bf16 + fo1_gemm_bf16
+    pinned to the same kernel: bit for bit — odd sizes (stride-2 borders), several images (no leak across image borders), bias / GELU."""
+    from vlm_fo1_amd import lib as L, ops
+    B, H, W, Cin, Cout, s = cfg["B"], cfg["H"], cfg["W"], cfg["Cin"], cfg["Cout"], cfg["stride"]
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(B * H * W, Cin, generator=g).to(BF).cuda()
+    nw, nb = (1 + 0.1 * torch.randn(Cin, generator=g)).to(BF).cuda(), (0.1 * torch.randn(Cin, generator=g)).to(BF).cuda()
+    w = (torch.randn(Cout, 9 * Cin, generator=g) * 0.02).to(BF).cuda()
+    b = (torch.randn(Cout, generator=g) * 0.2).to(BF).cuda() if cfg["bias"] else None
+    L.load().fo1_gemm_set_variant(0, 5)
+    try:
+        y = ops.layernorm(x, nw, nb, 1e-6)
+        col, Ho, Wo = ops.im2col(y, H, W, 3, 3, s, 1, batch=B)
+        ref = ops.gemm(col, w, b, act=cfg["act"])
+        pl = ops.conv3x3_plan(((H, W),) * B, s, Cin, "cuda")
+        assert pl.out_hw == [(Ho, Wo)] * B and pl.M_out == B * Ho * Wo
+        yp = ops.layernorm_rows(x, nw, nb, 1e-6, torch.zeros(pl.pad_rows, Cin, dtype=BF, device="cuda"), pl.rowmap)
+        got = ops.conv3x3_gemm(yp, pl, w, b, act=cfg["act"])
+        torch.cuda.synchronize()
+    finally:
+        L.load().fo1_gemm_set_variant(0, 0)
+    assert torch.equal(yp[pl.rowmap.long()], y), "layernorm_rows: the interior of the padded map"
+    assert got.shape == ref.shape and torch.equal(got, ref), f"{cfg['name']}: max diff {(got.float() - ref.float()).abs().max().item():.4g}"
+
+
 def test_mfma_clock_probe_reports_a_plausible_clock(ab_library):
     """fo1_mfma_clock_probe (csrc/probe.hip; an instrument of include/fo1_ab.h since round 5 — bench.py loads the test / bench build for it after the timed region): cycles / wall ticks of a register-resident MFMA loop = a clock inside the part's
     DVFS range, 32 cycles per 32x32x16 bf16 MFMA per SIMD (two waves share one), and zero operands never clock lower than random ones."""

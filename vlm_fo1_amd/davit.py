@@ -193,10 +193,19 @@ class DaViT:
         for i, C in enumerate(cfg["dims"]):
             cv = self.convs[i]
             k, s, p = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
-            if i > 0 and cfg["patch_prenorm"][i]:
-                x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
-            col, H, W = ops.im2col(x, H, W, k, k, s, p, ld=cv["Kp"], batch=B)
-            x = ops.gemm(col, cv["w"], cv["b"])
+            Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            if i > 0 and cfg["patch_prenorm"][i] and cv["Kp"] == k * k * x.shape[1] and ops.conv3x3_implicit_ok(B * Ho * Wo, C, x.shape[1], k, p):
+                # pre-norm ConvEmbed (modeling_davit.py:102-148) as an implicit GEMM: the LayerNorm writes the zero-padded map, the 256 x 256 GEMM
+                # gathers its 9 taps from it — no [M, 9 Cin] column matrix (same bits as layernorm + im2col + gemm)
+                pl = ops.conv3x3_plan(((H, W),) * B, s, x.shape[1], self.dev)
+                xp = ops.layernorm_rows(x, cv["nw"], cv["nb"], 1e-5, torch.zeros(pl.pad_rows, x.shape[1], dtype=torch.bfloat16, device=self.dev), pl.rowmap)
+                x = ops.conv3x3_gemm(xp, pl, cv["w"], cv["b"])
+                H, W = Ho, Wo
+            else:
+                if i > 0 and cfg["patch_prenorm"][i]:
+                    x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
+                col, H, W = ops.im2col(x, H, W, k, k, s, p, ld=cv["Kp"], batch=B)
+                x = ops.gemm(col, cv["w"], cv["b"])
             if i == 0 or not cfg["patch_prenorm"][i]:
                 x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
             for blk in self.blocks[i]:

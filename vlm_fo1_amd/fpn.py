@@ -51,9 +51,17 @@ class SimpleFPN:
 
     def _head(self, x, H, W, h, B=1):
         y = ops.gemm(x, h["w1"])
-        y = ops.layernorm(y, h["n1"][0], h["n1"][1], 1e-6)
-        col, _, _ = ops.im2col(y, H, W, 3, 3, 1, 1, batch=B)
-        y = ops.gemm(col, h["w3"])
+        C = y.shape[1]
+        if ops.conv3x3_implicit_ok(B * H * W, h["w3"].shape[0], C, 3, 1):
+            # the 3x3 output convolution (simple_fpn.py:141-176) as an implicit GEMM: the channel LayerNorm writes the zero-padded map, the GEMM
+            # gathers its taps from it (no im2col matrix: 2.2 GB per launch at the finest level); same bits as layernorm + im2col + gemm
+            pl = ops.conv3x3_plan(((H, W),) * B, 1, C, y.device)
+            yp = ops.layernorm_rows(y, h["n1"][0], h["n1"][1], 1e-6, torch.zeros(pl.pad_rows, C, dtype=torch.bfloat16, device=y.device), pl.rowmap)
+            y = ops.conv3x3_gemm(yp, pl, h["w3"])
+        else:
+            y = ops.layernorm(y, h["n1"][0], h["n1"][1], 1e-6)
+            col, _, _ = ops.im2col(y, H, W, 3, 3, 1, 1, batch=B)
+            y = ops.gemm(col, h["w3"])
         return ops.layernorm(y, h["n3"][0], h["n3"][1], 1e-6)
 
     # ---- ragged batches: maps of different grids packed row-wise ----------------------------------------------------------------

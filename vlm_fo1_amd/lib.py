@@ -220,6 +220,8 @@ SIGNATURES = {
                                    c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                    c_float, c_int, c_void_p, ctypes.c_double, c_void_p]),
     "fo1_gemm_takes_big_tile": (c_int, [c_int, c_int, c_int]),
+    "fo1_conv3x3_gemm_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_layernorm_rows_bf16": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_float, c_void_p]),
     "fo1_qkv_proj_rope_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p,
                                        c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_longlong, c_void_p]),
     "fo1_attention_prefix_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p,

@@ -310,6 +310,78 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: fl
     return out
 
 
+def layernorm_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float, out: torch.Tensor, out_rows: torch.Tensor) -> torch.Tensor:
+    """LayerNorm whose output row m goes to row out_rows[m] (int32) of `out` — the padded map of an implicit-GEMM convolution
+    (fo1_layernorm_rows_bf16; same arithmetic as layernorm)."""
+    _chk(x, "x"); _chk(weight, "weight"); _chk(bias, "bias"); _chk(out, "out")
+    px, ldx, M, D = _rows(x, "x")
+    po, ldy, _, _ = _rows(out, "out")
+    assert out_rows.dtype == torch.int32 and out_rows.is_contiguous() and out_rows.numel() == M and out_rows.device == x.device
+    _L.check(_L.load().fo1_layernorm_rows_bf16(px, ldx, weight.data_ptr(), bias.data_ptr(), po, ldy, out_rows.data_ptr(), M, D, float(eps), _stream()),
+             "fo1_layernorm_rows_bf16")
+    return out
+
+
+class Conv3x3Plan:
+    """Index tables of a 3x3 / pad 1 convolution run as an implicit GEMM (fo1_conv3x3_gemm_bf16) over images packed row-wise: the zero-padded
+    layout (one pixel per side, common row pitch Wp = widest image + 2), `rowmap` int32 [sum H W] = padded row of every input pixel (where
+    layernorm_rows writes it), `a_rows` uint32 [sum Ho Wo] = byte offset of every output pixel's top-left tap.  Host-built once per
+    (sizes, stride, channels) and cached (index bookkeeping belongs on the host)."""
+
+    def __init__(self, sizes, stride: int, cin: int, device):
+        import numpy as np
+        Wp = max(w for _, w in sizes) + 2
+        rowmap, a_rows, out_hw = [], [], []
+        pb = 0
+        for (H, W) in sizes:
+            Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+            yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing="ij")
+            rowmap.append((pb + (yy + 1) * Wp + (xx + 1)).reshape(-1))
+            oy, ox = np.meshgrid(np.arange(Ho), np.arange(Wo), indexing="ij")
+            a_rows.append(((pb + oy * stride * Wp + ox * stride).astype(np.int64) * (cin * 2)).reshape(-1))
+            out_hw.append((Ho, Wo))
+            pb += (H + 2) * Wp
+        ar = np.concatenate(a_rows)
+        assert pb * cin * 2 < 2 ** 32, "padded map exceeds the 32-bit byte offsets of the implicit-GEMM convolution"
+        self.Wp, self.cin, self.pad_rows, self.out_hw = Wp, cin, pb, out_hw
+        self.M_in, self.M_out = sum(h * w for h, w in sizes), int(ar.shape[0])
+        self.rowmap = torch.from_numpy(np.concatenate(rowmap).astype(np.int32)).to(device)
+        self.a_rows = torch.from_numpy(ar.astype(np.uint32).view(np.int32)).to(device)      # (uint32 bit patterns in an int32 tensor)
+
+
+_conv_plans: dict = {}
+
+
+def conv3x3_plan(sizes, stride: int, cin: int, device) -> Conv3x3Plan:
+    key = (tuple((int(h), int(w)) for h, w in sizes), int(stride), int(cin), str(device))
+    pl = _conv_plans.get(key)
+    if pl is None:
+        if len(_conv_plans) >= 64:
+            _conv_plans.pop(next(iter(_conv_plans)))
+        pl = _conv_plans[key] = Conv3x3Plan(key[0], stride, cin, device)
+    return pl
+
+
+def conv3x3_implicit_ok(M_out: int, cout: int, cin: int, k: int, pad: int) -> bool:
+    """The implicit-GEMM form (no im2col matrix) applies to 3x3 / pad 1 convolutions over >= 64 power-of-two channels whose GEMM runs on the
+    256 x 256 kernel anyway (then both forms give the same bits).  FO1_CONV_IMPLICIT=0 turns it off (A/B)."""
+    return (os.environ.get("FO1_CONV_IMPLICIT", "1") != "0" and k == 3 and pad == 1 and cin >= 64 and (cin & (cin - 1)) == 0 and cout % 8 == 0
+            and bool(_L.load().fo1_gemm_takes_big_tile(int(M_out), int(cout), 9 * int(cin))))
+
+
+def conv3x3_gemm(xpad: torch.Tensor, plan: Conv3x3Plan, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
+    """3x3 convolution of the zero-padded map `xpad` [plan.pad_rows, Cin] (layernorm_rows wrote it) as an implicit GEMM: -> [plan.M_out, Cout]."""
+    _chk(xpad, "xpad"); _chk(w, "w")
+    assert xpad.is_contiguous() and xpad.shape == (plan.pad_rows, plan.cin)
+    pw, ldw, N, K = _rows(w, "w")
+    assert K == 9 * plan.cin
+    out = torch.empty(plan.M_out, N, dtype=torch.bfloat16, device=xpad.device)
+    rc = _L.load().fo1_conv3x3_gemm_bf16(xpad.data_ptr(), plan.a_rows.data_ptr(), plan.Wp, plan.cin, pw, ldw, bias.data_ptr() if bias is not None else None,
+                                         out.data_ptr(), N, plan.M_out, N, int(act), _stream())
+    _L.check(rc, "fo1_conv3x3_gemm_bf16")
+    return out
+
+
 def interleave_gate_up(gate: torch.Tensor, up: torch.Tensor) -> torch.Tensor:
     """[F, ...] gate and up -> [2F, ...] rows interleaved in 16-row groups [gate 16 | up 16 | ...], the weight/bias
     layout of the fused SwiGLU GEMM epilogue (act = ACT_SWIGLU16).  F must be a multiple of 16."""
