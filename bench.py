@@ -483,6 +483,8 @@ def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, 
                     dist.barrier()
                 el = time.perf_counter() - t0
                 mine = {k: v for k, v in SE.LAST.items() if k != "merged"}
+                w0 = pipe.eng.llm.layers[0]
+                mine["weights_checksum"] = round(float(w0["wqkv"].float().sum() + pipe.eng.llm.lm_head[:64].float().sum() + pipe.eng.vit.blocks[0]["wqkv"].float().sum()), 4)
                 merged = SE.LAST.get("merged")
                 stats = [None] * world
                 if world > 1:
@@ -507,7 +509,8 @@ def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, 
                             first.append(k)
                         E.eval_coco(name, sub, data[1], data[2], out_dir + "_sample2", device=str(dev))      # and whether ONE rank repeats itself
                         again = dict(SE.LAST.get("merged") or [])
-                        same_detail = dict(items_differing=len(diff), first_differing_token_positions=sorted(first)[:16],
+                        same_detail = dict(items_differing=len(diff), differing_item_indices=sorted(diff)[:64], first_differing_token_positions=sorted(first)[:16],
+                                           per_rank_weights_checksum=[st.get("weights_checksum") for st in stats],
                                            one_rank_repeats_itself=all(again.get(i) == alone[i] for i in alone))
                     else:
                         same_detail = None

@@ -34,7 +34,7 @@ int fo1_gemm_set_variant(int staging, int tile);
 int fo1_gemm_set_splitk(int splits);
 int fo1_gemm_set_gemv(int on);   /* M <= 4 goes to the weight-streaming GEMV kernel (default on) */
 /* 256x256 kernels: tile rows per group of the XCD-grouped tile order (an XCD's ~32 concurrent tiles = rows x 32 / rows tile columns);
- * 0 = the product rule (8).  Bit-identical results for every value: a permutation of the output tiles. */
+ * 0 = the product rule (2; 8 until round 5).  Bit-identical results for every value: a permutation of the output tiles. */
 int fo1_gemm_set_group_m(int rows);
 /* 256x256 kernel, bit field: bit 0 = two fat phases per K tile with the DMA issued between MFMAs (0 = four phases); bit 1 = fragment-shaped
  * epilogue stores (0 = LDS-staged coalesced); bit 2 = persistent tile loop (bit-identical, measured 2-5 % slower); bit 3 = non-temporal

@@ -55,8 +55,10 @@ struct GemmParams {
     // ring kernels with BN = 128 (fo1_gemm_bf16_wtiled): W is a copy pre-tiled as [N / 128][K / 64][128 rows][64] — a K tile of a column tile is ONE
     // contiguous 16 KB block (the decode pool's weight streams: profiles/r04_hbm_stream_patterns.jsonl)
     int w_tiled = 0;
-    // 256 x 256 kernels: tile rows per group of the XCD-grouped tile order (tile_coords_grouped_id); 8 = the measured default
-    int gm = 8;
+    // 256 x 256 kernels: tile rows per group of the XCD-grouped tile order (tile_coords_grouped_id).  2 (round 5; 8 before): an XCD's ~32
+    // concurrent tiles are then 2 tile rows x 16 tile columns — measured in the 25-image pass with two passes in flight
+    // (profiles/r05_gemm_group_m_ab.json): 147.7 images/s at 8, 149.8 at 4, 150.1 at 2; the stand-alone products move by 0-4 %
+    int gm = 2;
     // fused q/k/v epilogue (fo1_qkv_proj_rope_bf16, EPI 6 / 7): rotary tables (LLM: bf16 cos / sin [M][128]; ViT: fp32 [M][40]), the K cache
     // (LLM), the V^T destination, head counts
     const void* rope_cos = nullptr;
@@ -657,8 +659,8 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
         asm volatile("" ::: "memory");        \
     } while (0)
 
-// grouped tile order inside each XCD's contiguous run: 8 tile rows x consecutive tile columns, so the ~32 tiles an XCD
-// runs at once share 8 A panels and 4 W panels in its L2
+// grouped tile order inside each XCD's contiguous run: p.gm tile rows x consecutive tile columns — the ~32 tiles an XCD runs at once
+// share p.gm A panels and 32 / p.gm W panels in its L2 (p.gm = 2 since round 5, see GemmParams)
 __device__ __forceinline__ void tile_coords_grouped_id(const GemmParams& p, int bid, int& tm, int& tn) {
     const int nwg = p.tiles_m * p.tiles_n;
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
