@@ -126,6 +126,8 @@ def test_bench_two_ranks_control_flow(tmp_path):
     # the `scale` block (round 5): evaluation/eval_coco.py's loop through sharded_eval.run_sharded ACROSS the two ranks — LPT shard, per-rank
     # prefetch + decode pool, ONE all_gather at the reducer — and the merged ids of a sample equal to what one rank computes alone
     sc = out["scale"]
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    json.dump(sc, open(os.path.join(root, "gpurun_out", "scale_block_two_ranks_one_device.json"), "w"), indent=1)
     assert sc["world_size"] == 2 and sc["dist_world_size"] == 2 and sc["backend"] == "gloo" and sc["one_device_gloo_test_mode"] is True
     assert sc["items"] == 128 and sc["per_rank_items"] == [64, 64] and len(sc["per_rank_shard_seconds"]) == 2 and len(sc["gather_ms"]) == 2
     assert sc["images_per_sec"] > 0 and sc["predictions_file_written"] and sc["host_threads_for_this_run"] == 2 * sc["host_threads_per_gpu"]

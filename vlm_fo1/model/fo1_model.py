@@ -265,7 +265,7 @@ class FO1ForCausalLM:
         if plan is None:
             return _Ready(self.generate_many(requests_kwargs))
         reqs, max_new, stop = plan
-        handles = [eng.submit_batch(reqs[i:i + eng.PREFILL_MAX], max_new, stop, self.use_graph) for i in range(0, len(reqs), eng.PREFILL_MAX)]
+        handles = [eng.submit_batch(grp, max_new, stop, self.use_graph) for grp in eng.split_passes(reqs)]      # <= 32 requests and <= 64k ViT rows per pass
         model = self
 
         class _Pending:

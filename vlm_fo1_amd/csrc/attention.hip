@@ -446,10 +446,6 @@ __global__ __launch_bounds__(512, 2) void attn_fwd32_kernel(const AttnParams p) 
             const uint4 v = *reinterpret_cast<const uint4*>(qp + kc * 16);
             qf[kc] = *reinterpret_cast<const bf16x8*>(&v);
         }
-        // the fragments are complete HERE: left pending, hipcc's waitcnt pass puts `s_waitcnt vmcnt(7) .. vmcnt(0)` in front of the QK^T MFMAs
-        // inside the tile loop (the first trip needs them), and every trip then drains the tile prefetch it has just issued
-#pragma unroll
-        for (int kc = 0; kc < NKC; ++kc) asm volatile("" : "+v"(qf[kc]));
     }
     f32x16 o[NDB];
 #pragma unroll
@@ -634,8 +630,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd32_kernel(const AttnParams p) 
         if (k >= hi_ && in) { k = it.kv_start; hi_ = own_hi; in = false; }
     };
     int k1 = k0, khi1 = khi; bool in21 = in2;
+    if (k0 < khi) gload(k0, khi);               // the first tile's loads go out right behind the Q loads: one round trip, not two
+    // the Q fragments are complete HERE (the empty asm uses them; in-order returns: it waits for them, not for the newer tile loads): left
+    // pending, hipcc's waitcnt pass puts `s_waitcnt vmcnt(7) .. vmcnt(0)` in front of the QK^T MFMAs inside the tile loop (the first trip
+    // needs them), and every trip then drains the tile prefetch it has just issued
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) asm volatile("" : "+v"(qf[kc]));
     if (k0 < khi) {
-        gload(k0, khi);
         advance(k1, khi1, in21);
         swrite(0, k0, khi);
         if (k1 < khi1) gload(k1, khi1);

@@ -365,6 +365,25 @@ class FO1Engine:
                         next_tokens=toks, region_ranges=ranges, row0=bp.row0, _keep=keep)
 
     PREFILL_MAX = 32       # requests per packed prefill pass of generate_batch
+    PREFILL_ROWS = 65536   # ... and ViT patch rows per pass: 32 COCO-sized images are 50k rows; a group of the datasets' largest images (32 x 10 800
+                           # patches: CountBench / Pixmo through evaluation/eval_countbench.py) would otherwise be ONE pass whose SimpleFPN scratch
+                           # alone is 44 GB (round 5: the driver-level CountBench run hit it)
+
+    def split_passes(self, requests: Sequence[dict]) -> List[List[dict]]:
+        """Consecutive requests -> packed prefill passes of <= PREFILL_MAX requests and <= PREFILL_ROWS ViT patch rows (a single request
+        larger than the row budget is its own pass).  Order is kept: the caller's results stay in request order."""
+        out, cur, rows = [], [], 0
+        for r in requests:
+            n = int(r["grid"][0]) * int(r["grid"][1]) if r.get("image_id") is None or not any(q.get("image_id") == r["image_id"] for q in cur) else 0
+            if cur and (len(cur) >= self.PREFILL_MAX or rows + n > self.PREFILL_ROWS):
+                out.append(cur)
+                cur, rows = [], 0
+                n = int(r["grid"][0]) * int(r["grid"][1])
+            cur.append(r)
+            rows += n
+        if cur:
+            out.append(cur)
+        return out
     DECODE_CONCURRENT = True   # decode groups of one pass advance together on their own streams (False: one after the other; A/B)
     DECODE_GROUPS = 1      # minimum number of decode groups when a pass has more sequences than one group holds
     DECODE_MAX_GROUP = 32  # sequences per decode group (<= BatchDecoder.MAX_BATCH); 16 = round 2's one-MFMA-column-group decode (A/B)
@@ -497,13 +516,11 @@ class FO1Engine:
         out: List[List[int]] = []
         if getattr(self, "_pool_svc", None) is not None:
             # decode pool: every pass's sequences join the shared pool; this call's later passes prefill while its earlier ones decode
-            handles = [self.submit_batch(requests[i:i + self.PREFILL_MAX], max_new_tokens, stop_ids, use_graph)
-                       for i in range(0, len(requests), self.PREFILL_MAX)]
+            handles = [self.submit_batch(grp, max_new_tokens, stop_ids, use_graph) for grp in self.split_passes(requests)]
             for h in handles:
                 out += h.result()
             return out
-        for i in range(0, len(requests), self.PREFILL_MAX):
-            grp = requests[i:i + self.PREFILL_MAX]
+        for grp in self.split_passes(requests):
             self.prefill_batch(grp, use_graph=use_graph)          # ONE packed pass for the whole group (its GEMMs see every image's rows)
             hp = self._last_batch
             first = self._last_next_tokens
