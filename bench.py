@@ -466,8 +466,10 @@ def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, 
         E.load_pretrained_model = lambda model_id, device="cuda": (tok, model, (primary, aux))
         env = dict(FO1_BATCH=str(batch), FO1_INFLIGHT=str(inflight), FO1_DECODE_POOL=str(pool_slots), FO1_MAX_NEW_TOKENS=str(K),
                    FO1_PREFETCH_THREADS=str(prefetch_threads))
-        saved = {k: os.environ.get(k) for k in list(env) + ["RANK", "WORLD_SIZE"]}
+        saved = {k: os.environ.get(k) for k in list(env) + ["RANK", "WORLD_SIZE", "LOCAL_RANK"]}
         os.environ.update(env)
+        if one_dev:      # the 1-GPU test mode: the eval driver picks cuda:$LOCAL_RANK itself, and every rank shares device 0
+            os.environ["LOCAL_RANK"] = "0"
         name = "synthetic/VLM-FO1_Qwen2.5-VL-3B-synthetic"
         out_dir = os.path.join(root, f"out_rank{rank}")
         try:
@@ -535,6 +537,7 @@ def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, 
                     per_rank_items=[st["shard_items"] for st in stats],
                     gather_ms=[round(st["gather_ms"], 2) for st in stats],
                     gather_record_bytes_per_rank=stats[0].get("gather_record_bytes_per_rank"),
+                    items_failed=sum(1 for _, t in (merged or []) if t is None),
                     sample_items=sample, sample_ids_equal_to_one_rank_alone=same, sample_difference=same_detail,
                     predictions_file_written=os.path.exists(os.path.join(out_dir, name.split("/")[-1], "eval_predictions.json")),
                     host_threads_per_gpu=threads, host_threads_for_this_run=threads * world,

@@ -408,6 +408,8 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
  *                                  2 fused QKV (bias -> bf16 -> mRoPE -> q rows out, K row + V^T column appended at state.pos)
  *   fo1_attention_decode_batch_bf16  split-KV attention of B one-token queries against their slots
  *   fo1_decode_argmax_accept       greedy pick per logits row + on-device accept: record id, stop check, advance state,
+ *                                  (n_stop == -1: PER-SEQUENCE stop sets — stop_ids is a table int32 [sets][17] = {count, ids[16]} and state[b][6] the
+ *                                  row of sequence b: a decode pool mixing requests with different stop rules, round 5)
  *                                  next step's embedding-gather plan
  *   fo1_kv_relocate                packed prefill rows -> per-sequence decode slots, all layers in one launch
  * ---------------------------------------------------------------------- */

@@ -290,7 +290,38 @@ def test_pool_stop_rule_budget_and_slot_reuse_mid_flight(product_library):
     assert [got[b] for b in (3, 4, 5)] == full[3:] and [got[10], got[11]] == full[:2]
 
 
-def test_pool_service_from_replica_threads_equals_direct_pool_runs(product_library):
+def test_pool_mixes_submissions_with_different_stop_sets_and_budgets(product_library):
+    """Round 5: stop-id sets are per SEQUENCE on the device (state[slot][6] -> a row of the pool's set table), so
+    submissions with different stop rules and budgets decode TOGETHER — each sequence ends by its own rule, with the ids it gets alone."""
+    from vlm_fo1_amd.llm import DecodePool
+    cfg, weights, eng = _engine()
+    reqs = _requests(6)
+    K = 12
+    eng.prefill_batch(reqs, use_graph=False)
+    hp, first = eng._last_batch, eng._last_next_tokens.clone()
+    pool = DecodePool(eng.llm, slots=64)
+    full = _pool_run(pool, eng, hp, first, list(range(6)), K)
+    stop_a, stop_b = full[0][3], full[4][5]
+    kc, vt = eng.llm.kcache, eng.llm.vtcache
+    pool.join(kc, vt, hp["seqs"][:2], hp["delta"][:2], first[:2], K, (stop_a,), tags=[0, 1])             # set A
+    pool.join(kc, vt, hp["seqs"][2:4], hp["delta"][2:4], first[2:4], 7, (), tags=[2, 3])                  # no stop ids, budget 7
+    pool.join(kc, vt, hp["seqs"][4:], hp["delta"][4:], first[4:], K, (stop_b, stop_a), tags=[4, 5])       # set B (contains A's id too)
+    assert len(pool.live) == 6 and len({pool.slot_set[s] for s in pool.live}) == 3
+    got = {tag: ids for _, tag, ids in pool.drain(poll=3)}
+
+    def cut(ids, stops, budget):
+        for i, t in enumerate(ids[:budget]):
+            if t in stops:
+                return ids[:i + 1]
+        return ids[:budget]
+
+    assert got[0] == cut(full[0], {stop_a}, K) and got[1] == cut(full[1], {stop_a}, K) and len(got[0]) == 4
+    assert got[2] == full[2][:7] and got[3] == full[3][:7]
+    assert got[4] == cut(full[4], {stop_a, stop_b}, K) and got[5] == cut(full[5], {stop_a, stop_b}, K) and len(got[4]) <= 6
+    assert sum(pool._set_users) == 0 and not pool.live
+
+
+def test_pool_service_from_replica_threads_equals_direct_pool_runs(product_library):def test_pool_service_from_replica_threads_equals_direct_pool_runs(product_library):
     """PoolService: three passes of three requests prefilled by two engine replicas on their own threads / streams, sequences of all
     passes decoding together; every request's ids == a direct DecodePool run of its pass (same prefill bits, slot-independent decode)."""
     from vlm_fo1_amd.llm import DecodePool

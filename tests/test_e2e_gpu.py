@@ -131,6 +131,7 @@ def test_bench_two_ranks_control_flow(tmp_path):
     assert sc["world_size"] == 2 and sc["dist_world_size"] == 2 and sc["backend"] == "gloo" and sc["one_device_gloo_test_mode"] is True
     assert sc["items"] == 128 and sc["per_rank_items"] == [64, 64] and len(sc["per_rank_shard_seconds"]) == 2 and len(sc["gather_ms"]) == 2
     assert sc["images_per_sec"] > 0 and sc["predictions_file_written"] and sc["host_threads_for_this_run"] == 2 * sc["host_threads_per_gpu"]
+    assert sc["items_failed"] == 0, sc
     assert sc["sample_ids_equal_to_one_rank_alone"] is True, sc.get("sample_difference")
 
 

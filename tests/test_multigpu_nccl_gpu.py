@@ -54,7 +54,7 @@ def test_bench_two_gpus_over_rccl():
     sc = out["scale"]
     assert sc["world_size"] == 2 and sc["dist_world_size"] == 2 and sc["backend"] == "nccl" and sc["one_device_gloo_test_mode"] is False
     assert sc["per_rank_items"] == [sc["items_per_gpu"]] * 2 and len(sc["gather_ms"]) == 2 and sc["images_per_sec"] > 0
-    assert sc["sample_ids_equal_to_one_rank_alone"] is True, sc
+    assert sc["items_failed"] == 0 and sc["sample_ids_equal_to_one_rank_alone"] is True, sc
 
 
 @need2

@@ -458,6 +458,11 @@ __device__ __forceinline__ void accept_token(int tok, int* st, int* plan, int* i
     ids_out[n] = tok;
     st[4] = n + 1;
     bool stop = (n + 1 >= st[5]) || (n + 1 >= ids_ld);
+    if (n_stop < 0) {       // per-sequence stop sets (the decode pool admits submissions with different sets): row st[6] of a table [sets][1 + 16] = {n, ids...}
+        stop_ids += st[6] * 17;
+        n_stop = min(stop_ids[0], 16);
+        ++stop_ids;
+    }
     for (int i = 0; i < n_stop; ++i) stop = stop || (tok == stop_ids[i]);
     if (stop) {
         st[3] = 1;
@@ -593,7 +598,7 @@ int fo1_decode_argmax_accept(const void* logits, long long ld_logits, int n_voca
                              int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids, int n_stop, int32_t* done, void* scratch,
                              void* stream) {
     using namespace fo1;
-    FO1_CHECK_ARG(state && plan && ids_out && done && B >= 1 && B <= 256 && ids_ld > 0 && n_stop >= 0 && (n_stop == 0 || stop_ids), "decode_accept: bad arguments");
+    FO1_CHECK_ARG(state && plan && ids_out && done && B >= 1 && B <= 256 && ids_ld > 0 && n_stop >= -1 && (n_stop == 0 || stop_ids), "decode_accept: bad arguments");
     FO1_CHECK_ARG((logits != nullptr) != (first_tokens != nullptr), "decode_accept: exactly one of logits / first_tokens");
     hipStream_t st = (hipStream_t)stream;
     float* pv = (float*)scratch;

@@ -789,6 +789,7 @@ class DecodePool:
     order is a function of the launch shape only, and the shape is always P rows; tests/test_decode_pool_gpu.py)."""
     IDS_CAP = 4096
     MAX_STOP = 16
+    MAX_SETS = 32            # distinct stop-id sets live in the pool at once
     KV_BUCKET = 256          # the attention launch geometry follows the longest live context rounded up to this many keys
 
     def __init__(self, llm: QwenLLM, slots: int = 128, slot_rows: int = 1024):
@@ -804,10 +805,13 @@ class DecodePool:
             self.plan = torch.zeros(P, 2, dtype=torch.int32, device=dev)
             self.ids = torch.zeros(P, self.IDS_CAP, dtype=torch.int32, device=dev)
             self.done = torch.zeros(1, dtype=torch.int32, device=dev)
-            self.stop = torch.zeros(self.MAX_STOP, dtype=torch.int32, device=dev)
+            # per-sequence stop rules (round 5): a table of stop-id sets {count, ids[16]}; state[slot][6] names a slot's set, so submissions
+            # with different stop ids / templates share the pool (before: one set per pool, anything else waited for a full drain)
+            self.stop = torch.zeros(self.MAX_SETS, 1 + self.MAX_STOP, dtype=torch.int32, device=dev)
             self.reloc = torch.zeros(2 * P, 4, dtype=torch.int32, device=dev)     # (a shared-prefix sequence moves in two pieces)
-        self.stop_ids: Optional[tuple] = None
-        self.n_stop = 0
+        self._sets: Dict[tuple, int] = {}              # stop-id tuple -> row of self.stop
+        self._set_users = [0] * self.MAX_SETS          # live slots per row (a row with users is never rewritten)
+        self.slot_set = [0] * P
         self.slot_rows = 0
         self.dk = self.dvt = None
         self.free = list(range(P))                     # host view of the slots
@@ -862,13 +866,7 @@ class DecodePool:
         stop_ids = tuple(sorted(set(int(t) for t in stop_ids)))
         if len(stop_ids) > self.MAX_STOP:
             raise ValueError(f"DecodePool evaluates at most {self.MAX_STOP} stop ids on the device (got {len(stop_ids)})")
-        if self.stop_ids is None or (not self.live and stop_ids != self.stop_ids):
-            self.stop_ids, self.n_stop = stop_ids, len(stop_ids)
-            sv = torch.tensor(list(stop_ids) + [0] * (self.MAX_STOP - len(stop_ids)), dtype=torch.int32)
-            self.stop.copy_(sv, non_blocking=True)
-            self._keep.append(sv)
-        elif stop_ids != self.stop_ids:
-            raise ValueError("DecodePool: every sequence of a pool shares one stop-id set (drain the pool to change it)")
+        set_row = self._stop_set_row(stop_ids)
         max_new = max(1, int(max_new_tokens))
         if max_new > self.IDS_CAP:
             raise ValueError(f"DecodePool keeps at most {self.IDS_CAP} generated ids per sequence (max_new_tokens={max_new})")
@@ -879,7 +877,7 @@ class DecodePool:
         self.free.sort()
         slots = [self.free.pop(0) for _ in range(B)]
         try:
-            self._join_slots(slots, kcache, vtcache, seqs, deltas, first_tokens, max_new)
+            self._join_slots(slots, kcache, vtcache, seqs, deltas, first_tokens, max_new, set_row)
         except BaseException:
             # nothing of this submission is live: its slots go back (their device state may be half written — the next occupant's
             # join rewrites state, plan and K / V^T rows; until then the slot is marked finished so that no step reads it)
@@ -900,12 +898,35 @@ class DecodePool:
             self.live[s] = tags[k] if tags is not None else object()
             self.bound[s] = seqs[k][1] + 1
             self.budget[s] = max_new
+            self.slot_set[s] = set_row
+            self._set_users[set_row] += 1
         return slots
 
-    def _join_slots(self, slots, kcache, vtcache, seqs, deltas, first_tokens, max_new):
+    def can_take(self, stop_ids: Sequence[int]) -> bool:
+        """Is there a table row for this stop-id set (its own, or one no live slot uses)?"""
+        key = tuple(sorted(set(int(t) for t in stop_ids)))
+        return key in self._sets or any(u == 0 for u in self._set_users)
+
+    def _stop_set_row(self, stop_ids: tuple) -> int:
+        row = self._sets.get(stop_ids)
+        if row is None:
+            free = [r for r in range(self.MAX_SETS) if self._set_users[r] == 0 and r not in self._sets.values()] or \
+                   [r for r in range(self.MAX_SETS) if self._set_users[r] == 0]
+            if not free:
+                raise RuntimeError(f"DecodePool: {self.MAX_SETS} different stop-id sets are live; wait for sequences to finish")
+            row = free[0]
+            for k in [k for k, v in self._sets.items() if v == row]:
+                del self._sets[k]
+            sv = torch.tensor([[len(stop_ids)] + list(stop_ids) + [0] * (self.MAX_STOP - len(stop_ids))], dtype=torch.int32)
+            self.stop[row:row + 1].copy_(sv, non_blocking=True)
+            self._keep.append(sv)
+            self._sets[stop_ids] = row
+        return row
+
+    def _join_slots(self, slots, kcache, vtcache, seqs, deltas, first_tokens, max_new, set_row):
         B = len(slots)
         R = self.slot_rows
-        state = torch.tensor([[s * R + L, L + d, s * R, 0, 0, max_new, 0, 0] for s, (_, L, *_), d in zip(slots, seqs, deltas)], dtype=torch.int32)
+        state = torch.tensor([[s * R + L, L + d, s * R, 0, 0, max_new, set_row, 0] for s, (_, L, *_), d in zip(slots, seqs, deltas)], dtype=torch.int32)
         first = first_tokens.to(torch.int32).contiguous()
         self._keep += [state]
         if len(self._keep) > 64:
@@ -925,7 +946,7 @@ class DecodePool:
                 self.state[a:a + n].copy_(state[i:j + 1], non_blocking=True)
                 ops.kv_relocate(kcache, self.dk, vtcache, self.dvt, self.reloc[2 * a:2 * a + nr], max(L for _, L, *_ in seqs[i:j + 1]))
                 ops.decode_argmax_accept(None, first[i:j + 1], self.state[a:a + n], self.plan[a:a + n], self.ids[a:a + n],
-                                         self.stop[:self.n_stop], self.done)
+                                         self.stop, self.done, per_sequence_sets=True)
                 i = j + 1
 
     # ---- step ------------------------------------------------------------------------------------------------------------------
@@ -998,7 +1019,7 @@ class DecodePool:
                     a = ops.gemm(ops.rmsnorm(x, w["ln2"], c.rms_norm_eps), w["wgu"], act=ops.ACT_SWIGLU16)
                     x = ops.gemm(a, w["wdown"], residual=x)
                 logits = ops.gemm(ops.rmsnorm(x, llm.norm, c.rms_norm_eps), llm.lm_head)
-            ops.decode_argmax_accept(logits, None, st, self.plan, self.ids, self.stop[:self.n_stop], self.done)
+            ops.decode_argmax_accept(logits, None, st, self.plan, self.ids, self.stop, self.done, per_sequence_sets=True)
             return logits
 
     def step(self, use_graph: bool = True):
@@ -1008,7 +1029,7 @@ class DecodePool:
             out = self._step_device(bucket)
         else:
             # (the step's form is part of the key: FUSED_SPLITK / SPLITS may be set per pool, scripts/pool_bench.py and the A/B test do)
-            key = (self.slot_rows, self.n_stop, bucket, self.llm.rope_epoch, self.llm.rope_cos.data_ptr(), bool(self.FUSED_SPLITK), tuple(sorted(self.SPLITS.items())), bool(self.TILED_WEIGHTS))
+            key = (self.slot_rows, bucket, self.llm.rope_epoch, self.llm.rope_cos.data_ptr(), bool(self.FUSED_SPLITK), tuple(sorted(self.SPLITS.items())), bool(self.TILED_WEIGHTS))
             ent = self._graphs.get(key)
             if ent is None:
                 with ops.graph_lock.capture(), torch.inference_mode(False):
@@ -1058,6 +1079,7 @@ class DecodePool:
                 out.append((s, tag, ids[s, :ngen[s]].tolist()))
                 del self.live[s]
                 self.free.append(s)
+                self._set_users[self.slot_set[s]] -= 1
         return out
 
     def drain(self, use_graph: bool = True, poll: int = 8) -> List[Tuple[int, object, List[int]]]:

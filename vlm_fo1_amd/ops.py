@@ -743,11 +743,15 @@ def pool_qkv_post_partials(part: torch.Tensor, splits: int, bias: Optional[torch
 
 
 def decode_argmax_accept(logits: Optional[torch.Tensor], first_tokens: Optional[torch.Tensor], state: torch.Tensor, plan: torch.Tensor,
-                         ids_out: torch.Tensor, stop_ids: torch.Tensor, done: torch.Tensor) -> None:
+                         ids_out: torch.Tensor, stop_ids: torch.Tensor, done: torch.Tensor, per_sequence_sets: bool = False) -> None:
+    """per_sequence_sets: stop_ids is a table int32 [sets, 17] = {count, ids[16]} and state[b, 6] names sequence b's row (decode pool)."""
     B = state.shape[0]
     assert state.dtype == plan.dtype == ids_out.dtype == done.dtype == torch.int32 and ids_out.is_contiguous() and plan.is_contiguous()
     sc = _workspace("argmax_rows", state.device, 2 * 128 * B * 4)
     n_stop = int(stop_ids.numel()) if stop_ids is not None else 0
+    if per_sequence_sets:
+        assert stop_ids is not None and stop_ids.dim() == 2 and stop_ids.shape[1] == 17 and stop_ids.is_contiguous() and stop_ids.dtype == torch.int32
+        n_stop = -1
     if logits is not None:
         _chk(logits, "logits")
         pl, ldl, Bl, V = _rows(logits, "logits")

@@ -131,8 +131,10 @@ class PoolService:
             h, kc, vt, seqs, deltas, first, max_new, stop_ids, ev = waiting[0]
             if len(seqs) > len(pool.free):
                 return
-            if pool.live and (pool.stop_ids != tuple(sorted(set(stop_ids))) or not pool.fits(seqs, max_new)):
-                return                                   # another stop-id set / longer slots: wait until the pool has drained
+            if not pool.can_take(stop_ids):
+                return                                   # every row of the stop-set table is in use by live sequences (32 different sets)
+            if pool.live and not pool.fits(seqs, max_new):
+                return                                   # longer slots than the pool has: its caches can only grow while it is empty
             waiting.pop(0)
             try:
                 torch.cuda.current_stream().wait_event(ev)       # the prefill that produced the rows and the first tokens
