@@ -10,6 +10,8 @@ import sys
 from collections import defaultdict
 
 BENCH_NAMES = [
+    (r"attn_fwd32_kernel<128", "attention32_hd128"),
+    (r"attn_fwd32_kernel<80", "attention32_hd80"),
     (r"attn_fwd_kernel<128, 4, false>", "attention_hd128"),
     (r"attn_fwd_kernel<80, 4, false>", "attention_hd80"),
     (r"hfre_pool_items_kernel", "hfre_pool_items"),
