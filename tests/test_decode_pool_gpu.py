@@ -321,7 +321,7 @@ def test_pool_mixes_submissions_with_different_stop_sets_and_budgets(product_lib
     assert sum(pool._set_users) == 0 and not pool.live
 
 
-def test_pool_service_from_replica_threads_equals_direct_pool_runs(product_library):def test_pool_service_from_replica_threads_equals_direct_pool_runs(product_library):
+def test_pool_service_from_replica_threads_equals_direct_pool_runs(product_library):
     """PoolService: three passes of three requests prefilled by two engine replicas on their own threads / streams, sequences of all
     passes decoding together; every request's ids == a direct DecodePool run of its pass (same prefill bits, slot-independent decode)."""
     from vlm_fo1_amd.llm import DecodePool
