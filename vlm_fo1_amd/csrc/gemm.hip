@@ -1477,7 +1477,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
                 ub = (g < 2 ? At : Wt) + (long long)((ABL & 16) ? 0 : kt0 + kt) * 128;
             }
             const uint32_t dst = lds0 + buf * BUFSZ + g * GROUP + (wave * 2 + i) * 1024;     // M0 = the piece's LDS base
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(so), "s"(ub), "s"(dst) : "memory");
+            // (M0 is on the clobber list — ADVICE r4: the compiler must know the statement rewrites it; hipcc accepts the reserved register with a
+            // -Winline-asm warning, silenced for this statement.  No compiler-generated M0 use exists in this kernel: its only LDS-DMA is this one.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(so), "s"(ub), "s"(dst) : "memory", "m0");
+#pragma clang diagnostic pop
         }
     };
     auto stage = [&](int g, int kt, int buf) __attribute__((always_inline)) {
