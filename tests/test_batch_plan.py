@@ -83,3 +83,23 @@ def test_plan_batch_share_prefix_reassembles_every_prompt():
     rr = reloc_rows(hp["seqs"][:2] + hp["seqs"][5:6], [0, 4096, 8192])
     (o, L, _, po, P), (o1, L1, *_), (o5, L5, _) = hp["seqs"][0], hp["seqs"][1], hp["seqs"][5]
     assert rr == [[po, 0, P, 0], [o, P, L - P, 0], [po, 4096, P, 0], [o1, 4096 + P, L1 - P, 0], [o5, 8192, L5, 0]]
+
+
+def test_conv_plan_outlives_its_cache_entry_through_the_pass_keep_list():
+    """A packed pass (and a hipGraph captured from it) holds a convolution plan's device tables by raw pointer: the plan must stay
+    alive through the pass's keep list after the bounded plan cache has evicted it (ops.keep_scope / ops.keep_alive)."""
+    from vlm_fo1_amd import ops
+    keep = []
+    with ops.keep_scope(keep):
+        pl = ops.conv3x3_plan(((6, 5),) * 2, 1, 64, "cpu")
+        assert ops.conv3x3_plan(((6, 5),) * 2, 1, 64, "cpu") is pl
+    assert keep == [pl]                                            # once, however often the pass asked for it
+    assert pl.M_in == 60 and pl.M_out == 60 and pl.Wp == 7 and pl.pad_rows == 2 * 8 * 7
+    # output pixel (0, 0) of image 1 reads its taps from padded row 8 * 7 on: byte offset = that row * Cin * 2
+    assert int(pl.a_rows[30].item()) == 8 * 7 * 64 * 2 and int(pl.rowmap[0].item()) == 7 + 1
+    for i in range(70):                                            # push the entry out of the 64-entry cache
+        ops.conv3x3_plan(((3 + i, 4),), 1, 64, "cpu")
+    assert ops.conv3x3_plan(((6, 5),) * 2, 1, 64, "cpu") is not pl  # evicted and rebuilt ...
+    assert keep[0] is pl and pl.rowmap.numel() == 60               # ... while the pass's list still owns the old tables
+    ops.keep_alive(object())                                       # outside a scope: a no-op
+    assert len(keep) == 1

@@ -346,8 +346,9 @@ class FO1Engine:
         return out, [ranges.get(i, (0, 0)) for i in range(len(want))]
 
     def _device_batch(self, st, meta):
-        with ops.workspace_scope(self._ws_owner):
-            self._pass_keep = keep = []      # host objects whose device tables this pass's launches (and a graph of them) point at
+        keep: list = []                      # host objects whose device tables this pass's launches (and a graph of them) point at
+        with ops.workspace_scope(self._ws_owner), ops.keep_scope(keep):
+            self._pass_keep = keep
             grids = meta["grids"]
             tokens, feats, bp = self.vit.forward_batch(st["pix"], grids, capture=self.capture)
             keep.append(bp)                  # (the ViT's batch plans are evicted from a 64-entry cache the same way)

@@ -114,6 +114,31 @@ class workspace_scope:
         return False
 
 
+class keep_scope:
+    """While active on this thread, host objects that own device index tables handed to launches (plans evicted from bounded caches:
+    Conv3x3Plan) are appended to `keep` — the list a packed pass returns with its result and a captured hipGraph of that pass is stored
+    with, so the tables outlive their cache entry for as long as a graph can replay launches that point at them (ADVICE r3's rule for
+    the ragged tower plans, applied to the uniform paths' convolution plans)."""
+
+    def __init__(self, keep: list):
+        self.keep = keep
+
+    def __enter__(self):
+        self.prev = getattr(_ws_tls, "keep", None)
+        _ws_tls.keep = self.keep
+        return self
+
+    def __exit__(self, *exc):
+        _ws_tls.keep = self.prev
+        return False
+
+
+def keep_alive(obj) -> None:
+    keep = getattr(_ws_tls, "keep", None)
+    if keep is not None and not any(o is obj for o in keep):
+        keep.append(obj)
+
+
 def _workspace(kind: str, device, nbytes: int) -> torch.Tensor:
     owner = getattr(_ws_tls, "owner", None)
     who = ("owner", owner) if owner is not None else ("stream", torch.cuda.current_stream().cuda_stream)
@@ -359,6 +384,7 @@ def conv3x3_plan(sizes, stride: int, cin: int, device) -> Conv3x3Plan:
         if len(_conv_plans) >= 64:
             _conv_plans.pop(next(iter(_conv_plans)))
         pl = _conv_plans[key] = Conv3x3Plan(key[0], stride, cin, device)
+    keep_alive(pl)       # a captured pass holds rowmap / a_rows by raw pointer: it keeps the plan past this cache's eviction
     return pl
 
 
