@@ -445,7 +445,9 @@ int fo1_kv_relocate(const void* ksrc, void* kdst, long long ks_layer, long long 
  *                        reference: modeling_qwen2_5_vl.py:436-504 (blocks :306-357, merger :140-158) as driven by
  *                        qwen2_5_vl_encoder.py:37-80,86-158,228-257
  *   fo1_llm_prefill      36-layer Qwen2.5 decoder over packed prompt rows (varlen causal segments), KV cache written at
- *                        [pos0, pos0 + rows); last-row final norm + lm_head + greedy pick per sequence.
+ *                        [pos0, pos0 + rows); last-row final norm + lm_head + greedy pick per sequence.  Where the q/k/v product runs on the
+ *                        256 x 256 GEMM kernel (fo1_gemm_takes_big_tile) and pos0 / the cache pitches are multiples of 8 rows, mRoPE, the K
+ *                        append and V^T ride in its epilogue (fo1_qkv_proj_rope_bf16), as in the Python mirror; otherwise GEMM + fo1_qkv_post_llm_bf16.
  *                        reference: modeling_qwen2_5_vl.py:1014-1095,1126-1242; omchat_qwen2_5_vl.py:143-155
  *   fo1_llm_decode_step  one token for `batch` sequences (state / plan / stop rule as in the batched decode block above).
  * ---------------------------------------------------------------------- */

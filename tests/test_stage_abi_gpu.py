@@ -97,6 +97,46 @@ def test_engine_through_stage_entries_bitwise(stage_switch):
     assert eng2.generate_batch(reqs, max_new_tokens=10, use_graph=True) == ref_ids
 
 
+def test_llm_prefill_entry_takes_the_fused_qkv_epilogue_where_the_python_path_does(stage_switch):
+    """A packed pass big enough for the 256 x 256 GEMM kernel (6 x ~650 rows >= 13 tile rows x 10 tile columns): both the Python orchestration
+    and fo1_llm_prefill put mRoPE + K append + V^T in the q/k/v GEMM's epilogue (fo1_qkv_proj_rope_bf16) — bit-identical to each other, to the
+    two-launch form (FO1_QKV_FUSED=0), and in the KV cache they leave behind (the decoded ids)."""
+    import os
+    from test_batched_prefill_gpu import make_request
+    from vlm_fo1_amd import lib as L
+    cfg, eng = build()
+    reqs = [make_request(80 + i, 640, 480, 100) for i in range(6)]
+    c = cfg.llm
+    keys = ("last_hidden", "logits")
+
+    def run():
+        out = eng.prefill_batch(reqs, use_graph=False)
+        ids = eng.generate_batch(reqs, max_new_tokens=6, use_graph=False)
+        return [{k: o[k].clone() for k in keys} | {"next_token": int(o["next_token"])} for o in out], ids
+
+    stage_switch(False)
+    fused, ids_fused = run()
+    rows = sum(len(r["ids"]) - 1 + r["grid"][0] * r["grid"][1] // 4 for r in reqs)      # a lower bound of the packed rows (one image sentinel each)
+    assert rows >= 3328 and L.load().fo1_gemm_takes_big_tile(rows, (c.num_heads + 2 * c.num_kv_heads) * c.head_dim, c.hidden_size) == 1
+    old = os.environ.get("FO1_QKV_FUSED")
+    os.environ["FO1_QKV_FUSED"] = "0"
+    try:
+        plain, ids_plain = run()
+    finally:
+        if old is None:
+            del os.environ["FO1_QKV_FUSED"]
+        else:
+            os.environ["FO1_QKV_FUSED"] = old
+    stage_switch(True)
+    staged, ids_staged = run()
+    for a, b, d in zip(fused, plain, staged):
+        for k in keys:
+            assert torch.equal(a[k], b[k]), f"fused vs two-launch: {k}"
+            assert torch.equal(a[k], d[k]), f"python vs stage entry: {k}"
+        assert a["next_token"] == b["next_token"] == d["next_token"]
+    assert ids_fused == ids_plain == ids_staged
+
+
 def test_stage_entries_report_errors():
     import ctypes
     from vlm_fo1_amd import lib as L, stage_abi

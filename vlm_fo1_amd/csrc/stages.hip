@@ -162,14 +162,24 @@ int fo1_llm_prefill(const fo1_llm_weights_t* w, const fo1_kv_cache_t* kv, const 
     const float scale = (float)(1.0 / sqrt((double)HD));
     const void* x = embeds;
     int ldx = ld_embeds;
+    // the Python mirror's rule (llm.py:_forward): where the projection runs on the 256 x 256 GEMM kernel anyway, mRoPE + K append + V^T ride in
+    // its epilogue (fo1_qkv_proj_rope_bf16: the same bits as fo1_gemm_bf16 + fo1_qkv_post_llm_bf16, one launch and one pass over [R, qd] less)
+    const bool fused_qkv = HD == 128 && pos0 % 8 == 0 && kv->vt_row_stride % 8 == 0 && kv->k_head_stride % 8 == 0 && qd % 256 == 0 &&
+                           ((uintptr_t)cos & 15) == 0 && ((uintptr_t)sin & 15) == 0 && fo1_gemm_takes_big_tile(R, qd, d) == 1;
     for (int li = 0; li < w->n_layers; ++li) {
         const fo1_llm_layer_t& L = w->layers[li];
         uint16_t* kc = (uint16_t*)kv->k + (long long)li * kv->k_layer_stride;
         uint16_t* vtc = (uint16_t*)kv->vt + (long long)li * kv->vt_layer_stride;
         FO1_TRY(fo1_rmsnorm_bf16(x, ldx, L.ln1, h, d, R, d, w->rms_eps, stream));
-        FO1_TRY(fo1_gemm_bf16_ws(h, d, L.wqkv, d, L.bqkv, nullptr, 0, qkv, qd, R, qd, d, 0, 0, gws, kGemmScratch, stream));
-        // mRoPE on q/k + K append + V^T, one launch; then causal attention of the packed segments against the cache
-        FO1_TRY(fo1_qkv_post_llm_bf16(qkv, qd, H, KV, HD, cos, sin, R, kc, kv->k_head_stride, vtc, kv->vt_row_stride, pos0, stream));
+        if (fused_qkv) {
+            FO1_TRY(fo1_qkv_proj_rope_bf16(h, d, L.wqkv, d, L.bqkv, qkv, qd, R, qd, d, 0, H, KV, cos, sin, kc, kv->k_head_stride, pos0, vtc, kv->vt_row_stride,
+                                           stream));
+        } else {
+            FO1_TRY(fo1_gemm_bf16_ws(h, d, L.wqkv, d, L.bqkv, nullptr, 0, qkv, qd, R, qd, d, 0, 0, gws, kGemmScratch, stream));
+            // mRoPE on q/k + K append + V^T, one launch
+            FO1_TRY(fo1_qkv_post_llm_bf16(qkv, qd, H, KV, HD, cos, sin, R, kc, kv->k_head_stride, vtc, kv->vt_row_stride, pos0, stream));
+        }
+        // causal attention of the packed segments against the cache
         FO1_TRY(fo1_attention_bf16((const uint16_t*)qkv - (long long)pos0 * qd, qd, HD, kc, HD, kv->k_head_stride, vtc, kv->vt_row_stride,
                                    (uint16_t*)att - (long long)pos0 * H * HD, (long long)H * HD, HD, items, n_items, q_block, H, KV, HD, scale, 1,
                                    nullptr, attn_flops, stream));
