@@ -436,8 +436,10 @@ int fo1_kv_relocate(const void* ksrc, void* kdst, long long ks_layer, long long 
  * Stage-level entries: one call per fused stage, for hosts that do not want to sequence the primitives
  * themselves.  Every pointer is a device pointer unless marked host; weights are bf16 in the engine's layouts (below); the
  * caller owns all memory including the workspace (sizes from the *_workspace_bytes queries); calls are asynchronous on
- * `stream`, allocate nothing, and may be captured in a hipGraph.  Each entry issues exactly the primitive launches of the
- * Python mirror (vlm_fo1_amd/vit.py, llm.py) — results are bit-identical to it (tests/test_stage_abi_gpu.py).
+ * `stream`, allocate nothing, and may be captured in a hipGraph.  Each entry issues the primitive launches of the
+ * Python mirror (vlm_fo1_amd/vit.py, llm.py) — results are bit-identical to it (tests/test_stage_abi_gpu.py); where the mirror takes
+ * a fused form (q/k/v epilogue, implicit-GEMM convolution) the LLM, DaViT and SimpleFPN entries take it too, the ViT entry keeps the
+ * two-launch q/k/v form (same bits; profiles/r05_stage_abi_path.json).
  *
  *   fo1_vit_forward      Qwen2.5-VL vision tower over packed patch rows (one or several images): window-ordered patch embed,
  *                        `depth` blocks (RMSNorm, QKV, 2-D RoPE, windowed / full attention, proj, SwiGLU MLP), merger; emits the

@@ -77,6 +77,47 @@ def test_davit_fpn_projector_entries_bitwise(stage_switch):
     assert all(torch.equal(a, b) for a, b in zip(m2, m3))
 
 
+def test_davit_fpn_entries_take_the_implicit_convolution_bitwise(stage_switch):
+    """Maps large enough for the 256 x 256 GEMM kernel: fo1_davit_forward / fo1_simplefpn_forward run the pre-norm ConvEmbed of stage 1 and the
+    3x3 output convolutions of the two finest FPN levels as implicit GEMMs (index tables built on the device), like davit.py / fpn.py — and all
+    three forms (stage entries, Python implicit, Python im2col) give the same bits."""
+    import os
+    from vlm_fo1_amd import lib as L
+    cfg, eng = build()
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(5, 3, 480, 640, generator=g).bfloat16().cuda()
+    vmap = torch.randn(2 * 34 * 46, 1280, generator=g).bfloat16().cuda()
+    lib = L.load()
+    assert lib.fo1_gemm_takes_big_tile(5 * 60 * 80, 512, 9 * 256) == 1            # DaViT stage 1 embed: 3x3 / stride 2 over 120 x 160 x 256
+    assert lib.fo1_gemm_takes_big_tile(2 * 136 * 184, 512, 9 * 512) == 1          # FPN level 0 head at (4H, 4W)
+
+    def run():
+        m, s_ = eng.davit.forward(img)
+        f, fs = eng.fpn.forward(vmap, 34, 46, batch=2)
+        return [t.clone() for t in m], s_, [t.clone() for t in f], fs
+
+    stage_switch(False)
+    m0, s0, f0, fs0 = run()
+    old = os.environ.get("FO1_CONV_IMPLICIT")
+    os.environ["FO1_CONV_IMPLICIT"] = "0"
+    try:
+        m2, s2, f2, fs2 = run()
+    finally:
+        if old is None:
+            del os.environ["FO1_CONV_IMPLICIT"]
+        else:
+            os.environ["FO1_CONV_IMPLICIT"] = old
+    stage_switch(True)
+    m1, s1, f1, fs1 = run()
+    assert s0 == s1 == s2 and fs0 == fs1 == fs2
+    for k, (a, b, c) in enumerate(zip(m0, m1, m2)):
+        assert torch.equal(a, c), f"DaViT stage {k}: implicit vs im2col"
+        assert torch.equal(a, b), f"DaViT stage {k}: python vs stage entry"
+    for k, (a, b, c) in enumerate(zip(f0, f1, f2)):
+        assert torch.equal(a, c), f"FPN level {k}: implicit vs im2col"
+        assert torch.equal(a, b), f"FPN level {k}: python vs stage entry"
+
+
 def test_engine_through_stage_entries_bitwise(stage_switch):
     cfg, eng = build()
     reqs = requests()

@@ -1,9 +1,12 @@
 // stages.hip — stage-level C-ABI entries ("one extern "C" function per fused stage"): the launch sequences of the
 // Qwen2.5-VL vision tower, the LLM prefill and the batched decode step as plain C calls over caller-owned device memory, so that a
-// host that is not Python can drive the hot path.  Each entry issues exactly the primitive launches the Python mirror issues
+// host that is not Python can drive the hot path.  Each entry issues the primitive launches the Python mirror issues
 // (vlm_fo1_amd/vit.py QwenViT._forward, vlm_fo1_amd/llm.py QwenLLM._forward / prefill_packed, BatchDecoder._step_device) in the
 // same order with the same arguments: results are bit-identical to that path (tests/test_stage_abi_gpu.py), and the calls are
 // asynchronous on the caller's stream and safe to capture in a hipGraph (no allocation, no synchronisation, no memset node).
+// Round 5's fused forms: fo1_llm_prefill takes the q/k/v epilogue (fo1_qkv_proj_rope_bf16) and the DaViT / SimpleFPN entries the
+// implicit-GEMM convolution (index tables filled on the device) under the mirror's own rules; fo1_vit_forward keeps GEMM +
+// fo1_qkv_post_vit_bf16 (the head-major weight copy is not in its weight table) — the same bits either way.
 //
 // Reference call sites replaced:
 //   fo1_vit_forward      Qwen2_5_VisionTransformerPretrainedModel.forward  modeling_qwen2_5_vl.py:436-504 (blocks :306-357,
@@ -296,6 +299,53 @@ struct Arena {   // stack allocator over the workspace; dry run when base is NUL
 
 inline int rup(int x, int m) { return (x + m - 1) / m * m; }
 
+// Index tables of an implicit-GEMM 3x3 / pad 1 convolution (fo1_conv3x3_gemm_bf16) over B images of one size — what ops.Conv3x3Plan builds on the
+// host for the Python mirror, the same values: rowmap[b H W + y W + x] = padded row of input pixel (b, y, x) in the zero-framed map (row pitch
+// W + 2 pixels, (H + 2)(W + 2) rows per image), a_rows[b Ho Wo + oy Wo + ox] = BYTE offset of output pixel (b, oy, ox)'s top-left tap.
+__global__ __launch_bounds__(256) void conv_plan_fill_kernel(int32_t* rowmap, uint32_t* a_rows, int H, int W, int B, int Ho, int Wo, int stride, int cin) {
+    const long long Wp = W + 2, blk = (long long)(H + 2) * Wp;
+    const long long n_in = (long long)B * H * W, n_out = (long long)B * Ho * Wo;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_in + n_out; i += (long long)gridDim.x * blockDim.x) {
+        if (i < n_in) {
+            const long long b = i / ((long long)H * W), r = i - b * H * W, y = r / W, x = r - y * W;
+            rowmap[i] = (int32_t)(b * blk + (y + 1) * Wp + (x + 1));
+        } else {
+            const long long j = i - n_in, b = j / ((long long)Ho * Wo), r = j - b * Ho * Wo, oy = r / Wo, ox = r - oy * Wo;
+            a_rows[j] = (uint32_t)((b * blk + oy * stride * Wp + ox * stride) * (long long)(cin * 2));
+        }
+    }
+}
+
+// the Python mirror's rule (ops.conv3x3_implicit_ok + Conv3x3Plan's 32-bit offsets): a 3x3 / pad 1 convolution over >= 64 power-of-two channels
+// whose im2col GEMM would run on the 256 x 256 kernel anyway takes the implicit form — the same bits without the [M, 9 Cin] column matrix
+inline bool conv_implicit_ok(int M_out, int cout, int cin, int k, int pad, int K_padded, int B, int H, int W) {
+    return k == 3 && pad == 1 && cin >= 64 && (cin & (cin - 1)) == 0 && cout % 8 == 0 && K_padded == 9 * cin &&
+           (long long)B * (H + 2) * (W + 2) * cin * 2 < (1ll << 32) && fo1_gemm_takes_big_tile(M_out, cout, 9 * cin) == 1;
+}
+
+// [LayerNorm ->] 3x3 convolution as an implicit GEMM: the norm writes the zero-framed map, the GEMM gathers its nine taps from it.
+// src rows [B H W, cin] -> dst rows [B Ho Wo, cout].
+int conv3x3_implicit(Arena& A, const void* src, const void* ln_w, const void* ln_b, float eps, const void* conv_w, const void* conv_b, void* dst,
+                     int H, int W, int B, int stride, int cin, int cout, void* stream) {
+    const size_t m = A.mark();
+    const int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1, Wp = W + 2;
+    const long long n_in = (long long)B * H * W, n_out = (long long)B * Ho * Wo, pad_rows = (long long)B * (H + 2) * Wp;
+    void* xpad = A.take(bf16_rows(pad_rows, cin));
+    int32_t* rowmap = (int32_t*)A.take((size_t)n_in * 4);
+    uint32_t* a_rows = (uint32_t*)A.take((size_t)n_out * 4);
+    FO1_RUN(fo1_zero_bytes(xpad, bf16_rows(pad_rows, cin), stream));
+    if (!A.dry()) {
+        const long long tot = n_in + n_out;
+        const int grid = (int)(tot / 256 + 1 < 2048 ? tot / 256 + 1 : 2048);
+        FO1_LAUNCH("conv_plan_fill", (double)tot * 4.0, conv_plan_fill_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, rowmap, a_rows, H, W, B, Ho, Wo,
+                   stride, cin);
+    }
+    FO1_RUN(fo1_layernorm_rows_bf16(src, cin, ln_w, ln_b, xpad, cin, rowmap, (int)n_in, cin, eps, stream));
+    FO1_RUN(fo1_conv3x3_gemm_bf16(xpad, a_rows, Wp, cin, conv_w, 9 * cin, conv_b, dst, cout, (int)n_out, cout, 0, stream));
+    A.release(m);
+    return FO1_OK;
+}
+
 // conv2 (depthwise 3x3 + residual) -> LayerNorm -> MLP (+ residual) -> dst      (modeling_davit.py:29-48,72-99,51-69)
 int davit_conv_ffn(Arena& A, const fo1_davit_half_t& d, const void* x, void* tmp_x, void* dst, int n, int H, int W, int C, int B, void* gws, void* stream) {
     const size_t m = A.mark();
@@ -327,7 +377,11 @@ int davit_run(Arena& A, const fo1_davit_weights_t* w, const fo1_davit_plan_t* pl
         const size_t stage_mark = A.mark();
         void* XA = A.take(bf16_rows(n, C));
         void* XB = A.take(bf16_rows(n, C));
-        {   // ConvEmbed (modeling_davit.py:102-148): [pre-norm] -> conv as im2col + GEMM -> [post-norm]
+        if (i > 0 && sg.prenorm && conv_implicit_ok(n, C, Cprev, k, pd, sg.K_padded, B, H, W)) {
+            // pre-norm ConvEmbed as an implicit GEMM (as davit.py does for the same shapes: same bits, no column matrix)
+            const int rc = conv3x3_implicit(A, prev, sg.norm_w, sg.norm_b, 1e-5f, sg.conv_w, sg.conv_b, XA, H, W, B, st, Cprev, C, stream);
+            if (rc != FO1_OK) return rc;
+        } else {   // ConvEmbed (modeling_davit.py:102-148): [pre-norm] -> conv as im2col + GEMM -> [post-norm]
             const size_t m = A.mark();
             const void* src = prev;
             if (i > 0 && sg.prenorm) {
@@ -405,12 +459,18 @@ int fpn_head(Arena& A, const fo1_fpn_head_t& hd, const void* x, int Cin, void* d
     const int n = B * H * W;
     void* y = A.take(bf16_rows(n, Cout));
     void* y2 = A.take(bf16_rows(n, Cout));
-    void* col = A.take(bf16_rows(n, 9 * Cout));
     FO1_RUN(fo1_gemm_bf16_ws(x, Cin, hd.w1, Cin, nullptr, nullptr, 0, y, Cout, n, Cout, Cin, 0, 0, gws, kGemmScratch, stream));
-    FO1_RUN(fo1_layernorm_bf16(y, Cout, hd.n1_w, hd.n1_b, y2, Cout, n, Cout, 1e-6f, stream));
-    FO1_RUN(fo1_im2col_bf16(y2, col, H, W, Cout, 3, 3, 1, 1, 9 * Cout, B, stream));
-    FO1_RUN(fo1_gemm_bf16_ws(col, 9 * Cout, hd.w3, 9 * Cout, nullptr, nullptr, 0, y, Cout, n, Cout, 9 * Cout, 0, 0, gws, kGemmScratch, stream));
-    FO1_RUN(fo1_layernorm_bf16(y, Cout, hd.n3_w, hd.n3_b, dst, Cout, n, Cout, 1e-6f, stream));
+    if (conv_implicit_ok(n, Cout, Cout, 3, 1, 9 * Cout, B, H, W)) {      // as fpn.py does for the same shapes (same bits, no column matrix)
+        const int rc = conv3x3_implicit(A, y, hd.n1_w, hd.n1_b, 1e-6f, hd.w3, nullptr, y2, H, W, B, 1, Cout, Cout, stream);
+        if (rc != FO1_OK) return rc;
+        FO1_RUN(fo1_layernorm_bf16(y2, Cout, hd.n3_w, hd.n3_b, dst, Cout, n, Cout, 1e-6f, stream));
+    } else {
+        void* col = A.take(bf16_rows(n, 9 * Cout));
+        FO1_RUN(fo1_layernorm_bf16(y, Cout, hd.n1_w, hd.n1_b, y2, Cout, n, Cout, 1e-6f, stream));
+        FO1_RUN(fo1_im2col_bf16(y2, col, H, W, Cout, 3, 3, 1, 1, 9 * Cout, B, stream));
+        FO1_RUN(fo1_gemm_bf16_ws(col, 9 * Cout, hd.w3, 9 * Cout, nullptr, nullptr, 0, y, Cout, n, Cout, 9 * Cout, 0, 0, gws, kGemmScratch, stream));
+        FO1_RUN(fo1_layernorm_bf16(y, Cout, hd.n3_w, hd.n3_b, dst, Cout, n, Cout, 1e-6f, stream));
+    }
     A.release(m);
     return FO1_OK;
 }
