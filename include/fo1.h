@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define FO1_ABI_VERSION 6   /* 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 7   /* 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -459,6 +459,9 @@ typedef struct fo1_vit_block {   /* bf16 device pointers; Linear weights [out, i
     const void* wo; const void* bo;                 /* [hidden, hidden], [hidden]                                        */
     const void* wgu; const void* bgu;               /* gate/up interleaved in 16-row groups, rows padded: [2 ff_padded, hidden] */
     const void* wd; const void* bd;                 /* [hidden, ff_padded] (zero columns beyond ff), [hidden]            */
+    const void* wqkv_hm; const void* bqkv_hm;       /* optional (NULL: never fused), ABI 7: the q/k/v weight and bias HEAD-MAJOR, per head [q 80 | k 80 | v 80 |
+                                                       16 zero rows] = [256 n_heads, hidden], [256 n_heads] (fo1_qkv_proj_rope_bf16 mode 1; head_dim 80 only):
+                                                       passes whose q/k/v product runs on the 256 x 256 GEMM kernel then rotate and transpose in its epilogue */
 } fo1_vit_block_t;
 typedef struct fo1_vit_weights {
     int32_t depth, hidden, n_heads, ff_padded, k_in, k_in_padded, merge, out_hidden;

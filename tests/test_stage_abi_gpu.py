@@ -53,6 +53,39 @@ def test_vit_forward_entry_bitwise(stage_switch):
     assert torch.equal(t2, t0) and torch.equal(f2[-1], f0[-1])
 
 
+def test_vit_forward_entry_takes_the_fused_qkv_epilogue_bitwise(stage_switch):
+    """Four 640 x 480 images in one pass (6 256 patch rows: the q/k/v product runs on the 256 x 256 GEMM kernel): vit.py puts the 2-D RoPE and V^T
+    into that GEMM's epilogue, and so does fo1_vit_forward given the head-major weight copy in its table (ABI 7) — bit-identical tokens and maps."""
+    from vlm_fo1_amd import lib as L
+    cfg, eng = build(depth=3)
+    assert eng.vit._fused_qkv and eng.vit.blocks[0]["wqkv_hm"] is not None
+    g = torch.Generator().manual_seed(6)
+    grids = [(34, 46)] * 4
+    S = sum(a * b for a, b in grids)
+    assert L.load().fo1_gemm_takes_big_tile(S, 3 * cfg.vit.hidden_size, cfg.vit.hidden_size) == 1
+    pix = torch.randn(S, 1176, generator=g).bfloat16().cuda()
+    stage_switch(False)
+    t0, f0, _ = eng.vit.forward_batch(pix, grids, capture="all")
+    t0, f0 = t0.clone(), [f.clone() for f in f0]
+    stage_switch(True)
+    t1, f1, _ = eng.vit.forward_batch(pix, grids, capture="all")
+    assert torch.equal(t0, t1) and len(f0) == len(f1) and all(torch.equal(a, b) for a, b in zip(f0, f1))
+    # without the copy in the table the entry runs GEMM + fo1_qkv_post_vit_bf16: the same bits again
+    from vlm_fo1_amd import stage_abi
+    st = stage_abi.vit_stage(eng.vit) if hasattr(stage_abi, "vit_stage") else None
+    if st is not None:
+        saved = [(b.wqkv_hm, b.bqkv_hm) for b in st._blocks]
+        for b in st._blocks:
+            b.wqkv_hm = None
+            b.bqkv_hm = None
+        try:
+            t2, f2, _ = eng.vit.forward_batch(pix, grids, capture="all")
+            assert torch.equal(t0, t2) and all(torch.equal(a, b) for a, b in zip(f0, f2))
+        finally:
+            for b, (x, y) in zip(st._blocks, saved):
+                b.wqkv_hm, b.bqkv_hm = x, y
+
+
 def test_davit_fpn_projector_entries_bitwise(stage_switch):
     cfg, eng = build()
     g = torch.Generator().manual_seed(4)

@@ -5,8 +5,8 @@
 // same order with the same arguments: results are bit-identical to that path (tests/test_stage_abi_gpu.py), and the calls are
 // asynchronous on the caller's stream and safe to capture in a hipGraph (no allocation, no synchronisation, no memset node).
 // Round 5's fused forms: fo1_llm_prefill takes the q/k/v epilogue (fo1_qkv_proj_rope_bf16) and the DaViT / SimpleFPN entries the
-// implicit-GEMM convolution (index tables filled on the device) under the mirror's own rules; fo1_vit_forward keeps GEMM +
-// fo1_qkv_post_vit_bf16 (the head-major weight copy is not in its weight table) — the same bits either way.
+// implicit-GEMM convolution (index tables filled on the device) under the mirror's own rules, fo1_vit_forward the q/k/v epilogue when
+// its weight table carries the head-major copy (wqkv_hm, ABI 7) — the same bits as the two-launch forms either way.
 //
 // Reference call sites replaced:
 //   fo1_vit_forward      Qwen2_5_VisionTransformerPretrainedModel.forward  modeling_qwen2_5_vl.py:436-504 (blocks :306-357,
@@ -55,7 +55,8 @@ static size_t vit_layout(const fo1_vit_weights_t* w, int S, int Sp, void* ws, si
     *xa = c.take(bf16_rows(S, d));
     *xb = c.take(bf16_rows(S, d));
     *h = c.take(bf16_rows(S, d));
-    *qkv = c.take(bf16_rows(S, 3 * d));
+    const bool hm = w->blocks && w->depth > 0 && w->blocks[0].wqkv_hm;      // head-major q/k/v copy present: rows of 256 columns per head
+    *qkv = c.take(bf16_rows(S, hm && 256 * w->n_heads > 3 * d ? 256 * w->n_heads : 3 * d));
     *att = c.take(bf16_rows(S, d));
     *a = c.take(bf16_rows(S, w->ff_padded));
     *vt = c.take(bf16_rows(d, Sp));
@@ -94,17 +95,28 @@ int fo1_vit_forward(const fo1_vit_weights_t* w, const fo1_vit_plan_t* g, const v
     FO1_TRY(fo1_gemm_bf16_ws(xin, w->k_in_padded, w->patch_w, w->k_in_padded, nullptr, nullptr, 0, x, d, S, d, w->k_in_padded, 0, 0, gws, kGemmScratch, stream));
     const float scale = (float)(1.0 / sqrt((double)hd));   // rounded once from double, like the Python mirror's argument
     int n_cap = 0;
+    const bool fused_qkv = hd == 80 && d % 64 == 0 && fo1_gemm_takes_big_tile(S, 3 * d, d) == 1;
     for (int i = 0; i < w->depth; ++i) {
         const fo1_vit_block_t& b = w->blocks[i];
         bool full = false;
         for (int k = 0; k < w->n_fullatt; ++k) full = full || (w->fullatt[k] == i);
         FO1_TRY(fo1_rmsnorm_bf16(x, d, b.n1, h, d, S, d, 1e-6f, stream));
-        FO1_TRY(fo1_gemm_bf16_ws(h, d, b.wqkv, d, b.bqkv, nullptr, 0, qkv, 3 * d, S, 3 * d, d, 0, 0, gws, kGemmScratch, stream));
-        FO1_TRY(fo1_qkv_post_vit_bf16(qkv, 3 * d, H, hd, g->cos, g->sin, S, vt, Sp, stream));   // 2-D RoPE on q/k + V -> V^T
-        FO1_TRY(fo1_attention_bf16(qkv, 3 * d, hd, (const uint16_t*)qkv + d, 3 * d, hd, vt, Sp, att, d, hd,
-                                   full ? g->items_full : g->items_win, full ? g->n_items_full : g->n_items_win,
-                                   full ? g->q_block_full : g->q_block_win, H, H, hd, scale, 0, nullptr,
-                                   full ? g->flops_full : g->flops_win, stream));
+        if (fused_qkv && b.wqkv_hm && b.bqkv_hm) {
+            // 2-D RoPE + V -> V^T in the q/k/v GEMM's epilogue (vit.py's rule: the same bits, one launch and one pass over [S, 3 d] less); q and k of
+            // head j sit at columns 256 j and 256 j + 80 of the head-major rows
+            FO1_TRY(fo1_qkv_proj_rope_bf16(h, d, b.wqkv_hm, d, b.bqkv_hm, qkv, 256 * H, S, 256 * H, d, 1, H, H, g->cos, g->sin, nullptr, 0, 0, vt, Sp, stream));
+            FO1_TRY(fo1_attention_bf16(qkv, 256 * H, 256, (const uint16_t*)qkv + hd, 256 * H, 256, vt, Sp, att, d, hd,
+                                       full ? g->items_full : g->items_win, full ? g->n_items_full : g->n_items_win,
+                                       full ? g->q_block_full : g->q_block_win, H, H, hd, scale, 0, nullptr,
+                                       full ? g->flops_full : g->flops_win, stream));
+        } else {
+            FO1_TRY(fo1_gemm_bf16_ws(h, d, b.wqkv, d, b.bqkv, nullptr, 0, qkv, 3 * d, S, 3 * d, d, 0, 0, gws, kGemmScratch, stream));
+            FO1_TRY(fo1_qkv_post_vit_bf16(qkv, 3 * d, H, hd, g->cos, g->sin, S, vt, Sp, stream));   // 2-D RoPE on q/k + V -> V^T
+            FO1_TRY(fo1_attention_bf16(qkv, 3 * d, hd, (const uint16_t*)qkv + d, 3 * d, hd, vt, Sp, att, d, hd,
+                                       full ? g->items_full : g->items_win, full ? g->n_items_full : g->n_items_win,
+                                       full ? g->q_block_full : g->q_block_win, H, H, hd, scale, 0, nullptr,
+                                       full ? g->flops_full : g->flops_win, stream));
+        }
         FO1_TRY(fo1_gemm_bf16_ws(att, d, b.wo, d, b.bo, x, d, xn, d, S, d, d, 0, 0, gws, kGemmScratch, stream));
         { void* t = x; x = xn; xn = t; }
         FO1_TRY(fo1_rmsnorm_bf16(x, d, b.n2, h, d, S, d, 1e-6f, stream));

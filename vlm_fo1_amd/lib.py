@@ -40,7 +40,7 @@ class HfreOpts(ctypes.Structure):
 
 class VitBlock(ctypes.Structure):
     """fo1_vit_block_t"""
-    _fields_ = [(n, c_void_p) for n in ("n1", "n2", "wqkv", "bqkv", "wo", "bo", "wgu", "bgu", "wd", "bd")]
+    _fields_ = [(n, c_void_p) for n in ("n1", "n2", "wqkv", "bqkv", "wo", "bo", "wgu", "bgu", "wd", "bd", "wqkv_hm", "bqkv_hm")]
 
 
 class VitWeights(ctypes.Structure):

@@ -62,6 +62,8 @@ class VitStage:
         for i, w in enumerate(vit.blocks):
             for k in ("n1", "n2", "wqkv", "bqkv", "wo", "bo", "wgu", "bgu", "wd", "bd"):
                 setattr(self._blocks[i], k, w[k].data_ptr())
+            for k in ("wqkv_hm", "bqkv_hm"):      # head-major copy for the fused q/k/v epilogue (ABI 7), when the tower built one
+                setattr(self._blocks[i], k, w[k].data_ptr() if w.get(k) is not None else None)
         W = _lib.VitWeights()
         W.depth, W.hidden, W.n_heads, W.ff_padded = c.depth, c.hidden_size, c.num_heads, vit.ffp
         W.k_in, W.k_in_padded, W.merge, W.out_hidden = vit.k_in, vit.k_in_p, c.spatial_merge_size, c.out_hidden_size
