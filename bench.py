@@ -745,6 +745,19 @@ def cpu_baseline(case, pipe, reps=3, decode_tokens=64):
     if dec is not None:
         out["decode_seconds_per_token"] = round(dec, 4)
         out["images_per_sec_with_%d_token_answer" % decode_tokens] = round(1.0 / (total + decode_tokens * dec), 4)
+    # `kind: reference` cannot be timed here (/root/reference does not exist on the GPU box).  The committed check from the build container,
+    # where it does: the reference's own modules against this port on the same workload and host threads (scripts/cpu_reference_vs_port.py)
+    try:
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_cpu_baseline_reference_vs_port_build_container.json")) as f:
+            chk = json.load(f)
+        out["reference_modules_check"] = dict(
+            source="profiles/r05_cpu_baseline_reference_vs_port_build_container.json (build container, %d threads; NOT timed in this run)" % chk["host_threads"],
+            reference_modules_seconds_per_image=chk["reference_modules"]["seconds_per_image"], port_seconds_per_image=chk["oracle_port"]["seconds_per_image"],
+            port_over_reference_seconds=chk["port_over_reference_seconds"],
+            same_first_token=chk["first_token_reference"] == chk["first_token_port"],
+            note="the port is the faster of the two on the same cores, so `value` is, if anything, a stronger CPU baseline than the reference's own modules")
+    except (OSError, ValueError, KeyError):
+        pass
     return out
 
 
