@@ -856,6 +856,8 @@ def main():
                     "streams); 1 = strictly one pass at a time")
     ap.add_argument("--pool-slots", type=int, default=128, choices=[0, 64, 128], help="end_to_end: slots of the decode pool the passes' sequences "
                     "join (continuous batching, vlm_fo1_amd/serving.py); 0 = every pass decodes its own group of <= 32 (round 3's form)")
+    ap.add_argument("--e2e-passes", type=int, default=0, help="end_to_end: timed passes (0 = min(steps, 24)); a longer loop weighs the decode pool's fill / drain "
+                    "phases at its two ends less (side measurement: the default line keeps 24)")
     ap.add_argument("--driver-items", type=int, default=768, help="driver_level: images of the synthetic COCO-shaped dataset run through "
                     "evaluation/eval_coco.py's own loop (0 = skip)")
     ap.add_argument("--driver-count-items", type=int, default=-1, help="driver_level_countbench: items per dataset of evaluation/eval_countbench.py's own loop on the "
@@ -1101,7 +1103,7 @@ def main():
                                  for i in range(B, BatchDecoder.MAX_BATCH)]
         # continuous batching (round 4): one decode pool of 128 slots per GPU, fed by the replicas' prefill passes; more passes than the
         # static form so that the pool's fill / drain phases at the two ends of the timed loop weigh little
-        e2e = end_to_end_run(pipe, e2e_cases, steps=max(8, min(args.steps, 24)), K=64, pool_slots=args.pool_slots)
+        e2e = end_to_end_run(pipe, e2e_cases, steps=(args.e2e_passes if args.e2e_passes > 0 else max(8, min(args.steps, 24))), K=64, pool_slots=args.pool_slots)
         if args.pool_slots:
             e2e["static_groups"] = end_to_end_run(pipe, e2e_cases, steps=max(4, min(args.steps, 12)), K=64, pool_slots=0)
 
