@@ -103,3 +103,60 @@ def test_conv_plan_outlives_its_cache_entry_through_the_pass_keep_list():
     assert keep[0] is pl and pl.rowmap.numel() == 60               # ... while the pass's list still owns the old tables
     ops.keep_alive(object())                                       # outside a scope: a no-op
     assert len(keep) == 1
+
+
+def test_split_passes_respects_request_and_row_budgets_and_keeps_order():
+    """FO1Engine.split_passes (host logic): <= PREFILL_MAX requests and <= PREFILL_ROWS ViT patch rows per packed pass, prompts over ONE image
+    count its rows once, a request larger than the budget is its own pass, request order is kept."""
+    from types import SimpleNamespace
+    from vlm_fo1_amd.model import FO1Engine
+    eng = SimpleNamespace(PREFILL_MAX=4, PREFILL_ROWS=1000)
+    split = lambda reqs: FO1Engine.split_passes(eng, reqs)
+    r = lambda k, gh, gw, image_id=None: dict(k=k, grid=(gh, gw), image_id=image_id)
+    assert split([]) == []
+    # request budget
+    out = split([r(i, 10, 10) for i in range(9)])
+    assert [[q["k"] for q in g] for g in out] == [[0, 1, 2, 3], [4, 5, 6, 7], [8]]
+    # row budget: 400 + 400 fit, the third 400 opens a new pass; a 2 000-row request is alone
+    out = split([r(0, 20, 20), r(1, 20, 20), r(2, 20, 20), r(3, 40, 50), r(4, 10, 10)])
+    assert [[q["k"] for q in g] for g in out] == [[0, 1], [2], [3], [4]]
+    # three prompts over one image: its 900 rows count once, so a 100-row image still fits beside them
+    out = split([r(0, 30, 30, "a"), r(1, 30, 30, "a"), r(2, 30, 30, "a"), r(3, 10, 10)])
+    assert [[q["k"] for q in g] for g in out] == [[0, 1, 2, 3]]
+    # ... and when the group is cut by the request budget the image's rows are counted again in the next pass
+    eng.PREFILL_MAX = 2
+    out = split([r(0, 30, 30, "a"), r(1, 30, 30, "a"), r(2, 30, 30, "a"), r(3, 20, 20)])
+    assert [[q["k"] for q in g] for g in out] == [[0, 1], [2], [3]]
+
+
+def test_attention_work_list_block_choice_and_lpt_order(monkeypatch):
+    """ops.pick_q_block / order_items / make_items (host logic of the attention work lists, round 5)."""
+    import torch
+    from vlm_fo1_amd import ops
+    monkeypatch.delenv("FO1_ATTN32", raising=False)
+    # LLM prefill: head dim 128, grouped-query (16 q heads on 2 kv heads) -> 128 queries x the 2 heads of a kv head
+    assert ops.pick_q_block([(0, 651)], 16, 128, 2) == 128
+    assert ops.pick_q_block([(0, 64)], 16, 128, 2) == 64             # a segment of one key tile stays on the 16x16 kernel
+    # ViT: head dim 80, no grouping -> 256 queries of one head for full attention, 64 for the 64-token windows
+    assert ops.pick_q_block([(0, 1564)], 16, 80) == 256
+    assert ops.pick_q_block([(0, 64), (64, 128)], 16, 80) == 64
+    assert ops.pick_q_block([(0, 5000)], 8, 32) == 64                # DaViT's head dim: always the 16x16 kernel
+    monkeypatch.setenv("FO1_ATTN32", "0")
+    assert ops.pick_q_block([(0, 651)], 16, 128, 2) == 64
+    monkeypatch.delenv("FO1_ATTN32")
+    # items: every query exactly once, blocks within their segment, longest walk first when causal (LPT over the launch)
+    segs = [(0, 652), (652, 1304), (1304, 1400)]
+    it = ops.make_items(segs, "cpu", causal=True, block=128)
+    assert it.q_block == 128 and it.dtype == torch.int32
+    rows = it.tolist()
+    covered = sorted(q for q0, q1, _, _ in rows for q in range(q0, q1))
+    assert covered == list(range(1400))
+    assert all(k0 <= q0 < q1 <= k1 and q1 - q0 <= 128 and (k0, k1) in segs for q0, q1, k0, k1 in rows)
+    tiles = [(q1 - k0 + 63) // 64 for q0, q1, k0, k1 in rows]
+    assert tiles == sorted(tiles, reverse=True)
+    # the 16x16 kernel's lists keep segment order (its grid is not walked longest-first)
+    it64 = ops.make_items(segs, "cpu", causal=True, block=64)
+    assert it64.tolist()[0][:2] == [0, 64] and it64.tolist()[-1][1] == 1400
+    # a second key range (shared prefix) counts in the walk
+    order = ops.order_items([[0, 128, 0, 128], [128, 256, 128, 256]], 128, True, prefix=[[0, 0], [0, 4096]])
+    assert order == [1, 0]
