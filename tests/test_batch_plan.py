@@ -160,3 +160,30 @@ def test_attention_work_list_block_choice_and_lpt_order(monkeypatch):
     # a second key range (shared prefix) counts in the walk
     order = ops.order_items([[0, 128, 0, 128], [128, 256, 128, 256]], 128, True, prefix=[[0, 0], [0, 4096]])
     assert order == [1, 0]
+
+
+def test_conv_plan_tables_address_exactly_the_im2col_matrix():
+    """ops.Conv3x3Plan on the host: writing a map's pixels to rowmap[...] of the zero-framed buffer and reading the nine taps of output pixel m
+    at a_rows[m] + (ky * Wp + kx) * Cin * 2 bytes reproduces F.unfold(pad 1, kernel 3) — for stride 1 and 2, and for images of different sizes
+    packed into one buffer with a common row pitch."""
+    import torch
+    import torch.nn.functional as F
+    from vlm_fo1_amd import ops
+    g = torch.Generator().manual_seed(12)
+    cin = 64
+    for sizes, stride in ((((5, 7),), 1), (((6, 8), (6, 8)), 2), (((4, 9), (7, 3), (5, 5)), 1), (((9, 4), (3, 11)), 2)):
+        pl = ops.conv3x3_plan(sizes, stride, cin, "cpu")
+        maps = [torch.randn(h, w, cin, generator=g) for h, w in sizes]
+        xpad = torch.zeros(pl.pad_rows, cin)
+        xpad[pl.rowmap.long()] = torch.cat([m.reshape(-1, cin) for m in maps])                       # what layernorm_rows does with its output rows
+        a = (pl.a_rows.numpy().view("uint32").astype("int64") // (cin * 2))                          # tap-0 row of every output pixel
+        assert (pl.a_rows.numpy().view("uint32").astype("int64") % (cin * 2) == 0).all()
+        col = torch.stack([xpad[torch.from_numpy(a + ky * pl.Wp + kx)] for ky in range(3) for kx in range(3)], 1)   # [M_out, 9, cin]: K order (ky, kx, c)
+        ref = []
+        for m in maps:
+            u = F.unfold(m.permute(2, 0, 1)[None], kernel_size=3, padding=1, stride=stride)[0]       # [cin * 9, Ho * Wo], rows (c, ky, kx)
+            ref.append(u.reshape(cin, 9, -1).permute(2, 1, 0))                                       # -> [Ho * Wo, 9, cin]
+        ref = torch.cat(ref)
+        assert col.shape == ref.shape == (pl.M_out, 9, cin)
+        assert torch.equal(col, ref), (sizes, stride)
+        assert pl.out_hw == [((h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1) for h, w in sizes]

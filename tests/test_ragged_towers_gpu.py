@@ -95,6 +95,40 @@ def test_fpn_ragged_pass_equals_one_image_passes(towers):
             assert torch.equal(maps[l][r0:r0 + h * w], ref[l]), f"image {b} (grid {grids[b]}) level {l}: ragged FPN differs from the one-image pass"
 
 
+def test_ragged_passes_take_the_implicit_convolution_bitwise(towers, monkeypatch):
+    """Ragged packs big enough for the 256 x 256 GEMM kernel (unpinned): DaViT's pre-norm ConvEmbed of stage 1 and the 3x3 output convolutions of
+    the finer FPN levels run as implicit GEMMs over ONE zero-framed buffer with a common row pitch (ops.Conv3x3Plan over images of different
+    sizes) — the same bits as layernorm + im2col_var + gemm (FO1_CONV_IMPLICIT=0)."""
+    from vlm_fo1_amd import ops
+    davit, fpn = towers
+    g = torch.Generator().manual_seed(8)
+    sizes = [(480, 640), (399, 500), (640, 480), (420, 420), (333, 711), (480, 640), (512, 384)]
+    imgs = [torch.randn(3, H, W, generator=g).bfloat16().cuda() for H, W in sizes]
+    grids = [(34, 46), (28, 36), (46, 34), (30, 30), (24, 50), (34, 46)]
+    xs = torch.cat([torch.randn(gh * gw, 1280, generator=g).bfloat16().cuda() for gh, gw in grids], 0)
+    row0, off = [], 0
+    for gh, gw in grids:
+        row0.append(off)
+        off += gh * gw
+    lv0 = [((H + 2 * 3 - 7) // 4 + 1, (W + 2 * 3 - 7) // 4 + 1) for H, W in sizes]                   # DaViT stage-0 maps = the input of stage 1's 3x3 / stride 2 embed
+    assert ops.conv3x3_implicit_for(lv0, 2, 512, 256, 3, 1), "the test's pack must be large enough for the implicit form"
+    assert ops.conv3x3_implicit_for([(4 * a, 4 * b) for a, b in grids], 1, 512, 512, 3, 1)
+
+    def run():
+        m, _ = davit.forward_ragged(imgs)
+        f, _ = fpn.forward_ragged(xs, grids, row0)
+        torch.cuda.synchronize()
+        return [t.clone() for t in m], [t.clone() for t in f]
+
+    m1, f1 = run()
+    monkeypatch.setenv("FO1_CONV_IMPLICIT", "0")
+    m0, f0 = run()
+    for l, (a, b) in enumerate(zip(m1, m0)):
+        assert torch.equal(a, b), f"DaViT level {l}: implicit vs im2col_var"
+    for l, (a, b) in enumerate(zip(f1, f0)):
+        assert torch.equal(a, b), f"FPN level {l}: implicit vs im2col_var"
+
+
 def test_ragged_spatial_kernels_against_torch_references():
     """The geometry-table path of each spatial kernel against plain torch on two images of different sizes (the same-size path has its
     own references in tests/test_vision_ops_gpu.py; here: no cross-image reads, right offsets, per-image channel-attention scale)."""

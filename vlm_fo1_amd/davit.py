@@ -165,12 +165,21 @@ class DaViT:
         for i, C in enumerate(cfg["dims"]):
             cv, lv = self.convs[i], plan.levels[i]
             k, s, p = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
-            if i > 0 and cfg["patch_prenorm"][i]:
-                x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
-            col = ops.im2col_var(x, lv["conv"], k, k, s, p, ld=cv["Kp"])
-            x = ops.gemm(col, cv["w"], cv["b"])
-            if i == 0 or not cfg["patch_prenorm"][i]:
-                x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
+            prev_sizes = plan.in_sizes if i == 0 else plan.sizes[i - 1]
+            if i > 0 and cfg["patch_prenorm"][i] and cv["Kp"] == k * k * x.shape[1] and ops.conv3x3_implicit_for(prev_sizes, s, C, x.shape[1], k, p):
+                # pre-norm ConvEmbed as an implicit GEMM over the ragged pack (as forward() does for uniform batches): one zero-framed buffer with a
+                # common row pitch, the same bits as layernorm + im2col_var + gemm without the [M, 9 Cin] column matrix
+                cp = ops.conv3x3_plan(prev_sizes, s, x.shape[1], self.dev)
+                assert cp.out_hw == [tuple(t) for t in plan.sizes[i]] and cp.M_in == x.shape[0]
+                xp = ops.layernorm_rows(x, cv["nw"], cv["nb"], 1e-5, torch.zeros(cp.pad_rows, x.shape[1], dtype=torch.bfloat16, device=self.dev), cp.rowmap)
+                x = ops.conv3x3_gemm(xp, cp, cv["w"], cv["b"])
+            else:
+                if i > 0 and cfg["patch_prenorm"][i]:
+                    x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
+                col = ops.im2col_var(x, lv["conv"], k, k, s, p, ld=cv["Kp"])
+                x = ops.gemm(col, cv["w"], cv["b"])
+                if i == 0 or not cfg["patch_prenorm"][i]:
+                    x = ops.layernorm(x, cv["nw"], cv["nb"], 1e-5)
             for blk in self.blocks[i]:
                 x = self._spatial_var(x, lv, C, cfg["heads"][i], blk["spatial_block"])
                 x = self._channel_var(x, lv, C, blk["channel_block"])
@@ -194,7 +203,7 @@ class DaViT:
             cv = self.convs[i]
             k, s, p = cfg["patch_size"][i], cfg["patch_stride"][i], cfg["patch_padding"][i]
             Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-            if i > 0 and cfg["patch_prenorm"][i] and cv["Kp"] == k * k * x.shape[1] and ops.conv3x3_implicit_ok(B * Ho * Wo, C, x.shape[1], k, p):
+            if i > 0 and cfg["patch_prenorm"][i] and cv["Kp"] == k * k * x.shape[1] and ops.conv3x3_implicit_for(((H, W),) * B, s, C, x.shape[1], k, p):
                 # pre-norm ConvEmbed (modeling_davit.py:102-148) as an implicit GEMM: the LayerNorm writes the zero-padded map, the 256 x 256 GEMM
                 # gathers its 9 taps from it — no [M, 9 Cin] column matrix (same bits as layernorm + im2col + gemm)
                 pl = ops.conv3x3_plan(((H, W),) * B, s, x.shape[1], self.dev)

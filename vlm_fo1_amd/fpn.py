@@ -52,7 +52,7 @@ class SimpleFPN:
     def _head(self, x, H, W, h, B=1):
         y = ops.gemm(x, h["w1"])
         C = y.shape[1]
-        if ops.conv3x3_implicit_ok(B * H * W, h["w3"].shape[0], C, 3, 1):
+        if ops.conv3x3_implicit_for(((H, W),) * B, 1, h["w3"].shape[0], C, 3, 1):
             # the 3x3 output convolution (simple_fpn.py:141-176) as an implicit GEMM: the channel LayerNorm writes the zero-padded map, the GEMM
             # gathers its taps from it (no im2col matrix: 2.2 GB per launch at the finest level); same bits as layernorm + im2col + gemm
             pl = ops.conv3x3_plan(((H, W),) * B, 1, C, y.device)
@@ -75,11 +75,19 @@ class SimpleFPN:
             pl = plans[key] = RaggedFpnPlan(key[0], key[1], self.dev)
         return pl
 
-    def _head_var(self, x, sg, h):
+    def _head_var(self, x, sg, h, sizes):
         y = ops.gemm(x, h["w1"])
-        y = ops.layernorm(y, h["n1"][0], h["n1"][1], 1e-6)
-        col = ops.im2col_var(y, sg, 3, 3, 1, 1)
-        y = ops.gemm(col, h["w3"])
+        C = y.shape[1]
+        if ops.conv3x3_implicit_for(sizes, 1, h["w3"].shape[0], C, 3, 1):
+            # the 3x3 output convolution as an implicit GEMM over the ragged pack (levels are packed back to back, image by image: RaggedFpnPlan)
+            cp = ops.conv3x3_plan(sizes, 1, C, y.device)
+            assert cp.M_in == y.shape[0]
+            yp = ops.layernorm_rows(y, h["n1"][0], h["n1"][1], 1e-6, torch.zeros(cp.pad_rows, C, dtype=torch.bfloat16, device=y.device), cp.rowmap)
+            y = ops.conv3x3_gemm(yp, cp, h["w3"])
+        else:
+            y = ops.layernorm(y, h["n1"][0], h["n1"][1], 1e-6)
+            col = ops.im2col_var(y, sg, 3, 3, 1, 1)
+            y = ops.gemm(col, h["w3"])
         return ops.layernorm(y, h["n3"][0], h["n3"][1], 1e-6)
 
     def forward_ragged(self, x: torch.Tensor, grids, row0):
@@ -96,12 +104,12 @@ class SimpleFPN:
         y = ops.layernorm(y, self.t1_ln[0], self.t1_ln[1], 1e-6)
         y = ops.bias_act(y, None, 1)
         y = up(y, pl.up_1b, self.t1b)
-        outs.append(self._head_var(y, pl.conv[0], self.heads[0]))
+        outs.append(self._head_var(y, pl.conv[0], self.heads[0], pl.sizes[0]))
         y = up(x, pl.up_1a, self.t2)
-        outs.append(self._head_var(y, pl.conv[1], self.heads[1]))
-        outs.append(self._head_var(x, pl.conv[2], self.heads[2]))
+        outs.append(self._head_var(y, pl.conv[1], self.heads[1], pl.sizes[1]))
+        outs.append(self._head_var(x, pl.conv[2], self.heads[2], pl.sizes[2]))
         y = ops.maxpool2_var(x, pl.pool)
-        outs.append(self._head_var(y, pl.conv[3], self.heads[3]))
+        outs.append(self._head_var(y, pl.conv[3], self.heads[3], pl.sizes[3]))
         return outs, pl
 
     def forward(self, x: torch.Tensor, H: int, W: int, batch: int = 1) -> Tuple[List[torch.Tensor], List[Tuple[int, int]]]:

@@ -395,6 +395,18 @@ def conv3x3_implicit_ok(M_out: int, cout: int, cin: int, k: int, pad: int) -> bo
             and bool(_L.load().fo1_gemm_takes_big_tile(int(M_out), int(cout), 9 * int(cin))))
 
 
+def conv3x3_implicit_for(sizes, stride: int, cout: int, cin: int, k: int, pad: int) -> bool:
+    """conv3x3_implicit_ok for images of `sizes` [(H, W)] packed row-wise (uniform or ragged), including the 32-bit byte offsets of the padded
+    map (Conv3x3Plan): False sends the caller to im2col + GEMM, the same bits."""
+    if k != 3 or pad != 1:
+        return False
+    Wp = max(int(w) for _, w in sizes) + 2
+    if sum(int(h) + 2 for h, _ in sizes) * Wp * int(cin) * 2 >= 2 ** 32:
+        return False
+    M_out = sum(((int(h) + 2 - 3) // stride + 1) * ((int(w) + 2 - 3) // stride + 1) for h, w in sizes)
+    return conv3x3_implicit_ok(M_out, cout, cin, k, pad)
+
+
 def conv3x3_gemm(xpad: torch.Tensor, plan: Conv3x3Plan, w: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE) -> torch.Tensor:
     """3x3 convolution of the zero-padded map `xpad` [plan.pad_rows, Cin] (layernorm_rows wrote it) as an implicit GEMM: -> [plan.M_out, Cout]."""
     _chk(xpad, "xpad"); _chk(w, "w")
