@@ -838,6 +838,92 @@ def pmc_traffic(kernel_name):
     return None, None
 
 
+# ---- the printed line (VERDICT r5 #2b): the driver keeps the LAST 2000 characters of stdout next to the parsed contract keys, so the line is
+# kept small (<= ~6 KB: verbose per-kernel tables, notes and loop descriptions go to --json-out) and the user-visible figures are
+# repeated in ONE flat `summary` object that is printed last ----
+_VERBOSE_KEYS = ("note", "loop", "includes", "excludes", "prefix_sharing", "decode", "launch", "packing", "what", "sample", "data")
+
+
+def compact_line(full: dict) -> dict:
+    """The contract line: every contract key of `full` unchanged, nested blocks without their prose (`note`, `loop`, ... and any string
+    longer than 120 characters) and without the per-kernel tables (`roofline.per_step_ms` / `launches`: in --json-out), then `summary`."""
+    def strip(o, top=False):
+        if isinstance(o, dict):
+            out = {}
+            for k, v in o.items():
+                if not top and (k in _VERBOSE_KEYS or k.endswith("_note")) and isinstance(v, (str, list)):
+                    continue
+                if top and (k in ("config", "cpu_baseline") or not isinstance(v, (dict, list))):
+                    out[k] = v              # contract keys verbatim (config.workload, cpu_baseline.sample are prose the contract asks for)
+                    continue
+                if isinstance(v, str) and len(v) > 120:
+                    v = v[:117] + "..."
+                out[k] = strip(v)
+            return out
+        if isinstance(o, list):
+            return [strip(v) for v in o]
+        if isinstance(o, float):
+            return float(f"{o:.6g}")
+        return o
+    line = strip(full, top=True)
+    roof = line.get("roofline")
+    if isinstance(roof, dict):
+        roof.pop("per_step_ms", None)
+        roof.pop("launches", None)
+    cfg = line.get("config")
+    if isinstance(cfg, dict):
+        cfg.pop("stages", None)
+    line.pop("stage_kernel_ms_note", None)
+
+    def g(*path):
+        o = full
+        for k in path:
+            if not isinstance(o, dict) or o.get(k) is None:
+                return None
+            o = o[k]
+        return float(f"{o:.5g}") if isinstance(o, float) else o
+    summary = dict(
+        value_images_per_sec=g("value"), ms_per_step=g("ms_per_step"),
+        end_to_end_images_per_sec=g("end_to_end", "images_per_sec"), end_to_end_pool_mean_live=g("end_to_end", "pool_mean_live_sequences"),
+        end_to_end_static_groups_images_per_sec=g("end_to_end", "static_groups", "images_per_sec"),
+        driver_level_images_per_sec=g("driver_level", "images_per_sec"), driver_level_vs_end_to_end=g("driver_level", "vs_end_to_end"),
+        driver_level_host_threads_per_gpu=g("driver_level", "host_threads_per_gpu"),
+        reference_literal_batch1_loop_images_per_sec=g("driver_level", "reference_literal_batch1_loop_images_per_sec"),
+        countbench_driver_images_per_sec=g("driver_level_countbench", "countbench", "images_per_sec"),
+        pixmo_driver_images_per_sec=g("driver_level_countbench", "pixmo", "images_per_sec"),
+        hires_bf16_images_per_sec=g("hires", "bf16", "images_per_sec"), hires_fp8_images_per_sec=g("hires", "fp8", "images_per_sec"),
+        hires_end_to_end_images_per_sec=g("hires", "end_to_end", "images_per_sec"),
+        one_image_ms=g("one_image_at_a_time", "ms_per_image"), one_pass_images_per_sec=g("one_pass_at_a_time", "images_per_sec"),
+        dataset_images_per_sec=g("dataset", "images_per_sec"), dataset_vs_uniform=g("dataset", "vs_uniform_headline"),
+        decode_ms_per_token=g("decode", "ms_per_token"), decode_hbm_frac=g("decode", "roofline", "frac"),
+        decode_batched_sequences=g("decode", "batched", "sequences"), decode_batched_ms_per_step=g("decode", "batched", "ms_per_step"),
+        decode_batched_hbm_frac=g("decode", "batched", "roofline", "frac"),
+        decode_pool_ms_per_step=g("decode", "pool", "ms_per_step"), decode_pool_tokens_per_sec=g("decode", "pool", "tokens_per_sec"),
+        decode_pool_hbm_frac=g("decode", "pool", "roofline", "frac"),
+        scale_images_per_sec=g("scale", "images_per_sec"), scale_world=g("scale", "world_size"),
+        gemm_frac_of_peak=g("roofline", "frac"), gemm_frac_of_sustained=g("roofline", "sustained_mfma", "frac_of_random_operand_rate"),
+        all_gemm_tflops=g("roofline", "all_gemm_tiles", "tflops"), hfre_hbm_frac=g("roofline", "hfre", "frac"),
+        hfre_us_all_launches=g("roofline", "hfre", "us_all_launches"),
+        cpu_baseline_images_per_sec=g("cpu_baseline", "value"), cpu_baseline_cores=g("cpu_baseline", "cores"))
+    line["summary"] = {k: v for k, v in summary.items() if v is not None}
+    return line
+
+
+def emit(full: dict, json_out: str) -> None:
+    """Full record -> json_out (per-kernel tables, notes, loop descriptions); compact contract line -> stdout (ONE line, last)."""
+    if json_out:
+        try:
+            d = os.path.dirname(json_out)
+            if d:
+                os.makedirs(d, exist_ok=True)
+            with open(json_out, "w") as f:
+                json.dump(full, f, indent=1)
+            full = dict(full, full_record=json_out)
+        except OSError as e:
+            full = dict(full, full_record=f"not written: {e}")
+    print(json.dumps(compact_line(full), separators=(",", ":")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -864,6 +950,8 @@ def main():
                     "CountBench and Pixmo-Count fixtures as files (-1 = all 487 + 529; 0 = skip)")
     ap.add_argument("--scale-items", type=int, default=256, help="multi-rank runs: images PER GPU of the `scale` block (evaluation/eval_coco.py's loop through "
                     "sharded_eval.run_sharded across the ranks, one all_gather at the reducer); a multiple of 32; 0 = skip")
+    ap.add_argument("--json-out", default="gpurun_out/bench_full.json", help="the FULL record (per-kernel tables, notes, loop descriptions); stdout carries the "
+                    "compact contract line whose last object, `summary`, repeats the user-visible figures ('' = do not write)")
     ap.add_argument("--no-hires", action="store_true", help="skip the `hires` block (BASELINE configs[4]'s geometry: 1344x1344 x 300 proposals, bf16 and fp8 linears)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--main-only", action="store_true", help="skip the side measurements (one image / one pass at a time, decode loops, preprocessing): "
@@ -1290,7 +1378,7 @@ def main():
             out["stage_kernel_ms_note"] = f"kernel time per packed pass of {B} images"
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(case, pipe, reps=args.cpu_reps, decode_tokens=args.cpu_decode_tokens)
-        print(json.dumps(out))
+        emit(out, args.json_out)
     if world > 1:
         torch.distributed.barrier()   # ranks leave together (rank 0 was still measuring decode / roofline)
         torch.distributed.destroy_process_group()

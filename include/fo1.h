@@ -22,6 +22,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default) /* libfo1hip*.so are built with -fvisibility=hidden: exactly the declarations of this header are exported */
+#endif
 
 #define FO1_ABI_VERSION 7   /* 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
@@ -293,7 +296,10 @@ int fo1_gemv_bf16(const void* x, int ldx, const void* W, int ldw, const void* bi
  * for short sequences).  q_block 128 or 256 (head_dim 80 / 128, no q_row_base): 32x32-MFMA kernel,
  * 8 waves x 32 queries per workgroup — 256 queries of one head, or 128 queries x the TWO query heads
  * of one KV head (n_q_heads / n_kv_heads even: both heads share the staged K / V^T tiles); O rows are
- * stored in 16-byte pieces (O 16-byte aligned, strides % 8 == 0), K / V^T row strides < 2^22.
+ * stored in 16-byte pieces (O 16-byte aligned, strides % 8 == 0), K / V^T row strides < 2^22, and the
+ * key rows are addressed with unsigned 32-bit byte offsets from the head's K base: every item's
+ * kv_end * k_tok_stride * 2 must stay below 2^32 (the items live on the device, so the CALLER checks:
+ * vlm_fo1_amd/ops.py pick_q_block / _check_attn32_extent fall back to q_block 64 past that).
  * V is passed transposed: VT[(kv_head*head_dim + d)*vt_row_stride + key] (fo1_transpose_bf16),
  * finite beyond kv_end up to the next multiple of 4.  Strides in elements.
  * ---------------------------------------------------------------------- */
@@ -659,6 +665,9 @@ int fo1_topk_desc_f32(const float* scores, int stride, int n, int k, int32_t* id
                       size_t workspace_bytes, void* stream);
 int fo1_gather_rows_f32(const float* table, int ld_table, const int32_t* idx, float* out, int ld_out, int n, int D, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

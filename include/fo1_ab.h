@@ -17,6 +17,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default) /* libfo1hip*.so are built with -fvisibility=hidden: exactly the declarations of this header are exported */
+#endif
 
 /* ---- HFRE gather ---- */
 /* footprint pixels one workgroup streams per row-slice (0 = auto: 256 up to 48 boxes, else 512). */
@@ -88,6 +91,9 @@ int fo1_mfma_clock_probe(int operands, int iters, int workgroups, void* out, voi
 /* Instrumentation (with fo1_profile_enable): per-shape kernel names in the profile rows instead of one row per kernel. */
 int fo1_gemm_profile_shapes(int on);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -23,6 +23,20 @@ def exported(so):
     return sorted({l.split()[-1] for l in out.splitlines() if l.split()[-1].startswith("fo1_") and " T " in l})
 
 
+def all_defined_dynamic_symbols(so):
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "vlm_fo1_amd", so)], capture_output=True, text=True, check=True).stdout
+    return sorted({l.split()[-1] for l in out.splitlines() if l.strip()})
+
+
+def test_export_table_is_exactly_the_headers():
+    """nothing but the declared C entry points leaves the libraries — no un-prefixed helper, no mangled fo1:: internal,
+    no kernel stub or kernel-handle object (-fvisibility=hidden + the headers' visibility pragma + csrc/exports.map)."""
+    prod, ab = declared_symbols(), declared_symbols("fo1_ab.h")
+    assert all_defined_dynamic_symbols("libfo1hip.so") == prod
+    assert all_defined_dynamic_symbols("libfo1hip_ab.so") == sorted(prod + ab)
+
+
 def test_library_exports_every_declared_symbol():
     lib = L.load()              # the test session's library: the PRODUCT build (tests/conftest.py)
     assert lib._name.endswith("libfo1hip.so")

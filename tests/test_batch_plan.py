@@ -129,6 +129,40 @@ def test_split_passes_respects_request_and_row_budgets_and_keeps_order():
     assert [[q["k"] for q in g] for g in out] == [[0, 1], [2], [3]]
 
 
+def test_split_passes_budgets_aux_pixels_too():
+    """the DaViT / SimpleFPN scratch follows the AUX image size (native resolution in `dynamic` mode), so small-grid images with large
+    aux tensors must not share one oversized pass; prompts over one image count its aux pixels once."""
+    from types import SimpleNamespace
+    import torch
+    from vlm_fo1_amd.model import FO1Engine
+    eng = SimpleNamespace(PREFILL_MAX=8, PREFILL_ROWS=10 ** 6, PREFILL_AUX_PIXELS=1000 * 1000)
+    split = lambda reqs: FO1Engine.split_passes(eng, reqs)
+    r = lambda k, h, w, image_id=None: dict(k=k, grid=(4, 4), aux=torch.empty(3, h, w, device="meta"), image_id=image_id)
+    out = split([r(0, 600, 800), r(1, 600, 800), r(2, 600, 800), r(3, 2000, 2000), r(4, 100, 100)])
+    assert [[q["k"] for q in g] for g in out] == [[0, 1], [2], [3], [4]]
+    out = split([r(0, 900, 1000, "a"), r(1, 900, 1000, "a"), r(2, 900, 1000, "a"), r(3, 300, 300)])
+    assert [[q["k"] for q in g] for g in out] == [[0, 1, 2, 3]]
+    # an engine without the budget (older callers' stand-ins) keeps the two other budgets only
+    del eng.PREFILL_AUX_PIXELS
+    assert len(split([r(i, 2000, 2000) for i in range(4)])) == 1
+
+
+def test_attention_32x32_form_is_not_chosen_past_its_32_bit_offsets():
+    """q_block 128 / 256 address key rows with 32-bit byte offsets from the K base; segments ending past 4 GiB / 8 KB rows take the
+    16x16 kernel, and a hand-built item list on such an operand fails loudly."""
+    import pytest
+    from vlm_fo1_amd import ops
+    assert ops.pick_q_block([(0, 1564)], 16, 80) == 256
+    far = 2 ** 32 // ops.ATTN32_MAX_ROW_BYTES
+    assert ops.pick_q_block([(far - 2000, far - 1)], 16, 80) == 256
+    assert ops.pick_q_block([(far - 2000, far)], 16, 80) == 64
+    assert ops.pick_q_block([(far, far + 700)], 16, 128, 2) == 64
+    ops._check_attn32_extent(64, far * 4, 8192)
+    ops._check_attn32_extent(256, far - 1, 8192)
+    with pytest.raises(ValueError, match="32-bit"):
+        ops._check_attn32_extent(256, far, 8192)
+
+
 def test_attention_work_list_block_choice_and_lpt_order(monkeypatch):
     """ops.pick_q_block / order_items / make_items (host logic of the attention work lists, round 5)."""
     import torch

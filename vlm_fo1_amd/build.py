@@ -23,6 +23,7 @@ def _deps():
     deps = sources() + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     deps.append(os.path.join(HERE, "..", "include", "fo1.h"))
     deps.append(os.path.join(HERE, "..", "include", "fo1_ab.h"))
+    deps.append(os.path.join(CSRC, "exports.map"))
     return deps
 
 
@@ -41,14 +42,14 @@ def _build_one(lib: str, objdir: str, defines, force: bool, verbose: bool) -> st
         ):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function"] + list(defines)
+               "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"] + list(defines)
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))
     for src, pr in procs:
         if pr.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", lib] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), "-o", lib] + objs
     subprocess.check_call(cmd)
     return lib
 

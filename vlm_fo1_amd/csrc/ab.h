@@ -3,6 +3,7 @@
 // kernel forms they select are not compiled in.
 #pragma once
 #ifdef FO1_ENABLE_AB
+#include "../../include/fo1_ab.h"   // declarations carry the export visibility (the build is -fvisibility=hidden)
 #define FO1_AB_VAR static int
 #define FO1_AB_EXTERN_VAR int
 #else

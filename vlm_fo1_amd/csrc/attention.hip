@@ -467,7 +467,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd32_kernel(const AttnParams p) 
     typedef __attribute__((ext_vector_type(4))) unsigned int v4u;
     typedef __attribute__((ext_vector_type(2))) unsigned int v2u;
     const int k_tok = (int)p.k_tok, vt_row = (int)p.vt_row;
-    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)VTb, 0, HD * vt_row * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc((void*)VTb, 0, (uint32_t)HD * (uint32_t)vt_row * 2u, 0x00020000);
     uint32_t koff[NKR], voff[NVR];
 #pragma unroll
     for (int i = 0; i < NKR; ++i) {
@@ -485,9 +485,9 @@ __global__ __launch_bounds__(512, 2) void attn_fwd32_kernel(const AttnParams p) 
     v4u rk[NKR];
     v2u rv[NVR];
     auto gload = [&](int k0, int hi_) {
-        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, hi_ * k_tok * 2, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kb, 0, (uint32_t)hi_ * (uint32_t)k_tok * 2u, 0x00020000);   // unsigned: rows up to 4 GiB from the base (host-checked)
 #pragma unroll
-        for (int i = 0; i < NKR; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[i], k0 * k_tok * 2, 0);
+        for (int i = 0; i < NKR; ++i) rk[i] = __builtin_amdgcn_raw_buffer_load_b128(rsK, koff[i], (int)((uint32_t)k0 * (uint32_t)k_tok * 2u), 0);
 #pragma unroll
         for (int i = 0; i < NVR; ++i) rv[i] = __builtin_amdgcn_raw_buffer_load_b64(rsV, voff[i], k0 * 2, 0);
     };

@@ -7,6 +7,7 @@
 #include <stdio.h>
 
 #include "../../include/fo1.h"
+#include "ab.h"   // test / bench build: include/fo1_ab.h (its declarations carry the export visibility)
 
 namespace fo1 {
 

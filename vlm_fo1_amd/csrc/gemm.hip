@@ -2272,6 +2272,22 @@ static int launch_qkv_p4(GemmParams& p, int mode, hipStream_t st) {
     return FO1_OK;
 }
 
+// THE statement of "this [M, K] x [N, K]^T product runs on the 256 x 256 two-phase kernel": gemm_dispatch picks its tile with it and
+// fo1_gemm_takes_big_tile answers callers with it (one predicate, ADVICE r5: the fused q/k/v and implicit-convolution forms are bit-identical to
+// the two-launch forms only while both sides agree).  Inputs beyond the shape: the staging pin (variant 1 = register staging has no 256 x 256
+// form), the tile pin, a forced split-K (the fused epilogues have no split-K form; test / bench build only — constants in the product).
+// large M (batched prefill): the kernel is taken once its tiles fill >= 60 % of the rounds they occupy and at least half the CUs (measured,
+// profiles/r02_gemm_bench_p8_v1.log: LLM o/down at 168 tiles 760 / 1007 TF vs 667 / 684 for the best small tile; merger 260 tiles = 51 % of two
+// rounds loses, 659 vs 894); K >= 256 (nk >= 4): with the two-phase schedule and the coalesced epilogue even four K tiles per output tile beat
+// the 64 x 128 tile (DaViT stage 0 at 25 images: ~400 vs 211 TFLOP/s).
+static inline bool big_tile_rule(int M, int N, int K, int batch) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % 64 != 0 || g_gemm_variant == 1) return false;
+    if (g_gemm_tile != 0) return g_gemm_tile == 5;
+    const int nk = K / 64;
+    const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 256) * batch;
+    return nk >= 4 && M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6;
+}
+
 int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws_bytes) {
     bool glds = (p.K % 64 == 0);
     if (g_gemm_variant == 1) glds = false;
@@ -2298,17 +2314,11 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         tile = (t128 >= 768 && nk >= 16) ? 1 : (t64x128 >= 512 ? 2 : 3);   // shallow K (DaViT stage 0, K=256): 64x128 wins
         if (glds && nk >= 16 && (long long)cdiv(p.M, 128) * cdiv(p.N, 256) * batch >= 1024) tile = 4;
         if (splits == 0 && can_split && nk >= 64 && t64x128 < 512) tile = 2;
-        // large M (batched prefill): the 256 x 256 ping-pong kernel once its tiles fill >= 60 % of the rounds they occupy and at
-        // least half the CUs (measured, profiles/r02_gemm_bench_p8_v1.log: LLM o/down at 168 tiles 760 / 1007 TF vs 667 / 684 for the
-        // best small tile; merger 260 tiles = 51 % of two rounds loses, 659 vs 894)
-        // K >= 256 (nk >= 4): with the two-phase schedule and the coalesced epilogue even four K tiles per output tile beat the 64 x 128
-        // tile (DaViT stage 0 at 25 images: ~400 vs 211 TFLOP/s); the first threshold (nk >= 8) dated from the four-phase kernel
         // 64 < M <= 128 with >= 128 row tiles (the decode pool's gate/up and lm_head products, llm.DecodePool): a weight stream whose
         // activations come back from L2 once per tile column — 128 x 128 tiles halve that re-read against 64 x 64 (cold weights,
         // profiles/r04_pool_gemm_stream_kernel_vs_tile_kernels.json: gate/up 34.4 -> 30.5 us, lm_head 163 -> 152 us at M = 128)
         if (glds && p.M > 64 && p.M <= 128 && t128 >= 128 && nk >= 16) tile = 1;
-        const long long t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256) * batch;
-        if (glds && nk >= 4 && p.M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) tile = 5;      // (fo1_gemm_takes_big_tile states this rule for callers)
+        if (big_tile_rule(p.M, p.N, p.K, batch)) tile = 5;      // large M (batched prefill): the 256 x 256 two-phase kernel
     }
     p.splits = 1;
     p.kper = nk + 1;
@@ -2507,11 +2517,7 @@ int fo1_conv3x3_gemm_bf16(const void* Xpad, const uint32_t* a_rows, int Wp, int 
 // wants the fused and the two-launch form to agree BIT FOR BIT takes the fused one exactly where this says 1.
 int fo1_gemm_takes_big_tile(int M, int N, int K) {
     using namespace fo1;
-    if (M <= 0 || N <= 0 || K <= 0 || K % 64) return 0;
-    if (g_gemm_tile != 0) return g_gemm_tile == 5 ? 1 : 0;
-    const int nk = K / 64;
-    const long long t256 = (long long)cdiv(M, 256) * cdiv(N, 256);
-    return (nk >= 4 && M >= 1024 && t256 >= 128 && (double)t256 / (double)(cdiv((int)t256, 256) * 256) >= 0.6) ? 1 : 0;
+    return (big_tile_rule(M, N, K, 1) && g_gemm_splitk <= 1) ? 1 : 0;      // (a forced split-K — test / bench build — sends the plain GEMM through fp32 planes)
 }
 
 // q/k/v projection + bias + rotary embedding + K-cache append + V^T write in ONE launch (the 256 x 256 kernel with the fused epilogue

@@ -276,8 +276,11 @@ class QwenLLM:
         scale = 1.0 / math.sqrt(HD)
         if flops is None:
             flops = 4.0 * H * HD * (L * (pos0 + (L + 1) / 2.0))
-        fused = (HD == 128 and pos0 % 8 == 0 and self.capacity % 8 == 0 and ops.qkv_fused_for(L, (H + 2 * KV) * HD, c.hidden_size)
-                 and not ops.fp8_routed(self.layers[0]["wqkv"], L))
+        # (the C entry's own preconditions, mirrored — csrc/stages.hip takes the two-launch path on the same terms: N a multiple of the 256-column
+        # tile, 16-byte aligned rope tables)
+        fused = (HD == 128 and pos0 % 8 == 0 and self.capacity % 8 == 0 and ((H + 2 * KV) * HD) % 256 == 0
+                 and cos.data_ptr() % 16 == 0 and sin.data_ptr() % 16 == 0 and cos.is_contiguous() and sin.is_contiguous()
+                 and ops.qkv_fused_for(L, (H + 2 * KV) * HD, c.hidden_size) and not ops.fp8_routed(self.layers[0]["wqkv"], L))
         for li, w in enumerate(self.layers):
             if fused:
                 # q/k/v projection with mRoPE + K append + V^T in the GEMM's epilogue (ops.qkv_proj_rope mode 0): same bits, one launch less and no

@@ -369,19 +369,29 @@ class FO1Engine:
     PREFILL_ROWS = 65536   # ... and ViT patch rows per pass: 32 COCO-sized images are 50k rows; a group of the datasets' largest images (32 x 10 800
                            # patches: CountBench / Pixmo through evaluation/eval_countbench.py) would otherwise be ONE pass whose SimpleFPN scratch
                            # alone is 44 GB (round 5: the driver-level CountBench run hit it)
+    PREFILL_AUX_PIXELS = 24 << 20   # ... and aux-image pixels per pass: the DaViT / SimpleFPN scratch follows the AUX size, which `dynamic` mode
+                           # takes from the native resolution, not from max_pixels — small-grid images with large aux tensors must not share one oversized pass
 
     def split_passes(self, requests: Sequence[dict]) -> List[List[dict]]:
-        """Consecutive requests -> packed prefill passes of <= PREFILL_MAX requests and <= PREFILL_ROWS ViT patch rows (a single request
+        """Consecutive requests -> packed prefill passes of <= PREFILL_MAX requests, <= PREFILL_ROWS ViT patch rows and <= PREFILL_AUX_PIXELS aux pixels (a single request
         larger than the row budget is its own pass).  Order is kept: the caller's results stay in request order."""
-        out, cur, rows = [], [], 0
+        out, cur, rows, apix = [], [], 0, 0
+        aux_budget = getattr(self, "PREFILL_AUX_PIXELS", None)
+
+        def aux_pixels(r):
+            a = r.get("aux")
+            return int(a.shape[-2]) * int(a.shape[-1]) if a is not None and hasattr(a, "shape") else 0
         for r in requests:
-            n = int(r["grid"][0]) * int(r["grid"][1]) if r.get("image_id") is None or not any(q.get("image_id") == r["image_id"] for q in cur) else 0
-            if cur and (len(cur) >= self.PREFILL_MAX or rows + n > self.PREFILL_ROWS):
+            new_image = r.get("image_id") is None or not any(q.get("image_id") == r["image_id"] for q in cur)
+            n = int(r["grid"][0]) * int(r["grid"][1]) if new_image else 0
+            a = aux_pixels(r) if new_image else 0
+            if cur and (len(cur) >= self.PREFILL_MAX or rows + n > self.PREFILL_ROWS or (aux_budget is not None and apix + a > aux_budget)):
                 out.append(cur)
-                cur, rows = [], 0
-                n = int(r["grid"][0]) * int(r["grid"][1])
+                cur, rows, apix = [], 0, 0
+                n, a = int(r["grid"][0]) * int(r["grid"][1]), aux_pixels(r)
             cur.append(r)
             rows += n
+            apix += a
         if cur:
             out.append(cur)
         return out

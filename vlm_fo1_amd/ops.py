@@ -375,15 +375,17 @@ class Conv3x3Plan:
 
 
 _conv_plans: dict = {}
+_conv_plans_lock = threading.Lock()      # the cache is shared by every engine replica / worker thread: ragged packs add ~7 plans per pass
 
 
 def conv3x3_plan(sizes, stride: int, cin: int, device) -> Conv3x3Plan:
     key = (tuple((int(h), int(w)) for h, w in sizes), int(stride), int(cin), str(device))
-    pl = _conv_plans.get(key)
-    if pl is None:
-        if len(_conv_plans) >= 64:
-            _conv_plans.pop(next(iter(_conv_plans)))
-        pl = _conv_plans[key] = Conv3x3Plan(key[0], stride, cin, device)
+    with _conv_plans_lock:
+        pl = _conv_plans.get(key)
+        if pl is None:
+            while len(_conv_plans) >= 64:
+                _conv_plans.pop(next(iter(_conv_plans)), None)
+            pl = _conv_plans[key] = Conv3x3Plan(key[0], stride, cin, device)
     keep_alive(pl)       # a captured pass holds rowmap / a_rows by raw pointer: it keeps the plan past this cache's eviction
     return pl
 
@@ -829,6 +831,15 @@ def decode_advance(state: torch.Tensor) -> None:
     _L.check(_L.load().fo1_decode_advance(state.data_ptr(), _stream()), "fo1_decode_advance")
 
 
+ATTN32_MAX_ROW_BYTES = 8192     # widest K row pitch of the engine (bytes): see pick_q_block
+
+
+def _check_attn32_extent(q_block: int, rows: int, row_bytes: int) -> None:
+    """fo1_attention_bf16 with q_block 128 / 256 builds 32-bit byte offsets from the K base: fail loudly instead of reading zeros."""
+    if q_block >= 128 and rows * row_bytes >= 2 ** 32:
+        raise ValueError(f"attention: q_block {q_block} addresses K rows with 32-bit byte offsets; {rows} rows x {row_bytes} B exceed 4 GiB — build the items with q_block 64")
+
+
 def pick_q_block(segments: Sequence[Sequence[int]], n_heads: int, head_dim: int = 0, n_kv_heads: Optional[int] = None) -> int:
     """Query block of an attention work list.
     64 (/ 32 / 16) = the 16x16-MFMA kernel, 4 / 2 / 1 waves x 16 queries per workgroup — smaller blocks re-stage every K/V tile once
@@ -838,6 +849,11 @@ def pick_q_block(segments: Sequence[Sequence[int]], n_heads: int, head_dim: int 
     K / V^T tile), 256 queries of one head otherwise (ViT full attention).  Short segments (ViT windows of 64 tokens, DaViT's 144-token
     windows at head dim 32, one-token extends) stay on the 64-query kernel.  FO1_ATTN32=0 turns the new form off (A/B)."""
     if head_dim in (80, 128) and os.environ.get("FO1_ATTN32", "1") != "0" and len(segments):
+        # the 32x32 form addresses K / V^T rows through buffer descriptors with 32-bit byte offsets from the operand's base (ADVICE r5): the
+        # last key row must stay below 2^32 bytes at the WIDEST row pitch the engine uses (head-major ViT q/k/v: 16 heads x 256 elements =
+        # 8 KB per token) — 524k rows; past that the 16x16 kernel (64-bit addresses) takes the launch
+        if max(int(e) for _, e, *_ in segments) * ATTN32_MAX_ROW_BYTES >= 2 ** 32:
+            return 64
         longest = max(int(e) - int(s) for s, e, *_ in segments)
         group = n_heads // (n_kv_heads or n_heads)
         if head_dim == 128 and group % 2 == 0 and longest > 64:
@@ -891,6 +907,7 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.T
         out = torch.empty(L, n_q_heads * head_dim, dtype=torch.bfloat16, device=q.device)
     po, ldo, _, _ = _rows(out, "out")
     hs = head_dim if qk_head_stride is None else int(qk_head_stride)
+    _check_attn32_extent(getattr(items, "q_block", 64), k.shape[0], ldk * 2)
     rc = _L.load().fo1_attention_bf16(pq, ldq, hs, pk, ldk, hs, pv, ldv, po, ldo, head_dim,
                                       items.data_ptr(), items.shape[0], getattr(items, "q_block", 64), n_q_heads, n_kv_heads,
                                       head_dim, float(scale), 1 if causal else 0, None, float(flops), _stream())
@@ -1138,6 +1155,7 @@ def attention_strided(q: torch.Tensor, q_row0: int, k: torch.Tensor, vt: torch.T
     po, ldo, _, _ = _rows(out, "out")
     if q_row_base is not None:
         q_row0 = 0
+    _check_attn32_extent(getattr(items, "q_block", 64), k.shape[1], k.stride(1) * 2)
     if prefix_ranges is not None:      # items with a second (shared-prefix) key range: fo1_attention_prefix_bf16
         assert prefix_ranges.dtype == torch.int32 and prefix_ranges.is_contiguous() and prefix_ranges.shape == (items.shape[0], 2) and q_row_base is None
         rc = _L.load().fo1_attention_prefix_bf16(pq - q_row0 * ldq * 2, ldq, head_dim, k.data_ptr(), k.stride(1), k.stride(0), pv, ldv,
