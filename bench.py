@@ -150,7 +150,7 @@ def dataset_run(pipe, name, n_items, batch, inflight, aux_mode="dynamic", decode
     return out
 
 
-def end_to_end_run(pipe, cases, steps, K=64, pool_slots=0):
+def end_to_end_run(pipe, cases, steps, K=64, pool_slots=0, pools=None):
     """END-TO-END images/s ("images completed / wall time", decode K reported) in ONE timed loop per pass of len(cases)
     images: resized uint8 images in pinned host memory -> upload -> device preprocessing of both towers (patchify / normalise,
     fo1_patchify_u8_bf16 / fo1_normalize_u8_bf16) -> ONE packed prefill pass -> K greedy tokens per image in the batched device decode
@@ -180,7 +180,7 @@ def end_to_end_run(pipe, cases, steps, K=64, pool_slots=0):
 
     svc = None
     if pool_slots:
-        svc = pipe.eng.enable_decode_pool(slots=pool_slots)
+        svc = pipe.eng.enable_decode_pool(slots=pool_slots, pools=pools)
         for e in pipe.engs:
             e._pool_svc = svc
 
@@ -238,7 +238,7 @@ def end_to_end_run(pipe, cases, steps, K=64, pool_slots=0):
     if svc is not None:
         st = dict(svc.stats)
         extra = dict(decode="continuous batching: one decode pool per GPU, sequences of successive prefill passes share every step",
-                     pool_slots=pool_slots, pool_steps=st["steps"], pool_mean_live_sequences=round(st["occupancy_sum"] / max(1, st["steps"]), 1))
+                     pool_slots=pool_slots, pools=st.get("pools", 1), pool_steps=st["steps"], pool_mean_live_sequences=round(st["occupancy_sum"] / max(1, st["steps"]), 1))
         pipe.eng.disable_decode_pool()
         for e in pipe.engs:
             e._pool_svc = None
@@ -535,6 +535,13 @@ def scale_run(pipe, world, rank, one_dev, items_per_gpu=256, n_warm_per_gpu=64, 
                     one_device_gloo_test_mode=bool(one_dev), new_tokens_per_image=K, images_per_pass=batch,
                     per_rank_shard_seconds=[round(st["shard_seconds"], 3) for st in stats],
                     per_rank_items=[st["shard_items"] for st in stats],
+                    # what separates the ranks, each on its own: the LPT deal (model cost and measured seconds, max / mean), how far
+                    # apart the ranks ENTERED the loop (same node, same wall clock), how long each waited for the slowest, the collective itself
+                    lpt_imbalance_model_cost=round(max(st["shard_cost"] for st in stats) / (sum(st["shard_cost"] for st in stats) / len(stats)), 4),
+                    lpt_imbalance_measured_seconds=round(max(st["shard_seconds"] for st in stats) / (sum(st["shard_seconds"] for st in stats) / len(stats)), 4),
+                    startup_skew_ms=round((max(st["enter_wall"] for st in stats) - min(st["enter_wall"] for st in stats)) * 1e3, 2),
+                    gather_wait_for_slowest_ms=[round(st.get("gather_wait_ms", 0.0), 2) for st in stats],
+                    gather_collective_ms=[round(st.get("gather_collective_ms", 0.0), 2) for st in stats],
                     gather_ms=[round(st["gather_ms"], 2) for st in stats],
                     gather_record_bytes_per_rank=stats[0].get("gather_record_bytes_per_rank"),
                     items_failed=sum(1 for _, t in (merged or []) if t is None),
@@ -820,19 +827,21 @@ def hfre_algorithmic_bytes(case, region_dim=5888, P=7):
     return dict(footprint_union=union + tail, full_map_upper_bound=full + tail)
 
 
-def pmc_traffic(kernel_name):
+def pmc_traffic(kernel_name, full=False):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r05_pmc_traffic.json, written by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs with the
-    gfx950 x2 FETCH correction of MI355X_MICROARCH.md applied).  PMC counters cannot be read from inside the process, so the
-    bench line carries the committed figure and names its source; null when no PMC pass exists for the kernel."""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):     # newest pass that has the kernel
+    (profiles/rNN_pmc_traffic.json, written by scripts/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE runs with the
+    gfx950 x2 FETCH correction of MI355X_MICROARCH.md applied; both counters calibrated on known byte counts in this engine's access patterns,
+    profiles/r06_pmc_calibration.json).  PMC counters cannot be read from inside the process, so the
+    bench line carries the committed figure and names its source; null when no PMC pass exists for the kernel.
+    full=True: (row dict, source) — the read / write split and, for the 256 x 256 GEMM, the algorithmic read / write bytes it is set against."""
+    for name in ("r06_pmc_traffic.json",):     # (rounds 3-5 files held ONE template instantiation per kernel name — scripts/pmc_summary.py, round 6 fix — and are not quoted any more)
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", name)
         try:
             with open(path) as f:
                 t = json.load(f)
             row = t["kernels"].get(kernel_name)
             if row:
-                return row["hbm_bytes_per_launch"], "profiles/" + name
+                return (row, "profiles/" + name) if full else (row["hbm_bytes_per_launch"], "profiles/" + name)
         except (OSError, ValueError, KeyError):
             pass
     return None, None
@@ -942,13 +951,15 @@ def main():
                     "streams); 1 = strictly one pass at a time")
     ap.add_argument("--pool-slots", type=int, default=128, choices=[0, 64, 128], help="end_to_end: slots of the decode pool the passes' sequences "
                     "join (continuous batching, vlm_fo1_amd/serving.py); 0 = every pass decodes its own group of <= 32 (round 3's form)")
+    ap.add_argument("--decode-pools", type=int, default=0, help="end_to_end: decode pools stepping concurrently on their own streams (serving.PoolGroup); 0 = the engine's default")
+    ap.add_argument("--e2e-only", action="store_true", help="print the end_to_end block and stop (A/B runs)")
     ap.add_argument("--e2e-passes", type=int, default=0, help="end_to_end: timed passes (0 = min(steps, 24)); a longer loop weighs the decode pool's fill / drain "
                     "phases at its two ends less (side measurement: the default line keeps 24)")
     ap.add_argument("--driver-items", type=int, default=768, help="driver_level: images of the synthetic COCO-shaped dataset run through "
                     "evaluation/eval_coco.py's own loop (0 = skip)")
     ap.add_argument("--driver-count-items", type=int, default=-1, help="driver_level_countbench: items per dataset of evaluation/eval_countbench.py's own loop on the "
                     "CountBench and Pixmo-Count fixtures as files (-1 = all 487 + 529; 0 = skip)")
-    ap.add_argument("--scale-items", type=int, default=256, help="multi-rank runs: images PER GPU of the `scale` block (evaluation/eval_coco.py's loop through "
+    ap.add_argument("--scale-items", type=int, default=2048, help="multi-rank runs: images PER GPU of the `scale` block (evaluation/eval_coco.py's loop through "
                     "sharded_eval.run_sharded across the ranks, one all_gather at the reducer); a multiple of 32; 0 = skip")
     ap.add_argument("--json-out", default="gpurun_out/bench_full.json", help="the FULL record (per-kernel tables, notes, loop descriptions); stdout carries the "
                     "compact contract line whose last object, `summary`, repeats the user-visible figures ('' = do not write)")
@@ -1101,7 +1112,7 @@ def main():
 
     # ---- greedy decode through the KV cache (fixed K new tokens, reported separately; not part of `value`) ----
     dec = None
-    if rank == 0 and not args.main_only:
+    if rank == 0 and not args.main_only and not args.e2e_only:
         K = 32
         out = pipe.step_single(use_graph)
         tok = out["next_token"]
@@ -1191,7 +1202,11 @@ def main():
                                  for i in range(B, BatchDecoder.MAX_BATCH)]
         # continuous batching (round 4): one decode pool of 128 slots per GPU, fed by the replicas' prefill passes; more passes than the
         # static form so that the pool's fill / drain phases at the two ends of the timed loop weigh little
-        e2e = end_to_end_run(pipe, e2e_cases, steps=(args.e2e_passes if args.e2e_passes > 0 else max(8, min(args.steps, 24))), K=64, pool_slots=args.pool_slots)
+        e2e = end_to_end_run(pipe, e2e_cases, steps=(args.e2e_passes if args.e2e_passes > 0 else max(8, min(args.steps, 24))), K=64, pool_slots=args.pool_slots,
+                             pools=args.decode_pools or None)
+        if args.e2e_only:
+            print(json.dumps(dict(end_to_end=e2e)))
+            return
         if args.pool_slots:
             e2e["static_groups"] = end_to_end_run(pipe, e2e_cases, steps=max(4, min(args.steps, 12)), K=64, pool_slots=0)
 
@@ -1294,6 +1309,7 @@ def main():
         ach = work / (avg_ms * 1e-3) / (1e12 if mfma else 1e9)
         peak = (MFMA_FP8_PEAK_TF if dom["name"].startswith("gemm_fp8") else MFMA_BF16_PEAK_TF) if mfma else HBM_PEAK_GBS
         traffic, traffic_src = pmc_traffic(dom["name"])
+        trow, _ = pmc_traffic(dom["name"], full=True)
         # all MFMA GEMM templates together (the three tile shapes are one kernel source)
         g_rows = [r for r in rows if r["name"].startswith("gemm_bt_")]
         g_ms = sum(r["total_ms"] for r in g_rows)
@@ -1301,6 +1317,10 @@ def main():
         roof = dict(kernel=dom["name"], bound="mfma" if mfma else "hbm", achieved=round(ach, 2), peak=peak,
                     unit="TFLOP/s" if mfma else "GB/s", frac=round(ach / peak, 5), traffic=traffic,
                     traffic_source=traffic_src,
+                    # read and write sides separately (VERDICT r5 #2a), each against what a launch must move (A + W (+ residual) once; C once)
+                    traffic_read=(trow or {}).get("fetch_bytes"), traffic_write=(trow or {}).get("write_bytes"),
+                    algorithmic_read=(trow or {}).get("algorithmic_read_bytes"), algorithmic_write=(trow or {}).get("algorithmic_write_bytes"),
+                    traffic_read_over_algorithmic=(trow or {}).get("read_over_algorithmic"), traffic_write_over_algorithmic=(trow or {}).get("write_over_algorithmic"),
                     all_gemm_tiles=dict(tflops=round(g_tf, 2) if g_tf else None, ms_per_step=round(g_ms / nprof, 3),
                                         launches_per_step=sum(r["calls"] for r in g_rows) // nprof),
                     avg_us=round(avg_ms * 1e3, 3), launches_per_step=dom["calls"] // nprof,

@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* libfo1hip*.so are built with -fvisibility=hidden: exactly the declarations of this header are exported */
 #endif
 
-#define FO1_ABI_VERSION 7   /* 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 8   /* 8: fo1_attention_decode_batch_partials_bf16 + fo1_gemv_attn_combine_bf16 (decode step at <= 2 sequences: the o-projection sums the split-KV partials in its prologue, no combine launch); 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -430,6 +430,20 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
                                     long long out_seq_stride, const int32_t* state, int batch, int max_kv_len,
                                     int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace,
                                     size_t workspace_bytes, void* stream);
+/* The split-KV half of fo1_attention_decode_batch_bf16 alone (reference: the 1-token fast path of omchat_qwen2_5_vl.py:143-155 through
+ * modeling_qwen2_5_vl.py:738-802): per sequence, KV head and chunk of *kv_chunk_out keys the unnormalised fp32 rows + (max, sum) go to
+ * `workspace` as [batch][chunks][n_kv_heads][16][head_dim + 2] (*part_seq_stride_out floats per sequence).  Consumer:
+ * fo1_gemv_attn_combine_bf16.  Workspace size: fo1_attention_decode_batch_workspace_bytes. */
+int fo1_attention_decode_batch_partials_bf16(const void* q, long long q_seq_stride, const void* kcache, long long k_tok_stride, long long k_head_stride,
+                                             const void* vtcache, long long vt_row_stride, const int32_t* state, int batch, int max_kv_len,
+                                             int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace, size_t workspace_bytes,
+                                             int* kv_chunk_out, long long* part_seq_stride_out, void* stream);
+/* The o-projection of a decode step at <= 2 sequences with the attention combine in its prologue (modeling_qwen2_5_vl.py:797-800: o_proj of the
+ * attention output, + residual at :1075): C[M, N] = bf16(bf16(x W^T) + residual), x = the rows attn_decode_combine would have written from
+ * `part` — bit for bit, one shared routine — without that launch and without the [M, heads x 128] activation.  M <= 2, K = n_q_heads * 128 <= 2048,
+ * N <= 4096, head_dim 128. */
+int fo1_gemv_attn_combine_bf16(const float* part, long long part_seq_stride, const int32_t* state, int kv_chunk, int n_q_heads, int n_kv_heads,
+                               const void* W, int ldw, const void* residual, int ldr, void* C, int ldc, int M, int N, void* stream);
 int fo1_decode_argmax_accept(const void* logits, long long ld_logits, int n_vocab, int B, const int32_t* first_tokens,
                              int32_t* state, int32_t* plan, int32_t* ids_out, int ids_ld, const int32_t* stop_ids,
                              int n_stop, int32_t* done, void* scratch, void* stream);

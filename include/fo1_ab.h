@@ -72,6 +72,8 @@ int fo1_attention_decode_set_impl(int impl);
 /* Keys per chunk of the batched decode attention for more than 32 sequences (decode pool): a multiple of 64 up to 4096, default 1024 = a pool
  * slot's whole context, for which the split kernel writes the output rows itself and no combine launch is made. */
 int fo1_attention_decode_set_pool_chunk(int keys);
+/* keys per split of the batched decode attention at <= 32 sequences (product: 64 up to ... see decode_batch_chunk in csrc/attention.hip). */
+int fo1_attention_decode_set_small_chunk(int keys);
 
 /* ---- measured no-gain kernel forms and instruments (round 5: moved out of the product ABI) ---- */
 /* SwiGLU over the split-K planes of fo1_gemm_bf16_partials for the gate/up projection against the 16-row interleaved weight:
@@ -88,6 +90,10 @@ int fo1_gemm_bf16_wtiled(const void* A, int lda, const void* W_tiled, const void
  * 100 MHz ticks (s_memrealtime)}.  operands 0 = zeros, 1 = pseudo-random bf16.  cycles / ticks = the DVFS clock; the dense bf16 peak of the
  * roofline (2.5 PFLOP/s) assumes 2.4 GHz. */
 int fo1_mfma_clock_probe(int operands, int iters, int workgroups, void* out, void* sink, void* stream);
+/* Instrumentation: moves exactly `bytes` in a named access pattern (0 stream store 16 B / lane, 1 the 256 x 256 GEMM's coalesced epilogue store,
+ * 2 stream load, 3 LDS-DMA tile load, 4 / 5 stream store 8 / 4 B per lane) so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated on a
+ * known byte count per pattern (MI355X_MICROARCH.md: WRITE_SIZE is uncalibrated; scripts/pmc_calibrate.py, profiles/r06_pmc_calibration.json). */
+int fo1_traffic_probe(int mode, void* buf, long long bytes, long long ld, int workgroups /* 0 = 2048 */, void* sink, void* stream);
 /* Instrumentation (with fo1_profile_enable): per-shape kernel names in the profile rows instead of one row per kernel. */
 int fo1_gemm_profile_shapes(int on);
 

@@ -62,7 +62,7 @@ def test_product_library_has_no_switches_and_the_ab_build_has_exactly_the_two_he
     assert exported("libfo1hip.so") == prod
     assert exported("libfo1hip_ab.so") == sorted(prod + ab)
     # fo1_ab.h = the process-global switches (`_set_`) + the measured no-gain kernel forms and instruments moved out of the product ABI in round 5
-    extra = {"fo1_gemm_bf16_wtiled", "fo1_splitk_swiglu_bf16", "fo1_mfma_clock_probe", "fo1_gemm_profile_shapes"}
+    extra = {"fo1_gemm_bf16_wtiled", "fo1_splitk_swiglu_bf16", "fo1_mfma_clock_probe", "fo1_gemm_profile_shapes", "fo1_traffic_probe"}
     assert all("_set_" in s or s in extra for s in ab) and extra <= set(ab) and not any("_set_" in s for s in prod)
     # the product build also leaves the measured-slower kernel forms out
     import subprocess
@@ -73,7 +73,7 @@ def test_product_library_has_no_switches_and_the_ab_build_has_exactly_the_two_he
 
 
 def test_abi_version():
-    assert L.load().fo1_abi_version() == 7
+    assert L.load().fo1_abi_version() == 8
 
 
 def test_hfre_argument_errors():

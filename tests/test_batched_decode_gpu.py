@@ -298,6 +298,69 @@ def test_attention_decode_workgroup_kernel_matches_split_kernel_and_reference(ab
         assert (out[1] - out[0]).abs().max().item() <= 2e-2
 
 
+def test_o_projection_with_the_attention_combine_in_its_prologue_equals_combine_then_gemv_bitwise():
+    """Round 6 (decode at <= 2 sequences, the reference's own batch-1 loop): fo1_attention_decode_batch_partials_bf16 + fo1_gemv_attn_combine_bf16 —
+    the o-projection sums the split-KV partials itself — against fo1_attention_decode_batch_bf16 (split + combine launch) + fo1_gemv_batch_bf16 with
+    the same residual: the SAME BITS (one shared combine routine, csrc/decode_common.h), for one and two sequences, ragged contexts from 1 key to a
+    full 2048-row slot, a finished sequence (zero attention row), and against the fp32 reference of the attention."""
+    from vlm_fo1_amd import ops
+    BF = torch.bfloat16
+    H, KV, HD, D = 16, 2, 128, 2048
+    g = torch.Generator().manual_seed(23)
+    wo = (torch.randn(D, H * HD, generator=g) * 0.03).to(BF).cuda()
+    for slot, lens, fin in ((2048, [651], [0]), (2048, [1, 2048], [0, 0]), (1024, [64, 65], [0, 0]), (4096, [700, 3000], [0, 1]), (1024, [130], [1])):
+        B = len(lens)
+        kc = torch.randn(KV, B * slot, HD, generator=g).to(BF).cuda()
+        vt = torch.randn(KV * HD, B * slot, generator=g).to(BF).cuda()
+        q = torch.randn(B, H * HD, generator=g).to(BF).cuda()
+        res = torch.randn(B, D, generator=g).to(BF).cuda()
+        state = torch.zeros(B, 8, dtype=torch.int32)
+        for b, n in enumerate(lens):
+            state[b, 2] = b * slot
+            state[b, 0] = b * slot + n - 1
+            state[b, 3] = fin[b]
+        state = state.cuda()
+        scale = HD ** -0.5
+        att = ops.attention_decode_batch(q, kc, vt, state, slot, H, KV, HD, scale)
+        want = ops.gemv_batch(att, wo, residual=res)
+        part, pstride, chunk = ops.attention_decode_batch_partials(q, kc, vt, state, slot, H, KV, HD, scale)
+        got = ops.gemv_attn_combine(part, pstride, state, chunk, H, KV, wo, residual=res)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), f"slot {slot} lens {lens}: fused o-projection differs from combine + gemv (max |d| {(got.float() - want.float()).abs().max().item():.4g})"
+        # and the attention rows themselves against fp32 softmax(q k^T / sqrt(d)) v (what both forms fed the projection)
+        kf, vf, qf = kc.float().cpu(), vt.float().cpu(), q.float().cpu()
+        a = att.float().cpu()
+        for b, n in enumerate(lens):
+            if fin[b]:
+                assert a[b].abs().max().item() == 0.0
+                continue
+            for h in (0, 7, 15):
+                kv = h // (H // KV)
+                p = torch.softmax(kf[kv, b * slot:b * slot + n] @ qf[b, h * HD:(h + 1) * HD] * scale, 0)
+                ref = vf[kv * HD:(kv + 1) * HD, b * slot:b * slot + n] @ p
+                assert (a[b, h * HD:(h + 1) * HD] - ref).abs().max().item() <= 2e-2
+
+
+def test_batch_decoder_fused_combine_gives_the_ids_of_the_combine_launch():
+    """BatchDecoder at one and two sequences with FUSED_COMBINE_MAX = 2 (product) and 0 (always the combine launch): the same generated ids —
+    so a sequence still decodes to the same ids alone and in any batch."""
+    from test_batched_prefill_gpu import make_request
+    from vlm_fo1_amd.llm import BatchDecoder
+    cfg, weights, eng = build()
+    reqs = [make_request(500 + i, 96 + 28 * i, 120, 3 + i) for i in range(2)]
+    K = 8
+    try:
+        got = {}
+        for fused in (2, 0):
+            BatchDecoder.FUSED_COMBINE_MAX = fused
+            eng._dec = None
+            got[fused] = [eng.generate_batch(reqs[:n], max_new_tokens=K, use_graph=ug) for n in (1, 2) for ug in (False, True)]
+        assert got[2] == got[0]
+        assert all(len(t) == K for run in got[2] for t in run)
+    finally:
+        BatchDecoder.FUSED_COMBINE_MAX = 2
+
+
 def test_gemv_batch_rows_independent_of_batch(ab_library):
     """Sequence m's outputs are the same numbers whether it runs alone or with 7 others, and whatever the rows-per-lane blocking:
     the per-(row, sequence) fp32 sum order is fixed by the shape alone (K segments, K split over waves, 8 lanes per row) — what

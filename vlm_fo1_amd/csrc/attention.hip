@@ -17,6 +17,7 @@
 // the transposed copy is written once per layer by fo1_transpose_bf16 (rope.hip).
 #include "common.h"
 #include "ab.h"
+#include "decode_common.h"
 
 namespace fo1 {
 
@@ -709,43 +710,11 @@ __global__ __launch_bounds__(HD) void attn_decode_combine_kernel(const float* __
         n_keys = *dyn_kv_len;
     }
     const int n_valid = (n_keys + kv_chunk - 1) / kv_chunk;
-    // (m, l) of every chunk in one parallel load (a serial walk is 2 x n_valid dependent L2 round trips: ~6 us at 12 chunks)
-    __shared__ float s_m[256], s_l[256];
-    for (int s = d; s < min(n_valid, 256); s += HD) {
-        const float* pr = part + (((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2);
-        s_m[s] = pr[HD];
-        s_l[s] = pr[HD + 1];
-    }
-    __syncthreads();
-    // n_valid <= 256 in every configuration built (slots <= 16384 rows); larger falls back to the serial walk below
-    float num = 0.f, den = 0.f;
-    if (n_valid <= 256) {
-        float M = -INFINITY;
-        for (int s = 0; s < n_valid; ++s) M = fmaxf(M, s_m[s]);
-        int s = 0;
-        for (; s + 4 <= n_valid; s += 4) {       // four independent loads in flight
-            float v[4], w[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = part[(((long long)(s + j) * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + d];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { w[j] = __expf(s_m[s + j] - M); num += w[j] * v[j]; den += w[j] * s_l[s + j]; }
-        }
-        for (; s < n_valid; ++s) {
-            const float w = __expf(s_m[s] - M);
-            num += w * part[(((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + d];
-            den += w * s_l[s];
-        }
-    } else {
-        float M = -INFINITY;
-        for (int s = 0; s < n_valid; ++s) M = fmaxf(M, part[(((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2) + HD]);
-        for (int s = 0; s < n_valid; ++s) {
-            const float* pr = part + (((long long)s * n_kv_heads + kvh) * 16 + slot) * (HD + 2);
-            const float w = __expf(pr[HD] - M);
-            num += w * pr[d];
-            den += w * pr[HD + 1];
-        }
-    }
-    out[(long long)head * HD + d] = f32_to_bf16(den > 0.f ? num / den : 0.f);
+    // the arithmetic lives in attn_combine_row (decode_common.h): the decode GEMV's fused prologue (M <= 2) runs the same code, so a sequence's
+    // attention rows are the same bits with and without this launch
+    float o1[1];
+    attn_combine_row<1>(part + ((long long)kvh * 16 + slot) * (HD + 2), (long long)n_kv_heads * 16 * (HD + 2), n_valid, d, o1);
+    out[(long long)head * HD + d] = f32_to_bf16(o1[0]);
 }
 
 // ---- decode attention, one workgroup per (KV head, sequence[, KV split]) ---------------------------------------------------
@@ -1349,9 +1318,15 @@ int fo1_attention_decode_set_impl(int impl) {
 namespace fo1 {
 FO1_AB_VAR g_attn_pool_chunk = 1024;     // A/B: fo1_attention_decode_set_pool_chunk.  1024 keys: a pool slot's whole context (slot_rows <= 1024) is ONE chunk —
                                          // the split kernel writes the rows itself, no combine launch (512: 23.7 + 4.3 us per layer, 1024: 22.2 + 0; profiles/r04_pool_step_attention_one_chunk.json)
-static inline int decode_batch_chunk(int batch) { return batch > 32 ? g_attn_pool_chunk : 64; }
+FO1_AB_VAR g_attn_small_chunk = 64;      // A/B: fo1_attention_decode_set_small_chunk (<= 32 sequences)
+static inline int decode_batch_chunk(int batch) { return batch > 32 ? g_attn_pool_chunk : g_attn_small_chunk; }
 }  // namespace fo1
 #ifdef FO1_ENABLE_AB
+int fo1_attention_decode_set_small_chunk(int keys) {
+    if (keys < 64 || keys > 4096 || keys % 64) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_small_chunk: %d", keys);
+    fo1::g_attn_small_chunk = keys;
+    return FO1_OK;
+}
 int fo1_attention_decode_set_pool_chunk(int keys) {
     if (keys < 64 || keys > 4096 || keys % 64) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_pool_chunk: %d", keys);
     fo1::g_attn_pool_chunk = keys;
@@ -1362,12 +1337,12 @@ size_t fo1_attention_decode_batch_workspace_bytes(int max_kv_len, int n_kv_heads
     return (size_t)batch * fo1::cdiv(max_kv_len, fo1::decode_batch_chunk(batch)) * n_kv_heads * 16 * (head_dim + 2) * sizeof(float);
 }
 
-int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const void* kcache, long long k_tok_stride, long long k_head_stride,
-                                    const void* vtcache, long long vt_row_stride, void* out, long long out_seq_stride, const int32_t* state,
-                                    int batch, int max_kv_len, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace,
-                                    size_t workspace_bytes, void* stream) {
+static int attention_decode_batch_impl(const void* q, long long q_seq_stride, const void* kcache, long long k_tok_stride, long long k_head_stride,
+                                       const void* vtcache, long long vt_row_stride, void* out, long long out_seq_stride, const int32_t* state,
+                                       int batch, int max_kv_len, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace,
+                                       size_t workspace_bytes, void* stream, bool combine) {
     using namespace fo1;
-    FO1_CHECK_ARG(q && kcache && vtcache && out && state && workspace && batch >= 1, "attention_decode_batch: NULL operand");
+    FO1_CHECK_ARG(q && kcache && vtcache && (out || !combine) && state && workspace && batch >= 1, "attention_decode_batch: NULL operand");
     FO1_CHECK_ARG(head_dim == 128, "attention_decode_batch: head_dim %d not built (128)", head_dim);
     FO1_CHECK_ARG(n_q_heads % n_kv_heads == 0 && n_q_heads / n_kv_heads <= 16, "attention_decode_batch: at most 16 query heads per KV head");
     FO1_CHECK_ARG(vt_row_stride % 4 == 0 && k_tok_stride % 8 == 0 && k_head_stride % 8 == 0 && q_seq_stride % 8 == 0, "attention_decode_batch: bad strides");
@@ -1411,7 +1386,7 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     p.part_seq_stride = (long long)p.n_items * n_kv_heads * 16 * (head_dim + 2);
     p.bias = nullptr; p.wlen = 0; p.sw_ws = p.sw_shift = p.sw_nwy = p.sw_nwx = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (p.n_items == 1 && batch > 32) {       // the pool: one chunk per (sequence, KV head) -> rows written by the split kernel itself, no combine launch
+    if (p.n_items == 1 && combine) {       // one chunk per (sequence, KV head) — the pool's slots, or a short context at any batch size -> rows written by the split kernel itself, no combine launch
         p.O = (uint16_t*)out; p.o_tok = out_seq_stride; p.o_head = head_dim;
         FO1_LAUNCH("attn_decode_one_chunk", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
                    dim3(1, n_kv_heads, batch), dim3(256), 0, st, p);
@@ -1419,10 +1394,34 @@ int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const
     }
     FO1_LAUNCH("attn_decode_split", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
                dim3(p.n_items, n_kv_heads, batch), dim3(256), 0, st, p);
+    if (!combine) return FO1_OK;       // the consumer sums the partials itself (fo1_gemv_attn_combine_bf16)
     FO1_LAUNCH("attn_decode_combine", (double)batch * n_q_heads * head_dim * 8.0, attn_decode_combine_kernel<128>, dim3(n_q_heads, batch), dim3(128), 0,
                st, (const float*)workspace, (const int*)nullptr, chunk, n_kv_heads, group, (uint16_t*)out, (const int*)state, p.part_seq_stride,
                out_seq_stride);
     return FO1_OK;
+}
+
+int fo1_attention_decode_batch_bf16(const void* q, long long q_seq_stride, const void* kcache, long long k_tok_stride, long long k_head_stride,
+                                    const void* vtcache, long long vt_row_stride, void* out, long long out_seq_stride, const int32_t* state,
+                                    int batch, int max_kv_len, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    return attention_decode_batch_impl(q, q_seq_stride, kcache, k_tok_stride, k_head_stride, vtcache, vt_row_stride, out, out_seq_stride, state, batch,
+                                       max_kv_len, n_q_heads, n_kv_heads, head_dim, scale, workspace, workspace_bytes, stream, true);
+}
+
+// The split-KV half of fo1_attention_decode_batch_bf16 alone: per sequence, KV head and chunk of `*kv_chunk_out` keys the unnormalised fp32 rows +
+// (m, l) go to `workspace` as [batch][chunks][n_kv_heads][16][head_dim + 2]; fo1_gemv_attn_combine_bf16 (the o-projection of a decode step at
+// <= 2 sequences) sums them in its prologue, so the combine launch and the [batch, heads x head_dim] activation never exist.
+int fo1_attention_decode_batch_partials_bf16(const void* q, long long q_seq_stride, const void* kcache, long long k_tok_stride, long long k_head_stride,
+                                             const void* vtcache, long long vt_row_stride, const int32_t* state, int batch, int max_kv_len,
+                                             int n_q_heads, int n_kv_heads, int head_dim, float scale, void* workspace, size_t workspace_bytes,
+                                             int* kv_chunk_out, long long* part_seq_stride_out, void* stream) {
+    FO1_CHECK_ARG(kv_chunk_out && part_seq_stride_out, "attention_decode_batch_partials: NULL output");
+    const int chunk = fo1::decode_batch_chunk(batch);
+    *kv_chunk_out = chunk;
+    *part_seq_stride_out = (long long)fo1::cdiv(max_kv_len, chunk) * n_kv_heads * 16 * (head_dim + 2);
+    return attention_decode_batch_impl(q, q_seq_stride, kcache, k_tok_stride, k_head_stride, vtcache, vt_row_stride, nullptr, 0, state, batch, max_kv_len,
+                                       n_q_heads, n_kv_heads, head_dim, scale, workspace, workspace_bytes, stream, false);
 }
 
 }  // extern "C"

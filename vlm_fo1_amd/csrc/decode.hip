@@ -590,6 +590,29 @@ int fo1_gemv_batch_bf16(const void* x, int ldx, const void* W, int ldw, const vo
     return gemv_b_any(p, mode, (hipStream_t)stream);
 }
 
+// The o-projection of a decode step at <= 2 sequences with the split-KV attention combine in its prologue: C[M, N] = bf16(bf16(x W^T) + residual),
+// x[m, head * 128 + d] = sum_s exp(m_s - M) O_s[d] / sum_s exp(m_s - M) l_s over the chunks of fo1_attention_decode_batch_partials_bf16 — the value
+// attn_decode_combine_kernel writes, bit for bit (one shared routine), without its launch.  K = n_q_heads * 128 <= 2048, N <= 4096.
+int fo1_gemv_attn_combine_bf16(const float* part, long long part_seq_stride, const int32_t* state, int kv_chunk, int n_q_heads, int n_kv_heads,
+                               const void* W, int ldw, const void* residual, int ldr, void* C, int ldc, int M, int N, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(part && state && W && C, "gemv_attn_combine: NULL operand");
+    const int K = n_q_heads * 128;
+    FO1_CHECK_ARG(M >= 1 && M <= 2 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && n_q_heads / n_kv_heads <= 16 && K <= 2048 && N > 0 && N <= 4096 && N % 4 == 0,
+                  "gemv_attn_combine: M=%d (1..2) heads %d / %d (K = heads x 128 <= 2048) N=%d (<= 4096)", M, n_q_heads, n_kv_heads, N);
+    FO1_CHECK_ARG(kv_chunk >= 64 && kv_chunk % 64 == 0 && ldw % 8 == 0 && ldw >= K && ((uintptr_t)W & 15) == 0 && ((uintptr_t)part & 7) == 0, "gemv_attn_combine: bad layout");
+    FO1_CHECK_ARG(ldc >= N && (residual == nullptr || (ldr % 4 == 0 && ldr >= N && ((uintptr_t)residual & 7) == 0)), "gemv_attn_combine: residual / output layout");
+    GemvBParams p;
+    p.X = (const uint16_t*)W; p.ldx = 0;      // (the staged rows come from the partials; the plain x loads of the kernel's prologue read valid memory and are ignored)
+    p.W = (const uint16_t*)W; p.bias = nullptr; p.res = (const uint16_t*)residual; p.C = (uint16_t*)C;
+    p.M = M; p.N = N; p.K = K; p.ldw = ldw; p.ldc = ldc; p.ldr = ldr;
+    p.norm_w = nullptr; p.norm_eps = 0.f; p.kp_chunks = 0;
+    p.n_q = p.n_kv = 0; p.cos_t = p.sin_t = nullptr; p.state = nullptr; p.kcache = p.vtcache = nullptr; p.kc_head_stride = p.vt_row_stride = 0;
+    p.attn_part = part; p.attn_part_seq_stride = part_seq_stride; p.attn_state = (const int*)state;
+    p.attn_chunk = kv_chunk; p.attn_n_kv = n_kv_heads; p.attn_group = n_q_heads / n_kv_heads;
+    return gemv_mfma_any(p, GB_PLAIN, (hipStream_t)stream);
+}
+
 // Greedy pick for B logits rows + the on-device bookkeeping of one decode step (see accept_token).
 // logits == NULL: accept `first_tokens` (int32[B], the prefill's argmax) without advancing the positions.
 // scratch: 2 * 128 * B * 4 bytes.  plan: int32[B][2] gather plan for the next step's embedding rows.  done: int32 counter of

@@ -271,7 +271,35 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         pos = stt[0];
         trow = stt[1];
     }
-    if (!MP) store_x(0, xr, nw);      // single piece: x staged (and normalised) once for every unit of this workgroup
+    if constexpr (!MP && MM == 8) {
+        if (p.attn_part != nullptr) {
+            // x rows = the attention output, combined from the split-KV partials right here (M <= 2: one (row, 16-byte chunk) per thread): what
+            // attn_decode_combine_kernel + the plain x staging produce, bit for bit (attn_combine_row is the arithmetic of both)
+            __syncthreads();
+            const int c = tid % CPR, m0 = tid / CPR;               // CPR = 256 chunks of K = 2048: rows 0, 1
+            uint4 o = uint4{0, 0, 0, 0};
+            if (m0 < p.M && c < kch) {
+                const int* stt = p.attn_state + m0 * 8;
+                if (!stt[3]) {
+                    const int head = c >> 4, d0 = (c & 15) * 8;
+                    const int kvh = head / p.attn_group, slot = head - kvh * p.attn_group;
+                    const int n_valid = (stt[0] + 1 - stt[2] + p.attn_chunk - 1) / p.attn_chunk;
+                    float v[8];
+                    attn_combine_row<8>(p.attn_part + (long long)m0 * p.attn_part_seq_stride + ((long long)kvh * 16 + slot) * 130,
+                                        (long long)p.attn_n_kv * 16 * 130, n_valid, d0, v);
+                    o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < XL; ++i) {
+                const int m = m0 + RPP * i;
+                *reinterpret_cast<uint4*>(sx + m * XPITCH + c * 16) = i == 0 ? o : uint4{0, 0, 0, 0};
+            }
+            __syncthreads();
+        } else {
+            store_x(0, xr, nw);
+        }
+    } else if (!MP) store_x(0, xr, nw);      // single piece: x staged (and normalised) once for every unit of this workgroup
     if constexpr (XREG) {
         // this wave's B fragments — k-steps wave + 8 d, both halves, both column groups — are the same for every unit: into registers,
         // then the x image is dead and its LDS becomes the weight scratch and the reduction buffers

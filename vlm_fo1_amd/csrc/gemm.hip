@@ -526,10 +526,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const GemmParam
 // LDS-DMA path, 3-stage ring: two K tiles in flight across each barrier (counted vmcnt + raw s_barrier;
 // __syncthreads() would drain the DMA queue with vmcnt(0)).  All LDS lives in ONE dynamic array.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int NS>
+// WGM x WGN = the 4 waves' layout over the tile (default 2 x 2).  4 x 1 (round 6): every wave owns 32 rows x ALL BN columns, so a tile of
+// 96 columns keeps the interleaved [gate 16 | up 16] SwiGLU pairs inside one wave (tile <128, 96>: 230 workgroups for the decode pool's
+// 22016-column gate/up product, one per CU, 5 ring stages = 4 K tiles of weights in flight per CU).
+template <int BM, int BN, int NS, int WGM = 2, int WGN = 2>
 __global__ __launch_bounds__(256) void gemm_bt_ring_kernel(const GemmParams p) {
+    static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int BK = 64;
-    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+    static_assert(WM % 16 == 0 && WN % 16 == 0 && ((BM + BN) / 8) % 4 == 0, "wave tile in 16 x 16 fragments; DMA pieces divide over 4 waves");
     constexpr int ROWS = BM + BN;
     constexpr int INST = ROWS / 8;
     constexpr int IPW = INST / 4;
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(256) void gemm_bt_ring_kernel(const GemmParams p) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const long long bz = blockIdx.y;
     const uint16_t* A = p.A + bz * p.sA;
     const uint16_t* W = p.W + bz * p.sW;
@@ -2174,18 +2179,45 @@ __global__ __launch_bounds__(256) void quantize_rows_e4m3_kernel(const uint16_t*
     for (int c = tid + RC * 256; c < nch; c += 256) quant8(*reinterpret_cast<const uint4*>(xr + c * 8), c);   // (L2 hit: just read)
 }
 
-template <int BM, int BN, int NS>
+template <int BM, int BN, int NS, int WGM = 2, int WGN = 2>
 static int launch_ring(GemmParams& p, const char* name, double flops, dim3 grid, hipStream_t st) {
     static_assert((NS - 2) * ((BM + BN) / 32) <= 63, "vmcnt is a 6-bit counter");
+    static_assert(NS - 2 <= 4, "the K loop's counted waits cover up to 4 tiles in flight behind the current one");
     constexpr int smem = NS * (BM + BN) * 128;
     static_assert(smem <= 160 * 1024, "LDS per workgroup");
     static bool attr_done = false;
     if (!attr_done) {
-        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_ring_kernel<BM, BN, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bt_ring_kernel<BM, BN, NS, WGM, WGN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
         attr_done = true;
     }
-    FO1_LAUNCH(name, flops, (gemm_bt_ring_kernel<BM, BN, NS>), grid, dim3(256), smem, st, p);
+    FO1_LAUNCH(name, flops, (gemm_bt_ring_kernel<BM, BN, NS, WGM, WGN>), grid, dim3(256), smem, st, p);
     return FO1_OK;
+}
+
+// Skinny-M weight streams of the decode pool (65..128 rows; round 6): tiles whose ring is DEEP — what a weight stream needs is bytes in flight
+// per CU (HBM latency x 6 TB/s = ~48 KB per CU chip-wide), and a 128 x 128 tile with 3 stages keeps 32 KB of W in flight on only 172 CUs.
+//   <128, 96> waves 4 x 1, 5 stages (140 KB): 48 KB of W in flight per workgroup, 230 workgroups for N = 22016 (SwiGLU pairs stay in a wave);
+//   <128, 64> waves 2 x 2, 6 stages (144 KB): 40 KB of W in flight, N / 64 column tiles x splits workgroups (down as split-K planes);
+//   <128, 64> 3 stages (72 KB): two workgroups per CU.
+template <int BM, int BN, int WGM, int WGN>
+static int launch_ring_deep(GemmParams& p, int ns, hipStream_t st) {
+    p.tiles_m = cdiv(p.M, BM);
+    p.tiles_n = cdiv(p.N, BN);
+    const dim3 grid(p.tiles_m * p.tiles_n, 1, p.splits);
+    const double flops = 2.0 * p.M * (double)p.N * p.K;
+    char pname[56];
+    snprintf(pname, sizeof pname, "gemm_bt_ring<%d,%d,%d>", BM, BN, ns);
+    if (profile_enabled() && g_gemm_profile_shapes) snprintf(pname, sizeof pname, "gemm %dx%dx%d t%dx%d s%d r%d", p.M, p.N, p.K, BM, BN, p.splits, ns);
+    p.stages = ns;
+    if constexpr (BN == 96) {
+        if (ns == 3) return launch_ring<BM, BN, 3, WGM, WGN>(p, pname, flops, grid, st);
+        if (ns == 4) return launch_ring<BM, BN, 4, WGM, WGN>(p, pname, flops, grid, st);
+        return launch_ring<BM, BN, 5, WGM, WGN>(p, pname, flops, grid, st);
+    } else {
+        if (ns == 3) return launch_ring<BM, BN, 3, WGM, WGN>(p, pname, flops, grid, st);
+        if (ns == 4) return launch_ring<BM, BN, 4, WGM, WGN>(p, pname, flops, grid, st);
+        return launch_ring<BM, BN, 6, WGM, WGN>(p, pname, flops, grid, st);
+    }
 }
 
 template <int BM, int BN>
@@ -2318,14 +2350,19 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         // activations come back from L2 once per tile column — 128 x 128 tiles halve that re-read against 64 x 64 (cold weights,
         // profiles/r04_pool_gemm_stream_kernel_vs_tile_kernels.json: gate/up 34.4 -> 30.5 us, lm_head 163 -> 152 us at M = 128)
         if (glds && p.M > 64 && p.M <= 128 && t128 >= 128 && nk >= 16) tile = 1;
+        // ... and the interleaved gate/up product (SwiGLU epilogue, N = 22016 -> 230 tiles of 96 columns = one per CU where 172 tiles of 128 leave a
+        // third of the chip idle): <128, 96>, waves 4 x 1 so that the [gate 16 | up 16] pairs stay inside a wave, 3 ring stages — deeper rings
+        // measured no faster (a CU's fetch rate is capped by its outstanding requests, not by the bytes a ring keeps in flight).  28.4 against
+        // 32.5-33.0 us at M = 128 with cold weights (profiles/r06_pool_gemm_deep_ring_tiles.json); same K order per element: bit-identical output
+        if (glds && p.M > 64 && p.M <= 128 && nk >= 16 && p.act == ACT_SWIGLU16 && p.N >= 8192 && batch == 1 && p.C32 == nullptr) tile = 6;
         if (big_tile_rule(p.M, p.N, p.K, batch)) tile = 5;      // large M (batched prefill): the 256 x 256 two-phase kernel
     }
     p.splits = 1;
     p.kper = nk + 1;
     p.part = nullptr;
     p.debug = g_gemm_debug;
-    long long tiles = tile == 3 ? t64 : (tile == 2 ? t64x128 : t128);
-    if (can_split) {
+    long long tiles = tile == 3 ? t64 : (tile == 2 ? t64x128 : (tile == 7 ? (long long)cdiv(p.M, 128) * cdiv(p.N, 64) : t128));
+    if (can_split && tile != 6) {
         if (splits == 0) {
             splits = 1;
             if (nk >= 64 && tiles < 512 && tile == 2) {
@@ -2349,6 +2386,18 @@ int gemm_dispatch(GemmParams& p, int batch, hipStream_t st, float* ws, size_t ws
         return launch_gemm_p8(p, batch, st);
     }
     if (tile == 5) tile = 1;
+    if ((tile == 6 || tile == 7) && !(glds && batch == 1 && p.C32 == nullptr)) tile = 1;
+    if (tile == 6) return launch_ring_deep<128, 96, 4, 1>(p, g_gemm_variant >= 3 ? g_gemm_variant : 3, st);
+    if (tile == 7) {
+        const int rc = launch_ring_deep<128, 64, 2, 2>(p, g_gemm_variant >= 3 ? g_gemm_variant : (p.splits > 1 ? 6 : 3), st);
+        if (rc != FO1_OK) return rc;
+        if (p.splits > 1) {
+            const long long total = (long long)p.M * (p.N / 4);
+            const int rg = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+            FO1_LAUNCH("gemm_splitk_reduce", (double)p.M * p.N * 4.0 * p.splits, gemm_splitk_reduce_kernel, dim3(rg), dim3(256), 0, st, p);
+        }
+        return FO1_OK;
+    }
     if (g_gemm_variant >= 3) p.stages = g_gemm_variant;
     else if (g_gemm_variant == 0 && glds && ((tile == 3 && t64 <= 768) || (tile == 2 && tiles * p.splits < 512) || (tile == 1 && auto_tile && p.M <= 128))) p.stages = 3;
     else p.stages = 2;
@@ -2365,7 +2414,7 @@ extern "C" {
 
 #ifdef FO1_ENABLE_AB      // include/fo1_ab.h: test / bench build only
 int fo1_gemm_set_variant(int staging, int tile) {
-    if (staging < 0 || staging > 6 || staging == 5 || tile < 0 || tile > 5) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
+    if (staging < 0 || staging > 6 || tile < 0 || tile > 7 || (staging == 5 && tile != 6)) return fo1::set_err(FO1_ERR_ARG, "gemm: bad variant %d/%d", staging, tile);
     fo1::g_gemm_variant = staging;
     fo1::g_gemm_tile = tile;
     return FO1_OK;
@@ -2585,6 +2634,7 @@ int fo1_gemm_bf16_partials(const void* A, int lda, const void* W, int ldw, int M
     if (p.splits < 2) return set_err(FO1_ERR_ARG, "gemm_partials: K too shallow for %d splits", splits);
     // wide outputs (gate/up: 22016 columns) at 65..128 rows: 128 x 256 tiles — the activations come back from L2 once per tile COLUMN, and
     // 86 column tiles x 3 planes fill the chip where 172 tiles of 128 x 128 with the SwiGLU epilogue leave a third of it idle
+    if (g_gemm_tile == 7 && M > 64 && M <= 128) return launch_ring_deep<128, 64, 2, 2>(p, g_gemm_variant >= 3 ? g_gemm_variant : 6, (hipStream_t)stream);   // (A/B pin)
     if (M > 64 && M <= 128 && N >= 8192 && nk >= 16) return launch_gemm_wide<128, 256>(p, 1, (hipStream_t)stream, false);
     // (128 x 128 tiles for the 65..128-row down projection — the weights fetched once instead of once per 64-row tile — measured no faster:
     // 17.4 vs 16.3 us at 12-16 planes, profiles/r04_pool_step_splitk_sweep.json)

@@ -48,6 +48,61 @@ __global__ __launch_bounds__(512) void mfma_clock_probe_kernel(int operands, int
     if (t == 123.456f) sink[0] = t;       // keeps the accumulators alive
 }
 
+
+// ---- HBM counter calibration (VERDICT r5 #2a): kernels that move a KNOWN number of bytes in the access patterns of the kernels whose
+// rocprofv3 FETCH_SIZE / WRITE_SIZE readings the roofline quotes.  MI355X_MICROARCH.md: FETCH_SIZE reads half of a wide coalesced stream,
+// "other access widths and WRITE_SIZE are uncalibrated: calibrate on a known byte count in your own access pattern".
+//   mode 0  stream store: every lane 16 B, a wave = 1 KB contiguous (the plain epilogues, norms, copies)
+//   mode 1  tile store: the 256 x 256 GEMM's coalesced epilogue — a wave instruction = 8 row segments of 128 B at the row pitch `ld` bytes,
+//           a workgroup of 512 threads writes a 256-row x 512-byte tile in 16 sweeps, tiles walk the [rows, ld] matrix
+//   mode 2  stream load: every lane 16 B contiguous (what the guide calibrated: x2)
+//   mode 3  tile load by LDS-DMA: global_load_lds_dwordx4, a wave instruction = 8 rows x 128 B at the row pitch (the GEMM's A / W staging)
+//   mode 4  stream store, 8 B per lane;  mode 5: stream store, 4 B per lane (the fragment-shaped epilogues)
+typedef unsigned int probe_u32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void traffic_probe_kernel(int mode, unsigned char* __restrict__ buf, long long bytes, long long ld, float* __restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[512 * 16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const probe_u32x4 val = {0x3F803F80u + (unsigned)tid, 0x40004000u, 0xBF80BF80u, (unsigned)blockIdx.x};
+    probe_u32x4 acc = {0u, 0u, 0u, 0u};
+    if (mode == 0 || mode == 2 || mode == 4 || mode == 5) {
+        const int w = mode == 4 ? 8 : (mode == 5 ? 4 : 16);
+        const long long n = bytes / w;
+        for (long long i = (long long)blockIdx.x * 512 + tid; i < n; i += (long long)gridDim.x * 512) {
+            if (mode == 0) *reinterpret_cast<probe_u32x4*>(buf + i * 16) = val;
+            else if (mode == 4) *reinterpret_cast<uint2*>(buf + i * 8) = uint2{val.x, val.y};
+            else if (mode == 5) *reinterpret_cast<unsigned*>(buf + i * 4) = val.x;
+            else { const probe_u32x4 v = *reinterpret_cast<const probe_u32x4*>(buf + i * 16); acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w; }
+        }
+    } else {
+        // [rows, ld bytes] matrix cut into tiles of 256 rows x 512 bytes
+        const long long rows = bytes / ld, tiles_n = ld / 512, tiles = (rows / 256) * tiles_n;
+        for (long long t = blockIdx.x; t < tiles; t += gridDim.x) {
+            const long long r0 = (t / tiles_n) * 256, c0 = (t % tiles_n) * 512;
+            if (mode == 1) {
+                // lane -> (row of an 8-row group, 16-byte piece of a 128-byte segment); a wave covers 8 rows x 128 B per store, 4 stores per 512-byte row
+#pragma unroll
+                for (int sw = 0; sw < 16; ++sw) {
+                    const int r = (sw >> 2) * 64 + wave * 8 + (lane >> 3), seg = sw & 3;
+                    *reinterpret_cast<probe_u32x4*>(buf + (r0 + r) * ld + c0 + seg * 128 + (lane & 7) * 16) = val;
+                }
+            } else {
+#pragma unroll
+                for (int sw = 0; sw < 16; ++sw) {
+                    const int r = (sw >> 2) * 64 + wave * 8 + (lane >> 3), seg = sw & 3;
+                    const unsigned char* src = buf + (r0 + r) * ld + c0 + seg * 128 + (lane & 7) * 16;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                     (__attribute__((address_space(3))) void*)(lds + wave * 1024), 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const probe_u32x4 v = *reinterpret_cast<const probe_u32x4*>(lds + tid * 16);
+                acc.x ^= v.x; acc.y ^= v.y;
+            }
+        }
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345679u) sink[0] = 1.f;     // keeps the loads alive
+}
+
 }  // namespace fo1
 
 extern "C" {
@@ -59,6 +114,19 @@ int fo1_mfma_clock_probe(int operands, int iters, int workgroups, void* out, voi
     FO1_CHECK_ARG(out && sink && iters >= 1 && workgroups >= 1 && (operands == 0 || operands == 1), "mfma_clock_probe: bad arguments");
     FO1_LAUNCH("mfma_clock_probe", (double)workgroups * 8.0 * iters * 32.0 * 32768.0, mfma_clock_probe_kernel, dim3(workgroups), dim3(512), 0,
                (hipStream_t)stream, operands, iters, (unsigned long long*)out, (float*)sink);
+    return FO1_OK;
+}
+
+
+// Moves exactly `bytes` (a multiple of 256 rows x ld for the tile modes; ld a multiple of 512) in one of the access patterns above: run it
+// under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` and divide (scripts/pmc_calibrate.py).  buf: device, >= bytes.
+int fo1_traffic_probe(int mode, void* buf, long long bytes, long long ld, int workgroups, void* sink, void* stream) {
+    using namespace fo1;
+    FO1_CHECK_ARG(buf && sink && mode >= 0 && mode <= 5 && bytes > 0 && bytes % 16 == 0, "traffic_probe: bad arguments");
+    if (mode == 1 || mode == 3) FO1_CHECK_ARG(ld >= 512 && ld % 512 == 0 && bytes % (256 * ld) == 0, "traffic_probe: tile modes need ld %% 512 == 0 and bytes %% (256 ld) == 0");
+    static const char* names[6] = {"traffic_probe_stream_store16", "traffic_probe_tile_store", "traffic_probe_stream_load16", "traffic_probe_tile_load_lds",
+                                   "traffic_probe_stream_store8", "traffic_probe_stream_store4"};
+    FO1_LAUNCH(names[mode], (double)bytes, traffic_probe_kernel, dim3(workgroups > 0 ? workgroups : 2048), dim3(512), 0, (hipStream_t)stream, mode, (unsigned char*)buf, bytes, ld, (float*)sink);
     return FO1_OK;
 }
 

@@ -265,10 +265,20 @@ int fo1_llm_decode_step(const fo1_llm_weights_t* w, const fo1_kv_cache_t* slots,
         // input_layernorm + QKV + bias + mRoPE + K row / V^T column append, one launch; q rows out
         FO1_TRY(fo1_gemv_batch_bf16(x, d, L.wqkv, d, L.bqkv, nullptr, 0, q, H * HD, B, qd, d, 2, L.ln1, w->rms_eps, H, KV, rope_cos, rope_sin, state, kc,
                                     slots->k_head_stride, vtc, slots->vt_row_stride, stream));
-        FO1_TRY(fo1_attention_decode_batch_bf16(q, (long long)H * HD, kc, HD, slots->k_head_stride, vtc, slots->vt_row_stride, att, (long long)H * HD, state, B,
-                                                max_kv_len, H, KV, HD, scale, aws, abytes, stream));
-        FO1_TRY(fo1_gemv_batch_bf16(att, H * HD, L.wo, H * HD, nullptr, x, d, y, d, B, d, H * HD, 0, nullptr, 0.f, 0, 0, nullptr, nullptr, nullptr, nullptr, 0,
-                                    nullptr, 0, stream));
+        if (B <= 2 && H * HD <= 2048 && d <= 4096) {
+            // one or two sequences: the o-projection sums the split-KV partials in its prologue (fo1_gemv_attn_combine_bf16) — no combine launch,
+            // same bits (the Python mirror, llm.BatchDecoder, takes the same route)
+            int chunk = 0;
+            long long pstride = 0;
+            FO1_TRY(fo1_attention_decode_batch_partials_bf16(q, (long long)H * HD, kc, HD, slots->k_head_stride, vtc, slots->vt_row_stride, state, B, max_kv_len, H, KV, HD,
+                                                             scale, aws, abytes, &chunk, &pstride, stream));
+            FO1_TRY(fo1_gemv_attn_combine_bf16((const float*)aws, pstride, state, chunk, H, KV, L.wo, H * HD, x, d, y, d, B, d, stream));
+        } else {
+            FO1_TRY(fo1_attention_decode_batch_bf16(q, (long long)H * HD, kc, HD, slots->k_head_stride, vtc, slots->vt_row_stride, att, (long long)H * HD, state, B,
+                                                    max_kv_len, H, KV, HD, scale, aws, abytes, stream));
+            FO1_TRY(fo1_gemv_batch_bf16(att, H * HD, L.wo, H * HD, nullptr, x, d, y, d, B, d, H * HD, 0, nullptr, 0.f, 0, 0, nullptr, nullptr, nullptr, nullptr, 0,
+                                        nullptr, 0, stream));
+        }
         // post_attention_layernorm + gate/up + SwiGLU, one launch; then down + residual
         FO1_TRY(fo1_gemv_batch_bf16(y, d, L.wgu, d, nullptr, nullptr, 0, a, I, B, 2 * I, d, 1, L.ln2, w->rms_eps, 0, 0, nullptr, nullptr, nullptr, nullptr, 0,
                                     nullptr, 0, stream));

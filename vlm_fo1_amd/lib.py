@@ -253,6 +253,10 @@ SIGNATURES = {
     "fo1_attention_decode_batch_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "fo1_attention_decode_batch_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p,
                                                 c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p]),
+    "fo1_attention_decode_batch_partials_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p, c_int, c_int,
+                                                         c_int, c_int, c_int, c_float, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "fo1_gemv_attn_combine_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int,
+                                           c_void_p]),
     "fo1_decode_argmax_accept": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int,
                                          c_void_p, c_void_p, c_void_p]),
     "fo1_kv_relocate": (c_int, [c_void_p, c_void_p, c_longlong, c_longlong, c_longlong, c_longlong, c_void_p, c_void_p, c_longlong, c_longlong,
@@ -276,9 +280,11 @@ SIGNATURES_AB = {
     "fo1_gemv_batch_set_impl": (c_int, [c_int]),
     "fo1_attention_decode_set_impl": (c_int, [c_int]),
     "fo1_attention_decode_set_pool_chunk": (c_int, [c_int]),
+    "fo1_attention_decode_set_small_chunk": (c_int, [c_int]),
     # measured no-gain kernel forms and instruments (round 5: out of the product ABI)
     "fo1_gemm_profile_shapes": (c_int, [c_int]),
     "fo1_mfma_clock_probe": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "fo1_traffic_probe": (c_int, [c_int, c_void_p, c_longlong, c_longlong, c_int, c_void_p, c_void_p]),
     "fo1_gemm_bf16_wtiled": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_splitk_swiglu_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
 }

@@ -577,6 +577,7 @@ class BatchDecoder:
     positions = cache position + rope delta (modeling_qwen2_5_vl.py:1848-1860); a sequence stops AFTER its EOS / keyword id has
     been appended, or at max_new_tokens (mm_utils.py:137-181, 640-654)."""
     MAX_BATCH = 32          # 17..32 sequences: two 16-column groups per weight fragment (decode_mfma.hip, MM = 32)
+    FUSED_COMBINE_MAX = 2   # up to this many sequences the o-projection combines the split-KV attention partials itself (0 = always the combine launch; A/B)
     IDS_CAP = 4096          # generated ids kept per sequence (every reference caller uses max_new_tokens <= 4096)
     MAX_STOP = 16           # stop ids the device-side rule compares against
 
@@ -683,8 +684,14 @@ class BatchDecoder:
             for li, w in enumerate(llm.layers):
                 q = ops.gemv_batch(x, w["wqkv"], w["bqkv"], mode=ops.GB_QKV, norm_weight=w["ln1"], norm_eps=c.rms_norm_eps,
                                    qkv=dict(n_q=H, n_kv=KV, cos=llm.rope_cos, sin=llm.rope_sin, state=st, kcache=self.dk[li], vtcache=self.dvt[li]))
-                att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, self.kv_bucket(), H, KV, HD, scale)
-                x = ops.gemv_batch(att, w["wo"], residual=x)
+                if B <= self.FUSED_COMBINE_MAX and H * HD <= 2048 and c.hidden_size <= 4096:
+                    # one or two sequences (the reference's own batch-1 loop): the o-projection sums the split-KV partials in its prologue — same
+                    # bits as the combine launch (one shared routine, csrc/decode_common.h), one launch less per layer
+                    part, pstride, chunk = ops.attention_decode_batch_partials(q, self.dk[li], self.dvt[li], st, self.kv_bucket(), H, KV, HD, scale)
+                    x = ops.gemv_attn_combine(part, pstride, st, chunk, H, KV, w["wo"], residual=x)
+                else:
+                    att = ops.attention_decode_batch(q, self.dk[li], self.dvt[li], st, self.kv_bucket(), H, KV, HD, scale)
+                    x = ops.gemv_batch(att, w["wo"], residual=x)
                 a = ops.gemv_batch(x, w["wgu"], mode=ops.GB_SWIGLU, norm_weight=w["ln2"], norm_eps=c.rms_norm_eps)
                 x = ops.gemv_batch(a, w["wdown"], residual=x)
             logits = ops.gemv_batch(x, llm.lm_head, norm_weight=llm.norm, norm_eps=c.rms_norm_eps)

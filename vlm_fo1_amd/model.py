@@ -12,6 +12,7 @@ and `OmChatMetaModel.__init__` (omchat_arch.py:8-33).  Host code orchestrates li
 from __future__ import annotations
 
 import math
+import os
 import re
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -568,13 +569,20 @@ class FO1Engine:
         return out
 
     # ---- continuous batching: one decode pool per GPU, shared by every replica (vlm_fo1_amd/serving.py) -------------------------------
-    def enable_decode_pool(self, slots: int = 128, slot_rows: int = 1024, steps_per_round: int = 4):
+    DECODE_POOLS = 1       # decode pools per GPU stepping concurrently on their own streams (serving.PoolGroup); FO1_DECODE_POOLS overrides
+
+    def enable_decode_pool(self, slots: int = 128, slot_rows: int = 1024, steps_per_round: int = 4, pools: Optional[int] = None):
         """From now on generate_batch() / submit_batch() of this engine AND of the replicas made from it afterwards hand their sequences
-        to ONE DecodePool (llm.DecodePool): the sequences of successive prefill passes — of any replica — share every decode step
-        (64 / 128 per weight stream instead of <= 32 per pass).  Returns the service."""
-        from .serving import PoolService
+        to the GPU's decode pool(s) (llm.DecodePool): the sequences of successive prefill passes — of any replica — share every decode step
+        (64 / 128 per weight stream instead of <= 32 per pass).  pools > 1: that many pools advance concurrently on their own HIP streams
+        (serving.PoolGroup).  Returns the service."""
+        from .serving import PoolGroup, PoolService
         if getattr(self, "_pool_svc", None) is None:
-            self._pool_svc = PoolService(self.llm, slots=slots, slot_rows=slot_rows, steps_per_round=steps_per_round)
+            n = int(pools if pools is not None else os.environ.get("FO1_DECODE_POOLS", self.DECODE_POOLS))
+            if n > 1:
+                self._pool_svc = PoolGroup(self.llm, pools=n, slots=slots, slot_rows=slot_rows, steps_per_round=steps_per_round)
+            else:
+                self._pool_svc = PoolService(self.llm, slots=slots, slot_rows=slot_rows, steps_per_round=steps_per_round)
         return self._pool_svc
 
     def disable_decode_pool(self) -> None:

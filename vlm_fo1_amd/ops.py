@@ -671,6 +671,42 @@ def attention_decode_batch(q: torch.Tensor, kcache: torch.Tensor, vtcache: torch
     return out
 
 
+def attention_decode_batch_partials(q: torch.Tensor, kcache: torch.Tensor, vtcache: torch.Tensor, state: torch.Tensor, max_kv_len: int,
+                                    n_q_heads: int, n_kv_heads: int, head_dim: int, scale: float):
+    """The split-KV half of attention_decode_batch alone -> (partials workspace, floats per sequence, keys per chunk) for gemv_attn_combine."""
+    _chk(q, "q"); _chk(kcache, "kcache"); _chk(vtcache, "vtcache")
+    assert state.dtype == torch.int32 and state.is_contiguous() and kcache.dim() == 3
+    pq, ldq, B, _ = _rows(q, "q")
+    need = _L.load().fo1_attention_decode_batch_workspace_bytes(max_kv_len, n_kv_heads, head_dim, B)
+    ws = _workspace("attn_decode", q.device, need)
+    pv, ldv, _, _ = _rows(vtcache, "vtcache")
+    chunk, stride = ctypes.c_int(0), ctypes.c_longlong(0)
+    rc = _L.load().fo1_attention_decode_batch_partials_bf16(pq, ldq, kcache.data_ptr(), kcache.stride(1), kcache.stride(0), pv, ldv, state.data_ptr(), B,
+                                                            max_kv_len, n_q_heads, n_kv_heads, head_dim, float(scale), ws.data_ptr(), ws.numel(),
+                                                            ctypes.byref(chunk), ctypes.byref(stride), _stream())
+    _L.check(rc, "fo1_attention_decode_batch_partials_bf16")
+    return ws, stride.value, chunk.value
+
+
+def gemv_attn_combine(part: torch.Tensor, part_seq_stride: int, state: torch.Tensor, kv_chunk: int, n_q_heads: int, n_kv_heads: int, w: torch.Tensor,
+                      residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """o-projection of a decode step at <= 2 sequences, the attention combine in its prologue (fo1_gemv_attn_combine_bf16)."""
+    _chk(w, "w")
+    pw, ldw, N, K = _rows(w, "w")
+    M = state.shape[0]
+    assert K == n_q_heads * 128 and M <= 2 and state.dtype == torch.int32 and state.is_contiguous()
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=w.device)
+    po, ldc, _, _ = _rows(out, "out")
+    pr, ldr = (None, 0)
+    if residual is not None:
+        pr, ldr, _, _ = _rows(residual, "residual")
+    rc = _L.load().fo1_gemv_attn_combine_bf16(part.data_ptr(), int(part_seq_stride), state.data_ptr(), int(kv_chunk), n_q_heads, n_kv_heads, pw, ldw, pr, ldr,
+                                              po, ldc, M, N, _stream())
+    _L.check(rc, "fo1_gemv_attn_combine_bf16")
+    return out
+
+
 # ---- decode pool: 64 / 128 sequence slots per weight stream (llm.DecodePool) ---------------------------------------------------------
 def pool_qkv_post(qkv: torch.Tensor, n_q: int, n_kv: int, head_dim: int, cos_table: torch.Tensor, sin_table: torch.Tensor, state: torch.Tensor,
                   kcache: torch.Tensor, vtcache: torch.Tensor) -> None:

@@ -209,3 +209,47 @@ class PoolService:
                     break
                 if it is not None:
                     it[0]._fail(e)
+
+
+class PoolGroup:
+    """Several decode pools on ONE GPU behind the PoolService interface (round 6).  A pool step is a chain of ~290 short dependent launches,
+    each with a ramp and a tail and none using more than ~40 % of the memory system; two such chains on two HIP streams interleave on the
+    GPU, and the second reader of a weight tile finds it in the 256 MB Infinity Cache while the chains stay within a layer of each other:
+    two pools of 128 live sequences stepping concurrently deliver 44.5k tokens/s where one delivers 32.9k (profiles/r06_two_decode_pools.json).
+    Every pool is a full PoolService (own scheduler thread, stream, DecodePool); a submission goes, whole, to the pool with the fewest
+    sequences in flight.  Per sequence nothing changes: same kernels, same launch shapes, same sums — the ids do not depend on which pool
+    or which neighbours a sequence has (tests/test_decode_pool_gpu.py)."""
+
+    def __init__(self, llm: QwenLLM, pools: int = 2, slots: int = 128, slot_rows: int = 1024, steps_per_round: int = 4, use_graph: bool = True):
+        if pools < 1:
+            raise ValueError("a pool group has at least one pool")
+        self.services = [PoolService(llm, slots=slots, slot_rows=slot_rows, steps_per_round=steps_per_round, use_graph=use_graph) for _ in range(pools)]
+        self._submitted = [0] * pools         # sequences handed to each pool so far (its own statistics count the finished ones)
+        self._lock = threading.Lock()
+
+    @property
+    def pool(self) -> DecodePool:
+        return self.services[0].pool
+
+    @property
+    def pools(self) -> List[DecodePool]:
+        return [s.pool for s in self.services]
+
+    @property
+    def stats(self) -> dict:
+        out = dict(steps=0, joined=0, finished=0, occupancy_sum=0)
+        for s in self.services:
+            for k in out:
+                out[k] += s.stats[k]
+        out["pools"] = len(self.services)
+        return out
+
+    def submit(self, src_llm: QwenLLM, seqs, deltas, first_tokens: torch.Tensor, max_new_tokens: int, stop_ids: Sequence[int] = ()) -> PoolHandle:
+        with self._lock:
+            k = min(range(len(self.services)), key=lambda i: (self._submitted[i] - self.services[i].stats["finished"], i))
+            self._submitted[k] += len(seqs)
+        return self.services[k].submit(src_llm, seqs, deltas, first_tokens, max_new_tokens, stop_ids)
+
+    def close(self):
+        for s in self.services:
+            s.close()

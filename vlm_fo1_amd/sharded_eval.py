@@ -77,8 +77,12 @@ def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu",
     dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
     kmax = max([len(t) for _, t in local if t is not None] + [0])
     meta = torch.tensor([kmax, len(local), 1 if fatal is not None else 0], dtype=torch.int64, device=dev)
+    import time
+    t_meet = time.perf_counter()
     dist.all_reduce(meta, op=dist.ReduceOp.MAX)
-    kmax, nmax = int(meta[0]), int(meta[1])
+    kmax, nmax = int(meta[0]), int(meta[1])          # (the host read waits for the collective: this rank has now MET the slowest one)
+    LAST.update(gather_wait_ms=(time.perf_counter() - t_meet) * 1e3)
+    t_coll = time.perf_counter()
     if int(meta[2]):
         if fatal is not None:
             raise fatal
@@ -100,7 +104,8 @@ def gather_records(local: List[Tuple[int, Optional[List[int]]]], device="cpu",
     dist.all_gather(out, rec)
     if dev.type == "cuda":
         torch.cuda.current_stream().synchronize()
-    LAST.update(gather_record_bytes_per_rank=int(host.nbytes), gather_backend=dist.get_backend(), gather_world=dist.get_world_size())
+    LAST.update(gather_record_bytes_per_rank=int(host.nbytes), gather_backend=dist.get_backend(), gather_world=dist.get_world_size(),
+                gather_collective_ms=(time.perf_counter() - t_coll) * 1e3)      # record block H2D + the one all_gather, after the ranks have met
     if rank != 0:
         return None
     merged = []
@@ -267,6 +272,7 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
     or `generate([i0, ...], [prepared0, ...])`."""
     import time
     t_start = time.perf_counter()
+    enter_wall = time.time()
     rank, world, _ = world_info()
     mine = assign(costs, world)[rank]
     workers = list(generate) if isinstance(generate, (list, tuple)) else [generate]
@@ -390,7 +396,8 @@ def run_sharded(n_items: int, costs: Sequence[float], generate, device="cpu", pr
     import time
     t_shard = time.perf_counter()
     LAST.clear()
-    LAST.update(rank=rank, world=world, shard_items=len(mine), shard_seconds=t_shard - t_start)
+    LAST.update(rank=rank, world=world, shard_items=len(mine), shard_seconds=t_shard - t_start, enter_wall=enter_wall,
+                shard_cost=float(sum(costs[i] for i in mine)))
     merged = gather_records(local, device, fatal=fatal)
     LAST.update(gather_ms=(time.perf_counter() - t_shard) * 1e3, merged=merged)
     return merged
