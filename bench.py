@@ -1028,6 +1028,8 @@ def main():
     L.load()
     if os.environ.get("FO1_GEMM_GROUP_M") and L.ab_build():      # A/B of the 256 x 256 GEMM's tile order (include/fo1_ab.h, FO1_AB=1 runs only)
         L.load().fo1_gemm_set_group_m(int(os.environ["FO1_GEMM_GROUP_M"]))
+    if os.environ.get("FO1_HFRE_ORDER") and L.ab_build():        # A/B of the HFRE work-list order: 0 = interleaved buckets (rounds 2-5), 1 = box-major (image-major)
+        L.load().fo1_hfre_set_tuning(8, 512, -4 if int(os.environ["FO1_HFRE_ORDER"]) else -3, 0)
     img_hw = tuple(int(v) for v in args.image.lower().split("x"))
     S_img = (round(img_hw[0] / 28) * 2) * (round(img_hw[1] / 28) * 2)
     auto_batch = args.batch <= 0

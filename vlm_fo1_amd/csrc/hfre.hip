@@ -78,6 +78,9 @@ struct HfreParams {
                                                 // before mm_projector_aux (omchat_qwen2_5_vl.py:106): the cast rides in the finish kernel
     int band_mode;                              // 1: hfre_pool_bands_kernel (slices = row ranges of rr rows), 0: work list (slices by pixel budget)
     int n_images, band_items;                   // band path: images in the call, total work items
+    int bucket_per;                             // work-list order: > 0 = (box, source) pair q appends to bucket q / bucket_per (the list is then walked
+                                                // box-major = IMAGE-major: what is in flight at any time reads ONE image's maps, 55 MB of the 256 MB
+                                                // Infinity Cache, so the overlapping proposals' re-reads stop at the cache instead of HBM); 0 = q % 64 (rounds 2-5)
     float* dimt;                                // work-list path: dim_t table of the sine embedding, region_dim / 8 entries (written by
                                                 // hfre_weights_kernel, read by hfre_finish_vec_kernel); nullptr = powf per element
 };
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(kHfreWThreads) void hfre_weights_kernel(const HfreP
         // results do not (every item owns its partial row, the finish sums in slice order)
         __shared__ int s_base;
         const int cnt = f.n_slices * s.nchunks;
-        const int bucket = blockIdx.x % kHfreBuckets;
+        const int bucket = p.bucket_per > 0 ? (int)blockIdx.x / p.bucket_per : (int)blockIdx.x % kHfreBuckets;
         if (tid == 0) s_base = atomicAdd(p.n_items + bucket * kHfreCtrStride, cnt);
         __syncthreads();
         int2* list = p.items + (size_t)bucket * p.items_cap;
@@ -788,6 +791,7 @@ FO1_AB_VAR g_hfre_finish_vec = 1;     // 16-byte finish (A/B: fo1_hfre_set_tunin
 FO1_AB_VAR g_hfre_grid = 4096;       // workgroups walking the work list (profiles/r02_hfre_sweep.json)
 FO1_AB_VAR g_hfre_bands = 0;         // 0 = work list (default), 1 = band kernel (every map row read once: measured 4x slower, A/B only); fo1_hfre_set_tuning(budget = -1 / -2)
 FO1_AB_VAR g_hfre_rr = 32;           // band path: rows per work item
+FO1_AB_VAR g_hfre_order = 1;         // work-list order: 1 = box-major (image-major) buckets, 0 = pairs interleaved over the 64 buckets (rounds 2-5); fo1_hfre_set_tuning(budget = -4 / -3)
 
 // workspace = [partials: n_boxes * ws_box_stride floats][weights: n_boxes*n_sources*2*kHfreWStride floats][headers: n_boxes*n_sources*8 ints]
 static size_t hfre_ws_total(const HfreParams& p, int n_sources, int n_boxes) {
@@ -878,6 +882,10 @@ int fo1_hfre_set_pixel_budget(int pixels) {
 // tuning hooks of fo1_hfre_region_pool_ex: unroll 8 | 16 independent loads per lane; chunk = channels per workgroup (64..512, power
 // of two); budget = pixels per slice (0 keeps the current value); grid = workgroups walking the work list (0 keeps)
 int fo1_hfre_set_tuning(int unroll, int chunk, int budget, int grid) {
+    if (budget == -3 || budget == -4) {                // A/B: work-list order, -3 = interleaved buckets (rounds 2-5), -4 = box-major buckets (default)
+        fo1::g_hfre_order = budget == -4 ? 1 : 0;
+        return FO1_OK;
+    }
     if (budget == -1 || budget == -2) {                // A/B: -1 = work-list form (default), -2 = band form; the rest is ignored
         fo1::g_hfre_bands = budget == -2 ? 1 : 0;
         if (grid > 0) fo1::g_hfre_rr = grid;           // with -2: rows per work item
@@ -1085,6 +1093,7 @@ int fo1_hfre_region_pool_ex(const fo1_hfre_source_t* sources, int n_sources, con
     p.hdr = (int*)(wsb + off_h);
     p.items = p.band_mode ? nullptr : (int2*)(wsb + off_i);      // band form: no work list (hfre_weights_kernel skips it)
     p.items_cap = hfre_bucket_cap(p, n_sources, n_boxes);
+    p.bucket_per = g_hfre_order ? (int)(((long long)n_boxes * n_sources + kHfreBuckets - 1) / kHfreBuckets) : 0;      // (the capacity rule of hfre_bucket_cap: <= ceil(pairs / 64) pairs per bucket either way)
     hipStream_t st = (hipStream_t)stream;
     FO1_LAUNCH("hfre_weights", (double)n_boxes * n_sources * 64.0, hfre_weights_kernel, dim3(n_boxes * n_sources), dim3(kHfreWThreads), 0, st, p);
     double bytes = (double)n_boxes * region_dim * 4.0 + (double)n_boxes * 16.0;
