@@ -361,31 +361,6 @@ def test_batch_decoder_fused_combine_gives_the_ids_of_the_combine_launch():
         BatchDecoder.FUSED_COMBINE_MAX = 2
 
 
-def test_deep_k_projection_in_one_piece_equals_the_piece_wise_walk_bitwise(ab_library):
-    """Round 6: `down` (K = 11008) at <= 4 sequences with the whole K of x in LDS and every register stage of a unit requested up front
-    (gemv_mfma_kernel XRQ / PDX) against the piece-wise walk (fo1_gemv_batch_set_impl bit 3) — the same bits, for M = 1..4, with a residual
-    and a K that is not a multiple of the k-step (clamped tail)."""
-    from vlm_fo1_amd import lib as L, ops
-    g = torch.Generator().manual_seed(5)
-    for N, K in ((2048, 11008), (2048, 8192 + 64), (1280, 5000 - 5000 % 8)):
-        w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
-        for M in (1, 2, 3, 4):
-            x = torch.randn(M, K, generator=g).bfloat16().cuda()
-            r = torch.randn(M, N, generator=g).bfloat16().cuda()
-            got = ops.gemv_batch(x, w, residual=r)
-            try:
-                L.check(L.load().fo1_gemv_batch_set_impl(1 | 8), "piece-wise")
-                want = ops.gemv_batch(x, w, residual=r)
-            finally:
-                L.load().fo1_gemv_batch_set_impl(1)
-            assert torch.equal(got, want), (N, K, M, (got.float() - want.float()).abs().max().item())
-            ref = (x.float() @ w.float().t()).bfloat16().float() + r.float()
-            assert (got.float() - ref).abs().max().item() <= 0.05 * ref.abs().max().item() + 0.05
-        # M = 5 keeps the piece-wise walk (8 staged rows do not fit): still equal to its own rows at M = 4
-        x5 = torch.randn(5, K, generator=g).bfloat16().cuda()
-        assert torch.equal(ops.gemv_batch(x5, w)[:4], ops.gemv_batch(x5[:4].contiguous(), w))
-
-
 def test_gemv_batch_rows_independent_of_batch(ab_library):
     """Sequence m's outputs are the same numbers whether it runs alone or with 7 others, and whatever the rows-per-lane blocking:
     the per-(row, sequence) fp32 sum order is fixed by the shape alone (K segments, K split over waves, 8 lanes per row) — what

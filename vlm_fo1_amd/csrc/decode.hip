@@ -556,8 +556,6 @@ int fo1_gemv_batch_set_rows_per_lane(int rpl) {
 // A/B hook: 1 (default) = MFMA skinny GEMM (decode_mfma.hip, M <= 32); 0 = the v_dot2 streaming kernel (M <= 8);
 // 3 = MFMA without any 8-row units; 5 = MFMA with the M <= 8 (HALF) units only, i.e. without round 3's R8 units for 9..32 sequences.
 int fo1_gemv_batch_set_impl(int impl) {
-    fo1::g_gemv_deep = (impl & 8) ? 0 : 1;          // bit 3: the piece-wise walk for deep-K projections at <= 4 sequences (round 6 A/B)
-    impl &= ~8;
     if (impl != 0 && impl != 1 && impl != 3 && impl != 5) return fo1::set_err(FO1_ERR_ARG, "gemv_batch_set_impl: %d", impl);
     fo1::g_gemv_impl = impl & 1;
     fo1::g_gemv_half = (impl & 2) ? 0 : ((impl & 4) ? 1 : 3);

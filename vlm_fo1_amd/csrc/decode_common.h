@@ -77,10 +77,8 @@ enum { GB_PLAIN = 0, GB_SWIGLU = 1, GB_QKV = 2 };
 // decode_mfma.hip
 #ifdef FO1_ENABLE_AB
 extern int g_gemv_half;   // decode_mfma.hip: bit 0 = 8-row units at M <= 8 (HALF), bit 1 = at 9..32 sequences (R8)
-extern int g_gemv_deep;   // decode_mfma.hip: the one-piece deep-K form at <= 4 sequences (round 6)
 #else
 [[maybe_unused]] static constexpr int g_gemv_half = 3;
-[[maybe_unused]] static constexpr int g_gemv_deep = 1;
 #endif
 int gemv_mfma_any(GemvBParams& p, int mode, hipStream_t st);
 

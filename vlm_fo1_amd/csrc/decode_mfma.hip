@@ -72,11 +72,7 @@ __device__ __forceinline__ void gm_lds_fence() {
 // MM: staged x rows (8 or 16).  NB: 16-row weight blocks per unit (SwiGLU / QKV pair two blocks whose rows meet in one lane).
 // MP: K spans several staged pieces (deep-K projections); single-piece kernels stage x once and carry no reload logic.
 // HALF: 8-row blocks, a register stage = the k-step pair (s, s + 8) of those rows (M <= 8 only; no SwiGLU form).
-// XRQ / PDX (round 6, deep-K projections at <= 4 sequences — `down`, K = 11008 — in ONE piece): XRQ = x rows staged (0 = MM: 8 rows of 22 KB do not fit,
-// 4 do), PDX = register stages per wave (0 = the default 2 / 4: 11 stages x the k-step pair (s, s + 8) cover 176 k-steps).  The whole K of x sits in LDS,
-// every stage of a unit is requested up front and there is no per-piece barrier; the k-steps enter each chain in the same increasing order as the
-// piece-wise walk, so the sums are the same bits.
-template <int MM, int MODE, int NB, bool MP, bool HALF, bool R8 = false, int XRQ = 0, int PDX = 0>
+template <int MM, int MODE, int NB, bool MP, bool HALF, bool R8 = false>
 __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, const int n_units, const int nsteps) {
     static_assert(MODE == GB_PLAIN || NB == 2, "paired modes use two row blocks");
     static_assert(!HALF || (MM == 8 && MODE != GB_SWIGLU), "HALF: M <= 8, plain or QKV");
@@ -87,20 +83,17 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     constexpr int MR = MM == 32 ? 16 : MM;                               // sequences per group
     constexpr bool XREG = MM == 32 && !MP;                               // x fragments live in registers (single-piece K)
     constexpr bool H8 = HALF || R8;                                      // 8-row blocks, a stage = the k-step pair (s, s + 8)
-    constexpr int XR = XRQ > 0 ? XRQ : MM;                               // x rows staged in LDS
-    static_assert(XRQ == 0 || (HALF && !MP && MM == 8 && MODE == GB_PLAIN && PDX > 0), "the few-row deep-K form: 8-row units, single piece, plain epilogue");
-    constexpr int PD = PDX > 0 ? PDX : (R8 ? 2 : ((HALF && !MP) ? 2 : ((MM == 32 && MP) ? 2 : 4)));   // register stages per wave = stages per staged piece
+    constexpr int PD = R8 ? 2 : ((HALF && !MP) ? 2 : ((MM == 32 && MP) ? 2 : 4));   // register stages per wave = stages per staged piece
     constexpr int SSTEP = H8 ? 16 : 8;                                   // k-step distance between a wave's consecutive stages
     constexpr int PSTEPS = SSTEP * PD;                                   // k-steps of x staged at a time: 32 (64: HALF && MP)
     constexpr int XPITCH = PSTEPS * 128 + 32;                            // bytes per staged x row (= 32 mod 256)
     constexpr int CPR = PSTEPS * 8;                                      // 16-byte chunks per staged x row
-    constexpr bool WIDE = CPR > GM_NT;                                   // a staged row is wider than one pass of the workgroup (XRQ form): flat (row, chunk) index
-    constexpr int RPP = WIDE ? 1 : GM_NT / CPR;                          // x rows per pass of the workgroup (2 or 1)
-    constexpr int XL = WIDE ? (XR * CPR + GM_NT - 1) / GM_NT : MM / RPP; // x loads per thread and piece
+    constexpr int RPP = GM_NT / CPR;                                     // x rows per pass of the workgroup (2 or 1)
+    constexpr int XL = MM / RPP;                                         // x loads per thread and piece
     constexpr int RB = H8 ? 8 : 16;                                      // weight rows per block
     extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
     unsigned char* const sx = gm_smem;                                   // [MM][XPITCH]
-    unsigned char* const sw = XREG ? gm_smem : gm_smem + XR * XPITCH;    // [GM_NW][NB][2048]  weight scratch (wave-private); XREG: over the dead x image
+    unsigned char* const sw = XREG ? gm_smem : gm_smem + MM * XPITCH;    // [GM_NW][NB][2048]  weight scratch (wave-private); XREG: over the dead x image
     float* const sred = reinterpret_cast<float*>(sw + GM_NW * NB * 2048);   // [2][NG][GM_NW][NB][64][4]
     float* const srstd = XREG ? reinterpret_cast<float*>(gm_smem + MM * XPITCH) : sred + 2 * NG * GM_NW * NB * 256;   // [32]
     static_assert(!XREG || GM_NW * NB * 2048 + 2 * NG * GM_NW * NB * 1024 <= MM * XPITCH, "scratch + reduction buffers fit in the x image");
@@ -110,7 +103,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     const int lrow = lane >> 3, lch = lane & 7;                          // load shape: row of an 8-row group, chunk of the 128-byte k-step
     const int fi = lane & 15, fg = lane >> 4;                            // fragment shape: MFMA row / column, k group
     unsigned char* const swv = sw + wave * (NB * 2048);
-    const int xrow = MR == 16 ? fi : (XR < 8 ? ((fi & 7) < XR ? (fi & 7) : XR - 1) : (fi & 7));      // (XRQ form: the columns past the staged rows repeat the last one; never stored)
+    const int xrow = MR == 16 ? fi : (fi & 7);
     const int n_rope = MODE == GB_QKV ? (p.n_q + p.n_kv) * (64 / RB) : 0;
     const int xsel = (HALF && fi >= 8) ? 8 * 128 : 0;                    // HALF: columns 8-15 take the pair's second k-step
 
@@ -201,15 +194,6 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     // beyond K) and the fused RMSNorm (single-piece K only: host-checked).  Split in two so that the loads can be issued BEFORE the
     // weight refills of the piece in progress: vmcnt retires in order, a younger x load would drain the whole weight pipeline.
     auto load_x = [&](int piece, uint4 (&t)[XL]) __attribute__((always_inline)) {
-        if constexpr (WIDE) {
-#pragma unroll
-            for (int i = 0; i < XL; ++i) {
-                const int idx = tid + GM_NT * i, m = idx / CPR, c = idx - m * CPR;
-                const int gcc = c < kch ? c : kch - 1;
-                t[i] = *reinterpret_cast<const uint4*>(p.X + (long long)(m < p.M ? m : p.M - 1) * p.ldx + gcc * 8);
-            }
-            return;
-        }
         const int c = tid % CPR, gc = piece * CPR + c;
         const int gcc = gc < kch ? gc : kch - 1;
 #pragma unroll
@@ -219,15 +203,6 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         }
     };
     auto store_x = [&](int piece, const uint4 (&t)[XL], const uint4& nw) __attribute__((always_inline)) {
-        if constexpr (WIDE) {            // (no fused RMSNorm in this form: host-checked)
-#pragma unroll
-            for (int i = 0; i < XL; ++i) {
-                const int idx = tid + GM_NT * i, m = idx / CPR, c = idx - m * CPR;
-                if (m < XR) *reinterpret_cast<uint4*>(sx + m * XPITCH + c * 16) = (m < p.M && c < kch) ? t[i] : uint4{0, 0, 0, 0};
-            }
-            __syncthreads();
-            return;
-        }
         const int c = tid % CPR, gc = piece * CPR + c;
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
@@ -296,7 +271,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         pos = stt[0];
         trow = stt[1];
     }
-    if constexpr (!MP && MM == 8 && XRQ == 0) {
+    if constexpr (!MP && MM == 8) {
         if (p.attn_part != nullptr) {
             // x rows = the attention output, combined from the split-KV partials right here (M <= 2: one (row, 16-byte chunk) per thread): what
             // attn_decode_combine_kernel + the plain x staging produce, bit for bit (attn_combine_row is the arithmetic of both)
@@ -537,20 +512,6 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 
 extern int g_gemv_profile_shapes;
 
-// the few-row deep-K form (M <= 4, K up to 176 k-steps = 11264): see XRQ / PDX at the kernel
-static int launch_gemv_mfma_deep(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
-    constexpr int XR = 4, PDv = 11, xpitch = 16 * PDv * 128 + 32;
-    const size_t smem = (size_t)XR * xpitch + (size_t)GM_NW * 1 * 2048 + (size_t)2 * 1 * GM_NW * 1 * 1024 + 128;
-    static bool attr = false;
-    if (!attr) {
-        FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<8, GB_PLAIN, 1, false, true, false, XR, PDv>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-        attr = true;
-    }
-    const int grid = n_units < 256 ? n_units : 256;
-    FO1_LAUNCH(name, (double)p.N * p.K * 2.0, (gemv_mfma_kernel<8, GB_PLAIN, 1, false, true, false, XR, PDv>), dim3(grid), dim3(GM_NT), smem, st, p, n_units, nsteps);
-    return FO1_OK;
-}
-
 template <int MM, int MODE, int NB, bool MP, bool HALF, bool R8 = false>
 static int launch_gemv_mfma_mp(const GemvBParams& p, int n_units, int nsteps, const char* name, hipStream_t st) {
     constexpr int pd = R8 ? 2 : ((HALF && !MP) ? 2 : ((MM == 32 && MP) ? 2 : 4));
@@ -578,7 +539,6 @@ static int launch_gemv_mfma(const GemvBParams& p, int n_units, int nsteps, const
 }
 
 #ifdef FO1_ENABLE_AB
-int g_gemv_deep = 1;     // A/B (fo1_gemv_batch_set_impl bit 3 set = off): the one-piece deep-K form at <= 4 sequences
 int g_gemv_half = 3;     // bit 0: M <= 8 8-row units (HALF); bit 1: 9..32 sequences 8-row units (R8; 17..32: single-piece K only) — few-row projections (A/B: fo1_gemv_batch_set_impl)
 #endif
 
@@ -601,9 +561,6 @@ static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
     if constexpr (MM == 8) {
         // M <= 8: half of the MFMA's columns are free — 8-row units with the k-step pair in the two halves (same sums, see the header)
         if ((g_gemv_half & 1) && mode == GB_QKV) return launch_gemv_mfma<8, GB_QKV, 2, true>(p, (p.n_q + p.n_kv) * 8 + p.n_kv * 8, nsteps, name, st);
-        // deep K at <= 4 sequences (`down`): x whole in LDS, one piece (bit-identical sums; FO1_AB: g_gemv_half bit 2 clear = the piece-wise walk)
-        if ((g_gemv_half & 1) != 0 && g_gemv_deep != 0 && mode == GB_PLAIN && p.N <= 4096 && p.M <= 4 && nsteps > 64 && nsteps <= 176 && !p.norm_w && !p.attn_part)
-            return launch_gemv_mfma_deep(p, cdiv(p.N, 8), nsteps, name, st);
         if ((g_gemv_half & 1) && mode == GB_PLAIN && p.N <= 4096) return launch_gemv_mfma<8, GB_PLAIN, 1, true>(p, cdiv(p.N, 8), nsteps, name, st);
     }
     if constexpr (MM == 16) {
