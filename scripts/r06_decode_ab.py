@@ -29,6 +29,8 @@ for B in batches:
     for chunk, bucket in [tuple(int(v) for v in t.split(":")) for t in os.environ.get("FO1_DECODE_CHUNKS", "64:2048").split()]:
         gemv_impl, attn_impl = 1, 0
         L.check(lib.fo1_attention_decode_set_small_chunk(chunk), "chunk")
+        if os.environ.get("FO1_ATTN_TILES"):          # 64-key tiles per attention item at 17..32 sequences (the partials do not depend on it)
+            L.check(lib.fo1_attention_decode_set_small_chunk(int(os.environ["FO1_ATTN_TILES"])), "tiles")
         type(eng._decoder()).KV_BUCKET = bucket
         L.check(lib.fo1_gemv_batch_set_impl(gemv_impl), "gemv impl")
         L.check(lib.fo1_attention_decode_set_impl(attn_impl), "attn impl")

@@ -392,6 +392,63 @@ def test_gemv_batch_rows_independent_of_batch(ab_library):
             L.load().fo1_gemv_batch_set_rows_per_lane(0)
 
 
+def test_decode_attention_rows_do_not_depend_on_the_batch_size_bitwise():
+    """The split-KV decode attention writes 64-key partials whatever the launch: at 17..32 sequences an item walks FOUR tiles and writes each tile's
+    partial separately (round 6), below that an item is one tile — a sequence's attention row is the same bits alone, in 16 and in 25."""
+    from vlm_fo1_amd import ops
+    BF = torch.bfloat16
+    H, KV, HD, slot = 16, 2, 128, 2048
+    g = torch.Generator().manual_seed(3)
+    lens = [1, 63, 64, 65, 129, 255, 256, 257, 651, 700, 1023, 1024, 1025, 1999, 2048, 5, 333, 900, 1500, 77, 640, 641, 12, 2047, 512]
+    B = len(lens)
+    kc = torch.randn(KV, B * slot, HD, generator=g).to(BF).cuda()
+    vt = torch.randn(KV * HD, B * slot, generator=g).to(BF).cuda()
+    q = torch.randn(B, H * HD, generator=g).to(BF).cuda()
+    state = torch.zeros(B, 8, dtype=torch.int32)
+    for b, n in enumerate(lens):
+        state[b, 2] = b * slot
+        state[b, 0] = b * slot + n - 1
+    state[19, 3] = 1                                    # a finished sequence: zero row in every batch
+    state = state.cuda()
+    scale = HD ** -0.5
+    full = ops.attention_decode_batch(q, kc, vt, state, slot, H, KV, HD, scale).clone()
+    assert full[19].abs().max().item() == 0.0
+    for lo, hi in ((0, 16), (3, 4), (8, 9), (14, 15), (24, 25), (16, 25), (0, 17)):
+        got = ops.attention_decode_batch(q[lo:hi].contiguous(), kc, vt, state[lo:hi].contiguous(), slot, H, KV, HD, scale)
+        assert torch.equal(got, full[lo:hi]), (lo, hi, (got.float() - full[lo:hi].float()).abs().max().item())
+    kf, vf, qf = kc.float().cpu(), vt.float().cpu(), q.float().cpu()
+    for b in (0, 3, 8, 14, 24):
+        n = lens[b]
+        for h in (0, 9):
+            kv = h // (H // KV)
+            pr = torch.softmax(kf[kv, b * slot:b * slot + n] @ qf[b, h * HD:(h + 1) * HD] * scale, 0)
+            ref = vf[kv * HD:(kv + 1) * HD, b * slot:b * slot + n] @ pr
+            assert (full[b, h * HD:(h + 1) * HD].float().cpu() - ref).abs().max().item() <= 2e-2
+
+
+def test_deep_k_eight_row_units_at_17_to_26_sequences_equal_the_sixteen_row_units_bitwise(ab_library):
+    """Round 6: `down` (K = 11008) at 17..26 sequences runs on 8-row units (256 workgroups) with the launch's own x rows staged per piece; 27..32
+    sequences and the A/B switch keep the 16-row units (128 workgroups).  The same sums: rows of a 32-sequence launch == the same rows launched as
+    17 / 25 / 26 sequences == the rows with the 8-row units switched off, with a residual operand and a ragged K."""
+    from vlm_fo1_amd import lib as L, ops
+    g = torch.Generator().manual_seed(17)
+    for N, K in ((2048, 11008), (1280, 4096 + 192)):
+        w = (torch.randn(N, K, generator=g) * 0.05).bfloat16().cuda()
+        x32 = torch.randn(32, K, generator=g).bfloat16().cuda()
+        r32 = torch.randn(32, N, generator=g).bfloat16().cuda()
+        full = ops.gemv_batch(x32, w, residual=r32)                 # 32 sequences: 16-row units
+        for M in (17, 21, 25, 26, 27):
+            got = ops.gemv_batch(x32[:M].contiguous(), w, residual=r32[:M].contiguous())
+            assert torch.equal(got, full[:M]), (N, K, M, (got.float() - full[:M].float()).abs().max().item())
+            try:
+                L.check(L.load().fo1_gemv_batch_set_impl(5), "16-row units at 9..32 sequences")
+                assert torch.equal(ops.gemv_batch(x32[:M].contiguous(), w, residual=r32[:M].contiguous()), got), (N, K, M, "A/B")
+            finally:
+                L.load().fo1_gemv_batch_set_impl(1)
+        ref = (x32.float() @ w.float().t()).bfloat16().float() + r32.float()
+        assert (full.float() - ref).abs().max().item() <= 0.05 * ref.abs().max().item() + 0.05
+
+
 def _gemv_batch_cases(gemm_ref, rb, ops, m16=False):
     BF = torch.bfloat16
     torch.manual_seed(5)

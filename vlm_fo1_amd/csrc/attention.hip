@@ -47,6 +47,10 @@ struct AttnParams {
     const int* dyn_kv_len;                           // optional: kv_end/kv_start of item i derived on device: chunk i of *dyn_kv_len keys
     int kv_chunk;
     int q_range_end;                                 // PARTIAL: number of query heads per KV head
+    int grid_batch;                                  // PARTIAL with seq_state: > 0 = 1-D grid of n_items x Hq x grid_batch workgroups walked sequence-fastest (see the kernel)
+    int part_tiles;                                  // PARTIAL, > 1: an item walks part_tiles 64-key tiles (kv_chunk = 64 x part_tiles) and writes ONE PARTIAL PER TILE, each
+                                                     // exactly what a one-tile item writes (state reset between tiles): the workgroup count and the load / compute overlap of a
+                                                     // long item with the partial sums of 64-key splits — a sequence's attention does not depend on the choice (round 6)
     // batched decode (PARTIAL): blockIdx.z = sequence; keys [state[z][2], state[z][0]] (decode.hip state layout)
     const int* seq_state;
     long long q_seq_stride;                          // Q elements between sequences
@@ -70,8 +74,19 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     __shared__ __attribute__((aligned(16))) uint16_t sK[KB * LDKR];
     __shared__ __attribute__((aligned(16))) uint16_t sVT[HD * LDVT];
 
+    // block coordinates.  Batched decode (PARTIAL with seq_state) launches a 1-D grid walked SEQUENCE-FASTEST: (chunk, kv head, sequence) with the
+    // chunk slowest — the dispatcher deals consecutive workgroups round-robin over the 8 XCDs, and with the chunk fastest the few chunks of a
+    // context that exist (11 of 32 at 700 keys in a 2048-key bucket) always landed on the same XCDs whenever the chunk count divided by 8
+    // (round 6: 16.1 -> 10.1 us per layer at 25 sequences); the empty chunks now come last.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (PARTIAL && p.seq_state && p.grid_batch > 0) {
+        const int lin = blockIdx.x;
+        bz = lin % p.grid_batch;
+        by = (lin / p.grid_batch) % p.Hq;
+        bx = lin / (p.grid_batch * p.Hq);
+    }
     AttnItem it;
-    if (!PARTIAL) it = p.items[blockIdx.x];
+    if (!PARTIAL) it = p.items[bx];
     const uint16_t* Qb = p.Q;
     float* partb = p.part;
     if (PARTIAL) {
@@ -79,16 +94,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
         it.q_end = p.q_range_end;   // chunk blockIdx.x of the sequence's keys; empty chunks leave (m, l) = (-inf, 0)
         int kv0 = 0, kv_len;
         if (p.seq_state) {
-            const int* st = p.seq_state + blockIdx.z * 8;
+            const int* st = p.seq_state + bz * 8;
             if (st[3]) {
                 // finished (or empty pool slot): nobody reads this sequence's tokens, but its attention row still flows through the
                 // o-projection into the slot's frozen K / V^T row of every later layer — it must be FINITE (0 x NaN would poison a later
                 // occupant whose keys come within the 4-key V^T piece of that row).  One-chunk form: the row is written
                 // here, as zeros; split form: attn_decode_combine_kernel writes it.
-                if (p.O != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {
+                if (p.O != nullptr && bx == 0 && threadIdx.x < 64) {
                     const int ql = threadIdx.x & 15, g = threadIdx.x >> 4;
                     if (ql < p.q_range_end) {
-                        uint16_t* op = p.O + (long long)blockIdx.z * p.o_tok + ((long long)blockIdx.y * p.q_range_end + ql) * p.o_head;
+                        uint16_t* op = p.O + (long long)bz * p.o_tok + ((long long)by * p.q_range_end + ql) * p.o_head;
 #pragma unroll
                         for (int db = 0; db < HD / 16; ++db) *reinterpret_cast<uint2*>(op + db * 16 + g * 4) = uint2{0u, 0u};
                     }
@@ -97,16 +112,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
             }
             kv0 = st[2];
             kv_len = st[0] + 1;
-            Qb += (long long)blockIdx.z * p.q_seq_stride;
-            partb += (long long)blockIdx.z * p.part_seq_stride;
+            Qb += (long long)bz * p.q_seq_stride;
+            partb += (long long)bz * p.part_seq_stride;
         } else {
             kv_len = *p.dyn_kv_len;
         }
-        it.kv_start = kv0 + blockIdx.x * p.kv_chunk;
+        it.kv_start = kv0 + bx * p.kv_chunk;
         it.kv_end = min(kv_len, it.kv_start + p.kv_chunk);
         if (it.kv_start >= kv_len) return;
     }
-    const int h = blockIdx.y, kvh = h / p.group;
+    const int h = by, kvh = h / p.group;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ql = lane & 15, g = lane >> 4;
     const int q_idx = it.q_start + wave * 16 + ql;          // this lane's query (score column)
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     // tile walk: the optional second range first (the shared prefix), then the item's own range
     const int own_hi = kv_hi;
     int2 r2 = int2{0, 0};
-    if (!PARTIAL && p.items2) r2 = p.items2[blockIdx.x];
+    if (!PARTIAL && p.items2) r2 = p.items2[bx];
     const bool has2 = r2.y > r2.x;
     int k0 = has2 ? r2.x : it.kv_start;
     kv_hi = has2 ? r2.y : own_hi;
@@ -336,10 +351,26 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
                 o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vk[db]), pf[half], o[db], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        if (PARTIAL && p.part_tiles > 1) {
+            // per-tile partial (wave-uniform branch): chunk index = item * part_tiles + tile of the item
+            if (wave == 0 && q_ok) {
+                const long long ci = (long long)bx * p.part_tiles + (k0 - it.kv_start) / KB;
+                float* pr = partb + ((ci * p.Hq + h) * 16 + ql) * (HD + 2);
+#pragma unroll
+                for (int db = 0; db < NDB; ++db)
+                    *reinterpret_cast<float4*>(pr + db * 16 + g * 4) = float4{o[db][0], o[db][1], o[db][2], o[db][3]};
+                if (g == 0) { pr[HD] = m_run * 0.6931471805599453f; pr[HD + 1] = l_run; }
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+            m_run = -INFINITY;
+            l_run = 0.f;
+        }
         k0 = nk0;
         kv_hi = nhi;
         in2 = nin2;
     }
+    if (PARTIAL && p.part_tiles > 1) return;
 
     if (PARTIAL) {
         if (p.O != nullptr) {
@@ -347,7 +378,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
             // the output — the value attn_decode_combine_kernel computes from a single partial (w = exp(0) = 1: num / den = o / l) —
             // and the combine launch is not made.  o_tok = the output's sequence stride, o_head = HD.
             if (wave == 0 && q_ok) {
-                uint16_t* op = p.O + (long long)blockIdx.z * p.o_tok + ((long long)h * p.q_range_end + ql) * p.o_head;
+                uint16_t* op = p.O + (long long)bz * p.o_tok + ((long long)h * p.q_range_end + ql) * p.o_head;
 #pragma unroll
                 for (int db = 0; db < NDB; ++db) {
                     uint2 w;
@@ -359,7 +390,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
             return;
         }
         if (wave == 0 && q_ok) {
-            float* pr = partb + (((long long)blockIdx.x * p.Hq + h) * 16 + ql) * (HD + 2);
+            float* pr = partb + (((long long)bx * p.Hq + h) * 16 + ql) * (HD + 2);
 #pragma unroll
             for (int db = 0; db < NDB; ++db)
                 *reinterpret_cast<float4*>(pr + db * 16 + g * 4) = float4{o[db][0], o[db][1], o[db][2], o[db][3]};
@@ -1181,7 +1212,7 @@ static int attention_entry(const void* Q, long long q_tok_stride, long long q_he
     p.items2 = (const int2*)prefix_ranges;
     p.n_items = n_items; p.Hq = n_q_heads; p.group = n_q_heads / n_kv_heads;
     p.scale = scale; p.causal = causal; p.q_row_base = (const int*)q_row_base;
-    p.part = nullptr; p.dyn_kv_len = nullptr; p.kv_chunk = 0; p.q_range_end = 0;
+    p.part = nullptr; p.dyn_kv_len = nullptr; p.kv_chunk = 0; p.q_range_end = 0; p.part_tiles = 0; p.grid_batch = 0;
     p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
     p.bias = bias; p.wlen = wlen; p.sw_ws = sw_ws; p.sw_shift = sw_shift; p.sw_nwy = sw_nwy; p.sw_nwx = sw_nwx;
     hipStream_t st = (hipStream_t)stream;
@@ -1287,7 +1318,7 @@ int fo1_attention_decode_bf16(const void* q, const void* kcache, long long k_tok
     p.part = (float*)workspace; p.dyn_kv_len = (const int*)dyn_kv_len; p.kv_chunk = 64;
     (void)one_item;
     p.items = nullptr; p.items2 = nullptr;
-    p.q_range_end = group;
+    p.q_range_end = group; p.part_tiles = 0; p.grid_batch = 0;
     p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
     p.bias = nullptr; p.wlen = 0; p.sw_ws = p.sw_shift = p.sw_nwy = p.sw_nwx = 0;
     hipStream_t st = (hipStream_t)stream;
@@ -1318,11 +1349,16 @@ int fo1_attention_decode_set_impl(int impl) {
 namespace fo1 {
 FO1_AB_VAR g_attn_pool_chunk = 1024;     // A/B: fo1_attention_decode_set_pool_chunk.  1024 keys: a pool slot's whole context (slot_rows <= 1024) is ONE chunk —
                                          // the split kernel writes the rows itself, no combine launch (512: 23.7 + 4.3 us per layer, 1024: 22.2 + 0; profiles/r04_pool_step_attention_one_chunk.json)
+FO1_AB_VAR g_attn_tiles_per_item = 2;    // 64-key tiles per item at 17..32 sequences (A/B: fo1_attention_decode_set_small_chunk(1 .. 8); profiles/r06_decode_attention_grid_order_ab.json: 1 / 2 / 3 / 4 tiles 2.96 / 2.89 / 2.91 / 2.98 ms per step at 25 sequences)
 FO1_AB_VAR g_attn_small_chunk = 64;      // A/B: fo1_attention_decode_set_small_chunk (<= 32 sequences)
 static inline int decode_batch_chunk(int batch) { return batch > 32 ? g_attn_pool_chunk : g_attn_small_chunk; }
 }  // namespace fo1
 #ifdef FO1_ENABLE_AB
 int fo1_attention_decode_set_small_chunk(int keys) {
+    if (keys >= 1 && keys <= 8) {          // 1 .. 8: tiles per item at 17..32 sequences (the partials do not depend on it)
+        fo1::g_attn_tiles_per_item = keys;
+        return FO1_OK;
+    }
     if (keys < 64 || keys > 4096 || keys % 64) return fo1::set_err(FO1_ERR_ARG, "attention_decode_set_small_chunk: %d", keys);
     fo1::g_attn_small_chunk = keys;
     return FO1_OK;
@@ -1378,22 +1414,26 @@ static int attention_decode_batch_impl(const void* q, long long q_seq_stride, co
     p.O = nullptr; p.o_tok = 0; p.o_head = 0;
     p.items = nullptr; p.items2 = nullptr;
     const int chunk = decode_batch_chunk(batch);
-    p.n_items = cdiv(max_kv_len, chunk); p.Hq = n_kv_heads; p.group = 1;
+    // 17..32 sequences: an item walks 2 tiles of 64 keys and writes each tile's partial separately (see AttnParams.part_tiles) — half the
+    // workgroups, the next tile's loads under the current tile's arithmetic, the SAME partials as one-tile items (the batch invariance holds)
+    const int n_chunks = cdiv(max_kv_len, chunk);
+    const int ptiles = (batch > 16 && batch <= 32 && chunk == 64 && combine) ? g_attn_tiles_per_item : 1;
+    p.n_items = cdiv(n_chunks, ptiles); p.Hq = n_kv_heads; p.group = 1;
     p.scale = scale; p.causal = 0; p.q_row_base = nullptr;
-    p.part = (float*)workspace; p.dyn_kv_len = nullptr; p.kv_chunk = chunk;
-    p.q_range_end = group;
+    p.part = (float*)workspace; p.dyn_kv_len = nullptr; p.kv_chunk = chunk * ptiles;
+    p.q_range_end = group; p.part_tiles = ptiles; p.grid_batch = batch;
     p.seq_state = (const int*)state; p.q_seq_stride = q_seq_stride;
-    p.part_seq_stride = (long long)p.n_items * n_kv_heads * 16 * (head_dim + 2);
+    p.part_seq_stride = (long long)n_chunks * n_kv_heads * 16 * (head_dim + 2);
     p.bias = nullptr; p.wlen = 0; p.sw_ws = p.sw_shift = p.sw_nwy = p.sw_nwx = 0;
     hipStream_t st = (hipStream_t)stream;
-    if (p.n_items == 1 && combine) {       // one chunk per (sequence, KV head) — the pool's slots, or a short context at any batch size -> rows written by the split kernel itself, no combine launch
+    if (n_chunks == 1 && combine) {       // one chunk per (sequence, KV head) — the pool's slots, or a short context at any batch size -> rows written by the split kernel itself, no combine launch
         p.O = (uint16_t*)out; p.o_tok = out_seq_stride; p.o_head = head_dim;
         FO1_LAUNCH("attn_decode_one_chunk", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
-                   dim3(1, n_kv_heads, batch), dim3(256), 0, st, p);
+                   dim3(n_kv_heads * batch), dim3(256), 0, st, p);
         return FO1_OK;
     }
     FO1_LAUNCH("attn_decode_split", (double)batch * max_kv_len * n_kv_heads * head_dim * 4.0, (attn_fwd_kernel<128, 4, true>),
-               dim3(p.n_items, n_kv_heads, batch), dim3(256), 0, st, p);
+               dim3(p.n_items * n_kv_heads * batch), dim3(256), 0, st, p);
     if (!combine) return FO1_OK;       // the consumer sums the partials itself (fo1_gemv_attn_combine_bf16)
     FO1_LAUNCH("attn_decode_combine", (double)batch * n_q_heads * head_dim * 8.0, attn_decode_combine_kernel<128>, dim3(n_q_heads, batch), dim3(128), 0,
                st, (const float*)workspace, (const int*)nullptr, chunk, n_kv_heads, group, (uint16_t*)out, (const int*)state, p.part_seq_stride,

@@ -93,7 +93,11 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
     constexpr int RB = H8 ? 8 : 16;                                      // weight rows per block
     extern __shared__ __attribute__((aligned(16))) unsigned char gm_smem[];
     unsigned char* const sx = gm_smem;                                   // [MM][XPITCH]
-    unsigned char* const sw = XREG ? gm_smem : gm_smem + MM * XPITCH;    // [GM_NW][NB][2048]  weight scratch (wave-private); XREG: over the dead x image
+    // XR32 (round 6): 17..26 sequences, deep K (`down`), 8-row units — 32 staged rows of a 32-k-step piece (132 KB) do not fit beside the scratch and the
+    // reduction buffers, M rows do up to M = 26: only the launch's own rows are staged, the column slots past them read the last staged row (never stored)
+    constexpr bool XR32 = MM == 32 && MP && R8;
+    const int xrows = XR32 ? p.M : MM;
+    unsigned char* const sw = XREG ? gm_smem : gm_smem + xrows * XPITCH; // [GM_NW][NB][2048]  weight scratch (wave-private); XREG: over the dead x image
     float* const sred = reinterpret_cast<float*>(sw + GM_NW * NB * 2048);   // [2][NG][GM_NW][NB][64][4]
     float* const srstd = XREG ? reinterpret_cast<float*>(gm_smem + MM * XPITCH) : sred + 2 * NG * GM_NW * NB * 256;   // [32]
     static_assert(!XREG || GM_NW * NB * 2048 + 2 * NG * GM_NW * NB * 1024 <= MM * XPITCH, "scratch + reduction buffers fit in the x image");
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 if constexpr (XREG) xv[g] = xf[d][0][h][g];
-                else xv[g] = *reinterpret_cast<const uint4*>(sx + (g * 16 + xrow) * XPITCH + xs * 128 + xsel + h * 64 + fg * 16);
+                else xv[g] = *reinterpret_cast<const uint4*>(sx + (XR32 ? min(g * 16 + xrow, xrows - 1) : g * 16 + xrow) * XPITCH + xs * 128 + xsel + h * 64 + fg * 16);
             }
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if constexpr (XREG) xw[g] = xf[d][H8 ? 1 : 0][h][g];
-                    else xw[g] = *reinterpret_cast<const uint4*>(sx + (g * 16 + xrow) * XPITCH + (xs + 8) * 128 + h * 64 + fg * 16);
+                    else xw[g] = *reinterpret_cast<const uint4*>(sx + (XR32 ? min(g * 16 + xrow, xrows - 1) : g * 16 + xrow) * XPITCH + (xs + 8) * 128 + h * 64 + fg * 16);
                 }
 #pragma unroll
                 for (int b = 0; b < NB; ++b) {
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(GM_NT) void gemv_mfma_kernel(const GemvBParams p, c
         for (int i = 0; i < XL; ++i) {
             const int m = tid / CPR + RPP * i;
             const bool ok = m < p.M && gc < kch;
-            *reinterpret_cast<uint4*>(sx + m * XPITCH + c * 16) = ok ? t[i] : uint4{0, 0, 0, 0};
+            if (!XR32 || m < xrows) *reinterpret_cast<uint4*>(sx + m * XPITCH + c * 16) = ok ? t[i] : uint4{0, 0, 0, 0};
         }
         __syncthreads();
         if (!MP && p.norm_w) {
@@ -518,8 +522,10 @@ static int launch_gemv_mfma_mp(const GemvBParams& p, int n_units, int nsteps, co
     constexpr int xpitch = ((HALF || R8) ? 16 : 8) * pd * 128 + 32;
     constexpr int ng = MM == 32 ? 2 : 1;
     // MM == 32, single piece: the weight scratch and the reduction buffers reuse the x image once its fragments sit in registers
+    const size_t xrows = (MM == 32 && MP && R8) ? (size_t)p.M : (size_t)MM;       // (deep-K 8-row units at 17..26 sequences: the launch's own rows only)
     const size_t smem = (MM == 32 && !MP) ? (size_t)MM * xpitch + 128
-                                          : (size_t)MM * xpitch + (size_t)GM_NW * NB * 2048 + (size_t)2 * ng * GM_NW * NB * 1024 + 128;
+                                          : xrows * xpitch + (size_t)GM_NW * NB * 2048 + (size_t)2 * ng * GM_NW * NB * 1024 + 128;
+    if (smem > 156 * 1024) return set_err(FO1_ERR_ARG, "gemv_batch: %zu B of LDS for M=%d K=%d (internal dispatch error)", smem, p.M, p.K);
     static bool attr = false;
     if (!attr) {
         FO1_CHECK_HIP(hipFuncSetAttribute((const void*)gemv_mfma_kernel<MM, MODE, NB, MP, HALF, R8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -573,6 +579,10 @@ static int dispatch_gemv_mfma(GemvBParams& p, int mode, hipStream_t st) {
         // 17..32 sequences, single-piece K only (a deep-K piece of 32 x 4 KB rows does not fit next to the buffers): the same 8-row units
         if ((g_gemv_half & 2) && nsteps <= 32 && mode == GB_QKV) return launch_gemv_mfma_mp<32, GB_QKV, 2, false, false, true>(p, (p.n_q + p.n_kv) * 8 + p.n_kv * 8, nsteps, name, st);
         if ((g_gemv_half & 2) && nsteps <= 32 && mode == GB_PLAIN && p.N <= 4096) return launch_gemv_mfma_mp<32, GB_PLAIN, 1, false, false, true>(p, cdiv(p.N, 8), nsteps, name, st);
+        // deep K (`down`), 17..27 sequences: the same 8-row units with x staged in 32-k-step pieces of the launch's OWN rows (M x 4 KB + 48 KB of LDS fit up to
+        // M = 26) — 256 workgroups where the 16-row units below have 128, the same sums; 27..32 sequences keep the 16-row units (bit 2 of the half switch off: A/B)
+        if ((g_gemv_half & 2) && nsteps > 32 && mode == GB_PLAIN && p.N <= 4096 && p.M <= 26 && !p.norm_w)
+            return launch_gemv_mfma_mp<32, GB_PLAIN, 1, true, false, true>(p, cdiv(p.N, 8), nsteps, name, st);
     }
     if (mode == GB_QKV) return launch_gemv_mfma<MM, GB_QKV, 2>(p, (p.n_q + p.n_kv) * 4 + p.n_kv * 4, nsteps, name, st);
     // plain: 16-row units for the few-row projections (every CU should stream), 32-row units for lm_head-sized matrices
