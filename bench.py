@@ -853,6 +853,36 @@ def pmc_traffic(kernel_name, full=False):
 _VERBOSE_KEYS = ("note", "loop", "includes", "excludes", "prefix_sharing", "decode", "launch", "packing", "what", "sample", "data")
 
 
+_COMPACT_DROP = (
+    "cpu_baseline.reference_modules_check", "cpu_baseline.pass_seconds", "cpu_baseline.stage_seconds", "cpu_baseline.host_cpus",
+    "cpu_baseline.threads", "cpu_baseline.passes_timed", "cpu_baseline.warmup_passes", "cpu_baseline.decode_seconds_per_token",
+    "cpu_baseline.images_per_sec_with_64_token_answer",
+    "roofline.sustained_mfma.zero_operands", "roofline.sustained_mfma.random_operands.us",
+    "roofline.hfre.algorithmic_bytes_full_map_upper_bound", "roofline.hfre.achieved_on_upper_bound_bytes", "roofline.hfre.achieved_main_kernel_only",
+    "roofline.hfre.images_per_launch", "roofline.hfre.us_per_image", "roofline.hfre.traffic_source", "roofline.hfre.kernel", "roofline.hfre.peak",
+    "roofline.hfre.unit",
+    "hires.workload", "hires.fp8.parity", "hires.fp8.dtype", "hires.bf16.dtype", "hires.end_to_end.dtype", "hires.llm_rows_per_pass_without_prefix_sharing",
+    "hires.end_to_end.pool_slots", "hires.end_to_end.pool_slot_rows", "hires.end_to_end.generated_tokens", "hires.end_to_end.passes_timed",
+    "dataset.patches_min", "dataset.patches_max", "dataset.distinct_grids", "dataset.distinct_aux_sizes", "dataset.boxes", "dataset.aux",
+    "dataset.passes", "dataset.images_per_pass_max", "dataset.passes_in_flight", "dataset.seconds", "dataset.patches_per_item",
+    "decode.roofline.bound", "decode.roofline.unit", "decode.roofline.peak", "decode.batched.roofline.bound", "decode.batched.roofline.unit",
+    "decode.batched.roofline.peak", "decode.pool.roofline.bound", "decode.pool.roofline.unit", "decode.pool.roofline.peak",
+    "decode.batched.roofline.algorithmic_bytes_per_step", "decode.pool.roofline.weight_bytes", "decode.pool.roofline.kv_bytes",
+    "decode.new_tokens_timed", "decode.host_loop_ms_per_token", "decode.batched.prefill_pass_ms",
+    "end_to_end.static_groups.new_tokens_per_image", "end_to_end.static_groups.passes_timed", "end_to_end.static_groups.images_per_pass",
+    "end_to_end.static_groups.passes_in_flight", "end_to_end.static_groups.generated_tokens_per_sec", "end_to_end.passes_timed",
+    "end_to_end.pool_steps", "driver_level.host_prepare_threads_needed_at_this_rate", "driver_level.predictions_file_written",
+    "driver_level_countbench.countbench.seconds_writing_the_files_untimed", "driver_level_countbench.pixmo.seconds_writing_the_files_untimed",
+    "driver_level_countbench.countbench.accuracy_on_random_weights", "driver_level_countbench.pixmo.accuracy_on_random_weights",
+    "dataset.region_tokens_per_sec", "dataset.uniform_equivalent_images_per_sec", "dataset.boxes_per_item", "hires.images_per_pass",
+    "hires.prompts_per_pass", "hires.passes_in_flight", "hires.llm_rows_per_pass", "hires.end_to_end.new_tokens_per_prompt",
+    "end_to_end.generated_tokens_per_sec", "end_to_end.decode_group", "end_to_end.static_groups.decode_group", "end_to_end.static_groups.ms_per_pass",
+    "driver_level.host_prepare_threads_needed_for_8_gpus", "driver_level.seconds", "driver_level_countbench.countbench.seconds",
+    "driver_level_countbench.pixmo.seconds", "roofline.traffic_source",
+    "region_tokens_per_sec_hfre_plus_connector", "region_tokens_per_sec_encode_regions", "preprocess",
+)
+
+
 def compact_line(full: dict) -> dict:
     """The contract line: every contract key of `full` unchanged, nested blocks without their prose (`note`, `loop`, ... and any string
     longer than 120 characters) and without the per-kernel tables (`roofline.per_step_ms` / `launches`: in --json-out), then `summary`."""
@@ -883,6 +913,14 @@ def compact_line(full: dict) -> dict:
     if isinstance(cfg, dict):
         cfg.pop("stages", None)
     line.pop("stage_kernel_ms_note", None)
+    # detail that only the full record carries (VERDICT r5 #2b: <= 6 KB on stdout): dotted paths inside the nested blocks
+    for path in _COMPACT_DROP:
+        o = line
+        *head, last = path.split(".")
+        for k in head:
+            o = o.get(k) if isinstance(o, dict) else None
+        if isinstance(o, dict):
+            o.pop(last, None)
 
     def g(*path):
         o = full
@@ -1030,6 +1068,8 @@ def main():
         L.load().fo1_gemm_set_group_m(int(os.environ["FO1_GEMM_GROUP_M"]))
     if os.environ.get("FO1_HFRE_ORDER") and L.ab_build():        # A/B of the HFRE work-list order: 0 = interleaved buckets (rounds 2-5), 1 = box-major (image-major)
         L.load().fo1_hfre_set_tuning(8, 512, -4 if int(os.environ["FO1_HFRE_ORDER"]) else -3, 0)
+    if os.environ.get("FO1_DWLN_FORM") and L.ab_build():         # A/B of DaViT's depthwise conv + LayerNorm: 0 = per-pixel form, 1 = product rule (sliding-window runs)
+        L.load().fo1_dwconv_ln_set_form(int(os.environ["FO1_DWLN_FORM"]))
     img_hw = tuple(int(v) for v in args.image.lower().split("x"))
     S_img = (round(img_hw[0] / 28) * 2) * (round(img_hw[1] / 28) * 2)
     auto_batch = args.batch <= 0

@@ -57,6 +57,12 @@ int fo1_gemm_set_debug(int bits);
  * (scripts/gemm_timeline.py) */
 int fo1_gemm_set_stamp_buffer(void* device_buffer);
 
+/* ---- DaViT ---- */
+/* fo1_dwconv3x3_ln_bf16 / _var: 1 (default) = product rule: the sliding-window form (a wave walks 8 pixels of a row — 4 at C = 1024 — with the
+ * 3 x 3 window in registers) for C = 128 / 256 / 512 / 1024 when the call has >= 4096 waves of runs, else one wave per pixel; 0 = per-pixel
+ * everywhere; 2 = the run form at every size it exists for.  Bit-identical. */
+int fo1_dwconv_ln_set_form(int run_form);
+
 /* ---- decode step ---- */
 /* fo1_gemv_batch_bf16, v_dot2 kernel: 0 (default) = a lane streams 1 / 2 / 4 weight rows per chunk position by M; 1 = always one row. */
 int fo1_gemv_batch_set_rows_per_lane(int rpl);

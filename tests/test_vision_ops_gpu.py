@@ -134,6 +134,61 @@ def test_dwconv_layernorm_fused_equals_separate_kernels():
         assert torch.equal(h, h_ref), f"{H}x{W}x{C}: LayerNorm output differs ({int((h != h_ref).sum())} elements)"
 
 
+def test_dwconv_layernorm_run_form_batched_and_ragged_equal_the_separate_kernels():
+    """Round 6: at C = 128 / 256 / 512 / 1024 fo1_dwconv3x3_ln_bf16 walks runs of 8 pixels with the 3 x 3 window in registers.  Same bits as the
+    separate kernels for stacked images (runs never cross a row or an image), for widths that are not a multiple of the run, and for the
+    ragged entry (one workgroup column per image)."""
+    from vlm_fo1_amd import lib as _L, ops
+    with _L.use_ab():
+        _L.load().fo1_dwconv_ln_set_form(2)         # the run form whatever the size (the product rule keeps small maps on the per-pixel form)
+        try:
+            _run_form_cases(ops)
+        finally:
+            _L.load().fo1_dwconv_ln_set_form(1)
+    # product rule, a map large enough to take the run form by itself
+    B, H, W, C = 2, 160, 120, 256
+    x = torch.randn(B * H * W, C).to(BF).cuda()
+    w9, b = (torch.randn(9, C) * 0.2).to(BF).cuda(), (torch.randn(C) * 0.1).to(BF).cuda()
+    lw, lb = (1 + 0.1 * torch.randn(C)).to(BF).cuda(), (0.1 * torch.randn(C)).to(BF).cuda()
+    y_ref = ops.dwconv3x3_res(x, w9, b, H, W, batch=B)
+    y, h = ops.dwconv3x3_res_ln(x, w9, b, H, W, lw, lb, 1e-5, batch=B)
+    assert torch.equal(y, y_ref) and torch.equal(h, ops.layernorm(y_ref, lw, lb, 1e-5))
+
+
+def _run_form_cases(ops):
+    torch.manual_seed(32)
+    for (B, H, W, C) in [(3, 5, 19, 128), (2, 9, 8, 256), (3, 6, 33, 512), (2, 11, 7, 1024), (4, 1, 1, 1024), (1, 2, 64, 256)]:
+        x = torch.randn(B * H * W, C).to(BF).cuda()
+        w9 = (torch.randn(9, C) * 0.2).to(BF).cuda()
+        b = (torch.randn(C) * 0.1).to(BF).cuda()
+        lw = (1 + 0.1 * torch.randn(C)).to(BF).cuda()
+        lb = (0.1 * torch.randn(C)).to(BF).cuda()
+        y_ref = ops.dwconv3x3_res(x, w9, b, H, W, batch=B)
+        h_ref = ops.layernorm(y_ref, lw, lb, 1e-5)
+        y, h = ops.dwconv3x3_res_ln(x, w9, b, H, W, lw, lb, 1e-5, batch=B)
+        assert torch.equal(y, y_ref) and torch.equal(h, h_ref), f"batch {B} x {H}x{W}x{C}"
+    # ragged pack: three images of different sizes, per-image results
+    C = 512
+    sizes = [(7, 13), (3, 40), (10, 9)]
+    xs = [torch.randn(h_ * w_, C).to(BF).cuda() for h_, w_ in sizes]
+    w9 = (torch.randn(9, C) * 0.2).to(BF).cuda()
+    b = (torch.randn(C) * 0.1).to(BF).cuda()
+    lw = (1 + 0.1 * torch.randn(C)).to(BF).cuda()
+    lb = (0.1 * torch.randn(C)).to(BF).cuda()
+    rows, r0 = [], 0
+    for h_, w_ in sizes:
+        rows.append((r0, h_, w_, r0, h_, w_))
+        r0 += h_ * w_
+    sg = ops.ImgSegs(rows, "cuda", max(h_ * w_ for h_, w_ in sizes), r0, max(h_ * w_ for h_, w_ in sizes), r0)
+    y, h = ops.dwconv3x3_res_ln_var(torch.cat(xs, 0), w9, b, sg, lw, lb, 1e-5)
+    r = 0
+    for (h_, w_), xi in zip(sizes, xs):
+        y1, h1 = ops.dwconv3x3_res_ln(xi, w9, b, h_, w_, lw, lb, 1e-5)
+        n = h_ * w_
+        assert torch.equal(y[r:r + n], y1) and torch.equal(h[r:r + n], h1), f"ragged image {h_}x{w_}"
+        r += n
+
+
 def test_batched_spatial_ops_equal_per_image_calls():
     """ABI 2: `batch` same-size images stacked along the rows.  Every spatial kernel must give, for image b, exactly what the
     one-image call gives (neighbourhoods / windows / channel-attention statistics never cross an image boundary)."""

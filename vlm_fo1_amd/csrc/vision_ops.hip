@@ -175,6 +175,146 @@ __global__ __launch_bounds__(256) void dwconv3x3_ln_kernel(const uint16_t* __res
     }
 }
 
+// Round 6: the same arithmetic with a SLIDING WINDOW — a wave walks a run of kDwRun consecutive pixels of one image row.  The 3 x 3 window of
+// every channel chunk lives in registers (a ring of four columns: three in use, the fourth receiving the next column while the taps run), so a
+// pixel costs 3 tap loads instead of 9, and the nine weight vectors, the bias and the LayerNorm parameters are loaded once per run instead of
+// once per pixel (18 + 2 loads per pixel and chunk -> 3.75): the per-pixel kernel kept the CU's texture path busy 2.6x longer than HBM needs.
+// Fully unrolled (static ring indices, no loop back-edge: a back-edge costs a vmcnt(0) that would also wait for the stores).  Rows outside the
+// image zero the row's weights once per run, columns outside zero the tap's weight at the two pixels that see them: fmaf(x, 0, acc) = acc,
+// the per-pixel kernel's rule, same sums bit for bit (tests/test_vision_ops_gpu.py).  Needs C = 8 * NCH * 64 / PPW exactly.
+constexpr int kDwRun = 8;
+template <int PPW, int NCH, int RUN>
+__global__ __launch_bounds__(256) void dwconv3x3_ln_run_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ wt,
+                                                               const uint16_t* __restrict__ bias, uint16_t* __restrict__ y,
+                                                               const uint16_t* __restrict__ ln_w, const uint16_t* __restrict__ ln_b,
+                                                               uint16_t* __restrict__ hout, int H, int W, int C, float eps, int B,
+                                                               const ImgSeg* __restrict__ segs) {
+    constexpr int LPP = 64 / PPW;
+    const int lane = threadIdx.x & 63, sub = lane % LPP;
+    if (segs) {
+        const ImgSeg sg = segs[blockIdx.y];
+        H = sg.H; W = sg.W; B = 1;
+        x += (long long)sg.in_row0 * C; y += (long long)sg.in_row0 * C; hout += (long long)sg.in_row0 * C;
+    }
+    const int rpr = (W + RUN - 1) / RUN, runs_img = H * rpr;
+    if (segs && (long long)blockIdx.x * 4 * PPW >= runs_img) return;            // whole workgroup past this image (uniform)
+    int run = (blockIdx.x * 4 + (threadIdx.x >> 6)) * PPW + lane / LPP;
+    const bool run_live = run < B * runs_img;
+    if (!run_live) run = B * runs_img - 1;                                       // (keeps the shuffles well defined; nothing is stored)
+    const int img = run / runs_img, rr = run - img * runs_img;
+    const int h = rr / rpr, w0 = (rr - h * rpr) * RUN;
+    const long long img_pix0 = (long long)img * H * W;
+    // stores through buffer descriptors: a pixel past the row's end (or a run past the last) stores at an offset outside the descriptor and the
+    // hardware drops it — no branch around a store, so the wait for a prefetched column never has to assume the stores in between were skipped
+    // (hipcc's waitcnt pass would then wait for the stores themselves: one store round trip per pixel).  Map <= 2 GiB (host-checked).
+    typedef __attribute__((ext_vector_type(4))) unsigned int v4u;
+    const uint32_t map_bytes = (uint32_t)B * (uint32_t)H * (uint32_t)W * (uint32_t)C * 2u;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, map_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc((void*)hout, 0, map_bytes, 0x00020000);
+    const uint32_t row_off = ((uint32_t)img_pix0 + (uint32_t)h * (uint32_t)W) * (uint32_t)C * 2u + (uint32_t)sub * 16u;
+    const bool rok[3] = {h > 0, true, h + 1 < H};
+    const uint16_t* const rowp[3] = {x + (img_pix0 + (long long)(h > 0 ? h - 1 : 0) * W) * C + sub * 8, x + (img_pix0 + (long long)h * W) * C + sub * 8,
+                                     x + (img_pix0 + (long long)(h + 1 < H ? h + 1 : H - 1) * W) * C + sub * 8};
+    auto colc = [&](int wcol) { return wcol < 0 ? 0 : (wcol >= W ? W - 1 : wcol); };
+    auto psum = [](float v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    const uint4 zero4 = uint4{0, 0, 0, 0};
+    // phase 1, chunk by chunk: the convolution of the run's pixels (y stored, its bf16 values kept packed: 4 registers per pixel and chunk)
+    uint4 pk[NCH][RUN];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int co = (sub + i * LPP) * 8;
+        uint4 wq[9], win[3][4];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const uint4 q = *reinterpret_cast<const uint4*>(wt + t * C + co);
+            wq[t] = rok[t / 3] ? q : zero4;
+        }
+        const uint4 bq = *reinterpret_cast<const uint4*>(bias + co);
+        // columns w0 - 1, w0, w0 + 1 -> ring slots 3, 0, 1 (column w0 + s sits in slot s & 3)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+                win[ky][(kx + 3) & 3] = *reinterpret_cast<const uint4*>(rowp[ky] + (long long)colc(w0 + kx - 1) * C + i * LPP * 8);
+#pragma unroll
+        for (int s = 0; s < RUN; ++s) {
+            const int w = w0 + s;
+            if (s + 1 < RUN) {          // column w + 2 for the next pixel, into the slot the window left at the last step
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+                    win[ky][(s + 2) & 3] = *reinterpret_cast<const uint4*>(rowp[ky] + (long long)colc(w + 2) * C + i * LPP * 8);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // the next column is requested BEFORE this pixel's taps (hipcc would sink the loads to their use)
+            const bool lok = w > 0, rgt = w + 1 < W;
+            float acc[8], ctr[8];
+            un8(bq, acc);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int ky = t / 3, kx = t % 3;
+                float xv[8], wv[8];
+                un8(win[ky][(s + kx + 3) & 3], xv);
+                const uint4 wsel = kx == 0 ? (lok ? wq[t] : zero4) : (kx == 2 ? (rgt ? wq[t] : zero4) : wq[t]);
+                un8(wsel, wv);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] = fmaf(xv[j], wv[j], acc[j]);
+                if (t == 4) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) ctr[j] = xv[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = ctr[j] + rbf(acc[j]);
+            const uint4 pv = pk8(acc);
+            pk[i][s] = pv;
+            const uint32_t soff = run_live && w < W ? row_off + (uint32_t)w * (uint32_t)C * 2u : 0xC0000000u;
+            __builtin_amdgcn_raw_buffer_store_b128(v4u{pv.x, pv.y, pv.z, pv.w}, rs_y, soff + (uint32_t)(i * LPP * 16), 0, 0);
+        }
+    }
+    // phase 2: LayerNorm of the 8 pixels from the stored bf16 values (the 8 reduction chains are independent: their shuffles overlap)
+    uint4 lw[NCH], lb[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        lw[i] = *reinterpret_cast<const uint4*>(ln_w + (sub + i * LPP) * 8);
+        lb[i] = *reinterpret_cast<const uint4*>(ln_b + (sub + i * LPP) * 8);
+    }
+#pragma unroll
+    for (int s = 0; s < RUN; ++s) {
+        const int w = w0 + s;
+        float val[NCH][8];
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            un8(pk[i][s], val[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sm += val[i][j];
+        }
+        sm = psum(sm);
+        const float mean = sm / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = val[i][j] - mean; q = fmaf(d, d, q); }
+        q = psum(q);
+        const float rstd = rsqrtf(q / (float)C + eps);
+        const uint32_t soff = run_live && w < W ? row_off + (uint32_t)w * (uint32_t)C * 2u : 0xC0000000u;
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            float wf[8], bf[8], o[8];
+            un8(lw[i], wf);
+            un8(lb[i], bf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = fmaf((val[i][j] - mean) * rstd, wf[j], bf[j]);
+            const uint4 po = pk8(o);
+            __builtin_amdgcn_raw_buffer_store_b128(v4u{po.x, po.y, po.z, po.w}, rs_h, soff + (uint32_t)(i * LPP * 16), 0, 0);
+        }
+    }
+}
+
 // col[(oy*Wo+ox), (ky*KW+kx)*C + c] = x[oy*s-p+ky, ox*s-p+kx, c]  (0 outside); row stride ldc >= KH*KW*C
 __global__ __launch_bounds__(256) void im2col_kernel(const uint16_t* __restrict__ x, uint16_t* __restrict__ col, int H, int W, int C,
                                                      int KH, int KW, int stride, int pad, int Ho, int Wo, int ldc, int B,
@@ -501,6 +641,22 @@ int fo1_dwconv3x3_bf16(const void* x, const void* weight9c, const void* bias, vo
     return FO1_OK;
 }
 
+#ifdef FO1_ENABLE_AB
+static int g_dwln_run = 1;      // 0 = per-pixel form everywhere, 1 = product rule, 2 = the run form at every size it exists for (tests)
+int fo1_dwconv_ln_set_form(int run_form) { g_dwln_run = run_form < 0 || run_form > 2 ? 1 : run_form; return FO1_OK; }
+#else
+static constexpr int g_dwln_run = 1;
+#endif
+// the sliding-window form exists for the widths that fill whole waves (C = 128, 256, 512, 1024): -> chunks, else 0 (per-pixel form)
+static int dwln_form(int chunks, long long map_pixels, long long total_pixels) {
+    if (!g_dwln_run || map_pixels * chunks * 16 > (1ll << 31)) return 0;       // (the run form's stores address a map of at most 2 GiB)
+    if (!(chunks == 16 || chunks == 32 || chunks == 64 || chunks == 128)) return 0;
+    // a run is one wave's work for 8 (4 at C = 1024) pixels: below ~16 waves per CU the per-pixel form's 8x more waves fill the chip better
+    // (one 48 x 48 x 1024 map: 13 us per-pixel, 21 us in runs; 25 of them: 160 against 112 — profiles/r06_dwconv_run_form_ab.json)
+    const long long waves = total_pixels / (chunks == 128 ? 4 : fo1::kDwRun) / (chunks <= 16 ? 4 : (chunks <= 32 ? 2 : 1));
+    return waves >= 4096 || g_dwln_run == 2 ? chunks : 0;
+}
+
 int fo1_dwconv3x3_ln_bf16(const void* x, const void* weight9c, const void* bias, void* y, const void* ln_weight, const void* ln_bias,
                           float ln_eps, void* h, int H, int W, int C, int batch, void* stream) {
     using namespace fo1;
@@ -508,19 +664,23 @@ int fo1_dwconv3x3_ln_bf16(const void* x, const void* weight9c, const void* bias,
                   "dwconv_ln: NULL operand or aliased buffers");
     FO1_CHECK_ARG(H > 0 && W > 0 && C > 0 && C % 8 == 0 && C <= 64 * kDwLnChunks * 8 && batch >= 1, "dwconv_ln: bad shape %dx%dx%d (C <= 2048)", H, W, C);
     const int chunks = C / 8, npix = batch * H * W;
-    if (chunks <= 16) {
-        FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<4>, dim3(cdiv(npix, 16)), dim3(256), 0, (hipStream_t)stream,
-                   (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
-                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch, (const ImgSeg*)nullptr);
-    } else if (chunks <= 32) {
-        FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<2>, dim3(cdiv(npix, 8)), dim3(256), 0, (hipStream_t)stream,
-                   (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
-                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch, (const ImgSeg*)nullptr);
-    } else {
-        FO1_LAUNCH("dwconv3x3_ln", (double)batch * H * W * C * 6.0, dwconv3x3_ln_kernel<1>, dim3(cdiv(npix, 4)), dim3(256), 0, (hipStream_t)stream,
-                   (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight,
-                   (const uint16_t*)ln_bias, (uint16_t*)h, H, W, C, ln_eps, batch, (const ImgSeg*)nullptr);
-    }
+    const uint16_t *xp = (const uint16_t*)x, *wp = (const uint16_t*)weight9c, *bp = (const uint16_t*)bias, *lwp = (const uint16_t*)ln_weight,
+                   *lbp = (const uint16_t*)ln_bias;
+    const double work = (double)batch * H * W * C * 6.0;
+    const long long runs = (long long)batch * H * cdiv(W, chunks == 128 ? 4 : kDwRun);
+    FO1_CHECK_ARG(runs < (1ll << 31), "dwconv_ln: too many pixel runs");
+#define FO1_DWLN_RUN(PPW, NCH) \
+    FO1_LAUNCH("dwconv3x3_ln", work, (dwconv3x3_ln_run_kernel<PPW, NCH, (NCH > 1 ? 4 : 8)>), dim3(cdiv((int)runs, 4 * PPW)), dim3(256), 0, (hipStream_t)stream, xp, wp, bp, \
+               (uint16_t*)y, lwp, lbp, (uint16_t*)h, H, W, C, ln_eps, batch, (const ImgSeg*)nullptr)
+#define FO1_DWLN_PIX(PPW) \
+    FO1_LAUNCH("dwconv3x3_ln", work, dwconv3x3_ln_kernel<PPW>, dim3(cdiv(npix, 4 * PPW)), dim3(256), 0, (hipStream_t)stream, xp, wp, bp, (uint16_t*)y, \
+               lwp, lbp, (uint16_t*)h, H, W, C, ln_eps, batch, (const ImgSeg*)nullptr)
+    const int form = dwln_form(chunks, npix, npix);
+    if (form == 16) { FO1_DWLN_RUN(4, 1); } else if (form == 32) { FO1_DWLN_RUN(2, 1); } else if (form == 64) { FO1_DWLN_RUN(1, 1); }
+    else if (form == 128) { FO1_DWLN_RUN(1, 2); }
+    else if (chunks <= 16) { FO1_DWLN_PIX(4); } else if (chunks <= 32) { FO1_DWLN_PIX(2); } else { FO1_DWLN_PIX(1); }
+#undef FO1_DWLN_RUN
+#undef FO1_DWLN_PIX
     return FO1_OK;
 }
 
@@ -642,7 +802,16 @@ int fo1_dwconv3x3_ln_var_bf16(const void* x, const void* weight9c, const void* b
     FO1_LAUNCH("dwconv3x3_ln", work, dwconv3x3_ln_kernel<PPW>, dim3(cdiv(max_pixels, PIXPB), n_img), dim3(256), 0, (hipStream_t)stream, \
                (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight, \
                (const uint16_t*)ln_bias, (uint16_t*)h, 0, 0, C, ln_eps, 1, sg)
-    if (chunks <= 16) { FO1_DWLN_VAR(4, 16); } else if (chunks <= 32) { FO1_DWLN_VAR(2, 8); } else { FO1_DWLN_VAR(1, 4); }
+    // the run form's grid: an image has H * ceil(W / 8) <= H * W runs; the workgroups past an image's last run leave at once
+#define FO1_DWLN_VAR_RUN(PPW, NCH) \
+    FO1_LAUNCH("dwconv3x3_ln", work, (dwconv3x3_ln_run_kernel<PPW, NCH, (NCH > 1 ? 4 : 8)>), dim3(cdiv(max_pixels, 4 * PPW), n_img), dim3(256), 0, (hipStream_t)stream, \
+               (const uint16_t*)x, (const uint16_t*)weight9c, (const uint16_t*)bias, (uint16_t*)y, (const uint16_t*)ln_weight, \
+               (const uint16_t*)ln_bias, (uint16_t*)h, 0, 0, C, ln_eps, 1, sg)
+    const int form = dwln_form(chunks, max_pixels, total_pixels);
+    if (form == 16) { FO1_DWLN_VAR_RUN(4, 1); } else if (form == 32) { FO1_DWLN_VAR_RUN(2, 1); } else if (form == 64) { FO1_DWLN_VAR_RUN(1, 1); }
+    else if (form == 128) { FO1_DWLN_VAR_RUN(1, 2); }
+    else if (chunks <= 16) { FO1_DWLN_VAR(4, 16); } else if (chunks <= 32) { FO1_DWLN_VAR(2, 8); } else { FO1_DWLN_VAR(1, 4); }
+#undef FO1_DWLN_VAR_RUN
 #undef FO1_DWLN_VAR
     return FO1_OK;
 }
