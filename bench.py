@@ -1070,6 +1070,8 @@ def main():
         L.load().fo1_hfre_set_tuning(8, 512, -4 if int(os.environ["FO1_HFRE_ORDER"]) else -3, 0)
     if os.environ.get("FO1_DWLN_FORM") and L.ab_build():         # A/B of DaViT's depthwise conv + LayerNorm: 0 = per-pixel form, 1 = product rule (sliding-window runs)
         L.load().fo1_dwconv_ln_set_form(int(os.environ["FO1_DWLN_FORM"]))
+    if os.environ.get("FO1_CHATTN_IMPL") and L.ab_build():       # A/B of DaViT's channel attention: 0 = fp32 FMA kernels (rounds 1-5), 1 = matrix-core kernels
+        L.load().fo1_channel_attention_set_impl(int(os.environ["FO1_CHATTN_IMPL"]))
     img_hw = tuple(int(v) for v in args.image.lower().split("x"))
     S_img = (round(img_hw[0] / 28) * 2) * (round(img_hw[1] / 28) * 2)
     auto_batch = args.batch <= 0

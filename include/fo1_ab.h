@@ -63,6 +63,10 @@ int fo1_gemm_set_stamp_buffer(void* device_buffer);
  * everywhere; 2 = the run form at every size it exists for.  Bit-identical. */
 int fo1_dwconv_ln_set_form(int run_form);
 
+/* fo1_channel_attention_bf16 / _var: 1 (default) = Gram matrices and the attention product on the matrix cores (v_mfma_f32_32x32x16_bf16; exact
+ * bf16 products, fp32 sums in the MFMA's order), 0 = the fp32 FMA kernels of rounds 1-5 (sequential sums).  Equal up to the order of fp32 additions. */
+int fo1_channel_attention_set_impl(int mfma);
+
 /* ---- decode step ---- */
 /* fo1_gemv_batch_bf16, v_dot2 kernel: 0 (default) = a lane streams 1 / 2 / 4 weight rows per chunk position by M; 1 = always one row. */
 int fo1_gemv_batch_set_rows_per_lane(int rpl);

@@ -82,6 +82,29 @@ def test_channel_attention():
         assert err < 0.03 * ref.abs().max() + 2e-3, f"channel attention N={N} C={C}: max err {err:.4g} (scale {ref.abs().max():.3g})"
 
 
+def test_channel_attention_matrix_core_kernels_against_the_fp32_fma_kernels():
+    """Round 6: the Gram matrices and the attention product run on v_mfma_f32_32x32x16_bf16.  Products of bf16 values are exact either way;
+    the two forms differ in the order of the fp32 additions only, so after the bf16 roundings (softmax input and output, result) almost every
+    output element is equal and none is more than a few bf16 steps away.  DaViT stage shapes incl. ragged token counts and stacked images."""
+    from vlm_fo1_amd import lib as _L, ops
+    torch.manual_seed(33)
+    for (B, N, C) in [(1, 1200, 1024), (3, 300, 256), (2, 37, 64), (1, 513, 32), (2, 4800, 512)]:
+        qkv = torch.randn(B * N, 3 * C).to(BF).cuda()
+        new = ops.channel_attention(qkv, C, batch=B)
+        with _L.use_ab():
+            _L.load().fo1_channel_attention_set_impl(0)
+            try:
+                old = ops.channel_attention(qkv, C, batch=B)
+            finally:
+                _L.load().fo1_channel_attention_set_impl(1)
+        d = (new.float() - old.float()).abs()
+        frac_equal = float((d == 0).float().mean())
+        assert frac_equal > 0.97, f"B={B} N={N} C={C}: only {frac_equal:.4f} of the elements equal"
+        assert float(d.max()) <= 0.02 * float(old.float().abs().max()) + 1e-3, f"B={B} N={N} C={C}: max diff {float(d.max()):.4g}"
+        # run to run: bitwise
+        assert torch.equal(new, ops.channel_attention(qkv, C, batch=B))
+
+
 def test_pixel_shuffle_maxpool_nchw_gather():
     from vlm_fo1_amd import ops
     torch.manual_seed(4)

@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void window_reverse_add_kernel(const uint16_t*
 // ---- channel attention (group width 32) -------------------------------------------------------
 // qkv: [N, 3C] rows = [q | k | v].  Phase 1: partial Gram matrices over token chunks.
 //   part[chunk][g][c][c'] = sum_{n in chunk} q[n, g*32+c] * k[n, g*32+c']      (fp32)
-constexpr int kCaTok = 512;  // tokens per chunk
+constexpr int kCaTok = 256;  // tokens per chunk (round 6: 512 -> 256, four groups per workgroup need the finer grid)
 __global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, float* __restrict__ part,
                                                           const ImgSeg* __restrict__ segs) {
     __shared__ float sq[64][33];
@@ -445,6 +445,92 @@ __global__ __launch_bounds__(256) void chattn_gram_kernel(const uint16_t* __rest
     o[(2 * ci) * 32 + 2 * cj] = a00; o[(2 * ci) * 32 + 2 * cj + 1] = a01;
     o[(2 * ci + 1) * 32 + 2 * cj] = a10; o[(2 * ci + 1) * 32 + 2 * cj + 1] = a11;
 }
+// Round 6: the same partial Gram matrices on the matrix cores.  The reduction runs over TOKENS, the memory-major index, so the operands
+// (8 consecutive tokens of one channel per lane) are read out of a staged [64 tokens][32 channels] bf16 tile column-wise (2-byte LDS reads;
+// 72-byte rows put the fragment's two token groups in different bank halves).  A workgroup = FOUR ADJACENT GROUPS of one token chunk, one
+// wave per group: together the waves consume whole 128-byte lines of the q and k rows (a group alone reads 64 of a row's 6 KB; with one
+// group per workgroup the other half of every line was fetched again by a workgroup on another XCD: PMC fetch 2.1x the footprint).  A wave
+// stages and multiplies its own tiles (the next tile's loads in flight meanwhile) and owns its 32 x 32 matrix: no workgroup barrier, no
+// cross-wave reduction.  Products of bf16 values are exact in fp32; only the order of the fp32 additions differs from chattn_gram_kernel.
+typedef __attribute__((ext_vector_type(8))) __bf16 ca_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float ca_f32x16;
+constexpr int kCaRow = 72;
+__global__ __launch_bounds__(256) void chattn_gram_mfma_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, float* __restrict__ part,
+                                                               const ImgSeg* __restrict__ segs) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * 2 * 64 * kCaRow];      // 36 KB: a q and a k tile per wave
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = C >> 5, g = blockIdx.y * 4 + wave, chunk = blockIdx.x;
+    if (segs) {
+        N = segs[blockIdx.z].H;
+        qkv += (long long)segs[blockIdx.z].in_row0 * ld;
+    } else {
+        qkv += (long long)blockIdx.z * N * ld;
+    }
+    if (chunk * kCaTok >= N || g >= G) return;                                    // (no barrier below: a wave may leave alone)
+    part += (long long)blockIdx.z * gridDim.x * G * 1024;
+    char* sq = smem + wave * (2 * 64 * kCaRow);
+    char* sk = sq + 64 * kCaRow;
+    const int n_begin = chunk * kCaTok, n_end = min(N, n_begin + kCaTok);
+    const int lr = lane >> 2, cc = lane & 3, fi = lane & 31, kg = lane >> 5;
+    const uint16_t* base = qkv + g * 32 + cc * 8;
+    constexpr int TILES = kCaTok / 64;
+    uint4 rq[TILES][4], rk[TILES][4];
+    // every tile of the chunk is requested before the first is used (32 loads per lane in flight: the wave's whole share of the chunk);
+    // rows past the chunk re-read its last row (a valid address, an L1 hit) and are zeroed when staged
+#pragma unroll
+    for (int t = 0; t < TILES; ++t)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = min(n_begin + t * 64 + 16 * p + lr, n_end - 1);
+            rq[t][p] = *reinterpret_cast<const uint4*>(base + (long long)r * ld);
+            rk[t][p] = *reinterpret_cast<const uint4*>(base + (long long)r * ld + C);
+        }
+    ca_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int t = 0; t < TILES; ++t) {
+        const int n0 = n_begin + t * 64;
+        if (n0 < n_end) {                                                 // wave-uniform
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const bool ok = n0 + 16 * p + lr < n_end;
+                const uint4 a = ok ? rq[t][p] : uint4{0, 0, 0, 0}, b = ok ? rk[t][p] : uint4{0, 0, 0, 0};
+                char* dq = sq + (16 * p + lr) * kCaRow + cc * 16;
+                char* dk = sk + (16 * p + lr) * kCaRow + cc * 16;
+                *reinterpret_cast<uint2*>(dq) = uint2{a.x, a.y}; *reinterpret_cast<uint2*>(dq + 8) = uint2{a.z, a.w};
+                *reinterpret_cast<uint2*>(dk) = uint2{b.x, b.y}; *reinterpret_cast<uint2*>(dk + 8) = uint2{b.z, b.w};
+            }
+            // the tile is wave-private and a wave's LDS instructions execute in order: no fence (a release fence would also wait for the
+            // loads of the tiles still in flight), only the compiler is held to the program order
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const char* pq = sq + (16 * m + 8 * kg) * kCaRow + 2 * fi;
+                const char* pk = sk + (16 * m + 8 * kg) * kCaRow + 2 * fi;
+                uint32_t wa[4], wb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    wa[u] = (uint32_t)*reinterpret_cast<const uint16_t*>(pq + (2 * u) * kCaRow) |
+                            ((uint32_t)*reinterpret_cast<const uint16_t*>(pq + (2 * u + 1) * kCaRow) << 16);
+                    wb[u] = (uint32_t)*reinterpret_cast<const uint16_t*>(pk + (2 * u) * kCaRow) |
+                            ((uint32_t)*reinterpret_cast<const uint16_t*>(pk + (2 * u + 1) * kCaRow) << 16);
+                }
+                const uint4 ua = uint4{wa[0], wa[1], wa[2], wa[3]}, ub = uint4{wb[0], wb[1], wb[2], wb[3]};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(ca_bf16x8, ua), __builtin_bit_cast(ca_bf16x8, ub), acc, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_wave_barrier();                              // the next tile overwrites what other lanes have just read
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* o = part + (((long long)chunk * G + g) * 32) * 32;             // D[q channel][k channel]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[((r >> 2) * 8 + kg * 4 + (r & 3)) * 32 + fi] = acc[r];
+}
+
 
 // Phase 2: A[g][c][:] = softmax_c'( bf16( scale * sum_chunks part ) ) rounded to bf16 (stored fp32).
 // One 1024-thread workgroup per group: thread (r, c) sums its element over the chunks in a fixed order
@@ -536,6 +622,73 @@ __global__ __launch_bounds__(256) void chattn_apply_kernel(const uint16_t* __res
             uint4 w;
             w.x = pack_bf16x2(o[0], o[1]); w.y = pack_bf16x2(o[2], o[3]); w.z = pack_bf16x2(o[4], o[5]); w.w = pack_bf16x2(o[6], o[7]);
             *reinterpret_cast<uint4*>(op + j * 8) = w;
+        }
+    }
+}
+
+// Round 6: out[n, i] = sum_k A[i][k] v[n, k] on the matrix cores — the reduction runs over the group's 32 channels, which are contiguous in
+// memory, so the v fragments are plain 16-byte loads (lane = token, 8 channels) and the attention matrix (bf16 values held as fp32) is the
+// register-resident other operand.  A lane ends up with 16 of a token's 32 output channels in 4-channel pieces; one exchange with the lane
+// 32 away turns them into 16 consecutive channels = two 16-byte stores.  fp32 sums of exact products, rounded to bf16 as chattn_apply_kernel.
+__global__ __launch_bounds__(256) void chattn_apply_mfma_kernel(const uint16_t* __restrict__ qkv, int ld, int N, int C, const float* __restrict__ A,
+                                                                uint16_t* __restrict__ out, int ldo, const ImgSeg* __restrict__ segs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = C >> 5, g = blockIdx.y * 4 + wave;      // four adjacent groups per workgroup, one per wave: whole 128-byte lines of the v rows
+    if (g >= G) return;
+    if (segs) {
+        N = segs[blockIdx.z].H;
+        qkv += (long long)segs[blockIdx.z].in_row0 * ld;
+        out += (long long)segs[blockIdx.z].in_row0 * ldo;
+    } else {
+        qkv += (long long)blockIdx.z * N * ld;
+        out += (long long)blockIdx.z * N * ldo;
+    }
+    A += ((long long)blockIdx.z * G + g) * 1024;
+    const int fi = lane & 31, kg = lane >> 5;
+    ca_bf16x8 af[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const float4 a0 = *reinterpret_cast<const float4*>(A + fi * 32 + 16 * c + 8 * kg), a1 = *reinterpret_cast<const float4*>(A + fi * 32 + 16 * c + 8 * kg + 4);
+        const uint4 u = uint4{pack_bf16x2(a0.x, a0.y), pack_bf16x2(a0.z, a0.w), pack_bf16x2(a1.x, a1.y), pack_bf16x2(a1.z, a1.w)};   // exact: bf16 values
+        af[c] = __builtin_bit_cast(ca_bf16x8, u);
+    }
+    // a wave = 4 consecutive 32-token blocks, all 8 loads requested before the first product (one latency per wave instead of four)
+    constexpr int NB = 4;
+    const int nb0 = blockIdx.x * (32 * NB);
+    if (nb0 >= N) return;                       // ragged: the grid covers the largest image
+    uint4 v0[NB], v1[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int n = min(nb0 + 32 * b + fi, N - 1);
+        const uint16_t* vp = qkv + (long long)n * ld + 2 * C + g * 32 + kg * 8;
+        v0[b] = *reinterpret_cast<const uint4*>(vp);
+        v1[b] = *reinterpret_cast<const uint4*>(vp + 16);
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int n = nb0 + 32 * b + fi;
+        ca_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], __builtin_bit_cast(ca_bf16x8, v0[b]), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], __builtin_bit_cast(ca_bf16x8, v1[b]), acc, 0, 0, 0);
+        // register r = output channel (r / 4) * 8 + kg * 4 + r % 4 of token n.  The lower half-wave keeps channels 0..15, the upper 16..31:
+        // each sends the 8 registers of the other's channels and receives the 4-channel pieces that complete its own 8-channel runs
+        float rcv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rcv[u] = __shfl_xor(kg ? acc[u] : acc[8 + u], 32, 64);
+        float o[16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            o[u] = kg ? rcv[u] : acc[u];                 // channels base + 0..3
+            o[4 + u] = kg ? acc[8 + u] : rcv[u];         //          base + 4..7
+            o[8 + u] = kg ? rcv[4 + u] : acc[4 + u];     //          base + 8..11
+            o[12 + u] = kg ? acc[12 + u] : rcv[4 + u];   //          base + 12..15
+        }
+        if (n < N) {
+            uint16_t* op = out + (long long)n * ldo + g * 32 + kg * 16;
+            *reinterpret_cast<uint4*>(op) = uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+            *reinterpret_cast<uint4*>(op + 8) = uint4{pack_bf16x2(o[8], o[9]), pack_bf16x2(o[10], o[11]), pack_bf16x2(o[12], o[13]), pack_bf16x2(o[14], o[15])};
         }
     }
 }
@@ -714,6 +867,13 @@ int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, i
     return FO1_OK;
 }
 
+#ifdef FO1_ENABLE_AB
+static int g_chattn_mfma = 1;
+int fo1_channel_attention_set_impl(int mfma) { g_chattn_mfma = mfma != 0; return FO1_OK; }
+#else
+static constexpr int g_chattn_mfma = 1;
+#endif
+
 size_t fo1_channel_attention_workspace_bytes(int N, int C, int batch) {
     const int G = C / 32, chunks = fo1::cdiv(N, fo1::kCaTok);
     return (size_t)batch * ((size_t)chunks * G * 1024 + (size_t)G * 1024) * sizeof(float);
@@ -732,14 +892,21 @@ int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out,
     float* part = (float*)workspace;
     float* A = part + (size_t)batch * chunks * G * 1024;
     hipStream_t st = (hipStream_t)stream;
-    FO1_LAUNCH("chattn_gram", (double)batch * N * C * 4.0, chattn_gram_kernel, dim3(chunks, G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part, (const ImgSeg*)nullptr);
+    if (g_chattn_mfma) {
+        FO1_LAUNCH("chattn_gram", (double)batch * N * C * 4.0, chattn_gram_mfma_kernel, dim3(chunks, cdiv(G, 4), batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part, (const ImgSeg*)nullptr);
+    } else {
+        FO1_LAUNCH("chattn_gram", (double)batch * N * C * 4.0, chattn_gram_kernel, dim3(chunks, G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C, part, (const ImgSeg*)nullptr);
+    }
     // reference: q * N^-0.5 (modeling_davit.py:165)
     FO1_LAUNCH("chattn_softmax", (double)batch * chunks * G * 4096.0, chattn_softmax_kernel, dim3(G, batch), dim3(1024), 0, st, (const float*)part, chunks, G,
                1.0f / sqrtf((float)N), A, (const ImgSeg*)nullptr);
-    int gx = cdiv(N, 256);
-    if (gx > 512) gx = 512;
-    FO1_LAUNCH("chattn_apply", (double)batch * N * C * 4.0, chattn_apply_kernel, dim3(gx, G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld, N, C,
-               (const float*)A, (uint16_t*)out, ldo, (const ImgSeg*)nullptr);
+    if (g_chattn_mfma) {
+        FO1_LAUNCH("chattn_apply", (double)batch * N * C * 4.0, chattn_apply_mfma_kernel, dim3(cdiv(N, 128), cdiv(G, 4), batch), dim3(256), 0, st, (const uint16_t*)qkv,
+                   ld, N, C, (const float*)A, (uint16_t*)out, ldo, (const ImgSeg*)nullptr);
+    } else {
+        FO1_LAUNCH("chattn_apply", (double)batch * N * C * 4.0, chattn_apply_kernel, dim3(min(cdiv(N, 256), 512), G, batch), dim3(256), 0, st, (const uint16_t*)qkv, ld,
+                   N, C, (const float*)A, (uint16_t*)out, ldo, (const ImgSeg*)nullptr);
+    }
     return FO1_OK;
 }
 
@@ -866,13 +1033,20 @@ int fo1_channel_attention_var_bf16(const void* qkv, int ld, const void* segs, in
     float* A = part + (size_t)n_img * chunks * G * 1024;
     hipStream_t st = (hipStream_t)stream;
     const ImgSeg* sg = (const ImgSeg*)segs;
-    FO1_LAUNCH("chattn_gram", (double)total_tokens * C * 4.0, chattn_gram_kernel, dim3(chunks, G, n_img), dim3(256), 0, st, (const uint16_t*)qkv, ld, 0, C, part, sg);
+    if (g_chattn_mfma) {
+        FO1_LAUNCH("chattn_gram", (double)total_tokens * C * 4.0, chattn_gram_mfma_kernel, dim3(chunks, cdiv(G, 4), n_img), dim3(256), 0, st, (const uint16_t*)qkv, ld, 0, C, part, sg);
+    } else {
+        FO1_LAUNCH("chattn_gram", (double)total_tokens * C * 4.0, chattn_gram_kernel, dim3(chunks, G, n_img), dim3(256), 0, st, (const uint16_t*)qkv, ld, 0, C, part, sg);
+    }
     FO1_LAUNCH("chattn_softmax", (double)n_img * chunks * G * 4096.0, chattn_softmax_kernel, dim3(G, n_img), dim3(1024), 0, st, (const float*)part, chunks, G,
                0.f, A, sg);
-    int gx = cdiv(max_tokens, 256);
-    if (gx > 512) gx = 512;
-    FO1_LAUNCH("chattn_apply", (double)total_tokens * C * 4.0, chattn_apply_kernel, dim3(gx, G, n_img), dim3(256), 0, st, (const uint16_t*)qkv, ld, 0, C,
-               (const float*)A, (uint16_t*)out, ldo, sg);
+    if (g_chattn_mfma) {
+        FO1_LAUNCH("chattn_apply", (double)total_tokens * C * 4.0, chattn_apply_mfma_kernel, dim3(cdiv(max_tokens, 128), cdiv(G, 4), n_img), dim3(256), 0, st,
+                   (const uint16_t*)qkv, ld, 0, C, (const float*)A, (uint16_t*)out, ldo, sg);
+    } else {
+        FO1_LAUNCH("chattn_apply", (double)total_tokens * C * 4.0, chattn_apply_kernel, dim3(min(cdiv(max_tokens, 256), 512), G, n_img), dim3(256), 0, st,
+                   (const uint16_t*)qkv, ld, 0, C, (const float*)A, (uint16_t*)out, ldo, sg);
+    }
     return FO1_OK;
 }
 

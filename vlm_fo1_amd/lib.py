@@ -282,6 +282,7 @@ SIGNATURES_AB = {
     "fo1_attention_decode_set_pool_chunk": (c_int, [c_int]),
     "fo1_attention_decode_set_small_chunk": (c_int, [c_int]),
     "fo1_dwconv_ln_set_form": (c_int, [c_int]),
+    "fo1_channel_attention_set_impl": (c_int, [c_int]),
     # measured no-gain kernel forms and instruments (round 5: out of the product ABI)
     "fo1_gemm_profile_shapes": (c_int, [c_int]),
     "fo1_mfma_clock_probe": (c_int, [c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
