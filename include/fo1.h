@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* libfo1hip*.so are built with -fvisibility=hidden: exactly the declarations of this header are exported */
 #endif
 
-#define FO1_ABI_VERSION 8   /* 8: fo1_attention_decode_batch_partials_bf16 + fo1_gemv_attn_combine_bf16 (decode step at <= 2 sequences: the o-projection sums the split-KV partials in its prologue, no combine launch); 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 9   /* 9: fo1_window_attention_bf16 (DaViT window attention on the q/k/v rows: no V^T copy); 8: fo1_attention_decode_batch_partials_bf16 + fo1_gemv_attn_combine_bf16 (decode step at <= 2 sequences: the o-projection sums the split-KV partials in its prologue, no combine launch); 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -333,6 +333,9 @@ int fo1_attention_prefix_bf16(const void* Q, long long q_tok_stride, long long q
  *                               (simple_fpn.py:165-175); the conv itself is fo1_gemm_bf16 on col
  *   fo1_window_partition_bf16   zero-pad to multiples of ws and regroup rows window by window (:208-213,244-254)
  *   fo1_window_reverse_add_bf16 y = shortcut + window_reverse(yw)[:H,:W]   (:216-222,272-281 + PreNorm residual)
+ *   fo1_window_attention_bf16   WindowAttention's softmax(q k^T * scale) v (:225-282) for head dim 32, straight on the q/k/v GEMM's
+ *                               [windows * window_tokens, 3C] rows (q | k | v, heads 32 columns apart): one wave per (window, head),
+ *                               no V^T copy, no item list (round 6; fo1_attention_bf16 + fo1_transpose_bf16 before)
  *   fo1_channel_attention_bf16  ChannelAttention (:151-172) for 32-wide groups: qkv rows [q|k|v] ->
  *                               out[n, g*32+c] = sum_c' softmax_c'(q_g^T k_g / sqrt(N))[c][c'] v[n, g*32+c']
  *   fo1_pixel_shuffle2_bf16     ConvTranspose2d(k=2,s=2) output regrouping (simple_fpn.py:141-150):
@@ -356,6 +359,10 @@ int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, i
                                 int batch, void* stream);
 /* N = tokens of ONE image; qkv / out hold batch * N rows and every image gets its own per-group attention matrices.
  * Rows are read / written 16 bytes at a time: ld % 8 == 0, ldo % 8 == 0, qkv and out 16-byte aligned. */
+/* out[w * window_tokens + i, h * 32 + d] for every window w < n_windows and head h < n_heads; C = n_heads * 32, window_tokens <= 160,
+ * ld >= 3 C, rows 16-byte aligned (ld % 8, ldo % 8), the output at most 2 GiB (32-bit store offsets). */
+int fo1_window_attention_bf16(const void* qkv, long long ld, int C, int n_heads, int window_tokens, int n_windows, void* out, long long ldo,
+                              float scale, void* stream);
 size_t fo1_channel_attention_workspace_bytes(int N, int C, int batch);
 int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, int batch, void* workspace,
                                size_t workspace_bytes, void* stream);

@@ -73,7 +73,7 @@ def test_product_library_has_no_switches_and_the_ab_build_has_exactly_the_two_he
 
 
 def test_abi_version():
-    assert L.load().fo1_abi_version() == 8
+    assert L.load().fo1_abi_version() == 9
 
 
 def test_hfre_argument_errors():

@@ -105,6 +105,35 @@ def test_channel_attention_matrix_core_kernels_against_the_fp32_fma_kernels():
         assert torch.equal(new, ops.channel_attention(qkv, C, batch=B))
 
 
+def test_window_attention_on_the_qkv_rows_against_a_torch_reference_and_the_general_kernel():
+    """Round 6: fo1_window_attention_bf16 — DaViT's WindowAttention core (modeling_davit.py:225-282) for head dim 32 on the q/k/v GEMM's
+    [windows * tokens, 3C] rows.  Against an fp32 torch softmax(q k^T / sqrt(32)) v per window and head (bf16 tolerance), against the general
+    attention kernel it replaces (same rounding points: within a couple of bf16 steps), window counts / token counts that are not multiples of
+    the tile sizes, and run to run bitwise."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(34)
+    for (n_win, wtok, heads) in [(7, 144, 8), (3, 144, 32), (5, 64, 4), (2, 37, 12), (1, 160, 16), (4, 1, 8)]:
+        C = heads * 32
+        n = n_win * wtok
+        qkv = (torch.randn(n, 3 * C) * 1.5).to(BF).cuda()
+        got = ops.window_attention(qkv, C, heads, wtok, 32 ** -0.5)
+        x = qkv.float().view(n_win, wtok, 3, heads, 32).permute(2, 0, 3, 1, 4)          # [3][win][head][tok][32]
+        att = torch.softmax(x[0] @ x[1].transpose(-1, -2) * 32 ** -0.5, dim=-1)
+        ref = (att @ x[2]).permute(0, 2, 1, 3).reshape(n, C)
+        err = (got.float() - ref).abs().max()
+        assert err < 0.02 * ref.abs().max() + 2e-3, f"{n_win} x {wtok} x {heads}: max err {float(err):.4g}"
+        assert torch.equal(got, ops.window_attention(qkv, C, heads, wtok, 32 ** -0.5))
+        # the general kernel over an item list with a transposed V
+        n_pad = (n + 63) // 64 * 64
+        vt = torch.zeros(C, n_pad, dtype=BF, device="cuda")
+        ops.transpose_into(qkv[:, 2 * C:], vt, 0)
+        segs = [(i * wtok, (i + 1) * wtok) for i in range(n_win)]
+        items = ops.make_items(segs, "cuda", block=ops.pick_q_block(segs, heads))
+        old = ops.attention(qkv[:, :C], qkv[:, C:2 * C], vt, items, heads, heads, 32, 32 ** -0.5, False)
+        d = (got.float() - old.float()).abs()
+        assert float(d.max()) <= 0.02 * float(old.float().abs().max()) + 1e-3, f"{n_win} x {wtok} x {heads}: vs the general kernel {float(d.max()):.4g}"
+
+
 def test_pixel_shuffle_maxpool_nchw_gather():
     from vlm_fo1_amd import ops
     torch.manual_seed(4)

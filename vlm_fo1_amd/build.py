@@ -15,6 +15,13 @@ LIB_AB = os.path.join(HERE, "libfo1hip_ab.so")
 ARCH = "gfx950"
 
 
+# per-file code generation flags: kernels whose MFMA results are consumed by VALU instructions at once keep the accumulators in VGPRs
+FILE_FLAGS = {
+    "window_attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+    "vision_ops.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],        # (the channel-attention kernels are its only MFMA code)
+}
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -42,7 +49,8 @@ def _build_one(lib: str, objdir: str, defines, force: bool, verbose: bool) -> st
         ):
             continue
         cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"] + list(defines)
+               "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-fvisibility-inlines-hidden"] + list(defines) + \
+            FILE_FLAGS.get(os.path.basename(src), [])
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd)))

@@ -442,9 +442,13 @@ int davit_run(Arena& A, const fo1_davit_weights_t* w, const fo1_davit_plan_t* pl
                 FO1_RUN(fo1_dwconv3x3_ln_bf16(XA, d.conv1_w, d.conv1_b, XB, d.an_w, d.an_b, 1e-5f, h, H, W, C, B, stream));
                 FO1_RUN(fo1_window_partition_bf16(h, hw, H, W, C, ws, B, stream));   // zero-padded AFTER the norm (:248-251)
                 FO1_RUN(fo1_gemm_bf16_ws(hw, C, d.qkv_w, C, d.qkv_b, nullptr, 0, qkv, 3 * C, nw, 3 * C, C, 0, 0, gws, kGemmScratch, stream));
-                FO1_RUN(fo1_transpose_bf16((const uint16_t*)qkv + 2 * C, 3 * C, vt, nw_pad, 0, nullptr, nw, C, stream));
-                FO1_RUN(fo1_attention_bf16(qkv, 3 * C, hd, (const uint16_t*)qkv + C, 3 * C, hd, vt, nw_pad, att, C, hd, pl->items[i], pl->n_items[i],
-                                           pl->q_block[i], heads, heads, hd, (float)pow((double)hd, -0.5), 0, nullptr, 4.0 * C * nw * ws * ws, stream));
+                if (hd == 32 && ws * ws <= 160) {      // every DaViT stage: the window kernel on the q/k/v rows themselves (no V^T copy)
+                    FO1_RUN(fo1_window_attention_bf16(qkv, 3 * C, C, heads, ws * ws, nw / (ws * ws), att, C, (float)pow((double)hd, -0.5), stream));
+                } else {
+                    FO1_RUN(fo1_transpose_bf16((const uint16_t*)qkv + 2 * C, 3 * C, vt, nw_pad, 0, nullptr, nw, C, stream));
+                    FO1_RUN(fo1_attention_bf16(qkv, 3 * C, hd, (const uint16_t*)qkv + C, 3 * C, hd, vt, nw_pad, att, C, hd, pl->items[i], pl->n_items[i],
+                                               pl->q_block[i], heads, heads, hd, (float)pow((double)hd, -0.5), 0, nullptr, 4.0 * C * nw * ws * ws, stream));
+                }
                 FO1_RUN(fo1_gemm_bf16_ws(att, C, d.proj_w, C, d.proj_b, nullptr, 0, y, C, nw, C, C, 0, 0, gws, kGemmScratch, stream));
                 FO1_RUN(fo1_window_reverse_add_bf16(y, XB, XA, H, W, C, ws, B, stream));
                 A.release(m);

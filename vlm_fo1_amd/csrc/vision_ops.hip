@@ -674,16 +674,21 @@ __global__ __launch_bounds__(256) void chattn_apply_mfma_kernel(const uint16_t* 
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], __builtin_bit_cast(ca_bf16x8, v1[b]), acc, 0, 0, 0);
         // register r = output channel (r / 4) * 8 + kg * 4 + r % 4 of token n.  The lower half-wave keeps channels 0..15, the upper 16..31:
         // each sends the 8 registers of the other's channels and receives the 4-channel pieces that complete its own 8-channel runs
+        // (bit selects, not `kg ? acc[u] : acc[8 + u]`: on the vector type that becomes a run-time element index = a 16-step select chain)
+        const uint32_t km = kg ? 0xffffffffu : 0u;
+        auto sel = [km](float a, float b) __attribute__((always_inline)) {           // kg ? a : b
+            return __builtin_bit_cast(float, (__builtin_bit_cast(uint32_t, a) & km) | (__builtin_bit_cast(uint32_t, b) & ~km));
+        };
         float rcv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) rcv[u] = __shfl_xor(kg ? acc[u] : acc[8 + u], 32, 64);
+        for (int u = 0; u < 8; ++u) rcv[u] = __shfl_xor(sel(acc[u], acc[8 + u]), 32, 64);
         float o[16];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            o[u] = kg ? rcv[u] : acc[u];                 // channels base + 0..3
-            o[4 + u] = kg ? acc[8 + u] : rcv[u];         //          base + 4..7
-            o[8 + u] = kg ? rcv[4 + u] : acc[4 + u];     //          base + 8..11
-            o[12 + u] = kg ? acc[12 + u] : rcv[4 + u];   //          base + 12..15
+            o[u] = sel(rcv[u], acc[u]);                  // channels base + 0..3
+            o[4 + u] = sel(acc[8 + u], rcv[u]);          //          base + 4..7
+            o[8 + u] = sel(rcv[4 + u], acc[4 + u]);      //          base + 8..11
+            o[12 + u] = sel(acc[12 + u], rcv[4 + u]);    //          base + 12..15
         }
         if (n < N) {
             uint16_t* op = out + (long long)n * ldo + g * 32 + kg * 16;

@@ -79,6 +79,21 @@ class DaViT:
             self._items[key] = ops.make_items(segs, self.dev, block=ops.pick_q_block(segs, heads))
         return self._items[key]
 
+    def _window_attention(self, qkv, C, heads, ws, device):
+        """softmax(q k^T / sqrt(hd)) v over the windows of ws * ws consecutive rows of the q/k/v GEMM output (modeling_davit.py:225-282).
+        Head dim 32 (every DaViT stage) and windows of <= 160 tokens: one launch on the [rows, 3C] map itself; otherwise the general
+        attention kernel over an item list, with V transposed into a scratch [C, rows] first."""
+        n, hd = qkv.shape[0], C // heads
+        if hd == 32 and ws * ws <= ops.WINDOW_ATTENTION_MAX_TOKENS:
+            return ops.window_attention(qkv, C, heads, ws * ws, float(hd) ** -0.5)
+        # V^T scratch [C, n padded to 64] from the owner-scoped pool (zero-initialised; the pad columns are never written):
+        # this module is shared by engine replicas, so the buffer must belong to the running request, not to the module
+        n_pad = _round_up(n, 64)
+        vt = ops._workspace(f"davit_vt_{C}", device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
+        ops.transpose_into(qkv[:, 2 * C:], vt, 0)
+        items = self._window_items(n // (ws * ws), ws * ws, heads)
+        return ops.attention(qkv[:, :C], qkv[:, C:2 * C], vt, items, heads, heads, hd, float(hd) ** -0.5, False, flops=4.0 * C * n * ws * ws)
+
     def _conv_ffn(self, x, H, W, d, B=1):
         """conv2 (depthwise 3x3 + residual) -> LayerNorm -> MLP(+residual); the conv and the norm are one launch."""
         x, h = ops.dwconv3x3_res_ln(x, d["conv2_w"], d["conv2_b"], H, W, d["fn_w"], d["fn_b"], 1e-5, batch=B)
@@ -90,16 +105,7 @@ class DaViT:
         x, h = ops.dwconv3x3_res_ln(x, d["conv1_w"], d["conv1_b"], H, W, d["an_w"], d["an_b"], 1e-5, batch=B)
         hw = ops.window_partition(h, H, W, ws, batch=B)   # zero-padded AFTER the norm, like the reference (:248-251)
         qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
-        n = hw.shape[0]
-        # V^T scratch [C, n padded to 64] from the owner-scoped pool (zero-initialised; the pad columns are never written):
-        # this module is shared by engine replicas, so the buffer must belong to the running request, not to the module
-        n_pad = _round_up(n, 64)
-        vt = ops._workspace(f"davit_vt_{C}", x.device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
-        ops.transpose_into(qkv[:, 2 * C:], vt, 0)
-        hd = C // heads
-        items = self._window_items(n // (ws * ws), ws * ws, heads)
-        att = ops.attention(qkv[:, :C], qkv[:, C:2 * C], vt, items, heads, heads, hd, float(hd) ** -0.5, False,
-                            flops=4.0 * C * n * ws * ws)
+        att = self._window_attention(qkv, C, heads, ws, x.device)
         y = ops.gemm(att, d["proj_w"], d["proj_b"])
         x = ops.window_reverse_add(y, x, H, W, ws, batch=B)
         return self._conv_ffn(x, H, W, d, B)
@@ -132,13 +138,7 @@ class DaViT:
         x, h = ops.dwconv3x3_res_ln_var(x, d["conv1_w"], d["conv1_b"], lv["pix"], d["an_w"], d["an_b"], 1e-5)
         hw = ops.window_partition_var(h, lv["win"], ws)         # per image zero-padded AFTER the norm, like the reference (:248-251)
         qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
-        n = hw.shape[0]
-        n_pad = _round_up(n, 64)
-        vt = ops._workspace(f"davit_vt_{C}", x.device, C * n_pad * 2)[:C * n_pad * 2].view(torch.bfloat16).view(C, n_pad)
-        ops.transpose_into(qkv[:, 2 * C:], vt, 0)
-        hd = C // heads
-        items = self._window_items(n // (ws * ws), ws * ws, heads)
-        att = ops.attention(qkv[:, :C], qkv[:, C:2 * C], vt, items, heads, heads, hd, float(hd) ** -0.5, False, flops=4.0 * C * n * ws * ws)
+        att = self._window_attention(qkv, C, heads, ws, x.device)
         y = ops.gemm(att, d["proj_w"], d["proj_b"])
         x = ops.window_reverse_add_var(y, x, lv["win"], ws)
         return self._conv_ffn_var(x, lv["pix"], d)

@@ -1008,6 +1008,21 @@ def window_reverse_add(yw: torch.Tensor, shortcut: torch.Tensor, H: int, W: int,
     return y
 
 
+WINDOW_ATTENTION_MAX_TOKENS = 160      # fo1_window_attention_bf16: tokens per window the head-dim-32 kernel is built for
+
+
+def window_attention(qkv: torch.Tensor, C: int, n_heads: int, window_tokens: int, scale: float) -> torch.Tensor:
+    """qkv [n_windows * window_tokens, 3C] (the q/k/v GEMM's rows of window-partitioned tokens) -> softmax(q k^T * scale) v per window and
+    head, [rows, C] (fo1_window_attention_bf16: head dim 32, DaViT's WindowAttention modeling_davit.py:225-282)."""
+    _chk(qkv, "qkv")
+    p, ld, n, _ = _rows(qkv, "qkv")
+    assert C == n_heads * 32 and n % window_tokens == 0 and window_tokens <= WINDOW_ATTENTION_MAX_TOKENS
+    out = torch.empty(n, C, dtype=torch.bfloat16, device=qkv.device)
+    _L.check(_L.load().fo1_window_attention_bf16(p, ld, C, n_heads, window_tokens, n // window_tokens, out.data_ptr(), C, float(scale), _stream()),
+             "fo1_window_attention_bf16")
+    return out
+
+
 def channel_attention(qkv: torch.Tensor, C: int, batch: int = 1) -> torch.Tensor:
     """qkv [batch*N, 3C]: per image, per 32-channel group attention over the image's own N tokens."""
     _chk(qkv, "qkv")
