@@ -1140,6 +1140,7 @@ __device__ __forceinline__ void epilogue32_qkv(const GemmParams& p, f32x16 (&acc
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
+        FO1_GEMM_STAMP(6);        // (timeline: tile staged, every wave past the barrier)
         if (rot_wave) {
 #pragma unroll
             for (int qt = 0; qt < 4; ++qt) {
@@ -1176,6 +1177,7 @@ __device__ __forceinline__ void epilogue32_qkv(const GemmParams& p, f32x16 (&acc
                 }
             }
         }
+        FO1_GEMM_STAMP(7);        // (timeline: rotation done — wave 0; wave 7 holds V and pad columns only)
         if (wn >= 2) {      // the head's V columns: tile columns 160..239 = block columns 32..63 of wave 2, 0..47 of wave 3
             uint16_t* vcol0 = p.vt + (long long)(head * 80 + wn * 64 - 160) * p.vt_ld + p.pos0 + m_base;
             if (wn == 2) store_vt(4, 8, vcol0);
@@ -1695,6 +1697,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_p4_kernel(const GemmParams p) 
     }
     if constexpr (EPI == 6 || EPI == 7) {       // fused q/k/v epilogue (fo1_qkv_proj_rope_bf16): always through the LDS image
         epilogue32_qkv<EPI - 6>(p, acc, smem, wave, m0 + wm * 128, n0 + wn * 64, lane);
+        FO1_GEMM_STAMP(3);
         return;
     } else {
         if constexpr (EPI != 4) {
@@ -2282,6 +2285,9 @@ static int launch_qkv_p4(GemmParams& p, int mode, hipStream_t st) {
     p.kper = p.K / 64 + 1;
     p.part = nullptr;
     p.debug = 0;
+#ifdef FO1_ENABLE_AB
+    if ((g_gemm_debug & 32) && g_gemm_stamp_buf) { p.debug = 32; p.part = (float*)g_gemm_stamp_buf; }      // workgroup timeline (scripts/r06_qkv_timeline.py)
+#endif
     p.coal = 1;
     p.stages = 2;
     const dim3 grid(p.tiles_m * p.tiles_n, 1, 1);
