@@ -12,7 +12,9 @@ for r in csv.DictReader(open(sys.argv[2])):
 
 
 def rocprof_avg(bench_name):
-    pats = {"attn_fwd": r"attn_fwd_kernel<\d+, 4, false>", "attn_fwd32": r"attn_fwd32_kernel<", "rmsnorm": r"rownorm_kernel<0[,>]", "layernorm": r"rownorm_kernel<1[,>]"}
+    pats = {"attn_fwd": r"attn_fwd_kernel<\d+, 4, false>", "attn_fwd32": r"attn_fwd32_kernel<", "rmsnorm": r"rownorm_kernel<0[,>]", "layernorm": r"rownorm_kernel<1[,>]",
+            "dwconv3x3_ln": r"dwconv3x3_ln(_run)?_kernel<", "chattn_gram": r"chattn_gram(_mfma)?_kernel", "chattn_apply": r"chattn_apply(_mfma)?_kernel",
+            "win_attn32": r"win_attn32_kernel<"}
     m = re.match(r"gemm_bt_p(\d)<", bench_name)
     if m:
         sel = [(c, a) for k, (c, a) in stats.items() if f"gemm_bt_p{m.group(1)}_kernel" in k]
