@@ -1112,68 +1112,68 @@ __device__ __forceinline__ void epilogue32_qkv(const GemmParams& p, f32x16 (&acc
             }
         }
     } else {
-        const int wn = wave & 3, head = n_base >> 8;
-        const int tc = wn * 64 + c * 8;                                 // this lane's first column inside the head's tile
-        const bool is_qk = tc < 160;
-        const int dd = tc < 80 ? tc : (tc < 160 ? tc - 80 : 0);         // column inside the q / k head (0 for the lanes that do not rotate)
-        const bool first = dd < 40;
-        const int ptc = is_qk ? (first ? tc + 40 : tc - 40) : tc;       // the rotate-half partner's tile column
-        const char* preg = smem + ((wave & 4) | (ptc >> 6)) * 16384;
-        const int pc = (ptc & 63) >> 3;
-        const int dm = first ? dd : dd - 40;
-        const float* cosf_ = reinterpret_cast<const float*>(p.rope_cos) + dm;
-        const float* sinf_ = reinterpret_cast<const float*>(p.rope_sin) + dm;
-        uint16_t* dst = p.C + n_base - wn * 64 + tc;
-        // fp32 tables: 64 B per lane and row — a rolling window of two 4-row quarters (128 registers), the first two requested before the barrier
-        float4 tb[2][4][4];
-        auto tload = [&](int qt, float4 (&t)[4][4]) {
+        const int wn = wave & 3, wm = wave >> 2, head = n_base >> 8;
+        // Rotation work items (round 6): (row r of the tile's 256, 8-angle piece j of the 40 rotary angles).  A lane rotates the q pair (columns 8 j,
+        // 40 + 8 j) AND the k pair (80 + 8 j, 120 + 8 j) of its row with ONE 64-byte piece of the fp32 tables: 80 KB of table reads per tile where the
+        // column-wise split (a lane = 8 columns of one row, partner columns re-read, every wave its own copy of the tables) read 384 KB — the
+        // rotation was bound by those loads (4.6 us of a 9.4 us epilogue, profiles/r06_qkv_epilogue_timeline.json).  1 280 items over the
+        // workgroup's 8 waves; same fmaf per element as rope.hip's rope_vit_body.  The tables are requested before the barrier.
+        // The four waves that also store V^T afterwards (wn >= 2) take one item per lane, the other four take four: 1 024 + 256 items.
+        constexpr int NIT = 4;
+        const bool vwave = wn >= 2;
+        const int nit = vwave ? 1 : NIT;                                 // wave-uniform
+        const int tid = vwave ? 1024 + (wm * 2 + wn - 2) * 64 + lane : (wm * 2 + wn) * 64 + lane;      // first item; the next ones 256 further
+        const int m0 = m_base - wm * 128;
+        uint16_t* dstC = p.C + (n_base - wn * 64);                       // tile column 0 of this head
+        float4 tb[NIT][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m_base + (qt * 4 + i) * 8 + lrow;
-                const long long mr = (long long)(m < p.M ? m : p.M - 1) * 40;
-                t[i][0] = *reinterpret_cast<const float4*>(cosf_ + mr); t[i][1] = *reinterpret_cast<const float4*>(cosf_ + mr + 4);
-                t[i][2] = *reinterpret_cast<const float4*>(sinf_ + mr); t[i][3] = *reinterpret_cast<const float4*>(sinf_ + mr + 4);
-            }
-        };
-        const bool rot_wave = wn < 3;                                  // wave 3 holds V and pad columns only
-        if (rot_wave) { tload(0, tb[0]); tload(1, tb[1]); }
+        for (int it = 0; it < NIT; ++it) {
+            if (it >= nit) break;
+            const int item = it * 256 + tid;
+            const int r = item / 5, j = item - r * 5;
+            const int m = m0 + r;
+            const long long mr = (long long)(m < p.M ? m : p.M - 1) * 40 + j * 8;
+            const float* cp = reinterpret_cast<const float*>(p.rope_cos) + mr;
+            const float* sp = reinterpret_cast<const float*>(p.rope_sin) + mr;
+            tb[it][0] = *reinterpret_cast<const float4*>(cp); tb[it][1] = *reinterpret_cast<const float4*>(cp + 4);
+            tb[it][2] = *reinterpret_cast<const float4*>(sp); tb[it][3] = *reinterpret_cast<const float4*>(sp + 4);
+        }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         __builtin_amdgcn_sched_barrier(0);
         FO1_GEMM_STAMP(6);        // (timeline: tile staged, every wave past the barrier)
-        if (rot_wave) {
 #pragma unroll
-            for (int qt = 0; qt < 4; ++qt) {
-                float4 (&t)[4][4] = tb[qt & 1];
-                uint4 xv[4], yv[4];
+        for (int it = 0; it < NIT; ++it) {
+            if (it >= nit) break;
+            {
+                const int item = it * 256 + tid;
+                const int r = item / 5, j = item - r * 5;
+                const int lr = r & 127;
+                const char* rows = smem + (r >> 7) * 4 * 16384 + lr * 128;
+                auto piece = [&](int tcol) { return *reinterpret_cast<const uint4*>(rows + (tcol >> 6) * 16384 + slot((tcol & 63) >> 3, lr)); };
+                const int tcol[4] = {8 * j, 40 + 8 * j, 80 + 8 * j, 120 + 8 * j};
+                const uint4 q1 = piece(tcol[0]), q2 = piece(tcol[1]), k1 = piece(tcol[2]), k2 = piece(tcol[3]);
+                const float cs[8] = {tb[it][0].x, tb[it][0].y, tb[it][0].z, tb[it][0].w, tb[it][1].x, tb[it][1].y, tb[it][1].z, tb[it][1].w};
+                const float sn[8] = {tb[it][2].x, tb[it][2].y, tb[it][2].z, tb[it][2].w, tb[it][3].x, tb[it][3].y, tb[it][3].z, tb[it][3].w};
+                auto rotate = [&](const uint4& a, const uint4& b, uint4& oa, uint4& ob) {      // (a, b) = (first half, second half) of a head's rotary pair
+                    float x[8], y[8], u[8], v[8];
+                    unpack8(a, x); unpack8(b, y);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = (qt * 4 + i) * 8 + lrow;
-                    xv[i] = *reinterpret_cast<const uint4*>(region + r * 128 + slot(c, r));
-                    yv[i] = *reinterpret_cast<const uint4*>(preg + r * 128 + slot(pc, r));
-                }
-                uint4 ov[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float x[8], y[8], o[8];
-                    unpack8(xv[i], x); unpack8(yv[i], y);
-                    const float cs[8] = {t[i][0].x, t[i][0].y, t[i][0].z, t[i][0].w, t[i][1].x, t[i][1].y, t[i][1].z, t[i][1].w};
-                    const float sn[8] = {t[i][2].x, t[i][2].y, t[i][2].z, t[i][2].w, t[i][3].x, t[i][3].y, t[i][3].z, t[i][3].w};
-                    if (first) {        // (the explicit contraction of rope.hip's rope_vit_body)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(x[j], cs[j], -(y[j] * sn[j]));
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = __builtin_fmaf(x[j], cs[j], y[j] * sn[j]);
+                    for (int e = 0; e < 8; ++e) {
+                        u[e] = __builtin_fmaf(x[e], cs[e], -(y[e] * sn[e]));       // first half:  x cos - y sin
+                        v[e] = __builtin_fmaf(y[e], cs[e], x[e] * sn[e]);          // second half: y cos + x sin
                     }
-                    ov[i] = uint4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                if (qt + 2 < 4) tload(qt + 2, tb[qt & 1]);             // the window moves on: its registers are free again
+                    oa = uint4{pack_bf16x2(u[0], u[1]), pack_bf16x2(u[2], u[3]), pack_bf16x2(u[4], u[5]), pack_bf16x2(u[6], u[7])};
+                    ob = uint4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
+                };
+                uint4 o[4];
+                rotate(q1, q2, o[0], o[1]);
+                rotate(k1, k2, o[2], o[3]);
+                const int m = m0 + r;
+                if (m < p.M) {
+                    uint16_t* drow = dstC + (long long)m * p.ldc;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int m = m_base + (qt * 4 + i) * 8 + lrow;
-                    if (m < p.M && is_qk) *reinterpret_cast<uint4*>(dst + (long long)m * p.ldc) = ov[i];
+                    for (int e = 0; e < 4; ++e) *reinterpret_cast<uint4*>(drow + tcol[e]) = o[e];
                 }
             }
         }
