@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* libfo1hip*.so are built with -fvisibility=hidden: exactly the declarations of this header are exported */
 #endif
 
-#define FO1_ABI_VERSION 9   /* 9: fo1_window_attention_bf16 (DaViT window attention on the q/k/v rows: no V^T copy); 8: fo1_attention_decode_batch_partials_bf16 + fo1_gemv_attn_combine_bf16 (decode step at <= 2 sequences: the o-projection sums the split-KV partials in its prologue, no combine launch); 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 9   /* 9: fo1_window_attention_bf16 (DaViT window attention on the q/k/v rows: no V^T copy), fo1_window_attention_map_bf16 / _var (the same on un-partitioned pixel rows: no window partition / reverse); 8: fo1_attention_decode_batch_partials_bf16 + fo1_gemv_attn_combine_bf16 (decode step at <= 2 sequences: the o-projection sums the split-KV partials in its prologue, no combine launch); 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -363,6 +363,16 @@ int fo1_window_reverse_add_bf16(const void* yw, const void* shortcut, void* y, i
  * ld >= 3 C, rows 16-byte aligned (ld % 8, ldo % 8), the output at most 2 GiB (32-bit store offsets). */
 int fo1_window_attention_bf16(const void* qkv, long long ld, int C, int n_heads, int window_tokens, int n_windows, void* out, long long ldo,
                               float scale, void* stream);
+/* The same attention WITHOUT window partition / reverse (round 6): qkv holds the q/k/v rows of the images' PIXELS in raster order ([batch * H * W, ld],
+ * the projection of the LayerNorm output itself), token (iy, ix) of window (wy, wx) is pixel (wy * window + iy, wx * window + ix); tokens outside the
+ * image are the reference's zero padding after the norm (modeling_davit.py:248-251) and read `pad_row` = the projection of a zero row = the layer's
+ * bf16 q/k/v bias [3C].  out [batch * H * W, ldo]: the pixels' rows (the proj GEMM then adds the residual in its own epilogue: no window_reverse).
+ * window == 12, head dim 32.  _var: images of different sizes, segs = the fo1_img_seg table of fo1_window_partition_var_bf16 (in_row0, H, W, -, windows
+ * down / across), max_windows = the most windows any image has. */
+int fo1_window_attention_map_bf16(const void* qkv, long long ld, int C, int n_heads, int window, int H, int W, int batch, const void* pad_row, void* out,
+                                  long long ldo, float scale, void* stream);
+int fo1_window_attention_map_var_bf16(const void* qkv, long long ld, int C, int n_heads, int window, const void* segs, int n_img, int max_windows,
+                                      long long total_pixels, const void* pad_row, void* out, long long ldo, float scale, void* stream);
 size_t fo1_channel_attention_workspace_bytes(int N, int C, int batch);
 int fo1_channel_attention_bf16(const void* qkv, int ld, int N, int C, void* out, int ldo, int batch, void* workspace,
                                size_t workspace_bytes, void* stream);

@@ -134,6 +134,55 @@ def test_window_attention_on_the_qkv_rows_against_a_torch_reference_and_the_gene
         assert float(d.max()) <= 0.02 * float(old.float().abs().max()) + 1e-3, f"{n_win} x {wtok} x {heads}: vs the general kernel {float(d.max()):.4g}"
 
 
+def test_window_attention_on_unpartitioned_rows_equals_partition_attention_reverse_bitwise():
+    """Round 6: fo1_window_attention_map_bf16 finds a window's tokens among the PIXEL rows (no window_partition, no padded rows in the GEMMs, no
+    window_reverse) and reads the q/k/v bias row for the reference's zero-padded tokens.  The whole spatial-attention sub-block — q/k/v GEMM,
+    attention, proj GEMM + residual — must equal window_partition -> GEMM -> fo1_window_attention_bf16 -> GEMM -> window_reverse_add bit for bit:
+    sizes that are not multiples of the window, several images, and the ragged entry against per-image calls."""
+    from vlm_fo1_amd import lib as _L, ops
+    torch.manual_seed(36)
+    ws = 12
+    with _L.use_ab():
+        _L.load().fo1_gemm_set_variant(2, 1); _L.load().fo1_gemm_set_splitk(1)     # one tile shape for every row count (the parity tests' determinism pin)
+        try:
+            for (B, H, W, heads) in [(2, 40, 30, 8), (1, 20, 15, 16), (3, 13, 25, 4), (1, 12, 12, 8), (2, 5, 7, 4)]:
+                C = heads * 32
+                n = B * H * W
+                h = torch.randn(n, C).to(BF).cuda()
+                x = torch.randn(n, C).to(BF).cuda()
+                wq, bq = (torch.randn(3 * C, C) * 0.08).to(BF).cuda(), (torch.randn(3 * C) * 0.3).to(BF).cuda()
+                wp, bp = (torch.randn(C, C) * 0.08).to(BF).cuda(), (torch.randn(C) * 0.1).to(BF).cuda()
+                # partition form
+                hw = ops.window_partition(h, H, W, ws, batch=B)
+                att_w = ops.window_attention(ops.gemm(hw, wq, bq), C, heads, ws * ws, 32 ** -0.5)
+                ref = ops.window_reverse_add(ops.gemm(att_w, wp, bp), x, H, W, ws, batch=B)
+                # map form
+                qkv = ops.gemm(h, wq, bq)
+                att = ops.window_attention_map(qkv, C, heads, ws, H, W, B, bq, 32 ** -0.5)
+                got = ops.gemm(att, wp, bp, residual=x)
+                assert torch.equal(got, ref), f"{B} x {H}x{W} x {heads} heads: {int((got != ref).sum())} elements differ"
+            # ragged: three images of different sizes in one call == the per-image calls
+            heads, C = 8, 256
+            sizes = [(40, 30), (13, 25), (7, 5)]
+            qs = [(torch.randn(a * b, 3 * C) * 0.7).to(BF).cuda() for a, b in sizes]
+            bq = (torch.randn(3 * C) * 0.3).to(BF).cuda()
+            rows, r0, w0 = [], 0, 0
+            for a, b in sizes:
+                nwy, nwx = -(-a // ws), -(-b // ws)
+                rows.append((r0, a, b, w0, nwy, nwx))
+                r0 += a * b
+                w0 += nwy * nwx * ws * ws
+            sg = ops.ImgSegs(rows, "cuda", max(a * b for a, b in sizes), r0, max(r[4] * r[5] * ws * ws for r in rows), w0)
+            got = ops.window_attention_map_var(torch.cat(qs, 0), C, heads, ws, sg, bq, 32 ** -0.5)
+            r = 0
+            for (a, b), q in zip(sizes, qs):
+                one = ops.window_attention_map(q, C, heads, ws, a, b, 1, bq, 32 ** -0.5)
+                assert torch.equal(got[r:r + a * b], one), f"ragged image {a}x{b}"
+                r += a * b
+        finally:
+            _L.load().fo1_gemm_set_variant(0, 0); _L.load().fo1_gemm_set_splitk(0)
+
+
 def test_pixel_shuffle_maxpool_nchw_gather():
     from vlm_fo1_amd import ops
     torch.manual_seed(4)

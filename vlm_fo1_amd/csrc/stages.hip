@@ -440,17 +440,25 @@ int davit_run(Arena& A, const fo1_davit_weights_t* w, const fo1_davit_plan_t* pl
                 void* att = A.take(bf16_rows(nw, C));
                 void* y = A.take(bf16_rows(nw, C));
                 FO1_RUN(fo1_dwconv3x3_ln_bf16(XA, d.conv1_w, d.conv1_b, XB, d.an_w, d.an_b, 1e-5f, h, H, W, C, B, stream));
-                FO1_RUN(fo1_window_partition_bf16(h, hw, H, W, C, ws, B, stream));   // zero-padded AFTER the norm (:248-251)
-                FO1_RUN(fo1_gemm_bf16_ws(hw, C, d.qkv_w, C, d.qkv_b, nullptr, 0, qkv, 3 * C, nw, 3 * C, C, 0, 0, gws, kGemmScratch, stream));
-                if (hd == 32 && ws * ws <= 160) {      // every DaViT stage: the window kernel on the q/k/v rows themselves (no V^T copy)
-                    FO1_RUN(fo1_window_attention_bf16(qkv, 3 * C, C, heads, ws * ws, nw / (ws * ws), att, C, (float)pow((double)hd, -0.5), stream));
+                if (hd == 32 && ws == 12 && d.qkv_b) {
+                    // davit.py's rule: no partition / padded GEMM rows / reverse — the attention finds the windows' tokens among the pixel rows, padded
+                    // tokens read the q/k/v bias row, the residual rides in the proj GEMM's epilogue (qkv / att: the first n rows of the buffers)
+                    FO1_RUN(fo1_gemm_bf16_ws(h, C, d.qkv_w, C, d.qkv_b, nullptr, 0, qkv, 3 * C, n, 3 * C, C, 0, 0, gws, kGemmScratch, stream));
+                    FO1_RUN(fo1_window_attention_map_bf16(qkv, 3 * C, C, heads, ws, H, W, B, d.qkv_b, att, C, (float)pow((double)hd, -0.5), stream));
+                    FO1_RUN(fo1_gemm_bf16_ws(att, C, d.proj_w, C, d.proj_b, XB, C, XA, C, n, C, C, 0, 0, gws, kGemmScratch, stream));
                 } else {
-                    FO1_RUN(fo1_transpose_bf16((const uint16_t*)qkv + 2 * C, 3 * C, vt, nw_pad, 0, nullptr, nw, C, stream));
-                    FO1_RUN(fo1_attention_bf16(qkv, 3 * C, hd, (const uint16_t*)qkv + C, 3 * C, hd, vt, nw_pad, att, C, hd, pl->items[i], pl->n_items[i],
-                                               pl->q_block[i], heads, heads, hd, (float)pow((double)hd, -0.5), 0, nullptr, 4.0 * C * nw * ws * ws, stream));
+                    FO1_RUN(fo1_window_partition_bf16(h, hw, H, W, C, ws, B, stream));   // zero-padded AFTER the norm (:248-251)
+                    FO1_RUN(fo1_gemm_bf16_ws(hw, C, d.qkv_w, C, d.qkv_b, nullptr, 0, qkv, 3 * C, nw, 3 * C, C, 0, 0, gws, kGemmScratch, stream));
+                    if (hd == 32 && ws * ws <= 160) {      // every DaViT stage: the window kernel on the q/k/v rows themselves (no V^T copy)
+                        FO1_RUN(fo1_window_attention_bf16(qkv, 3 * C, C, heads, ws * ws, nw / (ws * ws), att, C, (float)pow((double)hd, -0.5), stream));
+                    } else {
+                        FO1_RUN(fo1_transpose_bf16((const uint16_t*)qkv + 2 * C, 3 * C, vt, nw_pad, 0, nullptr, nw, C, stream));
+                        FO1_RUN(fo1_attention_bf16(qkv, 3 * C, hd, (const uint16_t*)qkv + C, 3 * C, hd, vt, nw_pad, att, C, hd, pl->items[i], pl->n_items[i],
+                                                   pl->q_block[i], heads, heads, hd, (float)pow((double)hd, -0.5), 0, nullptr, 4.0 * C * nw * ws * ws, stream));
+                    }
+                    FO1_RUN(fo1_gemm_bf16_ws(att, C, d.proj_w, C, d.proj_b, nullptr, 0, y, C, nw, C, C, 0, 0, gws, kGemmScratch, stream));
+                    FO1_RUN(fo1_window_reverse_add_bf16(y, XB, XA, H, W, C, ws, B, stream));
                 }
-                FO1_RUN(fo1_gemm_bf16_ws(att, C, d.proj_w, C, d.proj_b, nullptr, 0, y, C, nw, C, C, 0, 0, gws, kGemmScratch, stream));
-                FO1_RUN(fo1_window_reverse_add_bf16(y, XB, XA, H, W, C, ws, B, stream));
                 A.release(m);
                 const int rc = davit_conv_ffn(A, d, XA, XB, XA, n, H, W, C, B, gws, stream);
                 if (rc != FO1_OK) return rc;

@@ -13,6 +13,8 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -79,6 +81,13 @@ class DaViT:
             self._items[key] = ops.make_items(segs, self.dev, block=ops.pick_q_block(segs, heads))
         return self._items[key]
 
+    @staticmethod
+    def _window_map(C, heads, ws, d) -> bool:
+        """The un-partitioned form of the spatial block (ops.window_attention_map): head dim 32, 12 x 12 windows, a bf16 q/k/v bias to stand for the
+        padded tokens.  FO1_DAVIT_WINDOW_MAP=0 keeps window_partition -> GEMM -> attention -> GEMM -> window_reverse_add (A/B, tests)."""
+        return (C // heads == 32 and ws == ops.WINDOW_ATTENTION_MAP_WINDOW and d.get("qkv_b") is not None and d["qkv_b"].dtype == torch.bfloat16
+                and os.environ.get("FO1_DAVIT_WINDOW_MAP", "1") != "0")
+
     def _window_attention(self, qkv, C, heads, ws, device):
         """softmax(q k^T / sqrt(hd)) v over the windows of ws * ws consecutive rows of the q/k/v GEMM output (modeling_davit.py:225-282).
         Head dim 32 (every DaViT stage) and windows of <= 160 tokens: one launch on the [rows, 3C] map itself; otherwise the general
@@ -103,6 +112,13 @@ class DaViT:
     def _spatial(self, x, H, W, C, heads, d, B=1):
         ws = self.cfg["window"]
         x, h = ops.dwconv3x3_res_ln(x, d["conv1_w"], d["conv1_b"], H, W, d["an_w"], d["an_b"], 1e-5, batch=B)
+        if self._window_map(C, heads, ws, d):
+            # no partition, no padded rows in the GEMMs, no reverse: the attention finds a window's tokens among the pixel rows by arithmetic, the
+            # tokens of the reference's zero padding (:248-251) are the q/k/v bias row, and the residual rides in the proj GEMM's epilogue
+            qkv = ops.gemm(h, d["qkv_w"], d["qkv_b"])
+            att = ops.window_attention_map(qkv, C, heads, ws, H, W, B, d["qkv_b"], float(C // heads) ** -0.5)
+            x = ops.gemm(att, d["proj_w"], d["proj_b"], residual=x)
+            return self._conv_ffn(x, H, W, d, B)
         hw = ops.window_partition(h, H, W, ws, batch=B)   # zero-padded AFTER the norm, like the reference (:248-251)
         qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
         att = self._window_attention(qkv, C, heads, ws, x.device)
@@ -136,6 +152,11 @@ class DaViT:
     def _spatial_var(self, x, lv, C, heads, d):
         ws = self.cfg["window"]
         x, h = ops.dwconv3x3_res_ln_var(x, d["conv1_w"], d["conv1_b"], lv["pix"], d["an_w"], d["an_b"], 1e-5)
+        if self._window_map(C, heads, ws, d):
+            qkv = ops.gemm(h, d["qkv_w"], d["qkv_b"])
+            att = ops.window_attention_map_var(qkv, C, heads, ws, lv["win"], d["qkv_b"], float(C // heads) ** -0.5)
+            x = ops.gemm(att, d["proj_w"], d["proj_b"], residual=x)
+            return self._conv_ffn_var(x, lv["pix"], d)
         hw = ops.window_partition_var(h, lv["win"], ws)         # per image zero-padded AFTER the norm, like the reference (:248-251)
         qkv = ops.gemm(hw, d["qkv_w"], d["qkv_b"])
         att = self._window_attention(qkv, C, heads, ws, x.device)

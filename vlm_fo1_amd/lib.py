@@ -233,6 +233,9 @@ SIGNATURES = {
     "fo1_im2col_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_window_partition_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_window_reverse_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_window_attention_map_bf16": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
+    "fo1_window_attention_map_var_bf16": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p, c_longlong,
+                                                 c_float, c_void_p]),
     "fo1_window_attention_bf16": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_void_p, c_longlong, c_float, c_void_p]),
     "fo1_channel_attention_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fo1_channel_attention_bf16": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),

@@ -1023,6 +1023,33 @@ def window_attention(qkv: torch.Tensor, C: int, n_heads: int, window_tokens: int
     return out
 
 
+WINDOW_ATTENTION_MAP_WINDOW = 12       # fo1_window_attention_map_bf16: the window side its token -> pixel arithmetic is built for
+
+
+def window_attention_map(qkv: torch.Tensor, C: int, n_heads: int, window: int, H: int, W: int, batch: int, pad_row: torch.Tensor, scale: float) -> torch.Tensor:
+    """Window attention on UN-partitioned rows: qkv [batch * H * W, 3C] = the q/k/v projection of the images' pixels in raster order; the windows'
+    tokens are found by arithmetic, tokens outside the image read `pad_row` (the layer's bf16 q/k/v bias = the projection of the reference's zero
+    padding, modeling_davit.py:248-251).  -> [batch * H * W, C] in pixel order (fo1_window_attention_map_bf16)."""
+    _chk(qkv, "qkv"); _chk(pad_row, "pad_row")
+    p, ld, n, _ = _rows(qkv, "qkv")
+    assert C == n_heads * 32 and n == batch * H * W and window == WINDOW_ATTENTION_MAP_WINDOW and pad_row.numel() == 3 * C and pad_row.is_contiguous()
+    out = torch.empty(n, C, dtype=torch.bfloat16, device=qkv.device)
+    _L.check(_L.load().fo1_window_attention_map_bf16(p, ld, C, n_heads, window, H, W, batch, pad_row.data_ptr(), out.data_ptr(), C, float(scale), _stream()),
+             "fo1_window_attention_map_bf16")
+    return out
+
+
+def window_attention_map_var(qkv: torch.Tensor, C: int, n_heads: int, window: int, sg: "ImgSegs", pad_row: torch.Tensor, scale: float) -> torch.Tensor:
+    """window_attention_map for images of different sizes (sg = the window-partition geometry table: pixels row0, H, W, -, windows down / across)."""
+    _chk(qkv, "qkv"); _chk(pad_row, "pad_row")
+    p, ld, n, _ = _rows(qkv, "qkv")
+    assert C == n_heads * 32 and n == sg.total_in and window == WINDOW_ATTENTION_MAP_WINDOW and pad_row.numel() == 3 * C and pad_row.is_contiguous()
+    out = torch.empty(n, C, dtype=torch.bfloat16, device=qkv.device)
+    _L.check(_L.load().fo1_window_attention_map_var_bf16(p, ld, C, n_heads, window, sg.ptr, sg.n, sg.max_out // (window * window), sg.total_in,
+                                                         pad_row.data_ptr(), out.data_ptr(), C, float(scale), _stream()), "fo1_window_attention_map_var_bf16")
+    return out
+
+
 def channel_attention(qkv: torch.Tensor, C: int, batch: int = 1) -> torch.Tensor:
     """qkv [batch*N, 3C]: per image, per 32-channel group attention over the image's own N tokens."""
     _chk(qkv, "qkv")
