@@ -228,7 +228,7 @@ class DaViT:
                 # pre-norm ConvEmbed (modeling_davit.py:102-148) as an implicit GEMM: the LayerNorm writes the zero-padded map, the 256 x 256 GEMM
                 # gathers its 9 taps from it — no [M, 9 Cin] column matrix (same bits as layernorm + im2col + gemm)
                 pl = ops.conv3x3_plan(((H, W),) * B, s, x.shape[1], self.dev)
-                xp = ops.layernorm_rows(x, cv["nw"], cv["nb"], 1e-5, torch.zeros(pl.pad_rows, x.shape[1], dtype=torch.bfloat16, device=self.dev), pl.rowmap)
+                xp = ops.layernorm_rows(x, cv["nw"], cv["nb"], 1e-5, ops.conv3x3_padded(pl, self.dev), pl.rowmap)
                 x = ops.conv3x3_gemm(xp, pl, cv["w"], cv["b"])
                 H, W = Ho, Wo
             else:

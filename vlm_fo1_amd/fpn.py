@@ -56,7 +56,7 @@ class SimpleFPN:
             # the 3x3 output convolution (simple_fpn.py:141-176) as an implicit GEMM: the channel LayerNorm writes the zero-padded map, the GEMM
             # gathers its taps from it (no im2col matrix: 2.2 GB per launch at the finest level); same bits as layernorm + im2col + gemm
             pl = ops.conv3x3_plan(((H, W),) * B, 1, C, y.device)
-            yp = ops.layernorm_rows(y, h["n1"][0], h["n1"][1], 1e-6, torch.zeros(pl.pad_rows, C, dtype=torch.bfloat16, device=y.device), pl.rowmap)
+            yp = ops.layernorm_rows(y, h["n1"][0], h["n1"][1], 1e-6, ops.conv3x3_padded(pl, y.device), pl.rowmap)
             y = ops.conv3x3_gemm(yp, pl, h["w3"])
         else:
             y = ops.layernorm(y, h["n1"][0], h["n1"][1], 1e-6)

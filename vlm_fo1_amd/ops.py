@@ -6,6 +6,7 @@ PyTorch fallback; a missing library or a CPU tensor raises."""
 from __future__ import annotations
 
 import math
+import itertools
 import os
 import threading
 from typing import Optional, Sequence
@@ -149,6 +150,27 @@ def _workspace(kind: str, device, nbytes: int) -> torch.Tensor:
         ws = torch.zeros(size, dtype=torch.uint8, device=device)   # zeroed once: decode attention keeps arrival counters in its tail
         _ws_pool[key] = ws
     return ws
+
+
+_zero_framed_kinds: dict = {}
+_zero_framed_lock = threading.Lock()
+ZERO_FRAMED_MAX = 48       # distinct persistent zero-framed buffers per process (each lives as long as its owner: a captured pass holds its raw pointer)
+
+
+def zero_framed(key: tuple, rows: int, cols: int, device) -> torch.Tensor:
+    """[rows, cols] bf16 scratch whose elements the caller NEVER writes are zero — the frame of a zero-padded convolution input, the padding
+    columns of a V^T map.  `key` must determine which elements get written (a plan's serial number, a shape): the buffer is then zeroed once,
+    at its first use, instead of by a fill launch per pass (8 fills = 0.25 ms of the 25-image pass).  One buffer per (key, engine replica /
+    stream) from the scratch pool; past ZERO_FRAMED_MAX distinct keys (a server seeing ever new geometries) a fresh torch.zeros, as before."""
+    if os.environ.get("FO1_ZERO_FRAMED", "1") != "0":
+        with _zero_framed_lock:
+            kind = _zero_framed_kinds.get(key)
+            if kind is None and len(_zero_framed_kinds) < ZERO_FRAMED_MAX:
+                kind = _zero_framed_kinds[key] = f"zero_framed_{len(_zero_framed_kinds)}"
+        if kind is not None:
+            nbytes = rows * cols * 2
+            return _workspace(kind, device, nbytes)[:nbytes].view(torch.bfloat16).view(rows, cols)
+    return torch.zeros(rows, cols, dtype=torch.bfloat16, device=device)
 
 
 def release_workspaces(owner) -> int:
@@ -347,6 +369,9 @@ def layernorm_rows(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ep
     return out
 
 
+_conv_plan_serial = itertools.count()
+
+
 class Conv3x3Plan:
     """Index tables of a 3x3 / pad 1 convolution run as an implicit GEMM (fo1_conv3x3_gemm_bf16) over images packed row-wise: the zero-padded
     layout (one pixel per side, common row pitch Wp = widest image + 2), `rowmap` int32 [sum H W] = padded row of every input pixel (where
@@ -369,9 +394,19 @@ class Conv3x3Plan:
         ar = np.concatenate(a_rows)
         assert pb * cin * 2 < 2 ** 32, "padded map exceeds the 32-bit byte offsets of the implicit-GEMM convolution"
         self.Wp, self.cin, self.pad_rows, self.out_hw = Wp, cin, pb, out_hw
+        self.serial = next(_conv_plan_serial)      # (identifies the padded map's written rows: ops.zero_framed)
+        self.uniform = len(set(tuple(t) for t in sizes)) == 1
         self.M_in, self.M_out = sum(h * w for h, w in sizes), int(ar.shape[0])
         self.rowmap = torch.from_numpy(np.concatenate(rowmap).astype(np.int32)).to(device)
         self.a_rows = torch.from_numpy(ar.astype(np.uint32).view(np.int32)).to(device)      # (uint32 bit patterns in an int32 tensor)
+
+
+def conv3x3_padded(pl: "Conv3x3Plan", device) -> torch.Tensor:
+    """The zero-framed map layernorm_rows writes for plan `pl`: persistent for same-size batches (the frame stays zero from pass to pass, the
+    interior is rewritten by every pass), a fresh zero fill for ragged packs (their geometry rarely repeats)."""
+    if pl.uniform:
+        return zero_framed(("conv3x3", pl.serial), pl.pad_rows, pl.cin, device)
+    return torch.zeros(pl.pad_rows, pl.cin, dtype=torch.bfloat16, device=device)
 
 
 _conv_plans: dict = {}

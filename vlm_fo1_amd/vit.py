@@ -220,10 +220,10 @@ class QwenViT:
             return stage_abi.vit_stage(self).forward(pixel_values, g, capture)
         pix = pixel_values.to(torch.bfloat16)
         # window re-order folded into the patch-embed input gather; pad K 1176 -> 1216 (zeros)
-        xin = torch.zeros(S, self.k_in_p, dtype=torch.bfloat16, device=self.dev)
+        xin = ops.zero_framed(("vit_xin", S, self.k_in_p, self.k_in), S, self.k_in_p, self.dev)      # (the gather below writes columns [0, k_in) only)
         ops.gather_rows_into(g.plan_in, self.k_in, pix, out=xin)
         x = ops.gemm(xin, self.patch_w)
-        vt = torch.zeros(d, g.Sp, dtype=torch.bfloat16, device=self.dev)  # V^T scratch, reused by every block
+        vt = ops.zero_framed(("vit_vt", d, g.Sp, S), d, g.Sp, self.dev)  # V^T scratch, reused by every block; columns [S, Sp) are never written
         scale = 1.0 / math.sqrt(hd)
         if g.cu_window is not None:
             win_seg, full_seg = list(zip(g.cu_window[:-1], g.cu_window[1:])), [(0, S)]
