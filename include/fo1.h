@@ -26,7 +26,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* libfo1hip*.so are built with -fvisibility=hidden: exactly the declarations of this header are exported */
 #endif
 
-#define FO1_ABI_VERSION 9   /* 9: fo1_window_attention_bf16 (DaViT window attention on the q/k/v rows: no V^T copy), fo1_window_attention_map_bf16 / _var (the same on un-partitioned pixel rows: no window partition / reverse); 8: fo1_attention_decode_batch_partials_bf16 + fo1_gemv_attn_combine_bf16 (decode step at <= 2 sequences: the o-projection sums the split-KV partials in its prologue, no combine launch); 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
+#define FO1_ABI_VERSION 9   /* 9: fo1_window_attention_bf16 (DaViT window attention on the q/k/v rows: no V^T copy), fo1_window_attention_map_bf16 / _var (the same on un-partitioned pixel rows: no window partition / reverse), fo1_attention_windows_bf16 (single-tile work lists in a software pipeline; fo1_vit_plan_t.q_block_win 0 selects it); 8: fo1_attention_decode_batch_partials_bf16 + fo1_gemv_attn_combine_bf16 (decode step at <= 2 sequences: the o-projection sums the split-KV partials in its prologue, no combine launch); 7: fo1_vit_block_t gained wqkv_hm / bqkv_hm (optional head-major q/k/v copy: fo1_vit_forward then takes the fused q/k/v epilogue); 6: attention q_block 128 / 256 (32x32-MFMA prefill kernel); fo1_qkv_proj_rope_bf16 (q/k/v projection with RoPE / K append / V^T in the GEMM epilogue); fo1_gemm_bf16_wtiled, fo1_splitk_swiglu_bf16 (measured no-gain forms), fo1_mfma_clock_probe, fo1_gemm_profile_shapes (instruments) moved to fo1_ab.h; 5: split-K planes consumed by fused kernels in the decode pool (fo1_gemm_bf16_partials, fo1_splitk_residual_rmsnorm_bf16, fo1_pool_qkv_post_partials_bf16, fo1_splitk_swiglu_bf16), fo1_gemm_bf16_wtiled, fo1_mfma_clock_probe; 4: decode pool (fo1_pool_qkv_post_bf16; fo1_decode_argmax_accept up to 256 rows): continuous batching of 33..128 sequences; 3: fo1_hfre_opts_t grew out_bf16 / out_bf16_ld; fo1_img_seg + the *_var spatial entry points */
 #define FO1_OK 0
 #define FO1_ERR_ARG (-1)       /* bad argument / unsupported shape */
 #define FO1_ERR_WORKSPACE (-2) /* workspace too small */
@@ -310,6 +310,15 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
                        const int32_t* items, int n_items, int q_block, int n_q_heads, int n_kv_heads,
                        int head_dim, float scale, int causal, const int32_t* q_row_base, double flops_hint,
                        void* stream);
+/* fo1_attention_bf16 for work lists of SINGLE-TILE items (round 6; the ViT's 112-pixel windows, modeling_qwen2_5_vl.py:172-209): every item has at
+ * most 64 keys, its queries inside its key range, no causal mask.  A workgroup walks 4 consecutive items of the list for its head and requests
+ * item i + 1's K / V^T tile and queries while item i is computed (fo1_attention_bf16 runs such an item as one dependent chain with nothing to
+ * overlap).  Bit-identical to fo1_attention_bf16 (q_block 64) on the same list.  head_dim 80; o_rows = rows of O (32-bit store offsets: the
+ * output at most 2 GiB). */
+int fo1_attention_windows_bf16(const void* Q, long long q_tok_stride, long long q_head_stride, const void* K, long long k_tok_stride,
+                                long long k_head_stride, const void* VT, long long vt_row_stride, void* O, long long o_tok_stride, long long o_head_stride,
+                                long long o_rows, const int32_t* items, int n_items, int n_q_heads, int n_kv_heads, int head_dim, float scale,
+                                double flops_hint, void* stream);
 /* fo1_attention_bf16 with a second key range per item: prefix_ranges int32 [n_items][2] = [start, end) (empty when start >= end), attended
  * in full by every query of the item before its own (causal) range.  Several prompts over ONE image share the rows of their common
  * prefix (system text + image tokens): the prefix runs through a layer once, each prompt's remaining rows attend [prefix | own rows].
@@ -513,7 +522,7 @@ typedef struct fo1_vit_plan {    /* index plan of the packed images (host mirror
     const int32_t* plan_raster;                     /* [S][2]   raster row -> window-order row                            */
     const int32_t* plan_tokens;                     /* [S/4][2] raster-merged token -> window-order merge unit            */
     const float* cos; const float* sin;             /* [S][head_dim/2] 2-D rope angles in window order                    */
-    const int32_t* items_win; int32_t n_items_win, q_block_win;       /* attention work items (fo1_attention_bf16)       */
+    const int32_t* items_win; int32_t n_items_win, q_block_win;       /* attention work items (fo1_attention_bf16); q_block_win 0 = every item at most 64 keys: fo1_attention_windows_bf16 */
     const int32_t* items_full; int32_t n_items_full, q_block_full;
     double flops_win, flops_full;                   /* profiler hints                                                     */
 } fo1_vit_plan_t;

@@ -848,3 +848,38 @@ def test_mfma_clock_probe_reports_a_plausible_clock(ab_library):
         cycles_per_mfma = r["clock_ghz"] * 1e3 * r["us"] / (400 * 32 * 2)
         assert 31.0 <= cycles_per_mfma <= 36.0, (r, cycles_per_mfma)
     assert zero["tflops"] >= 0.97 * rnd["tflops"]
+
+
+def test_pipelined_single_tile_attention_equals_the_general_kernel_bitwise():
+    """Round 6: fo1_attention_windows_bf16 (a workgroup walks 4 single-tile items with the next item's loads in flight) == fo1_attention_bf16 with
+    q_block 64 on the same list, bit for bit: window lengths 4..64 (ragged edge windows), item counts that are not a multiple of 4, packed and
+    head-major (stride 256) q/k layouts."""
+    from vlm_fo1_amd import ops
+    torch.manual_seed(41)
+    H, hd = 16, 80
+    d = H * hd
+    for lens in ([64, 64, 32, 16, 4, 60, 64, 8, 48, 36, 64], [64] * 9, [12]):
+        S = sum(lens)
+        cu = [0]
+        for n in lens:
+            cu.append(cu[-1] + n)
+        segs = list(zip(cu[:-1], cu[1:]))
+        assert ops.single_tile_items(segs, hd)
+        items = ops.make_items(segs, "cuda", block=64)
+        items.single_tile = True
+        Sp = (S + 63) // 64 * 64
+        for head_major in (False, True):
+            qkv = (torch.randn(S, 3 * d) * 1.2).to(torch.bfloat16).cuda()
+            q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+            vt = torch.zeros(d, Sp, dtype=torch.bfloat16, device="cuda")
+            vt[:, :S] = v.t()
+            if head_major:
+                hm = torch.zeros(S, H * 256, dtype=torch.bfloat16, device="cuda")
+                hm.view(S, H, 256)[:, :, :hd] = q.view(S, H, hd)
+                hm.view(S, H, 256)[:, :, hd:2 * hd] = k.view(S, H, hd)
+                qa, ka, hs = hm, hm[:, hd:], 256
+            else:
+                qa, ka, hs = q, k, None
+            got = ops.attention_windows(qa, ka, vt, items, H, hd, hd ** -0.5, qk_head_stride=hs)
+            ref = ops.attention(qa, ka, vt, items, H, H, hd, hd ** -0.5, False, qk_head_stride=hs)
+            assert torch.equal(got, ref), f"{len(lens)} windows, head_major={head_major}: {int((got != ref).sum())} elements differ"

@@ -412,6 +412,189 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void attn_fwd_kernel(cons
     }
 }
 
+// ---- single-tile items in a software pipeline (round 6): the ViT's windows (modeling_qwen2_5_vl.py:172-209) ------------------------------------
+// attn_fwd_kernel spends a 64-token window as one workgroup: load K / V^T / Q -> S -> softmax -> PV -> store, one dependent chain of ~9 us with
+// nothing to overlap (a window is ONE key tile: the kernel's next-tile prefetch has nothing to fetch), three workgroups per CU.  Here a workgroup
+// walks IPW consecutive items of the list for its head and requests item i + 1's K / V^T tile and Q fragments right after item i's tile is in
+// LDS: the loads fly under item i's arithmetic.  Same fragment algebra, same instruction order per item as attn_fwd_kernel<HD, 4> on a
+// one-tile item (running maximum from -inf, o = 0 * alpha + V^T P^T): bit-identical outputs (tests/test_ops_gpu.py).  Items: non-causal,
+// at most 64 keys, q range inside the kv range; stores through a buffer descriptor (no branch around them: see dwconv3x3_ln_run_kernel).
+template <int HD, int IPW>
+__global__ __launch_bounds__(256, 2) void attn_win1_kernel(const AttnParams p, uint32_t o_bytes) {
+    constexpr int NT = 256;
+    constexpr int HDP = (HD + 31) / 32 * 32, NC = HDP / 32, NDB = HD / 16, KB = 64;
+    constexpr int LDKR = HDP + 8, LDVT = KB + 4;
+    __shared__ __attribute__((aligned(16))) uint16_t sK[KB * LDKR];
+    __shared__ __attribute__((aligned(16))) uint16_t sVT[HD * LDVT];
+    const int h = blockIdx.y, kvh = h / p.group;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ql = lane & 15, g = lane >> 4;
+    const int item0 = blockIdx.x * IPW;
+    if (item0 >= p.n_items) return;
+    const uint16_t* Kb = p.K + (long long)kvh * p.k_head;
+    const uint16_t* VTb = p.VT + (long long)kvh * HD * p.vt_row;
+    const uint16_t* Qh = p.Q + (long long)h * p.q_head;
+    typedef __attribute__((ext_vector_type(2))) unsigned int wv2u;
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc((void*)p.O, 0, o_bytes, 0x00020000);        // <= 2 GiB (host-checked)
+    constexpr int KCH = HDP / 8;
+    constexpr int NKR = (KB * KCH + NT - 1) / NT;
+    constexpr int NVR = (HD * (KB / 4) + NT - 1) / NT;
+    uint4 rk[NKR];
+    uint2 rv[NVR];
+    uint4 qn[NC];
+    // every load unconditional from a clamped address (rows / keys past the item: its last row / last 4-key piece — finite, masked below)
+    auto gload = [&](const AttnItem& it) {
+        const int k0 = it.kv_start, nk = it.kv_end - it.kv_start;
+#pragma unroll
+        for (int i = 0; i < NKR; ++i) {
+            const int q = min(tid + i * NT, KB * KCH - 1);
+            const int r = q / KCH, c = q - r * KCH;
+            rk[i] = *reinterpret_cast<const uint4*>(Kb + (long long)(k0 + min(r, nk - 1)) * p.k_tok + min(c * 8, HD - 8));
+        }
+#pragma unroll
+        for (int i = 0; i < NVR; ++i) {
+            const int q = min(tid + i * NT, HD * (KB / 4) - 1);
+            const int d = q / (KB / 4), c = q - d * (KB / 4);
+            rv[i] = *reinterpret_cast<const uint2*>(VTb + (long long)d * p.vt_row + k0 + min(c * 4, max((nk - 1) & ~3, 0)));
+        }
+        const int qi = min(it.q_start + wave * 16 + ql, it.q_end - 1);
+        const uint16_t* qp = Qh + (long long)qi * p.q_tok;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) qn[c] = *reinterpret_cast<const uint4*>(qp + min(c * 32 + g * 8, HD - 8));
+    };
+    AttnItem it = p.items[item0];
+    gload(it);
+    const float sl2 = p.scale * 1.44269504088896f;
+#pragma unroll
+    for (int rep = 0; rep < IPW; ++rep) {
+        if (item0 + rep >= p.n_items) break;                   // workgroup-uniform
+        const int nk = it.kv_end - it.kv_start;
+        // this item's registers -> LDS / fragments (the zero padding attn_fwd_kernel's guarded loads produce: rows past the item, columns past HD)
+        bf16x8 qf[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            uint4 v = qn[c];
+            if (c * 32 + g * 8 >= HD) v = uint4{0, 0, 0, 0};
+            qf[c] = *reinterpret_cast<bf16x8*>(&v);
+        }
+        __syncthreads();                                       // the previous item's tile is consumed
+#pragma unroll
+        for (int i = 0; i < NKR; ++i) {
+            const int q = tid + i * NT;
+            const int r = q / KCH, c = q - r * KCH;
+            const bool ok = q < KB * KCH && r < nk && c * 8 < HD;
+            if (q < KB * KCH) *reinterpret_cast<uint4*>(&sK[r * LDKR + c * 8]) = ok ? rk[i] : uint4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < NVR; ++i) {
+            const int q = tid + i * NT;
+            const int d = q / (KB / 4), c = q - d * (KB / 4);
+            const bool ok = q < HD * (KB / 4) && c * 4 < nk;
+            if (q < HD * (KB / 4)) *reinterpret_cast<uint2*>(&sVT[d * LDVT + c * 4]) = ok ? rv[i] : uint2{0, 0};
+        }
+        __syncthreads();
+        AttnItem nx = it;
+        if (rep + 1 < IPW && item0 + rep + 1 < p.n_items) {    // the next item's tile and queries: in flight under this item's arithmetic
+            nx = p.items[item0 + rep + 1];
+            gload(nx);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S^T = K Q^T (attn_fwd_kernel's block structure) ----
+        f32x4 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 2; ++kh) {
+            bf16x8 kf[2][NC];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int c = 0; c < NC; ++c) kf[kt][c] = *reinterpret_cast<const bf16x8*>(&sK[((kh * 2 + kt) * 16 + ql) * LDKR + c * 32 + g * 8]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+                    s[kh * 2 + kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt][c], qf[c], s[kh * 2 + kt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        uint2 vlo[NDB], vhi[NDB];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) {
+            const uint16_t* vr = &sVT[(db * 16 + ql) * LDVT + g * 4];
+            vlo[db] = *reinterpret_cast<const uint2*>(vr);
+            vhi[db] = *reinterpret_cast<const uint2*>(vr + 16);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (nk < KB) {                                         // workgroup-uniform
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s[kt][r] = kt * 16 + g * 4 + r < nk ? s[kt][r] : -INFINITY;
+        }
+        float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+        mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(s[2][0], s[2][1]), fmaxf(s[2][2], s[2][3])), fmaxf(fmaxf(s[3][0], s[3][1]), fmaxf(s[3][2], s[3][3]))));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = mx * sl2;                          // fmaxf(-inf, mx * c1)
+        const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+        float psum = 0.f;
+        bf16x8 pf[2];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t w[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kt = half * 2 + t;
+                float e[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    e[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], sl2, -m_use));
+                    psum += e[r];
+                }
+                w[t * 2 + 0] = pack_bf16x2(e[0], e[1]);
+                w[t * 2 + 1] = pack_bf16x2(e[2], e[3]);
+            }
+            uint4 pk = uint4{w[0], w[1], w[2], w[3]};
+            pf[half] = *reinterpret_cast<bf16x8*>(&pk);
+        }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        const float l_run = psum;                              // 0 * alpha + psum
+        f32x4 o[NDB];
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) o[db] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint4 vk[NDB];
+#pragma unroll
+            for (int db = 0; db < NDB; ++db) vk[db] = uint4{vlo[db].x, vlo[db].y, vhi[db].x, vhi[db].y};
+            if (half == 0) {
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) {
+                    const uint16_t* vr = &sVT[(db * 16 + ql) * LDVT + 32 + g * 4];
+                    vlo[db] = *reinterpret_cast<const uint2*>(vr);
+                    vhi[db] = *reinterpret_cast<const uint2*>(vr + 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int db = 0; db < NDB; ++db)
+                o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&vk[db]), pf[half], o[db], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // o[db][r] = O[query][d = db * 16 + g * 4 + r]
+        const int q_idx = it.q_start + wave * 16 + ql;
+        const float inv = l_run > 0.f ? 1.0f / l_run : 0.f;
+        const uint32_t obase = q_idx < it.q_end ? (uint32_t)(((long long)q_idx * p.o_tok + (long long)h * p.o_head + g * 4) * 2) : 0xC0000000u;
+#pragma unroll
+        for (int db = 0; db < NDB; ++db)
+            __builtin_amdgcn_raw_buffer_store_b64(wv2u{pack_bf16x2(o[db][0] * inv, o[db][1] * inv), pack_bf16x2(o[db][2] * inv, o[db][3] * inv)}, rs_o,
+                                                  obase + (uint32_t)(db * 32), 0, 0);
+        it = nx;
+    }
+}
+
 // ---- prefill attention on 32x32 MFMA tiles: 8 waves x 32 queries per workgroup -------------------------------------------------
 // The same fragment algebra as attn_fwd_kernel on v_mfma_f32_32x32x16_bf16: S^T = K Q^T (a = K rows, b = Q), so a lane owns ONE
 // query column (lane & 31) and 16 of the 32 keys of a sub-tile (the other 16 live in lane ^ 32): row maximum = in-lane chain + one
@@ -1249,6 +1432,36 @@ int fo1_attention_bf16(const void* Q, long long q_tok_stride, long long q_head_s
 // prefix (system text + the image tokens) — the prefix rows run through the layer once, every prompt's remaining rows attend
 // [prefix | own rows].  The prefix rows must precede the item's rows in the index space.  (The reference runs the whole model once per
 // prompt, mm_utils.py:600 caps a prompt at 100 region features: BASELINE configs[4]'s 300 proposals are three such prompts.)
+int fo1_attention_windows_bf16(const void* Q, long long q_tok_stride, long long q_head_stride, const void* K, long long k_tok_stride,
+                                long long k_head_stride, const void* VT, long long vt_row_stride, void* O, long long o_tok_stride, long long o_head_stride,
+                                long long o_rows, const int32_t* items, int n_items, int n_q_heads, int n_kv_heads, int head_dim, float scale,
+                                double flops_hint, void* stream) {
+    using namespace fo1;
+    if (n_items == 0) return FO1_OK;
+    FO1_CHECK_ARG(Q && K && VT && O && items, "attention_windows: NULL operand");
+    FO1_CHECK_ARG(head_dim == 80, "attention_windows: built for head dim 80 (got %d)", head_dim);
+    FO1_CHECK_ARG(n_items > 0 && n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0 && n_q_heads <= 65535, "attention_windows: bad head / item counts");
+    FO1_CHECK_ARG(q_tok_stride % 8 == 0 && q_head_stride % 8 == 0 && k_tok_stride % 8 == 0 && k_head_stride % 8 == 0 && vt_row_stride % 4 == 0 &&
+                  o_tok_stride % 4 == 0 && o_head_stride % 4 == 0, "attention_windows: strides (Q / K: multiples of 8 elements, V^T / O: of 4)");
+    FO1_CHECK_ARG(((uintptr_t)Q & 15) == 0 && ((uintptr_t)K & 15) == 0 && ((uintptr_t)VT & 7) == 0 && ((uintptr_t)O & 7) == 0, "attention_windows: misaligned operand");
+    const long long o_bytes = (o_rows - 1) * o_tok_stride * 2 + ((long long)(n_q_heads - 1) * o_head_stride + head_dim) * 2;
+    FO1_CHECK_ARG(o_rows > 0 && o_bytes <= (1ll << 31), "attention_windows: the output spans %lld bytes (32-bit store offsets: at most 2 GiB)", o_bytes);
+    AttnParams p;
+    p.Q = (const uint16_t*)Q; p.q_tok = q_tok_stride; p.q_head = q_head_stride;
+    p.K = (const uint16_t*)K; p.k_tok = k_tok_stride; p.k_head = k_head_stride;
+    p.VT = (const uint16_t*)VT; p.vt_row = vt_row_stride;
+    p.O = (uint16_t*)O; p.o_tok = o_tok_stride; p.o_head = o_head_stride;
+    p.items = (const AttnItem*)items; p.items2 = nullptr;
+    p.n_items = n_items; p.Hq = n_q_heads; p.group = n_q_heads / n_kv_heads;
+    p.scale = scale; p.causal = 0; p.q_row_base = nullptr;
+    p.part = nullptr; p.dyn_kv_len = nullptr; p.kv_chunk = 0; p.q_range_end = 0; p.part_tiles = 0; p.grid_batch = 0;
+    p.seq_state = nullptr; p.q_seq_stride = 0; p.part_seq_stride = 0;
+    p.bias = nullptr; p.wlen = 0; p.sw_ws = 0; p.sw_shift = 0; p.sw_nwy = 0; p.sw_nwx = 0;
+    constexpr int IPW = 4;
+    FO1_LAUNCH("attn_win1", flops_hint, (attn_win1_kernel<80, IPW>), dim3(cdiv(n_items, IPW), n_q_heads), dim3(256), 0, (hipStream_t)stream, p, (uint32_t)o_bytes);
+    return FO1_OK;
+}
+
 int fo1_attention_prefix_bf16(const void* Q, long long q_tok_stride, long long q_head_stride,
                               const void* K, long long k_tok_stride, long long k_head_stride,
                               const void* VT, long long vt_row_stride,

@@ -105,17 +105,27 @@ int fo1_vit_forward(const fo1_vit_weights_t* w, const fo1_vit_plan_t* g, const v
             // 2-D RoPE + V -> V^T in the q/k/v GEMM's epilogue (vit.py's rule: the same bits, one launch and one pass over [S, 3 d] less); q and k of
             // head j sit at columns 256 j and 256 j + 80 of the head-major rows
             FO1_TRY(fo1_qkv_proj_rope_bf16(h, d, b.wqkv_hm, d, b.bqkv_hm, qkv, 256 * H, S, 256 * H, d, 1, H, H, g->cos, g->sin, nullptr, 0, 0, vt, Sp, stream));
-            FO1_TRY(fo1_attention_bf16(qkv, 256 * H, 256, (const uint16_t*)qkv + hd, 256 * H, 256, vt, Sp, att, d, hd,
-                                       full ? g->items_full : g->items_win, full ? g->n_items_full : g->n_items_win,
-                                       full ? g->q_block_full : g->q_block_win, H, H, hd, scale, 0, nullptr,
-                                       full ? g->flops_full : g->flops_win, stream));
+            if (!full && g->q_block_win == 0) {     // single-tile items (windows of <= 64 tokens): the pipelined kernel, the same bits
+                FO1_TRY(fo1_attention_windows_bf16(qkv, 256 * H, 256, (const uint16_t*)qkv + hd, 256 * H, 256, vt, Sp, att, d, hd, S, g->items_win, g->n_items_win,
+                                                   H, H, hd, scale, g->flops_win, stream));
+            } else {
+                FO1_TRY(fo1_attention_bf16(qkv, 256 * H, 256, (const uint16_t*)qkv + hd, 256 * H, 256, vt, Sp, att, d, hd,
+                                           full ? g->items_full : g->items_win, full ? g->n_items_full : g->n_items_win,
+                                           full ? g->q_block_full : g->q_block_win, H, H, hd, scale, 0, nullptr,
+                                           full ? g->flops_full : g->flops_win, stream));
+            }
         } else {
             FO1_TRY(fo1_gemm_bf16_ws(h, d, b.wqkv, d, b.bqkv, nullptr, 0, qkv, 3 * d, S, 3 * d, d, 0, 0, gws, kGemmScratch, stream));
             FO1_TRY(fo1_qkv_post_vit_bf16(qkv, 3 * d, H, hd, g->cos, g->sin, S, vt, Sp, stream));   // 2-D RoPE on q/k + V -> V^T
-            FO1_TRY(fo1_attention_bf16(qkv, 3 * d, hd, (const uint16_t*)qkv + d, 3 * d, hd, vt, Sp, att, d, hd,
-                                       full ? g->items_full : g->items_win, full ? g->n_items_full : g->n_items_win,
-                                       full ? g->q_block_full : g->q_block_win, H, H, hd, scale, 0, nullptr,
-                                       full ? g->flops_full : g->flops_win, stream));
+            if (!full && g->q_block_win == 0) {
+                FO1_TRY(fo1_attention_windows_bf16(qkv, 3 * d, hd, (const uint16_t*)qkv + d, 3 * d, hd, vt, Sp, att, d, hd, S, g->items_win, g->n_items_win, H, H, hd,
+                                                   scale, g->flops_win, stream));
+            } else {
+                FO1_TRY(fo1_attention_bf16(qkv, 3 * d, hd, (const uint16_t*)qkv + d, 3 * d, hd, vt, Sp, att, d, hd,
+                                           full ? g->items_full : g->items_win, full ? g->n_items_full : g->n_items_win,
+                                           full ? g->q_block_full : g->q_block_win, H, H, hd, scale, 0, nullptr,
+                                           full ? g->flops_full : g->flops_win, stream));
+            }
         }
         FO1_TRY(fo1_gemm_bf16_ws(att, d, b.wo, d, b.bo, x, d, xn, d, S, d, d, 0, 0, gws, kGemmScratch, stream));
         { void* t = x; x = xn; xn = t; }

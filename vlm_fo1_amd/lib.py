@@ -233,6 +233,8 @@ SIGNATURES = {
     "fo1_im2col_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_window_partition_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "fo1_window_reverse_add_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "fo1_attention_windows_bf16": (c_int, [c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_longlong, c_void_p, c_longlong, c_void_p, c_longlong,
+                                    c_longlong, c_longlong, c_void_p, c_int, c_int, c_int, c_int, c_float, ctypes.c_double, c_void_p]),
     "fo1_window_attention_map_bf16": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
     "fo1_window_attention_map_var_bf16": (c_int, [c_void_p, c_longlong, c_int, c_int, c_int, c_void_p, c_int, c_int, c_longlong, c_void_p, c_void_p, c_longlong,
                                                  c_float, c_void_p]),

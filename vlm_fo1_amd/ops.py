@@ -986,6 +986,31 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.T
     return out
 
 
+def single_tile_items(segments: Sequence[Sequence[int]], head_dim: int) -> bool:
+    """True when the work list of these segments can go to fo1_attention_windows_bf16: head dim 80 and every segment at most 64 tokens (make_items
+    with block 64 then lists one item per segment).  FO1_WINATTN=0 turns it off (A/B)."""
+    if head_dim != 80 or os.environ.get("FO1_WINATTN", "1") == "0" or not len(segments):
+        return False
+    return all(0 < int(e) - int(s) <= 64 for s, e, *_ in segments)
+
+
+def attention_windows(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, items: torch.Tensor, n_heads: int, head_dim: int, scale: float,
+                      flops: float = 0.0, qk_head_stride: Optional[int] = None) -> torch.Tensor:
+    """ops.attention (non-causal, q_block 64) for a work list of single-tile items (items.single_tile, see single_tile_items): the pipelined
+    fo1_attention_windows_bf16, the same bits."""
+    _chk(q, "q"); _chk(k, "k"); _chk(vt, "vt")
+    assert items.dtype == torch.int32 and items.is_contiguous() and items.device == q.device and getattr(items, "single_tile", False)
+    pq, ldq, L, _ = _rows(q, "q")
+    pk, ldk, _, _ = _rows(k, "k")
+    pv, ldv, _, _ = _rows(vt, "vt")
+    out = torch.empty(L, n_heads * head_dim, dtype=torch.bfloat16, device=q.device)
+    hs = head_dim if qk_head_stride is None else int(qk_head_stride)
+    rc = _L.load().fo1_attention_windows_bf16(pq, ldq, hs, pk, ldk, hs, pv, ldv, out.data_ptr(), out.stride(0), head_dim, L, items.data_ptr(), items.shape[0],
+                                              n_heads, n_heads, head_dim, float(scale), float(flops), _stream())
+    _L.check(rc, "fo1_attention_windows_bf16")
+    return out
+
+
 # ---- DaViT / SimpleFPN / splice helpers -----------------------------------------------------
 # Every spatial op takes `batch`: that many same-size images stacked along the row dimension ([batch*H*W, C]).
 def dwconv3x3_res(x: torch.Tensor, w9c: torch.Tensor, bias: torch.Tensor, H: int, W: int, batch: int = 1) -> torch.Tensor:

@@ -81,7 +81,8 @@ class VitStage:
         P.S = g.S
         P.plan_in, P.plan_raster, P.plan_tokens = g.plan_in.data_ptr(), g.plan_raster.data_ptr(), g.plan_tokens.data_ptr()
         P.cos, P.sin = g.cos.data_ptr(), g.sin.data_ptr()
-        P.items_win, P.n_items_win, P.q_block_win = g.items_win.data_ptr(), g.items_win.shape[0], getattr(g.items_win, "q_block", 64)
+        P.items_win, P.n_items_win = g.items_win.data_ptr(), g.items_win.shape[0]
+        P.q_block_win = 0 if getattr(g.items_win, "single_tile", False) else getattr(g.items_win, "q_block", 64)      # 0: fo1_attention_windows_bf16
         P.items_full, P.n_items_full, P.q_block_full = g.items_full.data_ptr(), g.items_full.shape[0], getattr(g.items_full, "q_block", 64)
         if getattr(g, "cu_window", None) is not None:
             win, full = list(zip(g.cu_window[:-1], g.cu_window[1:])), [(0, g.S)]

@@ -86,6 +86,7 @@ class GridPlan:
         self.sin = fr.sin().contiguous().to(device)
         wins = [(a, b) for a, b in zip(cu[:-1], cu[1:])]
         self.items_win = ops.make_items(wins, device, block=ops.pick_q_block(wins, cfg.num_heads))
+        self.items_win.single_tile = ops.single_tile_items(wins, cfg.hidden_size // cfg.num_heads)      # -> fo1_attention_windows_bf16
         self.items_full = ops.make_items([(0, S)], device, block=ops.pick_q_block([(0, S)], cfg.num_heads, cfg.hidden_size // cfg.num_heads))
         self.cu_window = cu
         self.Sp = _round_up(S, 64)
@@ -126,6 +127,7 @@ class BatchPlan:
         self.cu_window = None
         self.win_segments, self.full_segments = wins, fulls
         self.items_win = ops.make_items(wins, device, block=ops.pick_q_block(wins, cfg.num_heads))
+        self.items_win.single_tile = ops.single_tile_items(wins, cfg.hidden_size // cfg.num_heads)
         self.items_full = ops.make_items(fulls, device, block=ops.pick_q_block(fulls, cfg.num_heads, cfg.hidden_size // cfg.num_heads))
         self.gh = self.gw = None
 
@@ -238,13 +240,19 @@ class QwenViT:
             if fused_qkv:
                 # q/k/v projection with 2-D RoPE + V -> V^T in the GEMM's epilogue (one launch, no second pass over [S, 3 d]); head-major columns
                 qkv = ops.qkv_proj_rope(ops.rmsnorm(x, w["n1"], 1e-6), w["wqkv_hm"], w["bqkv_hm"], 1, H, H, g.cos, g.sin, None, 0, vt)
-                att = ops.attention(qkv, qkv[:, hd:], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
-                                    flops=fl_full if full else fl_win, qk_head_stride=256)
+                if not full and getattr(g.items_win, "single_tile", False):
+                    att = ops.attention_windows(qkv, qkv[:, hd:], vt, g.items_win, H, hd, scale, flops=fl_win, qk_head_stride=256)
+                else:
+                    att = ops.attention(qkv, qkv[:, hd:], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
+                                        flops=fl_full if full else fl_win, qk_head_stride=256)
             else:
                 qkv = ops.norm_linear(x, w["n1"], 1e-6, w["wqkv"], w["bqkv"])
                 ops.qkv_post_vit(qkv, H, hd, g.cos, g.sin, vt)   # 2-D RoPE on q/k + V -> V^T, one launch
-                att = ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
-                                    flops=fl_full if full else fl_win)
+                if not full and getattr(g.items_win, "single_tile", False):
+                    att = ops.attention_windows(qkv[:, :d], qkv[:, d:2 * d], vt, g.items_win, H, hd, scale, flops=fl_win)
+                else:
+                    att = ops.attention(qkv[:, :d], qkv[:, d:2 * d], vt, g.items_full if full else g.items_win, H, H, hd, scale, False,
+                                        flops=fl_full if full else fl_win)
             x = ops.gemm(att, w["wo"], w["bo"], residual=x)
             a = ops.norm_linear(x, w["n2"], 1e-6, w["wgu"], w["bgu"], act=ops.ACT_SWIGLU16)
             x = ops.gemm(a, w["wd"], w["bd"], residual=x)
